@@ -1,0 +1,206 @@
+"""TEST INFRASTRUCTURE ONLY - generates tests/golden/*.npz by IMPORTING the reference.
+
+Run in the build container only (needs /root/reference; the GPU box never runs this):
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/oracle/gen_golden.py
+
+The reference's non-arithmetic third-party imports that are absent from this image (librosa,
+soundfile, dcase_util, sed_eval, youtube_dl) are stubbed in sys.modules; the only stubbed function
+that does arithmetic is ``librosa.amplitude_to_db``, which is bound to the oracle's restatement
+(so G6 pins Scaler / PadOrTrunc / ToTensor / Normalize, not the dB formula - that stays "parity
+unpinned", see oracle/__init__.py).  Fixtures hold reference OUTPUTS only; inputs and weights are
+regenerated from oracle/synth.py seeds.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, "/root/reference/baseline")
+    for n in ["librosa", "soundfile", "dcase_util", "dcase_util.data", "dcase_util.containers",
+              "sed_eval", "youtube_dl", "youtube_dl.utils"]:
+        sys.modules[n] = types.ModuleType(n)
+    sys.modules["dcase_util.data"].DecisionEncoder = object
+    sys.modules["dcase_util.data"].ProbabilityEncoder = object
+    sys.modules["dcase_util.containers"].AudioContainer = object
+    sys.modules["youtube_dl.utils"].ExtractorError = Exception
+    sys.modules["youtube_dl.utils"].DownloadError = Exception
+    from oracle import features_np
+    sys.modules["librosa"].amplitude_to_db = features_np.amplitude_to_db
+    import main  # noqa
+    import config as cfg
+    from models.CRNN import CRNN
+    return main, cfg, CRNN
+
+
+def load_params(model, params, bn=None):
+    import torch
+    sd = dict(model.named_parameters())
+    with torch.no_grad():
+        for k, v in params.items():
+            sd[k].copy_(v)
+        if bn is not None:
+            bufs = dict(model.named_buffers())
+            for k, v in bn.items():
+                bufs[k].copy_(v)
+
+
+def synth_bn(seed, nb=(64, 64, 64)):
+    import torch
+    rs = np.random.RandomState(5000 + seed)
+    st = {}
+    for i, c in enumerate(nb):
+        st[f"cnn.cnn.batchnorm{i}.running_mean"] = torch.tensor(rs.normal(0, 0.2, c), dtype=torch.float32)
+        st[f"cnn.cnn.batchnorm{i}.running_var"] = torch.tensor(rs.uniform(0.5, 1.5, c), dtype=torch.float32)
+    return st
+
+
+def main_():
+    import torch
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    os.makedirs(OUT, exist_ok=True)
+    main, cfg, CRNN = import_reference()
+    from oracle import synth, features_np, ref_cpu
+
+    kw = dict(cfg.crnn_kwargs)
+    kw0 = dict(kw)
+    kw0["dropout"] = 0
+
+    # ---- G1/G2: eval-mode posteriors (+ a few intermediate slices), T=628 and T=864 ----------
+    for T in (628, 864):
+        m = CRNN(**kw)
+        load_params(m, synth.make_params(0), synth_bn(0))
+        m.eval()
+        x = synth.make_input(T, 2, T)
+        inter = {}
+        hooks = []
+        for name in ["conv0", "batchnorm0", "glu0", "pooling0", "pooling1", "pooling2"]:
+            mod = getattr(m.cnn.cnn, name)
+            hooks.append(mod.register_forward_hook(lambda _m, _i, o, n=name: inter.__setitem__(n, o.detach())))
+        with torch.no_grad():
+            strong, weak = m(x)
+            gru = m.rnn(m.cnn(x).squeeze(-1).permute(0, 2, 1))
+        for h in hooks:
+            h.remove()
+        np.savez_compressed(
+            os.path.join(OUT, f"g1_eval_T{T}.npz"),
+            strong=strong.numpy(), weak=weak.numpy(),
+            conv0_s=inter["conv0"][:, :, :5, :7].numpy(), bn0_s=inter["batchnorm0"][:, :, :5, :7].numpy(),
+            glu0_s=inter["glu0"][:, :, :5, :7].numpy(), pool0_s=inter["pooling0"][:, :, :6, :].numpy(),
+            pool1_s=inter["pooling1"][:, :, :8, :].numpy(), pool2=inter["pooling2"].numpy(),
+            gru=gru.numpy())
+
+    # ---- G3: train-mode forward, dropout = 0, BN running stats after 2 passes ----------------
+    m = CRNN(**kw0)
+    load_params(m, synth.make_params(0))
+    m.train()
+    outs = []
+    with torch.no_grad():
+        for it in range(2):
+            x = synth.make_input(10 + it, 4, 628)
+            outs.append(m(x))
+    bufs = {k.replace(".", "_"): v.numpy() for k, v in m.named_buffers()}
+    np.savez_compressed(os.path.join(OUT, "g3_train_fwd.npz"),
+                        strong0=outs[0][0].numpy(), weak0=outs[0][1].numpy(),
+                        strong1=outs[1][0].numpy(), weak1=outs[1][1].numpy(), **bufs)
+
+    # ---- G4/G5: three steps of the real main.train -------------------------------------------
+    B, T = 8, 628
+    student = CRNN(**kw0)
+    teacher = CRNN(**kw0)
+    load_params(student, synth.make_params(0))
+    load_params(teacher, synth.make_params(1))
+    for p in teacher.parameters():
+        p.detach_()
+    student.train()
+    teacher.train()
+
+    rec = {"grads": [], "meters": []}
+
+    class RecAdam(torch.optim.Adam):
+        def step(self, closure=None):
+            rec["grads"].append([p.grad.detach().clone() for g in self.param_groups for p in g["params"]])
+            return super().step(closure)
+
+    class RecMeters(main.AverageMeterSet):
+        def update(self, name, value, n=1):
+            rec["meters"].append((name, float(value)))
+            return super().update(name, value, n)
+
+    main.AverageMeterSet = RecMeters
+    opt = RecAdam(filter(lambda p: p.requires_grad, student.parameters()), lr=0.001, betas=(0.9, 0.999))
+    batches = []
+    for it in range(3):
+        x = synth.make_input(20 + it, B, T)
+        xe = synth.make_input(30 + it, B, T)
+        tgt, wm, sm = synth.make_target(it, B, T // 8)
+        batches.append((x, xe, tgt))
+    main.train(batches, student, opt, 0, ema_model=teacher, weak_mask=wm, strong_mask=sm)
+
+    names = [n for n, _ in student.named_parameters()]
+    save = {}
+    for it in range(3):
+        for n, g in zip(names, rec["grads"][it]):
+            key = n.replace(".", "_")
+            save[f"s{it}_gnorm_{key}"] = np.array(float(g.double().norm()))
+            save[f"s{it}_ghead_{key}"] = g.flatten()[:16].numpy()
+    mnames = sorted(set(n for n, _ in rec["meters"]))
+    for mn in mnames:
+        save["meter_" + mn.replace(" ", "_")] = np.array([v for n, v in rec["meters"] if n == mn])
+    for n, p in student.named_parameters():
+        save["pS_sum_" + n.replace(".", "_")] = np.array(float(p.detach().double().sum()))
+        save["pS_head_" + n.replace(".", "_")] = p.detach().flatten()[:16].numpy()
+    for n, p in teacher.named_parameters():
+        save["pT_sum_" + n.replace(".", "_")] = np.array(float(p.detach().double().sum()))
+        save["pT_head_" + n.replace(".", "_")] = p.detach().flatten()[:16].numpy()
+    for n, b in student.named_buffers():
+        save["bS_" + n.replace(".", "_")] = b.numpy()
+    for n, b in teacher.named_buffers():
+        save["bT_" + n.replace(".", "_")] = b.numpy()
+    np.savez_compressed(os.path.join(OUT, "g5_train3.npz"), **save)
+
+    # ---- G6: Scaler + transform chain (reference DataLoad/Scaler code, oracle dB formula) ----
+    from utils.Scaler import Scaler
+    from utils.utils import get_transforms
+    rs = np.random.RandomState(77)
+    clips = [np.abs(rs.standard_normal((n, 64))).astype(np.float32) * 3.0 for n in (628, 600, 650, 628)]
+    labels = [np.zeros((78, 10), dtype=np.float32) for _ in clips]
+    tr0 = get_transforms(628)
+    pre = [tr0((c, l)) for c, l in zip(clips, labels)]
+    sc = Scaler()
+    sc.calculate_scaler([(p[0], p[1]) for p in pre])
+    tr = get_transforms(628, sc, augment_type="noise")
+    np.random.seed(123)
+    outs = [tr((c, l)) for c, l in zip(clips, labels)]
+    np.random.seed(123)
+    noises = [np.abs(np.random.normal(0, 0.5 ** 2, c.shape)) for c in clips]
+    trv = get_transforms(628, sc)
+    outv = [trv((c, l)) for c, l in zip(clips, labels)]
+    sel = np.r_[0:628:9, 590:628]          # subsampled frames + the zero-pad boundary region
+    np.savez_compressed(os.path.join(OUT, "g6_transforms.npz"),
+                        mean=sc.mean_, mean_of_square=sc.mean_of_square_, std=sc.std_, sel=sel,
+                        clean=np.stack([o[0].numpy()[:, sel] for o in outs]),
+                        noisy=np.stack([o[1].numpy()[:, sel] for o in outs]),
+                        valid=np.stack([o[0].numpy()[:, sel] for o in outv]),
+                        noise_head=np.stack([n[:4] for n in noises]))
+
+    # ---- G7: sigmoid_rampup table ------------------------------------------------------------
+    from utils import ramps
+    cur = np.array([0, 1, 10, 100, 5249, 10499, 10500, 20000], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "g7_rampup.npz"), current=cur,
+                        value=np.array([ramps.sigmoid_rampup(c, 10500) for c in cur]),
+                        value0=np.array([ramps.sigmoid_rampup(c, 0) for c in cur]))
+    print("wrote", sorted(os.listdir(OUT)))
+
+
+if __name__ == "__main__":
+    main_()

@@ -1,0 +1,130 @@
+"""TEST INFRASTRUCTURE ONLY - numpy statement of the counter-based RNG used by the HIP kernels.
+
+The reference draws dropout masks from torch's global generator (``nn.Dropout``,
+baseline/models/CNN.py:59-61, CRNN.py:26,74) and the teacher noise from ``np.random.normal``
+(baseline/DataLoad.py:283-285).  Those streams cannot be reproduced on a GPU, so the HIP path
+defines its own stream (Philox4x32-10, Salmon et al. SC'11) and the oracle takes the resulting
+masks / noise as explicit inputs.  This file states that stream so train-mode parity tests can run
+with dropout ON: same seed -> bit-identical masks on both sides.
+
+Stream definition (mirrored in dcase2019_task4_amd/csrc/philox.h):
+
+  key      = (seed & 0xffffffff, seed >> 32)
+  counter  = (index, 0, stream_id, 0x5ED0)
+  out[4]   = philox4x32_10(counter, key);  halfword i (0..7) = (out[i>>1] >> (16*(i&1))) & 0xffff
+  keep(hw) = hw >= round(p * 65536);  kept values are scaled by 1/(1-p)
+
+* conv-block dropout, block l (0,1,2), tensor laid out [B][H][W][C] with a (2,4) pooling window
+  behind it:  q = (b*Ho + h//2)*Wo + w//4,  dt = h & 1,  df = w & 3,
+              index = (q >> 1)*C + c,  stream_id = 2*l + dt,  halfword = (q & 1)*4 + df.
+  Rows h >= 2*Ho (odd H, dropped by the floor-mode pool) get no mask (value irrelevant; 0 here).
+* recurrent-output dropout, tensor [B][T][2H] flattened to e: index = e >> 3, stream_id = 8,
+  halfword = e & 7.
+* teacher noise, tensor [frames][n_mels] flattened to e per clip b: two 32-bit uniforms from
+  index = (b*frames*n_mels + e) >> 1, stream_id = 16, words (2*(e&1), 2*(e&1)+1) ->
+  Box-Muller normal -> |0.25 * n|.
+"""
+import numpy as np
+
+M0 = np.uint64(0xD2511F53)
+M1 = np.uint64(0xCD9E8D57)
+W0 = np.uint32(0x9E3779B9)
+W1 = np.uint32(0xBB67AE85)
+TAG = 0x5ED0
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised Philox4x32-10. All args uint32 arrays (broadcastable). Returns 4 uint32 arrays."""
+    c0 = np.asarray(c0, dtype=np.uint32)
+    c1 = np.broadcast_to(np.asarray(c1, dtype=np.uint32), c0.shape).copy()
+    c2 = np.broadcast_to(np.asarray(c2, dtype=np.uint32), c0.shape).copy()
+    c3 = np.broadcast_to(np.asarray(c3, dtype=np.uint32), c0.shape).copy()
+    c0 = c0.copy()
+    k0 = np.uint32(k0)
+    k1 = np.uint32(k1)
+    mask = np.uint64(0xFFFFFFFF)
+    with np.errstate(over="ignore"):
+        for _ in range(10):
+            p0 = M0 * c0.astype(np.uint64)
+            p1 = M1 * c2.astype(np.uint64)
+            hi0 = (p0 >> np.uint64(32)).astype(np.uint32)
+            lo0 = (p0 & mask).astype(np.uint32)
+            hi1 = (p1 >> np.uint64(32)).astype(np.uint32)
+            lo1 = (p1 & mask).astype(np.uint32)
+            n0 = hi1 ^ c1 ^ k0
+            n1 = lo1
+            n2 = hi0 ^ c3 ^ k1
+            n3 = lo0
+            c0, c1, c2, c3 = n0, n1, n2, n3
+            k0 = np.uint32((int(k0) + int(W0)) & 0xFFFFFFFF)
+            k1 = np.uint32((int(k1) + int(W1)) & 0xFFFFFFFF)
+    return c0, c1, c2, c3
+
+
+def _key(seed):
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    return seed & 0xFFFFFFFF, seed >> 32
+
+
+def _halfwords(index, stream_id, seed):
+    k0, k1 = _key(seed)
+    o = philox4x32_10(index, 0, np.uint32(stream_id), np.uint32(TAG), k0, k1)
+    hw = np.empty(index.shape + (8,), dtype=np.uint32)
+    for i in range(8):
+        hw[..., i] = (o[i >> 1] >> np.uint32(16 * (i & 1))) & np.uint32(0xFFFF)
+    return hw
+
+
+def thresh16(p):
+    return int(round(float(p) * 65536.0))
+
+
+def dropout_mask_pooled(seed, block, B, H, W, C, p):
+    """Mask for conv-block ``block`` in NHWC [B,H,W,C] float32: 0 or 1/(1-p)."""
+    if p <= 0.0:
+        return np.ones((B, H, W, C), dtype=np.float32)
+    Ho, Wo = H // 2, W // 4
+    b, h, w, c = np.meshgrid(np.arange(B), np.arange(2 * Ho), np.arange(4 * Wo), np.arange(C), indexing="ij")
+    q = (b * Ho + h // 2) * Wo + w // 4
+    dt = h & 1
+    df = w & 3
+    index = ((q >> 1) * C + c).astype(np.uint32)
+    sel = (q & 1) * 4 + df
+    out = np.zeros((B, H, W, C), dtype=np.float32)
+    keep = np.zeros(index.shape, dtype=bool)
+    for d in (0, 1):
+        m = dt == d
+        hw = _halfwords(index[m], 2 * block + d, seed)
+        keep[m] = np.take_along_axis(hw, sel[m][:, None], axis=1)[:, 0] >= thresh16(p)
+    out[:, : 2 * Ho, : 4 * Wo, :] = keep.astype(np.float32) / np.float32(1.0 - p)
+    return out
+
+
+def dropout_mask_flat(seed, stream_id, shape, p):
+    """Mask for a contiguous tensor of ``shape`` (recurrent-output dropout, stream 8)."""
+    n = int(np.prod(shape))
+    if p <= 0.0:
+        return np.ones(shape, dtype=np.float32)
+    e = np.arange(n)
+    hw = _halfwords((e >> 3).astype(np.uint32), stream_id, seed)
+    keep = hw[np.arange(n), e & 7] >= thresh16(p)
+    return (keep.astype(np.float32) / np.float32(1.0 - p)).reshape(shape)
+
+
+def teacher_noise(seed, B, frames, n_mels, std=0.25):
+    """|N(0, std)| noise [B, frames, n_mels] float32 (Box-Muller on Philox uniforms, stream 16).
+
+    u1 = (w0 + 1) * 2^-32 in (0,1],  u2 = w1 * 2^-32 in [0,1),
+    n  = sqrt(-2 ln u1) * cos(2 pi u2), computed in float32 on the device.
+    """
+    n = B * frames * n_mels
+    e = np.arange(n)
+    k0, k1 = _key(seed)
+    o = philox4x32_10((e >> 1).astype(np.uint32), 0, np.uint32(16), np.uint32(TAG), k0, k1)
+    o = np.stack(o, axis=-1)
+    w0 = o[np.arange(n), 2 * (e & 1)]
+    w1 = o[np.arange(n), 2 * (e & 1) + 1]
+    u1 = (w0.astype(np.float64) + 1.0) * 2.0 ** -32
+    u2 = w1.astype(np.float64) * 2.0 ** -32
+    g = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+    return np.abs(std * g).astype(np.float32).reshape(B, frames, n_mels)

@@ -1,0 +1,265 @@
+"""TEST INFRASTRUCTURE ONLY - torch-CPU restatement of the reference's CRNN mean-teacher path.
+
+This file restates, operator by operator, what the reference computes, so the HIP path can be
+checked against it on the GPU box (where /root/reference does not exist).  It is pinned against
+golden vectors captured from the imported reference (oracle/gen_golden.py, tests/golden/).
+
+Never imported by the product package.  Parameters are a flat ``dict[str, Tensor]`` keyed by the
+reference's ``named_parameters()`` / ``named_buffers()`` names (cnn.cnn.conv0.weight ...).
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-3        # baseline/models/CNN.py:49
+BN_MOMENTUM = 0.99   # baseline/models/CNN.py:49
+
+
+def param_shapes(n_in_channel=1, nclass=10, nb_filters=(64, 64, 64), n_RNN_cell=64, n_layers_RNN=2):
+    """Parameter names/shapes in the reference's named_parameters() order
+    (baseline/models/CRNN.py:12-31, CNN.py:40-67, RNN.py:12)."""
+    shapes = OrderedDict()
+    cin = n_in_channel
+    for i, co in enumerate(nb_filters):
+        shapes[f"cnn.cnn.conv{i}.weight"] = (co, cin, 3, 3)
+        shapes[f"cnn.cnn.conv{i}.bias"] = (co,)
+        shapes[f"cnn.cnn.batchnorm{i}.weight"] = (co,)
+        shapes[f"cnn.cnn.batchnorm{i}.bias"] = (co,)
+        shapes[f"cnn.cnn.glu{i}.linear.weight"] = (co, co)
+        shapes[f"cnn.cnn.glu{i}.linear.bias"] = (co,)
+        cin = co
+    H = n_RNN_cell
+    for l in range(n_layers_RNN):
+        n_in = nb_filters[-1] if l == 0 else 2 * H
+        for suf in ("", "_reverse"):
+            shapes[f"rnn.rnn.weight_ih_l{l}{suf}"] = (3 * H, n_in)
+            shapes[f"rnn.rnn.weight_hh_l{l}{suf}"] = (3 * H, H)
+            shapes[f"rnn.rnn.bias_ih_l{l}{suf}"] = (3 * H,)
+            shapes[f"rnn.rnn.bias_hh_l{l}{suf}"] = (3 * H,)
+    shapes["dense.weight"] = (nclass, 2 * H)
+    shapes["dense.bias"] = (nclass,)
+    shapes["dense_softmax.weight"] = (nclass, 2 * H)
+    shapes["dense_softmax.bias"] = (nclass,)
+    return shapes
+
+
+def new_bn_state(nb_filters=(64, 64, 64), dtype=torch.float32):
+    st = OrderedDict()
+    for i, c in enumerate(nb_filters):
+        st[f"cnn.cnn.batchnorm{i}.running_mean"] = torch.zeros(c, dtype=dtype)
+        st[f"cnn.cnn.batchnorm{i}.running_var"] = torch.ones(c, dtype=dtype)
+        st[f"cnn.cnn.batchnorm{i}.num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
+    return st
+
+
+def _gru_direction(x, w_ih, w_hh, b_ih, b_hh, reverse):
+    """One direction of one GRU layer, torch gate order (r, z, n), h0 = 0.
+    (baseline/models/RNN.py:12-16 -> torch.nn.GRU.)  x: [B, T, In] -> [B, T, H]."""
+    B, T, _ = x.shape
+    H = w_hh.shape[1]
+    gi_all = x @ w_ih.t() + b_ih            # [B, T, 3H]
+    h = x.new_zeros(B, H)
+    outs = [None] * T
+    steps = range(T - 1, -1, -1) if reverse else range(T)
+    for t in steps:
+        gi = gi_all[:, t]
+        gh = h @ w_hh.t() + b_hh
+        r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+        z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+        n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+        h = (1.0 - z) * n + z * h
+        outs[t] = h
+    return torch.stack(outs, dim=1)
+
+
+def crnn_forward(params, x, train, bn_state=None, masks=None, n_layers_RNN=2, update_bn=True,
+                 return_intermediates=False):
+    """CRNN.forward (baseline/models/CRNN.py:59-84) for activation="glu", attention=True, BGRU.
+
+    x      : [B, 1, T, F] float
+    masks  : None (no dropout) or dict {"drop0","drop1","drop2": NHWC [B,H,W,C] multiplicative masks,
+             "drop_rnn": [B, T//8, 2H]} - the Dropout layers at CNN.py:59-61 / CRNN.py:74 with the
+             random draw made explicit.
+    bn_state: running statistics dict, updated in place when train and update_bn.
+    Returns (strong [B,T//8,nclass], weak [B,nclass]) (+ dict of intermediates).
+    """
+    inter = {}
+    h = x
+    nblk = sum(1 for k in params if k.startswith("cnn.cnn.conv") and k.endswith(".weight"))
+    for i in range(nblk):
+        pre = f"cnn.cnn."
+        # Conv2d(k3, s1, p1)  CNN.py:46-47
+        h = F.conv2d(h, params[pre + f"conv{i}.weight"], params[pre + f"conv{i}.bias"], stride=1, padding=1)
+        if return_intermediates:
+            inter[f"conv{i}"] = h
+        # BatchNorm2d(eps=1e-3, momentum=0.99)  CNN.py:49
+        g, b = params[pre + f"batchnorm{i}.weight"], params[pre + f"batchnorm{i}.bias"]
+        if train:
+            mean = h.mean(dim=(0, 2, 3))
+            var = h.var(dim=(0, 2, 3), unbiased=False)
+            if bn_state is not None and update_bn:
+                n = h.numel() // h.shape[1]
+                with torch.no_grad():
+                    rm = bn_state[pre + f"batchnorm{i}.running_mean"]
+                    rv = bn_state[pre + f"batchnorm{i}.running_var"]
+                    rm.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * mean.detach())
+                    rv.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * var.detach() * n / (n - 1))
+                    bn_state[pre + f"batchnorm{i}.num_batches_tracked"] += 1
+        else:
+            mean = bn_state[pre + f"batchnorm{i}.running_mean"]
+            var = bn_state[pre + f"batchnorm{i}.running_var"]
+        h = (h - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + BN_EPS)
+        h = h * g[None, :, None, None] + b[None, :, None, None]
+        if return_intermediates:
+            inter[f"bn{i}"] = h
+        # GLU  CNN.py:11-16 : Linear over the channel axis times sigmoid of the same input
+        lin = F.linear(h.permute(0, 2, 3, 1), params[pre + f"glu{i}.linear.weight"],
+                       params[pre + f"glu{i}.linear.bias"]).permute(0, 3, 1, 2)
+        h = lin * torch.sigmoid(h)
+        if return_intermediates:
+            inter[f"glu{i}"] = h
+        # Dropout  CNN.py:59-61
+        if train and masks is not None and masks.get(f"drop{i}") is not None:
+            h = h * masks[f"drop{i}"].permute(0, 3, 1, 2)
+        # AvgPool2d((2,4))  CNN.py:67
+        h = F.avg_pool2d(h, (2, 4))
+        if return_intermediates:
+            inter[f"pool{i}"] = h
+    bs, chan, frames, freq = h.shape
+    assert freq == 1, "hot path only covers freq == 1 (CRNN.py:68-70)"
+    h = h.squeeze(-1).permute(0, 2, 1)                      # CRNN.py:69-70
+    # BidirectionalGRU  RNN.py:12-16
+    for l in range(n_layers_RNN):
+        fwd = _gru_direction(h, params[f"rnn.rnn.weight_ih_l{l}"], params[f"rnn.rnn.weight_hh_l{l}"],
+                             params[f"rnn.rnn.bias_ih_l{l}"], params[f"rnn.rnn.bias_hh_l{l}"], False)
+        bwd = _gru_direction(h, params[f"rnn.rnn.weight_ih_l{l}_reverse"], params[f"rnn.rnn.weight_hh_l{l}_reverse"],
+                             params[f"rnn.rnn.bias_ih_l{l}_reverse"], params[f"rnn.rnn.bias_hh_l{l}_reverse"], True)
+        h = torch.cat([fwd, bwd], dim=-1)
+        if return_intermediates:
+            inter[f"gru{l}"] = h
+    # Dropout  CRNN.py:74
+    if train and masks is not None and masks.get("drop_rnn") is not None:
+        h = h * masks["drop_rnn"]
+    strong = torch.sigmoid(F.linear(h, params["dense.weight"], params["dense.bias"]))      # CRNN.py:75-76
+    sof = F.linear(h, params["dense_softmax.weight"], params["dense_softmax.bias"])         # CRNN.py:78
+    sof = torch.softmax(sof, dim=-1)                                                         # CRNN.py:79
+    sof = torch.clamp(sof, min=1e-7, max=1)                                                  # CRNN.py:80
+    weak = (strong * sof).sum(1) / sof.sum(1)                                                # CRNN.py:81
+    if return_intermediates:
+        return strong, weak, inter
+    return strong, weak
+
+
+def bce(p, t):
+    """nn.BCELoss() (main.py:62): mean of -(t log p + (1-t) log(1-p)), each log clamped to >= -100."""
+    lp = torch.clamp(torch.log(p), min=-100.0)
+    l1p = torch.clamp(torch.log(1.0 - p), min=-100.0)
+    return -(t * lp + (1.0 - t) * l1p).mean()
+
+
+def sigmoid_rampup(current, rampup_length):
+    """baseline/utils/ramps.py:20-27."""
+    if rampup_length == 0:
+        return 1.0
+    current = float(np.clip(current, 0.0, rampup_length))
+    phase = 1.0 - current / rampup_length
+    return float(np.exp(-5.0 * phase * phase))
+
+
+def consistency_weight(global_step, rampup_length, max_consistency_cost=2.0):
+    """main.py:74-78,127 (cfg.max_consistency_cost = 2, config.py:36)."""
+    if global_step < rampup_length:
+        r = sigmoid_rampup(global_step, rampup_length)
+    else:
+        r = 1.0
+    return max_consistency_cost * r
+
+
+def mean_teacher_loss(strong, weak, strong_ema, weak_ema, target, weak_mask, strong_mask, cons_w):
+    """Loss of main.train (main.py:93-145). Returns (loss, dict of the logged meters)."""
+    meters = {}
+    target_weak = target.max(-2)[0]                                        # main.py:95
+    loss = None
+    if weak_mask is not None:
+        wl = bce(weak[weak_mask], target_weak[weak_mask])                  # main.py:97
+        meters["weak_class_loss"] = wl
+        meters["weak_ema_loss"] = bce(weak_ema[weak_mask], target_weak[weak_mask])   # main.py:98
+        loss = wl
+    if strong_mask is not None:
+        sl = bce(strong[strong_mask], target[strong_mask])                 # main.py:114
+        meters["strong_loss"] = sl
+        meters["strong_ema_loss"] = bce(strong_ema[strong_mask], target[strong_mask])  # main.py:117
+        loss = sl if loss is None else loss + sl
+    cs = cons_w * F.mse_loss(strong, strong_ema)                           # main.py:130-131
+    cw = cons_w * F.mse_loss(weak, weak_ema)                               # main.py:140
+    meters["cons_strong"] = cs
+    meters["cons_weak"] = cw
+    loss = cs + cw if loss is None else loss + cs + cw
+    meters["loss"] = loss
+    return loss, meters
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    """torch.optim.Adam(lr=1e-3, betas=(.9,.999)) single step (main.py:289-290,154), in place.
+    ``step`` is the 1-based step count after increment."""
+    b1, b2 = betas
+    bc1 = 1.0 - b1 ** step
+    bc2 = 1.0 - b2 ** step
+    for k in params:
+        g = grads[k]
+        exp_avg[k].mul_(b1).add_(g, alpha=1 - b1)
+        exp_avg_sq[k].mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (exp_avg_sq[k].sqrt() / math.sqrt(bc2)).add_(eps)
+        params[k].addcdiv_(exp_avg[k], denom, value=-lr / bc1)
+
+
+def ema_alpha(global_step, alpha=0.999):
+    """main.py:47 with global_step already incremented (main.py:155-157)."""
+    return min(1.0 - 1.0 / (global_step + 1), alpha)
+
+
+def ema_update(params, ema_params, global_step, alpha=0.999):
+    """update_ema_variables (main.py:45-49): parameters only, buffers untouched."""
+    a = ema_alpha(global_step, alpha)
+    for k in params:
+        ema_params[k].mul_(a).add_(params[k], alpha=1 - a)
+    return a
+
+
+class MeanTeacherOracle:
+    """Stateful restatement of main.train's loop body (main.py:73-157) for one model pair."""
+
+    def __init__(self, params, ema_params, lr=1e-3, betas=(0.9, 0.999), n_layers_RNN=2):
+        self.p = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in params.items())
+        self.pe = OrderedDict((k, v.clone()) for k, v in ema_params.items())
+        nb = [v.shape[0] for k, v in params.items() if k.startswith("cnn.cnn.conv") and k.endswith(".weight")]
+        dt = next(iter(params.values())).dtype
+        self.bn = new_bn_state(nb, dt)
+        self.bn_ema = new_bn_state(nb, dt)
+        self.m = OrderedDict((k, torch.zeros_like(v)) for k, v in params.items())
+        self.v = OrderedDict((k, torch.zeros_like(v)) for k, v in params.items())
+        self.lr, self.betas = lr, betas
+        self.n_layers_RNN = n_layers_RNN
+        self.global_step = 0
+        self.opt_step = 0
+
+    def step(self, x, x_ema, target, weak_mask, strong_mask, rampup_length, masks=None, masks_ema=None):
+        cons_w = consistency_weight(self.global_step, rampup_length)
+        with torch.no_grad():                                               # main.py:87-89 (+detach)
+            s_e, w_e = crnn_forward(self.pe, x_ema, True, self.bn_ema, masks_ema, self.n_layers_RNN)
+        s, w = crnn_forward(self.p, x, True, self.bn, masks, self.n_layers_RNN)   # main.py:91
+        loss, meters = mean_teacher_loss(s, w, s_e, w_e, target, weak_mask, strong_mask, cons_w)
+        grads = torch.autograd.grad(loss, list(self.p.values()))             # main.py:152-153
+        grads = OrderedDict(zip(self.p.keys(), grads))
+        self.opt_step += 1
+        with torch.no_grad():
+            adam_step(self.p, grads, self.m, self.v, self.opt_step, self.lr, self.betas)  # main.py:154
+            self.global_step += 1                                             # main.py:155
+            a = ema_update(self.p, self.pe, self.global_step)                 # main.py:156-157
+        meters = {k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in meters.items()}
+        meters["cons_weight"] = cons_w
+        meters["ema_alpha"] = a
+        return meters, grads, (s.detach(), w.detach(), s_e, w_e)

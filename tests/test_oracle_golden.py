@@ -1,0 +1,184 @@
+"""Pins the CPU oracle (oracle/ref_cpu.py, oracle/features_np.py) against golden vectors captured
+from the imported reference (oracle/gen_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu, synth, features_np
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _synth_bn(seed, nb=(64, 64, 64)):
+    rs = np.random.RandomState(5000 + seed)
+    st = ref_cpu.new_bn_state(nb)
+    for i, c in enumerate(nb):
+        st[f"cnn.cnn.batchnorm{i}.running_mean"] = torch.tensor(rs.normal(0, 0.2, c), dtype=torch.float32)
+        st[f"cnn.cnn.batchnorm{i}.running_var"] = torch.tensor(rs.uniform(0.5, 1.5, c), dtype=torch.float32)
+    return st
+
+
+@pytest.mark.parametrize("T", [628, 864])
+def test_eval_posteriors_match_reference(golden_dir, T):
+    g = _load(golden_dir, f"g1_eval_T{T}.npz")
+    p = synth.make_params(0)
+    x = synth.make_input(T, 2, T)
+    with torch.no_grad():
+        strong, weak, inter = ref_cpu.crnn_forward(p, x, False, _synth_bn(0), return_intermediates=True)
+    assert strong.shape == (2, T // 8, 10)
+    np.testing.assert_allclose(strong.numpy(), g["strong"], atol=2e-6)
+    np.testing.assert_allclose(weak.numpy(), g["weak"], atol=2e-6)
+    np.testing.assert_allclose(inter["conv0"][:, :, :5, :7].numpy(), g["conv0_s"], atol=1e-5)
+    np.testing.assert_allclose(inter["bn0"][:, :, :5, :7].numpy(), g["bn0_s"], atol=1e-5)
+    np.testing.assert_allclose(inter["glu0"][:, :, :5, :7].numpy(), g["glu0_s"], atol=1e-5)
+    np.testing.assert_allclose(inter["pool0"][:, :, :6, :].numpy(), g["pool0_s"], atol=1e-5)
+    np.testing.assert_allclose(inter["pool1"][:, :, :8, :].numpy(), g["pool1_s"], atol=1e-5)
+    np.testing.assert_allclose(inter["pool2"].numpy(), g["pool2"], atol=1e-5)
+    np.testing.assert_allclose(inter["gru1"].numpy(), g["gru"], atol=1e-5)
+
+
+def test_train_forward_and_running_stats(golden_dir):
+    g = _load(golden_dir, "g3_train_fwd.npz")
+    p = synth.make_params(0)
+    bn = ref_cpu.new_bn_state()
+    with torch.no_grad():
+        for it in range(2):
+            s, w = ref_cpu.crnn_forward(p, synth.make_input(10 + it, 4, 628), True, bn)
+            np.testing.assert_allclose(s.numpy(), g[f"strong{it}"], atol=3e-6)
+            np.testing.assert_allclose(w.numpy(), g[f"weak{it}"], atol=3e-6)
+    for k, v in bn.items():
+        np.testing.assert_allclose(v.numpy(), g[k.replace(".", "_")], rtol=2e-5, atol=2e-6)
+
+
+def test_three_steps_of_main_train(golden_dir):
+    """G5: the real main.train (3 steps, B=8) vs MeanTeacherOracle: meters, gradients, parameters."""
+    g = _load(golden_dir, "g5_train3.npz")
+    B, T = 8, 628
+    mt = ref_cpu.MeanTeacherOracle(synth.make_params(0), synth.make_params(1))
+    names = list(mt.p.keys())
+    rampup_length = 3 * 100 // 2      # len(train_loader) * cfg.n_epoch // 2  (main.py:72)
+    for it in range(3):
+        x = synth.make_input(20 + it, B, T)
+        xe = synth.make_input(30 + it, B, T)
+        tgt, wm, sm = synth.make_target(it, B, T // 8)
+        meters, grads, _ = mt.step(x, xe, tgt, wm, sm, rampup_length)
+        assert meters["weak_class_loss"] == pytest.approx(g["meter_weak_class_loss"][it], rel=2e-5)
+        assert meters["weak_ema_loss"] == pytest.approx(g["meter_Weak_EMA_loss"][it], rel=2e-5)
+        assert meters["strong_loss"] == pytest.approx(g["meter_Strong_loss"][it], rel=2e-5)
+        assert meters["strong_ema_loss"] == pytest.approx(g["meter_Strong_EMA_loss"][it], rel=2e-5)
+        assert meters["cons_strong"] == pytest.approx(g["meter_Consistency_strong"][it], rel=1e-4, abs=1e-9)
+        assert meters["cons_weak"] == pytest.approx(g["meter_Consistency_weak"][it], rel=1e-4, abs=1e-9)
+        assert meters["loss"] == pytest.approx(g["meter_Loss"][it], rel=2e-5)
+        assert meters["cons_weight"] == pytest.approx(g["meter_Consistency_weight"][2 * it], rel=1e-12)
+        assert meters["ema_alpha"] == pytest.approx([0.5, 2.0 / 3, 0.75][it])
+        for n in names:
+            key = n.replace(".", "_")
+            gn = float(grads[n].double().norm())
+            if ".conv" in n and n.endswith("bias"):
+                # a conv bias feeds a train-mode BatchNorm: its true gradient is exactly 0 and both
+                # sides hold only ~1e-6 of rounding noise there.
+                assert gn < 2e-5 and float(g[f"s{it}_gnorm_{key}"]) < 2e-5
+                continue
+            assert gn == pytest.approx(float(g[f"s{it}_gnorm_{key}"]), rel=5e-4), (it, n)
+            scale = gn / np.sqrt(grads[n].numel())          # typical element magnitude
+            np.testing.assert_allclose(grads[n].flatten()[:16].numpy(), g[f"s{it}_ghead_{key}"],
+                                       rtol=2e-3, atol=3e-3 * scale, err_msg=f"step {it} {n}")
+    for n in names:
+        key = n.replace(".", "_")
+        # Adam normalises every gradient to ~+-lr per step, so the conv biases (true gradient 0,
+        # rounding noise only - see above) random-walk by a few lr on either side.
+        tol = 1e-2 if (".conv" in n and n.endswith("bias")) else 2e-5
+        np.testing.assert_allclose(mt.p[n].detach().flatten()[:16].numpy(), g["pS_head_" + key], atol=tol)
+        np.testing.assert_allclose(mt.pe[n].flatten()[:16].numpy(), g["pT_head_" + key], atol=tol)
+        assert float(mt.p[n].detach().double().sum()) == pytest.approx(float(g["pS_sum_" + key]), abs=tol * mt.p[n].numel())
+    # running_mean contains the (random-walking, see above) conv bias; G3 pins it tightly without an
+    # optimiser in the loop, here it only gets the conv-bias tolerance.  running_var is unaffected.
+    for tag, bn in (("bS_", mt.bn), ("bT_", mt.bn_ema)):
+        for k, v in bn.items():
+            atol = 1e-2 if k.endswith("running_mean") else 3e-6
+            np.testing.assert_allclose(v.numpy(), g[tag + k.replace(".", "_")], rtol=3e-5, atol=atol)
+
+
+def test_transform_chain_and_scaler(golden_dir):
+    """G6: Scaler statistics + noise/log/pad/tensor/normalise chain as run by the reference's own
+    DataLoad/Scaler code (dB formula = oracle restatement on both sides)."""
+    g = _load(golden_dir, "g6_transforms.npz")
+    rs = np.random.RandomState(77)
+    clips = [np.abs(rs.standard_normal((n, 64))).astype(np.float32) * 3.0 for n in (628, 600, 650, 628)]
+    pre = [features_np.transform_chain(c, 628) for c in clips]
+    mean, msq, std = features_np.scaler_stats(pre)
+    np.testing.assert_allclose(mean, g["mean"], rtol=1e-12)
+    np.testing.assert_allclose(msq, g["mean_of_square"], rtol=1e-12)
+    np.testing.assert_allclose(std, g["std"], rtol=1e-10)
+    np.random.seed(123)
+    sel = g["sel"]
+    for i, c in enumerate(clips):
+        noise = np.abs(np.random.normal(0, 0.5 ** 2, c.shape))
+        np.testing.assert_allclose(noise[:4], g["noise_head"][i])
+        clean, noisy = features_np.transform_chain(c, 628, mean, std, noise)
+        np.testing.assert_allclose(clean[:, sel], g["clean"][i], atol=1e-6)
+        np.testing.assert_allclose(noisy[:, sel], g["noisy"][i], atol=1e-6)
+        valid = features_np.transform_chain(c, 628, mean, std)
+        np.testing.assert_allclose(valid[:, sel], g["valid"][i], atol=1e-6)
+
+
+def test_sigmoid_rampup(golden_dir):
+    g = _load(golden_dir, "g7_rampup.npz")
+    for c, v, v0 in zip(g["current"], g["value"], g["value0"]):
+        assert ref_cpu.sigmoid_rampup(c, 10500) == pytest.approx(v, rel=1e-15)
+        assert ref_cpu.sigmoid_rampup(c, 0) == v0
+
+
+def test_stft_matches_torch_stft():
+    """Independent cross-check of the (unpinned) librosa-style STFT restatement."""
+    y = synth.make_wave(0, 16000)
+    win = features_np.hamming_window(2048)
+    ours = features_np.stft_mag(y, 2048, 255, win)
+    ref = torch.stft(torch.tensor(y), 2048, hop_length=255, window=torch.tensor(win), center=True,
+                     pad_mode="reflect", return_complex=True).abs().numpy()
+    assert ours.shape == (1025, 1 + 16000 // 255)
+    np.testing.assert_allclose(ours, ref, atol=1e-9)
+
+
+def test_mel_filterbank_properties():
+    for sr, fmax in ((16000, 8000.0), (44100, 22050.0)):
+        fb = features_np.mel_filterbank(sr, 2048, 64, 0.0, fmax)
+        assert fb.shape == (64, 1025) and fb.dtype == np.float32
+        assert fb.min() >= 0.0 and fb.max() <= 1.0
+        assert (np.count_nonzero(fb, axis=0) <= 2).all()        # triangles overlap pairwise only
+        assert (fb.sum(axis=1) > 0).all()
+        centers = fb.argmax(axis=1)
+        assert (np.diff(centers) > 0).all()
+    # Slaney scale: linear below 1 kHz, 200/3 Hz per mel
+    assert features_np.hz_to_mel_slaney(1000.0) == pytest.approx(15.0)
+    assert features_np.mel_to_hz_slaney(features_np.hz_to_mel_slaney(4321.0)) == pytest.approx(4321.0)
+
+
+def test_amplitude_to_db_definition():
+    a = np.array([[1.0, 10.0, 1e-7, 0.0]])
+    db = features_np.amplitude_to_db(a)
+    np.testing.assert_allclose(db, [[0.0, 20.0, -60.0, -60.0]])   # top_db clamp: 20 - 80
+    assert features_np.calculate_mel_spec(synth.make_wave(1, 16000), 16000, 2048, 255, 64, 0.0, 8000.0).shape == (63, 64)
+
+
+def test_philox_known_answer():
+    """Philox4x32-10 known-answer vectors from the Random123 distribution (kat_vectors)."""
+    from oracle import philox
+    o = philox.philox4x32_10(np.array([0], np.uint32), 0, 0, 0, 0, 0)
+    assert [int(v[0]) for v in o] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    o = philox.philox4x32_10(np.array([0xffffffff], np.uint32), 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff)
+    assert [int(v[0]) for v in o] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    o = philox.philox4x32_10(np.array([0x243f6a88], np.uint32), 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0)
+    assert [int(v[0]) for v in o] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    m = philox.dropout_mask_pooled(7, 1, 2, 9, 8, 64, 0.5)
+    assert m.shape == (2, 9, 8, 64) and set(np.unique(m)) == {0.0, 2.0}
+    assert (m[:, 8] == 0).all()                                   # odd H: dropped row carries no mask
+    assert abs(m[:, :8].mean() - 1.0) < 0.05
+    f = philox.dropout_mask_flat(7, 8, (3, 78, 128), 0.5)
+    assert abs(f.mean() - 1.0) < 0.05
+    n = philox.teacher_noise(3, 2, 100, 64)
+    assert n.min() >= 0 and abs(n.mean() - 0.25 * np.sqrt(2 / np.pi)) < 0.01

@@ -1,0 +1,428 @@
+// blk0.hip - conv block 0 (1 -> 64 channels) fused end to end.
+//
+// Reference ops (baseline/models/CNN.py:46-67, GLU CNN.py:11-16):
+//   u = Conv2d(1,64,3,1,1)(x);  z = BatchNorm2d(u);  out = AvgPool2d((2,4))(Dropout(GLU(z)))
+//   GLU(z) = (Wglu z + bglu) * sigmoid(z)
+//
+// MI355X design: everything up to the GLU's Linear is affine in the 3x3 input patch P (9 taps +
+// a constant 1), so with the BN scale/shift folded in
+//     z[c]    = sum_t wz[c][t] * P[t]                       (wz = scale*w0, wz[9] = scale*b0+shift)
+//     lin[co] = sum_t wl[co][t] * P[t]                      (wl = Wglu @ wz, wl[9] += bglu)
+// i.e. block 0 is ONE 1->128-channel 3x3 conv (K = 10) followed by lin*sigmoid(z), dropout and
+// pooling.  The 64x64 per-pixel GLU GEMM (38% of the reference's forward FLOPs) disappears, and
+// the full-resolution tensors [B,64,T,64] (75% of the reference's activation bytes) are never
+// written: forward reads x and writes the pooled p0; the train-mode BatchNorm statistics come
+// from the 9+45 first/second moments of the patch (k_x_moments), and backward reduces to the
+// sums D = dlin^T P, E = dzgate^T P (two 64x10 matrices) from which k_blk0_bwd_finalize derives
+// every parameter gradient of the block in fp64.
+#include "common.h"
+#include "philox.h"
+#include "kernels.h"
+
+#define XS_W 66
+#define XS_H 10
+
+__device__ __forceinline__ int gidx(int a, int b) { return 9 + a * 9 - (a * (a - 1)) / 2 + (b - a); }  // a <= b
+
+// ---- patch moments: s[t] = sum_p P[p][t], G[a][b] = sum_p P[p][a] P[p][b] (upper triangle) ----
+__global__ __launch_bounds__(256) void k_x_moments(const float* __restrict__ x, int T, double* __restrict__ mom) {
+    __shared__ float xs[18 * XS_W];
+    __shared__ float red[4][54];
+    const int tid = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * 16;
+    for (int i = tid; i < 18 * XS_W; i += 256) {
+        int r = i / XS_W, c = i % XS_W;
+        int t = t0 - 1 + r, f = c - 1;
+        xs[i] = (t >= 0 && t < T && f >= 0 && f < 64) ? x[((size_t)b * T + t) * 64 + f] : 0.f;
+    }
+    __syncthreads();
+    float acc[54];
+#pragma unroll
+    for (int k = 0; k < 54; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int pix = tid + 256 * i;
+        int r = pix >> 6, c = pix & 63;
+        if (t0 + r < T) {
+            float p[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) p[k] = xs[(r + k / 3) * XS_W + c + k % 3];
+#pragma unroll
+            for (int a = 0; a < 9; ++a) {
+                acc[a] += p[a];
+#pragma unroll
+                for (int b2 = a; b2 < 9; ++b2) acc[gidx(a, b2)] += p[a] * p[b2];
+            }
+        }
+    }
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < 54; ++k) {
+        float v = wave_sum(acc[k]);
+        if (lane == 0) red[wv][k] = v;
+    }
+    __syncthreads();
+    if (tid < 54) atomicAdd(&mom[tid], (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid]);
+}
+
+// ---- fold BN into the conv weights; update running stats --------------------------------------
+struct Blk0PrepArgs {
+    const float *w0, *b0, *gamma, *beta, *wglu, *bglu;
+    float *run_mean, *run_var;
+    int64_t* tracked;
+    const double* mom;
+    double N;
+    int train, update;
+    float eps, momentum;
+    float *wz, *wl, *bn;   // wz/wl [64][12], bn [4][64] = mean, invstd, scale, shift
+};
+__global__ __launch_bounds__(64) void k_blk0_prep(Blk0PrepArgs a) {
+    __shared__ double wzs[64][10];
+    const int c = threadIdx.x;
+    double w[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[t] = a.w0[c * 9 + t];
+    const double b = a.b0[c];
+    double mean, var;
+    if (a.train) {
+        double ws = 0, wGw = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) ws += w[t] * a.mom[t];
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+#pragma unroll
+            for (int j = 0; j < 9; ++j) wGw += w[i] * w[j] * a.mom[i <= j ? gidx(i, j) : gidx(j, i)];
+        const double mu = ws / a.N;
+        mean = mu + b;
+        var = wGw / a.N - mu * mu;
+        if (var < 0) var = 0;
+        if (a.update) {
+            a.run_mean[c] = (float)((1.0 - a.momentum) * a.run_mean[c] + a.momentum * mean);
+            a.run_var[c] = (float)((1.0 - a.momentum) * a.run_var[c] + a.momentum * var * a.N / (a.N - 1.0));
+            if (c == 0 && a.tracked) a.tracked[0] += 1;
+        }
+    } else {
+        mean = a.run_mean[c];
+        var = a.run_var[c];
+    }
+    const double invstd = 1.0 / sqrt(var + (double)a.eps);
+    const double scale = a.gamma[c] * invstd;
+    const double shift = a.beta[c] - mean * scale;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wzs[c][t] = scale * w[t];
+    wzs[c][9] = scale * b + shift;
+#pragma unroll
+    for (int t = 0; t < 10; ++t) a.wz[c * 12 + t] = (float)wzs[c][t];
+    a.wz[c * 12 + 10] = 0.f; a.wz[c * 12 + 11] = 0.f;
+    a.bn[c] = (float)mean; a.bn[64 + c] = (float)invstd; a.bn[128 + c] = (float)scale; a.bn[192 + c] = (float)shift;
+    __syncthreads();
+    for (int t = 0; t < 10; ++t) {
+        double acc = (t == 9) ? (double)a.bglu[c] : 0.0;
+        for (int k = 0; k < 64; ++k) acc += (double)a.wglu[c * 64 + k] * wzs[k][t];
+        a.wl[c * 12 + t] = (float)acc;
+    }
+    a.wl[c * 12 + 10] = 0.f; a.wl[c * 12 + 11] = 0.f;
+}
+
+// ---- shared tile machinery ----------------------------------------------------------------------
+// A workgroup (4 waves) owns 4 pooled rows x 16 pooled cols of one clip = 8 x 64 input pixels.
+// Wave w owns pooled row w; it walks 4 "row blocks" g of 32 pixels = pooled cols 4g..4g+3.
+// MFMA row m of a row block: j = m>>3 (pooled col 4g+j), dt = (m>>2)&1, df = m&3, so that
+// D-fragment register r of lane l (row (r&3)+8(r>>2)+4(l>>5)) is pooled col r>>2, dt = l>>5, df = r&3.
+struct Blk0W {
+    float bw[5][4];   // B fragments: [k-step][col block]; col blocks 0,1 = lin, 2,3 = z
+};
+__device__ __forceinline__ void blk0_load_w(Blk0W& W, const float* __restrict__ wz, const float* __restrict__ wl, int lane) {
+    const int n = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int k = 2 * s + kh;
+        W.bw[s][0] = wl[n * 12 + k];
+        W.bw[s][1] = wl[(32 + n) * 12 + k];
+        W.bw[s][2] = wz[n * 12 + k];
+        W.bw[s][3] = wz[(32 + n) * 12 + k];
+    }
+}
+__device__ __forceinline__ void blk0_load_xs(float* xs, const float* __restrict__ x, int b, int T, int t0, int tid) {
+    for (int i = tid; i < XS_H * XS_W; i += 256) {
+        int r = i / XS_W, c = i % XS_W;
+        int t = t0 - 1 + r, f = c - 1;
+        xs[i] = (t >= 0 && t < T && f >= 0 && f < 64) ? x[((size_t)b * T + t) * 64 + f] : 0.f;
+    }
+}
+// computes lin (acc[0..1]) and z (acc[2..3]) of one 32-pixel row block
+__device__ __forceinline__ void blk0_rowblock(const float* xs, const Blk0W& W, int tl, int g, int lane, f32x16 acc[4]) {
+    const int m = lane & 31, kh = lane >> 5;
+    const int j = m >> 3, dt = (m >> 2) & 1, df = m & 3;
+    const int base = (2 * tl + dt) * XS_W + 16 * g + 4 * j + df;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int k = 2 * s + kh;
+        const float a = (k == 9) ? 1.0f : xs[base + (k / 3) * XS_W + (k % 3)];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[cb] = mfma32(a, W.bw[s][cb], acc[cb]);
+    }
+}
+
+// ---- forward --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_blk0_fwd(const float* __restrict__ x, const float* __restrict__ wz,
+                                                   const float* __restrict__ wl, float* __restrict__ p0, int B, int T,
+                                                   int H1, int tiles_per_clip, int n_tiles, int use_drop, float p_drop,
+                                                   const uint64_t* __restrict__ seed_ptr) {
+    __shared__ float xs[XS_H * XS_W];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 31, kh = lane >> 5;
+    Blk0W W;
+    blk0_load_w(W, wz, wl, lane);
+    const uint64_t seed = use_drop ? seed_ptr[0] : 0ull;
+    const uint32_t thr = drop_thresh16(p_drop);
+    const float keep_scale = use_drop ? 1.0f / (1.0f - p_drop) : 1.0f;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_clip, to0 = (tile % tiles_per_clip) * 4;
+        __syncthreads();
+        blk0_load_xs(xs, x, b, T, 2 * to0, tid);
+        __syncthreads();
+        const int to = to0 + wv;
+        if (to >= H1) continue;
+        for (int g = 0; g < 4; ++g) {
+            f32x16 acc[4];
+            blk0_rowblock(xs, W, wv, g, lane, acc);
+            const int q0 = (b * H1 + to) * 16 + 4 * g;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = 32 * h + n;
+                float pooled[4] = {0.f, 0.f, 0.f, 0.f};
+                if (use_drop) {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const u32x4 o = philox_stream((uint32_t)(((q0 >> 1) + jj) * 64 + c), (uint32_t)kh, seed);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int r = 8 * jj + i;
+                            const float v = acc[h][r] * sigmoidf_fast(acc[2 + h][r]);
+                            pooled[r >> 2] += (philox_hw(o, i) >= thr) ? v : 0.f;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pooled[r >> 2] += acc[h][r] * sigmoidf_fast(acc[2 + h][r]);
+                }
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) pooled[jx] += __shfl_xor(pooled[jx], 32);
+                const float sc = 0.125f * keep_scale;
+                const int j0 = 2 * kh;
+                p0[(size_t)(q0 + j0) * 64 + c] = (kh ? pooled[2] : pooled[0]) * sc;
+                p0[(size_t)(q0 + j0 + 1) * 64 + c] = (kh ? pooled[3] : pooled[1]) * sc;
+            }
+        }
+    }
+}
+
+// ---- backward: D[co][t] = sum_p dlin[p][co] P[p][t],  E[c][t] = sum_p dzgate[p][c] P[p][t] ------
+__global__ __launch_bounds__(256) void k_blk0_bwd(const float* __restrict__ x, const float* __restrict__ wz,
+                                                   const float* __restrict__ wl, const float* __restrict__ dp0, int B,
+                                                   int T, int H1, int tiles_per_clip, int n_tiles, int use_drop,
+                                                   float p_drop, const uint64_t* __restrict__ seed_ptr,
+                                                   double* __restrict__ de /* [2][64][10] */) {
+    __shared__ float xs[XS_H * XS_W];
+    __shared__ __attribute__((aligned(16))) float P[4][32 * 12];
+    __shared__ float red[4][2][2][32][10];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 31, kh = lane >> 5;
+    Blk0W W;
+    blk0_load_w(W, wz, wl, lane);
+    const uint64_t seed = use_drop ? seed_ptr[0] : 0ull;
+    const uint32_t thr = drop_thresh16(p_drop);
+    const float keep_scale = use_drop ? 1.0f / (1.0f - p_drop) : 1.0f;
+    float aD[2][10], aE[2][10];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int t = 0; t < 10; ++t) { aD[h][t] = 0.f; aE[h][t] = 0.f; }
+    float* Pw = P[wv];
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_clip, to0 = (tile % tiles_per_clip) * 4;
+        __syncthreads();
+        blk0_load_xs(xs, x, b, T, 2 * to0, tid);
+        __syncthreads();
+        const int to = to0 + wv;
+        if (to >= H1) continue;
+        for (int g = 0; g < 4; ++g) {
+            f32x16 acc[4];
+            blk0_rowblock(xs, W, wv, g, lane, acc);
+            // im2col of this row block for the reductions: P[m][0..8] taps, [9] = 1, [10..11] = 0
+            {
+                const int m = n, j = m >> 3, dt = (m >> 2) & 1, df = m & 3;
+                const int base = (2 * wv + dt) * XS_W + 16 * g + 4 * j + df;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const int k = kh * 6 + i;
+                    Pw[m * 12 + k] = (k < 9) ? xs[base + (k / 3) * XS_W + (k % 3)] : (k == 9 ? 1.0f : 0.f);
+                }
+            }
+            const int q0 = (b * H1 + to) * 16 + 4 * g;
+            float dl[2][16], dzg[2][16];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = 32 * h + n;
+                float gq[4];
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) gq[jx] = dp0[(size_t)(q0 + jx) * 64 + c] * (0.125f * keep_scale);
+                u32x4 o[2];
+                if (use_drop) {
+                    o[0] = philox_stream((uint32_t)(((q0 >> 1) + 0) * 64 + c), (uint32_t)kh, seed);
+                    o[1] = philox_stream((uint32_t)(((q0 >> 1) + 1) * 64 + c), (uint32_t)kh, seed);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float gg = gq[r >> 2];
+                    if (use_drop) gg = (philox_hw(o[r >> 3], r & 7) >= thr) ? gg : 0.f;
+                    const float sg = sigmoidf_fast(acc[2 + h][r]);
+                    dl[h][r] = gg * sg;
+                    dzg[h][r] = gg * acc[h][r] * sg * (1.0f - sg);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = mfma32_row(r, lane);
+                const f32x4 pa = *(const f32x4*)&Pw[i * 12 + 0];
+                const f32x4 pb = *(const f32x4*)&Pw[i * 12 + 4];
+                const f32x4 pc = *(const f32x4*)&Pw[i * 12 + 8];
+                const float pv[10] = {pa[0], pa[1], pa[2], pa[3], pb[0], pb[1], pb[2], pb[3], pc[0], pc[1]};
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int t = 0; t < 10; ++t) {
+                        aD[h][t] = fmaf(dl[h][r], pv[t], aD[h][t]);
+                        aE[h][t] = fmaf(dzg[h][r], pv[t], aE[h][t]);
+                    }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // reduce: half-waves share the channel; then waves; then fp64 atomics
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {
+            float vD = aD[h][t] + __shfl_xor(aD[h][t], 32);
+            float vE = aE[h][t] + __shfl_xor(aE[h][t], 32);
+            if (kh == 0) { red[wv][0][h][n][t] = vD; red[wv][1][h][n][t] = vE; }
+        }
+    __syncthreads();
+    for (int i = tid; i < 2 * 64 * 10; i += 256) {
+        const int which = i / 640, c = (i % 640) / 10, t = i % 10;
+        const int h = c >> 5, nn = c & 31;
+        double v = (double)red[0][which][h][nn][t] + (double)red[1][which][h][nn][t] + (double)red[2][which][h][nn][t] +
+                   (double)red[3][which][h][nn][t];
+        atomicAdd(&de[i], v);
+    }
+}
+
+// ---- backward finalize (fp64 algebra, one workgroup) ---------------------------------------------
+struct Blk0BwdFinArgs {
+    const float *w0, *b0, *gamma, *beta, *wglu;
+    const float* bn;       // mean, invstd, scale, shift
+    const double* mom;     // s, G
+    const double* de;      // D[64][10], E[64][10]
+    double N;
+    float *g_w0, *g_b0, *g_gamma, *g_beta, *g_wglu, *g_bglu;
+};
+__global__ __launch_bounds__(64) void k_blk0_bwd_finalize(Blk0BwdFinArgs a) {
+    __shared__ double wzs[64][10];
+    __shared__ double Ds[64][10];
+    const int c = threadIdx.x;
+    const double mean = a.bn[c], invstd = a.bn[64 + c], scale = a.bn[128 + c], shift = a.bn[192 + c];
+    double w[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { w[t] = a.w0[c * 9 + t]; wzs[c][t] = scale * w[t]; }
+    const double b = a.b0[c];
+    wzs[c][9] = scale * b + shift;
+#pragma unroll
+    for (int t = 0; t < 10; ++t) Ds[c][t] = a.de[c * 10 + t];
+    __syncthreads();
+    // GLU linear: dWglu[co][k] = sum_t D[co][t] wz[k][t];  dbglu[co] = D[co][9]      (row co = c)
+    for (int k = 0; k < 64; ++k) {
+        double acc = 0;
+#pragma unroll
+        for (int t = 0; t < 10; ++t) acc += Ds[c][t] * wzs[k][t];
+        a.g_wglu[c * 64 + k] = (float)acc;
+    }
+    a.g_bglu[c] = (float)Ds[c][9];
+    // total dz against the patch: S[t] = sum_co Wglu[co][c] D[co][t] + E[c][t]
+    double S[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t) S[t] = a.de[640 + c * 10 + t];
+    for (int co = 0; co < 64; ++co) {
+        const double wg = a.wglu[co * 64 + c];
+#pragma unroll
+        for (int t = 0; t < 10; ++t) S[t] += wg * Ds[co][t];
+    }
+    const double Sdz = S[9];
+    double Sdzu = b * Sdz;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) Sdzu += w[t] * S[t];
+    const double Sdzxhat = invstd * (Sdzu - mean * Sdz);
+    a.g_beta[c] = (float)Sdz;
+    a.g_gamma[c] = (float)Sdzxhat;
+    const double m1 = Sdz / a.N, m2 = Sdzxhat / a.N;
+    // du = scale * (dz - m1 - xhat * m2);  dW0[c][t] = sum_p du P[t]
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        double xhP = (b - mean) * a.mom[t];
+#pragma unroll
+        for (int t2 = 0; t2 < 9; ++t2) xhP += w[t2] * a.mom[t2 <= t ? gidx(t2, t) : gidx(t, t2)];
+        xhP *= invstd;
+        a.g_w0[c * 9 + t] = (float)(scale * (S[t] - m1 * a.mom[t] - m2 * xhP));
+    }
+    // sum_p du = scale * (Sdz - N m1 - m2 * sum xhat) = 0: a conv bias in front of a train-mode BN
+    a.g_b0[c] = 0.f;
+}
+
+// ---- host launchers -------------------------------------------------------------------------------
+int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const float* b0, const float* gamma,
+                        const float* beta, const float* wglu, const float* bglu, float* run_mean, float* run_var,
+                        int64_t* tracked, int train, int update, const uint64_t* seed, double* mom, float* wz,
+                        float* wl, float* bn, float* p0, hipStream_t st) {
+    if (train) {
+        SED_CHECK_HIP(hipMemsetAsync(mom, 0, 64 * sizeof(double), st));
+        dim3 grid((g.T + 15) / 16, g.B);
+        k_x_moments<<<grid, 256, 0, st>>>(x, g.T, mom);
+        SED_CHECK_LAUNCH();
+    }
+    Blk0PrepArgs a;
+    a.w0 = w0; a.b0 = b0; a.gamma = gamma; a.beta = beta; a.wglu = wglu; a.bglu = bglu;
+    a.run_mean = run_mean; a.run_var = run_var; a.tracked = tracked; a.mom = mom;
+    a.N = (double)g.B * g.T * g.F; a.train = train; a.update = update; a.eps = g.eps; a.momentum = g.mom;
+    a.wz = wz; a.wl = wl; a.bn = bn;
+    k_blk0_prep<<<1, 64, 0, st>>>(a);
+    SED_CHECK_LAUNCH();
+    const int tpc = (g.H1 + 3) / 4, nt = tpc * g.B;
+    const int use_drop = (train && g.p > 0.f) ? 1 : 0;
+    k_blk0_fwd<<<nt < 2048 ? nt : 2048, 256, 0, st>>>(x, wz, wl, p0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, seed);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}
+
+int launch_blk0_backward(const Geo& g, const float* x, const float* w0, const float* b0, const float* gamma,
+                         const float* beta, const float* wglu, const uint64_t* seed, const double* mom,
+                         const float* wz, const float* wl, const float* bn, const float* dp0, double* de,
+                         float* g_w0, float* g_b0, float* g_gamma, float* g_beta, float* g_wglu, float* g_bglu,
+                         hipStream_t st) {
+    SED_CHECK_HIP(hipMemsetAsync(de, 0, 2 * 64 * 10 * sizeof(double), st));
+    const int tpc = (g.H1 + 3) / 4, nt = tpc * g.B;
+    const int use_drop = (g.p > 0.f) ? 1 : 0;
+    k_blk0_bwd<<<nt < 512 ? nt : 512, 256, 0, st>>>(x, wz, wl, dp0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, seed, de);
+    SED_CHECK_LAUNCH();
+    Blk0BwdFinArgs a;
+    a.w0 = w0; a.b0 = b0; a.gamma = gamma; a.beta = beta; a.wglu = wglu; a.bn = bn; a.mom = mom; a.de = de;
+    a.N = (double)g.B * g.T * g.F;
+    a.g_w0 = g_w0; a.g_b0 = g_b0; a.g_gamma = g_gamma; a.g_beta = g_beta; a.g_wglu = g_wglu; a.g_bglu = g_bglu;
+    k_blk0_bwd_finalize<<<1, 64, 0, st>>>(a);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}

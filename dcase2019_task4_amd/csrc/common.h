@@ -1,0 +1,112 @@
+// common.h - shared device helpers, geometry and buffer layouts (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/dcase_sed.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define SED_C 64          // conv channels on the hot path
+#define SED_HID 64        // GRU hidden size on the hot path
+#define SED_WAVE 64
+
+// ---- error plumbing (host) ---------------------------------------------------------------
+void sed_set_error(const char* fmt, ...);
+#define SED_CHECK_ARG(cond, msg)                                   \
+    do {                                                           \
+        if (!(cond)) {                                             \
+            sed_set_error("%s:%d: %s", __FILE__, __LINE__, msg);   \
+            return SED_ERR_BAD_ARG;                                \
+        }                                                          \
+    } while (0)
+#define SED_CHECK_HIP(expr)                                                                 \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            sed_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return SED_ERR_LAUNCH;                                                          \
+        }                                                                                   \
+    } while (0)
+#define SED_CHECK_LAUNCH() SED_CHECK_HIP(hipGetLastError())
+#define SED_TRY(expr)               \
+    do {                            \
+        int _s = (expr);            \
+        if (_s != SED_OK) return _s; \
+    } while (0)
+
+// ---- geometry ------------------------------------------------------------------------------
+struct Geo {
+    int B, T, F, C, H, NC, L;
+    int H1, W1;   // after block 0 pooling: T/2 x 16
+    int H2, W2;   // after block 1 pooling: H1/2 x 4
+    int T3;       // after block 2 pooling: H2/2 (x 1)
+    float p, eps, mom;
+};
+static inline Geo make_geo(const sed_dims* d) {
+    Geo g;
+    g.B = d->B; g.T = d->T; g.F = d->F; g.C = d->C; g.H = d->H; g.NC = d->nclass; g.L = d->n_layers_rnn;
+    g.H1 = g.T / 2; g.W1 = g.F / 4;
+    g.H2 = g.H1 / 2; g.W2 = g.W1 / 4;
+    g.T3 = g.H2 / 2;
+    g.p = d->p_drop; g.eps = d->bn_eps; g.mom = d->bn_momentum;
+    return g;
+}
+int sed_validate_dims(const sed_dims* d);
+
+// flat parameter offsets (elements), reference named_parameters() order
+struct ParamOff {
+    int64_t conv_w[3], conv_b[3], bn_g[3], bn_b[3], glu_w[3], glu_b[3];
+    int64_t w_ih[2][2], w_hh[2][2], b_ih[2][2], b_hh[2][2];   // [layer][dir]
+    int64_t dense_w, dense_b, soft_w, soft_b;
+    int64_t total;
+    int count;
+};
+ParamOff make_param_off(const Geo& g, int64_t* offsets_out /* may be null */);
+
+// saved-context layout (byte offsets)
+struct CtxLayout {
+    size_t mom0, wz0, wl0, bn0;        // bn0: mean,invstd,scale,shift [4][64]
+    size_t p0;
+    size_t wpk1, y1, stat1, bn1, p1;
+    size_t wpk2, y2, stat2, bn2, p2;
+    size_t gi[2], gates[2], out[2];
+    size_t logits_s, strong_sv, weak_sv, den_sv;
+    size_t total;
+};
+CtxLayout make_ctx_layout(const Geo& g);
+
+struct WsLayout {
+    size_t d_out, dgi, dgh, hprev, d_in, heads_part;
+    size_t dz2, dp1, dz1, dp0, dp2;
+    size_t bnb, gluacc, coef, wpkT, wg_part, de0;
+    size_t total;
+    int wgrad_blocks;
+};
+WsLayout make_ws_layout(const Geo& g);
+#define SED_WGRAD_MAX_BLOCKS 256
+
+// ---- device helpers ------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float sigmoidf_fast(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// mfma_f32_32x32x2f32 fragment maps (cdna_hip_programming.md section 3):
+//   A[i][k]: lane l holds i = l & 31, k = l >> 5
+//   B[k][j]: lane l holds k = l >> 5, j = l & 31
+//   D[i][j]: lane l, reg r: j = l & 31, i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int mfma32_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// host launch helpers implemented per file; declared in kernels.h

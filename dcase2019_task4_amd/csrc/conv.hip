@@ -1,0 +1,320 @@
+// conv.hip - 3x3 / stride 1 / pad 1 convolution, 64 -> 64 channels, channels-last fp32, as an
+// implicit GEMM on the f32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32, 157 TF peak).
+//
+// Reference op: nn.Conv2d(64, 64, 3, 1, 1) of conv blocks 1 and 2 (baseline/models/CNN.py:46-47)
+// and its autograd (dgrad / wgrad).  Images are [B][H][W][64] with W = 16 (block 1) or 4 (block 2),
+// so one workgroup tile spans the full width: 128 pixels = TH rows x TW cols.
+//
+//  * forward / dgrad (k_conv3x3): GEMM M = pixels, N = 64, K = 9 taps x 64 channels.  The halo tile
+//    ((TH+2) x (TW+2) pixels x 64 ch) is staged ONCE in LDS with a 65-float pixel stride and a row
+//    stride == TW (mod 32) so the A-fragment reads (lane = pixel) are bank-conflict free; the
+//    per-tap 64x64 weight slab is double-buffered in LDS.  Each of the 4 waves owns 32 pixels x 64
+//    outputs (2 independent accumulators -> back-to-back MFMA issue).  The forward epilogue adds
+//    the bias and accumulates the BatchNorm batch statistics (sum, sum of squares per channel) so
+//    the conv output is read only once more, by the fused BN+GLU+pool kernel.  In dgrad mode the
+//    loader applies the BatchNorm-backward affine dy = ca*dz + cb*y + cc on the fly, so dy is
+//    never materialised.
+//  * wgrad (k_conv3x3_wgrad): GEMM M = co, N = ci, K = pixels per tap.  Persistent workgroups keep
+//    all 9 taps' 32x32 accumulators of their quadrant in registers (144 VGPRs), walk many tiles,
+//    write one partial each, and k_wgrad_reduce sums the partials (deterministic, no atomics).
+#include "common.h"
+#include "kernels.h"
+
+template <int TW>
+struct ConvCfg {
+    static constexpr int TH = 128 / TW;
+    static constexpr int HW = TW + 2;
+    static constexpr int HH = TH + 2;
+    static constexpr int PS = 65;
+    static constexpr int RS = HW * PS + (((TW - HW * PS) % 32) + 32) % 32;
+    static constexpr int HALO_FLOATS = HH * RS;
+    static constexpr int W_FLOATS = 64 * 64;
+    static constexpr size_t LDS_BYTES = (size_t)(HALO_FLOATS + 2 * W_FLOATS) * 4;
+};
+
+__global__ void k_conv_pack(const float* __restrict__ w, float* __restrict__ wpk, float* __restrict__ wpkT) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over [tap][ci][co]
+    if (i >= 9 * 64 * 64) return;
+    const int tap = i / 4096, ci = (i / 64) % 64, co = i % 64;
+    wpk[i] = w[(co * 64 + ci) * 9 + tap];
+    if (wpkT) {
+        // wpkT[tap][co'][ci'] with (co' = input channel of the transposed conv = co, ci' = output = ci)
+        const int k = (i / 64) % 64, n = i % 64;      // k = co, n = ci
+        wpkT[i] = w[(k * 64 + n) * 9 + (8 - tap)];
+    }
+}
+
+// MODE 0: forward (in = activations, epilogue bias + stats).  MODE 1: dgrad (in = affine(dz, y)).
+template <int TW, int MODE>
+__global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in0, const float* __restrict__ in1,
+                                                  const float* __restrict__ coef, const float* __restrict__ wpk,
+                                                  const float* __restrict__ bias, float* __restrict__ out,
+                                                  double* __restrict__ stat, int B, int H, int tiles_per_clip) {
+    using Cfg = ConvCfg<TW>;
+    constexpr int TH = Cfg::TH, HW = Cfg::HW, HH = Cfg::HH, PS = Cfg::PS, RS = Cfg::RS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* halo = smem;
+    float* Ws = smem + Cfg::HALO_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 31, kh = lane >> 5;
+    const int b = blockIdx.x / tiles_per_clip, y0 = (blockIdx.x % tiles_per_clip) * TH;
+    const int W = TW;
+
+    // ---- stage halo -------------------------------------------------------------------------
+    for (int f = tid; f < HH * HW * 16; f += 256) {
+        const int pix = f >> 4, c4 = (f & 15) * 4;
+        const int hy = pix / HW, hx = pix % HW;
+        const int iy = y0 - 1 + hy, ix = hx - 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+            const size_t g = (((size_t)b * H + iy) * W + ix) * 64 + c4;
+            v = *(const float4*)(in0 + g);
+            if (MODE == 1) {
+                const float4 yv = *(const float4*)(in1 + g);
+                const float4 ca = *(const float4*)(coef + c4);
+                const float4 cb = *(const float4*)(coef + 64 + c4);
+                const float4 cc = *(const float4*)(coef + 128 + c4);
+                v.x = ca.x * v.x + cb.x * yv.x + cc.x;
+                v.y = ca.y * v.y + cb.y * yv.y + cc.y;
+                v.z = ca.z * v.z + cb.z * yv.z + cc.z;
+                v.w = ca.w * v.w + cb.w * yv.w + cc.w;
+            }
+        }
+        float* dst = halo + hy * RS + hx * PS + c4;
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+    // ---- stage tap 0 weights ----------------------------------------------------------------
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int f = tid + 256 * it;
+        *(float4*)(Ws + f * 4) = *(const float4*)(wpk + f * 4);
+    }
+    __syncthreads();
+
+    const int m = 32 * wv + n;
+    const int ty = m / TW, tx = m % TW;
+    const float* Ab = halo + (ty + 1) * RS + (tx + 1) * PS + kh;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+    for (int tap = 0; tap < 9; ++tap) {
+        float4 pre[4];
+        if (tap < 8) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) pre[it] = *(const float4*)(wpk + (tap + 1) * 4096 + (tid + 256 * it) * 4);
+        }
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const float* A = Ab + dy * RS + dx * PS;
+        const float* Bw = Ws + (tap & 1) * 4096 + kh * 64 + n;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const float a = A[2 * s];
+            const float b0 = Bw[2 * s * 64];
+            const float b1 = Bw[2 * s * 64 + 32];
+            acc0 = mfma32(a, b0, acc0);
+            acc1 = mfma32(a, b1, acc1);
+        }
+        if (tap < 8) {
+            float* Wn = Ws + ((tap + 1) & 1) * 4096;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) *(float4*)(Wn + (tid + 256 * it) * 4) = pre[it];
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    const float bia0 = (MODE == 0) ? bias[n] : 0.f, bia1 = (MODE == 0) ? bias[32 + n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int mm = 32 * wv + mfma32_row(r, lane);
+        const int yy = y0 + mm / TW, xx = mm % TW;
+        if (yy < H) {
+            const size_t g = (((size_t)b * H + yy) * W + xx) * 64;
+            const float v0 = acc0[r] + bia0, v1 = acc1[r] + bia1;
+            out[g + n] = v0;
+            out[g + 32 + n] = v1;
+            if (MODE == 0) { s1[0] += v0; s2[0] += v0 * v0; s1[1] += v1; s2[1] += v1 * v1; }
+        }
+    }
+    if (MODE == 0 && stat != nullptr) {
+        float* red = smem;   // reuse (all waves are past the last barrier of the main loop)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float a = s1[h] + __shfl_xor(s1[h], 32);
+            float q = s2[h] + __shfl_xor(s2[h], 32);
+            if (kh == 0) { red[(wv * 2 + 0) * 64 + 32 * h + n] = a; red[(wv * 2 + 1) * 64 + 32 * h + n] = q; }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int which = tid >> 6, c = tid & 63;
+            double v = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) v += (double)red[(w2 * 2 + which) * 64 + c];
+            atomicAdd(&stat[which * 64 + c], v);
+        }
+    }
+}
+
+// ---- wgrad ------------------------------------------------------------------------------------
+template <int TW>
+struct WgCfg {
+    static constexpr int TH = 128 / TW;
+    static constexpr int HW = TW + 2;
+    static constexpr int HH = TH + 2;
+    static constexpr int XH_FLOATS = HH * HW * 64;
+    static constexpr int DY_FLOATS = 128 * 64;
+    static constexpr size_t LDS_BYTES = (size_t)(XH_FLOATS + DY_FLOATS) * 4;
+};
+
+template <int TW>
+__global__ __launch_bounds__(256) void k_conv3x3_wgrad(const float* __restrict__ dz, const float* __restrict__ yin,
+                                                        const float* __restrict__ coef, const float* __restrict__ xin,
+                                                        float* __restrict__ part, int B, int H, int tiles_per_clip,
+                                                        int n_tiles) {
+    using Cfg = WgCfg<TW>;
+    constexpr int TH = Cfg::TH, HW = Cfg::HW, HH = Cfg::HH;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xh = smem;
+    float* dyt = smem + Cfg::XH_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 31, kh = lane >> 5;
+    const int cob = wv >> 1, cib = wv & 1;
+    const int W = TW;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_clip, y0 = (tile % tiles_per_clip) * TH;
+        __syncthreads();
+        for (int f = tid; f < HH * HW * 16; f += 256) {
+            const int pix = f >> 4, c4 = (f & 15) * 4;
+            const int hy = pix / HW, hx = pix % HW;
+            const int iy = y0 - 1 + hy, ix = hx - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *(const float4*)(xin + (((size_t)b * H + iy) * W + ix) * 64 + c4);
+            *(float4*)(xh + pix * 64 + c4) = v;
+        }
+        for (int f = tid; f < 128 * 16; f += 256) {
+            const int pix = f >> 4, c4 = (f & 15) * 4;
+            const int yy = y0 + pix / TW, xx = pix % TW;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (yy < H) {
+                const size_t g = (((size_t)b * H + yy) * W + xx) * 64 + c4;
+                const float4 d = *(const float4*)(dz + g);
+                const float4 yv = *(const float4*)(yin + g);
+                const float4 ca = *(const float4*)(coef + c4);
+                const float4 cb = *(const float4*)(coef + 64 + c4);
+                const float4 cc = *(const float4*)(coef + 128 + c4);
+                v.x = ca.x * d.x + cb.x * yv.x + cc.x;
+                v.y = ca.y * d.y + cb.y * yv.y + cc.y;
+                v.z = ca.z * d.z + cb.z * yv.z + cc.z;
+                v.w = ca.w * d.w + cb.w * yv.w + cc.w;
+            }
+            *(float4*)(dyt + pix * 64 + c4) = v;
+        }
+        __syncthreads();
+        const float* Ab = dyt + kh * 64 + 32 * cob + n;
+        const float* Bb = xh + kh * 64 + 32 * cib + n;
+        for (int ty = 0; ty < TH; ++ty) {
+#pragma unroll
+            for (int txp = 0; txp < TW / 2; ++txp) {
+                const float a = Ab[(ty * TW + 2 * txp) * 64];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                    const float bv = Bb[((ty + 1 + dy) * HW + 2 * txp + 1 + dx) * 64];
+                    acc[tap] = mfma32(a, bv, acc[tap]);
+                }
+            }
+        }
+    }
+    float* dst = part + (size_t)blockIdx.x * 9 * 4096;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = 32 * cob + mfma32_row(r, lane);
+            dst[tap * 4096 + co * 64 + 32 * cib + n] = acc[tap][r];
+        }
+}
+
+__global__ void k_wgrad_reduce(const float* __restrict__ part, int n_blocks, float* __restrict__ g_w) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;    // over [tap][co][ci]
+    if (i >= 9 * 4096) return;
+    float s = 0.f;
+    for (int k = 0; k < n_blocks; ++k) s += part[(size_t)k * 9 * 4096 + i];
+    const int tap = i / 4096, co = (i / 64) % 64, ci = i % 64;
+    g_w[(co * 64 + ci) * 9 + tap] = s;
+}
+
+// ---- host launchers ---------------------------------------------------------------------------
+int launch_conv_pack(const float* w, float* wpk, float* wpkT, hipStream_t st) {
+    k_conv_pack<<<(9 * 4096 + 255) / 256, 256, 0, st>>>(w, wpk, wpkT);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}
+
+template <int TW, int MODE>
+static int conv_launch_t(const float* in0, const float* in1, const float* coef, const float* wpk, const float* bias,
+                         float* out, double* stat, int B, int H, hipStream_t st) {
+    using Cfg = ConvCfg<TW>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3<TW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)Cfg::LDS_BYTES));
+        attr_done = true;
+    }
+    const int tpc = (H + Cfg::TH - 1) / Cfg::TH;
+    k_conv3x3<TW, MODE><<<B * tpc, 256, Cfg::LDS_BYTES, st>>>(in0, in1, coef, wpk, bias, out, stat, B, H, tpc);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}
+
+int launch_conv_fwd(const float* in, const float* wpk, const float* bias, float* y, double* stat, int B, int H, int W,
+                    hipStream_t st) {
+    if (stat) SED_CHECK_HIP(hipMemsetAsync(stat, 0, 128 * sizeof(double), st));
+    if (W == 16) return conv_launch_t<16, 0>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st);
+    if (W == 4) return conv_launch_t<4, 0>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st);
+    sed_set_error("conv: unsupported width %d", W);
+    return SED_ERR_UNSUPPORTED;
+}
+
+int launch_conv_dgrad(const float* dz, const float* yin, const float* coef, const float* wpkT, float* dx, int B, int H,
+                      int W, hipStream_t st) {
+    if (W == 16) return conv_launch_t<16, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st);
+    if (W == 4) return conv_launch_t<4, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st);
+    sed_set_error("conv dgrad: unsupported width %d", W);
+    return SED_ERR_UNSUPPORTED;
+}
+
+template <int TW>
+static int wgrad_launch_t(const float* dz, const float* yin, const float* coef, const float* xin, float* part,
+                          int n_blocks, float* g_w, int B, int H, hipStream_t st) {
+    using Cfg = WgCfg<TW>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad<TW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)Cfg::LDS_BYTES));
+        attr_done = true;
+    }
+    const int tpc = (H + Cfg::TH - 1) / Cfg::TH, nt = B * tpc;
+    const int nb = nt < n_blocks ? nt : n_blocks;
+    k_conv3x3_wgrad<TW><<<nb, 256, Cfg::LDS_BYTES, st>>>(dz, yin, coef, xin, part, B, H, tpc, nt);
+    SED_CHECK_LAUNCH();
+    k_wgrad_reduce<<<(9 * 4096 + 255) / 256, 256, 0, st>>>(part, nb, g_w);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}
+
+int launch_conv_wgrad(const float* dz, const float* yin, const float* coef, const float* xin, float* part, int n_blocks,
+                      float* g_w, int B, int H, int W, hipStream_t st) {
+    if (W == 16) return wgrad_launch_t<16>(dz, yin, coef, xin, part, n_blocks, g_w, B, H, st);
+    if (W == 4) return wgrad_launch_t<4>(dz, yin, coef, xin, part, n_blocks, g_w, B, H, st);
+    sed_set_error("conv wgrad: unsupported width %d", W);
+    return SED_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,305 @@
+// crnn.hip - CRNN forward / backward orchestration behind the C-ABI (include/dcase_sed.h).
+//
+// Mirrors the operator sequence of CRNN.forward (baseline/models/CRNN.py:59-84):
+//   conv block 0 (blk0.hip, fully fused) -> [conv3x3 + BN stats (conv.hip) -> BN/GLU/dropout/pool
+//   (bnglu.hip)] x 2 -> 2-layer BiGRU (gemm.hip + gru.hip) -> heads (heads.hip)
+// All launches go to the caller's stream; no allocation, no synchronisation.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include "common.h"
+#include "kernels.h"
+
+static thread_local char g_err[512] = "";
+void sed_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* sed_last_error(void) { return g_err; }
+extern "C" int sed_version(void) { return 100; }
+
+int sed_validate_dims(const sed_dims* d) {
+    SED_CHECK_ARG(d != nullptr, "null dims");
+    if (d->F != 64 || d->C != 64 || d->H != 64) {
+        sed_set_error("hot path supports F = C = H = 64 only (got F=%d C=%d H=%d)", d->F, d->C, d->H);
+        return SED_ERR_UNSUPPORTED;
+    }
+    SED_CHECK_ARG(d->B >= 1 && d->T >= 16, "need B >= 1 and T >= 16");
+    SED_CHECK_ARG(d->nclass >= 1 && d->nclass <= 16, "nclass must be in [1, 16]");
+    SED_CHECK_ARG(d->n_layers_rnn == 1 || d->n_layers_rnn == 2, "n_layers_rnn must be 1 or 2");
+    SED_CHECK_ARG(d->p_drop >= 0.f && d->p_drop < 1.f, "p_drop must be in [0, 1)");
+    SED_CHECK_ARG((int64_t)d->B * d->T * d->F * d->C < (1ll << 31), "batch too large for 32-bit pixel indices");
+    return SED_OK;
+}
+
+ParamOff make_param_off(const Geo& g, int64_t* out) {
+    ParamOff P;
+    int64_t o = 0;
+    int k = 0;
+    auto put = [&](int64_t& field, int64_t n) {
+        field = o;
+        if (out) out[k] = o;
+        ++k;
+        o += n;
+    };
+    for (int i = 0; i < 3; ++i) {
+        const int cin = (i == 0) ? 1 : g.C;
+        put(P.conv_w[i], (int64_t)g.C * cin * 9);
+        put(P.conv_b[i], g.C);
+        put(P.bn_g[i], g.C);
+        put(P.bn_b[i], g.C);
+        put(P.glu_w[i], (int64_t)g.C * g.C);
+        put(P.glu_b[i], g.C);
+    }
+    for (int l = 0; l < g.L; ++l) {
+        const int nin = (l == 0) ? g.C : 2 * g.H;
+        for (int dir = 0; dir < 2; ++dir) {
+            put(P.w_ih[l][dir], (int64_t)3 * g.H * nin);
+            put(P.w_hh[l][dir], (int64_t)3 * g.H * g.H);
+            put(P.b_ih[l][dir], 3 * g.H);
+            put(P.b_hh[l][dir], 3 * g.H);
+        }
+    }
+    put(P.dense_w, (int64_t)g.NC * 2 * g.H);
+    put(P.dense_b, g.NC);
+    put(P.soft_w, (int64_t)g.NC * 2 * g.H);
+    put(P.soft_b, g.NC);
+    P.total = o;
+    P.count = k;
+    if (out) out[k] = o;
+    return P;
+}
+
+static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+CtxLayout make_ctx_layout(const Geo& g) {
+    CtxLayout L;
+    size_t o = 0;
+    auto put = [&](size_t& f, size_t bytes) { f = o; o = al(o + bytes); };
+    const size_t n0 = (size_t)g.B * g.H1 * g.W1 * 64, n1 = (size_t)g.B * g.H2 * g.W2 * 64, n2 = (size_t)g.B * g.T3 * 64;
+    put(L.mom0, 64 * sizeof(double));
+    put(L.wz0, 64 * 12 * 4); put(L.wl0, 64 * 12 * 4); put(L.bn0, 256 * 4);
+    put(L.p0, n0 * 4);
+    put(L.wpk1, 9 * 4096 * 4); put(L.y1, n0 * 4); put(L.stat1, 128 * sizeof(double)); put(L.bn1, 256 * 4); put(L.p1, n1 * 4);
+    put(L.wpk2, 9 * 4096 * 4); put(L.y2, n1 * 4); put(L.stat2, 128 * sizeof(double)); put(L.bn2, 256 * 4); put(L.p2, n2 * 4);
+    const size_t bt = (size_t)g.B * g.T3;
+    for (int l = 0; l < 2; ++l) {
+        put(L.gi[l], bt * 384 * 4); put(L.gates[l], bt * 512 * 4); put(L.out[l], bt * 128 * 4);
+    }
+    put(L.logits_s, bt * g.NC * 4); put(L.strong_sv, bt * g.NC * 4);
+    put(L.weak_sv, (size_t)g.B * g.NC * 4); put(L.den_sv, (size_t)g.B * g.NC * 4);
+    L.total = o;
+    return L;
+}
+
+WsLayout make_ws_layout(const Geo& g) {
+    WsLayout W;
+    size_t o = 0;
+    auto put = [&](size_t& f, size_t bytes) { f = o; o = al(o + bytes); };
+    const size_t n0 = (size_t)g.B * g.H1 * g.W1 * 64, n1 = (size_t)g.B * g.H2 * g.W2 * 64, bt = (size_t)g.B * g.T3;
+    put(W.d_out, bt * 128 * 4); put(W.dgi, bt * 384 * 4); put(W.dgh, bt * 384 * 4); put(W.hprev, bt * 128 * 4);
+    put(W.d_in, bt * 128 * 4); put(W.heads_part, (size_t)g.B * 2 * (g.NC * 128 + g.NC) * 4);
+    put(W.dp2, bt * 64 * 4); put(W.dz2, n1 * 4); put(W.dp1, n1 * 4); put(W.dz1, n0 * 4); put(W.dp0, n0 * 4);
+    put(W.bnb, 256 * sizeof(double)); put(W.gluacc, 4288 * sizeof(double)); put(W.coef, 192 * 4);
+    put(W.wpkT, 9 * 4096 * 4);
+    W.wgrad_blocks = SED_WGRAD_MAX_BLOCKS;
+    put(W.wg_part, (size_t)W.wgrad_blocks * 9 * 4096 * 4);
+    put(W.de0, 2 * 64 * 10 * sizeof(double));
+    W.total = o;
+    return W;
+}
+
+extern "C" int sed_param_count(const sed_dims* d) {
+    if (sed_validate_dims(d) != SED_OK) return -1;
+    const Geo g = make_geo(d);
+    return make_param_off(g, nullptr).count;
+}
+extern "C" int sed_param_layout(const sed_dims* d, int64_t* offsets) {
+    SED_TRY(sed_validate_dims(d));
+    SED_CHECK_ARG(offsets != nullptr, "null offsets");
+    const Geo g = make_geo(d);
+    make_param_off(g, offsets);
+    return SED_OK;
+}
+extern "C" size_t sed_crnn_ctx_bytes(const sed_dims* d) {
+    if (sed_validate_dims(d) != SED_OK) return 0;
+    return make_ctx_layout(make_geo(d)).total;
+}
+extern "C" size_t sed_crnn_bwd_ws_bytes(const sed_dims* d) {
+    if (sed_validate_dims(d) != SED_OK) return 0;
+    return make_ws_layout(make_geo(d)).total;
+}
+
+extern "C" int sed_crnn_ctx_view(const sed_dims* d, const char* name, size_t* offset, size_t* bytes) {
+    SED_TRY(sed_validate_dims(d));
+    SED_CHECK_ARG(name && offset && bytes, "null argument");
+    const Geo g = make_geo(d);
+    const CtxLayout L = make_ctx_layout(g);
+    const size_t n0 = (size_t)g.B * g.H1 * g.W1 * 64 * 4, n1 = (size_t)g.B * g.H2 * g.W2 * 64 * 4, bt = (size_t)g.B * g.T3;
+    struct { const char* n; size_t o, b; } tab[] = {
+        {"mom0", L.mom0, 64 * 8}, {"wz0", L.wz0, 64 * 12 * 4}, {"wl0", L.wl0, 64 * 12 * 4}, {"bn0", L.bn0, 1024},
+        {"p0", L.p0, n0}, {"y1", L.y1, n0}, {"stat1", L.stat1, 1024}, {"bn1", L.bn1, 1024}, {"p1", L.p1, n1},
+        {"y2", L.y2, n1}, {"stat2", L.stat2, 1024}, {"bn2", L.bn2, 1024}, {"p2", L.p2, bt * 64 * 4},
+        {"gi0", L.gi[0], bt * 384 * 4}, {"gi1", L.gi[1], bt * 384 * 4},
+        {"gates0", L.gates[0], bt * 512 * 4}, {"gates1", L.gates[1], bt * 512 * 4},
+        {"gru0", L.out[0], bt * 128 * 4}, {"gru1", L.out[1], bt * 128 * 4},
+        {"logits_s", L.logits_s, bt * g.NC * 4}, {"den", L.den_sv, (size_t)g.B * g.NC * 4},
+    };
+    for (auto& t : tab)
+        if (strcmp(t.n, name) == 0) { *offset = t.o; *bytes = t.b; return SED_OK; }
+    sed_set_error("sed_crnn_ctx_view: unknown buffer '%s'", name);
+    return SED_ERR_BAD_ARG;
+}
+
+#define CTXF(off) ((float*)((char*)ctx + (off)))
+#define CTXD(off) ((double*)((char*)ctx + (off)))
+#define WSF(off) ((float*)((char*)ws + (off)))
+#define WSD(off) ((double*)((char*)ws + (off)))
+
+extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* bn_running, int64_t* bn_tracked,
+                                const float* x, int train, int update_bn, const uint64_t* seed_dev, void* ctx,
+                                size_t ctx_bytes, float* strong, float* weak, void* stream) {
+    SED_TRY(sed_validate_dims(d));
+    SED_CHECK_ARG(params && bn_running && x && ctx && strong && weak, "sed_crnn_forward: null argument");
+    const Geo g = make_geo(d);
+    const ParamOff P = make_param_off(g, nullptr);
+    const CtxLayout L = make_ctx_layout(g);
+    if (ctx_bytes < L.total) {
+        sed_set_error("sed_crnn_forward: ctx has %zu bytes, needs %zu", ctx_bytes, L.total);
+        return SED_ERR_WORKSPACE;
+    }
+    const int use_drop = (train && g.p > 0.f) ? 1 : 0;
+    SED_CHECK_ARG(!use_drop || seed_dev, "sed_crnn_forward: dropout enabled but seed_dev is null");
+    hipStream_t st = (hipStream_t)stream;
+    const int upd = (train && update_bn) ? 1 : 0;
+    int64_t* trk[3] = {bn_tracked ? bn_tracked + 0 : nullptr, bn_tracked ? bn_tracked + 1 : nullptr,
+                       bn_tracked ? bn_tracked + 2 : nullptr};
+
+    // ---- conv block 0 ---------------------------------------------------------------------------
+    SED_TRY(launch_blk0_forward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
+                                params + P.glu_w[0], params + P.glu_b[0], bn_running + 0, bn_running + 64, trk[0], train,
+                                upd, seed_dev, CTXD(L.mom0), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), CTXF(L.p0), st));
+    // ---- conv blocks 1, 2 -----------------------------------------------------------------------
+    const float* in = CTXF(L.p0);
+    const size_t wpk[3] = {0, L.wpk1, L.wpk2}, yo[3] = {0, L.y1, L.y2}, so[3] = {0, L.stat1, L.stat2},
+                 bo[3] = {0, L.bn1, L.bn2}, po[3] = {0, L.p1, L.p2};
+    const int Hs[3] = {0, g.H1, g.H2}, Ws[3] = {0, g.W1, g.W2};
+    for (int i = 1; i <= 2; ++i) {
+        SED_TRY(launch_conv_pack(params + P.conv_w[i], CTXF(wpk[i]), nullptr, st));
+        SED_TRY(launch_conv_fwd(in, CTXF(wpk[i]), params + P.conv_b[i], CTXF(yo[i]), train ? CTXD(so[i]) : nullptr, g.B,
+                                Hs[i], Ws[i], st));
+        SED_TRY(launch_bn_prep(CTXD(so[i]), (double)g.B * Hs[i] * Ws[i], params + P.bn_g[i], params + P.bn_b[i],
+                               bn_running + (2 * i) * 64, bn_running + (2 * i + 1) * 64, trk[i], train, upd, g.eps, g.mom,
+                               CTXF(bo[i]), st));
+        SED_TRY(launch_glu_pool_fwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], CTXF(po[i]), g.B,
+                                    Hs[i], Ws[i], i, use_drop, g.p, seed_dev, st));
+        in = CTXF(po[i]);
+    }
+    // ---- BiGRU ----------------------------------------------------------------------------------
+    const int BT = g.B * g.T3;
+    int nin = 64;
+    for (int l = 0; l < g.L; ++l) {
+        for (int dir = 0; dir < 2; ++dir) {
+            GemmDesc q;
+            q.A = in; q.sAm = nin; q.sAk = 1;
+            q.B = params + P.w_ih[l][dir]; q.sBk = 1; q.sBn = nin;
+            q.C = CTXF(L.gi[l]) + dir * 192; q.ldc = 384;
+            q.bias = params + P.b_ih[l][dir];
+            q.M = BT; q.N = 192; q.K = nin; q.accumulate = 0;
+            SED_TRY(launch_gemm(q, st));
+        }
+        SED_TRY(launch_gru_fwd(CTXF(L.gi[l]), params + P.w_hh[l][0], params + P.w_hh[l][1], params + P.b_hh[l][0],
+                               params + P.b_hh[l][1], CTXF(L.out[l]), train ? CTXF(L.gates[l]) : nullptr, g.B, g.T3, st));
+        in = CTXF(L.out[l]);
+        nin = 128;
+    }
+    // ---- heads ----------------------------------------------------------------------------------
+    SED_TRY(launch_heads_fwd(in, params + P.dense_w, params + P.dense_b, params + P.soft_w, params + P.soft_b, strong, weak,
+                             CTXF(L.logits_s), CTXF(L.den_sv), g.B, g.T3, g.NC, use_drop, g.p, seed_dev, st));
+    if (train) {
+        SED_CHECK_HIP(hipMemcpyAsync(CTXF(L.strong_sv), strong, (size_t)BT * g.NC * 4, hipMemcpyDeviceToDevice, st));
+        SED_CHECK_HIP(hipMemcpyAsync(CTXF(L.weak_sv), weak, (size_t)g.B * g.NC * 4, hipMemcpyDeviceToDevice, st));
+    }
+    return SED_OK;
+}
+
+extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const float* x, const uint64_t* seed_dev,
+                                 void* ctx, size_t ctx_bytes, const float* d_strong, const float* d_weak, float* grads,
+                                 void* ws, size_t ws_bytes, void* stream) {
+    SED_TRY(sed_validate_dims(d));
+    SED_CHECK_ARG(params && x && ctx && d_strong && d_weak && grads && ws, "sed_crnn_backward: null argument");
+    const Geo g = make_geo(d);
+    const ParamOff P = make_param_off(g, nullptr);
+    const CtxLayout L = make_ctx_layout(g);
+    const WsLayout W = make_ws_layout(g);
+    if (ctx_bytes < L.total || ws_bytes < W.total) {
+        sed_set_error("sed_crnn_backward: ctx %zu/%zu bytes, ws %zu/%zu bytes", ctx_bytes, L.total, ws_bytes, W.total);
+        return SED_ERR_WORKSPACE;
+    }
+    const int use_drop = (g.p > 0.f) ? 1 : 0;
+    SED_CHECK_ARG(!use_drop || seed_dev, "sed_crnn_backward: dropout enabled but seed_dev is null");
+    hipStream_t st = (hipStream_t)stream;
+    const int BT = g.B * g.T3;
+
+    // ---- heads ----------------------------------------------------------------------------------
+    const float* h_last = CTXF(L.out[g.L - 1]);
+    SED_TRY(launch_heads_bwd(h_last, params + P.dense_w, params + P.soft_w, CTXF(L.strong_sv), CTXF(L.weak_sv),
+                             CTXF(L.logits_s), CTXF(L.den_sv), d_strong, d_weak, WSF(W.d_out), WSF(W.heads_part),
+                             grads + P.dense_w, grads + P.dense_b, grads + P.soft_w, grads + P.soft_b, g.B, g.T3, g.NC,
+                             use_drop, g.p, seed_dev, st));
+    // ---- BiGRU ----------------------------------------------------------------------------------
+    const float* d_cur = WSF(W.d_out);
+    for (int l = g.L - 1; l >= 0; --l) {
+        const int nin = (l == 0) ? 64 : 128;
+        const float* input = (l == 0) ? CTXF(L.p2) : CTXF(L.out[l - 1]);
+        float* d_in = (l == 0) ? WSF(W.dp2) : WSF(W.d_in);
+        SED_TRY(launch_gru_bwd(d_cur, CTXF(L.out[l]), CTXF(L.gates[l]), params + P.w_hh[l][0], params + P.w_hh[l][1],
+                               WSF(W.dgi), WSF(W.dgh), WSF(W.hprev), g.B, g.T3, st));
+        for (int dir = 0; dir < 2; ++dir) {
+            GemmDesc q;
+            // dW_ih[g][i] = sum_bt dgi[bt][g] * input[bt][i]
+            q.A = WSF(W.dgi) + dir * 192; q.sAm = 1; q.sAk = 384;
+            q.B = input; q.sBk = nin; q.sBn = 1;
+            q.C = grads + P.w_ih[l][dir]; q.ldc = nin; q.bias = nullptr;
+            q.M = 192; q.N = nin; q.K = BT; q.accumulate = 0;
+            SED_TRY(launch_gemm(q, st));
+            // dW_hh[g][j] = sum_bt dgh[bt][g] * hprev[bt][j]
+            q.A = WSF(W.dgh) + dir * 192;
+            q.B = WSF(W.hprev) + dir * 64; q.sBk = 128; q.sBn = 1;
+            q.C = grads + P.w_hh[l][dir]; q.ldc = 64; q.N = 64;
+            SED_TRY(launch_gemm(q, st));
+            SED_TRY(launch_colsum(WSF(W.dgi) + dir * 192, BT, 192, 384, grads + P.b_ih[l][dir], st));
+            SED_TRY(launch_colsum(WSF(W.dgh) + dir * 192, BT, 192, 384, grads + P.b_hh[l][dir], st));
+            // d_in[bt][i] (+)= sum_g dgi[bt][g] * W_ih[g][i]
+            q.A = WSF(W.dgi) + dir * 192; q.sAm = 384; q.sAk = 1;
+            q.B = params + P.w_ih[l][dir]; q.sBk = nin; q.sBn = 1;
+            q.C = d_in; q.ldc = nin; q.M = BT; q.N = nin; q.K = 192; q.accumulate = dir;
+            SED_TRY(launch_gemm(q, st));
+        }
+        d_cur = d_in;
+    }
+    // ---- conv blocks 2, 1 -----------------------------------------------------------------------
+    const size_t wpk[3] = {0, L.wpk1, L.wpk2}, yo[3] = {0, L.y1, L.y2}, bo[3] = {0, L.bn1, L.bn2};
+    const size_t pin[3] = {0, L.p0, L.p1};
+    const size_t dzo[3] = {0, W.dz1, W.dz2}, dpo[3] = {W.dp0, W.dp1, W.dp2};
+    const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};
+    for (int i = 2; i >= 1; --i) {
+        SED_TRY(launch_glu_pool_bwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], WSF(dpo[i]),
+                                    WSF(dzo[i]), WSD(W.gluacc), g.B, Hs[i], Wd[i], i, use_drop, g.p, seed_dev, st));
+        SED_TRY(launch_bn_bwd_prep(WSD(W.gluacc), (double)g.B * Hs[i] * Wd[i], params + P.bn_g[i], CTXF(bo[i]), WSF(W.coef),
+                                   grads + P.bn_g[i], grads + P.bn_b[i], grads + P.glu_w[i], grads + P.glu_b[i],
+                                   grads + P.conv_b[i], st));
+        SED_TRY(launch_conv_pack(params + P.conv_w[i], CTXF(wpk[i]), WSF(W.wpkT), st));
+        SED_TRY(launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef), CTXF(pin[i]), WSF(W.wg_part), W.wgrad_blocks,
+                                  grads + P.conv_w[i], g.B, Hs[i], Wd[i], st));
+        SED_TRY(launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef), WSF(W.wpkT), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], st));
+    }
+    // ---- conv block 0 ---------------------------------------------------------------------------
+    SED_TRY(launch_blk0_backward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
+                                 params + P.glu_w[0], seed_dev, CTXD(L.mom0), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0),
+                                 WSF(W.dp0), WSD(W.de0), grads + P.conv_w[0], grads + P.conv_b[0], grads + P.bn_g[0],
+                                 grads + P.bn_b[0], grads + P.glu_w[0], grads + P.glu_b[0], st));
+    return SED_OK;
+}

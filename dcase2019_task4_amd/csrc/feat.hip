@@ -1,0 +1,206 @@
+// feat.hip - feature front-end: STFT + mel projection, and the log / noise / pad / normalise chain.
+//
+// Reference ops:
+//  * DatasetDcase2019Task4.calculate_mel_spec (baseline/DatasetDcase2019Task4.py:197-231):
+//      np.hamming(2048) -> librosa.stft(center=True, pad_mode='reflect') -> |.| ->
+//      librosa.feature.melspectrogram(S=|.|, htk=False, norm=None) -> .T -> float32
+//    librosa runs this in float64 (soundfile hands it float64 audio); so does k_stft_mel: the
+//    front-end is ~0.12 GFLOP per clip, three orders of magnitude below the CRNN, so fp64 costs
+//    nothing and keeps parity at the 1e-12 level instead of fp32-FFT noise near the -80 dB floor.
+//  * get_transforms chain (baseline/utils/utils.py:397-412; DataLoad.py:262-350; Scaler.py:99-105):
+//      [x + |N(0, 0.25)|] -> amplitude_to_db (amin 1e-5, top_db 80 per clip) -> pad/trunc ->
+//      float32 -> (x - mean) / std in float64 -> float32
+//
+// k_stft_mel: one workgroup per frame.  The 2048 windowed samples (reflect-padded on the fly) are
+// packed as a 1024-point complex sequence, transformed by a 5-stage radix-4 Stockham FFT held
+// entirely in LDS (2 x 16 KB ping-pong, fp64), unpacked to the 1025 real-FFT magnitudes in LDS,
+// and projected on the 64 mel filters straight from LDS - the 1025 x 628 spectrogram never
+// exists in HBM.  HBM traffic per clip: 640 KB of waveform in (L2-shared between overlapping
+// frames), 161 KB of mel out.
+#include <math.h>
+#include "common.h"
+#include "philox.h"
+#include "kernels.h"
+
+#define NFFT 2048
+#define NH 1024
+
+__global__ void k_feat_tables(double2* __restrict__ tw, double* __restrict__ win, const float* __restrict__ window) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < NFFT) {
+        double s, c;
+        sincospi(-2.0 * (double)i / (double)NFFT, &s, &c);      // W_2048^i = exp(-2 pi i / 2048)
+        tw[i] = make_double2(c, s);
+        // np.hamming(n): 0.54 - 0.46 cos(2 pi k / (n - 1))   (symmetric)
+        win[i] = window ? (double)window[i] : 0.54 - 0.46 * cospi(2.0 * (double)i / (double)(NFFT - 1));
+    }
+}
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+__global__ __launch_bounds__(256) void k_stft_mel(const float* __restrict__ wave, int n_samples, int hop, int frames,
+                                                   const double2* __restrict__ tw, const double* __restrict__ win,
+                                                   const float* __restrict__ mel_basis, int n_mels, float* __restrict__ mel) {
+    __shared__ double2 bufA[NH];
+    __shared__ double2 bufB[NH];
+    const int tid = threadIdx.x;
+    const int f = blockIdx.x, clip = blockIdx.y;
+    const float* w = wave + (size_t)clip * n_samples;
+    // ---- windowed, reflect-padded frame packed as z[m] = x[2m] + i x[2m+1] ------------------------
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int m = tid + 256 * it;
+        double v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = 2 * m + h;
+            int idx = f * hop + n - NFFT / 2;
+            if (idx < 0) idx = -idx;
+            if (idx >= n_samples) idx = 2 * (n_samples - 1) - idx;
+            v[h] = (double)w[idx] * win[n];
+        }
+        bufA[m] = make_double2(v[0], v[1]);
+    }
+    __syncthreads();
+    // ---- radix-4 Stockham, N = 1024 -------------------------------------------------------------
+    double2* src = bufA;
+    double2* dst = bufB;
+#pragma unroll
+    for (int p = 1; p < NH; p <<= 2) {
+        const int i = tid, k = i & (p - 1), j = ((i - k) << 2) + k;
+        const int tstep = 512 / p;
+        const double2 u0 = src[i];
+        const double2 u1 = cmul(src[i + 256], tw[(k * tstep) & (NFFT - 1)]);
+        const double2 u2 = cmul(src[i + 512], tw[(2 * k * tstep) & (NFFT - 1)]);
+        const double2 u3 = cmul(src[i + 768], tw[(3 * k * tstep) & (NFFT - 1)]);
+        const double2 a02 = make_double2(u0.x + u2.x, u0.y + u2.y), s02 = make_double2(u0.x - u2.x, u0.y - u2.y);
+        const double2 a13 = make_double2(u1.x + u3.x, u1.y + u3.y), s13 = make_double2(u1.x - u3.x, u1.y - u3.y);
+        dst[j] = make_double2(a02.x + a13.x, a02.y + a13.y);
+        dst[j + p] = make_double2(s02.x + s13.y, s02.y - s13.x);          // u0 - i u1 - u2 + i u3
+        dst[j + 2 * p] = make_double2(a02.x - a13.x, a02.y - a13.y);
+        dst[j + 3 * p] = make_double2(s02.x - s13.y, s02.y + s13.x);      // u0 + i u1 - u2 - i u3
+        __syncthreads();
+        double2* t = src; src = dst; dst = t;
+    }
+    // ---- real-FFT unpack -> magnitudes (into dst, reinterpreted as double[]) ----------------------
+    double* mag = (double*)dst;
+    for (int k = tid; k <= NH; k += 256) {
+        const double2 Zk = src[k & (NH - 1)];
+        const double2 Zm = src[(NH - k) & (NH - 1)];
+        const double2 Zc = make_double2(Zm.x, -Zm.y);
+        const double2 e = make_double2(0.5 * (Zk.x + Zc.x), 0.5 * (Zk.y + Zc.y));
+        const double2 o = make_double2(0.5 * (Zk.x - Zc.x), 0.5 * (Zk.y - Zc.y));
+        const double2 t = cmul(tw[k], o);                                   // W^k * o
+        const double re = e.x + t.y, im = e.y - t.x;                        // e - i * t
+        mag[k] = sqrt(re * re + im * im);
+    }
+    __syncthreads();
+    // ---- mel projection: thread = (mel m, quarter q) ----------------------------------------------
+    for (int m0 = 0; m0 < n_mels; m0 += 64) {
+        const int m = m0 + (tid >> 2), q = tid & 3;
+        double s = 0.0;
+        if (m < n_mels) {
+            const float* row = mel_basis + (size_t)m * (NH + 1);
+            for (int k = q; k <= NH; k += 4) s += (double)row[k] * mag[k];
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (q == 0 && m < n_mels) mel[((size_t)clip * frames + f) * n_mels + m] = (float)s;
+    }
+}
+
+// ---- log / noise / pad / normalise ----------------------------------------------------------------
+__device__ __forceinline__ double teacher_noise(uint32_t e_global, uint64_t seed) {
+    const u32x4 o = philox4x32_10(e_global >> 1, 0u, 16u, PHILOX_TAG, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint32_t w0 = (e_global & 1) ? o.z : o.x, w1 = (e_global & 1) ? o.w : o.y;
+    const double u1 = ((double)w0 + 1.0) * 2.3283064365386963e-10, u2 = (double)w1 * 2.3283064365386963e-10;
+    const double g = sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+    return (double)(float)fabs(0.25 * g);
+}
+__device__ __forceinline__ double amp_db(double a) {
+    // librosa.amplitude_to_db(ref=1, amin=1e-5): 10 log10(max(amin^2, a^2)) - 10 log10(max(amin^2, 1))
+    return 10.0 * log10(fmax(1e-10, a * a));
+}
+
+__global__ __launch_bounds__(256) void k_logmel_transform(const float* __restrict__ mel, int frames, int n_mels,
+                                                           int max_frames, const float* __restrict__ mean,
+                                                           const float* __restrict__ stdv,
+                                                           const uint64_t* __restrict__ seed_ptr,
+                                                           float* __restrict__ out_clean, float* __restrict__ out_noisy) {
+    __shared__ double red[2][4];
+    const int tid = threadIdx.x, clip = blockIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = frames * n_mels;
+    const float* src = mel + (size_t)clip * n;
+    const uint64_t seed = out_noisy ? seed_ptr[0] : 0ull;
+    // per-clip maxima (amplitude_to_db clamps at max - 80 dB over the WHOLE clip, before padding)
+    double mc = 0.0, mn = 0.0;
+    for (int e = tid; e < n; e += 256) {
+        const double a = fabs((double)src[e]);
+        mc = fmax(mc, a);
+        if (out_noisy) mn = fmax(mn, fabs((double)src[e] + teacher_noise((uint32_t)(clip * n + e), seed)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mc = fmax(mc, __shfl_xor(mc, o)); mn = fmax(mn, __shfl_xor(mn, o)); }
+    if (lane == 0) { red[0][wv] = mc; red[1][wv] = mn; }
+    __syncthreads();
+    const double floor_c = amp_db(fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3]))) - 80.0;
+    const double floor_n = amp_db(fmax(fmax(red[1][0], red[1][1]), fmax(red[1][2], red[1][3]))) - 80.0;
+    const int n_out = max_frames * n_mels;
+    for (int e = tid; e < n_out; e += 256) {
+        const int t = e / n_mels, m = e % n_mels;
+        float vc = 0.f, vn = 0.f;                               // PadOrTrunc pads with 0 (dB) AFTER the log
+        if (t < frames) {
+            vc = (float)fmax(amp_db((double)src[e]), floor_c);  // ToTensor: .float()
+            if (out_noisy) vn = (float)fmax(amp_db((double)src[e] + teacher_noise((uint32_t)(clip * n + e), seed)), floor_n);
+        }
+        if (mean) {                                             // Scaler.normalize in float64, torch.Tensor() -> fp32
+            vc = (float)(((double)vc - (double)mean[m]) / (double)stdv[m]);
+            vn = (float)(((double)vn - (double)mean[m]) / (double)stdv[m]);
+        }
+        out_clean[(size_t)clip * n_out + e] = vc;
+        if (out_noisy) out_noisy[(size_t)clip * n_out + e] = vn;
+    }
+}
+
+extern "C" size_t sed_mel_spec_ws_bytes(int n_clips, int n_samples, int hop, int n_fft, int n_mels) {
+    (void)n_clips; (void)n_samples; (void)hop; (void)n_mels;
+    if (n_fft != NFFT) return 0;
+    return (size_t)NFFT * sizeof(double2) + (size_t)NFFT * sizeof(double);
+}
+
+extern "C" int sed_mel_spec(const float* wave, int n_clips, int n_samples, int hop, int n_fft, const float* window,
+                            const float* mel_basis, int n_mels, float* mel, void* ws, size_t ws_bytes, void* stream) {
+    SED_CHECK_ARG(wave && mel_basis && mel && ws, "sed_mel_spec: null argument");
+    if (n_fft != NFFT) {
+        sed_set_error("sed_mel_spec: n_fft must be 2048 (config.py:18), got %d", n_fft);
+        return SED_ERR_UNSUPPORTED;
+    }
+    SED_CHECK_ARG(n_clips >= 1 && hop >= 1 && n_mels >= 1 && n_samples > NFFT / 2, "sed_mel_spec: bad sizes (reflect padding needs n_samples > n_fft/2)");
+    if (ws_bytes < sed_mel_spec_ws_bytes(n_clips, n_samples, hop, n_fft, n_mels)) {
+        sed_set_error("sed_mel_spec: workspace too small");
+        return SED_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    double2* tw = (double2*)ws;
+    double* win = (double*)((char*)ws + (size_t)NFFT * sizeof(double2));
+    k_feat_tables<<<NFFT / 256, 256, 0, st>>>(tw, win, window);
+    SED_CHECK_LAUNCH();
+    const int frames = 1 + n_samples / hop;
+    k_stft_mel<<<dim3(frames, n_clips), 256, 0, st>>>(wave, n_samples, hop, frames, tw, win, mel_basis, n_mels, mel);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}
+
+extern "C" int sed_logmel_transform(const float* mel, int n_clips, int frames, int n_mels, int max_frames,
+                                    const float* mean, const float* std, const uint64_t* seed_dev, float* out_clean,
+                                    float* out_noisy, void* stream) {
+    SED_CHECK_ARG(mel && out_clean, "sed_logmel_transform: null argument");
+    SED_CHECK_ARG((mean == nullptr) == (std == nullptr), "sed_logmel_transform: mean and std go together");
+    SED_CHECK_ARG(!out_noisy || seed_dev, "sed_logmel_transform: noise requested but seed_dev is null");
+    SED_CHECK_ARG(n_clips >= 1 && frames >= 1 && n_mels >= 1 && max_frames >= 1, "sed_logmel_transform: bad sizes");
+    SED_CHECK_ARG((int64_t)n_clips * frames * n_mels < (1ll << 32), "sed_logmel_transform: too many elements for the noise stream");
+    k_logmel_transform<<<n_clips, 256, 0, (hipStream_t)stream>>>(mel, frames, n_mels, max_frames, mean,
+                                                                 std, seed_dev, out_clean, out_noisy);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}

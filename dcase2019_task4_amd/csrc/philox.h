@@ -1,0 +1,39 @@
+// philox.h - Philox4x32-10 counter RNG and the dropout / noise stream definition.
+// Mirrored bit-for-bit by oracle/philox.py (test infrastructure) so train-mode parity tests run
+// with dropout enabled.  Stands in for nn.Dropout's generator (models/CNN.py:59-61, CRNN.py:74)
+// and np.random.normal in AugmentGaussianNoise (DataLoad.py:285).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PHILOX_M0 0xD2511F53u
+#define PHILOX_M1 0xCD9E8D57u
+#define PHILOX_W0 0x9E3779B9u
+#define PHILOX_W1 0xBB67AE85u
+#define PHILOX_TAG 0x5ED0u
+
+struct u32x4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        uint32_t hi0 = __umulhi(PHILOX_M0, c0), lo0 = PHILOX_M0 * c0;
+        uint32_t hi1 = __umulhi(PHILOX_M1, c2), lo1 = PHILOX_M1 * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += PHILOX_W0; k1 += PHILOX_W1;
+    }
+    u32x4 r = {c0, c1, c2, c3};
+    return r;
+}
+
+// 8 x 16-bit uniforms for (index, stream): halfword i = (word[i>>1] >> 16*(i&1)) & 0xffff
+__device__ __forceinline__ u32x4 philox_stream(uint32_t index, uint32_t stream, uint64_t seed) {
+    return philox4x32_10(index, 0u, stream, PHILOX_TAG, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+__device__ __forceinline__ uint32_t philox_hw(const u32x4& o, int i) {
+    uint32_t w = (i >> 1) == 0 ? o.x : (i >> 1) == 1 ? o.y : (i >> 1) == 2 ? o.z : o.w;
+    return (w >> (16 * (i & 1))) & 0xffffu;
+}
+__device__ __forceinline__ uint32_t drop_thresh16(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }

@@ -1,0 +1,242 @@
+"""Mean-teacher train step on MI355X - host-side mirror of baseline/main.py:45-165.
+
+Two ways in:
+
+* drop-in: keep baseline/main.py's own ``train`` loop and ``torch.optim.Adam`` and just build the
+  models with ``dcase2019_task4_amd.crnn.CRNN`` - forward/backward then run in the HIP kernels
+  through one autograd node.  ``update_ema_variables`` below is the same call as main.py:45-49
+  fused into one kernel over the flat parameter buffers.
+* fused: ``MeanTeacherStep`` runs the whole body of the loop (main.py:84-157: teacher forward,
+  student forward, losses, backward, Adam, EMA, step counter) as a fixed sequence of C-ABI calls
+  on persistent buffers, optionally captured into one hipGraph, with every per-step scalar
+  (consistency weight, EMA alpha, Adam bias correction, dropout seeds) advanced ON DEVICE - none
+  of the ~11 host syncs per step of the reference loop (main.py:106-149 ``.item()``).  ``train``
+  wraps it in the reference's epoch-loop signature.
+"""
+import ctypes as C
+import time
+
+import torch
+
+from . import _lib
+from .crnn import CRNN
+
+LOSS_NAMES = ("loss", "weak_class_loss", "strong_loss", "cons_strong", "cons_weak", "weak_ema_loss",
+              "strong_ema_loss", "cons_weight")
+
+
+def update_ema_variables(model, ema_model, alpha, global_step):
+    """main.py:45-49 - ``alpha = min(1 - 1/(global_step+1), alpha)``; parameters only (buffers are
+    not averaged).  One fused kernel over the two flat buffers."""
+    alpha = min(1 - 1 / (global_step + 1), alpha)
+    model.flatten_parameters_()
+    ema_model.flatten_parameters_()
+    n = model._flat.numel()
+    _lib.check(_lib.lib().sed_ema_update(n, _lib.ptr(model._flat), _lib.ptr(ema_model._flat), float(alpha),
+                                         _lib.stream_ptr()), "sed_ema_update")
+
+
+def _slice_range(s, B):
+    if s is None:
+        return 0, 0
+    lo, hi, st = s.indices(B)
+    if st != 1:
+        raise NotImplementedError("masks must be contiguous slices (main.py:241,247)")
+    return lo, max(lo, hi)
+
+
+class MeanTeacherStep:
+    """The body of main.train's loop (main.py:84-157) as one fused, graph-capturable device step."""
+
+    def __init__(self, student, teacher, batch_size, n_frames, rampup_length, weak_mask, strong_mask, lr=1e-3,
+                 betas=(0.9, 0.999), eps=1e-8, ema_decay=0.999, max_consistency_cost=2.0, seed=0, use_graph=True,
+                 process_group=None, overlap_streams=True):
+        assert isinstance(student, CRNN) and isinstance(teacher, CRNN)
+        self.l = _lib.lib()
+        self.student, self.teacher = student, teacher
+        dev = next(student.parameters()).device
+        if dev.type != "cuda":
+            raise _lib.SedError("MeanTeacherStep needs the models on the GPU (no CPU fallback)")
+        self.device = dev
+        student.flatten_parameters_(dev)
+        teacher.flatten_parameters_(dev)
+        self.B, self.T = int(batch_size), int(n_frames)
+        self.dims = _lib.make_dims(self.B, self.T, 64, 64, 64, student._nclass, student._n_layers, student._p_drop)
+        self.T3, self.NC = self.T // 8, student._nclass
+        self.wlo, self.whi = _slice_range(weak_mask, self.B)
+        self.slo, self.shi = _slice_range(strong_mask, self.B)
+        n = student._flat.numel()
+        self.n = n
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.grads = torch.zeros(n, **f32)
+        self.exp_avg = torch.zeros(n, **f32)
+        self.exp_avg_sq = torch.zeros(n, **f32)
+        self.state = torch.zeros(C.sizeof(_lib.SedStepState), device=dev, dtype=torch.uint8)
+        _lib.check(self.l.sed_step_state_init(_lib.ptr(self.state), int(seed) & (2 ** 64 - 1), int(rampup_length),
+                                              float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                              float(ema_decay), float(max_consistency_cost), _lib.stream_ptr()),
+                   "sed_step_state_init")
+        base = self.state.data_ptr()
+        self._seed_s = C.c_void_p(base + _lib.SedStepState.seed_student.offset)
+        self._seed_t = C.c_void_p(base + _lib.SedStepState.seed_teacher.offset)
+        self.ctx_bytes = self.l.sed_crnn_ctx_bytes(C.byref(self.dims))
+        self.ws_bytes = self.l.sed_crnn_bwd_ws_bytes(C.byref(self.dims))
+        if self.ctx_bytes == 0 or self.ws_bytes == 0:
+            raise _lib.SedError(self.l.sed_last_error().decode())
+        self.ctx_s = torch.empty(self.ctx_bytes, device=dev, dtype=torch.uint8)
+        self.ctx_t = torch.empty(self.ctx_bytes, device=dev, dtype=torch.uint8)
+        self.ws = torch.empty(self.ws_bytes, device=dev, dtype=torch.uint8)
+        self.x = torch.zeros(self.B, 1, self.T, 64, **f32)
+        self.x_ema = torch.zeros(self.B, 1, self.T, 64, **f32)
+        self.target = torch.zeros(self.B, self.T3, self.NC, **f32)
+        self.strong = torch.empty(self.B, self.T3, self.NC, **f32)
+        self.weak = torch.empty(self.B, self.NC, **f32)
+        self.strong_ema = torch.empty(self.B, self.T3, self.NC, **f32)
+        self.weak_ema = torch.empty(self.B, self.NC, **f32)
+        self.d_strong = torch.empty(self.B, self.T3, self.NC, **f32)
+        self.d_weak = torch.empty(self.B, self.NC, **f32)
+        self.losses = torch.zeros(8, **f32)
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(process_group)
+        self.use_graph = bool(use_graph)
+        self.overlap = bool(overlap_streams)
+        self._side = torch.cuda.Stream(device=dev) if self.overlap else None
+        self._graph_a = None
+        self._graph_b = None
+        self._warm = 0
+        self.steps_done = 0
+
+    # ---- pieces ------------------------------------------------------------------------------------
+    def _forward(self, model, x, ctx, seed, strong, weak):
+        _lib.check(self.l.sed_crnn_forward(C.byref(self.dims), _lib.ptr(model._flat), _lib.ptr(model._bn_flat),
+                                           _lib.ptr(model._bn_tracked), _lib.ptr(x), 1, 1, seed, _lib.ptr(ctx),
+                                           self.ctx_bytes, _lib.ptr(strong), _lib.ptr(weak), _lib.stream_ptr()),
+                   "sed_crnn_forward")
+
+    def _fwd_bwd(self):
+        """teacher forward (main.py:87-89), student forward (:91), losses (:93-145), backward (:152-153)."""
+        if self._side is not None:
+            # the teacher forward is independent of the student forward: run it on a second stream
+            cur = torch.cuda.current_stream()
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                self._forward(self.teacher, self.x_ema, self.ctx_t, self._seed_t, self.strong_ema, self.weak_ema)
+            self._forward(self.student, self.x, self.ctx_s, self._seed_s, self.strong, self.weak)
+            cur.wait_stream(self._side)
+        else:
+            self._forward(self.teacher, self.x_ema, self.ctx_t, self._seed_t, self.strong_ema, self.weak_ema)
+            self._forward(self.student, self.x, self.ctx_s, self._seed_s, self.strong, self.weak)
+        _lib.check(self.l.sed_mt_loss(C.byref(self.dims), _lib.ptr(self.strong), _lib.ptr(self.weak),
+                                      _lib.ptr(self.strong_ema), _lib.ptr(self.weak_ema), _lib.ptr(self.target),
+                                      self.wlo, self.whi, self.slo, self.shi, _lib.ptr(self.state),
+                                      _lib.ptr(self.losses), _lib.ptr(self.d_strong), _lib.ptr(self.d_weak),
+                                      _lib.stream_ptr()), "sed_mt_loss")
+        _lib.check(self.l.sed_crnn_backward(C.byref(self.dims), _lib.ptr(self.student._flat), _lib.ptr(self.x),
+                                            self._seed_s, _lib.ptr(self.ctx_s), self.ctx_bytes,
+                                            _lib.ptr(self.d_strong), _lib.ptr(self.d_weak), _lib.ptr(self.grads),
+                                            _lib.ptr(self.ws), self.ws_bytes, _lib.stream_ptr()), "sed_crnn_backward")
+
+    def _update(self):
+        """Adam (main.py:154) + EMA teacher (:155-157) + step counters, one kernel each."""
+        _lib.check(self.l.sed_adam_ema(self.n, _lib.ptr(self.student._flat), _lib.ptr(self.grads),
+                                       _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
+                                       _lib.ptr(self.teacher._flat), _lib.ptr(self.state), 1.0 / self.world,
+                                       _lib.stream_ptr()), "sed_adam_ema")
+        _lib.check(self.l.sed_step_state_advance(_lib.ptr(self.state), _lib.stream_ptr()), "sed_step_state_advance")
+
+    def _allreduce(self):
+        if self.pg is not None and self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.pg)
+
+    # ---- public ------------------------------------------------------------------------------------
+    def load_batch(self, x, x_ema, target):
+        self.x.copy_(x.reshape(self.x.shape), non_blocking=True)
+        self.x_ema.copy_(x_ema.reshape(self.x.shape), non_blocking=True)
+        self.target.copy_(target, non_blocking=True)
+
+    def run(self):
+        """One step on the batch currently in self.x / self.x_ema / self.target."""
+        if not self.use_graph or self._warm < 2:
+            self._fwd_bwd()
+            self._allreduce()
+            self._update()
+            self._warm += 1
+        else:
+            if self._graph_a is None:
+                self._capture()
+            if self.world > 1:
+                self._graph_a.replay()
+                self._allreduce()
+                self._graph_b.replay()
+            else:
+                self._graph_a.replay()
+        self.steps_done += 1
+
+    def step(self, x, x_ema, target):
+        self.load_batch(x, x_ema, target)
+        self.run()
+
+    def _capture(self):
+        torch.cuda.synchronize(self.device)
+        if self.world > 1:
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                self._fwd_bwd()
+            with torch.cuda.graph(gb):
+                self._update()
+            # capture executes nothing: the captured step still has to run once via replay
+            self._graph_a, self._graph_b = ga, gb
+        else:
+            ga = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                self._fwd_bwd()
+                self._update()
+            self._graph_a = ga
+
+    def meters(self):
+        """The meters main.train logs (main.py:106-149); ONE device->host copy."""
+        return dict(zip(LOSS_NAMES, self.losses.tolist()))
+
+    def read_state(self):
+        raw = bytes(self.state.cpu().numpy().tobytes())
+        return _lib.SedStepState.from_buffer_copy(raw)
+
+
+def train(train_loader, model, optimizer, epoch, ema_model=None, weak_mask=None, strong_mask=None, n_epoch=100,
+          log=print):
+    """main.train (main.py:52-165) with the loop body replaced by MeanTeacherStep.
+
+    ``optimizer`` supplies lr / betas / eps (its per-tensor state is not used: Adam moments live in the
+    step object's flat buffers, kept on ``model._mt_step`` across epochs)."""
+    if ema_model is None:
+        raise NotImplementedError("the fused step implements the mean-teacher path; use the reference "
+                                  "main_simple_CRNN.train loop with dcase2019_task4_amd.crnn.CRNN for supervised training")
+    start = time.time()
+    step_obj = getattr(model, "_mt_step", None)
+    it = iter(train_loader)
+    n_batches = len(train_loader)
+    for i in range(n_batches):
+        batch_input, ema_batch_input, target = next(it)
+        if step_obj is None:
+            B, T = batch_input.shape[0], batch_input.shape[-2]
+            pg0 = optimizer.param_groups[0]
+            dev = torch.device("cuda", torch.cuda.current_device())
+            model.to(dev)
+            ema_model.to(dev)
+            step_obj = MeanTeacherStep(model, ema_model, B, T, n_batches * n_epoch // 2, weak_mask, strong_mask,
+                                       lr=pg0["lr"], betas=pg0["betas"], eps=pg0["eps"])
+            model._mt_step = step_obj
+        step_obj.step(batch_input.to(step_obj.device, non_blocking=True),
+                      ema_batch_input.to(step_obj.device, non_blocking=True),
+                      target.to(step_obj.device, non_blocking=True))
+    m = step_obj.meters()
+    loss = m["loss"]
+    assert not (loss != loss or loss > 1e5), 'Loss explosion: {}'.format(loss)       # main.py:147
+    assert not loss < 0, 'Loss problem, cannot be negative'                            # main.py:148
+    log('Epoch: {}\tTime {:.2f}\t{}'.format(epoch, time.time() - start,
+                                            "\t".join(f"{k} {v:.4g}" for k, v in m.items())))
+    return m

@@ -1,0 +1,181 @@
+/* dcase_sed.h - C-ABI of libdcase_sed_mi355.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for ONE hot path of turpaultn/DCASE2019_task4: the mean-teacher CRNN train
+ * step and its feature front-end.  The reference has no native code and no FFI;
+ * what a maintainer binds these entry points to is the Python call sites listed next to each
+ * declaration (paths relative to the reference root, baseline/...).  The Python host side that
+ * mirrors those call sites lives in dcase2019_task4_amd/ and calls this library through ctypes
+ * (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *  - plain C types, raw DEVICE pointers, explicit hipStream_t (passed as void*); no torch types.
+ *  - the caller owns ALL memory (outputs, saved context, workspace).  The library never
+ *    allocates, frees or synchronises, so every entry point is hipGraph-capturable.
+ *  - return 0 on success, negative sed_status on failure; sed_last_error() gives a
+ *    thread-local message.  Entry points are stateless and re-entrant.
+ *  - activations are channels-last fp32: [B][T][F][C]; parameters keep the reference's
+ *    shapes, packed into ONE flat fp32 buffer in named_parameters() order (sed_param_layout).
+ */
+#ifndef DCASE_SED_H
+#define DCASE_SED_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    SED_OK = 0,
+    SED_ERR_BAD_ARG = -1,        /* unsupported dims / null pointer */
+    SED_ERR_WORKSPACE = -2,      /* ctx / workspace too small */
+    SED_ERR_LAUNCH = -3,         /* HIP launch / runtime error */
+    SED_ERR_UNSUPPORTED = -4     /* configuration outside the hot path */
+} sed_status;
+
+/* Model + batch geometry.  Mirrors cfg.crnn_kwargs (baseline/config.py:53-58) for the one
+ * configuration on the hot path: activation="glu", attention=True, BGRU, 3 conv blocks,
+ * kernel 3 / stride 1 / pad 1, pooling (2,4) x3 (so F must be 64), n_in_channel = 1. */
+typedef struct {
+    int32_t B;            /* clips in the batch                                  */
+    int32_t T;            /* input frames (628 for BASELINE, 864 for config.py)  */
+    int32_t F;            /* mel bins; must be 64                                */
+    int32_t C;            /* conv filters per block; must be 64                  */
+    int32_t H;            /* n_RNN_cell; must be 64                              */
+    int32_t nclass;       /* <= 16 (10 in the reference)                         */
+    int32_t n_layers_rnn; /* 1 or 2                                              */
+    float   p_drop;       /* dropout probability (config.py:56), 0 disables      */
+    float   bn_eps;       /* 1e-3 (models/CNN.py:49)                             */
+    float   bn_momentum;  /* 0.99 (models/CNN.py:49)                             */
+} sed_dims;
+
+/* Per-step scalars kept in DEVICE memory so that a captured hipGraph can be replayed while the
+ * step counter, consistency weight, EMA alpha, Adam bias corrections and dropout seeds advance.
+ * Restates the host arithmetic of main.train (main.py:72-78,127,155-157), ramps.sigmoid_rampup
+ * (utils/ramps.py:20-27), update_ema_variables' alpha (main.py:47) and torch.optim.Adam's bias
+ * correction.  Advanced by sed_step_state_advance(). */
+typedef struct {
+    int64_t  global_step;     /* main.py global_step BEFORE this step's increment       */
+    int64_t  opt_step;        /* Adam step count of this step (1-based)                 */
+    int64_t  rampup_length;   /* len(train_loader) * n_epoch // 2 (main.py:72)          */
+    uint64_t base_seed;       /* user seed for the dropout / noise streams              */
+    uint64_t seed_student;    /* Philox key for the student forward of this step        */
+    uint64_t seed_teacher;    /* Philox key for the teacher forward of this step        */
+    double   lr, beta1, beta2, eps;   /* torch.optim.Adam hyper-parameters (main.py:289) */
+    double   ema_decay;       /* 0.999 (main.py:157)                                    */
+    double   max_cons_cost;   /* cfg.max_consistency_cost = 2 (config.py:36)            */
+    /* derived for this step: */
+    float    cons_weight;     /* max_consistency_cost * rampup (main.py:74-78,127)      */
+    float    ema_alpha;       /* min(1 - 1/(global_step+2), ema_decay) (main.py:47,155) */
+    float    adam_step_size;  /* lr / (1 - beta1^opt_step)                              */
+    float    adam_sqrt_bc2;   /* sqrt(1 - beta2^opt_step)                               */
+} sed_step_state;
+
+const char* sed_last_error(void);
+int sed_version(void);
+
+/* ---- parameter layout --------------------------------------------------------------------
+ * Number of parameter tensors and their element offsets inside the flat buffer, in the
+ * reference's named_parameters() order (cnn(18) -> rnn(8*n_layers) -> dense(2) ->
+ * dense_softmax(2); models/CRNN.py:12-31).  offsets must hold n+1 entries (last = total). */
+int sed_param_count(const sed_dims* d);
+int sed_param_layout(const sed_dims* d, int64_t* offsets);
+
+/* ---- CRNN forward / backward ---------------------------------------------------------------
+ * Replaces CRNN.forward (models/CRNN.py:59-84) + CNN.forward (models/CNN.py:85-89) +
+ * GLU.forward (CNN.py:11-16) + BidirectionalGRU.forward (RNN.py:14-16), called from
+ * main.train (main.py:87,91) and evaluation (evaluation_measures.py:40-45,203-209).
+ *   params      flat parameters (sed_param_layout)
+ *   bn_running  [3][2][C] running_mean / running_var per block (read in eval; updated in train
+ *               when update_bn != 0: BatchNorm2d momentum rule, CNN.py:49)
+ *   bn_tracked  [3] int64 num_batches_tracked (incremented with bn_running), may be NULL
+ *   x           [B][1][T][F] fp32
+ *   train       1 = module.train() semantics (batch statistics, dropout), 0 = eval
+ *   seed_dev    device pointer to the 64-bit Philox key of this forward (ignored if p_drop==0
+ *               or train==0); the same pointer/value must be given to backward
+ *   ctx         saved activations for backward + scratch; sed_crnn_ctx_bytes(d)
+ *   strong/weak outputs [B][T/8][nclass], [B][nclass]                                        */
+size_t sed_crnn_ctx_bytes(const sed_dims* d);
+int sed_crnn_forward(const sed_dims* d, const float* params, float* bn_running, int64_t* bn_tracked,
+                     const float* x, int train, int update_bn, const uint64_t* seed_dev,
+                     void* ctx, size_t ctx_bytes, float* strong, float* weak, void* stream);
+
+/* Backward of the above in train mode (autograd of main.py:153 loss.backward()).
+ *   d_strong/d_weak  gradients w.r.t. the two outputs
+ *   grads            flat, same layout as params; OVERWRITTEN with dLoss/dparams
+ *   ws               scratch, sed_crnn_bwd_ws_bytes(d)                                       */
+size_t sed_crnn_bwd_ws_bytes(const sed_dims* d);
+int sed_crnn_backward(const sed_dims* d, const float* params, const float* x, const uint64_t* seed_dev,
+                      void* ctx, size_t ctx_bytes, const float* d_strong, const float* d_weak,
+                      float* grads, void* ws, size_t ws_bytes, void* stream);
+
+/* Debug / test access to intermediates inside ctx: name in {"p0","y1","p1","y2","p2","gru0",
+ * "gru1","wz0","mean0","scale1","shift1",...}. Returns 0 and fills offset/bytes, or <0. */
+int sed_crnn_ctx_view(const sed_dims* d, const char* name, size_t* offset, size_t* bytes);
+
+/* ---- mean-teacher loss ---------------------------------------------------------------------
+ * Replaces the loss block of main.train (main.py:93-145): target_weak = target.max(-2),
+ * BCE(weak[wm]) + BCE(strong[sm]) + w*MSE(strong, strong_ema) + w*MSE(weak, weak_ema), with
+ * w = state->cons_weight, and its gradient w.r.t. the student outputs.
+ *   masks are the reference's Python slices (main.py:241,247) as [lo, hi) row ranges; lo==hi
+ *   disables the term (weak_mask / strong_mask = None).
+ *   losses[8] = {loss, weak_bce, strong_bce, cons_strong, cons_weak, weak_ema_bce,
+ *                strong_ema_bce, cons_weight}  (the meters of main.py:106-149)                */
+int sed_mt_loss(const sed_dims* d, const float* strong, const float* weak, const float* strong_ema,
+                const float* weak_ema, const float* target, int weak_lo, int weak_hi, int strong_lo,
+                int strong_hi, const sed_step_state* state_dev, float* losses, float* d_strong,
+                float* d_weak, void* stream);
+
+/* ---- optimiser + EMA -----------------------------------------------------------------------
+ * Replaces optimizer.step() of torch.optim.Adam(lr, betas) (main.py:154,289-290) fused with
+ * update_ema_variables (main.py:45-49,156-157) over the flat buffers. grad_scale multiplies
+ * the gradient first (1/world_size after a sum all-reduce; 1 otherwise). */
+int sed_adam_ema(int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                 float* ema_params, const sed_step_state* state_dev, float grad_scale, void* stream);
+
+/* Plain EMA for the drop-in update_ema_variables(model, ema_model, alpha, global_step) call. */
+int sed_ema_update(int64_t n, const float* params, float* ema_params, float alpha, void* stream);
+
+/* Initialise / advance the device step state (one tiny kernel; graph-capturable).
+ * init: global_step = 0, opt_step = 1 and the derived fields of the first step.
+ * advance: called once at the END of each train step; moves to the next step's values. */
+int sed_step_state_init(sed_step_state* state_dev, uint64_t base_seed, int64_t rampup_length,
+                        double lr, double beta1, double beta2, double eps, double ema_decay,
+                        double max_cons_cost, void* stream);
+int sed_step_state_advance(sed_step_state* state_dev, void* stream);
+
+/* ---- feature front-end ---------------------------------------------------------------------
+ * sed_mel_spec replaces DatasetDcase2019Task4.calculate_mel_spec (DatasetDcase2019Task4.py:
+ * 197-231) with save_log_feature=False: symmetric Hamming-n_fft STFT (center, reflect pad),
+ * magnitude, mel_basis @ |S|, transposed -> mel [n_clips][frames][n_mels] fp32 (linear).
+ *   wave       [n_clips][n_samples] fp32
+ *   window     [n_fft] fp32 (np.hamming(n_fft))
+ *   mel_basis  [n_mels][n_fft/2+1] fp32 (librosa.filters.mel(..., htk=False, norm=None))
+ *   n_fft must be 2048; frames = 1 + n_samples / hop.                                         */
+size_t sed_mel_spec_ws_bytes(int n_clips, int n_samples, int hop, int n_fft, int n_mels);
+int sed_mel_spec(const float* wave, int n_clips, int n_samples, int hop, int n_fft,
+                 const float* window, const float* mel_basis, int n_mels, float* mel,
+                 void* ws, size_t ws_bytes, void* stream);
+
+/* sed_logmel_transform replaces the per-sample transform chain of get_transforms
+ * (utils/utils.py:397-412): [AugmentGaussianNoise] -> ApplyLog (librosa.amplitude_to_db, amin
+ * 1e-5, top_db 80 per clip) -> PadOrTrunc(max_frames) -> ToTensor -> Normalize(scaler)
+ * (DataLoad.py:262-287,189-207,210-259,290-321,324-350; Scaler.normalize Scaler.py:99-105).
+ *   mel     [n_clips][frames][n_mels] linear mel
+ *   mean/std  [n_mels] or NULL (no Normalize)
+ *   out_clean [n_clips][max_frames][n_mels]; out_noisy same or NULL (no augmentation)
+ *   seed_dev  Philox key for the teacher noise |N(0, 0.25)| (DataLoad.py:285)                 */
+int sed_logmel_transform(const float* mel, int n_clips, int frames, int n_mels, int max_frames,
+                         const float* mean, const float* std, const uint64_t* seed_dev,
+                         float* out_clean, float* out_noisy, void* stream);
+
+/* ---- self tests (run on the GPU box by tests/) ---------------------------------------------
+ * Checks the MFMA fragment mapping and Philox stream this build assumes. out[0..3] receives
+ * max abs errors / mismatch counts; returns 0 if all checks pass. */
+int sed_selftest(float* out_dev4, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCASE_SED_H */

@@ -1,0 +1,80 @@
+"""CPU-side checks of the C-ABI boundary: the shared library builds/loads and exports exactly the
+symbols include/dcase_sed.h declares; argument validation paths that need no GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from dcase2019_task4_amd import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(REPO, "include", "dcase_sed.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sed_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    assert _header_functions() == _lib.exported_symbols()
+
+
+def test_library_exports_every_declared_symbol():
+    l = _lib.lib()
+    for name in _header_functions():
+        assert hasattr(l, name), name
+    assert l.sed_version() >= 100
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(_lib.SedDims) == 40
+    assert C.sizeof(_lib.SedStepState) == 6 * 8 + 6 * 8 + 4 * 4
+    assert _lib.SedStepState.seed_student.offset == 32 and _lib.SedStepState.seed_teacher.offset == 40
+
+
+def test_param_layout_matches_reference_order():
+    from oracle import ref_cpu
+    import numpy as np
+    d = _lib.make_dims(24, 628)
+    offs = _lib.param_layout(d)
+    shapes = list(ref_cpu.param_shapes().values())
+    assert len(offs) == len(shapes) + 1 == 39
+    sizes = [int(np.prod(s)) for s in shapes]
+    assert [offs[i + 1] - offs[i] for i in range(len(shapes))] == sizes
+    assert offs[-1] == 214356
+    d1 = _lib.make_dims(24, 628, n_layers_rnn=1)
+    assert _lib.param_layout(d1)[-1] == 214356 - 2 * (192 * 128 + 192 * 64 + 2 * 192)
+
+
+def test_unsupported_configurations_fail_loudly():
+    l = _lib.lib()
+    bad = _lib.make_dims(24, 628, F=128)
+    assert l.sed_crnn_ctx_bytes(C.byref(bad)) == 0
+    assert b"64" in l.sed_last_error()
+    assert l.sed_param_count(C.byref(_lib.make_dims(24, 628, nclass=40))) < 0
+    assert l.sed_mel_spec_ws_bytes(1, 160000, 255, 1024, 64) == 0
+    ok = _lib.make_dims(24, 628)
+    assert l.sed_crnn_ctx_bytes(C.byref(ok)) > 0 and l.sed_crnn_bwd_ws_bytes(C.byref(ok)) > 0
+
+
+def test_module_refuses_configs_outside_the_hot_path_and_cpu_tensors():
+    import torch
+    from dcase2019_task4_amd.crnn import CRNN
+    kw = dict(n_in_channel=1, nclass=10, attention=True, n_RNN_cell=64, n_layers_RNN=2, activation="glu", dropout=0.5,
+              kernel_size=3 * [3], padding=3 * [1], stride=3 * [1], nb_filters=[64, 64, 64], pooling=list(3 * ((2, 4),)))
+    m = CRNN(**kw)
+    names = [n for n, _ in m.named_parameters()]
+    from oracle import ref_cpu
+    assert names == list(ref_cpu.param_shapes().keys())
+    sd = m.state_dict()
+    assert set(sd) == {"cnn", "rnn", "dense", "dense_softmax"}
+    assert "conv0.weight" in sd["cnn"] and "batchnorm2.num_batches_tracked" in sd["cnn"]
+    assert "rnn.weight_hh_l1_reverse" in sd["rnn"]
+    with pytest.raises(_lib.SedError):
+        m(torch.zeros(2, 1, 64, 64))               # CPU tensor: no fallback
+    with pytest.raises(NotImplementedError):
+        CRNN(**dict(kw, activation="relu"))
+    with pytest.raises(NotImplementedError):
+        CRNN(**dict(kw, attention=False))

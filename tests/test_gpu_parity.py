@@ -1,0 +1,326 @@
+"""-m gpu parity tests: the HIP path (through the C-ABI) against the CPU oracle and against the
+golden vectors captured from the reference.  Tolerances: posteriors 1e-3 is the north-star bound;
+the tests hold the fp32 path to 2e-5 (it lands at ~1e-6)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu, synth
+from tests import gpu_util as gu
+
+pytestmark = pytest.mark.gpu
+
+POST_TOL = 2e-5
+
+
+def _golden(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_selftest_mfma_layout_and_philox():
+    from dcase2019_task4_amd import _lib
+    out = torch.full((4,), -1.0, device="cuda")
+    _lib.check(_lib.lib().sed_selftest(_lib.ptr(out), None, 0, _lib.stream_ptr()), "sed_selftest")
+    o = out.cpu().tolist()
+    assert o[0] < 1e-5, f"MFMA 32x32x2 f32 fragment map mismatch: max err {o[0]}"
+    assert o[1] == 0.0, "Philox4x32-10 known-answer vectors mismatch"
+
+
+def test_native_library_is_the_one_loaded():
+    from dcase2019_task4_amd import _lib
+    _lib.lib()
+    maps = open("/proc/self/maps").read()
+    assert "libdcase_sed_mi355.so" in maps
+
+
+def _synth_bn(seed):
+    rs = np.random.RandomState(5000 + seed)
+    st = ref_cpu.new_bn_state()
+    for i in range(3):
+        st[f"cnn.cnn.batchnorm{i}.running_mean"] = torch.tensor(rs.normal(0, 0.2, 64), dtype=torch.float32)
+        st[f"cnn.cnn.batchnorm{i}.running_var"] = torch.tensor(rs.uniform(0.5, 1.5, 64), dtype=torch.float32)
+    return st
+
+
+@pytest.mark.parametrize("T", [628, 864])
+def test_eval_posteriors_vs_reference_goldens(golden_dir, T):
+    """G1: eval-mode CRNN posteriors of the reference itself (T=628 BASELINE shape, T=864 config.py shape)."""
+    g = _golden(golden_dir, f"g1_eval_T{T}.npz")
+    model, _ = gu.make_model(0)
+    gu.set_bn(model, _synth_bn(0))
+    model.eval()
+    x = synth.make_input(T, 2, T).cuda()
+    with torch.no_grad():
+        strong, weak = model(x)
+    torch.cuda.synchronize()
+    p0 = gu.nchw(model.ctx_view("p0").view(2, T // 2, 16, 64)).cpu()
+    p1 = gu.nchw(model.ctx_view("p1").view(2, T // 4, 4, 64)).cpu()
+    p2 = model.ctx_view("p2").view(2, T // 8, 64).cpu()
+    gru = model.ctx_view("gru1").view(2, T // 8, 128).cpu()
+    gu.report("pool0", p0[:, :, :6, :], g["pool0_s"])
+    gu.report("pool1", p1[:, :, :8, :], g["pool1_s"])
+    gu.report("pool2", p2.permute(0, 2, 1), g["pool2"][..., 0])
+    gu.report("gru", gru, g["gru"])
+    es, _ = gu.report("strong", strong.cpu(), g["strong"])
+    ew, _ = gu.report("weak", weak.cpu(), g["weak"])
+    np.testing.assert_allclose(p0[:, :, :6, :].numpy(), g["pool0_s"], atol=2e-5)
+    np.testing.assert_allclose(p1[:, :, :8, :].numpy(), g["pool1_s"], atol=2e-5)
+    np.testing.assert_allclose(p2.permute(0, 2, 1).numpy(), g["pool2"][..., 0], atol=2e-5)
+    np.testing.assert_allclose(gru.numpy(), g["gru"], atol=2e-5)
+    assert es < POST_TOL and ew < POST_TOL
+    assert strong.shape == (2, T // 8, 10) and weak.shape == (2, 10)
+
+
+def test_train_forward_and_running_stats_vs_reference_goldens(golden_dir):
+    """G3: train-mode forward (dropout 0) twice; posteriors and BatchNorm running statistics."""
+    g = _golden(golden_dir, "g3_train_fwd.npz")
+    model, _ = gu.make_model(0, dropout=0)
+    model.train()
+    with torch.no_grad():
+        for it in range(2):
+            s, w = model(synth.make_input(10 + it, 4, 628).cuda())
+            es, _ = gu.report(f"train strong{it}", s.cpu(), g[f"strong{it}"])
+            ew, _ = gu.report(f"train weak{it}", w.cpu(), g[f"weak{it}"])
+            assert es < POST_TOL and ew < POST_TOL
+    for k, v in model.named_buffers():
+        gu.report(k, v.cpu(), g[k.replace(".", "_")])
+        np.testing.assert_allclose(v.cpu().numpy(), g[k.replace(".", "_")], rtol=3e-5, atol=3e-6)
+
+
+def _fwd_bwd_both(B, T, p, seed, n_layers=2):
+    """Train-mode forward+backward of the HIP module and of the oracle on identical inputs/masks."""
+    model, params = gu.make_model(0, dropout=p, n_layers=n_layers)
+    model.train()
+    x = synth.make_input(40, B, T)
+    tgt, wm, sm = synth.make_target(5, B, T // 8)
+    rs = np.random.RandomState(99)
+    s_ema = torch.tensor(rs.uniform(0.05, 0.95, (B, T // 8, 10)), dtype=torch.float32)
+    w_ema = torch.tensor(rs.uniform(0.05, 0.95, (B, 10)), dtype=torch.float32)
+    cons_w = 0.7
+
+    def loss_fn(s, w, dev):
+        l, _ = ref_cpu.mean_teacher_loss(s, w, s_ema.to(dev), w_ema.to(dev), tgt.to(dev), wm, sm, cons_w)
+        return l
+
+    s, w = model(x.cuda(), seed=gu.seed_tensor(seed) if p > 0 else None)
+    loss = loss_fn(s, w, "cuda")
+    loss.backward()
+    torch.cuda.synchronize()
+    g_hip = gu.grads_dict(model)
+    bn_hip = gu.bn_state_from_model(model)
+
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    bn = ref_cpu.new_bn_state()
+    so, wo = ref_cpu.crnn_forward(po, x, True, bn, gu.oracle_masks(seed, B, T, p), n_layers_RNN=n_layers)
+    lo = loss_fn(so, wo, "cpu")
+    go = dict(zip(po.keys(), torch.autograd.grad(lo, list(po.values()))))
+    return (s.detach().cpu(), w.detach().cpu(), float(loss), g_hip, bn_hip), (so.detach(), wo.detach(), float(lo), go, bn)
+
+
+def _check_grads(g_hip, go):
+    worst = 0.0
+    for n, g in go.items():
+        gn = float(g.double().norm())
+        if ".conv" in n and n.endswith("bias"):
+            # true gradient is exactly 0 (conv bias in front of a train-mode BN): oracle holds ~1e-6 of
+            # rounding noise, the HIP path writes the exact 0
+            assert float(g_hip[n].abs().max()) < 2e-5, n
+            continue
+        scale = gn / np.sqrt(g.numel())
+        err = float((g_hip[n] - g).abs().max())
+        rel = err / (scale + 1e-30)
+        worst = max(worst, rel)
+        print(f"[grad] {n:40s} |g| {gn:.3e}  max|err| {err:.3e}  err/typ {rel:.3e}")
+        assert float(g_hip[n].double().norm()) == pytest.approx(gn, rel=2e-3), n
+        np.testing.assert_allclose(g_hip[n].numpy(), g.numpy(), rtol=5e-3, atol=5e-3 * scale, err_msg=n)
+    return worst
+
+
+@pytest.mark.parametrize("B,T,p,n_layers", [(4, 128, 0.0, 2), (4, 128, 0.5, 2), (2, 628, 0.5, 2), (3, 216, 0.5, 1),
+                                            (2, 150, 0.25, 2)])
+def test_train_forward_backward_vs_oracle(B, T, p, n_layers):
+    """Posteriors, loss, every parameter gradient and the BN running stats against the oracle, with
+    dropout ON (same Philox masks on both sides).  T=150 exercises odd H (rows dropped by the pool)."""
+    hip, orc = _fwd_bwd_both(B, T, p, seed=123456789, n_layers=n_layers)
+    es, _ = gu.report("strong", hip[0], orc[0])
+    ew, _ = gu.report("weak", hip[1], orc[1])
+    assert es < POST_TOL and ew < POST_TOL
+    assert hip[2] == pytest.approx(orc[2], rel=1e-5)
+    _check_grads(hip[3], orc[3])
+    for k, v in orc[4].items():
+        np.testing.assert_allclose(hip[4][k].numpy(), v.numpy(), rtol=3e-5, atol=3e-6, err_msg=k)
+
+
+def test_dropout_statistics_and_determinism():
+    model, _ = gu.make_model(0, dropout=0.5)
+    model.train()
+    x = synth.make_input(1, 2, 128).cuda()
+    with torch.no_grad():
+        a = model(x, seed=gu.seed_tensor(7))[0].clone()
+        b = model(x, seed=gu.seed_tensor(7))[0].clone()
+        c = model(x, seed=gu.seed_tensor(8))[0].clone()
+        d1 = model(x)[0].clone()
+        d2 = model(x)[0].clone()
+    assert torch.equal(a, b)
+    assert not torch.equal(a, c) and not torch.equal(d1, d2)
+
+
+def test_mt_loss_kernel_vs_oracle():
+    from dcase2019_task4_amd import _lib
+    from dcase2019_task4_amd.train import MeanTeacherStep
+    B, T = 8, 128
+    student, _ = gu.make_model(0, dropout=0)
+    teacher, _ = gu.make_model(1, dropout=0)
+    tgt, wm, sm = synth.make_target(3, B, T // 8)
+    st = MeanTeacherStep(student, teacher, B, T, 150, wm, sm, use_graph=False)
+    rs = np.random.RandomState(5)
+    for name in ("strong", "strong_ema"):
+        getattr(st, name).copy_(torch.tensor(rs.uniform(0.02, 0.98, (B, T // 8, 10)), dtype=torch.float32))
+    for name in ("weak", "weak_ema"):
+        getattr(st, name).copy_(torch.tensor(rs.uniform(0.02, 0.98, (B, 10)), dtype=torch.float32))
+    st.target.copy_(tgt)
+    _lib.check(st.l.sed_mt_loss(C.byref(st.dims), _lib.ptr(st.strong), _lib.ptr(st.weak), _lib.ptr(st.strong_ema),
+                                _lib.ptr(st.weak_ema), _lib.ptr(st.target), st.wlo, st.whi, st.slo, st.shi,
+                                _lib.ptr(st.state), _lib.ptr(st.losses), _lib.ptr(st.d_strong), _lib.ptr(st.d_weak),
+                                _lib.stream_ptr()), "sed_mt_loss")
+    s = st.strong.cpu().requires_grad_(True)
+    w = st.weak.cpu().requires_grad_(True)
+    cw = ref_cpu.consistency_weight(0, 150)
+    loss, meters = ref_cpu.mean_teacher_loss(s, w, st.strong_ema.cpu(), st.weak_ema.cpu(), tgt, wm, sm, cw)
+    ds, dw = torch.autograd.grad(loss, [s, w])
+    m = st.meters()
+    for k in ("loss", "weak_class_loss", "strong_loss", "cons_strong", "cons_weak", "weak_ema_loss", "strong_ema_loss"):
+        assert m[k] == pytest.approx(float(meters[k]), rel=2e-5, abs=1e-9), k
+    assert m["cons_weight"] == pytest.approx(cw, rel=1e-6)
+    np.testing.assert_allclose(st.d_strong.cpu().numpy(), ds.numpy(), rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(st.d_weak.cpu().numpy(), dw.numpy(), rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_three_fused_steps_vs_real_main_train_goldens(golden_dir, use_graph):
+    """G5: three steps of the REAL baseline/main.py train() (B=8, dropout 0): meters, student and
+    EMA-teacher parameters, BN buffers - against the fused MeanTeacherStep (eager and hipGraph)."""
+    from dcase2019_task4_amd.train import MeanTeacherStep
+    g = _golden(golden_dir, "g5_train3.npz")
+    B, T = 8, 628
+    student, _ = gu.make_model(0, dropout=0)
+    teacher, _ = gu.make_model(1, dropout=0)
+    student.train(); teacher.train()
+    _, wm, sm = synth.make_target(0, B, T // 8)
+    st = MeanTeacherStep(student, teacher, B, T, 3 * 100 // 2, wm, sm, use_graph=use_graph)
+    if use_graph:
+        st._warm = 2                # capture on the very first step so all three run as graph replays
+    key = {"weak_class_loss": "meter_weak_class_loss", "weak_ema_loss": "meter_Weak_EMA_loss", "strong_loss": "meter_Strong_loss",
+           "strong_ema_loss": "meter_Strong_EMA_loss", "cons_strong": "meter_Consistency_strong",
+           "cons_weak": "meter_Consistency_weak", "loss": "meter_Loss"}
+    for it in range(3):
+        tgt, _, _ = synth.make_target(it, B, T // 8)
+        st.step(synth.make_input(20 + it, B, T).cuda(), synth.make_input(30 + it, B, T).cuda(), tgt.cuda())
+        m = st.meters()
+        for k, gk in key.items():
+            assert m[k] == pytest.approx(float(g[gk][it]), rel=1e-4, abs=1e-9), (it, k)
+        assert m["cons_weight"] == pytest.approx(float(g["meter_Consistency_weight"][2 * it]), rel=1e-6)
+    state = st.read_state()
+    assert state.global_step == 3 and state.opt_step == 4
+    for (n, p), (_, pe) in zip(student.named_parameters(), teacher.named_parameters()):
+        k = n.replace(".", "_")
+        tol = 1e-2 if (".conv" in n and n.endswith("bias")) else 3e-5     # see tests/test_oracle_golden.py
+        np.testing.assert_allclose(p.detach().flatten()[:16].cpu().numpy(), g["pS_head_" + k], atol=tol, err_msg=n)
+        np.testing.assert_allclose(pe.detach().flatten()[:16].cpu().numpy(), g["pT_head_" + k], atol=tol, err_msg=n)
+        assert float(p.detach().double().sum()) == pytest.approx(float(g["pS_sum_" + k]), abs=tol * p.numel())
+    for tag, mdl in (("bS_", student), ("bT_", teacher)):
+        for k, v in mdl.named_buffers():
+            atol = 1e-2 if k.endswith("running_mean") else 3e-6
+            np.testing.assert_allclose(v.cpu().numpy(), g[tag + k.replace(".", "_")], rtol=3e-5, atol=atol, err_msg=k)
+
+
+def test_fused_step_with_dropout_vs_oracle_trajectory():
+    """Two fused steps with dropout 0.5 against MeanTeacherOracle driven by the same Philox masks
+    (seeds read back from the device step state)."""
+    from dcase2019_task4_amd.train import MeanTeacherStep
+    B, T = 4, 128
+    student, ps = gu.make_model(0, dropout=0.5)
+    teacher, pt = gu.make_model(1, dropout=0.5)
+    student.train(); teacher.train()
+    _, wm, sm = synth.make_target(0, B, T // 8)
+    st = MeanTeacherStep(student, teacher, B, T, 50, wm, sm, use_graph=False, seed=42)
+    mt = ref_cpu.MeanTeacherOracle(ps, pt)
+    for it in range(2):
+        state = st.read_state()
+        x, xe = synth.make_input(50 + it, B, T), synth.make_input(60 + it, B, T)
+        tgt, _, _ = synth.make_target(it, B, T // 8)
+        st.step(x.cuda(), xe.cuda(), tgt.cuda())
+        mo, go, _ = mt.step(x, xe, tgt, wm, sm, 50, gu.oracle_masks(state.seed_student, B, T, 0.5),
+                            gu.oracle_masks(state.seed_teacher, B, T, 0.5))
+        m = st.meters()
+        for k in ("loss", "weak_class_loss", "strong_loss", "weak_ema_loss", "strong_ema_loss"):
+            assert m[k] == pytest.approx(mo[k], rel=2e-4), (it, k)
+        if it == 0:
+            gh = {n: st.grads[o0:o1].view(shp).cpu() for n, (o0, o1, shp) in zip(go.keys(), student._layout)}
+            _check_grads(gh, go)
+    for n, p in student.named_parameters():
+        tol = 1e-2 if (".conv" in n and n.endswith("bias")) else 5e-5
+        np.testing.assert_allclose(p.detach().cpu().numpy(), mt.p[n].detach().numpy(), atol=tol, err_msg=n)
+    for n, p in teacher.named_parameters():
+        tol = 1e-2 if (".conv" in n and n.endswith("bias")) else 5e-5
+        np.testing.assert_allclose(p.detach().cpu().numpy(), mt.pe[n].numpy(), atol=tol, err_msg=n)
+
+
+def test_drop_in_module_path_with_torch_adam_matches_oracle():
+    """The drop-in flow of baseline/main.py:279-290 + train(): module forward/backward through
+    autograd, torch.optim.Adam on the (flat-view) parameters, update_ema_variables."""
+    from dcase2019_task4_amd.train import update_ema_variables
+    B, T = 4, 128
+    student, ps = gu.make_model(0, dropout=0)
+    teacher, pt = gu.make_model(1, dropout=0)
+    for p in teacher.parameters():
+        p.detach_()
+    student.train(); teacher.train()
+    opt = torch.optim.Adam(filter(lambda p: p.requires_grad, student.parameters()), lr=0.001, betas=(0.9, 0.999))
+    mt = ref_cpu.MeanTeacherOracle(ps, pt)
+    _, wm, sm = synth.make_target(0, B, T // 8)
+    bce, mse = torch.nn.BCELoss(), torch.nn.MSELoss()
+    for it in range(2):
+        x, xe = synth.make_input(70 + it, B, T), synth.make_input(80 + it, B, T)
+        tgt, _, _ = synth.make_target(it, B, T // 8)
+        se, we = teacher(xe.cuda())
+        se, we = se.detach(), we.detach()
+        s, w = student(x.cuda())
+        tg = tgt.cuda()
+        cw = ref_cpu.consistency_weight(it, 50)
+        loss = bce(w[wm], tg.max(-2)[0][wm]) + bce(s[sm], tg[sm]) + cw * mse(s, se) + cw * mse(w, we)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        update_ema_variables(student, teacher, 0.999, it + 1)
+        mo, _, _ = mt.step(x, xe, tgt, wm, sm, 50)
+        assert float(loss) == pytest.approx(mo["loss"], rel=1e-4)
+    for n, p in student.named_parameters():
+        tol = 1e-2 if (".conv" in n and n.endswith("bias")) else 5e-5
+        np.testing.assert_allclose(p.detach().cpu().numpy(), mt.p[n].detach().numpy(), atol=tol, err_msg=n)
+    for n, p in teacher.named_parameters():
+        tol = 1e-2 if (".conv" in n and n.endswith("bias")) else 5e-5
+        np.testing.assert_allclose(p.detach().cpu().numpy(), mt.pe[n].numpy(), atol=tol, err_msg=n)
+
+
+def test_checkpoint_roundtrip_reference_format(tmp_path):
+    """state_dict / save / load keep the reference's nested layout (CRNN.py:33-57, TestModel.py:30-36)."""
+    from dcase2019_task4_amd.crnn import CRNN
+    model, _ = gu.make_model(0)
+    model.eval()
+    x = synth.make_input(3, 2, 128).cuda()
+    with torch.no_grad():
+        s0, w0 = model(x)
+    state = {"model": {"kwargs": gu.CRNN_KW, "state_dict": model.state_dict()}}
+    f = tmp_path / "ckpt"
+    torch.save(state, f)
+    st = torch.load(f, weights_only=False)
+    m2 = CRNN(**st["model"]["kwargs"])
+    m2.load(parameters=st["model"]["state_dict"])
+    m2 = m2.cuda().eval()
+    with torch.no_grad():
+        s1, w1 = m2(x)
+    assert torch.equal(s0, s1) and torch.equal(w0, w1)

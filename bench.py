@@ -1,0 +1,243 @@
+"""bench.py - 10-s clips/s of one mean-teacher train step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one synthetic batch already resident in HBM:
+teacher forward + student forward + BCE/MSE losses + student backward (+ gradient all-reduce over
+RCCL when N > 1) + fused Adam + EMA, exactly what baseline/main.py:84-157 does per batch.
+Workload (N=1): BASELINE.json configs[1] - mean-teacher CRNN of baseline/config.py:53-58, batch 24,
+precomputed log-mel [24,1,628,64] fp32 in HBM, dropout 0.5, BatchNorm in train mode for both models.
+N > 1: weak scaling, 24 clips per GPU, each rank keeps the [weak|unlabeled|strong] = [6|12|6]
+composition (main.py:238-247) and the flat gradient buffer is all-reduced once per step.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+B_PER_GPU = 24
+T_FRAMES = 628
+N_MELS = 64
+
+# algorithmic work per clip: forward GEMM-shaped FLOPs and block-boundary bytes
+FWD_FLOP_PER_CLIP = {  # 2 * MACs
+    "conv0": 2 * 64 * 9 * 628 * 64, "glu0": 2 * 64 * 64 * 628 * 64,
+    "conv1": 2 * 64 * 576 * 314 * 16, "glu1": 2 * 64 * 64 * 314 * 16,
+    "conv2": 2 * 64 * 576 * 157 * 4, "glu2": 2 * 64 * 64 * 157 * 4,
+}
+STEP_FLOP_PER_CLIP = 3.432e9      # 4 x forward (teacher fwd + student fwd + 2x for backward)
+STEP_BYTES_PER_CLIP = 12.0e6      # 7 passes over the block-boundary tensors, fp32
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def synthetic_batch(B, T, seed, device):
+    """x ~ N(0,1) (already-normalised log-mel), teacher input = a second draw,
+    targets: rows [0,B/4) weak-style, [B/4,3B/4) unlabeled (-1), [3B/4,B) strong-style."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(B, 1, T, N_MELS, generator=g)
+    xe = x + 0.1 * torch.randn(B, 1, T, N_MELS, generator=g).abs()
+    T3 = T // 8
+    tgt = torch.zeros(B, T3, 10)
+    nw = B // 4
+    tgt[:nw] = (torch.rand(nw, 1, 10, generator=g) < 0.2).float()
+    tgt[nw:B - nw] = -1.0
+    tgt[B - nw:] = (torch.rand(nw, T3, 10, generator=g) < 0.2).float()
+    return x.to(device), xe.to(device), tgt.to(device), slice(nw), slice(B - nw, B)
+
+
+def build_models(device, seed):
+    from dcase2019_task4_amd.crnn import CRNN
+    kw = dict(n_in_channel=1, nclass=10, attention=True, n_RNN_cell=64, n_layers_RNN=2, activation="glu", dropout=0.5,
+              kernel_size=3 * [3], padding=3 * [1], stride=3 * [1], nb_filters=[64, 64, 64], pooling=list(3 * ((2, 4),)))
+    torch.manual_seed(seed)
+    models = []
+    for _ in range(2):
+        m = CRNN(**kw)
+        # weights_init (baseline/utils/utils.py:205-224): random init of the reference architecture
+        for mod in m.modules():
+            name = mod.__class__.__name__
+            if name.find('Conv2d') != -1:
+                torch.nn.init.xavier_uniform_(mod.weight, gain=np.sqrt(2)); mod.bias.data.fill_(0)
+            elif name.find('BatchNorm') != -1:
+                mod.weight.data.normal_(1.0, 0.02); mod.bias.data.fill_(0)
+            elif name.find('GRU') != -1:
+                for w in mod.parameters():
+                    if len(w.size()) > 1:
+                        torch.nn.init.orthogonal_(w.data)
+            elif name.find('Linear') != -1:
+                mod.weight.data.normal_(0, 0.01); mod.bias.data.zero_()
+        models.append(m.to(device).train())
+    return models
+
+
+def cpu_baseline(n_steps=2):
+    """The oracle (oracle/ref_cpu.py, a torch-CPU port of the reference step) on this box's host
+    cores: B=24, T=628, 1 warm-up + n_steps timed steps (a bounded sample: ~10-30 s of CPU work)."""
+    from oracle import ref_cpu, synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B, T = B_PER_GPU, T_FRAMES
+    mt = ref_cpu.MeanTeacherOracle(synth.make_params(0), synth.make_params(1))
+    x, xe, tgt, wm, sm = synthetic_batch(B, T, 0, "cpu")
+
+    def masks(seed):
+        g = torch.Generator().manual_seed(seed)
+        mk = lambda *s: (torch.rand(*s, generator=g) < 0.5).float() * 2.0
+        return {"drop0": mk(B, T, 64, 64), "drop1": mk(B, T // 2, 16, 64), "drop2": mk(B, T // 4, 4, 64),
+                "drop_rnn": mk(B, T // 8, 128)}
+    times = []
+    for it in range(n_steps + 1):
+        t0 = time.perf_counter()
+        mt.step(x, xe, tgt, wm, sm, 10500, masks(2 * it), masks(2 * it + 1))     # mask draw timed like nn.Dropout's
+        times.append(time.perf_counter() - t0)
+    dt = float(np.mean(times[1:]))
+    return {"value": B / dt, "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/ref_cpu.MeanTeacherOracle, B={B} T={T}, 1 warm-up + {n_steps} timed steps, "
+                      f"{dt:.2f} s/step, torch {torch.__version__} CPU threads={torch.get_num_threads()}"}
+
+
+def kernel_roofline(step, iters=20):
+    """HIP-event timing of the dominant kernels, each re-launched on the step's own buffers (same
+    shapes and data as in the timed region) on the current stream."""
+    import ctypes as C
+    from dcase2019_task4_amd import _lib
+    l = _lib.lib()
+    B = step.B
+    px1, px2 = B * 314 * 16, B * 157 * 4
+    algo = {  # name -> (flops, hbm bytes) per launch: algorithmic (reads of inputs + writes of outputs, once each)
+        "conv1_fwd": (B * FWD_FLOP_PER_CLIP["conv1"], 2 * px1 * 64 * 4 + 9 * 4096 * 4),
+        "conv1_dgrad": (B * FWD_FLOP_PER_CLIP["conv1"], 3 * px1 * 64 * 4 + 9 * 4096 * 4),
+        "conv1_wgrad": (B * FWD_FLOP_PER_CLIP["conv1"], 3 * px1 * 64 * 4),
+        "glu1_fwd": (B * FWD_FLOP_PER_CLIP["glu1"], px1 * 64 * 4 + px1 * 8 * 4),
+        "glu1_bwd": (3 * B * FWD_FLOP_PER_CLIP["glu1"], 2 * px1 * 64 * 4 + px1 * 8 * 4),
+        "blk0_fwd": (2 * B * FWD_FLOP_PER_CLIP["conv0"], B * 628 * 64 * 4 + px1 * 64 * 4),
+        "blk0_bwd": (4 * B * FWD_FLOP_PER_CLIP["conv0"], B * 628 * 64 * 4 + px1 * 64 * 4),
+        "conv2_fwd": (B * FWD_FLOP_PER_CLIP["conv2"], 2 * px2 * 64 * 4 + 9 * 4096 * 4),
+        "gru1_fwd": (B * 78 * 2 * 2 * 192 * 64, B * 78 * (384 + 128 + 512) * 4),
+        "gru1_bwd": (B * 78 * 2 * 2 * 192 * 64, B * 78 * (128 + 512 + 384 * 2 + 128) * 4),
+    }
+    out = {}
+    st = _lib.stream_ptr()
+    for name, (fl, by) in algo.items():
+        def call():
+            _lib.check(l.sed_kernel_replay(name.encode(), C.byref(step.dims), _lib.ptr(step.student._flat), _lib.ptr(step.x),
+                                           step._seed_s, _lib.ptr(step.ctx_s), step.ctx_bytes, _lib.ptr(step.grads),
+                                           _lib.ptr(step.ws), step.ws_bytes, st), name)
+        call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        out[name] = {"us": round(us, 2), "tflops": round(fl / us * 1e-6, 2), "gbs": round(by / us * 1e-3, 1)}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=B_PER_GPU)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs a launcher providing WORLD_SIZE={args.gpus} "
+                         "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path is the only product path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        pg = dist.group.WORLD
+
+    from dcase2019_task4_amd.train import MeanTeacherStep
+    B = args.batch
+    student, teacher = build_models(device, seed=0)        # identical replicas on every rank
+    x, xe, tgt, wm, sm = synthetic_batch(B, T_FRAMES, 1000 + rank, device)
+    step = MeanTeacherStep(student, teacher, B, T_FRAMES, rampup_length=210 * 100 // 2, weak_mask=wm, strong_mask=sm,
+                           seed=1234 + rank, use_graph=not args.no_graph, process_group=pg)
+    step.load_batch(x, xe, tgt)
+    for _ in range(max(args.warmup, 3)):       # >= 3: two eager warm-ups + graph capture/first replay
+        step.run()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step.run()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    meters = step.meters()
+    assert np.isfinite(meters["loss"]), meters
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        clips = B * world * args.steps / elapsed
+        t_clip_us = elapsed / args.steps / B * 1e6
+        res = {
+            "metric": "10-s clips/sec mean-teacher train step (64-mel x 628)",
+            "value": round(clips, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "mean-teacher CRNN train step (baseline/main.py config), batch 24 per GPU, "
+                                   "precomputed log-mel [24,1,628,64] fp32 resident in HBM, dropout 0.5",
+                       "global_batch": B * world, "frames": T_FRAMES, "n_mels": N_MELS,
+                       "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
+            "loss": round(meters["loss"], 5),
+        }
+        kr = kernel_roofline(step)
+        dom = max(kr, key=lambda k: kr[k]["us"])
+        res["roofline"] = {
+            "bound": "mfma", "kernel": dom, "achieved": kr[dom]["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(kr[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "avg_launch_us": kr[dom]["us"],
+            "whole_step": {"algorithmic_tflops": round(STEP_FLOP_PER_CLIP / t_clip_us * 1e-6, 2),
+                           "frac_of_f32_mfma_peak": round(STEP_FLOP_PER_CLIP / t_clip_us * 1e-6 / PEAK_F32_MFMA_TFLOPS, 4),
+                           "algorithmic_gbs": round(STEP_BYTES_PER_CLIP / t_clip_us * 1e-3, 1)},
+            "kernels": kr,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -52,6 +52,7 @@ _SIGS = {
     "sed_mel_spec": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_size_t, _P]),
     "sed_logmel_transform": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
     "sed_selftest": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "sed_kernel_replay": (C.c_int, [C.c_char_p, C.POINTER(SedDims), _P, _P, _P, _P, C.c_size_t, _P, _P, C.c_size_t, _P]),
 }
 
 _lib = None

@@ -303,3 +303,64 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
                                  grads + P.bn_b[0], grads + P.glu_w[0], grads + P.glu_b[0], st));
     return SED_OK;
 }
+
+extern "C" int sed_kernel_replay(const char* name, const sed_dims* d, const float* params, const float* x,
+                                 const uint64_t* seed_dev, void* ctx, size_t ctx_bytes, float* grads, void* ws,
+                                 size_t ws_bytes, void* stream) {
+    SED_TRY(sed_validate_dims(d));
+    SED_CHECK_ARG(name && params && x && ctx && grads && ws, "sed_kernel_replay: null argument");
+    const Geo g = make_geo(d);
+    const ParamOff P = make_param_off(g, nullptr);
+    const CtxLayout L = make_ctx_layout(g);
+    const WsLayout W = make_ws_layout(g);
+    if (ctx_bytes < L.total || ws_bytes < W.total) {
+        sed_set_error("sed_kernel_replay: buffers too small");
+        return SED_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int use_drop = (g.p > 0.f) ? 1 : 0;
+    const int BT = g.B * g.T3;
+    const size_t wpk[3] = {0, L.wpk1, L.wpk2}, yo[3] = {0, L.y1, L.y2}, so[3] = {0, L.stat1, L.stat2},
+                 bo[3] = {0, L.bn1, L.bn2}, po[3] = {L.p0, L.p1, L.p2};
+    const size_t dzo[3] = {0, W.dz1, W.dz2}, dpo[3] = {W.dp0, W.dp1, W.dp2};
+    const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};
+    auto is = [&](const char* n) { return strcmp(name, n) == 0; };
+    if (is("blk0_fwd")) {
+        const int tpc = (g.H1 + 3) / 4;
+        (void)tpc;
+        return launch_blk0_forward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
+                                   params + P.glu_w[0], params + P.glu_b[0], WSF(W.coef), WSF(W.coef) + 64, nullptr, 1, 0,
+                                   seed_dev, CTXD(L.mom0), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), CTXF(L.p0), st);
+    }
+    for (int i = 1; i <= 2; ++i) {
+        char nm[32];
+        snprintf(nm, sizeof nm, "conv%d_fwd", i);
+        if (is(nm)) return launch_conv_fwd(CTXF(po[i - 1]), CTXF(wpk[i]), params + P.conv_b[i], CTXF(yo[i]), CTXD(so[i]), g.B, Hs[i], Wd[i], st);
+        snprintf(nm, sizeof nm, "glu%d_fwd", i);
+        if (is(nm)) return launch_glu_pool_fwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], CTXF(po[i]), g.B, Hs[i], Wd[i], i, use_drop, g.p, seed_dev, st);
+        snprintf(nm, sizeof nm, "glu%d_bwd", i);
+        if (is(nm)) return launch_glu_pool_bwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], WSF(dpo[i]), WSF(dzo[i]), WSD(W.gluacc), g.B, Hs[i], Wd[i], i, use_drop, g.p, seed_dev, st);
+        snprintf(nm, sizeof nm, "conv%d_wgrad", i);
+        if (is(nm)) return launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef), CTXF(po[i - 1]), WSF(W.wg_part), W.wgrad_blocks, grads + P.conv_w[i], g.B, Hs[i], Wd[i], st);
+        snprintf(nm, sizeof nm, "conv%d_dgrad", i);
+        if (is(nm)) return launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef), WSF(W.wpkT), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], st);
+    }
+    for (int l = 0; l < g.L; ++l) {
+        char nm[32];
+        snprintf(nm, sizeof nm, "gru%d_fwd", l);
+        if (is(nm)) return launch_gru_fwd(CTXF(L.gi[l]), params + P.w_hh[l][0], params + P.w_hh[l][1], params + P.b_hh[l][0], params + P.b_hh[l][1], CTXF(L.out[l]), CTXF(L.gates[l]), g.B, g.T3, st);
+        snprintf(nm, sizeof nm, "gru%d_bwd", l);
+        if (is(nm)) return launch_gru_bwd(l == g.L - 1 ? WSF(W.d_out) : WSF(W.d_in), CTXF(L.out[l]), CTXF(L.gates[l]), params + P.w_hh[l][0], params + P.w_hh[l][1], WSF(W.dgi), WSF(W.dgh), WSF(W.hprev), g.B, g.T3, st);
+    }
+    if (is("heads_fwd"))
+        return launch_heads_fwd(CTXF(L.out[g.L - 1]), params + P.dense_w, params + P.dense_b, params + P.soft_w, params + P.soft_b,
+                                CTXF(L.strong_sv), CTXF(L.weak_sv), CTXF(L.logits_s), CTXF(L.den_sv), g.B, g.T3, g.NC, use_drop, g.p, seed_dev, st);
+    if (is("blk0_bwd"))
+        return launch_blk0_backward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
+                                    params + P.glu_w[0], seed_dev, CTXD(L.mom0), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), WSF(W.dp0),
+                                    WSD(W.de0), grads + P.conv_w[0], grads + P.conv_b[0], grads + P.bn_g[0], grads + P.bn_b[0],
+                                    grads + P.glu_w[0], grads + P.glu_b[0], st);
+    (void)BT;
+    sed_set_error("sed_kernel_replay: unknown kernel '%s'", name);
+    return SED_ERR_BAD_ARG;
+}

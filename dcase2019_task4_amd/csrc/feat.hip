@@ -123,8 +123,8 @@ __device__ __forceinline__ double amp_db(double a) {
 }
 
 __global__ __launch_bounds__(256) void k_logmel_transform(const float* __restrict__ mel, int frames, int n_mels,
-                                                           int max_frames, const float* __restrict__ mean,
-                                                           const float* __restrict__ stdv,
+                                                           int max_frames, const double* __restrict__ mean,
+                                                           const double* __restrict__ stdv,
                                                            const uint64_t* __restrict__ seed_ptr,
                                                            float* __restrict__ out_clean, float* __restrict__ out_noisy) {
     __shared__ double red[2][4];
@@ -154,8 +154,8 @@ __global__ __launch_bounds__(256) void k_logmel_transform(const float* __restric
             if (out_noisy) vn = (float)fmax(amp_db((double)src[e] + teacher_noise((uint32_t)(clip * n + e), seed)), floor_n);
         }
         if (mean) {                                             // Scaler.normalize in float64, torch.Tensor() -> fp32
-            vc = (float)(((double)vc - (double)mean[m]) / (double)stdv[m]);
-            vn = (float)(((double)vn - (double)mean[m]) / (double)stdv[m]);
+            vc = (float)(((double)vc - mean[m]) / stdv[m]);
+            vn = (float)(((double)vn - mean[m]) / stdv[m]);
         }
         out_clean[(size_t)clip * n_out + e] = vc;
         if (out_noisy) out_noisy[(size_t)clip * n_out + e] = vn;
@@ -192,7 +192,7 @@ extern "C" int sed_mel_spec(const float* wave, int n_clips, int n_samples, int h
 }
 
 extern "C" int sed_logmel_transform(const float* mel, int n_clips, int frames, int n_mels, int max_frames,
-                                    const float* mean, const float* std, const uint64_t* seed_dev, float* out_clean,
+                                    const double* mean, const double* std, const uint64_t* seed_dev, float* out_clean,
                                     float* out_noisy, void* stream) {
     SED_CHECK_ARG(mel && out_clean, "sed_logmel_transform: null argument");
     SED_CHECK_ARG((mean == nullptr) == (std == nullptr), "sed_logmel_transform: mean and std go together");

@@ -1,0 +1,203 @@
+"""Feature front-end on MI355X - host-side mirror of the reference's feature interfaces.
+
+* ``FeatureExtractor.calculate_mel_spec(audio)`` keeps the signature of
+  ``DatasetDcase2019Task4.calculate_mel_spec`` (baseline/DatasetDcase2019Task4.py:197-231):
+  numpy waveform in, float32 ``[frames, n_mels]`` linear-mel out; ``calculate_mel_spec_batch`` is the
+  same for a batch of clips resident on the GPU.  The STFT + mel projection run in
+  ``sed_mel_spec`` (csrc/feat.hip).
+* ``LogMelTransform`` is the batched GPU form of ``get_transforms(frames, scaler, augment_type)``
+  (baseline/utils/utils.py:397-412): [teacher noise] -> amplitude_to_db -> pad/trunc -> channel
+  axis -> normalise, in ``sed_logmel_transform``.
+* ``Scaler`` mirrors baseline/utils/Scaler.py (statistics pass stays in numpy: it is a one-off
+  reduction before training).
+
+The mel filterbank and the Hamming window are built on the host at construction time exactly as
+librosa / numpy do (float64 math, float32 filterbank); they are inputs of the kernel, not part of
+the per-clip work.
+"""
+import ctypes as C
+import json
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+@dataclass
+class FeatureConfig:
+    """baseline/config.py:17-25 (defaults = the reference's 44.1 kHz setting)."""
+    sample_rate: int = 44100
+    n_window: int = 2048
+    hop_length: int = 511
+    n_mels: int = 64
+    max_len_seconds: float = 10.0
+    f_min: float = 0.0
+    f_max: float = 22050.0
+
+    @property
+    def max_frames(self):
+        return math.ceil(self.max_len_seconds * self.sample_rate / self.hop_length)
+
+    @classmethod
+    def baseline_16k(cls):
+        """The 16 kHz / hop 255 setting behind BASELINE.json's 64-mel x 628-frame shape."""
+        return cls(sample_rate=16000, n_window=2048, hop_length=255, n_mels=64, f_min=0.0, f_max=8000.0)
+
+
+def _hz_to_mel(f):
+    f = np.asarray(f, dtype=np.float64)
+    lin = f / (200.0 / 3)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        log = 15.0 + np.log(np.maximum(f, 1e-30) / 1000.0) / (np.log(6.4) / 27.0)
+    return np.where(f >= 1000.0, log, lin)
+
+
+def _mel_to_hz(m):
+    m = np.asarray(m, dtype=np.float64)
+    lin = (200.0 / 3) * m
+    log = 1000.0 * np.exp((np.log(6.4) / 27.0) * (m - 15.0))
+    return np.where(m >= 15.0, log, lin)
+
+
+def mel_filterbank(sr, n_fft, n_mels, fmin, fmax):
+    """Slaney-scale triangular filterbank, peak 1 (librosa.filters.mel(htk=False, norm=None)),
+    float32 [n_mels, 1 + n_fft//2]."""
+    freqs = np.linspace(0.0, sr / 2.0, 1 + n_fft // 2)
+    pts = _mel_to_hz(np.linspace(_hz_to_mel(fmin), _hz_to_mel(fmax), n_mels + 2))
+    width = np.diff(pts)
+    ramps = pts[:, None] - freqs[None, :]
+    fb = np.zeros((n_mels, 1 + n_fft // 2))
+    for i in range(n_mels):
+        fb[i] = np.maximum(0.0, np.minimum(-ramps[i] / width[i], ramps[i + 2] / width[i + 1]))
+    return fb.astype(np.float32)
+
+
+class FeatureExtractor:
+    """GPU feature extractor with the reference's calculate_mel_spec call signature."""
+
+    def __init__(self, cfg=None, device="cuda", save_log_feature=False):
+        self.cfg = cfg or FeatureConfig()
+        if self.cfg.n_window != 2048:
+            raise NotImplementedError("hot path implements n_window = 2048 (config.py:18)")
+        if save_log_feature:
+            raise NotImplementedError("main.py stores linear features (save_log_feature=False, main.py:199-201); "
+                                      "the log is applied by LogMelTransform")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.SedError("FeatureExtractor needs a GPU device (no CPU fallback)")
+        c = self.cfg
+        self.mel_basis = torch.tensor(mel_filterbank(c.sample_rate, c.n_window, c.n_mels, c.f_min, c.f_max), device=self.device)
+        self.window = torch.tensor(np.hamming(c.n_window).astype(np.float32), device=self.device)
+        self._ws = None
+
+    def n_frames(self, n_samples):
+        return 1 + n_samples // self.cfg.hop_length
+
+    def calculate_mel_spec_batch(self, waves, exact_window=True):
+        """waves: float tensor [n_clips, n_samples] (any device) -> float32 cuda [n_clips, frames, n_mels]."""
+        l = _lib.lib()
+        c = self.cfg
+        waves = torch.as_tensor(waves).to(self.device, torch.float32).contiguous()
+        if waves.dim() == 1:
+            waves = waves[None]
+        n, ns = waves.shape
+        frames = self.n_frames(ns)
+        need = l.sed_mel_spec_ws_bytes(n, ns, c.hop_length, c.n_window, c.n_mels)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, device=self.device, dtype=torch.uint8)
+        out = torch.empty(n, frames, c.n_mels, device=self.device, dtype=torch.float32)
+        # window=None -> the kernel builds np.hamming(2048) itself in float64 (what librosa multiplies by)
+        _lib.check(l.sed_mel_spec(_lib.ptr(waves), n, ns, c.hop_length, c.n_window,
+                                  None if exact_window else _lib.ptr(self.window), _lib.ptr(self.mel_basis), c.n_mels,
+                                  _lib.ptr(out), _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr()), "sed_mel_spec")
+        return out
+
+    def calculate_mel_spec(self, audio):
+        """DatasetDcase2019Task4.calculate_mel_spec(audio) -> np.ndarray float32 [frames, n_mels]."""
+        out = self.calculate_mel_spec_batch(torch.as_tensor(np.asarray(audio, dtype=np.float32))[None])
+        return out[0].cpu().numpy()
+
+
+class Scaler:
+    """baseline/utils/Scaler.py: per-mel mean / mean-of-square in float64 over a dataset."""
+
+    def __init__(self):
+        self.mean_ = None
+        self.mean_of_square_ = None
+        self.std_ = None
+
+    def calculate_scaler(self, dataset):
+        n = 0
+        for sample in dataset:
+            x = sample[0] if isinstance(sample, (tuple, list)) and len(sample) == 2 else sample
+            a = x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+            m, q = a, a ** 2
+            while m.ndim != 1:
+                m = np.mean(m, axis=0, dtype=np.float64)
+                q = np.mean(q, axis=0, dtype=np.float64)
+            self.mean_ = m if self.mean_ is None else self.mean_ + m
+            self.mean_of_square_ = q if self.mean_of_square_ is None else self.mean_of_square_ + q
+            n += 1
+        self.mean_ = self.mean_ / n
+        self.mean_of_square_ = self.mean_of_square_ / n
+        self.std_ = np.sqrt(self.mean_of_square_ - self.mean_ ** 2)
+        return self.mean_, self.std_
+
+    def normalize(self, batch):
+        if torch.is_tensor(batch):
+            return torch.Tensor((batch.cpu().numpy() - self.mean_) / self.std_)
+        return (batch - self.mean_) / self.std_
+
+    def state_dict(self):
+        return {"mean_": self.mean_.tolist(), "mean_of_square_": self.mean_of_square_.tolist()}
+
+    def load_state_dict(self, sd):
+        self.mean_ = np.array(sd["mean_"])
+        self.mean_of_square_ = np.array(sd["mean_of_square_"])
+        self.std_ = np.sqrt(self.mean_of_square_ - self.mean_ ** 2)
+
+    def save(self, path):
+        with open(path, "w") as f:
+            json.dump(self.state_dict(), f)
+
+    def load(self, path):
+        with open(path) as f:
+            self.load_state_dict(json.load(f))
+
+
+class LogMelTransform:
+    """Batched GPU form of get_transforms(frames, scaler, add_axis_conv=True, augment_type)."""
+
+    def __init__(self, frames, scaler=None, augment_type=None, device="cuda", seed=0):
+        if augment_type not in (None, "noise"):
+            raise NotImplementedError("only augment_type='noise' exists (utils.py:404-406)")
+        self.frames = int(frames)
+        self.noise = augment_type == "noise"
+        self.device = torch.device(device)
+        self.mean = self.std = None
+        if scaler is not None:
+            self.mean = torch.tensor(np.asarray(scaler.mean_), dtype=torch.float64, device=self.device)
+            self.std = torch.tensor(np.asarray(scaler.std_), dtype=torch.float64, device=self.device)
+        self._seed = int(seed)
+        self._calls = 0
+
+    def __call__(self, mel, seed=None):
+        """mel: float32 cuda [n_clips, frames, n_mels] linear mel -> clean [n,1,T,n_mels] (, noisy)."""
+        l = _lib.lib()
+        mel = mel.to(self.device, torch.float32).contiguous()
+        n, fr, nm = mel.shape
+        clean = torch.empty(n, 1, self.frames, nm, device=self.device, dtype=torch.float32)
+        noisy = torch.empty_like(clean) if self.noise else None
+        seed_t = None
+        if self.noise:
+            if seed is None:
+                self._calls += 1
+                seed = (self._seed * 0x9E3779B97F4A7C15 + self._calls) & 0x7FFFFFFFFFFFFFFF
+            seed_t = torch.tensor([seed], dtype=torch.int64, device=self.device)
+        _lib.check(l.sed_logmel_transform(_lib.ptr(mel), n, fr, nm, self.frames, _lib.ptr(self.mean), _lib.ptr(self.std),
+                                          _lib.ptr(seed_t), _lib.ptr(clean), _lib.ptr(noisy), _lib.stream_ptr()),
+                   "sed_logmel_transform")
+        return (clean, noisy) if self.noise else clean

@@ -163,12 +163,24 @@ int sed_mel_spec(const float* wave, int n_clips, int n_samples, int hop, int n_f
  * 1e-5, top_db 80 per clip) -> PadOrTrunc(max_frames) -> ToTensor -> Normalize(scaler)
  * (DataLoad.py:262-287,189-207,210-259,290-321,324-350; Scaler.normalize Scaler.py:99-105).
  *   mel     [n_clips][frames][n_mels] linear mel
- *   mean/std  [n_mels] or NULL (no Normalize)
+ *   mean/std  [n_mels] float64 (Scaler.mean_/std_ are float64) or NULL (no Normalize)
  *   out_clean [n_clips][max_frames][n_mels]; out_noisy same or NULL (no augmentation)
  *   seed_dev  Philox key for the teacher noise |N(0, 0.25)| (DataLoad.py:285)                 */
 int sed_logmel_transform(const float* mel, int n_clips, int frames, int n_mels, int max_frames,
-                         const float* mean, const float* std, const uint64_t* seed_dev,
+                         const double* mean, const double* std, const uint64_t* seed_dev,
                          float* out_clean, float* out_noisy, void* stream);
+
+/* ---- single-kernel replay (measurement) ----------------------------------------------------
+ * Re-launches ONE kernel of the step on the buffers left by a finished sed_crnn_forward +
+ * sed_crnn_backward (same shapes, same data; outputs are rewritten with identical values), so
+ * that a caller can bracket it with HIP events on `stream` (bench.py's roofline leg) and so that
+ * tests can exercise one kernel at a time.  name is one of
+ *   "blk0_fwd" "conv1_fwd" "glu1_fwd" "conv2_fwd" "glu2_fwd" "gru0_fwd" "gru1_fwd" "heads_fwd"
+ *   "heads_bwd" "gru1_bwd" "gru0_bwd" "glu2_bwd" "conv2_wgrad" "conv2_dgrad" "glu1_bwd"
+ *   "conv1_wgrad" "conv1_dgrad" "blk0_bwd". */
+int sed_kernel_replay(const char* name, const sed_dims* d, const float* params, const float* x,
+                      const uint64_t* seed_dev, void* ctx, size_t ctx_bytes, float* grads, void* ws,
+                      size_t ws_bytes, void* stream);
 
 /* ---- self tests (run on the GPU box by tests/) ---------------------------------------------
  * Checks the MFMA fragment mapping and Philox stream this build assumes. out[0..3] receives

@@ -1,0 +1,82 @@
+"""-m gpu parity of the feature front-end (csrc/feat.hip through the C-ABI) against the numpy oracle.
+Tolerances: linear mel relative 1e-6 of the clip maximum (fp64 FFT, fp32 output rounding); dB-domain
+features 1e-4 dB before normalisation."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import features_np, philox, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("cfg_name,n_samples", [("16k", 160000), ("44k", 441000), ("16k", 40001)])
+def test_mel_spec_vs_oracle(cfg_name, n_samples):
+    from dcase2019_task4_amd.features import FeatureConfig, FeatureExtractor
+    cfg = FeatureConfig.baseline_16k() if cfg_name == "16k" else FeatureConfig()
+    fe = FeatureExtractor(cfg)
+    waves = np.stack([synth.make_wave(i, n_samples) for i in range(2)]).astype(np.float32)
+    got = fe.calculate_mel_spec_batch(torch.tensor(waves)).cpu().numpy()
+    frames = 1 + n_samples // cfg.hop_length
+    assert got.shape == (2, frames, 64)
+    if n_samples == 160000:
+        assert frames == 628
+    if n_samples == 441000:
+        assert frames == 864 == cfg.max_frames
+    for i in range(2):
+        want = features_np.calculate_mel_spec(waves[i].astype(np.float64), cfg.sample_rate, cfg.n_window, cfg.hop_length,
+                                              cfg.n_mels, cfg.f_min, cfg.f_max)
+        err = np.abs(got[i] - want).max()
+        print(f"[feat] {cfg_name} clip {i}: max|err| {err:.3e}  max {want.max():.3e}")
+        np.testing.assert_allclose(got[i], want, rtol=2e-6, atol=1e-6 * want.max())
+    single = fe.calculate_mel_spec(waves[0])          # reference call signature: ndarray in, ndarray out
+    assert single.dtype == np.float32 and single.shape == (frames, 64)
+    np.testing.assert_array_equal(single, got[0])
+
+
+def test_mel_basis_matches_oracle():
+    from dcase2019_task4_amd.features import mel_filterbank
+    for sr, fmax in ((16000, 8000.0), (44100, 22050.0)):
+        np.testing.assert_array_equal(mel_filterbank(sr, 2048, 64, 0.0, fmax), features_np.mel_filterbank(sr, 2048, 64, 0.0, fmax))
+
+
+@pytest.mark.parametrize("frames", [628, 600, 650])
+def test_logmel_transform_vs_oracle(frames):
+    """noise -> dB (per-clip top_db clamp) -> pad/trunc to 628 -> normalise, student and teacher copies."""
+    from dcase2019_task4_amd.features import LogMelTransform, Scaler
+    rs = np.random.RandomState(11)
+    n = 3
+    mel = (np.abs(rs.standard_normal((n, frames, 64))) * 3.0).astype(np.float32)
+    mel[0, 5, :] *= 1e-7                     # exercises the amin floor / top_db clamp
+    sc = Scaler()
+    sc.calculate_scaler([features_np.transform_chain(m, 628) for m in mel])
+    seed = 987654321
+    tr = LogMelTransform(628, sc, augment_type="noise")
+    clean, noisy = tr(torch.tensor(mel).cuda(), seed=seed)
+    noise = philox.teacher_noise(seed, n, frames, 64)
+    for i in range(n):
+        wc, wn = features_np.transform_chain(mel[i], 628, sc.mean_, sc.std_, noise[i].astype(np.float64))
+        ec = np.abs(clean[i].cpu().numpy() - wc).max()
+        en = np.abs(noisy[i].cpu().numpy() - wn).max()
+        print(f"[feat] transform clip {i}: clean err {ec:.3e} noisy err {en:.3e}")
+        np.testing.assert_allclose(clean[i].cpu().numpy(), wc, atol=2e-5)
+        np.testing.assert_allclose(noisy[i].cpu().numpy(), wn, atol=2e-5)
+    valid = LogMelTransform(628, sc)(torch.tensor(mel).cuda())
+    np.testing.assert_allclose(valid.cpu().numpy(), clean.cpu().numpy(), atol=0)
+    raw = LogMelTransform(628)(torch.tensor(mel).cuda())
+    np.testing.assert_allclose(raw[0].cpu().numpy(), features_np.transform_chain(mel[0], 628), atol=2e-5)
+    assert clean.shape == (n, 1, 628, 64)
+
+
+def test_waveform_to_posteriors_pipeline_runs():
+    """raw 16 kHz waveform -> mel -> log/normalise -> CRNN eval posteriors, all on the GPU."""
+    from dcase2019_task4_amd.features import FeatureConfig, FeatureExtractor, LogMelTransform
+    from tests import gpu_util as gu
+    fe = FeatureExtractor(FeatureConfig.baseline_16k())
+    waves = torch.tensor(np.stack([synth.make_wave(i, 160000) for i in range(2)]).astype(np.float32))
+    x = LogMelTransform(628)(fe.calculate_mel_spec_batch(waves))
+    model, _ = gu.make_model(0)
+    model.eval()
+    with torch.no_grad():
+        s, w = model(x)
+    assert s.shape == (2, 78, 10) and torch.isfinite(s).all() and torch.isfinite(w).all()

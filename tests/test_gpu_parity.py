@@ -139,8 +139,8 @@ def _check_grads(g_hip, go):
     return worst
 
 
-@pytest.mark.parametrize("B,T,p,n_layers", [(4, 128, 0.0, 2), (4, 128, 0.5, 2), (2, 628, 0.5, 2), (3, 216, 0.5, 1),
-                                            (2, 150, 0.25, 2)])
+@pytest.mark.parametrize("B,T,p,n_layers", [(4, 128, 0.0, 2), (4, 128, 0.5, 2), (4, 628, 0.5, 2), (5, 216, 0.5, 1),
+                                            (4, 150, 0.25, 2)])
 def test_train_forward_backward_vs_oracle(B, T, p, n_layers):
     """Posteriors, loss, every parameter gradient and the BN running stats against the oracle, with
     dropout ON (same Philox masks on both sides).  T=150 exercises odd H (rows dropped by the pool)."""

@@ -127,7 +127,7 @@ class _CRNNFunction(torch.autograd.Function):
         ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
         _lib.check(l.sed_crnn_backward(C.byref(dims), _lib.ptr(module._flat), _lib.ptr(x), _lib.ptr(ctx.seed_t),
                                        _lib.ptr(ctx.cbuf), ctx.cbuf.numel(), _lib.ptr(d_strong), _lib.ptr(d_weak),
-                                       _lib.ptr(gflat), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),
+                                       _lib.ptr(gflat), _lib.ptr(ws), ws_bytes, 3, _lib.stream_ptr()),
                    "sed_crnn_backward")
         grads = []
         for i, (o0, o1, shp) in enumerate(module._layout):

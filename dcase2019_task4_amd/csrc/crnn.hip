@@ -227,9 +227,10 @@ extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* b
 
 extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const float* x, const uint64_t* seed_dev,
                                  void* ctx, size_t ctx_bytes, const float* d_strong, const float* d_weak, float* grads,
-                                 void* ws, size_t ws_bytes, void* stream) {
+                                 void* ws, size_t ws_bytes, int parts, void* stream) {
     SED_TRY(sed_validate_dims(d));
     SED_CHECK_ARG(params && x && ctx && d_strong && d_weak && grads && ws, "sed_crnn_backward: null argument");
+    SED_CHECK_ARG(parts >= 1 && parts <= 3, "sed_crnn_backward: parts must be 1, 2 or 3");
     const Geo g = make_geo(d);
     const ParamOff P = make_param_off(g, nullptr);
     const CtxLayout L = make_ctx_layout(g);
@@ -243,6 +244,7 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
     hipStream_t st = (hipStream_t)stream;
     const int BT = g.B * g.T3;
 
+    if (parts & 1) {
     // ---- heads ----------------------------------------------------------------------------------
     const float* h_last = CTXF(L.out[g.L - 1]);
     SED_TRY(launch_heads_bwd(h_last, params + P.dense_w, params + P.soft_w, CTXF(L.strong_sv), CTXF(L.weak_sv),
@@ -280,6 +282,8 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
         }
         d_cur = d_in;
     }
+    }
+    if (!(parts & 2)) return SED_OK;
     // ---- conv blocks 2, 1 -----------------------------------------------------------------------
     const size_t wpk[3] = {0, L.wpk1, L.wpk2}, yo[3] = {0, L.y1, L.y2}, bo[3] = {0, L.bn1, L.bn2};
     const size_t pin[3] = {0, L.p0, L.p1};

@@ -19,6 +19,7 @@ import time
 import torch
 
 from . import _lib
+from . import dist as sdist
 from .crnn import CRNN
 
 LOSS_NAMES = ("loss", "weak_class_loss", "strong_loss", "cons_strong", "cons_weak", "weak_ema_loss",
@@ -101,11 +102,15 @@ class MeanTeacherStep:
         if process_group is not None:
             import torch.distributed as dist
             self.world = dist.get_world_size(process_group)
+            # replicas must start identical (the reference has one copy; DDP convention: rank 0 wins)
+            sdist.broadcast_parameters([student._flat, teacher._flat], process_group)
         self.use_graph = bool(use_graph)
         self.overlap = bool(overlap_streams)
         self._side = torch.cuda.Stream(device=dev) if self.overlap else None
         self._graph_a = None
+        self._graph_a2 = None
         self._graph_b = None
+        self._buckets = sdist.grad_buckets(student._layout)
         self._warm = 0
         self.steps_done = 0
 
@@ -134,10 +139,15 @@ class MeanTeacherStep:
                                       self.wlo, self.whi, self.slo, self.shi, _lib.ptr(self.state),
                                       _lib.ptr(self.losses), _lib.ptr(self.d_strong), _lib.ptr(self.d_weak),
                                       _lib.stream_ptr()), "sed_mt_loss")
+        self._backward(1)
+        if self.world == 1:
+            self._backward(2)
+
+    def _backward(self, parts):
         _lib.check(self.l.sed_crnn_backward(C.byref(self.dims), _lib.ptr(self.student._flat), _lib.ptr(self.x),
                                             self._seed_s, _lib.ptr(self.ctx_s), self.ctx_bytes,
                                             _lib.ptr(self.d_strong), _lib.ptr(self.d_weak), _lib.ptr(self.grads),
-                                            _lib.ptr(self.ws), self.ws_bytes, _lib.stream_ptr()), "sed_crnn_backward")
+                                            _lib.ptr(self.ws), self.ws_bytes, parts, _lib.stream_ptr()), "sed_crnn_backward")
 
     def _update(self):
         """Adam (main.py:154) + EMA teacher (:155-157) + step counters, one kernel each."""
@@ -147,10 +157,15 @@ class MeanTeacherStep:
                                        _lib.stream_ptr()), "sed_adam_ema")
         _lib.check(self.l.sed_step_state_advance(_lib.ptr(self.state), _lib.stream_ptr()), "sed_step_state_advance")
 
-    def _allreduce(self):
-        if self.pg is not None and self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.pg)
+    def _allreduce_tail(self):
+        """GRU + heads gradients are complete after backward part 1: start their all-reduce now so it
+        runs over xGMI while the conv-block backward (part 2) is still computing."""
+        (lo, hi), _ = self._buckets
+        return sdist.allreduce_bucket(self.grads, lo, hi, self.pg, async_op=True)
+
+    def _allreduce_head(self):
+        _, (lo, hi) = self._buckets
+        return sdist.allreduce_bucket(self.grads, lo, hi, self.pg, async_op=True)
 
     # ---- public ------------------------------------------------------------------------------------
     def load_batch(self, x, x_ema, target):
@@ -160,20 +175,26 @@ class MeanTeacherStep:
 
     def run(self):
         """One step on the batch currently in self.x / self.x_ema / self.target."""
-        if not self.use_graph or self._warm < 2:
-            self._fwd_bwd()
-            self._allreduce()
-            self._update()
-            self._warm += 1
-        else:
-            if self._graph_a is None:
-                self._capture()
-            if self.world > 1:
+        graph = self.use_graph and self._warm >= 2
+        if graph and self._graph_a is None:
+            self._capture()
+        if self.world == 1:
+            if graph:
                 self._graph_a.replay()
-                self._allreduce()
-                self._graph_b.replay()
             else:
-                self._graph_a.replay()
+                self._fwd_bwd()
+                self._update()
+        else:
+            # forward + loss + backward part 1 | all-reduce(tail) || backward part 2 | all-reduce(head) | update
+            self._graph_a.replay() if graph else self._fwd_bwd()
+            w1 = self._allreduce_tail()
+            self._graph_a2.replay() if graph else self._backward(2)
+            w2 = self._allreduce_head()
+            for w in (w1, w2):
+                if w is not None:
+                    w.wait()
+            self._graph_b.replay() if graph else self._update()
+        self._warm += 1
         self.steps_done += 1
 
     def step(self, x, x_ema, target):
@@ -183,19 +204,21 @@ class MeanTeacherStep:
     def _capture(self):
         torch.cuda.synchronize(self.device)
         if self.world > 1:
-            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            ga, ga2, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga):
                 self._fwd_bwd()
+            with torch.cuda.graph(ga2):
+                self._backward(2)
             with torch.cuda.graph(gb):
                 self._update()
-            # capture executes nothing: the captured step still has to run once via replay
-            self._graph_a, self._graph_b = ga, gb
+            self._graph_a, self._graph_a2, self._graph_b = ga, ga2, gb
         else:
             ga = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga):
                 self._fwd_bwd()
                 self._update()
             self._graph_a = ga
+        # capture executes nothing: the captured work runs on replay
 
     def meters(self):
         """The meters main.train logs (main.py:106-149); ONE device->host copy."""

@@ -104,11 +104,15 @@ int sed_crnn_forward(const sed_dims* d, const float* params, float* bn_running, 
 /* Backward of the above in train mode (autograd of main.py:153 loss.backward()).
  *   d_strong/d_weak  gradients w.r.t. the two outputs
  *   grads            flat, same layout as params; OVERWRITTEN with dLoss/dparams
- *   ws               scratch, sed_crnn_bwd_ws_bytes(d)                                       */
+ *   ws               scratch, sed_crnn_bwd_ws_bytes(d)
+ *   parts            bit 0: heads + BiGRU (writes the rnn/dense tail of grads), bit 1: conv blocks
+ *                    (writes the cnn head of grads; needs bit 0 to have run on the same ws).
+ *                    3 = whole backward.  Splitting lets a data-parallel caller start the
+ *                    all-reduce of the tail bucket while the conv blocks are still running.     */
 size_t sed_crnn_bwd_ws_bytes(const sed_dims* d);
 int sed_crnn_backward(const sed_dims* d, const float* params, const float* x, const uint64_t* seed_dev,
                       void* ctx, size_t ctx_bytes, const float* d_strong, const float* d_weak,
-                      float* grads, void* ws, size_t ws_bytes, void* stream);
+                      float* grads, void* ws, size_t ws_bytes, int parts, void* stream);
 
 /* Debug / test access to intermediates inside ctx: name in {"p0","y1","p1","y2","p2","gru0",
  * "gru1","wz0","mean0","scale1","shift1",...}. Returns 0 and fills offset/bytes, or <0. */

@@ -82,11 +82,27 @@ def build_models(device, seed):
     return models
 
 
-def cpu_baseline(n_steps=2):
+def usable_cores():
+    """Host cores this process may actually use (affinity mask and cgroup CPU quota, not just cpu_count)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(budget_s=45.0, max_steps=3):
     """The oracle (oracle/ref_cpu.py, a torch-CPU port of the reference step) on this box's host
-    cores: B=24, T=628, 1 warm-up + n_steps timed steps (a bounded sample: ~10-30 s of CPU work)."""
+    cores: B=24, T=628, one warm-up step + timed steps until `budget_s` is spent (a bounded sample)."""
     from oracle import ref_cpu, synth
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     B, T = B_PER_GPU, T_FRAMES
     mt = ref_cpu.MeanTeacherOracle(synth.make_params(0), synth.make_params(1))
@@ -98,13 +114,18 @@ def cpu_baseline(n_steps=2):
         return {"drop0": mk(B, T, 64, 64), "drop1": mk(B, T // 2, 16, 64), "drop2": mk(B, T // 4, 4, 64),
                 "drop_rnn": mk(B, T // 8, 128)}
     times = []
-    for it in range(n_steps + 1):
+    t_start = time.perf_counter()
+    for it in range(max_steps + 1):
         t0 = time.perf_counter()
         mt.step(x, xe, tgt, wm, sm, 10500, masks(2 * it), masks(2 * it + 1))     # mask draw timed like nn.Dropout's
         times.append(time.perf_counter() - t0)
-    dt = float(np.mean(times[1:]))
-    return {"value": B / dt, "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/ref_cpu.MeanTeacherOracle, B={B} T={T}, 1 warm-up + {n_steps} timed steps, "
+        print(f"[cpu_baseline] step {it}: {times[-1]:.2f} s ({cores} threads)", file=sys.stderr, flush=True)
+        if it >= 1 and time.perf_counter() - t_start > budget_s:
+            break
+    timed = times[1:] if len(times) > 1 else times
+    dt = float(np.mean(timed))
+    return {"value": round(B / dt, 3), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/ref_cpu.MeanTeacherOracle, B={B} T={T}, 1 warm-up + {len(timed)} timed steps, "
                       f"{dt:.2f} s/step, torch {torch.__version__} CPU threads={torch.get_num_threads()}"}
 
 

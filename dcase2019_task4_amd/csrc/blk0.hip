@@ -25,11 +25,12 @@
 __device__ __forceinline__ int gidx(int a, int b) { return 9 + a * 9 - (a * (a - 1)) / 2 + (b - a); }  // a <= b
 
 // ---- patch moments: s[t] = sum_p P[p][t], G[a][b] = sum_p P[p][a] P[p][b] (upper triangle) ----
+#define MOM_ROWS 64
 __global__ __launch_bounds__(256) void k_x_moments(const float* __restrict__ x, int T, double* __restrict__ mom) {
-    __shared__ float xs[18 * XS_W];
+    __shared__ float xs[(MOM_ROWS + 2) * XS_W];
     __shared__ float red[4][54];
-    const int tid = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * 16;
-    for (int i = tid; i < 18 * XS_W; i += 256) {
+    const int tid = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * MOM_ROWS;
+    for (int i = tid; i < (MOM_ROWS + 2) * XS_W; i += 256) {
         int r = i / XS_W, c = i % XS_W;
         int t = t0 - 1 + r, f = c - 1;
         xs[i] = (t >= 0 && t < T && f >= 0 && f < 64) ? x[((size_t)b * T + t) * 64 + f] : 0.f;
@@ -38,8 +39,7 @@ __global__ __launch_bounds__(256) void k_x_moments(const float* __restrict__ x, 
     float acc[54];
 #pragma unroll
     for (int k = 0; k < 54; ++k) acc[k] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MOM_ROWS / 4; ++i) {
         int pix = tid + 256 * i;
         int r = pix >> 6, c = pix & 63;
         if (t0 + r < T) {
@@ -386,11 +386,11 @@ __global__ __launch_bounds__(64) void k_blk0_bwd_finalize(Blk0BwdFinArgs a) {
 // ---- host launchers -------------------------------------------------------------------------------
 int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const float* b0, const float* gamma,
                         const float* beta, const float* wglu, const float* bglu, float* run_mean, float* run_var,
-                        int64_t* tracked, int train, int update, const uint64_t* seed, double* mom, float* wz,
-                        float* wl, float* bn, float* p0, hipStream_t st) {
+                        int64_t* tracked, int train, int update, const uint64_t* seed, double* mom, int zero_mom,
+                        float* wz, float* wl, float* bn, float* p0, hipStream_t st) {
     if (train) {
-        SED_CHECK_HIP(hipMemsetAsync(mom, 0, 64 * sizeof(double), st));
-        dim3 grid((g.T + 15) / 16, g.B);
+        if (zero_mom) SED_CHECK_HIP(hipMemsetAsync(mom, 0, 64 * sizeof(double), st));
+        dim3 grid((g.T + MOM_ROWS - 1) / MOM_ROWS, g.B);
         k_x_moments<<<grid, 256, 0, st>>>(x, g.T, mom);
         SED_CHECK_LAUNCH();
     }
@@ -410,10 +410,10 @@ int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const flo
 
 int launch_blk0_backward(const Geo& g, const float* x, const float* w0, const float* b0, const float* gamma,
                          const float* beta, const float* wglu, const uint64_t* seed, const double* mom,
-                         const float* wz, const float* wl, const float* bn, const float* dp0, double* de,
+                         const float* wz, const float* wl, const float* bn, const float* dp0, double* de, int zero_de,
                          float* g_w0, float* g_b0, float* g_gamma, float* g_beta, float* g_wglu, float* g_bglu,
                          hipStream_t st) {
-    SED_CHECK_HIP(hipMemsetAsync(de, 0, 2 * 64 * 10 * sizeof(double), st));
+    if (zero_de) SED_CHECK_HIP(hipMemsetAsync(de, 0, 2 * 64 * 10 * sizeof(double), st));
     const int tpc = (g.H1 + 3) / 4, nt = tpc * g.B;
     const int use_drop = (g.p > 0.f) ? 1 : 0;
     k_blk0_bwd<<<nt < 512 ? nt : 512, 256, 0, st>>>(x, wz, wl, dp0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, seed, de);

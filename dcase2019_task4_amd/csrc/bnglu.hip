@@ -336,8 +336,8 @@ int launch_glu_pool_fwd(const float* y, const float* bn, const float* wglu, cons
 }
 
 int launch_glu_pool_bwd(const float* y, const float* bn, const float* wglu, const float* bglu, const float* dp, float* dz,
-                        double* acc, int B, int H, int W, int block_id, int use_drop, float p_drop, const uint64_t* seed,
-                        hipStream_t st) {
+                        double* acc, int zero_acc, int B, int H, int W, int block_id, int use_drop, float p_drop,
+                        const uint64_t* seed, hipStream_t st) {
     const int Ho = H / 2, Wo = W / 4, Q = B * Ho * Wo;
     const size_t lds = (size_t)4 * 3 * 32 * ZS * sizeof(float);
     static bool attr_done = false;
@@ -345,7 +345,7 @@ int launch_glu_pool_bwd(const float* y, const float* bn, const float* wglu, cons
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_glu_pool_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    SED_CHECK_HIP(hipMemsetAsync(acc, 0, GLUACC_N * sizeof(double), st));
+    if (zero_acc) SED_CHECK_HIP(hipMemsetAsync(acc, 0, GLUACC_N * sizeof(double), st));
     if (H & 1) SED_CHECK_HIP(hipMemsetAsync(dz, 0, (size_t)B * H * W * 64 * sizeof(float), st));
     const int n_rb = (Q + 3) / 4;
     int grid = (n_rb + 3) / 4;

@@ -67,7 +67,9 @@ ParamOff make_param_off(const Geo& g, int64_t* offsets_out /* may be null */);
 
 // saved-context layout (byte offsets)
 struct CtxLayout {
+    size_t acc0;                       // mom0 | stat1 | stat2 contiguous (320 doubles, zeroed by ONE memset)
     size_t mom0, wz0, wl0, bn0;        // bn0: mean,invstd,scale,shift [4][64]
+    size_t wpkT1, wpkT2;               // flipped/transposed conv weights for dgrad (train only)
     size_t p0;
     size_t wpk1, y1, stat1, bn1, p1;
     size_t wpk2, y2, stat2, bn2, p2;
@@ -80,12 +82,14 @@ CtxLayout make_ctx_layout(const Geo& g);
 struct WsLayout {
     size_t d_out, dgi, dgh, hprev, d_in, heads_part;
     size_t dz2, dp1, dz1, dp0, dp2;
-    size_t bnb, gluacc, coef, wpkT, wg_part, de0;
+    size_t bwd_acc;                    // gluacc1 | gluacc2 | de0 contiguous doubles, zeroed by ONE memset
+    size_t bnb, gluacc1, gluacc2, coef, wg_part, de0, gemm_part;
     size_t total;
     int wgrad_blocks;
 };
 WsLayout make_ws_layout(const Geo& g);
 #define SED_WGRAD_MAX_BLOCKS 256
+#define SED_GRU_SPLITK 16
 
 // ---- device helpers ------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

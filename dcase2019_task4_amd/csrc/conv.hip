@@ -32,14 +32,20 @@ struct ConvCfg {
     static constexpr size_t LDS_BYTES = (size_t)(HALO_FLOATS + 2 * W_FLOATS) * 4;
 };
 
-__global__ void k_conv_pack(const float* __restrict__ w, float* __restrict__ wpk, float* __restrict__ wpkT) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over [tap][ci][co]
-    if (i >= 9 * 64 * 64) return;
+__global__ void k_conv_pack(const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ wpk1,
+                            float* __restrict__ wpk2, float* __restrict__ wpkT1, float* __restrict__ wpkT2) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;   // over [layer][tap][ci][co]
+    if (i >= 2 * 9 * 64 * 64) return;
+    const int layer = i / (9 * 4096);
+    i -= layer * 9 * 4096;
+    const float* w = layer ? w2 : w1;
+    float* wpk = layer ? wpk2 : wpk1;
+    float* wpkT = layer ? wpkT2 : wpkT1;
     const int tap = i / 4096, ci = (i / 64) % 64, co = i % 64;
     wpk[i] = w[(co * 64 + ci) * 9 + tap];
     if (wpkT) {
-        // wpkT[tap][co'][ci'] with (co' = input channel of the transposed conv = co, ci' = output = ci)
-        const int k = (i / 64) % 64, n = i % 64;      // k = co, n = ci
+        // transposed conv for dgrad: wpkT[tap'][k = co][n = ci] = W[co][ci][8 - tap']
+        const int k = ci, n = co;      // reuse the index split: (i/64)%64 -> k, i%64 -> n
         wpkT[i] = w[(k * 64 + n) * 9 + (8 - tap)];
     }
 }
@@ -246,15 +252,22 @@ __global__ __launch_bounds__(256) void k_conv3x3_wgrad(const float* __restrict__
 __global__ void k_wgrad_reduce(const float* __restrict__ part, int n_blocks, float* __restrict__ g_w) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;    // over [tap][co][ci]
     if (i >= 9 * 4096) return;
-    float s = 0.f;
-    for (int k = 0; k < n_blocks; ++k) s += part[(size_t)k * 9 * 4096 + i];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= n_blocks; k += 4) {
+        s0 += part[(size_t)(k + 0) * 9 * 4096 + i];
+        s1 += part[(size_t)(k + 1) * 9 * 4096 + i];
+        s2 += part[(size_t)(k + 2) * 9 * 4096 + i];
+        s3 += part[(size_t)(k + 3) * 9 * 4096 + i];
+    }
+    for (; k < n_blocks; ++k) s0 += part[(size_t)k * 9 * 4096 + i];
     const int tap = i / 4096, co = (i / 64) % 64, ci = i % 64;
-    g_w[(co * 64 + ci) * 9 + tap] = s;
+    g_w[(co * 64 + ci) * 9 + tap] = (s0 + s1) + (s2 + s3);
 }
 
 // ---- host launchers ---------------------------------------------------------------------------
-int launch_conv_pack(const float* w, float* wpk, float* wpkT, hipStream_t st) {
-    k_conv_pack<<<(9 * 4096 + 255) / 256, 256, 0, st>>>(w, wpk, wpkT);
+int launch_conv_pack(const float* w1, const float* w2, float* wpk1, float* wpk2, float* wpkT1, float* wpkT2, hipStream_t st) {
+    k_conv_pack<<<(2 * 9 * 4096 + 255) / 256, 256, 0, st>>>(w1, w2, wpk1, wpk2, wpkT1, wpkT2);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
@@ -275,9 +288,9 @@ static int conv_launch_t(const float* in0, const float* in1, const float* coef, 
     return SED_OK;
 }
 
-int launch_conv_fwd(const float* in, const float* wpk, const float* bias, float* y, double* stat, int B, int H, int W,
-                    hipStream_t st) {
-    if (stat) SED_CHECK_HIP(hipMemsetAsync(stat, 0, 128 * sizeof(double), st));
+int launch_conv_fwd(const float* in, const float* wpk, const float* bias, float* y, double* stat, int zero_stat, int B,
+                    int H, int W, hipStream_t st) {
+    if (stat && zero_stat) SED_CHECK_HIP(hipMemsetAsync(stat, 0, 128 * sizeof(double), st));
     if (W == 16) return conv_launch_t<16, 0>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st);
     if (W == 4) return conv_launch_t<4, 0>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st);
     sed_set_error("conv: unsupported width %d", W);

@@ -79,11 +79,12 @@ CtxLayout make_ctx_layout(const Geo& g) {
     size_t o = 0;
     auto put = [&](size_t& f, size_t bytes) { f = o; o = al(o + bytes); };
     const size_t n0 = (size_t)g.B * g.H1 * g.W1 * 64, n1 = (size_t)g.B * g.H2 * g.W2 * 64, n2 = (size_t)g.B * g.T3 * 64;
-    put(L.mom0, 64 * sizeof(double));
+    put(L.acc0, 320 * sizeof(double));
+    L.mom0 = L.acc0; L.stat1 = L.acc0 + 64 * sizeof(double); L.stat2 = L.acc0 + 192 * sizeof(double);
     put(L.wz0, 64 * 12 * 4); put(L.wl0, 64 * 12 * 4); put(L.bn0, 256 * 4);
     put(L.p0, n0 * 4);
-    put(L.wpk1, 9 * 4096 * 4); put(L.y1, n0 * 4); put(L.stat1, 128 * sizeof(double)); put(L.bn1, 256 * 4); put(L.p1, n1 * 4);
-    put(L.wpk2, 9 * 4096 * 4); put(L.y2, n1 * 4); put(L.stat2, 128 * sizeof(double)); put(L.bn2, 256 * 4); put(L.p2, n2 * 4);
+    put(L.wpk1, 9 * 4096 * 4); put(L.wpkT1, 9 * 4096 * 4); put(L.y1, n0 * 4); put(L.bn1, 256 * 4); put(L.p1, n1 * 4);
+    put(L.wpk2, 9 * 4096 * 4); put(L.wpkT2, 9 * 4096 * 4); put(L.y2, n1 * 4); put(L.bn2, 256 * 4); put(L.p2, n2 * 4);
     const size_t bt = (size_t)g.B * g.T3;
     for (int l = 0; l < 2; ++l) {
         put(L.gi[l], bt * 384 * 4); put(L.gates[l], bt * 512 * 4); put(L.out[l], bt * 128 * 4);
@@ -102,11 +103,12 @@ WsLayout make_ws_layout(const Geo& g) {
     put(W.d_out, bt * 128 * 4); put(W.dgi, bt * 384 * 4); put(W.dgh, bt * 384 * 4); put(W.hprev, bt * 128 * 4);
     put(W.d_in, bt * 128 * 4); put(W.heads_part, (size_t)g.B * 2 * (g.NC * 128 + g.NC) * 4);
     put(W.dp2, bt * 64 * 4); put(W.dz2, n1 * 4); put(W.dp1, n1 * 4); put(W.dz1, n0 * 4); put(W.dp0, n0 * 4);
-    put(W.bnb, 256 * sizeof(double)); put(W.gluacc, 4288 * sizeof(double)); put(W.coef, 192 * 4);
-    put(W.wpkT, 9 * 4096 * 4);
+    put(W.bnb, 256 * sizeof(double)); put(W.coef, 192 * 4);
+    put(W.bwd_acc, (2 * 4288 + 2 * 64 * 10) * sizeof(double));
+    W.gluacc1 = W.bwd_acc; W.gluacc2 = W.bwd_acc + 4288 * sizeof(double); W.de0 = W.bwd_acc + 2 * 4288 * sizeof(double);
     W.wgrad_blocks = SED_WGRAD_MAX_BLOCKS;
     put(W.wg_part, (size_t)W.wgrad_blocks * 9 * 4096 * 4);
-    put(W.de0, 2 * 64 * 10 * sizeof(double));
+    put(W.gemm_part, gemm_part_floats(4, SED_GRU_SPLITK, 192, 129) * 4);
     W.total = o;
     return W;
 }
@@ -177,18 +179,22 @@ extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* b
     int64_t* trk[3] = {bn_tracked ? bn_tracked + 0 : nullptr, bn_tracked ? bn_tracked + 1 : nullptr,
                        bn_tracked ? bn_tracked + 2 : nullptr};
 
+    // one memset for every fp64 accumulator of the forward (patch moments, BN sums of blocks 1 and 2)
+    if (train) SED_CHECK_HIP(hipMemsetAsync(CTXD(L.acc0), 0, 320 * sizeof(double), st));
+    // conv1 / conv2 weights -> [tap][ci][co] (+ flipped/transposed copies for dgrad), one launch
+    SED_TRY(launch_conv_pack(params + P.conv_w[1], params + P.conv_w[2], CTXF(L.wpk1), CTXF(L.wpk2),
+                             train ? CTXF(L.wpkT1) : nullptr, train ? CTXF(L.wpkT2) : nullptr, st));
     // ---- conv block 0 ---------------------------------------------------------------------------
     SED_TRY(launch_blk0_forward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
                                 params + P.glu_w[0], params + P.glu_b[0], bn_running + 0, bn_running + 64, trk[0], train,
-                                upd, seed_dev, CTXD(L.mom0), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), CTXF(L.p0), st));
+                                upd, seed_dev, CTXD(L.mom0), 0, CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), CTXF(L.p0), st));
     // ---- conv blocks 1, 2 -----------------------------------------------------------------------
     const float* in = CTXF(L.p0);
     const size_t wpk[3] = {0, L.wpk1, L.wpk2}, yo[3] = {0, L.y1, L.y2}, so[3] = {0, L.stat1, L.stat2},
                  bo[3] = {0, L.bn1, L.bn2}, po[3] = {0, L.p1, L.p2};
     const int Hs[3] = {0, g.H1, g.H2}, Ws[3] = {0, g.W1, g.W2};
     for (int i = 1; i <= 2; ++i) {
-        SED_TRY(launch_conv_pack(params + P.conv_w[i], CTXF(wpk[i]), nullptr, st));
-        SED_TRY(launch_conv_fwd(in, CTXF(wpk[i]), params + P.conv_b[i], CTXF(yo[i]), train ? CTXD(so[i]) : nullptr, g.B,
+        SED_TRY(launch_conv_fwd(in, CTXF(wpk[i]), params + P.conv_b[i], CTXF(yo[i]), train ? CTXD(so[i]) : nullptr, 0, g.B,
                                 Hs[i], Ws[i], st));
         SED_TRY(launch_bn_prep(CTXD(so[i]), (double)g.B * Hs[i] * Ws[i], params + P.bn_g[i], params + P.bn_b[i],
                                bn_running + (2 * i) * 64, bn_running + (2 * i + 1) * 64, trk[i], train, upd, g.eps, g.mom,
@@ -201,14 +207,15 @@ extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* b
     const int BT = g.B * g.T3;
     int nin = 64;
     for (int l = 0; l < g.L; ++l) {
-        for (int dir = 0; dir < 2; ++dir) {
-            GemmDesc q;
-            q.A = in; q.sAm = nin; q.sAk = 1;
-            q.B = params + P.w_ih[l][dir]; q.sBk = 1; q.sBn = nin;
-            q.C = CTXF(L.gi[l]) + dir * 192; q.ldc = 384;
-            q.bias = params + P.b_ih[l][dir];
-            q.M = BT; q.N = 192; q.K = nin; q.accumulate = 0;
-            SED_TRY(launch_gemm(q, st));
+        {
+            // gi[:, dir, :] = in @ W_ih[dir]^T + b_ih[dir] for both directions in one launch
+            GemmBatch gb;
+            gb.n_prob = 2; gb.splits = 1; gb.part = nullptr; gb.part_stride = 0;
+            for (int dir = 0; dir < 2; ++dir) {
+                gb.p[dir] = gemm_prob(in, nin, 1, params + P.w_ih[l][dir], 1, nin, CTXF(L.gi[l]) + dir * 192, 384, BT, 192, nin);
+                gb.p[dir].bias = params + P.b_ih[l][dir];
+            }
+            SED_TRY(launch_gemm_batch(gb, st));
         }
         SED_TRY(launch_gru_fwd(CTXF(L.gi[l]), params + P.w_hh[l][0], params + P.w_hh[l][1], params + P.b_hh[l][0],
                                params + P.b_hh[l][1], CTXF(L.out[l]), train ? CTXF(L.gates[l]) : nullptr, g.B, g.T3, st));
@@ -217,11 +224,8 @@ extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* b
     }
     // ---- heads ----------------------------------------------------------------------------------
     SED_TRY(launch_heads_fwd(in, params + P.dense_w, params + P.dense_b, params + P.soft_w, params + P.soft_b, strong, weak,
-                             CTXF(L.logits_s), CTXF(L.den_sv), g.B, g.T3, g.NC, use_drop, g.p, seed_dev, st));
-    if (train) {
-        SED_CHECK_HIP(hipMemcpyAsync(CTXF(L.strong_sv), strong, (size_t)BT * g.NC * 4, hipMemcpyDeviceToDevice, st));
-        SED_CHECK_HIP(hipMemcpyAsync(CTXF(L.weak_sv), weak, (size_t)g.B * g.NC * 4, hipMemcpyDeviceToDevice, st));
-    }
+                             train ? CTXF(L.strong_sv) : nullptr, train ? CTXF(L.weak_sv) : nullptr, CTXF(L.logits_s),
+                             CTXF(L.den_sv), g.B, g.T3, g.NC, use_drop, g.p, seed_dev, st));
     return SED_OK;
 }
 
@@ -259,51 +263,54 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
         float* d_in = (l == 0) ? WSF(W.dp2) : WSF(W.d_in);
         SED_TRY(launch_gru_bwd(d_cur, CTXF(L.out[l]), CTXF(L.gates[l]), params + P.w_hh[l][0], params + P.w_hh[l][1],
                                WSF(W.dgi), WSF(W.dgh), WSF(W.hprev), g.B, g.T3, st));
-        for (int dir = 0; dir < 2; ++dir) {
-            GemmDesc q;
-            // dW_ih[g][i] = sum_bt dgi[bt][g] * input[bt][i]
-            q.A = WSF(W.dgi) + dir * 192; q.sAm = 1; q.sAk = 384;
-            q.B = input; q.sBk = nin; q.sBn = 1;
-            q.C = grads + P.w_ih[l][dir]; q.ldc = nin; q.bias = nullptr;
-            q.M = 192; q.N = nin; q.K = BT; q.accumulate = 0;
-            SED_TRY(launch_gemm(q, st));
-            // dW_hh[g][j] = sum_bt dgh[bt][g] * hprev[bt][j]
-            q.A = WSF(W.dgh) + dir * 192;
-            q.B = WSF(W.hprev) + dir * 64; q.sBk = 128; q.sBn = 1;
-            q.C = grads + P.w_hh[l][dir]; q.ldc = 64; q.N = 64;
-            SED_TRY(launch_gemm(q, st));
-            SED_TRY(launch_colsum(WSF(W.dgi) + dir * 192, BT, 192, 384, grads + P.b_ih[l][dir], st));
-            SED_TRY(launch_colsum(WSF(W.dgh) + dir * 192, BT, 192, 384, grads + P.b_hh[l][dir], st));
-            // d_in[bt][i] (+)= sum_g dgi[bt][g] * W_ih[g][i]
-            q.A = WSF(W.dgi) + dir * 192; q.sAm = 384; q.sAk = 1;
-            q.B = params + P.w_ih[l][dir]; q.sBk = nin; q.sBn = 1;
-            q.C = d_in; q.ldc = nin; q.M = BT; q.N = nin; q.K = 192; q.accumulate = dir;
-            SED_TRY(launch_gemm(q, st));
+        {
+            // weight + bias gradients of both directions: 4 problems, split-K over the B*T/8 rows
+            //   dW_ih[g][i] = sum_bt dgi[bt][g] input[bt][i],  db_ih[g] = sum_bt dgi[bt][g]
+            //   dW_hh[g][j] = sum_bt dgh[bt][g] hprev[bt][j],  db_hh[g] = sum_bt dgh[bt][g]
+            GemmBatch gb;
+            gb.n_prob = 4; gb.splits = SED_GRU_SPLITK; gb.part = WSF(W.gemm_part); gb.part_stride = 0;
+            for (int dir = 0; dir < 2; ++dir) {
+                gb.p[2 * dir] = gemm_prob(WSF(W.dgi) + dir * 192, 1, 384, input, nin, 1, grads + P.w_ih[l][dir], nin, 192, nin, BT);
+                gb.p[2 * dir].Cones = grads + P.b_ih[l][dir];
+                gb.p[2 * dir + 1] = gemm_prob(WSF(W.dgh) + dir * 192, 1, 384, WSF(W.hprev) + dir * 64, 128, 1,
+                                              grads + P.w_hh[l][dir], 64, 192, 64, BT);
+                gb.p[2 * dir + 1].Cones = grads + P.b_hh[l][dir];
+            }
+            SED_TRY(launch_gemm_batch(gb, st));
+        }
+        {
+            // d_in[bt][i] = sum_{dir,g} dgi[bt][dir][g] W_ih[dir][g][i]   (K = 384 = both directions)
+            GemmBatch gb;
+            gb.n_prob = 1; gb.splits = 1; gb.part = nullptr; gb.part_stride = 0;
+            gb.p[0] = gemm_prob(WSF(W.dgi), 384, 1, params + P.w_ih[l][0], nin, 1, d_in, nin, BT, nin, 384);
+            gb.p[0].B2 = params + P.w_ih[l][1]; gb.p[0].k2 = 192;
+            SED_TRY(launch_gemm_batch(gb, st));
         }
         d_cur = d_in;
     }
     }
     if (!(parts & 2)) return SED_OK;
     // ---- conv blocks 2, 1 -----------------------------------------------------------------------
-    const size_t wpk[3] = {0, L.wpk1, L.wpk2}, yo[3] = {0, L.y1, L.y2}, bo[3] = {0, L.bn1, L.bn2};
-    const size_t pin[3] = {0, L.p0, L.p1};
+    const size_t wpkT[3] = {0, L.wpkT1, L.wpkT2}, yo[3] = {0, L.y1, L.y2}, bo[3] = {0, L.bn1, L.bn2};
+    const size_t pin[3] = {0, L.p0, L.p1}, gacc[3] = {0, W.gluacc1, W.gluacc2};
     const size_t dzo[3] = {0, W.dz1, W.dz2}, dpo[3] = {W.dp0, W.dp1, W.dp2};
     const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};
+    // one memset for every fp64 accumulator of the conv-block backward
+    SED_CHECK_HIP(hipMemsetAsync(WSD(W.bwd_acc), 0, (2 * 4288 + 2 * 64 * 10) * sizeof(double), st));
     for (int i = 2; i >= 1; --i) {
         SED_TRY(launch_glu_pool_bwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], WSF(dpo[i]),
-                                    WSF(dzo[i]), WSD(W.gluacc), g.B, Hs[i], Wd[i], i, use_drop, g.p, seed_dev, st));
-        SED_TRY(launch_bn_bwd_prep(WSD(W.gluacc), (double)g.B * Hs[i] * Wd[i], params + P.bn_g[i], CTXF(bo[i]), WSF(W.coef),
+                                    WSF(dzo[i]), WSD(gacc[i]), 0, g.B, Hs[i], Wd[i], i, use_drop, g.p, seed_dev, st));
+        SED_TRY(launch_bn_bwd_prep(WSD(gacc[i]), (double)g.B * Hs[i] * Wd[i], params + P.bn_g[i], CTXF(bo[i]), WSF(W.coef),
                                    grads + P.bn_g[i], grads + P.bn_b[i], grads + P.glu_w[i], grads + P.glu_b[i],
                                    grads + P.conv_b[i], st));
-        SED_TRY(launch_conv_pack(params + P.conv_w[i], CTXF(wpk[i]), WSF(W.wpkT), st));
         SED_TRY(launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef), CTXF(pin[i]), WSF(W.wg_part), W.wgrad_blocks,
                                   grads + P.conv_w[i], g.B, Hs[i], Wd[i], st));
-        SED_TRY(launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef), WSF(W.wpkT), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], st));
+        SED_TRY(launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], st));
     }
     // ---- conv block 0 ---------------------------------------------------------------------------
     SED_TRY(launch_blk0_backward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
                                  params + P.glu_w[0], seed_dev, CTXD(L.mom0), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0),
-                                 WSF(W.dp0), WSD(W.de0), grads + P.conv_w[0], grads + P.conv_b[0], grads + P.bn_g[0],
+                                 WSF(W.dp0), WSD(W.de0), 0, grads + P.conv_w[0], grads + P.conv_b[0], grads + P.bn_g[0],
                                  grads + P.bn_b[0], grads + P.glu_w[0], grads + P.glu_b[0], st));
     return SED_OK;
 }
@@ -324,9 +331,9 @@ extern "C" int sed_kernel_replay(const char* name, const sed_dims* d, const floa
     hipStream_t st = (hipStream_t)stream;
     const int use_drop = (g.p > 0.f) ? 1 : 0;
     const int BT = g.B * g.T3;
-    const size_t wpk[3] = {0, L.wpk1, L.wpk2}, yo[3] = {0, L.y1, L.y2}, so[3] = {0, L.stat1, L.stat2},
-                 bo[3] = {0, L.bn1, L.bn2}, po[3] = {L.p0, L.p1, L.p2};
-    const size_t dzo[3] = {0, W.dz1, W.dz2}, dpo[3] = {W.dp0, W.dp1, W.dp2};
+    const size_t wpk[3] = {0, L.wpk1, L.wpk2}, wpkT[3] = {0, L.wpkT1, L.wpkT2}, yo[3] = {0, L.y1, L.y2},
+                 so[3] = {0, L.stat1, L.stat2}, bo[3] = {0, L.bn1, L.bn2}, po[3] = {L.p0, L.p1, L.p2};
+    const size_t dzo[3] = {0, W.dz1, W.dz2}, dpo[3] = {W.dp0, W.dp1, W.dp2}, gacc[3] = {0, W.gluacc1, W.gluacc2};
     const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};
     auto is = [&](const char* n) { return strcmp(name, n) == 0; };
     if (is("blk0_fwd")) {
@@ -334,20 +341,20 @@ extern "C" int sed_kernel_replay(const char* name, const sed_dims* d, const floa
         (void)tpc;
         return launch_blk0_forward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
                                    params + P.glu_w[0], params + P.glu_b[0], WSF(W.coef), WSF(W.coef) + 64, nullptr, 1, 0,
-                                   seed_dev, CTXD(L.mom0), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), CTXF(L.p0), st);
+                                   seed_dev, CTXD(L.mom0), 1, CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), CTXF(L.p0), st);
     }
     for (int i = 1; i <= 2; ++i) {
         char nm[32];
         snprintf(nm, sizeof nm, "conv%d_fwd", i);
-        if (is(nm)) return launch_conv_fwd(CTXF(po[i - 1]), CTXF(wpk[i]), params + P.conv_b[i], CTXF(yo[i]), CTXD(so[i]), g.B, Hs[i], Wd[i], st);
+        if (is(nm)) return launch_conv_fwd(CTXF(po[i - 1]), CTXF(wpk[i]), params + P.conv_b[i], CTXF(yo[i]), CTXD(so[i]), 1, g.B, Hs[i], Wd[i], st);
         snprintf(nm, sizeof nm, "glu%d_fwd", i);
         if (is(nm)) return launch_glu_pool_fwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], CTXF(po[i]), g.B, Hs[i], Wd[i], i, use_drop, g.p, seed_dev, st);
         snprintf(nm, sizeof nm, "glu%d_bwd", i);
-        if (is(nm)) return launch_glu_pool_bwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], WSF(dpo[i]), WSF(dzo[i]), WSD(W.gluacc), g.B, Hs[i], Wd[i], i, use_drop, g.p, seed_dev, st);
+        if (is(nm)) return launch_glu_pool_bwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], WSF(dpo[i]), WSF(dzo[i]), WSD(gacc[i]), 1, g.B, Hs[i], Wd[i], i, use_drop, g.p, seed_dev, st);
         snprintf(nm, sizeof nm, "conv%d_wgrad", i);
         if (is(nm)) return launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef), CTXF(po[i - 1]), WSF(W.wg_part), W.wgrad_blocks, grads + P.conv_w[i], g.B, Hs[i], Wd[i], st);
         snprintf(nm, sizeof nm, "conv%d_dgrad", i);
-        if (is(nm)) return launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef), WSF(W.wpkT), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], st);
+        if (is(nm)) return launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], st);
     }
     for (int l = 0; l < g.L; ++l) {
         char nm[32];
@@ -358,11 +365,12 @@ extern "C" int sed_kernel_replay(const char* name, const sed_dims* d, const floa
     }
     if (is("heads_fwd"))
         return launch_heads_fwd(CTXF(L.out[g.L - 1]), params + P.dense_w, params + P.dense_b, params + P.soft_w, params + P.soft_b,
-                                CTXF(L.strong_sv), CTXF(L.weak_sv), CTXF(L.logits_s), CTXF(L.den_sv), g.B, g.T3, g.NC, use_drop, g.p, seed_dev, st);
+                                CTXF(L.strong_sv), CTXF(L.weak_sv), nullptr, nullptr, CTXF(L.logits_s), CTXF(L.den_sv), g.B, g.T3, g.NC,
+                                use_drop, g.p, seed_dev, st);
     if (is("blk0_bwd"))
         return launch_blk0_backward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
                                     params + P.glu_w[0], seed_dev, CTXD(L.mom0), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), WSF(W.dp0),
-                                    WSD(W.de0), grads + P.conv_w[0], grads + P.conv_b[0], grads + P.bn_g[0], grads + P.bn_b[0],
+                                    WSD(W.de0), 1, grads + P.conv_w[0], grads + P.conv_b[0], grads + P.bn_g[0], grads + P.bn_b[0],
                                     grads + P.glu_w[0], grads + P.glu_b[0], st);
     (void)BT;
     sed_set_error("sed_kernel_replay: unknown kernel '%s'", name);

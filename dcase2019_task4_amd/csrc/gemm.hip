@@ -1,8 +1,17 @@
-// gemm.hip - small strided fp32 GEMM on the f32 MFMA, used for the GRU input projections
-// (x @ W_ih^T + b_ih, torch.nn.GRU inside baseline/models/RNN.py:12) and for the GRU weight /
-// input gradients.  C[m][n] = sum_k A(m,k) * B(k,n) (+ bias[n]) (+ C), arbitrary element strides
-// so the same kernel serves NN / NT / TN products.  Sizes here are tiny (M <= B*T/8, N <= 192,
-// K <= B*T/8), so the kernel is a plain 64x64x16 LDS-tiled loop, 4 waves x one 32x32 tile each.
+// gemm.hip - small strided fp32 GEMMs on the f32 MFMA for the GRU: input projections
+// (x @ W_ih^T + b_ih, torch.nn.GRU inside baseline/models/RNN.py:12), weight / bias gradients and the
+// gradient w.r.t. the layer input.  C[m][n] = sum_k A(m,k) * B(k,n) with arbitrary element strides
+// (NN / NT / TN from one kernel).
+//
+// The shapes are awkward for a GPU: either M = B*T/8 (1 872) with tiny N, K, or tiny M x N
+// (192 x 64..128) with K = 1 872.  A one-problem-per-launch kernel leaves the chip empty (first
+// profile: 3-6 workgroups, 120 us per launch, 39 % of the step).  So one launch takes a BATCH of up
+// to 4 independent problems (both directions, W_ih and W_hh) and an optional split-K factor:
+//   grid = (N tiles, M tiles, problems x splits); partial tiles go to a scratch buffer and
+//   k_gemm_reduce sums them in a fixed order (deterministic; no float atomics) and applies
+//   bias / accumulate.  A virtual all-ones column of B (n == N) yields the bias gradients
+//   (column sums of A) in the same pass, and B may be the K-concatenation of two matrices
+//   (B2 from row k2 on) so dX = [dgi_fwd | dgi_rev] @ [W_ih_fwd ; W_ih_rev] is one launch.
 #include "common.h"
 #include "kernels.h"
 
@@ -10,29 +19,49 @@
 #define GT_N 64
 #define GT_K 16
 
-__global__ __launch_bounds__(256) void k_gemm(GemmDesc d) {
+__device__ __forceinline__ int prob_nx(const GemmProb& p) { return p.N + (p.Cones ? 1 : 0); }
+
+__global__ __launch_bounds__(256) void k_gemm_batched(GemmBatch gb) {
     __shared__ float As[GT_M * (GT_K + 1)];
     __shared__ float Bs[GT_K * (GT_N + 1)];
+    const int pi = blockIdx.z / gb.splits, split = blockIdx.z % gb.splits;
+    const GemmProb& d = gb.p[pi];
+    const int Nx = prob_nx(d);
+    const int m0 = blockIdx.y * GT_M, n0 = blockIdx.x * GT_N;
+    if (m0 >= d.M || n0 >= Nx) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
     const int wm = wv >> 1, wn = wv & 1;
-    const int m0 = blockIdx.y * GT_M, n0 = blockIdx.x * GT_N;
+    int kbeg = 0, kend = d.K;
+    if (gb.splits > 1) {
+        const int chunk = ((d.K + gb.splits - 1) / gb.splits + GT_K - 1) / GT_K * GT_K;
+        kbeg = split * chunk;
+        kend = min(d.K, kbeg + chunk);
+    }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int k0 = 0; k0 < d.K; k0 += GT_K) {
+    for (int k0 = kbeg; k0 < kend; k0 += GT_K) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int e = tid + 256 * it;
             int m, k;
             if (d.sAk == 1) { m = e >> 4; k = e & 15; } else { m = e & 63; k = e >> 6; }
             float v = 0.f;
-            if (m0 + m < d.M && k0 + k < d.K) v = d.A[(int64_t)(m0 + m) * d.sAm + (int64_t)(k0 + k) * d.sAk];
+            if (m0 + m < d.M && k0 + k < kend) v = d.A[(int64_t)(m0 + m) * d.sAm + (int64_t)(k0 + k) * d.sAk];
             As[m * (GT_K + 1) + k] = v;
             int kb, nb;
             if (d.sBn == 1) { kb = e >> 6; nb = e & 63; } else { kb = e & 15; nb = e >> 4; }
             float w = 0.f;
-            if (k0 + kb < d.K && n0 + nb < d.N) w = d.B[(int64_t)(k0 + kb) * d.sBk + (int64_t)(n0 + nb) * d.sBn];
+            const int kk = k0 + kb, nn = n0 + nb;
+            if (kk < kend) {
+                if (nn < d.N) {
+                    w = (d.B2 && kk >= d.k2) ? d.B2[(int64_t)(kk - d.k2) * d.sBk + (int64_t)nn * d.sBn]
+                                             : d.B[(int64_t)kk * d.sBk + (int64_t)nn * d.sBn];
+                } else if (nn == d.N && d.Cones) {
+                    w = 1.0f;
+                }
+            }
             Bs[kb * (GT_N + 1) + nb] = w;
         }
         __syncthreads();
@@ -45,22 +74,60 @@ __global__ __launch_bounds__(256) void k_gemm(GemmDesc d) {
         __syncthreads();
     }
     const int col = n0 + 32 * wn + n;
-    if (col < d.N) {
-        const float bv = d.bias ? d.bias[col] : 0.f;
+    if (col >= Nx) return;
+    if (gb.splits > 1) {
+        float* P = gb.part + ((size_t)blockIdx.z * gb.part_stride);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + 32 * wm + mfma32_row(r, lane);
-            if (row < d.M) {
-                float* c = d.C + (int64_t)row * d.ldc + col;
-                float v = acc[r] + bv;
-                if (d.accumulate) v += *c;
-                *c = v;
-            }
+            if (row < d.M) P[(size_t)row * Nx + col] = acc[r];
+        }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + 32 * wm + mfma32_row(r, lane);
+        if (row >= d.M) continue;
+        if (col < d.N) {
+            float* c = d.C + (int64_t)row * d.ldc + col;
+            float v = acc[r] + (d.bias ? d.bias[col] : 0.f);
+            if (d.accumulate) v += *c;
+            *c = v;
+        } else {
+            d.Cones[row] = acc[r];
         }
     }
 }
 
-// out[n] = sum_m A[m*lda + n]
+__global__ __launch_bounds__(256) void k_gemm_reduce(GemmBatch gb) {
+    const int pi = blockIdx.y;
+    const GemmProb& d = gb.p[pi];
+    const int Nx = prob_nx(d);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.M * Nx) return;
+    const float* P = gb.part + (size_t)pi * gb.splits * gb.part_stride + i;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = 0;
+    for (; z + 4 <= gb.splits; z += 4) {
+        s0 += P[(size_t)(z + 0) * gb.part_stride];
+        s1 += P[(size_t)(z + 1) * gb.part_stride];
+        s2 += P[(size_t)(z + 2) * gb.part_stride];
+        s3 += P[(size_t)(z + 3) * gb.part_stride];
+    }
+    for (; z < gb.splits; ++z) s0 += P[(size_t)z * gb.part_stride];
+    float v = (s0 + s1) + (s2 + s3);
+    const int row = i / Nx, col = i % Nx;
+    if (col < d.N) {
+        float* c = d.C + (int64_t)row * d.ldc + col;
+        v += d.bias ? d.bias[col] : 0.f;
+        if (d.accumulate) v += *c;
+        *c = v;
+    } else {
+        d.Cones[row] = v;
+    }
+}
+
+// out[n] = sum_m A[m*lda + n]   (few rows: the per-clip partials of the head gradients)
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ A, int M, int N, int64_t lda, float* __restrict__ out) {
     __shared__ float red[4][64];
     const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
@@ -73,10 +140,30 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ A, int
     if (r == 0 && col < N) out[col] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
 
-int launch_gemm(const GemmDesc& d, hipStream_t st) {
-    dim3 grid((d.N + GT_N - 1) / GT_N, (d.M + GT_M - 1) / GT_M);
-    k_gemm<<<grid, 256, 0, st>>>(d);
+size_t gemm_part_floats(int n_prob, int splits, int max_m, int max_nx) {
+    return (size_t)n_prob * splits * max_m * max_nx;
+}
+
+int launch_gemm_batch(GemmBatch& gb, hipStream_t st) {
+    int maxM = 0, maxNx = 0;
+    for (int i = 0; i < gb.n_prob; ++i) {
+        const int nx = gb.p[i].N + (gb.p[i].Cones ? 1 : 0);
+        maxM = gb.p[i].M > maxM ? gb.p[i].M : maxM;
+        maxNx = nx > maxNx ? nx : maxNx;
+    }
+    if (gb.splits < 1) gb.splits = 1;
+    if (gb.splits > 1) {
+        SED_CHECK_ARG(gb.part != nullptr, "split-K gemm needs a partial buffer");
+        gb.part_stride = (size_t)maxM * maxNx;
+    }
+    dim3 grid((maxNx + GT_N - 1) / GT_N, (maxM + GT_M - 1) / GT_M, gb.n_prob * gb.splits);
+    k_gemm_batched<<<grid, 256, 0, st>>>(gb);
     SED_CHECK_LAUNCH();
+    if (gb.splits > 1) {
+        dim3 g2((maxM * maxNx + 255) / 256, gb.n_prob);
+        k_gemm_reduce<<<g2, 256, 0, st>>>(gb);
+        SED_CHECK_LAUNCH();
+    }
     return SED_OK;
 }
 

@@ -40,7 +40,8 @@ __device__ __forceinline__ void heads_stage(const float* __restrict__ h, float* 
 __global__ __launch_bounds__(256) void k_heads_fwd(const float* __restrict__ h, const float* __restrict__ wd,
                                                     const float* __restrict__ bd, const float* __restrict__ ws,
                                                     const float* __restrict__ bs, float* __restrict__ strong,
-                                                    float* __restrict__ weak, float* __restrict__ logits_s,
+                                                    float* __restrict__ weak, float* __restrict__ strong_sv,
+                                                    float* __restrict__ weak_sv, float* __restrict__ logits_s,
                                                     float* __restrict__ den_out, int T, int NC, int use_drop, float p_drop,
                                                     const uint64_t* __restrict__ seed_ptr) {
     __shared__ float xs[HD_TC * HD_FS];
@@ -86,6 +87,7 @@ __global__ __launch_bounds__(256) void k_heads_fwd(const float* __restrict__ h, 
                     sof = fminf(fmaxf(sof, 1e-7f), 1.0f);
                     const float sv = sigmoidf_fast(lg[tid * HD_MAXO + c]);
                     strong[(size_t)(b * T + t) * NC + c] = sv;
+                    if (strong_sv) strong_sv[(size_t)(b * T + t) * NC + c] = sv;
                     logits_s[(size_t)(b * T + t) * NC + c] = ls;
                     nums[tid][c] = sv * sof;
                     dens[tid][c] = sof;
@@ -103,7 +105,9 @@ __global__ __launch_bounds__(256) void k_heads_fwd(const float* __restrict__ h, 
     }
     __syncthreads();
     if (tid < NC) {
-        weak[b * NC + tid] = num_acc[tid] / den_acc[tid];
+        const float wk = num_acc[tid] / den_acc[tid];
+        weak[b * NC + tid] = wk;
+        if (weak_sv) weak_sv[b * NC + tid] = wk;
         den_out[b * NC + tid] = den_acc[tid];
     }
 }
@@ -214,13 +218,14 @@ __device__ __forceinline__ float bce_term(float p, float t) {
 }
 __device__ __forceinline__ float bce_grad(float p, float t) { return (p - t) / fmaxf((1.0f - p) * p, 1e-12f); }
 
-__global__ __launch_bounds__(256) void k_mt_loss(const float* __restrict__ strong, const float* __restrict__ weak,
+#define LOSS_THREADS 1024
+__global__ __launch_bounds__(LOSS_THREADS) void k_mt_loss(const float* __restrict__ strong, const float* __restrict__ weak,
                                                   const float* __restrict__ strong_ema, const float* __restrict__ weak_ema,
                                                   const float* __restrict__ target, int B, int T, int NC, int wlo, int whi,
                                                   int slo, int shi, const sed_step_state* __restrict__ state,
                                                   float* __restrict__ losses, float* __restrict__ d_strong,
                                                   float* __restrict__ d_weak) {
-    __shared__ float red[4][8];
+    __shared__ float red[LOSS_THREADS / 64][8];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float cw = state->cons_weight;
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // weak_bce, strong_bce, mse_strong, mse_weak, weak_ema_bce, strong_ema_bce
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(256) void k_mt_loss(const float* __restrict__ stron
     const float inv_nS = 1.0f / (float)nS, inv_nW = 1.0f / (float)nW;
     const float inv_sb = (shi > slo) ? 1.0f / (float)((shi - slo) * T * NC) : 0.f;
     const float inv_wb = (whi > wlo) ? 1.0f / (float)((whi - wlo) * NC) : 0.f;
-    for (int e = tid; e < nS; e += 256) {
+    for (int e = tid; e < nS; e += LOSS_THREADS) {
         const int b = e / (T * NC);
         const float p = strong[e], pe = strong_ema[e];
         const float diff = p - pe;
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(256) void k_mt_loss(const float* __restrict__ stron
         }
         d_strong[e] = g;
     }
-    for (int e = tid; e < nW; e += 256) {
+    for (int e = tid; e < nW; e += LOSS_THREADS) {
         const int b = e / NC, c = e % NC;
         const float p = weak[e], pe = weak_ema[e];
         const float diff = p - pe;
@@ -265,7 +270,10 @@ __global__ __launch_bounds__(256) void k_mt_loss(const float* __restrict__ stron
     __syncthreads();
     if (tid == 0) {
         float s[6];
-        for (int k = 0; k < 6; ++k) s[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+        for (int k = 0; k < 6; ++k) {
+            s[k] = 0.f;
+            for (int w2 = 0; w2 < LOSS_THREADS / 64; ++w2) s[k] += red[w2][k];
+        }
         const float wb = s[0] * inv_wb, sb = s[1] * inv_sb;
         const float cs = cw * s[2] * inv_nS, cwk = cw * s[3] * inv_nW;
         losses[0] = wb + sb + cs + cwk;
@@ -276,9 +284,10 @@ __global__ __launch_bounds__(256) void k_mt_loss(const float* __restrict__ stron
 
 // ---- host launchers -------------------------------------------------------------------------------
 int launch_heads_fwd(const float* h, const float* wd, const float* bd, const float* ws, const float* bs, float* strong,
-                     float* weak, float* logits_s, float* den, int B, int T, int NC, int use_drop, float p_drop,
-                     const uint64_t* seed, hipStream_t st) {
-    k_heads_fwd<<<B, 256, 0, st>>>(h, wd, bd, ws, bs, strong, weak, logits_s, den, T, NC, use_drop, p_drop, seed);
+                     float* weak, float* strong_sv, float* weak_sv, float* logits_s, float* den, int B, int T, int NC,
+                     int use_drop, float p_drop, const uint64_t* seed, hipStream_t st) {
+    k_heads_fwd<<<B, 256, 0, st>>>(h, wd, bd, ws, bs, strong, weak, strong_sv, weak_sv, logits_s, den, T, NC, use_drop, p_drop,
+                                   seed);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
@@ -305,7 +314,7 @@ extern "C" int sed_mt_loss(const sed_dims* d, const float* strong, const float* 
     const Geo g = make_geo(d);
     SED_CHECK_ARG(weak_lo >= 0 && weak_hi <= g.B && weak_lo <= weak_hi && strong_lo >= 0 && strong_hi <= g.B &&
                       strong_lo <= strong_hi, "sed_mt_loss: bad mask range");
-    k_mt_loss<<<1, 256, 0, (hipStream_t)stream>>>(strong, weak, strong_ema, weak_ema, target, g.B, g.T3, g.NC, weak_lo,
+    k_mt_loss<<<1, LOSS_THREADS, 0, (hipStream_t)stream>>>(strong, weak, strong_ema, weak_ema, target, g.B, g.T3, g.NC, weak_lo,
                                                   weak_hi, strong_lo, strong_hi, state_dev, losses, d_strong, d_weak);
     SED_CHECK_LAUNCH();
     return SED_OK;

@@ -6,20 +6,20 @@
 // blk0.hip
 int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const float* b0, const float* gamma,
                         const float* beta, const float* wglu, const float* bglu, float* run_mean, float* run_var,
-                        int64_t* tracked, int train, int update, const uint64_t* seed, double* mom, float* wz,
-                        float* wl, float* bn, float* p0, hipStream_t st);
+                        int64_t* tracked, int train, int update, const uint64_t* seed, double* mom, int zero_mom,
+                        float* wz, float* wl, float* bn, float* p0, hipStream_t st);
 int launch_blk0_backward(const Geo& g, const float* x, const float* w0, const float* b0, const float* gamma,
                          const float* beta, const float* wglu, const uint64_t* seed, const double* mom,
-                         const float* wz, const float* wl, const float* bn, const float* dp0, double* de,
+                         const float* wz, const float* wl, const float* bn, const float* dp0, double* de, int zero_de,
                          float* g_w0, float* g_b0, float* g_gamma, float* g_beta, float* g_wglu, float* g_bglu,
                          hipStream_t st);
 
 // conv.hip : 3x3, 64 -> 64 channels, channels-last, image [B][H][W][64] with W in {16, 4}
-int launch_conv_pack(const float* w /*[co][ci][3][3]*/, float* wpk /*[tap][ci][co]*/, float* wpkT /*[tap'][co][ci] flipped, may be null*/,
-                     hipStream_t st);
+// packs conv1 and conv2 weights [co][ci][3][3] -> wpk [tap][ci][co] (+ flipped/transposed wpkT for dgrad, may be null)
+int launch_conv_pack(const float* w1, const float* w2, float* wpk1, float* wpk2, float* wpkT1, float* wpkT2, hipStream_t st);
 // forward: y = conv(in) + bias; optional per-channel sum / sum-of-squares (fp64 atomics into stat[128])
-int launch_conv_fwd(const float* in, const float* wpk, const float* bias, float* y, double* stat, int B, int H, int W,
-                    hipStream_t st);
+int launch_conv_fwd(const float* in, const float* wpk, const float* bias, float* y, double* stat, int zero_stat, int B,
+                    int H, int W, hipStream_t st);
 // dgrad: dx = conv_flipped(dy), dy = ca*dz + cb*yin + cc (per channel) inside the image, 0 outside
 int launch_conv_dgrad(const float* dz, const float* yin, const float* coef /*[3][64]*/, const float* wpkT, float* dx,
                       int B, int H, int W, hipStream_t st);
@@ -35,22 +35,39 @@ int launch_glu_pool_fwd(const float* y, const float* bn, const float* wglu, cons
 // backward pass 1: dz (full-res grad wrt BN output), GLU weight grads and BN reduction sums
 //   acc: double [64*64 (dWglu) + 64 (dbglu) + 64 (sum dz) + 64 (sum dz*y)]
 int launch_glu_pool_bwd(const float* y, const float* bn, const float* wglu, const float* bglu, const float* dp, float* dz,
-                        double* acc, int B, int H, int W, int block_id, int use_drop, float p_drop, const uint64_t* seed,
-                        hipStream_t st);
+                        double* acc, int zero_acc, int B, int H, int W, int block_id, int use_drop, float p_drop,
+                        const uint64_t* seed, hipStream_t st);
 // backward pass 1b: write GLU grads, BN grads and the coefficients of dy = ca*dz + cb*y + cc
 int launch_bn_bwd_prep(const double* acc, double N, const float* gamma, const float* bn, float* coef, float* g_gamma,
                        float* g_beta, float* g_wglu, float* g_bglu, float* g_convb, hipStream_t st);
 
-// gemm.hip : C[m][n] (ldc) = alpha-free  sum_k A(m,k) B(k,n) (+ bias[n]) (+ C if accumulate)
-struct GemmDesc {
+// gemm.hip : batched / split-K strided GEMM  C[m][n] = sum_k A(m,k) B(k,n) (+ bias[n]) (+ C)
+struct GemmProb {
     const float* A; int64_t sAm, sAk;
     const float* B; int64_t sBk, sBn;
+    const float* B2; int k2;      // optional: rows k >= k2 of B come from B2[(k - k2)]
     float* C; int64_t ldc;
-    const float* bias;
+    const float* bias;            // per output column (may be null)
+    float* Cones;                 // optional: receives sum_k A(m,k) (virtual all-ones column n == N)
     int M, N, K;
     int accumulate;
 };
-int launch_gemm(const GemmDesc& d, hipStream_t st);
+struct GemmBatch {
+    GemmProb p[4];
+    int n_prob;
+    int splits;                   // split-K factor (>1 needs part)
+    float* part;                  // scratch: n_prob * splits * max(M) * max(N+1) floats
+    size_t part_stride;           // filled by launch_gemm_batch
+};
+static inline GemmProb gemm_prob(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBk, int64_t sBn, float* C,
+                                 int64_t ldc, int M, int N, int K) {
+    GemmProb q;
+    q.A = A; q.sAm = sAm; q.sAk = sAk; q.B = B; q.sBk = sBk; q.sBn = sBn; q.B2 = nullptr; q.k2 = 0;
+    q.C = C; q.ldc = ldc; q.bias = nullptr; q.Cones = nullptr; q.M = M; q.N = N; q.K = K; q.accumulate = 0;
+    return q;
+}
+size_t gemm_part_floats(int n_prob, int splits, int max_m, int max_nx);
+int launch_gemm_batch(GemmBatch& gb, hipStream_t st);
 int launch_colsum(const float* A, int M, int N, int64_t lda, float* out, hipStream_t st);
 
 // gru.hip
@@ -62,8 +79,8 @@ int launch_gru_bwd(const float* d_out, const float* out, const float* gates, con
 
 // heads.hip
 int launch_heads_fwd(const float* h /*[B][T][128]*/, const float* wd, const float* bd, const float* ws, const float* bs,
-                     float* strong, float* weak, float* logits_s, float* den, int B, int T, int NC, int use_drop,
-                     float p_drop, const uint64_t* seed, hipStream_t st);
+                     float* strong, float* weak, float* strong_sv, float* weak_sv, float* logits_s, float* den, int B, int T,
+                     int NC, int use_drop, float p_drop, const uint64_t* seed, hipStream_t st);
 int launch_heads_bwd(const float* h, const float* wd, const float* ws, const float* strong, const float* weak,
                      const float* logits_s, const float* den, const float* d_strong, const float* d_weak, float* dh,
                      float* part /*[B][2*(NC*128+NC)]*/, float* g_wd, float* g_bd, float* g_ws, float* g_bs, int B, int T,

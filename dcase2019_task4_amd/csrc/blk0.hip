@@ -171,15 +171,15 @@ __device__ __forceinline__ void blk0_rowblock(const float* xs, const Blk0W& W, i
 __global__ __launch_bounds__(256) void k_blk0_fwd(const float* __restrict__ x, const float* __restrict__ wz,
                                                    const float* __restrict__ wl, float* __restrict__ p0, int B, int T,
                                                    int H1, int tiles_per_clip, int n_tiles, int use_drop, float p_drop,
-                                                   const uint64_t* __restrict__ seed_ptr) {
+                                                   const uint64_t* __restrict__ seed_ptr, uint16_t* __restrict__ mask_out) {
     __shared__ float xs[XS_H * XS_W];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
     Blk0W W;
     blk0_load_w(W, wz, wl, lane);
     const uint64_t seed = use_drop ? seed_ptr[0] : 0ull;
-    const uint32_t thr = drop_thresh16(p_drop);
-    const float keep_scale = use_drop ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const uint32_t thr = drop_thresh8(p_drop);
+    const float keep_scale = use_drop ? drop_scale8(p_drop) : 1.0f;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int b = tile / tiles_per_clip, to0 = (tile % tiles_per_clip) * 4;
         __syncthreads();
@@ -196,15 +196,14 @@ __global__ __launch_bounds__(256) void k_blk0_fwd(const float* __restrict__ x, c
                 const int c = 32 * h + n;
                 float pooled[4] = {0.f, 0.f, 0.f, 0.f};
                 if (use_drop) {
+                    // one Philox draw = 16 bytes = this lane's 16 elements (4 pooled pixels x 4 df) of channel c
+                    const u32x4 o = philox_stream((uint32_t)((q0 >> 2) * 64 + c), (uint32_t)kh, seed);
+                    const uint32_t m16 = philox_keep16(o, thr);
+                    if (mask_out) mask_out[((size_t)(q0 >> 2) * 2 + h) * 64 + lane] = (uint16_t)m16;
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        const u32x4 o = philox_stream((uint32_t)(((q0 >> 1) + jj) * 64 + c), (uint32_t)kh, seed);
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const int r = 8 * jj + i;
-                            const float v = acc[h][r] * sigmoidf_fast(acc[2 + h][r]);
-                            pooled[r >> 2] += (philox_hw(o, i) >= thr) ? v : 0.f;
-                        }
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[h][r] * sigmoidf_fast(acc[2 + h][r]);
+                        pooled[r >> 2] += ((m16 >> r) & 1u) ? v : 0.f;
                     }
                 } else {
 #pragma unroll
@@ -225,7 +224,7 @@ __global__ __launch_bounds__(256) void k_blk0_fwd(const float* __restrict__ x, c
 __global__ __launch_bounds__(256) void k_blk0_bwd(const float* __restrict__ x, const float* __restrict__ wz,
                                                    const float* __restrict__ wl, const float* __restrict__ dp0, int B,
                                                    int T, int H1, int tiles_per_clip, int n_tiles, int use_drop,
-                                                   float p_drop, const uint64_t* __restrict__ seed_ptr,
+                                                   float p_drop, const uint16_t* __restrict__ mask_in,
                                                    double* __restrict__ de /* [2][64][10] */) {
     __shared__ float xs[XS_H * XS_W];
     __shared__ __attribute__((aligned(16))) float P[4][32 * 12];
@@ -234,9 +233,7 @@ __global__ __launch_bounds__(256) void k_blk0_bwd(const float* __restrict__ x, c
     const int n = lane & 31, kh = lane >> 5;
     Blk0W W;
     blk0_load_w(W, wz, wl, lane);
-    const uint64_t seed = use_drop ? seed_ptr[0] : 0ull;
-    const uint32_t thr = drop_thresh16(p_drop);
-    const float keep_scale = use_drop ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const float keep_scale = use_drop ? drop_scale8(p_drop) : 1.0f;
     float aD[2][10], aE[2][10];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -271,15 +268,11 @@ __global__ __launch_bounds__(256) void k_blk0_bwd(const float* __restrict__ x, c
                 float gq[4];
 #pragma unroll
                 for (int jx = 0; jx < 4; ++jx) gq[jx] = dp0[(size_t)(q0 + jx) * 64 + c] * (0.125f * keep_scale);
-                u32x4 o[2];
-                if (use_drop) {
-                    o[0] = philox_stream((uint32_t)(((q0 >> 1) + 0) * 64 + c), (uint32_t)kh, seed);
-                    o[1] = philox_stream((uint32_t)(((q0 >> 1) + 1) * 64 + c), (uint32_t)kh, seed);
-                }
+                // the forward stored its 16 keep bits per (row block, half, lane): no RNG in backward
+                const uint32_t m16 = use_drop ? (uint32_t)mask_in[((size_t)(q0 >> 2) * 2 + h) * 64 + lane] : 0xffffu;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float gg = gq[r >> 2];
-                    if (use_drop) gg = (philox_hw(o[r >> 3], r & 7) >= thr) ? gg : 0.f;
+                    const float gg = ((m16 >> r) & 1u) ? gq[r >> 2] : 0.f;
                     const float sg = sigmoidf_fast(acc[2 + h][r]);
                     dl[h][r] = gg * sg;
                     dzg[h][r] = gg * acc[h][r] * sg * (1.0f - sg);
@@ -387,7 +380,7 @@ __global__ __launch_bounds__(64) void k_blk0_bwd_finalize(Blk0BwdFinArgs a) {
 int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const float* b0, const float* gamma,
                         const float* beta, const float* wglu, const float* bglu, float* run_mean, float* run_var,
                         int64_t* tracked, int train, int update, const uint64_t* seed, double* mom, int zero_mom,
-                        float* wz, float* wl, float* bn, float* p0, hipStream_t st) {
+                        float* wz, float* wl, float* bn, float* p0, uint16_t* mask_out, hipStream_t st) {
     if (train) {
         if (zero_mom) SED_CHECK_HIP(hipMemsetAsync(mom, 0, 64 * sizeof(double), st));
         dim3 grid((g.T + MOM_ROWS - 1) / MOM_ROWS, g.B);
@@ -403,20 +396,20 @@ int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const flo
     SED_CHECK_LAUNCH();
     const int tpc = (g.H1 + 3) / 4, nt = tpc * g.B;
     const int use_drop = (train && g.p > 0.f) ? 1 : 0;
-    k_blk0_fwd<<<nt < 2048 ? nt : 2048, 256, 0, st>>>(x, wz, wl, p0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, seed);
+    k_blk0_fwd<<<nt < 2048 ? nt : 2048, 256, 0, st>>>(x, wz, wl, p0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, seed, mask_out);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
 
 int launch_blk0_backward(const Geo& g, const float* x, const float* w0, const float* b0, const float* gamma,
-                         const float* beta, const float* wglu, const uint64_t* seed, const double* mom,
+                         const float* beta, const float* wglu, const uint16_t* mask_in, const double* mom,
                          const float* wz, const float* wl, const float* bn, const float* dp0, double* de, int zero_de,
                          float* g_w0, float* g_b0, float* g_gamma, float* g_beta, float* g_wglu, float* g_bglu,
                          hipStream_t st) {
     if (zero_de) SED_CHECK_HIP(hipMemsetAsync(de, 0, 2 * 64 * 10 * sizeof(double), st));
     const int tpc = (g.H1 + 3) / 4, nt = tpc * g.B;
     const int use_drop = (g.p > 0.f) ? 1 : 0;
-    k_blk0_bwd<<<nt < 512 ? nt : 512, 256, 0, st>>>(x, wz, wl, dp0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, seed, de);
+    k_blk0_bwd<<<nt < 512 ? nt : 512, 256, 0, st>>>(x, wz, wl, dp0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, mask_in, de);
     SED_CHECK_LAUNCH();
     Blk0BwdFinArgs a;
     a.w0 = w0; a.b0 = b0; a.gamma = gamma; a.beta = beta; a.wglu = wglu; a.bn = bn; a.mom = mom; a.de = de;

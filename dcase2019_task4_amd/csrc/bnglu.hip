@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k_glu_pool_fwd(const float* __restrict__ 
                                                        const float* __restrict__ wglu, const float* __restrict__ bglu,
                                                        float* __restrict__ p, int H, int W, int Ho, int Wo, int Q,
                                                        int block_id, int use_drop, float p_drop,
-                                                       const uint64_t* __restrict__ seed_ptr) {
+                                                       const uint64_t* __restrict__ seed_ptr, uint16_t* __restrict__ mask_out) {
     __shared__ float zts[4][32 * ZS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
@@ -101,8 +101,8 @@ __global__ __launch_bounds__(256) void k_glu_pool_fwd(const float* __restrict__ 
     }
     const float bg[2] = {bglu[n], bglu[32 + n]};
     const uint64_t seed = use_drop ? seed_ptr[0] : 0ull;
-    const uint32_t thr = drop_thresh16(p_drop);
-    const float sc = 0.125f * (use_drop ? 1.0f / (1.0f - p_drop) : 1.0f);
+    const uint32_t thr = drop_thresh8(p_drop);
+    const float sc = 0.125f * (use_drop ? drop_scale8(p_drop) : 1.0f);
     const int n_rb = (Q + 3) / 4;
     for (int rb = blockIdx.x * 4 + wv; rb < n_rb; rb += gridDim.x * 4) {
         const int q0 = rb * 4;
@@ -121,17 +121,17 @@ __global__ __launch_bounds__(256) void k_glu_pool_fwd(const float* __restrict__ 
         for (int h = 0; h < 2; ++h) {
             const int c = 32 * h + n;
             float pooled[4] = {0.f, 0.f, 0.f, 0.f};
-            u32x4 o[2];
+            uint32_t m16 = 0xffffu;
             if (use_drop) {
-                o[0] = philox_stream((uint32_t)(((q0 >> 1) + 0) * 64 + c), (uint32_t)(2 * block_id + kh), seed);
-                o[1] = philox_stream((uint32_t)(((q0 >> 1) + 1) * 64 + c), (uint32_t)(2 * block_id + kh), seed);
+                const u32x4 o = philox_stream((uint32_t)(rb * 64 + c), (uint32_t)(2 * block_id + kh), seed);
+                m16 = philox_keep16(o, thr);
+                if (mask_out) mask_out[((size_t)rb * 2 + h) * 64 + lane] = (uint16_t)m16;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float zr = zt[mfma32_row(r, lane) * ZS + c];
-                float v = (acc[h][r] + bg[h]) * sigmoidf_fast(zr);
-                if (use_drop) v = (philox_hw(o[r >> 3], r & 7) >= thr) ? v : 0.f;
-                pooled[r >> 2] += v;
+                const float v = (acc[h][r] + bg[h]) * sigmoidf_fast(zr);
+                pooled[r >> 2] += ((m16 >> r) & 1u) ? v : 0.f;
             }
 #pragma unroll
             for (int jx = 0; jx < 4; ++jx) pooled[jx] += __shfl_xor(pooled[jx], 32);
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ 
                                                        const float* __restrict__ dp, float* __restrict__ dz,
                                                        double* __restrict__ accg, int H, int W, int Ho, int Wo, int Q,
                                                        int block_id, int use_drop, float p_drop,
-                                                       const uint64_t* __restrict__ seed_ptr) {
+                                                       const uint16_t* __restrict__ mask_in) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
@@ -166,9 +166,8 @@ __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ 
         bwT[s][1] = wglu[(2 * s + kh) * 64 + 32 + n];
     }
     const float bg[2] = {bglu[n], bglu[32 + n]};
-    const uint64_t seed = use_drop ? seed_ptr[0] : 0ull;
-    const uint32_t thr = drop_thresh16(p_drop);
-    const float sc = 0.125f * (use_drop ? 1.0f / (1.0f - p_drop) : 1.0f);
+    const float sc = 0.125f * (use_drop ? drop_scale8(p_drop) : 1.0f);
+    (void)block_id;
     f32x16 dW[2][2];   // [co block][c block]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -200,16 +199,11 @@ __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ 
             float gq[4];
 #pragma unroll
             for (int jx = 0; jx < 4; ++jx) gq[jx] = (q0 + jx < Q) ? dp[(size_t)(q0 + jx) * 64 + c] * sc : 0.f;
-            u32x4 o[2];
-            if (use_drop) {
-                o[0] = philox_stream((uint32_t)(((q0 >> 1) + 0) * 64 + c), (uint32_t)(2 * block_id + kh), seed);
-                o[1] = philox_stream((uint32_t)(((q0 >> 1) + 1) * 64 + c), (uint32_t)(2 * block_id + kh), seed);
-            }
+            const uint32_t m16 = use_drop ? (uint32_t)mask_in[((size_t)rb * 2 + h) * 64 + lane] : 0xffffu;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = mfma32_row(r, lane);
-                float gg = gq[r >> 2];
-                if (use_drop) gg = (philox_hw(o[r >> 3], r & 7) >= thr) ? gg : 0.f;
+                const float gg = ((m16 >> r) & 1u) ? gq[r >> 2] : 0.f;
                 const float sg = sigmoidf_fast(zt[i * ZS + c]);
                 const float dl = gg * sg;
                 dlt[i * ZS + c] = dl;
@@ -325,19 +319,20 @@ int launch_bn_prep(const double* stat, double N, const float* gamma, const float
 }
 
 int launch_glu_pool_fwd(const float* y, const float* bn, const float* wglu, const float* bglu, float* p, int B, int H,
-                        int W, int block_id, int use_drop, float p_drop, const uint64_t* seed, hipStream_t st) {
+                        int W, int block_id, int use_drop, float p_drop, const uint64_t* seed, uint16_t* mask_out,
+                        hipStream_t st) {
     const int Ho = H / 2, Wo = W / 4, Q = B * Ho * Wo;
     const int n_rb = (Q + 3) / 4;
     int grid = (n_rb + 3) / 4;
     if (grid > 1024) grid = 1024;
-    k_glu_pool_fwd<<<grid, 256, 0, st>>>(y, bn, wglu, bglu, p, H, W, Ho, Wo, Q, block_id, use_drop, p_drop, seed);
+    k_glu_pool_fwd<<<grid, 256, 0, st>>>(y, bn, wglu, bglu, p, H, W, Ho, Wo, Q, block_id, use_drop, p_drop, seed, mask_out);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
 
 int launch_glu_pool_bwd(const float* y, const float* bn, const float* wglu, const float* bglu, const float* dp, float* dz,
                         double* acc, int zero_acc, int B, int H, int W, int block_id, int use_drop, float p_drop,
-                        const uint64_t* seed, hipStream_t st) {
+                        const uint16_t* mask_in, hipStream_t st) {
     const int Ho = H / 2, Wo = W / 4, Q = B * Ho * Wo;
     const size_t lds = (size_t)4 * 3 * 32 * ZS * sizeof(float);
     static bool attr_done = false;
@@ -350,7 +345,7 @@ int launch_glu_pool_bwd(const float* y, const float* bn, const float* wglu, cons
     const int n_rb = (Q + 3) / 4;
     int grid = (n_rb + 3) / 4;
     if (grid > 256) grid = 256;
-    k_glu_pool_bwd<<<grid, 256, lds, st>>>(y, bn, wglu, bglu, dp, dz, acc, H, W, Ho, Wo, Q, block_id, use_drop, p_drop, seed);
+    k_glu_pool_bwd<<<grid, 256, lds, st>>>(y, bn, wglu, bglu, dp, dz, acc, H, W, Ho, Wo, Q, block_id, use_drop, p_drop, mask_in);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

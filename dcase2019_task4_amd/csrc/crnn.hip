@@ -91,6 +91,9 @@ CtxLayout make_ctx_layout(const Geo& g) {
     }
     put(L.logits_s, bt * g.NC * 4); put(L.strong_sv, bt * g.NC * 4);
     put(L.weak_sv, (size_t)g.B * g.NC * 4); put(L.den_sv, (size_t)g.B * g.NC * 4);
+    auto mask_bytes = [](size_t Q) { return ((Q + 3) / 4) * 2 * 64 * sizeof(uint16_t); };
+    put(L.mask0, mask_bytes((size_t)g.B * g.H1 * g.W1)); put(L.mask1, mask_bytes((size_t)g.B * g.H2 * g.W2));
+    put(L.mask2, mask_bytes((size_t)g.B * g.T3));
     L.total = o;
     return L;
 }
@@ -159,6 +162,7 @@ extern "C" int sed_crnn_ctx_view(const sed_dims* d, const char* name, size_t* of
 #define CTXD(off) ((double*)((char*)ctx + (off)))
 #define WSF(off) ((float*)((char*)ws + (off)))
 #define WSD(off) ((double*)((char*)ws + (off)))
+#define CTXM(off) ((uint16_t*)((char*)ctx + (off)))
 
 extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* bn_running, int64_t* bn_tracked,
                                 const float* x, int train, int update_bn, const uint64_t* seed_dev, void* ctx,
@@ -187,11 +191,12 @@ extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* b
     // ---- conv block 0 ---------------------------------------------------------------------------
     SED_TRY(launch_blk0_forward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
                                 params + P.glu_w[0], params + P.glu_b[0], bn_running + 0, bn_running + 64, trk[0], train,
-                                upd, seed_dev, CTXD(L.mom0), 0, CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), CTXF(L.p0), st));
+                                upd, seed_dev, CTXD(L.mom0), 0, CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), CTXF(L.p0),
+                                use_drop ? CTXM(L.mask0) : nullptr, st));
     // ---- conv blocks 1, 2 -----------------------------------------------------------------------
     const float* in = CTXF(L.p0);
     const size_t wpk[3] = {0, L.wpk1, L.wpk2}, yo[3] = {0, L.y1, L.y2}, so[3] = {0, L.stat1, L.stat2},
-                 bo[3] = {0, L.bn1, L.bn2}, po[3] = {0, L.p1, L.p2};
+                 bo[3] = {0, L.bn1, L.bn2}, po[3] = {0, L.p1, L.p2}, mo[3] = {L.mask0, L.mask1, L.mask2};
     const int Hs[3] = {0, g.H1, g.H2}, Ws[3] = {0, g.W1, g.W2};
     for (int i = 1; i <= 2; ++i) {
         SED_TRY(launch_conv_fwd(in, CTXF(wpk[i]), params + P.conv_b[i], CTXF(yo[i]), train ? CTXD(so[i]) : nullptr, 0, g.B,
@@ -200,7 +205,7 @@ extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* b
                                bn_running + (2 * i) * 64, bn_running + (2 * i + 1) * 64, trk[i], train, upd, g.eps, g.mom,
                                CTXF(bo[i]), st));
         SED_TRY(launch_glu_pool_fwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], CTXF(po[i]), g.B,
-                                    Hs[i], Ws[i], i, use_drop, g.p, seed_dev, st));
+                                    Hs[i], Ws[i], i, use_drop, g.p, seed_dev, use_drop ? CTXM(mo[i]) : nullptr, st));
         in = CTXF(po[i]);
     }
     // ---- BiGRU ----------------------------------------------------------------------------------
@@ -292,14 +297,14 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
     if (!(parts & 2)) return SED_OK;
     // ---- conv blocks 2, 1 -----------------------------------------------------------------------
     const size_t wpkT[3] = {0, L.wpkT1, L.wpkT2}, yo[3] = {0, L.y1, L.y2}, bo[3] = {0, L.bn1, L.bn2};
-    const size_t pin[3] = {0, L.p0, L.p1}, gacc[3] = {0, W.gluacc1, W.gluacc2};
+    const size_t pin[3] = {0, L.p0, L.p1}, gacc[3] = {0, W.gluacc1, W.gluacc2}, mo[3] = {L.mask0, L.mask1, L.mask2};
     const size_t dzo[3] = {0, W.dz1, W.dz2}, dpo[3] = {W.dp0, W.dp1, W.dp2};
     const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};
     // one memset for every fp64 accumulator of the conv-block backward
     SED_CHECK_HIP(hipMemsetAsync(WSD(W.bwd_acc), 0, (2 * 4288 + 2 * 64 * 10) * sizeof(double), st));
     for (int i = 2; i >= 1; --i) {
         SED_TRY(launch_glu_pool_bwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], WSF(dpo[i]),
-                                    WSF(dzo[i]), WSD(gacc[i]), 0, g.B, Hs[i], Wd[i], i, use_drop, g.p, seed_dev, st));
+                                    WSF(dzo[i]), WSD(gacc[i]), 0, g.B, Hs[i], Wd[i], i, use_drop, g.p, CTXM(mo[i]), st));
         SED_TRY(launch_bn_bwd_prep(WSD(gacc[i]), (double)g.B * Hs[i] * Wd[i], params + P.bn_g[i], CTXF(bo[i]), WSF(W.coef),
                                    grads + P.bn_g[i], grads + P.bn_b[i], grads + P.glu_w[i], grads + P.glu_b[i],
                                    grads + P.conv_b[i], st));
@@ -309,7 +314,7 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
     }
     // ---- conv block 0 ---------------------------------------------------------------------------
     SED_TRY(launch_blk0_backward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
-                                 params + P.glu_w[0], seed_dev, CTXD(L.mom0), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0),
+                                 params + P.glu_w[0], CTXM(L.mask0), CTXD(L.mom0), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0),
                                  WSF(W.dp0), WSD(W.de0), 0, grads + P.conv_w[0], grads + P.conv_b[0], grads + P.bn_g[0],
                                  grads + P.bn_b[0], grads + P.glu_w[0], grads + P.glu_b[0], st));
     return SED_OK;
@@ -332,7 +337,8 @@ extern "C" int sed_kernel_replay(const char* name, const sed_dims* d, const floa
     const int use_drop = (g.p > 0.f) ? 1 : 0;
     const int BT = g.B * g.T3;
     const size_t wpk[3] = {0, L.wpk1, L.wpk2}, wpkT[3] = {0, L.wpkT1, L.wpkT2}, yo[3] = {0, L.y1, L.y2},
-                 so[3] = {0, L.stat1, L.stat2}, bo[3] = {0, L.bn1, L.bn2}, po[3] = {L.p0, L.p1, L.p2};
+                 so[3] = {0, L.stat1, L.stat2}, bo[3] = {0, L.bn1, L.bn2}, po[3] = {L.p0, L.p1, L.p2},
+                 mo[3] = {L.mask0, L.mask1, L.mask2};
     const size_t dzo[3] = {0, W.dz1, W.dz2}, dpo[3] = {W.dp0, W.dp1, W.dp2}, gacc[3] = {0, W.gluacc1, W.gluacc2};
     const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};
     auto is = [&](const char* n) { return strcmp(name, n) == 0; };
@@ -341,16 +347,17 @@ extern "C" int sed_kernel_replay(const char* name, const sed_dims* d, const floa
         (void)tpc;
         return launch_blk0_forward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
                                    params + P.glu_w[0], params + P.glu_b[0], WSF(W.coef), WSF(W.coef) + 64, nullptr, 1, 0,
-                                   seed_dev, CTXD(L.mom0), 1, CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), CTXF(L.p0), st);
+                                   seed_dev, CTXD(L.mom0), 1, CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), CTXF(L.p0),
+                                   use_drop ? CTXM(L.mask0) : nullptr, st);
     }
     for (int i = 1; i <= 2; ++i) {
         char nm[32];
         snprintf(nm, sizeof nm, "conv%d_fwd", i);
         if (is(nm)) return launch_conv_fwd(CTXF(po[i - 1]), CTXF(wpk[i]), params + P.conv_b[i], CTXF(yo[i]), CTXD(so[i]), 1, g.B, Hs[i], Wd[i], st);
         snprintf(nm, sizeof nm, "glu%d_fwd", i);
-        if (is(nm)) return launch_glu_pool_fwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], CTXF(po[i]), g.B, Hs[i], Wd[i], i, use_drop, g.p, seed_dev, st);
+        if (is(nm)) return launch_glu_pool_fwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], CTXF(po[i]), g.B, Hs[i], Wd[i], i, use_drop, g.p, seed_dev, use_drop ? CTXM(mo[i]) : nullptr, st);
         snprintf(nm, sizeof nm, "glu%d_bwd", i);
-        if (is(nm)) return launch_glu_pool_bwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], WSF(dpo[i]), WSF(dzo[i]), WSD(gacc[i]), 1, g.B, Hs[i], Wd[i], i, use_drop, g.p, seed_dev, st);
+        if (is(nm)) return launch_glu_pool_bwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], WSF(dpo[i]), WSF(dzo[i]), WSD(gacc[i]), 1, g.B, Hs[i], Wd[i], i, use_drop, g.p, CTXM(mo[i]), st);
         snprintf(nm, sizeof nm, "conv%d_wgrad", i);
         if (is(nm)) return launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef), CTXF(po[i - 1]), WSF(W.wg_part), W.wgrad_blocks, grads + P.conv_w[i], g.B, Hs[i], Wd[i], st);
         snprintf(nm, sizeof nm, "conv%d_dgrad", i);
@@ -369,7 +376,7 @@ extern "C" int sed_kernel_replay(const char* name, const sed_dims* d, const floa
                                 use_drop, g.p, seed_dev, st);
     if (is("blk0_bwd"))
         return launch_blk0_backward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
-                                    params + P.glu_w[0], seed_dev, CTXD(L.mom0), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), WSF(W.dp0),
+                                    params + P.glu_w[0], CTXM(L.mask0), CTXD(L.mom0), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), WSF(W.dp0),
                                     WSD(W.de0), 1, grads + P.conv_w[0], grads + P.conv_b[0], grads + P.bn_g[0], grads + P.bn_b[0],
                                     grads + P.glu_w[0], grads + P.glu_b[0], st);
     (void)BT;

@@ -33,10 +33,16 @@ __global__ __launch_bounds__(192) void k_gru_fwd(const float* __restrict__ gi, c
     const float bh = (dir ? b_hh_r : b_hh_f)[g];
     if (g < 64) hs[g] = 0.f;
     float hprev = 0.f;
+    // gi of the NEXT step is fetched one iteration ahead: its HBM/L2 latency hides under this step
+    float gi_next = gi[((size_t)(b * T + (dir ? T - 1 : 0)) * 2 + dir) * 192 + g];
     __syncthreads();
     for (int step = 0; step < T; ++step) {
         const int t = dir ? (T - 1 - step) : step;
-        const float giv = gi[((size_t)(b * T + t) * 2 + dir) * 192 + g];
+        const float giv = gi_next;
+        if (step + 1 < T) {
+            const int tn = dir ? (T - 2 - step) : (step + 1);
+            gi_next = gi[((size_t)(b * T + tn) * 2 + dir) * 192 + g];
+        }
         float a0 = bh, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
         for (int j = 0; j < 64; j += 4) {
@@ -80,14 +86,22 @@ __global__ __launch_bounds__(192) void k_gru_bwd(const float* __restrict__ d_out
 #pragma unroll
     for (int i = 0; i < 64; ++i) wt[i] = whh[(part * 64 + i) * 64 + j];
     float dh_carry = 0.f, dh_z = 0.f;
+    // operands of the NEXT step are fetched one iteration ahead (tid < 64 only)
+    float n_do = 0.f, n_r = 0.f, n_z = 0.f, n_n = 0.f, n_g = 0.f, n_hp = 0.f;
+    auto fetch = [&](int t) {
+        n_do = d_out[(size_t)(b * T + t) * 128 + dir * 64 + j];
+        const float* gs = gates + ((size_t)(b * T + t) * 2 + dir) * 256;
+        n_r = gs[j]; n_z = gs[64 + j]; n_n = gs[128 + j]; n_g = gs[192 + j];
+        const int tp = dir ? t + 1 : t - 1;
+        n_hp = (tp >= 0 && tp < T) ? out[(size_t)(b * T + tp) * 128 + dir * 64 + j] : 0.f;
+    };
+    if (tid < 64) fetch(dir ? 0 : T - 1);
     for (int step = 0; step < T; ++step) {
         const int t = dir ? step : (T - 1 - step);
         if (tid < 64) {
-            const float dh = d_out[(size_t)(b * T + t) * 128 + dir * 64 + j] + dh_carry;
-            const float* gs = gates + ((size_t)(b * T + t) * 2 + dir) * 256;
-            const float r = gs[j], z = gs[64 + j], nn = gs[128 + j], ghn = gs[192 + j];
-            const int tp = dir ? t + 1 : t - 1;
-            const float hp = (tp >= 0 && tp < T) ? out[(size_t)(b * T + tp) * 128 + dir * 64 + j] : 0.f;
+            const float dh = n_do + dh_carry;
+            const float r = n_r, z = n_z, nn = n_n, ghn = n_g, hp = n_hp;
+            if (step + 1 < T) fetch(dir ? step + 1 : T - 2 - step);
             const float dn_pre = dh * (1.0f - z) * (1.0f - nn * nn);
             const float dz_pre = dh * (hp - nn) * z * (1.0f - z);
             const float dr_pre = dn_pre * ghn * r * (1.0f - r);

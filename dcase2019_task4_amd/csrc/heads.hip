@@ -12,21 +12,22 @@
 #include "philox.h"
 #include "kernels.h"
 
-#define HD_TC 32      // frames per chunk
+#define HD_TC 128     // frames per chunk (one chunk covers T/8 <= 128, i.e. clips up to 1024 frames)
+#define HD_THREADS 1024
 #define HD_F 128      // 2 * hidden
 #define HD_FS 129     // padded row stride
 #define HD_MAXO 32    // 2 * max nclass
 
 __device__ __forceinline__ float rnn_drop(float v, int use_drop, size_t e, uint64_t seed, uint32_t thr, float ks) {
     if (!use_drop) return v;
-    const u32x4 o = philox_stream((uint32_t)(e >> 3), 8u, seed);
-    return (philox_hw(o, (int)(e & 7)) >= thr) ? v * ks : 0.f;
+    const u32x4 o = philox_stream((uint32_t)(e >> 4), 8u, seed);
+    return (philox_byte(o, (int)(e & 15)) >= thr) ? v * ks : 0.f;
 }
 
 // loads a chunk of frames (dropout applied) and both weight matrices into LDS
 __device__ __forceinline__ void heads_stage(const float* __restrict__ h, float* xs, int b, int T, int t0, int use_drop,
                                             uint64_t seed, uint32_t thr, float ks, int tid) {
-    for (int e = tid; e < HD_TC * HD_F; e += 256) {
+    for (int e = tid; e < HD_TC * HD_F; e += HD_THREADS) {
         const int tl = e >> 7, f = e & 127, t = t0 + tl;
         float v = 0.f;
         if (t < T) {
@@ -37,24 +38,27 @@ __device__ __forceinline__ void heads_stage(const float* __restrict__ h, float* 
     }
 }
 
-__global__ __launch_bounds__(256) void k_heads_fwd(const float* __restrict__ h, const float* __restrict__ wd,
+__global__ __launch_bounds__(HD_THREADS) void k_heads_fwd(const float* __restrict__ h, const float* __restrict__ wd,
                                                     const float* __restrict__ bd, const float* __restrict__ ws,
                                                     const float* __restrict__ bs, float* __restrict__ strong,
                                                     float* __restrict__ weak, float* __restrict__ strong_sv,
                                                     float* __restrict__ weak_sv, float* __restrict__ logits_s,
                                                     float* __restrict__ den_out, int T, int NC, int use_drop, float p_drop,
                                                     const uint64_t* __restrict__ seed_ptr) {
-    __shared__ float xs[HD_TC * HD_FS];
-    __shared__ float wsm[HD_MAXO * HD_FS];
-    __shared__ float lg[HD_TC * HD_MAXO];
-    __shared__ float nums[HD_TC][16], dens[HD_TC][16];
-    __shared__ float num_acc[16], den_acc[16];
+    extern __shared__ __attribute__((aligned(16))) float hsm[];
+    float* xs = hsm;                                   // [HD_TC][HD_FS]
+    float* wsm = xs + HD_TC * HD_FS;                   // [HD_MAXO][HD_FS]
+    float* lg = wsm + HD_MAXO * HD_FS;                 // [HD_TC][HD_MAXO]
+    float (*nums)[16] = (float (*)[16])(lg + HD_TC * HD_MAXO);
+    float (*dens)[16] = (float (*)[16])(lg + HD_TC * HD_MAXO + HD_TC * 16);
+    float* num_acc = lg + HD_TC * HD_MAXO + 2 * HD_TC * 16;
+    float* den_acc = num_acc + 16;
     const int tid = threadIdx.x, b = blockIdx.x;
     const uint64_t seed = use_drop ? seed_ptr[0] : 0ull;
-    const uint32_t thr = drop_thresh16(p_drop);
-    const float ks = use_drop ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const uint32_t thr = drop_thresh8(p_drop);
+    const float ks = use_drop ? drop_scale8(p_drop) : 1.0f;
     const int NO = 2 * NC;
-    for (int e = tid; e < NO * HD_F; e += 256) {
+    for (int e = tid; e < NO * HD_F; e += HD_THREADS) {
         const int o = e >> 7, f = e & 127;
         wsm[o * HD_FS + f] = (o < NC) ? wd[o * HD_F + f] : ws[(o - NC) * HD_F + f];
     }
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(256) void k_heads_fwd(const float* __restrict__ h, 
         __syncthreads();
         heads_stage(h, xs, b, T, t0, use_drop, seed, thr, ks, tid);
         __syncthreads();
-        for (int e = tid; e < HD_TC * NO; e += 256) {
+        for (int e = tid; e < HD_TC * NO; e += HD_THREADS) {
             const int tl = e / NO, o = e % NO;
             float a = (o < NC) ? bd[o] : bs[o - NC];
             const float* xr = xs + tl * HD_FS;
@@ -114,23 +118,25 @@ __global__ __launch_bounds__(256) void k_heads_fwd(const float* __restrict__ h, 
 
 // part row layout (matches the flat parameter order dense.weight, dense.bias, dense_softmax.weight,
 // dense_softmax.bias): [NC*128 dWd][NC dbd][NC*128 dWs][NC dbs]
-__global__ __launch_bounds__(256) void k_heads_bwd(const float* __restrict__ h, const float* __restrict__ wd,
+__global__ __launch_bounds__(HD_THREADS) void k_heads_bwd(const float* __restrict__ h, const float* __restrict__ wd,
                                                     const float* __restrict__ ws, const float* __restrict__ strong,
                                                     const float* __restrict__ weak, const float* __restrict__ logits_s,
                                                     const float* __restrict__ den, const float* __restrict__ d_strong,
                                                     const float* __restrict__ d_weak, float* __restrict__ dh,
                                                     float* __restrict__ part, int T, int NC, int use_drop, float p_drop,
                                                     const uint64_t* __restrict__ seed_ptr) {
-    __shared__ float xs[HD_TC * HD_FS];
-    __shared__ float wsm[HD_MAXO * HD_FS];
-    __shared__ float dl[HD_TC * HD_MAXO];
-    __shared__ float dnum[16], dden[16];
+    extern __shared__ __attribute__((aligned(16))) float hsm[];
+    float* xs = hsm;                                   // [HD_TC][HD_FS]
+    float* wsm = xs + HD_TC * HD_FS;                   // [HD_MAXO][HD_FS]
+    float* dl = wsm + HD_MAXO * HD_FS;                 // [HD_TC][HD_MAXO]
+    float* dnum = dl + HD_TC * HD_MAXO;
+    float* dden = dnum + 16;
     const int tid = threadIdx.x, b = blockIdx.x;
     const uint64_t seed = use_drop ? seed_ptr[0] : 0ull;
-    const uint32_t thr = drop_thresh16(p_drop);
-    const float ks = use_drop ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const uint32_t thr = drop_thresh8(p_drop);
+    const float ks = use_drop ? drop_scale8(p_drop) : 1.0f;
     const int NO = 2 * NC;
-    for (int e = tid; e < NO * HD_F; e += 256) {
+    for (int e = tid; e < NO * HD_F; e += HD_THREADS) {
         const int o = e >> 7, f = e & 127;
         wsm[o * HD_FS + f] = (o < NC) ? wd[o * HD_F + f] : ws[(o - NC) * HD_F + f];
     }
@@ -140,9 +146,9 @@ __global__ __launch_bounds__(256) void k_heads_bwd(const float* __restrict__ h, 
         dden[tid] = -dw * weak[b * NC + tid] / dn;
     }
     // weight-gradient accumulators: outputs e = tid + 256*i over [NO][128]
-    float wacc[(HD_MAXO * HD_F) / 256];
+    float wacc[(HD_MAXO * HD_F) / HD_THREADS];
 #pragma unroll
-    for (int i = 0; i < (HD_MAXO * HD_F) / 256; ++i) wacc[i] = 0.f;
+    for (int i = 0; i < (HD_MAXO * HD_F) / HD_THREADS; ++i) wacc[i] = 0.f;
     float bacc = 0.f;    // thread o < NO
     for (int t0 = 0; t0 < T; t0 += HD_TC) {
         __syncthreads();
@@ -176,8 +182,8 @@ __global__ __launch_bounds__(256) void k_heads_bwd(const float* __restrict__ h, 
         __syncthreads();
         // dW[o][f] += sum_t dl[t][o] * x[t][f]
 #pragma unroll
-        for (int i = 0; i < (HD_MAXO * HD_F) / 256; ++i) {
-            const int e = tid + 256 * i, o = e >> 7, f = e & 127;
+        for (int i = 0; i < (HD_MAXO * HD_F) / HD_THREADS; ++i) {
+            const int e = tid + HD_THREADS * i, o = e >> 7, f = e & 127;
             if (o < NO) {
                 float a = 0.f;
                 for (int tl = 0; tl < HD_TC; ++tl) a = fmaf(dl[tl * HD_MAXO + o], xs[tl * HD_FS + f], a);
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(256) void k_heads_bwd(const float* __restrict__ h, 
             bacc += a;
         }
         // dx[t][f] = (sum_o dl[t][o] W[o][f]) * mask
-        for (int e = tid; e < HD_TC * HD_F; e += 256) {
+        for (int e = tid; e < HD_TC * HD_F; e += HD_THREADS) {
             const int tl = e >> 7, f = e & 127, t = t0 + tl;
             if (t < T) {
                 float a = 0.f;
@@ -202,8 +208,8 @@ __global__ __launch_bounds__(256) void k_heads_bwd(const float* __restrict__ h, 
     }
     float* pr = part + (size_t)b * (2 * (NC * HD_F + NC));
 #pragma unroll
-    for (int i = 0; i < (HD_MAXO * HD_F) / 256; ++i) {
-        const int e = tid + 256 * i, o = e >> 7, f = e & 127;
+    for (int i = 0; i < (HD_MAXO * HD_F) / HD_THREADS; ++i) {
+        const int e = tid + HD_THREADS * i, o = e >> 7, f = e & 127;
         if (o < NC) pr[o * HD_F + f] = wacc[i];
         else if (o < NO) pr[NC * HD_F + NC + (o - NC) * HD_F + f] = wacc[i];
     }
@@ -286,8 +292,14 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_mt_loss(const float* __restric
 int launch_heads_fwd(const float* h, const float* wd, const float* bd, const float* ws, const float* bs, float* strong,
                      float* weak, float* strong_sv, float* weak_sv, float* logits_s, float* den, int B, int T, int NC,
                      int use_drop, float p_drop, const uint64_t* seed, hipStream_t st) {
-    k_heads_fwd<<<B, 256, 0, st>>>(h, wd, bd, ws, bs, strong, weak, strong_sv, weak_sv, logits_s, den, T, NC, use_drop, p_drop,
-                                   seed);
+    const size_t lds = (size_t)(HD_TC * HD_FS + HD_MAXO * HD_FS + HD_TC * HD_MAXO + 2 * HD_TC * 16 + 32) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_heads_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    k_heads_fwd<<<B, HD_THREADS, lds, st>>>(h, wd, bd, ws, bs, strong, weak, strong_sv, weak_sv, logits_s, den, T, NC, use_drop,
+                                            p_drop, seed);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
@@ -297,8 +309,14 @@ int launch_heads_bwd(const float* h, const float* wd, const float* ws, const flo
                      float* part, float* g_wd, float* g_bd, float* g_ws, float* g_bs, int B, int T, int NC, int use_drop,
                      float p_drop, const uint64_t* seed, hipStream_t st) {
     (void)g_bd; (void)g_ws; (void)g_bs;
-    k_heads_bwd<<<B, 256, 0, st>>>(h, wd, ws, strong, weak, logits_s, den, d_strong, d_weak, dh, part, T, NC, use_drop,
-                                   p_drop, seed);
+    const size_t lds = (size_t)(HD_TC * HD_FS + HD_MAXO * HD_FS + HD_TC * HD_MAXO + 32) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_heads_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    k_heads_bwd<<<B, HD_THREADS, lds, st>>>(h, wd, ws, strong, weak, logits_s, den, d_strong, d_weak, dh, part, T, NC, use_drop,
+                                            p_drop, seed);
     SED_CHECK_LAUNCH();
     // dense.weight, dense.bias, dense_softmax.weight, dense_softmax.bias are contiguous in the flat layout
     return launch_colsum(part, B, 2 * (NC * HD_F + NC), 2 * (NC * HD_F + NC), g_wd, st);

@@ -7,9 +7,9 @@
 int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const float* b0, const float* gamma,
                         const float* beta, const float* wglu, const float* bglu, float* run_mean, float* run_var,
                         int64_t* tracked, int train, int update, const uint64_t* seed, double* mom, int zero_mom,
-                        float* wz, float* wl, float* bn, float* p0, hipStream_t st);
+                        float* wz, float* wl, float* bn, float* p0, uint16_t* mask_out, hipStream_t st);
 int launch_blk0_backward(const Geo& g, const float* x, const float* w0, const float* b0, const float* gamma,
-                         const float* beta, const float* wglu, const uint64_t* seed, const double* mom,
+                         const float* beta, const float* wglu, const uint16_t* mask_in, const double* mom,
                          const float* wz, const float* wl, const float* bn, const float* dp0, double* de, int zero_de,
                          float* g_w0, float* g_b0, float* g_gamma, float* g_beta, float* g_wglu, float* g_bglu,
                          hipStream_t st);
@@ -31,12 +31,13 @@ int launch_conv_wgrad(const float* dz, const float* yin, const float* coef, cons
 int launch_bn_prep(const double* stat, double N, const float* gamma, const float* beta, float* run_mean, float* run_var,
                    int64_t* tracked, int train, int update, float eps, float momentum, float* bn /*[4][64]*/, hipStream_t st);
 int launch_glu_pool_fwd(const float* y, const float* bn, const float* wglu, const float* bglu, float* p, int B, int H,
-                        int W, int block_id, int use_drop, float p_drop, const uint64_t* seed, hipStream_t st);
+                        int W, int block_id, int use_drop, float p_drop, const uint64_t* seed, uint16_t* mask_out,
+                        hipStream_t st);
 // backward pass 1: dz (full-res grad wrt BN output), GLU weight grads and BN reduction sums
 //   acc: double [64*64 (dWglu) + 64 (dbglu) + 64 (sum dz) + 64 (sum dz*y)]
 int launch_glu_pool_bwd(const float* y, const float* bn, const float* wglu, const float* bglu, const float* dp, float* dz,
                         double* acc, int zero_acc, int B, int H, int W, int block_id, int use_drop, float p_drop,
-                        const uint64_t* seed, hipStream_t st);
+                        const uint16_t* mask_in, hipStream_t st);
 // backward pass 1b: write GLU grads, BN grads and the coefficients of dy = ca*dz + cb*y + cc
 int launch_bn_bwd_prep(const double* acc, double N, const float* gamma, const float* bn, float* coef, float* g_gamma,
                        float* g_beta, float* g_wglu, float* g_bglu, float* g_convb, hipStream_t st);

@@ -28,12 +28,22 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
     return r;
 }
 
-// 8 x 16-bit uniforms for (index, stream): halfword i = (word[i>>1] >> 16*(i&1)) & 0xffff
+// 16 x 8-bit uniforms for (index, stream): byte i = (word[i>>2] >> 8*(i&3)) & 0xff.
+// keep(byte) = byte >= thresh8(p) with thresh8 = round(p * 256); kept values are scaled by
+// 256 / (256 - thresh8)  (the exact keep probability of the 8-bit draw; p = 0.5 and 0.25 are exact).
 __device__ __forceinline__ u32x4 philox_stream(uint32_t index, uint32_t stream, uint64_t seed) {
     return philox4x32_10(index, 0u, stream, PHILOX_TAG, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
-__device__ __forceinline__ uint32_t philox_hw(const u32x4& o, int i) {
-    uint32_t w = (i >> 1) == 0 ? o.x : (i >> 1) == 1 ? o.y : (i >> 1) == 2 ? o.z : o.w;
-    return (w >> (16 * (i & 1))) & 0xffffu;
+__device__ __forceinline__ uint32_t philox_byte(const u32x4& o, int i) {
+    uint32_t w = (i >> 2) == 0 ? o.x : (i >> 2) == 1 ? o.y : (i >> 2) == 2 ? o.z : o.w;
+    return (w >> (8 * (i & 3))) & 0xffu;
 }
-__device__ __forceinline__ uint32_t drop_thresh16(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
+__device__ __forceinline__ uint32_t drop_thresh8(float p) { return (uint32_t)(p * 256.0f + 0.5f); }
+__device__ __forceinline__ float drop_scale8(float p) { return 256.0f / (256.0f - (float)drop_thresh8(p)); }
+// 16 keep bits (bit i = byte i kept) of one draw
+__device__ __forceinline__ uint32_t philox_keep16(const u32x4& o, uint32_t thr) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m |= (philox_byte(o, i) >= thr ? 1u : 0u) << i;
+    return m;
+}

@@ -11,15 +11,16 @@ Stream definition (mirrored in dcase2019_task4_amd/csrc/philox.h):
 
   key      = (seed & 0xffffffff, seed >> 32)
   counter  = (index, 0, stream_id, 0x5ED0)
-  out[4]   = philox4x32_10(counter, key);  halfword i (0..7) = (out[i>>1] >> (16*(i&1))) & 0xffff
-  keep(hw) = hw >= round(p * 65536);  kept values are scaled by 1/(1-p)
+  out[4]   = philox4x32_10(counter, key);  byte i (0..15) = (out[i>>2] >> (8*(i&3))) & 0xff
+  keep(b)  = b >= thr, thr = round(p * 256);  kept values are scaled by 256/(256 - thr)
+             (the exact keep probability of an 8-bit draw; p = 0.5, 0.25 are represented exactly)
 
 * conv-block dropout, block l (0,1,2), tensor laid out [B][H][W][C] with a (2,4) pooling window
   behind it:  q = (b*Ho + h//2)*Wo + w//4,  dt = h & 1,  df = w & 3,
-              index = (q >> 1)*C + c,  stream_id = 2*l + dt,  halfword = (q & 1)*4 + df.
+              index = (q >> 2)*C + c,  stream_id = 2*l + dt,  byte = (q & 3)*4 + df.
   Rows h >= 2*Ho (odd H, dropped by the floor-mode pool) get no mask (value irrelevant; 0 here).
-* recurrent-output dropout, tensor [B][T][2H] flattened to e: index = e >> 3, stream_id = 8,
-  halfword = e & 7.
+* recurrent-output dropout, tensor [B][T][2H] flattened to e: index = e >> 4, stream_id = 8,
+  byte = e & 15.
 * teacher noise, tensor [frames][n_mels] flattened to e per clip b: two 32-bit uniforms from
   index = (b*frames*n_mels + e) >> 1, stream_id = 16, words (2*(e&1), 2*(e&1)+1) ->
   Box-Muller normal -> |0.25 * n|.
@@ -66,37 +67,44 @@ def _key(seed):
     return seed & 0xFFFFFFFF, seed >> 32
 
 
-def _halfwords(index, stream_id, seed):
+def _bytes(index, stream_id, seed):
     k0, k1 = _key(seed)
     o = philox4x32_10(index, 0, np.uint32(stream_id), np.uint32(TAG), k0, k1)
-    hw = np.empty(index.shape + (8,), dtype=np.uint32)
-    for i in range(8):
-        hw[..., i] = (o[i >> 1] >> np.uint32(16 * (i & 1))) & np.uint32(0xFFFF)
-    return hw
+    by = np.empty(index.shape + (16,), dtype=np.uint32)
+    for i in range(16):
+        by[..., i] = (o[i >> 2] >> np.uint32(8 * (i & 3))) & np.uint32(0xFF)
+    return by
 
 
-def thresh16(p):
-    return int(round(float(p) * 65536.0))
+def thresh8(p):
+    return int(float(p) * 256.0 + 0.5)
+
+
+def keep_scale(p):
+    return np.float32(256.0) / np.float32(256.0 - thresh8(p))
 
 
 def dropout_mask_pooled(seed, block, B, H, W, C, p):
-    """Mask for conv-block ``block`` in NHWC [B,H,W,C] float32: 0 or 1/(1-p)."""
+    """Mask for conv-block ``block`` in NHWC [B,H,W,C] float32: 0 or 256/(256-thr)."""
     if p <= 0.0:
         return np.ones((B, H, W, C), dtype=np.float32)
     Ho, Wo = H // 2, W // 4
-    b, h, w, c = np.meshgrid(np.arange(B), np.arange(2 * Ho), np.arange(4 * Wo), np.arange(C), indexing="ij")
-    q = (b * Ho + h // 2) * Wo + w // 4
-    dt = h & 1
-    df = w & 3
-    index = ((q >> 1) * C + c).astype(np.uint32)
-    sel = (q & 1) * 4 + df
     out = np.zeros((B, H, W, C), dtype=np.float32)
-    keep = np.zeros(index.shape, dtype=bool)
+    # one Philox draw per (row block of 4 pooled pixels, channel, dt): 16 bytes = 4 pooled x 4 df
+    Q = B * Ho * Wo
+    nrb = (Q + 3) // 4
+    rb, c = np.meshgrid(np.arange(nrb), np.arange(C), indexing="ij")
+    index = (rb * C + c).astype(np.uint32)
+    thr = thresh8(p)
+    keepv = keep_scale(p)
+    res = np.zeros((B * Ho * Wo, 2, 4, C), dtype=np.float32)               # [q, dt, df, c]
     for d in (0, 1):
-        m = dt == d
-        hw = _halfwords(index[m], 2 * block + d, seed)
-        keep[m] = np.take_along_axis(hw, sel[m][:, None], axis=1)[:, 0] >= thresh16(p)
-    out[:, : 2 * Ho, : 4 * Wo, :] = keep.astype(np.float32) / np.float32(1.0 - p)
+        by = _bytes(index, 2 * block + d, seed)                              # [nrb, C, 16]
+        keep = (by >= thr).astype(np.float32) * keepv
+        keep = keep.reshape(nrb, C, 4, 4).transpose(0, 2, 3, 1).reshape(nrb * 4, 4, C)[:Q]   # [q, df, c]
+        res[:, d] = keep
+    res = res.reshape(B, Ho, Wo, 2, 4, C).transpose(0, 1, 3, 2, 4, 5).reshape(B, 2 * Ho, 4 * Wo, C)
+    out[:, : 2 * Ho, : 4 * Wo, :] = res
     return out
 
 
@@ -105,10 +113,9 @@ def dropout_mask_flat(seed, stream_id, shape, p):
     n = int(np.prod(shape))
     if p <= 0.0:
         return np.ones(shape, dtype=np.float32)
-    e = np.arange(n)
-    hw = _halfwords((e >> 3).astype(np.uint32), stream_id, seed)
-    keep = hw[np.arange(n), e & 7] >= thresh16(p)
-    return (keep.astype(np.float32) / np.float32(1.0 - p)).reshape(shape)
+    ncall = (n + 15) // 16
+    by = _bytes(np.arange(ncall, dtype=np.uint32), stream_id, seed).reshape(-1)[:n]
+    return ((by >= thresh8(p)).astype(np.float32) * keep_scale(p)).reshape(shape)
 
 
 def teacher_noise(seed, B, frames, n_mels, std=0.25):

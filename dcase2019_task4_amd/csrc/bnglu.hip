@@ -90,14 +90,17 @@ __global__ __launch_bounds__(256) void k_glu_pool_fwd(const float* __restrict__ 
                                                        int block_id, int use_drop, float p_drop,
                                                        const uint64_t* __restrict__ seed_ptr, uint16_t* __restrict__ mask_out) {
     __shared__ float zts[4][32 * ZS];
+    __shared__ float WsT[64 * ZS];     // Wglu transposed [c][co], stride 65: coalesced global read, conflict-free both ways
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
     float* zt = zts[wv];
+    for (int e = tid; e < 4096; e += 256) WsT[(e & 63) * ZS + (e >> 6)] = wglu[e];
+    __syncthreads();
     float bw[32][2];
 #pragma unroll
     for (int s = 0; s < 32; ++s) {
-        bw[s][0] = wglu[n * 64 + 2 * s + kh];
-        bw[s][1] = wglu[(32 + n) * 64 + 2 * s + kh];
+        bw[s][0] = WsT[(2 * s + kh) * ZS + n];            // B[k = c][j = co] = Wglu[co][c]
+        bw[s][1] = WsT[(2 * s + kh) * ZS + 32 + n];
     }
     const float bg[2] = {bglu[n], bglu[32 + n]};
     const uint64_t seed = use_drop ? seed_ptr[0] : 0ull;
@@ -154,15 +157,18 @@ __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
+    float* WsT = smem + 4 * (3 * 32 * ZS);               // Wglu transposed [c][co], stride 65
     float* zt = smem + wv * (3 * 32 * ZS);
     float* yt = zt + 32 * ZS;
     float* dlt = yt + 32 * ZS;
+    for (int e = tid; e < 4096; e += 256) WsT[(e & 63) * ZS + (e >> 6)] = wglu[e];
+    __syncthreads();
     float bw[32][2], bwT[32][2];
 #pragma unroll
     for (int s = 0; s < 32; ++s) {
-        bw[s][0] = wglu[n * 64 + 2 * s + kh];            // B[k=c][j=co]  = Wglu[co][c]
-        bw[s][1] = wglu[(32 + n) * 64 + 2 * s + kh];
-        bwT[s][0] = wglu[(2 * s + kh) * 64 + n];         // B[k=co][j=c]  = Wglu[co][c]
+        bw[s][0] = WsT[(2 * s + kh) * ZS + n];           // B[k=c][j=co]  = Wglu[co][c]
+        bw[s][1] = WsT[(2 * s + kh) * ZS + 32 + n];
+        bwT[s][0] = wglu[(2 * s + kh) * 64 + n];         // B[k=co][j=c]  = Wglu[co][c]  (coalesced as is)
         bwT[s][1] = wglu[(2 * s + kh) * 64 + 32 + n];
     }
     const float bg[2] = {bglu[n], bglu[32 + n]};
@@ -324,7 +330,7 @@ int launch_glu_pool_fwd(const float* y, const float* bn, const float* wglu, cons
     const int Ho = H / 2, Wo = W / 4, Q = B * Ho * Wo;
     const int n_rb = (Q + 3) / 4;
     int grid = (n_rb + 3) / 4;
-    if (grid > 1024) grid = 1024;
+    if (grid > 512) grid = 512;
     k_glu_pool_fwd<<<grid, 256, 0, st>>>(y, bn, wglu, bglu, p, H, W, Ho, Wo, Q, block_id, use_drop, p_drop, seed, mask_out);
     SED_CHECK_LAUNCH();
     return SED_OK;
@@ -334,7 +340,7 @@ int launch_glu_pool_bwd(const float* y, const float* bn, const float* wglu, cons
                         double* acc, int zero_acc, int B, int H, int W, int block_id, int use_drop, float p_drop,
                         const uint16_t* mask_in, hipStream_t st) {
     const int Ho = H / 2, Wo = W / 4, Q = B * Ho * Wo;
-    const size_t lds = (size_t)4 * 3 * 32 * ZS * sizeof(float);
+    const size_t lds = (size_t)(4 * 3 * 32 * ZS + 64 * ZS) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_glu_pool_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -103,6 +103,11 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
 }
+// Workgroup barrier that only orders LDS traffic.  __syncthreads() also drains every outstanding
+// global load/store of the wave (s_waitcnt vmcnt(0), CDNA4 counts stores too), which puts the full
+// HBM/L2 write latency on the critical path of loops that store per iteration (GRU steps) or keep
+// prefetch loads in flight across the barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ float sigmoidf_fast(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // mfma_f32_32x32x2f32 fragment maps (cdna_hip_programming.md section 3):

@@ -28,7 +28,8 @@ struct ConvCfg {
     static constexpr int PS = 65;
     static constexpr int RS = HW * PS + (((TW - HW * PS) % 32) + 32) % 32;
     static constexpr int HALO_FLOATS = HH * RS;
-    static constexpr size_t LDS_BYTES = (size_t)HALO_FLOATS * 4;
+    static constexpr int W_FLOATS = 64 * 64;
+    static constexpr size_t LDS_BYTES = (size_t)(HALO_FLOATS + 2 * W_FLOATS) * 4;
 };
 
 __global__ void k_conv_pack(const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ wpk1,
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in0, 
     constexpr int TH = Cfg::TH, HW = Cfg::HW, HH = Cfg::HH, PS = Cfg::PS, RS = Cfg::RS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* halo = smem;
+    float* Ws = smem + Cfg::HALO_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
     const int b = blockIdx.x / tiles_per_clip, y0 = (blockIdx.x % tiles_per_clip) * TH;
@@ -87,6 +89,12 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in0, 
         float* dst = halo + hy * RS + hx * PS + c4;
         dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
     }
+    // ---- stage tap 0 weights ----------------------------------------------------------------
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int f = tid + 256 * it;
+        *(float4*)(Ws + f * 4) = *(const float4*)(wpk + f * 4);
+    }
     __syncthreads();
 
     const int m = 32 * wv + n;
@@ -96,35 +104,29 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in0, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 
-    // B fragments come straight from global/L2 into registers (the 16 KB per-tap slab is shared by
-    // every wave on the chip and lives in L1/L2): no LDS weight buffer, NO barrier in the main loop.
-    // Two half-tap register buffers (16 k-steps each) are software-pipelined against the MFMAs.
-    const float* Wl = wpk + kh * 64 + n;          // element [k = 2s + kh][n] of a tap slab is Wl[2s*64]
-    float bA[16][2], bB[16][2];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) { bA[s][0] = Wl[2 * s * 64]; bA[s][1] = Wl[2 * s * 64 + 32]; }
     for (int tap = 0; tap < 9; ++tap) {
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        const float* A = Ab + dy * RS + dx * PS;
-        const float* Wt = Wl + tap * 4096;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) { bB[s][0] = Wt[(32 + 2 * s) * 64]; bB[s][1] = Wt[(32 + 2 * s) * 64 + 32]; }
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float a = A[2 * s];
-            acc0 = mfma32(a, bA[s][0], acc0);
-            acc1 = mfma32(a, bA[s][1], acc1);
-        }
+        float4 pre[4];
         if (tap < 8) {
 #pragma unroll
-            for (int s = 0; s < 16; ++s) { bA[s][0] = Wt[4096 + 2 * s * 64]; bA[s][1] = Wt[4096 + 2 * s * 64 + 32]; }
+            for (int it = 0; it < 4; ++it) pre[it] = *(const float4*)(wpk + (tap + 1) * 4096 + (tid + 256 * it) * 4);
         }
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const float* A = Ab + dy * RS + dx * PS;
+        const float* Bw = Ws + (tap & 1) * 4096 + kh * 64 + n;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float a = A[32 + 2 * s];
-            acc0 = mfma32(a, bB[s][0], acc0);
-            acc1 = mfma32(a, bB[s][1], acc1);
+        for (int s = 0; s < 32; ++s) {
+            const float a = A[2 * s];
+            const float b0 = Bw[2 * s * 64];
+            const float b1 = Bw[2 * s * 64 + 32];
+            acc0 = mfma32(a, b0, acc0);
+            acc1 = mfma32(a, b1, acc1);
         }
+        if (tap < 8) {
+            float* Wn = Ws + ((tap + 1) & 1) * 4096;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) *(float4*)(Wn + (tid + 256 * it) * 4) = pre[it];
+        }
+        lds_barrier();
     }
 
     // ---- epilogue -----------------------------------------------------------------------------
@@ -143,8 +145,7 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in0, 
         }
     }
     if (MODE == 0 && stat != nullptr) {
-        __syncthreads();     // every wave is done reading the halo before it is reused as scratch
-        float* red = smem;
+        float* red = smem;   // reuse (all waves are past the last barrier of the main loop)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             float a = s1[h] + __shfl_xor(s1[h], 32);

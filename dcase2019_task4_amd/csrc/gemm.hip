@@ -17,7 +17,7 @@
 
 #define GT_M 64
 #define GT_N 64
-#define GT_K 16
+#define GT_K 32
 
 __device__ __forceinline__ int prob_nx(const GemmProb& p) { return p.N + (p.Cones ? 1 : 0); }
 
@@ -41,19 +41,25 @@ __global__ __launch_bounds__(256) void k_gemm_batched(GemmBatch gb) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int k0 = kbeg; k0 < kend; k0 += GT_K) {
+    // per-thread tile coordinates (fixed over the K loop); 8 A and 8 B elements per thread per tile
+    constexpr int NE = (GT_M * GT_K) / 256;
+    int am[NE], ak[NE], bk[NE], bn[NE];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int e = tid + 256 * it;
-            int m, k;
-            if (d.sAk == 1) { m = e >> 4; k = e & 15; } else { m = e & 63; k = e >> 6; }
+    for (int it = 0; it < NE; ++it) {
+        const int e = tid + 256 * it;
+        if (d.sAk == 1) { am[it] = e / GT_K; ak[it] = e % GT_K; } else { am[it] = e % GT_M; ak[it] = e / GT_M; }
+        if (d.sBn == 1) { bk[it] = e / GT_N; bn[it] = e % GT_N; } else { bk[it] = e % GT_K; bn[it] = e / GT_K; }
+    }
+    float ra[NE], rb[NE];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < NE; ++it) {
             float v = 0.f;
-            if (m0 + m < d.M && k0 + k < kend) v = d.A[(int64_t)(m0 + m) * d.sAm + (int64_t)(k0 + k) * d.sAk];
-            As[m * (GT_K + 1) + k] = v;
-            int kb, nb;
-            if (d.sBn == 1) { kb = e >> 6; nb = e & 63; } else { kb = e & 15; nb = e >> 4; }
+            if (m0 + am[it] < d.M && k0 + ak[it] < kend)
+                v = d.A[(int64_t)(m0 + am[it]) * d.sAm + (int64_t)(k0 + ak[it]) * d.sAk];
+            ra[it] = v;
             float w = 0.f;
-            const int kk = k0 + kb, nn = n0 + nb;
+            const int kk = k0 + bk[it], nn = n0 + bn[it];
             if (kk < kend) {
                 if (nn < d.N) {
                     w = (d.B2 && kk >= d.k2) ? d.B2[(int64_t)(kk - d.k2) * d.sBk + (int64_t)nn * d.sBn]
@@ -62,16 +68,25 @@ __global__ __launch_bounds__(256) void k_gemm_batched(GemmBatch gb) {
                     w = 1.0f;
                 }
             }
-            Bs[kb * (GT_N + 1) + nb] = w;
+            rb[it] = w;
         }
-        __syncthreads();
+    };
+    if (kbeg < kend) load_tile(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += GT_K) {
+#pragma unroll
+        for (int it = 0; it < NE; ++it) {
+            As[am[it] * (GT_K + 1) + ak[it]] = ra[it];
+            Bs[bk[it] * (GT_N + 1) + bn[it]] = rb[it];
+        }
+        lds_barrier();
+        if (k0 + GT_K < kend) load_tile(k0 + GT_K);      // next tile's loads fly under this tile's MFMAs
 #pragma unroll
         for (int s = 0; s < GT_K / 2; ++s) {
             const float a = As[(32 * wm + n) * (GT_K + 1) + 2 * s + kh];
             const float b = Bs[(2 * s + kh) * (GT_N + 1) + 32 * wn + n];
             acc = mfma32(a, b, acc);
         }
-        __syncthreads();
+        lds_barrier();
     }
     const int col = n0 + 32 * wn + n;
     if (col >= Nx) return;

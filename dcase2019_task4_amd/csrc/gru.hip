@@ -22,12 +22,15 @@ __global__ __launch_bounds__(192) void k_gru_fwd(const float* __restrict__ gi, c
     __shared__ __attribute__((aligned(16))) float hs[64];
     __shared__ float ghs[192];
     __shared__ float gis[192];
+    __shared__ __attribute__((aligned(16))) float Wl[192 * 68];   // W_hh staged coalesced; row stride 68: conflict-free b128 row reads
     const int b = blockIdx.x, dir = blockIdx.y, g = threadIdx.x;
     const float* whh = dir ? w_hh_r : w_hh_f;
+    for (int e = g; e < 192 * 64; e += 192) Wl[(e >> 6) * 68 + (e & 63)] = whh[e];
+    __syncthreads();
     float w[64];
 #pragma unroll
     for (int j = 0; j < 64; j += 4) {
-        const float4 v = *(const float4*)(whh + g * 64 + j);
+        const float4 v = *(const float4*)(Wl + g * 68 + j);
         w[j] = v.x; w[j + 1] = v.y; w[j + 2] = v.z; w[j + 3] = v.w;
     }
     const float bh = (dir ? b_hh_r : b_hh_f)[g];
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(192) void k_gru_fwd(const float* __restrict__ gi, c
         }
         ghs[g] = (a0 + a1) + (a2 + a3);
         gis[g] = giv;
-        __syncthreads();
+        lds_barrier();
         if (g < 64) {
             const float r = sigmoidf_fast(gis[g] + ghs[g]);
             const float z = sigmoidf_fast(gis[64 + g] + ghs[64 + g]);
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(192) void k_gru_fwd(const float* __restrict__ gi, c
             hs[g] = h;
             hprev = h;
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(192) void k_gru_bwd(const float* __restrict__ d_out
             hprev_out[((size_t)(b * T + t) * 2 + dir) * 64 + j] = hp;
             dh_z = dh * z;
         }
-        __syncthreads();
+        lds_barrier();
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
         for (int i = 0; i < 64; i += 4) {
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(192) void k_gru_bwd(const float* __restrict__ d_out
             a3 = fmaf(wt[i + 3], d4.w, a3);
         }
         parts[part][j] = (a0 + a1) + (a2 + a3);
-        __syncthreads();
+        lds_barrier();
         if (tid < 64) dh_carry = dh_z + parts[0][j] + parts[1][j] + parts[2][j];
     }
 }

@@ -52,6 +52,7 @@ _SIGS = {
     "sed_mel_spec": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_size_t, _P]),
     "sed_logmel_transform": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
     "sed_selftest": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "sed_debug_set": (C.c_int, [C.c_int]),
     "sed_kernel_replay": (C.c_int, [C.c_char_p, C.POINTER(SedDims), _P, _P, _P, _P, C.c_size_t, _P, _P, C.c_size_t, _P]),
 }
 
@@ -77,6 +78,8 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = l
+        if os.environ.get("SED_DEBUG"):          # timing experiments only (see sed_debug_set)
+            l.sed_debug_set(int(os.environ["SED_DEBUG"]))
     return _lib
 
 

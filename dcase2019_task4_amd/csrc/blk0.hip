@@ -26,7 +26,7 @@ __device__ __forceinline__ int gidx(int a, int b) { return 9 + a * 9 - (a * (a -
 
 // ---- patch moments: s[t] = sum_p P[p][t], G[a][b] = sum_p P[p][a] P[p][b] (upper triangle) ----
 #define MOM_ROWS 64
-__global__ __launch_bounds__(256) void k_x_moments(const float* __restrict__ x, int T, double* __restrict__ mom) {
+__global__ __launch_bounds__(256) void k_x_moments(const float* __restrict__ x, int T, double* __restrict__ mom, int no_atomic) {
     __shared__ float xs[(MOM_ROWS + 2) * XS_W];
     __shared__ float red[4][54];
     const int tid = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * MOM_ROWS;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void k_x_moments(const float* __restrict__ x, 
         if (lane == 0) red[wv][k] = v;
     }
     __syncthreads();
-    if (tid < 54) atomicAdd(&mom[tid], (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid]);
+    if (tid < 54 && !no_atomic) atomicAdd(&mom[tid], (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid]);
 }
 
 // ---- fold BN into the conv weights; update running stats --------------------------------------
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void k_blk0_bwd(const float* __restrict__ x, c
                                                    const float* __restrict__ wl, const float* __restrict__ dp0, int B,
                                                    int T, int H1, int tiles_per_clip, int n_tiles, int use_drop,
                                                    float p_drop, const uint16_t* __restrict__ mask_in,
-                                                   double* __restrict__ de /* [2][64][10] */) {
+                                                   double* __restrict__ de /* [2][64][10] */, int no_atomic) {
     __shared__ float xs[XS_H * XS_W];
     __shared__ __attribute__((aligned(16))) float P[4][32 * 12];
     __shared__ float red[4][2][2][32][10];
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void k_blk0_bwd(const float* __restrict__ x, c
         const int h = c >> 5, nn = c & 31;
         double v = (double)red[0][which][h][nn][t] + (double)red[1][which][h][nn][t] + (double)red[2][which][h][nn][t] +
                    (double)red[3][which][h][nn][t];
-        atomicAdd(&de[i], v);
+        if (!no_atomic) atomicAdd(&de[i], v);
     }
 }
 
@@ -384,7 +384,7 @@ int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const flo
     if (train) {
         if (zero_mom) SED_CHECK_HIP(hipMemsetAsync(mom, 0, 64 * sizeof(double), st));
         dim3 grid((g.T + MOM_ROWS - 1) / MOM_ROWS, g.B);
-        k_x_moments<<<grid, 256, 0, st>>>(x, g.T, mom);
+        k_x_moments<<<grid, 256, 0, st>>>(x, g.T, mom, g_sed_debug & 1);
         SED_CHECK_LAUNCH();
     }
     Blk0PrepArgs a;
@@ -409,7 +409,7 @@ int launch_blk0_backward(const Geo& g, const float* x, const float* w0, const fl
     if (zero_de) SED_CHECK_HIP(hipMemsetAsync(de, 0, 2 * 64 * 10 * sizeof(double), st));
     const int tpc = (g.H1 + 3) / 4, nt = tpc * g.B;
     const int use_drop = (g.p > 0.f) ? 1 : 0;
-    k_blk0_bwd<<<nt < 512 ? nt : 512, 256, 0, st>>>(x, wz, wl, dp0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, mask_in, de);
+    k_blk0_bwd<<<nt < 512 ? nt : 512, 256, 0, st>>>(x, wz, wl, dp0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, mask_in, de, g_sed_debug & 1);
     SED_CHECK_LAUNCH();
     Blk0BwdFinArgs a;
     a.w0 = w0; a.b0 = b0; a.gamma = gamma; a.beta = beta; a.wglu = wglu; a.bn = bn; a.mom = mom; a.de = de;

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ 
                                                        const float* __restrict__ dp, float* __restrict__ dz,
                                                        double* __restrict__ accg, int H, int W, int Ho, int Wo, int Q,
                                                        int block_id, int use_drop, float p_drop,
-                                                       const uint16_t* __restrict__ mask_in) {
+                                                       const uint16_t* __restrict__ mask_in, int no_atomic) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; ++r) red[wv * 4096 + (32 * a + mfma32_row(r, lane)) * 64 + 32 * b2 + n] = dW[a][b2][r];
     __syncthreads();
-    for (int i = tid; i < 4096; i += 256)
+    for (int i = tid; i < 4096 && !no_atomic; i += 256)
         atomicAdd(&accg[i], (double)red[i] + (double)red[4096 + i] + (double)red[8192 + i] + (double)red[12288 + i]);
     __syncthreads();
 #pragma unroll
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ 
         double v = 0;
 #pragma unroll
         for (int w2 = 0; w2 < 4; ++w2) v += (double)red[(w2 * 3 + which) * 64 + c];
-        atomicAdd(&accg[4096 + which * 64 + c], v);
+        if (!no_atomic) atomicAdd(&accg[4096 + which * 64 + c], v);
     }
 }
 
@@ -351,7 +351,7 @@ int launch_glu_pool_bwd(const float* y, const float* bn, const float* wglu, cons
     const int n_rb = (Q + 3) / 4;
     int grid = (n_rb + 3) / 4;
     if (grid > 256) grid = 256;
-    k_glu_pool_bwd<<<grid, 256, lds, st>>>(y, bn, wglu, bglu, dp, dz, acc, H, W, Ho, Wo, Q, block_id, use_drop, p_drop, mask_in);
+    k_glu_pool_bwd<<<grid, 256, lds, st>>>(y, bn, wglu, bglu, dp, dz, acc, H, W, Ho, Wo, Q, block_id, use_drop, p_drop, mask_in, g_sed_debug & 1);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

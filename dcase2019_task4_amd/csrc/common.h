@@ -108,7 +108,12 @@ __device__ __forceinline__ float wave_max(float v) {
 // HBM/L2 write latency on the critical path of loops that store per iteration (GRU steps) or keep
 // prefetch loads in flight across the barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-__device__ __forceinline__ float sigmoidf_fast(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each): a plain `1.0f / x` compiles to the ~10-instruction IEEE division
+// sequence, which made the sigmoid the dominant VALU cost of the fused GLU epilogues.
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoidf_fast(float x) { return rcp_fast(1.0f + __expf(-x)); }
+// debug knob (sed_debug_set): bit 0 = skip the fp64 atomics of the reduction epilogues (timing experiments only)
+extern int g_sed_debug;
 
 // mfma_f32_32x32x2f32 fragment maps (cdna_hip_programming.md section 3):
 //   A[i][k]: lane l holds i = l & 31, k = l >> 5

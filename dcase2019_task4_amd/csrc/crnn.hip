@@ -19,6 +19,8 @@ void sed_set_error(const char* fmt, ...) {
 }
 extern "C" const char* sed_last_error(void) { return g_err; }
 extern "C" int sed_version(void) { return 100; }
+int g_sed_debug = 0;
+extern "C" int sed_debug_set(int flags) { const int old = g_sed_debug; g_sed_debug = flags; return old; }
 
 int sed_validate_dims(const sed_dims* d) {
     SED_CHECK_ARG(d != nullptr, "null dims");

@@ -13,7 +13,7 @@
 #include "common.h"
 #include "kernels.h"
 
-__device__ __forceinline__ float tanhf_fast(float x) { return 1.0f - 2.0f / (1.0f + __expf(2.0f * x)); }
+__device__ __forceinline__ float tanhf_fast(float x) { return 1.0f - 2.0f * rcp_fast(1.0f + __expf(2.0f * x)); }
 
 __global__ __launch_bounds__(192) void k_gru_fwd(const float* __restrict__ gi, const float* __restrict__ w_hh_f,
                                                   const float* __restrict__ w_hh_r, const float* __restrict__ b_hh_f,

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_fwd(const float* __restric
                 for (int c = 0; c < NC; ++c) mx = fmaxf(mx, lg[tid * HD_MAXO + NC + c]);
                 float se = 0.f;
                 for (int c = 0; c < NC; ++c) se += __expf(lg[tid * HD_MAXO + NC + c] - mx);
-                const float inv = 1.0f / se;
+                const float inv = rcp_fast(se);
                 for (int c = 0; c < NC; ++c) {
                     const float ls = lg[tid * HD_MAXO + NC + c];
                     float sof = __expf(ls - mx) * inv;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_bwd(const float* __restric
                 for (int c = 0; c < NC; ++c) mx = fmaxf(mx, logits_s[(size_t)(b * T + t) * NC + c]);
                 float se = 0.f;
                 for (int c = 0; c < NC; ++c) se += __expf(logits_s[(size_t)(b * T + t) * NC + c] - mx);
-                const float inv = 1.0f / se;
+                const float inv = rcp_fast(se);
                 float dot = 0.f;
                 float sraw[16], dsof[16];
                 for (int c = 0; c < NC; ++c) {

@@ -186,6 +186,10 @@ int sed_kernel_replay(const char* name, const sed_dims* d, const float* params, 
                       const uint64_t* seed_dev, void* ctx, size_t ctx_bytes, float* grads, void* ws,
                       size_t ws_bytes, void* stream);
 
+/* Debug knob for timing experiments (returns the previous value). bit 0: skip the fp64 atomics of
+ * the reduction epilogues (results are then WRONG); 0 restores normal operation. */
+int sed_debug_set(int flags);
+
 /* ---- self tests (run on the GPU box by tests/) ---------------------------------------------
  * Checks the MFMA fragment mapping and Philox stream this build assumes. out[0..3] receives
  * max abs errors / mismatch counts; returns 0 if all checks pass. */

@@ -75,52 +75,56 @@ struct Blk0PrepArgs {
     float eps, momentum;
     float *wz, *wl, *bn;   // wz/wl [64][12], bn [4][64] = mean, invstd, scale, shift
 };
-__global__ __launch_bounds__(64) void k_blk0_prep(Blk0PrepArgs a) {
+__global__ __launch_bounds__(640) void k_blk0_prep(Blk0PrepArgs a) {
     __shared__ double wzs[64][10];
-    const int c = threadIdx.x;
-    double w[9];
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        const int c = tid;
+        double w[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) w[t] = a.w0[c * 9 + t];
-    const double b = a.b0[c];
-    double mean, var;
-    if (a.train) {
-        double ws = 0, wGw = 0;
+        for (int t = 0; t < 9; ++t) w[t] = a.w0[c * 9 + t];
+        const double b = a.b0[c];
+        double mean, var;
+        if (a.train) {
+            double ws = 0, wGw = 0;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) ws += w[t] * a.mom[t];
+            for (int t = 0; t < 9; ++t) ws += w[t] * a.mom[t];
 #pragma unroll
-        for (int i = 0; i < 9; ++i)
+            for (int i = 0; i < 9; ++i)
 #pragma unroll
-            for (int j = 0; j < 9; ++j) wGw += w[i] * w[j] * a.mom[i <= j ? gidx(i, j) : gidx(j, i)];
-        const double mu = ws / a.N;
-        mean = mu + b;
-        var = wGw / a.N - mu * mu;
-        if (var < 0) var = 0;
-        if (a.update) {
-            a.run_mean[c] = (float)((1.0 - a.momentum) * a.run_mean[c] + a.momentum * mean);
-            a.run_var[c] = (float)((1.0 - a.momentum) * a.run_var[c] + a.momentum * var * a.N / (a.N - 1.0));
-            if (c == 0 && a.tracked) a.tracked[0] += 1;
+                for (int j = 0; j < 9; ++j) wGw += w[i] * w[j] * a.mom[i <= j ? gidx(i, j) : gidx(j, i)];
+            const double mu = ws / a.N;
+            mean = mu + b;
+            var = wGw / a.N - mu * mu;
+            if (var < 0) var = 0;
+            if (a.update) {
+                a.run_mean[c] = (float)((1.0 - a.momentum) * a.run_mean[c] + a.momentum * mean);
+                a.run_var[c] = (float)((1.0 - a.momentum) * a.run_var[c] + a.momentum * var * a.N / (a.N - 1.0));
+                if (c == 0 && a.tracked) a.tracked[0] += 1;
+            }
+        } else {
+            mean = a.run_mean[c];
+            var = a.run_var[c];
         }
-    } else {
-        mean = a.run_mean[c];
-        var = a.run_var[c];
+        const double invstd = 1.0 / sqrt(var + (double)a.eps);
+        const double scale = a.gamma[c] * invstd;
+        const double shift = a.beta[c] - mean * scale;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wzs[c][t] = scale * w[t];
+        wzs[c][9] = scale * b + shift;
+#pragma unroll
+        for (int t = 0; t < 10; ++t) a.wz[c * 12 + t] = (float)wzs[c][t];
+        a.wz[c * 12 + 10] = 0.f; a.wz[c * 12 + 11] = 0.f;
+        a.wl[c * 12 + 10] = 0.f; a.wl[c * 12 + 11] = 0.f;
+        a.bn[c] = (float)mean; a.bn[64 + c] = (float)invstd; a.bn[128 + c] = (float)scale; a.bn[192 + c] = (float)shift;
     }
-    const double invstd = 1.0 / sqrt(var + (double)a.eps);
-    const double scale = a.gamma[c] * invstd;
-    const double shift = a.beta[c] - mean * scale;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) wzs[c][t] = scale * w[t];
-    wzs[c][9] = scale * b + shift;
-#pragma unroll
-    for (int t = 0; t < 10; ++t) a.wz[c * 12 + t] = (float)wzs[c][t];
-    a.wz[c * 12 + 10] = 0.f; a.wz[c * 12 + 11] = 0.f;
-    a.bn[c] = (float)mean; a.bn[64 + c] = (float)invstd; a.bn[128 + c] = (float)scale; a.bn[192 + c] = (float)shift;
     __syncthreads();
-    for (int t = 0; t < 10; ++t) {
+    {   // wl[c][t] = sum_k Wglu[c][k] wz[k][t] (+ bglu at t = 9): one thread per (c, t)
+        const int c = tid / 10, t = tid % 10;
         double acc = (t == 9) ? (double)a.bglu[c] : 0.0;
         for (int k = 0; k < 64; ++k) acc += (double)a.wglu[c * 64 + k] * wzs[k][t];
         a.wl[c * 12 + t] = (float)acc;
     }
-    a.wl[c * 12 + 10] = 0.f; a.wl[c * 12 + 11] = 0.f;
 }
 
 // ---- shared tile machinery ----------------------------------------------------------------------
@@ -325,55 +329,61 @@ struct Blk0BwdFinArgs {
     double N;
     float *g_w0, *g_b0, *g_gamma, *g_beta, *g_wglu, *g_bglu;
 };
-__global__ __launch_bounds__(64) void k_blk0_bwd_finalize(Blk0BwdFinArgs a) {
+__global__ __launch_bounds__(640) void k_blk0_bwd_finalize(Blk0BwdFinArgs a) {
     __shared__ double wzs[64][10];
     __shared__ double Ds[64][10];
-    const int c = threadIdx.x;
-    const double mean = a.bn[c], invstd = a.bn[64 + c], scale = a.bn[128 + c], shift = a.bn[192 + c];
-    double w[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) { w[t] = a.w0[c * 9 + t]; wzs[c][t] = scale * w[t]; }
-    const double b = a.b0[c];
-    wzs[c][9] = scale * b + shift;
-#pragma unroll
-    for (int t = 0; t < 10; ++t) Ds[c][t] = a.de[c * 10 + t];
+    __shared__ double Ss[64][10];
+    const int tid = threadIdx.x;
+    {   // thread per (c, t)
+        const int c = tid / 10, t = tid % 10;
+        const double scale = a.bn[128 + c], shift = a.bn[192 + c];
+        wzs[c][t] = (t < 9) ? scale * (double)a.w0[c * 9 + t] : scale * (double)a.b0[c] + shift;
+        Ds[c][t] = a.de[c * 10 + t];
+    }
     __syncthreads();
-    // GLU linear: dWglu[co][k] = sum_t D[co][t] wz[k][t];  dbglu[co] = D[co][9]      (row co = c)
-    for (int k = 0; k < 64; ++k) {
+    // GLU linear: dWglu[co][k] = sum_t D[co][t] wz[k][t];  dbglu[co] = D[co][9]
+    for (int e = tid; e < 4096; e += 640) {
+        const int co = e >> 6, k = e & 63;
         double acc = 0;
 #pragma unroll
-        for (int t = 0; t < 10; ++t) acc += Ds[c][t] * wzs[k][t];
-        a.g_wglu[c * 64 + k] = (float)acc;
+        for (int t = 0; t < 10; ++t) acc += Ds[co][t] * wzs[k][t];
+        a.g_wglu[e] = (float)acc;
     }
-    a.g_bglu[c] = (float)Ds[c][9];
-    // total dz against the patch: S[t] = sum_co Wglu[co][c] D[co][t] + E[c][t]
-    double S[10];
-#pragma unroll
-    for (int t = 0; t < 10; ++t) S[t] = a.de[640 + c * 10 + t];
-    for (int co = 0; co < 64; ++co) {
-        const double wg = a.wglu[co * 64 + c];
-#pragma unroll
-        for (int t = 0; t < 10; ++t) S[t] += wg * Ds[co][t];
+    {   // total dz against the patch: S[c][t] = sum_co Wglu[co][c] D[co][t] + E[c][t]
+        const int c = tid / 10, t = tid % 10;
+        double acc = a.de[640 + c * 10 + t];
+        for (int co = 0; co < 64; ++co) acc += (double)a.wglu[co * 64 + c] * Ds[co][t];
+        Ss[c][t] = acc;
     }
-    const double Sdz = S[9];
-    double Sdzu = b * Sdz;
+    __syncthreads();
+    if (tid < 64) {
+        const int c = tid;
+        const double mean = a.bn[c], invstd = a.bn[64 + c], scale = a.bn[128 + c];
+        double w[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) Sdzu += w[t] * S[t];
-    const double Sdzxhat = invstd * (Sdzu - mean * Sdz);
-    a.g_beta[c] = (float)Sdz;
-    a.g_gamma[c] = (float)Sdzxhat;
-    const double m1 = Sdz / a.N, m2 = Sdzxhat / a.N;
-    // du = scale * (dz - m1 - xhat * m2);  dW0[c][t] = sum_p du P[t]
+        for (int t = 0; t < 9; ++t) w[t] = a.w0[c * 9 + t];
+        const double b = a.b0[c];
+        a.g_bglu[c] = (float)Ds[c][9];
+        const double Sdz = Ss[c][9];
+        double Sdzu = b * Sdz;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        double xhP = (b - mean) * a.mom[t];
+        for (int t = 0; t < 9; ++t) Sdzu += w[t] * Ss[c][t];
+        const double Sdzxhat = invstd * (Sdzu - mean * Sdz);
+        a.g_beta[c] = (float)Sdz;
+        a.g_gamma[c] = (float)Sdzxhat;
+        const double m1 = Sdz / a.N, m2 = Sdzxhat / a.N;
+        // du = scale * (dz - m1 - xhat * m2);  dW0[c][t] = sum_p du P[t]
 #pragma unroll
-        for (int t2 = 0; t2 < 9; ++t2) xhP += w[t2] * a.mom[t2 <= t ? gidx(t2, t) : gidx(t, t2)];
-        xhP *= invstd;
-        a.g_w0[c * 9 + t] = (float)(scale * (S[t] - m1 * a.mom[t] - m2 * xhP));
+        for (int t = 0; t < 9; ++t) {
+            double xhP = (b - mean) * a.mom[t];
+#pragma unroll
+            for (int t2 = 0; t2 < 9; ++t2) xhP += w[t2] * a.mom[t2 <= t ? gidx(t2, t) : gidx(t, t2)];
+            xhP *= invstd;
+            a.g_w0[c * 9 + t] = (float)(scale * (Ss[c][t] - m1 * a.mom[t] - m2 * xhP));
+        }
+        // sum_p du = scale * (Sdz - N m1 - m2 * sum xhat) = 0: a conv bias in front of a train-mode BN
+        a.g_b0[c] = 0.f;
     }
-    // sum_p du = scale * (Sdz - N m1 - m2 * sum xhat) = 0: a conv bias in front of a train-mode BN
-    a.g_b0[c] = 0.f;
 }
 
 // ---- host launchers -------------------------------------------------------------------------------
@@ -392,7 +402,7 @@ int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const flo
     a.run_mean = run_mean; a.run_var = run_var; a.tracked = tracked; a.mom = mom;
     a.N = (double)g.B * g.T * g.F; a.train = train; a.update = update; a.eps = g.eps; a.momentum = g.mom;
     a.wz = wz; a.wl = wl; a.bn = bn;
-    k_blk0_prep<<<1, 64, 0, st>>>(a);
+    k_blk0_prep<<<1, 640, 0, st>>>(a);
     SED_CHECK_LAUNCH();
     const int tpc = (g.H1 + 3) / 4, nt = tpc * g.B;
     const int use_drop = (train && g.p > 0.f) ? 1 : 0;
@@ -415,7 +425,7 @@ int launch_blk0_backward(const Geo& g, const float* x, const float* w0, const fl
     a.w0 = w0; a.b0 = b0; a.gamma = gamma; a.beta = beta; a.wglu = wglu; a.bn = bn; a.mom = mom; a.de = de;
     a.N = (double)g.B * g.T * g.F;
     a.g_w0 = g_w0; a.g_b0 = g_b0; a.g_gamma = g_gamma; a.g_beta = g_beta; a.g_wglu = g_wglu; a.g_bglu = g_bglu;
-    k_blk0_bwd_finalize<<<1, 64, 0, st>>>(a);
+    k_blk0_bwd_finalize<<<1, 640, 0, st>>>(a);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

@@ -81,10 +81,10 @@ struct CtxLayout {
 CtxLayout make_ctx_layout(const Geo& g);
 
 struct WsLayout {
-    size_t d_out, dgi, dgh, hprev, d_in, heads_part;
+    size_t d_out, dgi[2], dgh[2], hprev[2], d_in, heads_part;   // dgi/dgh/hprev per GRU layer (read by the side stream)
     size_t dz2, dp1, dz1, dp0, dp2;
     size_t bwd_acc;                    // gluacc1 | gluacc2 | de0 contiguous doubles, zeroed by ONE memset
-    size_t bnb, gluacc1, gluacc2, coef, wg_part, de0, gemm_part;
+    size_t bnb, gluacc1, gluacc2, coef[3], wg_part, de0, gemm_part;   // coef per conv block (1, 2)
     size_t total;
     int wgrad_blocks;
 };

@@ -51,7 +51,9 @@ __global__ void k_conv_pack(const float* __restrict__ w1, const float* __restric
 }
 
 // MODE 0: forward (in = activations, epilogue bias + stats).  MODE 1: dgrad (in = affine(dz, y)).
-template <int TW, int MODE>
+// NS = 2 splits the 64 output channels over two workgroups (blockIdx.y): used for the narrow block-2
+// images, whose B*ceil(H/32) tiles alone would leave half the chip idle.
+template <int TW, int MODE, int NS>
 __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in0, const float* __restrict__ in1,
                                                   const float* __restrict__ coef, const float* __restrict__ wpk,
                                                   const float* __restrict__ bias, float* __restrict__ out,
@@ -65,6 +67,7 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in0, 
     const int n = lane & 31, kh = lane >> 5;
     const int b = blockIdx.x / tiles_per_clip, y0 = (blockIdx.x % tiles_per_clip) * TH;
     const int W = TW;
+    const int nh = (NS == 2) ? blockIdx.y : 0;      // which half of the output channels
 
     // ---- stage halo -------------------------------------------------------------------------
     for (int f = tid; f < HH * HW * 16; f += 256) {
@@ -112,14 +115,16 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in0, 
         }
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
         const float* A = Ab + dy * RS + dx * PS;
-        const float* Bw = Ws + (tap & 1) * 4096 + kh * 64 + n;
+        const float* Bw = Ws + (tap & 1) * 4096 + kh * 64 + n + 32 * nh;
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
             const float a = A[2 * s];
             const float b0 = Bw[2 * s * 64];
-            const float b1 = Bw[2 * s * 64 + 32];
             acc0 = mfma32(a, b0, acc0);
-            acc1 = mfma32(a, b1, acc1);
+            if (NS == 1) {
+                const float b1 = Bw[2 * s * 64 + 32];
+                acc1 = mfma32(a, b1, acc1);
+            }
         }
         if (tap < 8) {
             float* Wn = Ws + ((tap + 1) & 1) * 4096;
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in0, 
 
     // ---- epilogue -----------------------------------------------------------------------------
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-    const float bia0 = (MODE == 0) ? bias[n] : 0.f, bia1 = (MODE == 0) ? bias[32 + n] : 0.f;
+    const float bia0 = (MODE == 0) ? bias[32 * nh + n] : 0.f, bia1 = (MODE == 0 && NS == 1) ? bias[32 + n] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int mm = 32 * wv + mfma32_row(r, lane);
@@ -139,8 +144,8 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in0, 
         if (yy < H) {
             const size_t g = (((size_t)b * H + yy) * W + xx) * 64;
             const float v0 = acc0[r] + bia0, v1 = acc1[r] + bia1;
-            out[g + n] = v0;
-            out[g + 32 + n] = v1;
+            out[g + 32 * nh + n] = v0;
+            if (NS == 1) out[g + 32 + n] = v1;
             if (MODE == 0) { s1[0] += v0; s2[0] += v0 * v0; s1[1] += v1; s2[1] += v1 * v1; }
         }
     }
@@ -154,11 +159,12 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in0, 
         }
         __syncthreads();
         if (tid < 128) {
-            const int which = tid >> 6, c = tid & 63;
+            const int which = tid >> 6, c = tid & 63;     // c = local channel slot: [0,32) first block, [32,64) second
             double v = 0;
 #pragma unroll
             for (int w2 = 0; w2 < 4; ++w2) v += (double)red[(w2 * 2 + which) * 64 + c];
-            atomicAdd(&stat[which * 64 + c], v);
+            if (NS == 1) atomicAdd(&stat[which * 64 + c], v);
+            else if (c < 32) atomicAdd(&stat[which * 64 + 32 * nh + c], v);
         }
     }
 }
@@ -174,7 +180,9 @@ struct WgCfg {
     static constexpr size_t LDS_BYTES = (size_t)(XH_FLOATS + DY_FLOATS) * 4;
 };
 
-template <int TW>
+// TS = 3 splits the 9 taps (by kernel row) over three workgroups (blockIdx.y) writing disjoint tap
+// slices of the same partial slab: 3x the parallelism for the narrow block-2 images.
+template <int TW, int TS>
 __global__ __launch_bounds__(256) void k_conv3x3_wgrad(const float* __restrict__ dz, const float* __restrict__ yin,
                                                         const float* __restrict__ coef, const float* __restrict__ xin,
                                                         float* __restrict__ part, int B, int H, int tiles_per_clip,
@@ -188,9 +196,11 @@ __global__ __launch_bounds__(256) void k_conv3x3_wgrad(const float* __restrict__
     const int n = lane & 31, kh = lane >> 5;
     const int cob = wv >> 1, cib = wv & 1;
     const int W = TW;
-    f32x16 acc[9];
+    constexpr int NT = 9 / TS;                       // taps per workgroup
+    const int tap0 = (TS == 3) ? 3 * blockIdx.y : 0;
+    f32x16 acc[NT];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -231,21 +241,21 @@ __global__ __launch_bounds__(256) void k_conv3x3_wgrad(const float* __restrict__
             for (int txp = 0; txp < TW / 2; ++txp) {
                 const float a = Ab[(ty * TW + 2 * txp) * 64];
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                for (int tl = 0; tl < NT; ++tl) {
+                    const int dy = (TS == 3) ? (int)blockIdx.y - 1 : tl / 3 - 1, dx = tl % 3 - 1;
                     const float bv = Bb[((ty + 1 + dy) * HW + 2 * txp + 1 + dx) * 64];
-                    acc[tap] = mfma32(a, bv, acc[tap]);
+                    acc[tl] = mfma32(a, bv, acc[tl]);
                 }
             }
         }
     }
     float* dst = part + (size_t)blockIdx.x * 9 * 4096;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int tl = 0; tl < NT; ++tl)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = 32 * cob + mfma32_row(r, lane);
-            dst[tap * 4096 + co * 64 + 32 * cib + n] = acc[tap][r];
+            dst[(tap0 + tl) * 4096 + co * 64 + 32 * cib + n] = acc[tl][r];
         }
 }
 
@@ -272,18 +282,18 @@ int launch_conv_pack(const float* w1, const float* w2, float* wpk1, float* wpk2,
     return SED_OK;
 }
 
-template <int TW, int MODE>
+template <int TW, int MODE, int NS>
 static int conv_launch_t(const float* in0, const float* in1, const float* coef, const float* wpk, const float* bias,
                          float* out, double* stat, int B, int H, hipStream_t st) {
     using Cfg = ConvCfg<TW>;
     static bool attr_done = false;
     if (!attr_done) {
-        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3<TW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3<TW, MODE, NS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)Cfg::LDS_BYTES));
         attr_done = true;
     }
     const int tpc = (H + Cfg::TH - 1) / Cfg::TH;
-    k_conv3x3<TW, MODE><<<B * tpc, 256, Cfg::LDS_BYTES, st>>>(in0, in1, coef, wpk, bias, out, stat, B, H, tpc);
+    k_conv3x3<TW, MODE, NS><<<dim3(B * tpc, NS), 256, Cfg::LDS_BYTES, st>>>(in0, in1, coef, wpk, bias, out, stat, B, H, tpc);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
@@ -291,33 +301,33 @@ static int conv_launch_t(const float* in0, const float* in1, const float* coef, 
 int launch_conv_fwd(const float* in, const float* wpk, const float* bias, float* y, double* stat, int zero_stat, int B,
                     int H, int W, hipStream_t st) {
     if (stat && zero_stat) SED_CHECK_HIP(hipMemsetAsync(stat, 0, 128 * sizeof(double), st));
-    if (W == 16) return conv_launch_t<16, 0>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st);
-    if (W == 4) return conv_launch_t<4, 0>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st);
+    if (W == 16) return conv_launch_t<16, 0, 1>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st);
+    if (W == 4) return conv_launch_t<4, 0, 2>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st);
     sed_set_error("conv: unsupported width %d", W);
     return SED_ERR_UNSUPPORTED;
 }
 
 int launch_conv_dgrad(const float* dz, const float* yin, const float* coef, const float* wpkT, float* dx, int B, int H,
                       int W, hipStream_t st) {
-    if (W == 16) return conv_launch_t<16, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st);
-    if (W == 4) return conv_launch_t<4, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st);
+    if (W == 16) return conv_launch_t<16, 1, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st);
+    if (W == 4) return conv_launch_t<4, 1, 2>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st);
     sed_set_error("conv dgrad: unsupported width %d", W);
     return SED_ERR_UNSUPPORTED;
 }
 
-template <int TW>
+template <int TW, int TS>
 static int wgrad_launch_t(const float* dz, const float* yin, const float* coef, const float* xin, float* part,
                           int n_blocks, float* g_w, int B, int H, hipStream_t st) {
     using Cfg = WgCfg<TW>;
     static bool attr_done = false;
     if (!attr_done) {
-        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad<TW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad<TW, TS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)Cfg::LDS_BYTES));
         attr_done = true;
     }
     const int tpc = (H + Cfg::TH - 1) / Cfg::TH, nt = B * tpc;
     const int nb = nt < n_blocks ? nt : n_blocks;
-    k_conv3x3_wgrad<TW><<<nb, 256, Cfg::LDS_BYTES, st>>>(dz, yin, coef, xin, part, B, H, tpc, nt);
+    k_conv3x3_wgrad<TW, TS><<<dim3(nb, TS), 256, Cfg::LDS_BYTES, st>>>(dz, yin, coef, xin, part, B, H, tpc, nt);
     SED_CHECK_LAUNCH();
     k_wgrad_reduce<<<(9 * 4096 + 255) / 256, 256, 0, st>>>(part, nb, g_w);
     SED_CHECK_LAUNCH();
@@ -326,8 +336,8 @@ static int wgrad_launch_t(const float* dz, const float* yin, const float* coef, 
 
 int launch_conv_wgrad(const float* dz, const float* yin, const float* coef, const float* xin, float* part, int n_blocks,
                       float* g_w, int B, int H, int W, hipStream_t st) {
-    if (W == 16) return wgrad_launch_t<16>(dz, yin, coef, xin, part, n_blocks, g_w, B, H, st);
-    if (W == 4) return wgrad_launch_t<4>(dz, yin, coef, xin, part, n_blocks, g_w, B, H, st);
+    if (W == 16) return wgrad_launch_t<16, 1>(dz, yin, coef, xin, part, n_blocks, g_w, B, H, st);
+    if (W == 4) return wgrad_launch_t<4, 3>(dz, yin, coef, xin, part, n_blocks, g_w, B, H, st);
     sed_set_error("conv wgrad: unsupported width %d", W);
     return SED_ERR_UNSUPPORTED;
 }

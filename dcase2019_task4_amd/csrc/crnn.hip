@@ -105,10 +105,11 @@ WsLayout make_ws_layout(const Geo& g) {
     size_t o = 0;
     auto put = [&](size_t& f, size_t bytes) { f = o; o = al(o + bytes); };
     const size_t n0 = (size_t)g.B * g.H1 * g.W1 * 64, n1 = (size_t)g.B * g.H2 * g.W2 * 64, bt = (size_t)g.B * g.T3;
-    put(W.d_out, bt * 128 * 4); put(W.dgi, bt * 384 * 4); put(W.dgh, bt * 384 * 4); put(W.hprev, bt * 128 * 4);
+    put(W.d_out, bt * 128 * 4);
+    for (int l = 0; l < 2; ++l) { put(W.dgi[l], bt * 384 * 4); put(W.dgh[l], bt * 384 * 4); put(W.hprev[l], bt * 128 * 4); }
     put(W.d_in, bt * 128 * 4); put(W.heads_part, (size_t)g.B * 2 * (g.NC * 128 + g.NC) * 4);
     put(W.dp2, bt * 64 * 4); put(W.dz2, n1 * 4); put(W.dp1, n1 * 4); put(W.dz1, n0 * 4); put(W.dp0, n0 * 4);
-    put(W.bnb, 256 * sizeof(double)); put(W.coef, 192 * 4);
+    put(W.bnb, 256 * sizeof(double)); W.coef[0] = 0; put(W.coef[1], 192 * 4); put(W.coef[2], 192 * 4);
     put(W.bwd_acc, (2 * 4288 + 2 * 64 * 10) * sizeof(double));
     W.gluacc1 = W.bwd_acc; W.gluacc2 = W.bwd_acc + 4288 * sizeof(double); W.de0 = W.bwd_acc + 2 * 4288 * sizeof(double);
     W.wgrad_blocks = SED_WGRAD_MAX_BLOCKS;
@@ -159,6 +160,37 @@ extern "C" int sed_crnn_ctx_view(const sed_dims* d, const char* name, size_t* of
     sed_set_error("sed_crnn_ctx_view: unknown buffer '%s'", name);
     return SED_ERR_BAD_ARG;
 }
+
+// ---- side stream: weight-gradient work that is off the backward critical path ---------------------
+// The dX chain (heads -> GRU -> dgrad2 -> dgrad1 -> block 0) is serial; the GRU dW/db GEMMs and the conv
+// wgrads only feed the optimiser.  They are forked onto a second stream (created once, on the first
+// eager call) and joined before the call returns, so the caller still sees one stream-ordered op and a
+// hipGraph capture records the fork/join as graph edges.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool ok = false;
+};
+static SideStream& side_stream() {
+    static SideStream ss;
+    if (!ss.ok) {
+        if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess)
+            ss.ok = true;
+    }
+    return ss;
+}
+#define SIDE_FORK(main_st)                                          \
+    do {                                                            \
+        SED_CHECK_HIP(hipEventRecord(sd.fork, (main_st)));          \
+        SED_CHECK_HIP(hipStreamWaitEvent(sd.s, sd.fork, 0));        \
+    } while (0)
+#define SIDE_JOIN(main_st)                                          \
+    do {                                                            \
+        SED_CHECK_HIP(hipEventRecord(sd.join, sd.s));               \
+        SED_CHECK_HIP(hipStreamWaitEvent((main_st), sd.join, 0));   \
+    } while (0)
 
 #define CTXF(off) ((float*)((char*)ctx + (off)))
 #define CTXD(off) ((double*)((char*)ctx + (off)))
@@ -254,6 +286,9 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
     SED_CHECK_ARG(!use_drop || seed_dev, "sed_crnn_backward: dropout enabled but seed_dev is null");
     hipStream_t st = (hipStream_t)stream;
     const int BT = g.B * g.T3;
+    SideStream& sd = side_stream();
+    hipStream_t ss = sd.ok ? sd.s : st;       // without a side stream everything stays on the caller's
+    bool forked = false;
 
     if (parts & 1) {
     // ---- heads ----------------------------------------------------------------------------------
@@ -269,7 +304,8 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
         const float* input = (l == 0) ? CTXF(L.p2) : CTXF(L.out[l - 1]);
         float* d_in = (l == 0) ? WSF(W.dp2) : WSF(W.d_in);
         SED_TRY(launch_gru_bwd(d_cur, CTXF(L.out[l]), CTXF(L.gates[l]), params + P.w_hh[l][0], params + P.w_hh[l][1],
-                               WSF(W.dgi), WSF(W.dgh), WSF(W.hprev), g.B, g.T3, st));
+                               WSF(W.dgi[l]), WSF(W.dgh[l]), WSF(W.hprev[l]), g.B, g.T3, st));
+        if (sd.ok) { SIDE_FORK(st); forked = true; }
         {
             // weight + bias gradients of both directions: 4 problems, split-K over the B*T/8 rows
             //   dW_ih[g][i] = sum_bt dgi[bt][g] input[bt][i],  db_ih[g] = sum_bt dgi[bt][g]
@@ -277,26 +313,29 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
             GemmBatch gb;
             gb.n_prob = 4; gb.splits = SED_GRU_SPLITK; gb.part = WSF(W.gemm_part); gb.part_stride = 0;
             for (int dir = 0; dir < 2; ++dir) {
-                gb.p[2 * dir] = gemm_prob(WSF(W.dgi) + dir * 192, 1, 384, input, nin, 1, grads + P.w_ih[l][dir], nin, 192, nin, BT);
+                gb.p[2 * dir] = gemm_prob(WSF(W.dgi[l]) + dir * 192, 1, 384, input, nin, 1, grads + P.w_ih[l][dir], nin, 192, nin, BT);
                 gb.p[2 * dir].Cones = grads + P.b_ih[l][dir];
-                gb.p[2 * dir + 1] = gemm_prob(WSF(W.dgh) + dir * 192, 1, 384, WSF(W.hprev) + dir * 64, 128, 1,
+                gb.p[2 * dir + 1] = gemm_prob(WSF(W.dgh[l]) + dir * 192, 1, 384, WSF(W.hprev[l]) + dir * 64, 128, 1,
                                               grads + P.w_hh[l][dir], 64, 192, 64, BT);
                 gb.p[2 * dir + 1].Cones = grads + P.b_hh[l][dir];
             }
-            SED_TRY(launch_gemm_batch(gb, st));
+            SED_TRY(launch_gemm_batch(gb, ss));          // side stream: only the optimiser needs these
         }
         {
             // d_in[bt][i] = sum_{dir,g} dgi[bt][dir][g] W_ih[dir][g][i]   (K = 384 = both directions)
             GemmBatch gb;
             gb.n_prob = 1; gb.splits = 1; gb.part = nullptr; gb.part_stride = 0;
-            gb.p[0] = gemm_prob(WSF(W.dgi), 384, 1, params + P.w_ih[l][0], nin, 1, d_in, nin, BT, nin, 384);
+            gb.p[0] = gemm_prob(WSF(W.dgi[l]), 384, 1, params + P.w_ih[l][0], nin, 1, d_in, nin, BT, nin, 384);
             gb.p[0].B2 = params + P.w_ih[l][1]; gb.p[0].k2 = 192;
             SED_TRY(launch_gemm_batch(gb, st));
         }
         d_cur = d_in;
     }
     }
-    if (!(parts & 2)) return SED_OK;
+    if (!(parts & 2)) {
+        if (forked) SIDE_JOIN(st);
+        return SED_OK;
+    }
     // ---- conv blocks 2, 1 -----------------------------------------------------------------------
     const size_t wpkT[3] = {0, L.wpkT1, L.wpkT2}, yo[3] = {0, L.y1, L.y2}, bo[3] = {0, L.bn1, L.bn2};
     const size_t pin[3] = {0, L.p0, L.p1}, gacc[3] = {0, W.gluacc1, W.gluacc2}, mo[3] = {L.mask0, L.mask1, L.mask2};
@@ -307,18 +346,20 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
     for (int i = 2; i >= 1; --i) {
         SED_TRY(launch_glu_pool_bwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], WSF(dpo[i]),
                                     WSF(dzo[i]), WSD(gacc[i]), 0, g.B, Hs[i], Wd[i], i, use_drop, g.p, CTXM(mo[i]), st));
-        SED_TRY(launch_bn_bwd_prep(WSD(gacc[i]), (double)g.B * Hs[i] * Wd[i], params + P.bn_g[i], CTXF(bo[i]), WSF(W.coef),
+        SED_TRY(launch_bn_bwd_prep(WSD(gacc[i]), (double)g.B * Hs[i] * Wd[i], params + P.bn_g[i], CTXF(bo[i]), WSF(W.coef[i]),
                                    grads + P.bn_g[i], grads + P.bn_b[i], grads + P.glu_w[i], grads + P.glu_b[i],
                                    grads + P.conv_b[i], st));
-        SED_TRY(launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef), CTXF(pin[i]), WSF(W.wg_part), W.wgrad_blocks,
-                                  grads + P.conv_w[i], g.B, Hs[i], Wd[i], st));
-        SED_TRY(launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], st));
+        if (sd.ok) { SIDE_FORK(st); forked = true; }
+        SED_TRY(launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(pin[i]), WSF(W.wg_part), W.wgrad_blocks,
+                                  grads + P.conv_w[i], g.B, Hs[i], Wd[i], ss));      // side stream
+        SED_TRY(launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], st));
     }
     // ---- conv block 0 ---------------------------------------------------------------------------
     SED_TRY(launch_blk0_backward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
                                  params + P.glu_w[0], CTXM(L.mask0), CTXD(L.mom0), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0),
                                  WSF(W.dp0), WSD(W.de0), 0, grads + P.conv_w[0], grads + P.conv_b[0], grads + P.bn_g[0],
                                  grads + P.bn_b[0], grads + P.glu_w[0], grads + P.glu_b[0], st));
+    if (forked) SIDE_JOIN(st);
     return SED_OK;
 }
 
@@ -348,7 +389,7 @@ extern "C" int sed_kernel_replay(const char* name, const sed_dims* d, const floa
         const int tpc = (g.H1 + 3) / 4;
         (void)tpc;
         return launch_blk0_forward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
-                                   params + P.glu_w[0], params + P.glu_b[0], WSF(W.coef), WSF(W.coef) + 64, nullptr, 1, 0,
+                                   params + P.glu_w[0], params + P.glu_b[0], WSF(W.coef[1]), WSF(W.coef[1]) + 64, nullptr, 1, 0,
                                    seed_dev, CTXD(L.mom0), 1, CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), CTXF(L.p0),
                                    use_drop ? CTXM(L.mask0) : nullptr, st);
     }
@@ -361,16 +402,16 @@ extern "C" int sed_kernel_replay(const char* name, const sed_dims* d, const floa
         snprintf(nm, sizeof nm, "glu%d_bwd", i);
         if (is(nm)) return launch_glu_pool_bwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], WSF(dpo[i]), WSF(dzo[i]), WSD(gacc[i]), 1, g.B, Hs[i], Wd[i], i, use_drop, g.p, CTXM(mo[i]), st);
         snprintf(nm, sizeof nm, "conv%d_wgrad", i);
-        if (is(nm)) return launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef), CTXF(po[i - 1]), WSF(W.wg_part), W.wgrad_blocks, grads + P.conv_w[i], g.B, Hs[i], Wd[i], st);
+        if (is(nm)) return launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(po[i - 1]), WSF(W.wg_part), W.wgrad_blocks, grads + P.conv_w[i], g.B, Hs[i], Wd[i], st);
         snprintf(nm, sizeof nm, "conv%d_dgrad", i);
-        if (is(nm)) return launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], st);
+        if (is(nm)) return launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], st);
     }
     for (int l = 0; l < g.L; ++l) {
         char nm[32];
         snprintf(nm, sizeof nm, "gru%d_fwd", l);
         if (is(nm)) return launch_gru_fwd(CTXF(L.gi[l]), params + P.w_hh[l][0], params + P.w_hh[l][1], params + P.b_hh[l][0], params + P.b_hh[l][1], CTXF(L.out[l]), CTXF(L.gates[l]), g.B, g.T3, st);
         snprintf(nm, sizeof nm, "gru%d_bwd", l);
-        if (is(nm)) return launch_gru_bwd(l == g.L - 1 ? WSF(W.d_out) : WSF(W.d_in), CTXF(L.out[l]), CTXF(L.gates[l]), params + P.w_hh[l][0], params + P.w_hh[l][1], WSF(W.dgi), WSF(W.dgh), WSF(W.hprev), g.B, g.T3, st);
+        if (is(nm)) return launch_gru_bwd(l == g.L - 1 ? WSF(W.d_out) : WSF(W.d_in), CTXF(L.out[l]), CTXF(L.gates[l]), params + P.w_hh[l][0], params + P.w_hh[l][1], WSF(W.dgi[l]), WSF(W.dgh[l]), WSF(W.hprev[l]), g.B, g.T3, st);
     }
     if (is("heads_fwd"))
         return launch_heads_fwd(CTXF(L.out[g.L - 1]), params + P.dense_w, params + P.dense_b, params + P.soft_w, params + P.soft_b,

@@ -261,7 +261,15 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_mt_loss(const float* __restric
         float g = cw * 2.0f * diff * inv_nW;
         if (b >= wlo && b < whi) {
             float t = -3.0e38f;       // target_weak = target.max(-2)  (main.py:95)
-            for (int tt = 0; tt < T; ++tt) t = fmaxf(t, target[(size_t)(b * T + tt) * NC + c]);
+            int tt = 0;
+            for (; tt + 16 <= T; tt += 16) {        // 16 independent loads in flight (a rolled loop waits per load)
+                float v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = target[(size_t)(b * T + tt + i) * NC + c];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) t = fmaxf(t, v[i]);
+            }
+            for (; tt < T; ++tt) t = fmaxf(t, target[(size_t)(b * T + tt) * NC + c]);
             acc[0] += bce_term(p, t);
             acc[4] += bce_term(pe, t);
             g += bce_grad(p, t) * inv_wb;

@@ -237,6 +237,20 @@ def test_three_fused_steps_vs_real_main_train_goldens(golden_dir, use_graph):
             np.testing.assert_allclose(v.cpu().numpy(), g[tag + k.replace(".", "_")], rtol=3e-5, atol=atol, err_msg=k)
 
 
+def _assert_params_close(got, want, name, n_steps, lr=1e-3):
+    """Parameters after a few Adam steps.  Adam normalises each gradient element to ~+-lr, so an
+    element whose gradient is ~0 (|g| at rounding-noise level) can legitimately move differently on
+    the two sides - by up to ~lr per step.  Hence: (almost) everything within 5e-5, a vanishing
+    fraction within a few lr, and the conv biases (exactly-zero gradient)
+    only bounded."""
+    d = np.abs(np.asarray(got, dtype=np.float64) - np.asarray(want, dtype=np.float64))
+    if ".conv" in name and name.endswith("bias"):
+        assert d.max() < 1e-2, name
+        return
+    assert d.max() < 3.0 * lr * n_steps, (name, d.max())
+    assert (d > 5e-5).mean() <= 2e-3, (name, float((d > 5e-5).mean()), d.max())
+
+
 def test_fused_step_with_dropout_vs_oracle_trajectory():
     """Two fused steps with dropout 0.5 against MeanTeacherOracle driven by the same Philox masks
     (seeds read back from the device step state)."""
@@ -262,11 +276,9 @@ def test_fused_step_with_dropout_vs_oracle_trajectory():
             gh = {n: st.grads[o0:o1].view(shp).cpu() for n, (o0, o1, shp) in zip(go.keys(), student._layout)}
             _check_grads(gh, go)
     for n, p in student.named_parameters():
-        tol = 1e-2 if (".conv" in n and n.endswith("bias")) else 5e-5
-        np.testing.assert_allclose(p.detach().cpu().numpy(), mt.p[n].detach().numpy(), atol=tol, err_msg=n)
+        _assert_params_close(p.detach().cpu().numpy(), mt.p[n].detach().numpy(), n, 2)
     for n, p in teacher.named_parameters():
-        tol = 1e-2 if (".conv" in n and n.endswith("bias")) else 5e-5
-        np.testing.assert_allclose(p.detach().cpu().numpy(), mt.pe[n].numpy(), atol=tol, err_msg=n)
+        _assert_params_close(p.detach().cpu().numpy(), mt.pe[n].numpy(), n, 2)
 
 
 def test_drop_in_module_path_with_torch_adam_matches_oracle():
@@ -299,11 +311,9 @@ def test_drop_in_module_path_with_torch_adam_matches_oracle():
         mo, _, _ = mt.step(x, xe, tgt, wm, sm, 50)
         assert float(loss) == pytest.approx(mo["loss"], rel=1e-4)
     for n, p in student.named_parameters():
-        tol = 1e-2 if (".conv" in n and n.endswith("bias")) else 5e-5
-        np.testing.assert_allclose(p.detach().cpu().numpy(), mt.p[n].detach().numpy(), atol=tol, err_msg=n)
+        _assert_params_close(p.detach().cpu().numpy(), mt.p[n].detach().numpy(), n, 2)
     for n, p in teacher.named_parameters():
-        tol = 1e-2 if (".conv" in n and n.endswith("bias")) else 5e-5
-        np.testing.assert_allclose(p.detach().cpu().numpy(), mt.pe[n].numpy(), atol=tol, err_msg=n)
+        _assert_params_close(p.detach().cpu().numpy(), mt.pe[n].numpy(), n, 2)
 
 
 def test_checkpoint_roundtrip_reference_format(tmp_path):

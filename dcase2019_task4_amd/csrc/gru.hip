@@ -36,15 +36,24 @@ __global__ __launch_bounds__(192) void k_gru_fwd(const float* __restrict__ gi, c
     const float bh = (dir ? b_hh_r : b_hh_f)[g];
     if (g < 64) hs[g] = 0.f;
     float hprev = 0.f;
-    // gi of the NEXT step is fetched one iteration ahead: its HBM/L2 latency hides under this step
-    float gi_next = gi[((size_t)(b * T + (dir ? T - 1 : 0)) * 2 + dir) * 192 + g];
+    // Wave roles keep global LOADS and global STORES in different waves.  vmcnt counts both and they
+    // complete out of order with respect to each other, so a wave that does both must drain its stores
+    // (full write latency) every time it needs a loaded value.  Wave 0 (gate math) only stores; waves 1-2
+    // only load - gi of the NEXT step, one iteration ahead, for all 192 gate rows - and hand it over in LDS.
+    float gi_a = 0.f, gi_b = 0.f;
+    auto fetch = [&](int t) {
+        const float* src = gi + ((size_t)(b * T + t) * 2 + dir) * 192;
+        gi_a = src[g];
+        if (g < 128) gi_b = src[g - 64];
+    };
+    if (g >= 64) fetch(dir ? T - 1 : 0);
     __syncthreads();
     for (int step = 0; step < T; ++step) {
         const int t = dir ? (T - 1 - step) : step;
-        const float giv = gi_next;
-        if (step + 1 < T) {
-            const int tn = dir ? (T - 2 - step) : (step + 1);
-            gi_next = gi[((size_t)(b * T + tn) * 2 + dir) * 192 + g];
+        float cur_a = 0.f, cur_b = 0.f;
+        if (g >= 64) {
+            cur_a = gi_a; cur_b = gi_b;
+            if (step + 1 < T) fetch(dir ? (T - 2 - step) : (step + 1));
         }
         float a0 = bh, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
@@ -56,7 +65,10 @@ __global__ __launch_bounds__(192) void k_gru_fwd(const float* __restrict__ gi, c
             a3 = fmaf(w[j + 3], h4.w, a3);
         }
         ghs[g] = (a0 + a1) + (a2 + a3);
-        gis[g] = giv;
+        if (g >= 64) {
+            gis[g] = cur_a;
+            if (g < 128) gis[g - 64] = cur_b;
+        }
         lds_barrier();
         if (g < 64) {
             const float r = sigmoidf_fast(gis[g] + ghs[g]);
@@ -89,22 +101,47 @@ __global__ __launch_bounds__(192) void k_gru_bwd(const float* __restrict__ d_out
 #pragma unroll
     for (int i = 0; i < 64; ++i) wt[i] = whh[(part * 64 + i) * 64 + j];
     float dh_carry = 0.f, dh_z = 0.f;
-    // operands of the NEXT step are fetched one iteration ahead (tid < 64 only)
-    float n_do = 0.f, n_r = 0.f, n_z = 0.f, n_n = 0.f, n_g = 0.f, n_hp = 0.f;
+    // Same load/store wave split as the forward: wave 0 computes and stores, waves 1-2 prefetch the six
+    // operand rows (d_out, r, z, n, gh_n, h_prev) of the NEXT step and pass them through LDS.
+    __shared__ float ops[2][6][64];
+    float pre[3] = {0.f, 0.f, 0.f};
+    const int u = tid - 64;     // 0..127 for the loader waves
     auto fetch = [&](int t) {
-        n_do = d_out[(size_t)(b * T + t) * 128 + dir * 64 + j];
-        const float* gs = gates + ((size_t)(b * T + t) * 2 + dir) * 256;
-        n_r = gs[j]; n_z = gs[64 + j]; n_n = gs[128 + j]; n_g = gs[192 + j];
-        const int tp = dir ? t + 1 : t - 1;
-        n_hp = (tp >= 0 && tp < T) ? out[(size_t)(b * T + tp) * 128 + dir * 64 + j] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int idx = u + 128 * k, a = idx >> 6, jj = idx & 63;
+            float v;
+            if (a == 0) v = d_out[(size_t)(b * T + t) * 128 + dir * 64 + jj];
+            else if (a < 5) v = gates[((size_t)(b * T + t) * 2 + dir) * 256 + (a - 1) * 64 + jj];
+            else {
+                const int tp = dir ? t + 1 : t - 1;
+                v = (tp >= 0 && tp < T) ? out[(size_t)(b * T + tp) * 128 + dir * 64 + jj] : 0.f;
+            }
+            pre[k] = v;
+        }
     };
-    if (tid < 64) fetch(dir ? 0 : T - 1);
+    auto publish = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int idx = u + 128 * k;
+            ops[buf][idx >> 6][idx & 63] = pre[k];
+        }
+    };
+    if (tid >= 64) {
+        fetch(dir ? 0 : T - 1);
+        publish(0);
+        if (T > 1) fetch(dir ? 1 : T - 2);
+    }
+    __syncthreads();
     for (int step = 0; step < T; ++step) {
         const int t = dir ? step : (T - 1 - step);
-        if (tid < 64) {
-            const float dh = n_do + dh_carry;
-            const float r = n_r, z = n_z, nn = n_n, ghn = n_g, hp = n_hp;
-            if (step + 1 < T) fetch(dir ? step + 1 : T - 2 - step);
+        if (tid >= 64) {
+            if (step + 1 < T) publish((step + 1) & 1);                  // operands of step+1 (loaded a step ago)
+            if (step + 2 < T) fetch(dir ? step + 2 : T - 3 - step);     // start loading step+2
+        } else {
+            const float (*o)[64] = ops[step & 1];
+            const float dh = o[0][j] + dh_carry;
+            const float r = o[1][j], z = o[2][j], nn = o[3][j], ghn = o[4][j], hp = o[5][j];
             const float dn_pre = dh * (1.0f - z) * (1.0f - nn * nn);
             const float dz_pre = dh * (hp - nn) * z * (1.0f - z);
             const float dr_pre = dn_pre * ghn * r * (1.0f - r);

@@ -6,21 +6,12 @@
 // with gi = W_ih x + b_ih (one batched GEMM over all time steps, gemm.hip) and
 // gh = W_hh h + b_hh (this file).
 //
-// The recurrence is a serial chain of T/8 steps: latency-, not throughput-bound.  One workgroup per
-// (clip, direction) keeps its W_hh slice in REGISTERS for all steps (192 threads x 64 weights) and
-// broadcasts h through LDS; all B x 2 chains run concurrently on separate CUs.
-//
-// The per-step loop touches NO global memory.  On CDNA4 `vmcnt` counts loads and stores alike and they
-// retire out of order with respect to each other, so a wave that needs a loaded value has to drain all
-// its outstanding stores first - a full HBM/L2 write latency per step when every step both loads its
-// inputs and stores its outputs (first version: 0.72 us/step).  Instead the inputs of GRU_SB steps are
-// pulled into LDS and the outputs of GRU_SB steps are pushed out of LDS at block boundaries, with the
-// next block's loads issued GRU_SB steps before they are needed; inside a block the only
-// synchronisation is an LDS-only barrier (lds_barrier: no vmcnt drain).
+// The recurrence is a serial chain of T/8 steps, so it is latency- not throughput-bound: one
+// workgroup per (clip, direction) keeps its W_hh slice in REGISTERS for all steps (192 threads x
+// 64 weights), broadcasts h through LDS, and all B x 2 chains run concurrently on separate CUs.
+// Backward keeps W_hh^T the same way (thread = (gate block, hidden unit j)).
 #include "common.h"
 #include "kernels.h"
-
-#define GRU_SB 8
 
 __device__ __forceinline__ float tanhf_fast(float x) { return 1.0f - 2.0f * rcp_fast(1.0f + __expf(2.0f * x)); }
 
@@ -28,12 +19,10 @@ __global__ __launch_bounds__(192) void k_gru_fwd(const float* __restrict__ gi, c
                                                   const float* __restrict__ w_hh_r, const float* __restrict__ b_hh_f,
                                                   const float* __restrict__ b_hh_r, float* __restrict__ out,
                                                   float* __restrict__ gates, int T) {
-    extern __shared__ __attribute__((aligned(16))) float gsm[];
-    float* hs = gsm;                                  // [64]
-    float* ghs = hs + 64;                             // [192]
-    float* gi_s = ghs + 192;                          // [2][GRU_SB][192]
-    float* hist = gi_s + 2 * GRU_SB * 192;            // [2][GRU_SB][320] : h, r, z, n, gh_n
-    float* Wl = hist + 2 * GRU_SB * 320;              // [192][68] staging of W_hh (coalesced global read)
+    __shared__ __attribute__((aligned(16))) float hs[64];
+    __shared__ float ghs[192];
+    __shared__ float gis[192];
+    __shared__ __attribute__((aligned(16))) float Wl[192 * 68];   // W_hh staged coalesced; row stride 68: conflict-free b128 row reads
     const int b = blockIdx.x, dir = blockIdx.y, g = threadIdx.x;
     const float* whh = dir ? w_hh_r : w_hh_f;
     for (int e = g; e < 192 * 64; e += 192) Wl[(e >> 6) * 68 + (e & 63)] = whh[e];
@@ -44,235 +33,152 @@ __global__ __launch_bounds__(192) void k_gru_fwd(const float* __restrict__ gi, c
         const float4 v = *(const float4*)(Wl + g * 68 + j);
         w[j] = v.x; w[j + 1] = v.y; w[j + 2] = v.z; w[j + 3] = v.w;
     }
-    float bh = (dir ? b_hh_r : b_hh_f)[g];
-    // pin the wait for this load HERE: left to the compiler it lands at the first use inside the step loop,
-    // where `s_waitcnt vmcnt(0)` also drains the block-boundary stores on every re-entry
-    asm volatile("" : "+v"(bh));
+    const float bh = (dir ? b_hh_r : b_hh_f)[g];
     if (g < 64) hs[g] = 0.f;
     float hprev = 0.f;
-    const int nblk = (T + GRU_SB - 1) / GRU_SB;
-    auto t_of = [&](int step) { return dir ? (T - 1 - step) : step; };
-    // block 0 inputs
-    {
-        float first[GRU_SB];
-#pragma unroll
-        for (int s = 0; s < GRU_SB; ++s) first[s] = (s < T) ? gi[((size_t)(b * T + t_of(s)) * 2 + dir) * 192 + g] : 0.f;
-#pragma unroll
-        for (int s = 0; s < GRU_SB; ++s) gi_s[s * 192 + g] = first[s];
-    }
+    // Wave roles keep global LOADS and global STORES in different waves.  vmcnt counts both and they
+    // complete out of order with respect to each other, so a wave that does both must drain its stores
+    // (full write latency) every time it needs a loaded value.  Wave 0 (gate math) only stores; waves 1-2
+    // only load - gi of the NEXT step, one iteration ahead, for all 192 gate rows - and hand it over in LDS.
+    float gi_a = 0.f, gi_b = 0.f;
+    auto fetch = [&](int t) {
+        const float* src = gi + ((size_t)(b * T + t) * 2 + dir) * 192;
+        gi_a = src[g];
+        if (g < 128) gi_b = src[g - 64];
+    };
+    if (g >= 64) fetch(dir ? T - 1 : 0);
     __syncthreads();
-    for (int blk = 0; blk < nblk; ++blk) {
-        const int cur = blk & 1, s0 = blk * GRU_SB;
-        const int sb = min(GRU_SB, T - s0);
-        // ---- block boundary: push the previous block's outputs, pull the next block's inputs ----------
-        if (blk > 0) {
-            const float* hp = hist + (cur ^ 1) * GRU_SB * 320;
-            for (int e = g; e < GRU_SB * 320; e += 192) {
-                const int s = e / 320, k = e % 320;
-                const int t = t_of(s0 - GRU_SB + s);
-                if (k < 64) out[(size_t)(b * T + t) * 128 + dir * 64 + k] = hp[e];
-                else if (gates) gates[((size_t)(b * T + t) * 2 + dir) * 256 + (k - 64)] = hp[e];
-            }
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? (T - 1 - step) : step;
+        float cur_a = 0.f, cur_b = 0.f;
+        if (g >= 64) {
+            cur_a = gi_a; cur_b = gi_b;
+            if (step + 1 < T) fetch(dir ? (T - 2 - step) : (step + 1));
         }
-        float nxt[GRU_SB];
+        float a0 = bh, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-        for (int s = 0; s < GRU_SB; ++s) {
-            const int st = s0 + GRU_SB + s;
-            nxt[s] = (st < T) ? gi[((size_t)(b * T + t_of(st)) * 2 + dir) * 192 + g] : 0.f;
+        for (int j = 0; j < 64; j += 4) {
+            const float4 h4 = *(const float4*)(hs + j);
+            a0 = fmaf(w[j], h4.x, a0);
+            a1 = fmaf(w[j + 1], h4.y, a1);
+            a2 = fmaf(w[j + 2], h4.z, a2);
+            a3 = fmaf(w[j + 3], h4.w, a3);
         }
-        // ---- GRU_SB steps on LDS only ---------------------------------------------------------------------
-        const float* gib = gi_s + cur * GRU_SB * 192;
-        float* hb = hist + cur * GRU_SB * 320;
-        for (int s = 0; s < sb; ++s) {
-            float a0 = bh, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-            for (int j = 0; j < 64; j += 4) {
-                const float4 h4 = *(const float4*)(hs + j);
-                a0 = fmaf(w[j], h4.x, a0);
-                a1 = fmaf(w[j + 1], h4.y, a1);
-                a2 = fmaf(w[j + 2], h4.z, a2);
-                a3 = fmaf(w[j + 3], h4.w, a3);
-            }
-            ghs[g] = (a0 + a1) + (a2 + a3);
-            lds_barrier();
-            if (g < 64) {
-                const float* gr = gib + s * 192;
-                const float r = sigmoidf_fast(gr[g] + ghs[g]);
-                const float z = sigmoidf_fast(gr[64 + g] + ghs[64 + g]);
-                const float ghn = ghs[128 + g];
-                const float nn = tanhf_fast(gr[128 + g] + r * ghn);
-                const float h = (1.0f - z) * nn + z * hprev;
-                float* ho = hb + s * 320;
-                ho[g] = h; ho[64 + g] = r; ho[128 + g] = z; ho[192 + g] = nn; ho[256 + g] = ghn;
-                hs[g] = h;
-                hprev = h;
-            }
-            lds_barrier();
+        ghs[g] = (a0 + a1) + (a2 + a3);
+        if (g >= 64) {
+            gis[g] = cur_a;
+            if (g < 128) gis[g - 64] = cur_b;
         }
-        // ---- hand the prefetched inputs of the next block to LDS (loads were issued GRU_SB steps ago) ----
-        float* gin = gi_s + (cur ^ 1) * GRU_SB * 192;
-#pragma unroll
-        for (int s = 0; s < GRU_SB; ++s) gin[s * 192 + g] = nxt[s];
         lds_barrier();
-    }
-    {   // last block's outputs
-        const int blk = nblk - 1, s0 = blk * GRU_SB, sb = T - s0;
-        const float* hp = hist + (blk & 1) * GRU_SB * 320;
-        for (int e = g; e < sb * 320; e += 192) {
-            const int s = e / 320, k = e % 320;
-            const int t = t_of(s0 + s);
-            if (k < 64) out[(size_t)(b * T + t) * 128 + dir * 64 + k] = hp[e];
-            else if (gates) gates[((size_t)(b * T + t) * 2 + dir) * 256 + (k - 64)] = hp[e];
+        if (g < 64) {
+            const float r = sigmoidf_fast(gis[g] + ghs[g]);
+            const float z = sigmoidf_fast(gis[64 + g] + ghs[64 + g]);
+            const float ghn = ghs[128 + g];
+            const float nn = tanhf_fast(gis[128 + g] + r * ghn);
+            const float h = (1.0f - z) * nn + z * hprev;
+            out[(size_t)(b * T + t) * 128 + dir * 64 + g] = h;
+            if (gates) {
+                float* gs = gates + ((size_t)(b * T + t) * 2 + dir) * 256;
+                gs[g] = r; gs[64 + g] = z; gs[128 + g] = nn; gs[192 + g] = ghn;
+            }
+            hs[g] = h;
+            hprev = h;
         }
+        lds_barrier();
     }
 }
 
-// Backward through time.  Thread = (gate block part = tid>>6, hidden unit j = tid&63) holds column j of
-// W_hh's gate block `part` (W_hh^T mat-vec: dh_prev = W_hh^T dgh).  Per step inputs: d_out, r, z, n, gh_n,
-// h_prev (6 x 64); outputs: dgi (192), dgh (192), h_prev (64).
 __global__ __launch_bounds__(192) void k_gru_bwd(const float* __restrict__ d_out, const float* __restrict__ out,
                                                   const float* __restrict__ gates, const float* __restrict__ w_hh_f,
                                                   const float* __restrict__ w_hh_r, float* __restrict__ dgi,
                                                   float* __restrict__ dgh, float* __restrict__ hprev_out, int T) {
-    extern __shared__ __attribute__((aligned(16))) float gsm[];
-    float* dghs = gsm;                                // [192]
-    float* parts = dghs + 192;                        // [3][64]
-    float* ops = parts + 192;                         // [2][GRU_SB][384] : d_out, r, z, n, gh_n, h_prev
-    float* hist = ops + 2 * GRU_SB * 384;             // [2][GRU_SB][448] : dgi(192), dgh(192), h_prev(64)
+    __shared__ __attribute__((aligned(16))) float dghs[192];
+    __shared__ float parts[3][64];
     const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
     const int part = tid >> 6, j = tid & 63;
     const float* whh = dir ? w_hh_r : w_hh_f;
     float wt[64];   // W_hh[part*64 + i][j], i = 0..63
 #pragma unroll
     for (int i = 0; i < 64; ++i) wt[i] = whh[(part * 64 + i) * 64 + j];
-#pragma unroll
-    for (int i = 0; i < 64; ++i) asm volatile("" : "+v"(wt[i]));      // same reason as `bh` in k_gru_fwd
     float dh_carry = 0.f, dh_z = 0.f;
-    const int nblk = (T + GRU_SB - 1) / GRU_SB;
-    auto t_of = [&](int step) { return dir ? step : (T - 1 - step); };     // reverse of the forward order
-    // address of operand k (0..383: d_out, r, z, n, gh_n, h_prev rows of 64) of recurrence step `step`,
-    // always a valid address (clamped) so that the loads can be issued unconditionally, back to back;
-    // `ok` says whether the value is real or must read as 0 (past the end / h_prev before the first step)
-    auto op_addr = [&](int step, int k, bool& ok) -> const float* {
-        const int t = t_of(min(step, T - 1)), a = k >> 6, jj = k & 63;
-        const int tp = dir ? t + 1 : t - 1;
-        const int tpc = min(max(tp, 0), T - 1);
-        ok = (step < T) && (a != 5 || (tp >= 0 && tp < T));
-        const float* p0 = d_out + (size_t)(b * T + t) * 128 + dir * 64 + jj;
-        const float* p1 = gates + ((size_t)(b * T + t) * 2 + dir) * 256 + (max(a, 1) - 1) * 64 + jj;
-        const float* p2 = out + (size_t)(b * T + tpc) * 128 + dir * 64 + jj;
-        return a == 0 ? p0 : (a < 5 ? p1 : p2);
-    };
-    constexpr int NOP = (GRU_SB * 384) / 192;       // 16 operand values per thread per block
-    {
-        float first[NOP];
-        unsigned okm = 0;
+    // Same load/store wave split as the forward: wave 0 computes and stores, waves 1-2 prefetch the six
+    // operand rows (d_out, r, z, n, gh_n, h_prev) of the NEXT step and pass them through LDS.
+    __shared__ float ops[2][6][64];
+    float pre[3] = {0.f, 0.f, 0.f};
+    const int u = tid - 64;     // 0..127 for the loader waves
+    auto fetch = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < NOP; ++i) {
-            const int e = tid + 192 * i;
-            bool ok;
-            first[i] = *op_addr(e / 384, e % 384, ok);
-            okm |= (ok ? 1u : 0u) << i;
+        for (int k = 0; k < 3; ++k) {
+            const int idx = u + 128 * k, a = idx >> 6, jj = idx & 63;
+            float v;
+            if (a == 0) v = d_out[(size_t)(b * T + t) * 128 + dir * 64 + jj];
+            else if (a < 5) v = gates[((size_t)(b * T + t) * 2 + dir) * 256 + (a - 1) * 64 + jj];
+            else {
+                const int tp = dir ? t + 1 : t - 1;
+                v = (tp >= 0 && tp < T) ? out[(size_t)(b * T + tp) * 128 + dir * 64 + jj] : 0.f;
+            }
+            pre[k] = v;
         }
+    };
+    auto publish = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NOP; ++i) ops[tid + 192 * i] = ((okm >> i) & 1u) ? first[i] : 0.f;
+        for (int k = 0; k < 3; ++k) {
+            const int idx = u + 128 * k;
+            ops[buf][idx >> 6][idx & 63] = pre[k];
+        }
+    };
+    if (tid >= 64) {
+        fetch(dir ? 0 : T - 1);
+        publish(0);
+        if (T > 1) fetch(dir ? 1 : T - 2);
     }
     __syncthreads();
-    for (int blk = 0; blk < nblk; ++blk) {
-        const int cur = blk & 1, s0 = blk * GRU_SB;
-        const int sb = min(GRU_SB, T - s0);
-        if (blk > 0) {
-            const float* hp = hist + (cur ^ 1) * GRU_SB * 448;
-            for (int e = tid; e < GRU_SB * 448; e += 192) {
-                const int s = e / 448, k = e % 448;
-                const size_t bt = (size_t)(b * T + t_of(s0 - GRU_SB + s)) * 2 + dir;
-                if (k < 192) dgi[bt * 192 + k] = hp[e];
-                else if (k < 384) dgh[bt * 192 + (k - 192)] = hp[e];
-                else hprev_out[bt * 64 + (k - 384)] = hp[e];
-            }
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? step : (T - 1 - step);
+        if (tid >= 64) {
+            if (step + 1 < T) publish((step + 1) & 1);                  // operands of step+1 (loaded a step ago)
+            if (step + 2 < T) fetch(dir ? step + 2 : T - 3 - step);     // start loading step+2
+        } else {
+            const float (*o)[64] = ops[step & 1];
+            const float dh = o[0][j] + dh_carry;
+            const float r = o[1][j], z = o[2][j], nn = o[3][j], ghn = o[4][j], hp = o[5][j];
+            const float dn_pre = dh * (1.0f - z) * (1.0f - nn * nn);
+            const float dz_pre = dh * (hp - nn) * z * (1.0f - z);
+            const float dr_pre = dn_pre * ghn * r * (1.0f - r);
+            const size_t base = ((size_t)(b * T + t) * 2 + dir) * 192;
+            dgi[base + j] = dr_pre; dgi[base + 64 + j] = dz_pre; dgi[base + 128 + j] = dn_pre;
+            const float dghn = dn_pre * r;
+            dgh[base + j] = dr_pre; dgh[base + 64 + j] = dz_pre; dgh[base + 128 + j] = dghn;
+            dghs[j] = dr_pre; dghs[64 + j] = dz_pre; dghs[128 + j] = dghn;
+            hprev_out[((size_t)(b * T + t) * 2 + dir) * 64 + j] = hp;
+            dh_z = dh * z;
         }
-        float nxt[NOP];
-        unsigned okm = 0;
-#pragma unroll
-        for (int i = 0; i < NOP; ++i) {
-            const int e = tid + 192 * i;
-            bool ok;
-            nxt[i] = *op_addr(s0 + GRU_SB + e / 384, e % 384, ok);
-            okm |= (ok ? 1u : 0u) << i;
-        }
-        const float* ob = ops + cur * GRU_SB * 384;
-        float* hb = hist + cur * GRU_SB * 448;
-        for (int s = 0; s < sb; ++s) {
-            if (tid < 64) {
-                const float* o = ob + s * 384;
-                const float dh = o[j] + dh_carry;
-                const float r = o[64 + j], z = o[128 + j], nn = o[192 + j], ghn = o[256 + j], hp = o[320 + j];
-                const float dn_pre = dh * (1.0f - z) * (1.0f - nn * nn);
-                const float dz_pre = dh * (hp - nn) * z * (1.0f - z);
-                const float dr_pre = dn_pre * ghn * r * (1.0f - r);
-                const float dghn = dn_pre * r;
-                float* ho = hb + s * 448;
-                ho[j] = dr_pre; ho[64 + j] = dz_pre; ho[128 + j] = dn_pre;
-                ho[192 + j] = dr_pre; ho[256 + j] = dz_pre; ho[320 + j] = dghn;
-                ho[384 + j] = hp;
-                dghs[j] = dr_pre; dghs[64 + j] = dz_pre; dghs[128 + j] = dghn;
-                dh_z = dh * z;
-            }
-            lds_barrier();
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-            for (int i = 0; i < 64; i += 4) {
-                const float4 d4 = *(const float4*)(dghs + part * 64 + i);
-                a0 = fmaf(wt[i], d4.x, a0);
-                a1 = fmaf(wt[i + 1], d4.y, a1);
-                a2 = fmaf(wt[i + 2], d4.z, a2);
-                a3 = fmaf(wt[i + 3], d4.w, a3);
-            }
-            parts[part * 64 + j] = (a0 + a1) + (a2 + a3);
-            lds_barrier();
-            if (tid < 64) dh_carry = dh_z + parts[j] + parts[64 + j] + parts[128 + j];
-        }
-        float* on = ops + (cur ^ 1) * GRU_SB * 384;
-#pragma unroll
-        for (int i = 0; i < NOP; ++i) on[tid + 192 * i] = ((okm >> i) & 1u) ? nxt[i] : 0.f;
         lds_barrier();
-    }
-    {
-        const int blk = nblk - 1, s0 = blk * GRU_SB, sb = T - s0;
-        const float* hp = hist + (blk & 1) * GRU_SB * 448;
-        for (int e = tid; e < sb * 448; e += 192) {
-            const int s = e / 448, k = e % 448;
-            const size_t bt = (size_t)(b * T + t_of(s0 + s)) * 2 + dir;
-            if (k < 192) dgi[bt * 192 + k] = hp[e];
-            else if (k < 384) dgh[bt * 192 + (k - 192)] = hp[e];
-            else hprev_out[bt * 64 + (k - 384)] = hp[e];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 64; i += 4) {
+            const float4 d4 = *(const float4*)(dghs + part * 64 + i);
+            a0 = fmaf(wt[i], d4.x, a0);
+            a1 = fmaf(wt[i + 1], d4.y, a1);
+            a2 = fmaf(wt[i + 2], d4.z, a2);
+            a3 = fmaf(wt[i + 3], d4.w, a3);
         }
+        parts[part][j] = (a0 + a1) + (a2 + a3);
+        lds_barrier();
+        if (tid < 64) dh_carry = dh_z + parts[0][j] + parts[1][j] + parts[2][j];
     }
 }
 
-static const size_t GRU_FWD_LDS = (size_t)(64 + 192 + 2 * GRU_SB * 192 + 2 * GRU_SB * 320 + 192 * 68) * sizeof(float);
-static const size_t GRU_BWD_LDS = (size_t)(192 + 192 + 2 * GRU_SB * 384 + 2 * GRU_SB * 448) * sizeof(float);
-
 int launch_gru_fwd(const float* gi, const float* w_hh_f, const float* w_hh_r, const float* b_hh_f, const float* b_hh_r,
                    float* out, float* gates, int B, int T, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gru_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRU_FWD_LDS));
-        attr_done = true;
-    }
-    k_gru_fwd<<<dim3(B, 2), 192, GRU_FWD_LDS, st>>>(gi, w_hh_f, w_hh_r, b_hh_f, b_hh_r, out, gates, T);
+    k_gru_fwd<<<dim3(B, 2), 192, 0, st>>>(gi, w_hh_f, w_hh_r, b_hh_f, b_hh_r, out, gates, T);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
 
 int launch_gru_bwd(const float* d_out, const float* out, const float* gates, const float* w_hh_f, const float* w_hh_r,
                    float* dgi, float* dgh, float* hprev, int B, int T, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gru_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRU_BWD_LDS));
-        attr_done = true;
-    }
-    k_gru_bwd<<<dim3(B, 2), 192, GRU_BWD_LDS, st>>>(d_out, out, gates, w_hh_f, w_hh_r, dgi, dgh, hprev, T);
+    k_gru_bwd<<<dim3(B, 2), 192, 0, st>>>(d_out, out, gates, w_hh_f, w_hh_r, dgi, dgh, hprev, T);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

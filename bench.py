@@ -164,7 +164,8 @@ def kernel_roofline(step, iters=20):
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / iters
-        out[name] = {"us": round(us, 2), "tflops": round(fl / us * 1e-6, 2), "gbs": round(by / us * 1e-3, 1)}
+        out[name] = {"us": round(us, 2), "tflops": round(fl / us * 1e-6, 2), "gbs": round(by / us * 1e-3, 1),
+                     "flops": int(fl), "bytes": int(by)}
     return out
 
 
@@ -242,11 +243,25 @@ def main():
             "loss": round(meters["loss"], 5),
         }
         kr = kernel_roofline(step)
-        dom = max(kr, key=lambda k: kr[k]["us"])
+        mfma_kernels = ("conv1_fwd", "conv1_dgrad", "conv1_wgrad")       # the genuinely dense GEMM kernels
+        dom = max(mfma_kernels, key=lambda k: kr[k]["us"])
+        traffic, traffic_src = None, None
+        pmc_file = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        pmc_name = {"conv1_fwd": "void k_conv3x3<16, 0, 1>", "conv1_dgrad": "void k_conv3x3<16, 1, 1>",
+                    "conv1_wgrad": "void k_conv3x3_wgrad<16, 1>"}[dom]
+        if os.path.exists(pmc_file):
+            pmc = json.load(open(pmc_file)).get(pmc_name)
+            if pmc:
+                traffic = pmc["read_bytes"] + pmc["write_bytes"]
+                traffic_src = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench "
+                               "(2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes), per launch; measured offline, not in this run")
         res["roofline"] = {
             "bound": "mfma", "kernel": dom, "achieved": kr[dom]["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(kr[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(kr[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "traffic_source": traffic_src, "algorithmic_bytes": kr[dom]["bytes"], "algorithmic_flops": kr[dom]["flops"],
             "avg_launch_us": kr[dom]["us"],
+            "timing": "HIP events on the launch stream around 20 re-launches of this kernel on the step's own "
+                      "buffers (sed_kernel_replay) right after the timed region",
             "whole_step": {"algorithmic_tflops": round(STEP_FLOP_PER_CLIP / t_clip_us * 1e-6, 2),
                            "frac_of_f32_mfma_peak": round(STEP_FLOP_PER_CLIP / t_clip_us * 1e-6 / PEAK_F32_MFMA_TFLOPS, 4),
                            "algorithmic_gbs": round(STEP_BYTES_PER_CLIP / t_clip_us * 1e-3, 1)},

@@ -6,179 +6,305 @@
 // with gi = W_ih x + b_ih (one batched GEMM over all time steps, gemm.hip) and
 // gh = W_hh h + b_hh (this file).
 //
-// The recurrence is a serial chain of T/8 steps, so it is latency- not throughput-bound: one
-// workgroup per (clip, direction) keeps its W_hh slice in REGISTERS for all steps (192 threads x
-// 64 weights), broadcasts h through LDS, and all B x 2 chains run concurrently on separate CUs.
-// Backward keeps W_hh^T the same way (thread = (gate block, hidden unit j)).
+// The recurrence is a serial chain of T/8 steps: latency-, not throughput-bound (measured: the step time is
+// instruction latency + barrier skew, not memory).  Design, one workgroup = 2 waves per (clip, direction),
+// all B x 2 chains concurrently on separate CUs:
+//   * wave 0 COMPUTES ALONE: lane j owns hidden unit j and keeps the three W_hh rows (r, z, n) of that unit
+//     - 192 weights - in registers for all steps.  Everything a step needs from other lanes is the 64-float
+//     h vector, broadcast through LDS inside the wave: in-order LDS, NO workgroup barrier in the step loop
+//     (the first version split the rows over 3 waves and paid 2 barriers + cross-wave skew per step).
+//     The mat-vec is written on float2 so it compiles to v_pk_fma_f32 on natural register pairs.
+//   * wave 1 does ALL global memory traffic, GRU_SB steps at a time: prefetches the next block's inputs,
+//     writes the previous block's outputs from an LDS ring, hands the inputs over in LDS.  On CDNA4 `vmcnt`
+//     counts loads and stores alike and they retire out of order w.r.t. each other, so a wave that both
+//     loads and stores per step would drain its stores (full write latency) before every use of a load.
+//   The two waves meet at ONE LDS-only barrier per block of GRU_SB steps.
+// Backward is the same structure with lane j owning COLUMN j of W_hh (dh_prev = W_hh^T dgh).
 #include "common.h"
 #include "kernels.h"
 
-__device__ __forceinline__ float tanhf_fast(float x) { return 1.0f - 2.0f * rcp_fast(1.0f + __expf(2.0f * x)); }
+#define GRU_SB 8
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(192) void k_gru_fwd(const float* __restrict__ gi, const float* __restrict__ w_hh_f,
+__device__ __forceinline__ float tanhf_fast(float x) { return 1.0f - 2.0f * rcp_fast(1.0f + __expf(2.0f * x)); }
+__device__ __forceinline__ v2f pkfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_gru_fwd(const float* __restrict__ gi, const float* __restrict__ w_hh_f,
                                                   const float* __restrict__ w_hh_r, const float* __restrict__ b_hh_f,
                                                   const float* __restrict__ b_hh_r, float* __restrict__ out,
                                                   float* __restrict__ gates, int T) {
-    __shared__ __attribute__((aligned(16))) float hs[64];
-    __shared__ float ghs[192];
-    __shared__ float gis[192];
-    __shared__ __attribute__((aligned(16))) float Wl[192 * 68];   // W_hh staged coalesced; row stride 68: conflict-free b128 row reads
-    const int b = blockIdx.x, dir = blockIdx.y, g = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    float* hs = gsm;                                  // [64]
+    float* gi_s = hs + 64;                            // [2][GRU_SB][192]
+    float* hist = gi_s + 2 * GRU_SB * 192;            // [2][GRU_SB][320] : h, r, z, n, gh_n
+    float* Wl = hist + 2 * GRU_SB * 320;              // [192][68] staging of W_hh (coalesced global read)
+    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+    const bool io = tid >= 64;                        // wave 1
+    const int l = tid & 63;
     const float* whh = dir ? w_hh_r : w_hh_f;
-    for (int e = g; e < 192 * 64; e += 192) Wl[(e >> 6) * 68 + (e & 63)] = whh[e];
-    __syncthreads();
-    float w[64];
+    const float* bhh = dir ? b_hh_r : b_hh_f;
+    const int nblk = (T + GRU_SB - 1) / GRU_SB;
+    auto t_of = [&](int step) { return dir ? (T - 1 - step) : step; };
+    const size_t gi_base = ((size_t)b * T * 2 + dir) * 192;     // + t * 384 + k
+    for (int e = tid; e < 192 * 64; e += 128) Wl[(e >> 6) * 68 + (e & 63)] = whh[e];
+    if (io) {   // inputs of block 0
+        float first[3 * GRU_SB];
 #pragma unroll
-    for (int j = 0; j < 64; j += 4) {
-        const float4 v = *(const float4*)(Wl + g * 68 + j);
-        w[j] = v.x; w[j + 1] = v.y; w[j + 2] = v.z; w[j + 3] = v.w;
+        for (int i = 0; i < 3 * GRU_SB; ++i)
+            first[i] = gi[gi_base + (size_t)t_of(min(i / 3, T - 1)) * 384 + 64 * (i % 3) + l];
+#pragma unroll
+        for (int i = 0; i < 3 * GRU_SB; ++i) gi_s[(i / 3) * 192 + 64 * (i % 3) + l] = first[i];
+    } else {
+        hs[l] = 0.f;
     }
-    const float bh = (dir ? b_hh_r : b_hh_f)[g];
-    if (g < 64) hs[g] = 0.f;
-    float hprev = 0.f;
-    // Wave roles keep global LOADS and global STORES in different waves.  vmcnt counts both and they
-    // complete out of order with respect to each other, so a wave that does both must drain its stores
-    // (full write latency) every time it needs a loaded value.  Wave 0 (gate math) only stores; waves 1-2
-    // only load - gi of the NEXT step, one iteration ahead, for all 192 gate rows - and hand it over in LDS.
-    float gi_a = 0.f, gi_b = 0.f;
-    auto fetch = [&](int t) {
-        const float* src = gi + ((size_t)(b * T + t) * 2 + dir) * 192;
-        gi_a = src[g];
-        if (g < 128) gi_b = src[g - 64];
-    };
-    if (g >= 64) fetch(dir ? T - 1 : 0);
     __syncthreads();
-    for (int step = 0; step < T; ++step) {
-        const int t = dir ? (T - 1 - step) : step;
-        float cur_a = 0.f, cur_b = 0.f;
-        if (g >= 64) {
-            cur_a = gi_a; cur_b = gi_b;
-            if (step + 1 < T) fetch(dir ? (T - 2 - step) : (step + 1));
-        }
-        float a0 = bh, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+
+    if (io) {
+        // ================================ I/O wave ==========================================================
+        for (int blk = 0; blk < nblk; ++blk) {
+            const int cur = blk & 1, s0 = blk * GRU_SB;
+            float nxt[3 * GRU_SB];
+            const bool more = s0 + GRU_SB < T;
+            if (more) {
 #pragma unroll
-        for (int j = 0; j < 64; j += 4) {
-            const float4 h4 = *(const float4*)(hs + j);
-            a0 = fmaf(w[j], h4.x, a0);
-            a1 = fmaf(w[j + 1], h4.y, a1);
-            a2 = fmaf(w[j + 2], h4.z, a2);
-            a3 = fmaf(w[j + 3], h4.w, a3);
-        }
-        ghs[g] = (a0 + a1) + (a2 + a3);
-        if (g >= 64) {
-            gis[g] = cur_a;
-            if (g < 128) gis[g - 64] = cur_b;
-        }
-        lds_barrier();
-        if (g < 64) {
-            const float r = sigmoidf_fast(gis[g] + ghs[g]);
-            const float z = sigmoidf_fast(gis[64 + g] + ghs[64 + g]);
-            const float ghn = ghs[128 + g];
-            const float nn = tanhf_fast(gis[128 + g] + r * ghn);
-            const float h = (1.0f - z) * nn + z * hprev;
-            out[(size_t)(b * T + t) * 128 + dir * 64 + g] = h;
-            if (gates) {
-                float* gs = gates + ((size_t)(b * T + t) * 2 + dir) * 256;
-                gs[g] = r; gs[64 + g] = z; gs[128 + g] = nn; gs[192 + g] = ghn;
+                for (int i = 0; i < 3 * GRU_SB; ++i) {
+                    const int st = min(s0 + GRU_SB + i / 3, T - 1);
+                    nxt[i] = gi[gi_base + (size_t)t_of(st) * 384 + 64 * (i % 3) + l];
+                }
             }
-            hs[g] = h;
+            if (blk > 0) {      // outputs of the previous block
+                const float* hp = hist + (cur ^ 1) * GRU_SB * 320;
+#pragma unroll
+                for (int i = 0; i < 5 * GRU_SB; ++i) {
+                    const int s = i / 5, a = i % 5;
+                    const int t = t_of(s0 - GRU_SB + s);
+                    const float v = hp[s * 320 + 64 * a + l];
+                    if (a == 0) out[(size_t)(b * T + t) * 128 + dir * 64 + l] = v;
+                    else if (gates) gates[((size_t)(b * T + t) * 2 + dir) * 256 + 64 * (a - 1) + l] = v;
+                }
+            }
+            if (more) {
+                float* gin = gi_s + (cur ^ 1) * GRU_SB * 192;
+#pragma unroll
+                for (int i = 0; i < 3 * GRU_SB; ++i) gin[(i / 3) * 192 + 64 * (i % 3) + l] = nxt[i];
+            }
+            lds_barrier();      // block boundary
+        }
+        {   // outputs of the last block
+            const int blk = nblk - 1, s0 = blk * GRU_SB, sb = T - s0;
+            const float* hp = hist + (blk & 1) * GRU_SB * 320;
+            for (int i = 0; i < 5 * sb; ++i) {
+                const int s = i / 5, a = i % 5;
+                const int t = t_of(s0 + s);
+                const float v = hp[s * 320 + 64 * a + l];
+                if (a == 0) out[(size_t)(b * T + t) * 128 + dir * 64 + l] = v;
+                else if (gates) gates[((size_t)(b * T + t) * 2 + dir) * 256 + 64 * (a - 1) + l] = v;
+            }
+        }
+        return;
+    }
+    // ==================================== compute wave =======================================================
+    v2f wr[32], wz[32], wn[32];       // rows l, 64+l, 128+l of W_hh
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const v4f a = *(const v4f*)(Wl + l * 68 + 4 * q);
+        const v4f c = *(const v4f*)(Wl + (64 + l) * 68 + 4 * q);
+        const v4f d = *(const v4f*)(Wl + (128 + l) * 68 + 4 * q);
+        wr[2 * q] = a.xy; wr[2 * q + 1] = a.zw;
+        wz[2 * q] = c.xy; wz[2 * q + 1] = c.zw;
+        wn[2 * q] = d.xy; wn[2 * q + 1] = d.zw;
+    }
+    float bh_r = bhh[l], bh_z = bhh[64 + l], bh_n = bhh[128 + l];
+    asm volatile("" : "+v"(bh_r), "+v"(bh_z), "+v"(bh_n));      // pin the waits for these loads before the loop
+    float hprev = 0.f;
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int cur = blk & 1, s0 = blk * GRU_SB, sb = min(GRU_SB, T - s0);
+        const float* gib = gi_s + cur * GRU_SB * 192;
+        float* hb = hist + cur * GRU_SB * 320;
+        for (int s = 0; s < sb; ++s) {
+            v2f ar0 = {bh_r, 0.f}, ar1 = {0.f, 0.f}, az0 = {bh_z, 0.f}, az1 = {0.f, 0.f}, an0 = {bh_n, 0.f}, an1 = {0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const v4f h4 = *(const v4f*)(hs + 4 * q);
+                ar0 = pkfma(wr[2 * q], h4.xy, ar0); ar1 = pkfma(wr[2 * q + 1], h4.zw, ar1);
+                az0 = pkfma(wz[2 * q], h4.xy, az0); az1 = pkfma(wz[2 * q + 1], h4.zw, az1);
+                an0 = pkfma(wn[2 * q], h4.xy, an0); an1 = pkfma(wn[2 * q + 1], h4.zw, an1);
+            }
+            const float gh_r = (ar0.x + ar0.y) + (ar1.x + ar1.y);
+            const float gh_z = (az0.x + az0.y) + (az1.x + az1.y);
+            const float ghn = (an0.x + an0.y) + (an1.x + an1.y);
+            const float* gr = gib + s * 192;
+            const float r = sigmoidf_fast(gr[l] + gh_r);
+            const float z = sigmoidf_fast(gr[64 + l] + gh_z);
+            const float nn = tanhf_fast(gr[128 + l] + r * ghn);
+            const float h = (1.0f - z) * nn + z * hprev;
+            float* ho = hb + s * 320;
+            ho[l] = h; ho[64 + l] = r; ho[128 + l] = z; ho[192 + l] = nn; ho[256 + l] = ghn;
+            hs[l] = h;          // same wave reads it back next step: in-order LDS, no barrier
             hprev = h;
         }
-        lds_barrier();
+        lds_barrier();          // block boundary: next block's inputs are in LDS, this block's outputs may be read
     }
 }
 
-__global__ __launch_bounds__(192) void k_gru_bwd(const float* __restrict__ d_out, const float* __restrict__ out,
+// ---------------------------------------------------------------------------------------------------------
+// Backward through time.  Per step inputs: d_out, r, z, n, gh_n, h_prev (6 rows of 64); outputs: dgi (192),
+// dgh (192), h_prev (64) = 7 rows of 64.
+__global__ __launch_bounds__(128) void k_gru_bwd(const float* __restrict__ d_out, const float* __restrict__ out,
                                                   const float* __restrict__ gates, const float* __restrict__ w_hh_f,
                                                   const float* __restrict__ w_hh_r, float* __restrict__ dgi,
                                                   float* __restrict__ dgh, float* __restrict__ hprev_out, int T) {
-    __shared__ __attribute__((aligned(16))) float dghs[192];
-    __shared__ float parts[3][64];
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    float* dghs = gsm;                                // [192]
+    float* ops = dghs + 192;                          // [2][GRU_SB][384] : d_out, r, z, n, gh_n, h_prev
+    float* hist = ops + 2 * GRU_SB * 384;             // [2][GRU_SB][448] : dgi(192), dgh(192), h_prev(64)
     const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
-    const int part = tid >> 6, j = tid & 63;
-    const float* whh = dir ? w_hh_r : w_hh_f;
-    float wt[64];   // W_hh[part*64 + i][j], i = 0..63
-#pragma unroll
-    for (int i = 0; i < 64; ++i) wt[i] = whh[(part * 64 + i) * 64 + j];
-    float dh_carry = 0.f, dh_z = 0.f;
-    // Same load/store wave split as the forward: wave 0 computes and stores, waves 1-2 prefetch the six
-    // operand rows (d_out, r, z, n, gh_n, h_prev) of the NEXT step and pass them through LDS.
-    __shared__ float ops[2][6][64];
-    float pre[3] = {0.f, 0.f, 0.f};
-    const int u = tid - 64;     // 0..127 for the loader waves
-    auto fetch = [&](int t) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int idx = u + 128 * k, a = idx >> 6, jj = idx & 63;
-            float v;
-            if (a == 0) v = d_out[(size_t)(b * T + t) * 128 + dir * 64 + jj];
-            else if (a < 5) v = gates[((size_t)(b * T + t) * 2 + dir) * 256 + (a - 1) * 64 + jj];
-            else {
-                const int tp = dir ? t + 1 : t - 1;
-                v = (tp >= 0 && tp < T) ? out[(size_t)(b * T + tp) * 128 + dir * 64 + jj] : 0.f;
-            }
-            pre[k] = v;
+    const bool io = tid >= 64;
+    const int l = tid & 63;
+    const int nblk = (T + GRU_SB - 1) / GRU_SB;
+    auto t_of = [&](int step) { return dir ? step : (T - 1 - step); };     // reverse of the forward order
+    // operand row a (0: d_out, 1-4: r z n gh_n, 5: h_prev) of recurrence step `step`, lane l; clamped address +
+    // validity, so that the loads issue unconditionally back to back
+    auto op_load = [&](int step, int a, bool& ok) -> float {
+        const int t = t_of(min(step, T - 1));
+        const int tp = dir ? t + 1 : t - 1;
+        const int tpc = min(max(tp, 0), T - 1);
+        ok = (step < T) && (a != 5 || (tp >= 0 && tp < T));
+        const float* p = (a == 0) ? d_out + (size_t)(b * T + t) * 128 + dir * 64 + l
+                       : (a < 5)  ? gates + ((size_t)(b * T + t) * 2 + dir) * 256 + (a - 1) * 64 + l
+                                  : out + (size_t)(b * T + tpc) * 128 + dir * 64 + l;
+        return *p;
+    };
+    auto store_hist = [&](const float* hp, int s0, int n_steps) {
+        for (int i = 0; i < 7 * n_steps; ++i) {
+            const int s = i / 7, a = i % 7;
+            const size_t bt = (size_t)(b * T + t_of(s0 + s)) * 2 + dir;
+            const float v = hp[s * 448 + 64 * a + l];
+            if (a < 3) dgi[bt * 192 + 64 * a + l] = v;
+            else if (a < 6) dgh[bt * 192 + 64 * (a - 3) + l] = v;
+            else hprev_out[bt * 64 + l] = v;
         }
     };
-    auto publish = [&](int buf) {
+    if (io) {
+        float first[6 * GRU_SB];
+        unsigned long long okm = 0;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int idx = u + 128 * k;
-            ops[buf][idx >> 6][idx & 63] = pre[k];
+        for (int i = 0; i < 6 * GRU_SB; ++i) {
+            bool ok;
+            first[i] = op_load(i / 6, i % 6, ok);
+            okm |= (ok ? 1ull : 0ull) << i;
         }
-    };
-    if (tid >= 64) {
-        fetch(dir ? 0 : T - 1);
-        publish(0);
-        if (T > 1) fetch(dir ? 1 : T - 2);
+#pragma unroll
+        for (int i = 0; i < 6 * GRU_SB; ++i) ops[(i / 6) * 384 + 64 * (i % 6) + l] = ((okm >> i) & 1ull) ? first[i] : 0.f;
     }
     __syncthreads();
-    for (int step = 0; step < T; ++step) {
-        const int t = dir ? step : (T - 1 - step);
-        if (tid >= 64) {
-            if (step + 1 < T) publish((step + 1) & 1);                  // operands of step+1 (loaded a step ago)
-            if (step + 2 < T) fetch(dir ? step + 2 : T - 3 - step);     // start loading step+2
-        } else {
-            const float (*o)[64] = ops[step & 1];
-            const float dh = o[0][j] + dh_carry;
-            const float r = o[1][j], z = o[2][j], nn = o[3][j], ghn = o[4][j], hp = o[5][j];
+
+    if (io) {
+        // ================================ I/O wave ==========================================================
+        for (int blk = 0; blk < nblk; ++blk) {
+            const int cur = blk & 1, s0 = blk * GRU_SB;
+            float nxt[6 * GRU_SB];
+            unsigned long long okm = 0;
+            const bool more = s0 + GRU_SB < T;
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < 6 * GRU_SB; ++i) {
+                    bool ok;
+                    nxt[i] = op_load(s0 + GRU_SB + i / 6, i % 6, ok);
+                    okm |= (ok ? 1ull : 0ull) << i;
+                }
+            }
+            if (blk > 0) {
+                const float* hp = hist + (cur ^ 1) * GRU_SB * 448;
+#pragma unroll
+                for (int i = 0; i < 7 * GRU_SB; ++i) {
+                    const int s = i / 7, a = i % 7;
+                    const size_t bt = (size_t)(b * T + t_of(s0 - GRU_SB + s)) * 2 + dir;
+                    const float v = hp[s * 448 + 64 * a + l];
+                    if (a < 3) dgi[bt * 192 + 64 * a + l] = v;
+                    else if (a < 6) dgh[bt * 192 + 64 * (a - 3) + l] = v;
+                    else hprev_out[bt * 64 + l] = v;
+                }
+            }
+            if (more) {
+                float* on = ops + (cur ^ 1) * GRU_SB * 384;
+#pragma unroll
+                for (int i = 0; i < 6 * GRU_SB; ++i) on[(i / 6) * 384 + 64 * (i % 6) + l] = ((okm >> i) & 1ull) ? nxt[i] : 0.f;
+            }
+            lds_barrier();
+        }
+        store_hist(hist + ((nblk - 1) & 1) * GRU_SB * 448, (nblk - 1) * GRU_SB, T - (nblk - 1) * GRU_SB);
+        return;
+    }
+    // ==================================== compute wave =======================================================
+    const float* whh = dir ? w_hh_r : w_hh_f;
+    v2f wt[96];   // column l of W_hh: wt[i/2][i&1] = W_hh[i][l], i = 0..191
+#pragma unroll
+    for (int i = 0; i < 96; ++i) {
+        wt[i].x = whh[(2 * i) * 64 + l];
+        wt[i].y = whh[(2 * i + 1) * 64 + l];
+    }
+#pragma unroll
+    for (int i = 0; i < 96; ++i) asm volatile("" : "+v"(wt[i]));      // pin the load waits before the loop
+    float dh_carry = 0.f;
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int cur = blk & 1, s0 = blk * GRU_SB, sb = min(GRU_SB, T - s0);
+        const float* ob = ops + cur * GRU_SB * 384;
+        float* hb = hist + cur * GRU_SB * 448;
+        for (int s = 0; s < sb; ++s) {
+            const float* o = ob + s * 384;
+            const float dh = o[l] + dh_carry;
+            const float r = o[64 + l], z = o[128 + l], nn = o[192 + l], ghn = o[256 + l], hp = o[320 + l];
             const float dn_pre = dh * (1.0f - z) * (1.0f - nn * nn);
             const float dz_pre = dh * (hp - nn) * z * (1.0f - z);
             const float dr_pre = dn_pre * ghn * r * (1.0f - r);
-            const size_t base = ((size_t)(b * T + t) * 2 + dir) * 192;
-            dgi[base + j] = dr_pre; dgi[base + 64 + j] = dz_pre; dgi[base + 128 + j] = dn_pre;
             const float dghn = dn_pre * r;
-            dgh[base + j] = dr_pre; dgh[base + 64 + j] = dz_pre; dgh[base + 128 + j] = dghn;
-            dghs[j] = dr_pre; dghs[64 + j] = dz_pre; dghs[128 + j] = dghn;
-            hprev_out[((size_t)(b * T + t) * 2 + dir) * 64 + j] = hp;
-            dh_z = dh * z;
-        }
-        lds_barrier();
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            float* ho = hb + s * 448;
+            ho[l] = dr_pre; ho[64 + l] = dz_pre; ho[128 + l] = dn_pre;
+            ho[192 + l] = dr_pre; ho[256 + l] = dz_pre; ho[320 + l] = dghn;
+            ho[384 + l] = hp;
+            dghs[l] = dr_pre; dghs[64 + l] = dz_pre; dghs[128 + l] = dghn;     // read back by this same wave
+            v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 64; i += 4) {
-            const float4 d4 = *(const float4*)(dghs + part * 64 + i);
-            a0 = fmaf(wt[i], d4.x, a0);
-            a1 = fmaf(wt[i + 1], d4.y, a1);
-            a2 = fmaf(wt[i + 2], d4.z, a2);
-            a3 = fmaf(wt[i + 3], d4.w, a3);
+            for (int q = 0; q < 48; q += 2) {
+                const v4f d0 = *(const v4f*)(dghs + 4 * q);
+                const v4f d1 = *(const v4f*)(dghs + 4 * q + 4);
+                a0 = pkfma(wt[2 * q], d0.xy, a0);
+                a1 = pkfma(wt[2 * q + 1], d0.zw, a1);
+                a2 = pkfma(wt[2 * q + 2], d1.xy, a2);
+                a3 = pkfma(wt[2 * q + 3], d1.zw, a3);
+            }
+            dh_carry = dh * z + ((a0.x + a0.y) + (a1.x + a1.y)) + ((a2.x + a2.y) + (a3.x + a3.y));
         }
-        parts[part][j] = (a0 + a1) + (a2 + a3);
         lds_barrier();
-        if (tid < 64) dh_carry = dh_z + parts[0][j] + parts[1][j] + parts[2][j];
     }
 }
 
+static const size_t GRU_FWD_LDS = (size_t)(64 + 2 * GRU_SB * 192 + 2 * GRU_SB * 320 + 192 * 68) * sizeof(float);
+static const size_t GRU_BWD_LDS = (size_t)(192 + 2 * GRU_SB * 384 + 2 * GRU_SB * 448) * sizeof(float);
+
 int launch_gru_fwd(const float* gi, const float* w_hh_f, const float* w_hh_r, const float* b_hh_f, const float* b_hh_r,
                    float* out, float* gates, int B, int T, hipStream_t st) {
-    k_gru_fwd<<<dim3(B, 2), 192, 0, st>>>(gi, w_hh_f, w_hh_r, b_hh_f, b_hh_r, out, gates, T);
+    static bool attr_done = false;
+    if (!attr_done) {
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gru_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRU_FWD_LDS));
+        attr_done = true;
+    }
+    k_gru_fwd<<<dim3(B, 2), 128, GRU_FWD_LDS, st>>>(gi, w_hh_f, w_hh_r, b_hh_f, b_hh_r, out, gates, T);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
 
 int launch_gru_bwd(const float* d_out, const float* out, const float* gates, const float* w_hh_f, const float* w_hh_r,
                    float* dgi, float* dgh, float* hprev, int B, int T, hipStream_t st) {
-    k_gru_bwd<<<dim3(B, 2), 192, 0, st>>>(d_out, out, gates, w_hh_f, w_hh_r, dgi, dgh, hprev, T);
+    static bool attr_done = false;
+    if (!attr_done) {
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gru_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRU_BWD_LDS));
+        attr_done = true;
+    }
+    k_gru_bwd<<<dim3(B, 2), 128, GRU_BWD_LDS, st>>>(d_out, out, gates, w_hh_f, w_hh_r, dgi, dgh, hprev, T);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

@@ -169,6 +169,188 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in0, 
     }
 }
 
+
+// ---- weight-stationary persistent variant for W = 16 (conv block 1: 88 % of the conv FLOPs) ------------------
+// PMC on the tile kernel above (k_conv3x3<16,..>): MFMA pipe busy 55 % of the kernel, waves parked in
+// s_waitcnt / s_barrier 38 % of their cycles - the per-tap weight slab hand-over (LDS double buffer + barrier)
+// and the un-overlapped halo staging keep the 2 resident waves per SIMD from covering each other.  Here the
+// WEIGHTS stay in registers for the whole life of a persistent workgroup instead:
+//   * wave w owns output channels [16w, 16w+16) and holds their full K = 9 x 64 weight panel as
+//     v_mfma_f32_16x16x4_f32 B fragments: 144 VGPRs, loaded once;
+//   * a tile is 8 image rows x 16 pixels; each wave computes all 128 pixels x its 16 channels
+//     (8 independent 16x16 accumulators -> back-to-back MFMA issue from one wave per SIMD);
+//   * no LDS weight traffic and NO barrier inside a tile; the next tile's halo is prefetched into registers
+//     while the current tile computes and is written to the other LDS halo buffer afterwards (one barrier
+//     per tile); halo pixel stride 66 floats makes the A-fragment reads (lane = pixel x 4 channels)
+//     bank-conflict free;
+//   * BatchNorm sums are accumulated in registers across all tiles of the workgroup: 32 atomics per wave
+//     per launch.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+struct Ws16 {
+    static constexpr int TH = 8, TW = 16, HW = 18, HH = 10, PS = 66, RS = HW * PS;
+    static constexpr int HALO_FLOATS = HH * RS;
+    static constexpr size_t LDS_BYTES = (size_t)2 * HALO_FLOATS * 4;
+    static constexpr int NLD = (HH * HW * 16 + 255) / 256;     // float4 loads per thread per halo
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void k_conv16_ws(const float* __restrict__ in0, const float* __restrict__ in1,
+                                                       const float* __restrict__ coef, const float* __restrict__ wpk,
+                                                       const float* __restrict__ bias, float* __restrict__ out,
+                                                       double* __restrict__ stat, int H, int tiles_per_clip, int n_tiles) {
+    using C = Ws16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int p16 = lane & 15, kq = lane >> 4;
+    float st1 = 0.f, st2 = 0.f;
+
+    float4 pre0[C::NLD], pre1[C::NLD];
+    auto load_halo = [&](int tile) {
+        const int b = tile / tiles_per_clip, y0 = (tile % tiles_per_clip) * C::TH;
+#pragma unroll
+        for (int it = 0; it < C::NLD; ++it) {
+            const int f = tid + 256 * it;
+            const int pix = f >> 4, c4 = (f & 15) * 4;
+            const int hy = pix / C::HW, hx = pix % C::HW;
+            const int iy = y0 - 1 + hy, ix = hx - 1;
+            const bool ok = (f < C::HH * C::HW * 16) && iy >= 0 && iy < H && ix >= 0 && ix < C::TW;
+            const size_t g = ok ? (((size_t)b * H + iy) * C::TW + ix) * 64 + c4 : 0;
+            float4 v = *(const float4*)(in0 + g);
+            if (MODE == 1) pre1[it] = *(const float4*)(in1 + g);
+            if (!ok) { v = make_float4(0.f, 0.f, 0.f, 0.f); if (MODE == 1) pre1[it] = v; }
+            pre0[it] = v;
+        }
+    };
+    auto store_halo = [&](float* halo, int tile) {
+        const int y0 = (tile % tiles_per_clip) * C::TH;
+#pragma unroll
+        for (int it = 0; it < C::NLD; ++it) {
+            const int f = tid + 256 * it;
+            if (f >= C::HH * C::HW * 16) continue;
+            const int pix = f >> 4, c4 = (f & 15) * 4;
+            const int hy = pix / C::HW, hx = pix % C::HW;
+            float4 v = pre0[it];
+            if (MODE == 1) {
+                const int iy = y0 - 1 + hy, ix = hx - 1;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < C::TW) {      // padding stays exactly 0
+                    const float4 yv = pre1[it];
+                    const float4 ca = *(const float4*)(coef + c4);
+                    const float4 cb = *(const float4*)(coef + 64 + c4);
+                    const float4 cc = *(const float4*)(coef + 128 + c4);
+                    v.x = ca.x * v.x + cb.x * yv.x + cc.x;
+                    v.y = ca.y * v.y + cb.y * yv.y + cc.y;
+                    v.z = ca.z * v.z + cb.z * yv.z + cc.z;
+                    v.w = ca.w * v.w + cb.w * yv.w + cc.w;
+                }
+            }
+            float* d = halo + hy * C::RS + hx * C::PS + c4;          // 8-byte aligned (PS even, c4 % 4 == 0)
+            *(float2*)d = make_float2(v.x, v.y);
+            *(float2*)(d + 2) = make_float2(v.z, v.w);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < n_tiles) load_halo(tile);           // first halo in flight while the weight panel is fetched
+    // ---- this wave's weight panel -> registers --------------------------------------------------------
+    float bw[9][16];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int s4 = 0; s4 < 16; ++s4) bw[t][s4] = wpk[t * 4096 + (4 * s4 + kq) * 64 + 16 * wv + p16];
+    const float bia = (MODE == 0) ? bias[16 * wv + p16] : 0.f;
+    if (tile < n_tiles) store_halo(smem, tile);
+    __syncthreads();
+    int cur = 0;
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int nxt_tile = tile + gridDim.x;
+        if (nxt_tile < n_tiles) load_halo(nxt_tile);          // in flight during this tile's MFMAs
+        const float* halo = smem + cur * C::HALO_FLOATS;
+        const float* Ab = halo + C::RS + (1 + p16) * C::PS + kq;   // pixel (row 0, x = p16), channel kq
+        f32x4_t acc[8];
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb) acc[rb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        // 72 groups of 16 MFMAs (one tap, two 4-channel K steps, 8 image rows).  The A fragments of group
+        // g+1 are read from LDS BEFORE the MFMAs of group g are issued (explicit register double buffer,
+        // pinned with sched_barrier): with one wave per SIMD nothing else would cover the LDS latency.
+        auto load_a = [&](float (&a)[16], int gi) {
+            const int t = gi / 8, sp = gi % 8;
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int rb = 0; rb < 8; ++rb) a[q * 8 + rb] = Ab[(rb + dy) * C::RS + dx * C::PS + 4 * (2 * sp + q)];
+        };
+        auto mma = [&](const float (&a)[16], int gi) {
+            const int t = gi / 8, sp = gi % 8;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int rb = 0; rb < 8; ++rb)
+                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q * 8 + rb], bw[t][2 * sp + q], acc[rb], 0, 0, 0);
+        };
+        float a0[16], a1[16];
+        load_a(a0, 0);
+#pragma unroll
+        for (int gi = 0; gi < 72; gi += 2) {
+            load_a(a1, gi + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, gi);
+            __builtin_amdgcn_sched_barrier(0);
+            if (gi + 2 < 72) load_a(a0, gi + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, gi + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // next tile's halo -> the other LDS buffer BEFORE this tile's output stores are issued: its loads were
+        // issued a whole tile ago, and no store is outstanding yet, so the vmcnt(0) this needs costs nothing
+        // (vmcnt counts stores too; after the epilogue it would drain 32 fresh stores per lane)
+        if (nxt_tile < n_tiles) store_halo(smem + (cur ^ 1) * C::HALO_FLOATS, nxt_tile);
+        // ---- epilogue: D[i][j]: j = lane & 15 -> channel 16*wv + j, i = 4*(lane>>4) + r -> pixel x ------
+        {
+            const int b = tile / tiles_per_clip, y0 = (tile % tiles_per_clip) * C::TH;
+#pragma unroll
+            for (int rb = 0; rb < 8; ++rb) {
+                const int yy = y0 + rb;
+                if (yy < H) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int xx = 4 * kq + r;
+                        const float v = acc[rb][r] + bia;
+                        out[(((size_t)b * H + yy) * C::TW + xx) * 64 + 16 * wv + p16] = v;
+                        if (MODE == 0) { st1 += v; st2 += v * v; }
+                    }
+                }
+            }
+        }
+        lds_barrier();          // LDS-only: the output stores stay in flight across the tile boundary
+        cur ^= 1;
+    }
+    if (MODE == 0 && stat != nullptr) {
+        st1 += __shfl_xor(st1, 16); st1 += __shfl_xor(st1, 32);
+        st2 += __shfl_xor(st2, 16); st2 += __shfl_xor(st2, 32);
+        if (kq == 0) {
+            atomicAdd(&stat[16 * wv + p16], (double)st1);
+            atomicAdd(&stat[64 + 16 * wv + p16], (double)st2);
+        }
+    }
+}
+
+template <int MODE>
+static int conv16_ws_launch(const float* in0, const float* in1, const float* coef, const float* wpk, const float* bias,
+                            float* out, double* stat, int B, int H, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv16_ws<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)Ws16::LDS_BYTES));
+        attr_done = true;
+    }
+    const int tpc = (H + Ws16::TH - 1) / Ws16::TH, nt = B * tpc;
+    const int grid = nt < 256 ? nt : 256;          // one persistent workgroup per CU
+    k_conv16_ws<MODE><<<grid, 256, Ws16::LDS_BYTES, st>>>(in0, in1, coef, wpk, bias, out, stat, H, tpc, nt);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}
+
 // ---- wgrad ------------------------------------------------------------------------------------
 template <int TW>
 struct WgCfg {
@@ -301,7 +483,8 @@ static int conv_launch_t(const float* in0, const float* in1, const float* coef, 
 int launch_conv_fwd(const float* in, const float* wpk, const float* bias, float* y, double* stat, int zero_stat, int B,
                     int H, int W, hipStream_t st) {
     if (stat && zero_stat) SED_CHECK_HIP(hipMemsetAsync(stat, 0, 128 * sizeof(double), st));
-    if (W == 16) return conv_launch_t<16, 0, 1>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st);
+    if (W == 16) return (g_sed_debug & 2) ? conv_launch_t<16, 0, 1>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st)
+                                          : conv16_ws_launch<0>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st);
     if (W == 4) return conv_launch_t<4, 0, 2>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st);
     sed_set_error("conv: unsupported width %d", W);
     return SED_ERR_UNSUPPORTED;
@@ -309,7 +492,10 @@ int launch_conv_fwd(const float* in, const float* wpk, const float* bias, float*
 
 int launch_conv_dgrad(const float* dz, const float* yin, const float* coef, const float* wpkT, float* dx, int B, int H,
                       int W, hipStream_t st) {
-    if (W == 16) return conv_launch_t<16, 1, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st);
+    // dgrad: the tile kernel measures the same as the weight-stationary one here (the two extra prefetch
+    // registers sets of the affine loader push the WS variant into AGPR shuffling); bit 2 of the debug knob flips it
+    if (W == 16) return (g_sed_debug & 4) ? conv16_ws_launch<1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st)
+                                          : conv_launch_t<16, 1, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st);
     if (W == 4) return conv_launch_t<4, 1, 2>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st);
     sed_set_error("conv dgrad: unsupported width %d", W);
     return SED_ERR_UNSUPPORTED;

@@ -251,7 +251,32 @@ __global__ __launch_bounds__(256) void k_blk0_bwd(const float* __restrict__ x, c
         __syncthreads();
         const int to = to0 + wv;
         if (to >= H1) continue;
+        // pooled gradients + keep bits of a row block are fetched one row block AHEAD: this kernel runs one
+        // wave per SIMD (256 VGPRs), so a load issued right before its use stalls the whole SIMD for a full
+        // HBM/L2 round trip (~1 us per row block in the first version)
+        float gq_n[2][4];
+        uint32_t m_n[2];
+        auto fetch = [&](int g) {
+            const int q0 = (b * H1 + to) * 16 + 4 * g;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = 32 * h + n;
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) gq_n[h][jx] = dp0[(size_t)(q0 + jx) * 64 + c];
+                m_n[h] = use_drop ? (uint32_t)mask_in[((size_t)(q0 >> 2) * 2 + h) * 64 + lane] : 0xffffu;
+            }
+        };
+        fetch(0);
         for (int g = 0; g < 4; ++g) {
+            float gq_c[2][4];
+            uint32_t m_c[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                m_c[h] = m_n[h];
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) gq_c[h][jx] = gq_n[h][jx] * (0.125f * keep_scale);
+            }
+            if (g < 3) fetch(g + 1);
             f32x16 acc[4];
             blk0_rowblock(xs, W, wv, g, lane, acc);
             // im2col of this row block for the reductions: P[m][0..8] taps, [9] = 1, [10..11] = 0
@@ -264,19 +289,12 @@ __global__ __launch_bounds__(256) void k_blk0_bwd(const float* __restrict__ x, c
                     Pw[m * 12 + k] = (k < 9) ? xs[base + (k / 3) * XS_W + (k % 3)] : (k == 9 ? 1.0f : 0.f);
                 }
             }
-            const int q0 = (b * H1 + to) * 16 + 4 * g;
             float dl[2][16], dzg[2][16];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int c = 32 * h + n;
-                float gq[4];
-#pragma unroll
-                for (int jx = 0; jx < 4; ++jx) gq[jx] = dp0[(size_t)(q0 + jx) * 64 + c] * (0.125f * keep_scale);
-                // the forward stored its 16 keep bits per (row block, half, lane): no RNG in backward
-                const uint32_t m16 = use_drop ? (uint32_t)mask_in[((size_t)(q0 >> 2) * 2 + h) * 64 + lane] : 0xffffu;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float gg = ((m16 >> r) & 1u) ? gq[r >> 2] : 0.f;
+                    const float gg = ((m_c[h] >> r) & 1u) ? gq_c[h][r >> 2] : 0.f;
                     const float sg = sigmoidf_fast(acc[2 + h][r]);
                     dl[h][r] = gg * sg;
                     dzg[h][r] = gg * acc[h][r] * sg * (1.0f - sg);

@@ -301,26 +301,9 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
     const float* d_cur = WSF(W.d_out);
     for (int l = g.L - 1; l >= 0; --l) {
         const int nin = (l == 0) ? 64 : 128;
-        const float* input = (l == 0) ? CTXF(L.p2) : CTXF(L.out[l - 1]);
         float* d_in = (l == 0) ? WSF(W.dp2) : WSF(W.d_in);
         SED_TRY(launch_gru_bwd(d_cur, CTXF(L.out[l]), CTXF(L.gates[l]), params + P.w_hh[l][0], params + P.w_hh[l][1],
                                WSF(W.dgi[l]), WSF(W.dgh[l]), WSF(W.hprev[l]), g.B, g.T3, st));
-        if (sd.ok) { SIDE_FORK(st); forked = true; }
-        {
-            // weight + bias gradients of both directions: 4 problems, split-K over the B*T/8 rows
-            //   dW_ih[g][i] = sum_bt dgi[bt][g] input[bt][i],  db_ih[g] = sum_bt dgi[bt][g]
-            //   dW_hh[g][j] = sum_bt dgh[bt][g] hprev[bt][j],  db_hh[g] = sum_bt dgh[bt][g]
-            GemmBatch gb;
-            gb.n_prob = 4; gb.splits = SED_GRU_SPLITK; gb.part = WSF(W.gemm_part); gb.part_stride = 0;
-            for (int dir = 0; dir < 2; ++dir) {
-                gb.p[2 * dir] = gemm_prob(WSF(W.dgi[l]) + dir * 192, 1, 384, input, nin, 1, grads + P.w_ih[l][dir], nin, 192, nin, BT);
-                gb.p[2 * dir].Cones = grads + P.b_ih[l][dir];
-                gb.p[2 * dir + 1] = gemm_prob(WSF(W.dgh[l]) + dir * 192, 1, 384, WSF(W.hprev[l]) + dir * 64, 128, 1,
-                                              grads + P.w_hh[l][dir], 64, 192, 64, BT);
-                gb.p[2 * dir + 1].Cones = grads + P.b_hh[l][dir];
-            }
-            SED_TRY(launch_gemm_batch(gb, ss));          // side stream: only the optimiser needs these
-        }
         {
             // d_in[bt][i] = sum_{dir,g} dgi[bt][dir][g] W_ih[dir][g][i]   (K = 384 = both directions)
             GemmBatch gb;
@@ -330,6 +313,25 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
             SED_TRY(launch_gemm_batch(gb, st));
         }
         d_cur = d_in;
+    }
+    // weight + bias gradients of every GRU layer and direction, on the side stream, forked ONCE after the
+    // whole dX chain of the GRU has been issued (fork points inside the chain cost cross-queue latency):
+    //   dW_ih[g][i] = sum_bt dgi[bt][g] input[bt][i],  db_ih[g] = sum_bt dgi[bt][g]
+    //   dW_hh[g][j] = sum_bt dgh[bt][g] hprev[bt][j],  db_hh[g] = sum_bt dgh[bt][g]
+    if (sd.ok) { SIDE_FORK(st); forked = true; }
+    for (int l = g.L - 1; l >= 0; --l) {
+        const int nin = (l == 0) ? 64 : 128;
+        const float* input = (l == 0) ? CTXF(L.p2) : CTXF(L.out[l - 1]);
+        GemmBatch gb;
+        gb.n_prob = 4; gb.splits = SED_GRU_SPLITK; gb.part = WSF(W.gemm_part); gb.part_stride = 0;
+        for (int dir = 0; dir < 2; ++dir) {
+            gb.p[2 * dir] = gemm_prob(WSF(W.dgi[l]) + dir * 192, 1, 384, input, nin, 1, grads + P.w_ih[l][dir], nin, 192, nin, BT);
+            gb.p[2 * dir].Cones = grads + P.b_ih[l][dir];
+            gb.p[2 * dir + 1] = gemm_prob(WSF(W.dgh[l]) + dir * 192, 1, 384, WSF(W.hprev[l]) + dir * 64, 128, 1,
+                                          grads + P.w_hh[l][dir], 64, 192, 64, BT);
+            gb.p[2 * dir + 1].Cones = grads + P.b_hh[l][dir];
+        }
+        SED_TRY(launch_gemm_batch(gb, ss));
     }
     }
     if (!(parts & 2)) {

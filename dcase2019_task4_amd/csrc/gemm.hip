@@ -41,43 +41,78 @@ __global__ __launch_bounds__(256) void k_gemm_batched(GemmBatch gb) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    // per-thread tile coordinates (fixed over the K loop); 8 A and 8 B elements per thread per tile
-    constexpr int NE = (GT_M * GT_K) / 256;
-    int am[NE], ak[NE], bk[NE], bn[NE];
+    // per-thread tile coordinates (fixed over the K loop); 8 A and 8 B elements per thread per tile, as two
+    // groups of 4 consecutive elements along whichever axis is contiguous in memory, so that a group is ONE
+    // float4 load when it is in range and 16-byte aligned (scalar loads with per-element bounds checks and
+    // 64-bit address arithmetic made the K loop latency-bound: ~1.5 us per iteration)
+    constexpr int NG = (GT_M * GT_K) / 256 / 4;          // float4 groups per thread per matrix (= 2)
+    int am[NG], ak[NG], bk[NG], bn[NG];
+    const bool a_kc = (d.sAk == 1), b_nc = (d.sBn == 1);
 #pragma unroll
-    for (int it = 0; it < NE; ++it) {
-        const int e = tid + 256 * it;
-        if (d.sAk == 1) { am[it] = e / GT_K; ak[it] = e % GT_K; } else { am[it] = e % GT_M; ak[it] = e / GT_M; }
-        if (d.sBn == 1) { bk[it] = e / GT_N; bn[it] = e % GT_N; } else { bk[it] = e % GT_K; bn[it] = e / GT_K; }
+    for (int it = 0; it < NG; ++it) {
+        const int e4 = (tid + 256 * it) * 4;               // first element of the group
+        if (a_kc) { am[it] = e4 / GT_K; ak[it] = e4 % GT_K; } else { am[it] = e4 % GT_M; ak[it] = e4 / GT_M; }
+        if (b_nc) { bk[it] = e4 / GT_N; bn[it] = e4 % GT_N; } else { bk[it] = e4 % GT_K; bn[it] = e4 / GT_K; }
     }
-    float ra[NE], rb[NE];
+    float ra[NG][4], rb[NG][4];
     auto load_tile = [&](int k0) {
 #pragma unroll
-        for (int it = 0; it < NE; ++it) {
-            float v = 0.f;
-            if (m0 + am[it] < d.M && k0 + ak[it] < kend)
-                v = d.A[(int64_t)(m0 + am[it]) * d.sAm + (int64_t)(k0 + ak[it]) * d.sAk];
-            ra[it] = v;
-            float w = 0.f;
-            const int kk = k0 + bk[it], nn = n0 + bn[it];
-            if (kk < kend) {
-                if (nn < d.N) {
-                    w = (d.B2 && kk >= d.k2) ? d.B2[(int64_t)(kk - d.k2) * d.sBk + (int64_t)nn * d.sBn]
-                                             : d.B[(int64_t)kk * d.sBk + (int64_t)nn * d.sBn];
-                } else if (nn == d.N && d.Cones) {
-                    w = 1.0f;
+        for (int it = 0; it < NG; ++it) {
+            // ---- A group: 4 consecutive k (a_kc) or 4 consecutive m ----
+            {
+                const int m = m0 + am[it], k = k0 + ak[it];
+                const float* p = d.A + (int64_t)m * d.sAm + (int64_t)k * d.sAk;
+                const bool full = a_kc ? (m < d.M && k + 3 < kend) : (m + 3 < d.M && k < kend);
+                if (full && (((uintptr_t)p & 15) == 0)) {
+                    const float4 v = *(const float4*)p;
+                    ra[it][0] = v.x; ra[it][1] = v.y; ra[it][2] = v.z; ra[it][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int mm = a_kc ? m : m + q, kk = a_kc ? k + q : k;
+                        ra[it][q] = (mm < d.M && kk < kend) ? d.A[(int64_t)mm * d.sAm + (int64_t)kk * d.sAk] : 0.f;
+                    }
                 }
             }
-            rb[it] = w;
+            // ---- B group: 4 consecutive n (b_nc) or 4 consecutive k ----
+            {
+                const int kk0 = k0 + bk[it], nn0 = n0 + bn[it];
+                const bool two = d.B2 != nullptr;
+                const float* base = (two && kk0 >= d.k2) ? d.B2 - (int64_t)d.k2 * d.sBk : d.B;
+                const float* p = base + (int64_t)kk0 * d.sBk + (int64_t)nn0 * d.sBn;
+                const bool same_src = !two || b_nc || (kk0 >= d.k2) == (kk0 + 3 >= d.k2);
+                const bool full = same_src && (b_nc ? (kk0 < kend && nn0 + 3 < d.N) : (kk0 + 3 < kend && nn0 < d.N));
+                if (full && (((uintptr_t)p & 15) == 0)) {
+                    const float4 v = *(const float4*)p;
+                    rb[it][0] = v.x; rb[it][1] = v.y; rb[it][2] = v.z; rb[it][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int kk = b_nc ? kk0 : kk0 + q, nn = b_nc ? nn0 + q : nn0;
+                        float w = 0.f;
+                        if (kk < kend) {
+                            if (nn < d.N) {
+                                w = (two && kk >= d.k2) ? d.B2[(int64_t)(kk - d.k2) * d.sBk + (int64_t)nn * d.sBn]
+                                                        : d.B[(int64_t)kk * d.sBk + (int64_t)nn * d.sBn];
+                            } else if (nn == d.N && d.Cones) {
+                                w = 1.0f;
+                            }
+                        }
+                        rb[it][q] = w;
+                    }
+                }
+            }
         }
     };
     if (kbeg < kend) load_tile(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += GT_K) {
 #pragma unroll
-        for (int it = 0; it < NE; ++it) {
-            As[am[it] * (GT_K + 1) + ak[it]] = ra[it];
-            Bs[bk[it] * (GT_N + 1) + bn[it]] = rb[it];
-        }
+        for (int it = 0; it < NG; ++it)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                As[(a_kc ? am[it] : am[it] + q) * (GT_K + 1) + (a_kc ? ak[it] + q : ak[it])] = ra[it][q];
+                Bs[(b_nc ? bk[it] : bk[it] + q) * (GT_N + 1) + (b_nc ? bn[it] + q : bn[it])] = rb[it][q];
+            }
         lds_barrier();
         if (k0 + GT_K < kend) load_tile(k0 + GT_K);      // next tile's loads fly under this tile's MFMAs
 #pragma unroll

@@ -25,43 +25,63 @@
 __device__ __forceinline__ int gidx(int a, int b) { return 9 + a * 9 - (a * (a - 1)) / 2 + (b - a); }  // a <= b
 
 // ---- patch moments: s[t] = sum_p P[p][t], G[a][b] = sum_p P[p][a] P[p][b] (upper triangle) ----
+// The 10x10 Gram matrix of the patch matrix P~ = [9 taps | 1] holds both (s = G~[.][9]).  It is a rank-4
+// update per MFMA: v_mfma_f32_16x16x4_f32 with A[i][k] = B[k][i] = P~[pixel k][tap i], i.e. the SAME
+// register feeds both operands - one LDS read per 4 pixels per lane, no cross-lane reduction at all
+// (the first version did 54 FMAs per pixel on the VALU and then 54 six-step shuffle reductions: 22-32 us).
+// fp32 accumulation runs over 1 024 pixels per wave; the cross-wave sums are fp64 and go to a per-workgroup
+// partial row which k_blk0_prep (the next kernel anyway) adds up in fixed order: no memset, no same-address
+// fp64 atomics (240 of them per address cost 7.5 us), bit-reproducible statistics.
 #define MOM_ROWS 64
-__global__ __launch_bounds__(256) void k_x_moments(const float* __restrict__ x, int T, double* __restrict__ mom, int no_atomic) {
+__global__ __launch_bounds__(256) void k_x_moments(const float* __restrict__ x, int T, double* __restrict__ part) {
     __shared__ float xs[(MOM_ROWS + 2) * XS_W];
-    __shared__ float red[4][54];
+    __shared__ float red[4][10][10];
     const int tid = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * MOM_ROWS;
-    for (int i = tid; i < (MOM_ROWS + 2) * XS_W; i += 256) {
-        int r = i / XS_W, c = i % XS_W;
-        int t = t0 - 1 + r, f = c - 1;
-        xs[i] = (t >= 0 && t < T && f >= 0 && f < 64) ? x[((size_t)b * T + t) * 64 + f] : 0.f;
-    }
-    __syncthreads();
-    float acc[54];
+    // the tile (rows t0-1 .. t0+MOM_ROWS of 64 floats) is contiguous in x: float4 loads, zero rows outside the clip
 #pragma unroll
-    for (int k = 0; k < 54; ++k) acc[k] = 0.f;
-    for (int i = 0; i < MOM_ROWS / 4; ++i) {
-        int pix = tid + 256 * i;
-        int r = pix >> 6, c = pix & 63;
-        if (t0 + r < T) {
-            float p[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) p[k] = xs[(r + k / 3) * XS_W + c + k % 3];
-#pragma unroll
-            for (int a = 0; a < 9; ++a) {
-                acc[a] += p[a];
-#pragma unroll
-                for (int b2 = a; b2 < 9; ++b2) acc[gidx(a, b2)] += p[a] * p[b2];
-            }
+    for (int k = 0; k < ((MOM_ROWS + 2) * 16 + 255) / 256; ++k) {
+        const int e = tid + 256 * k;
+        if (e < (MOM_ROWS + 2) * 16) {
+            const int r = e >> 4, c4 = e & 15, t = t0 - 1 + r;
+            float4 v = {0.f, 0.f, 0.f, 0.f};
+            if (t >= 0 && t < T) v = *(const float4*)&x[((size_t)b * T + t) * 64 + 4 * c4];
+            float* d = &xs[r * XS_W + 1 + 4 * c4];
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
     }
+    if (tid < 2 * (MOM_ROWS + 2)) xs[(tid >> 1) * XS_W + (tid & 1) * 65] = 0.f;
+    __syncthreads();
     const int lane = tid & 63, wv = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int toff = (i < 9) ? (i / 3) * XS_W + (i % 3) : 0;
+    const float tap_mul = (i < 9) ? 1.0f : 0.f, tap_add = (i == 9) ? 1.0f : 0.f;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < MOM_ROWS / 4; ++r) {
+        const int row = (MOM_ROWS / 4) * wv + r;
+        if (t0 + row >= T) break;                      // wave-uniform
+        const float* base = xs + row * XS_W + kq + toff;
 #pragma unroll
-    for (int k = 0; k < 54; ++k) {
-        float v = wave_sum(acc[k]);
-        if (lane == 0) red[wv][k] = v;
+        for (int c4 = 0; c4 < 16; c4 += 2) {
+            const float a0 = fmaf(base[4 * c4], tap_mul, tap_add);
+            const float a1 = fmaf(base[4 * c4 + 4], tap_mul, tap_add);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, a0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, a1, acc1, 0, 0, 0);
+        }
+    }
+    // D layout of the 16x16 tile: lane (j = lane & 15, q = lane >> 4), register r -> row 4q + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * kq + r;
+        if (row < 10 && i < 10) red[wv][row][i] = acc0[r] + acc1[r];
     }
     __syncthreads();
-    if (tid < 54 && !no_atomic) atomicAdd(&mom[tid], (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid]);
+    if (tid < 100) {
+        const int a = tid / 10, c = tid % 10;
+        if (a <= c && a < 9) {
+            const double v = (double)red[0][a][c] + (double)red[1][a][c] + (double)red[2][a][c] + (double)red[3][a][c];
+            part[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 54 + (c == 9 ? a : gidx(a, c))] = v;
+        }
+    }
 }
 
 // ---- fold BN into the conv weights; update running stats --------------------------------------
@@ -69,7 +89,9 @@ struct Blk0PrepArgs {
     const float *w0, *b0, *gamma, *beta, *wglu, *bglu;
     float *run_mean, *run_var;
     int64_t* tracked;
-    const double* mom;
+    double* mom;             // [54] s | G, written here from the partials (train) for the backward finalize
+    const double* mompart;   // [n_part][54] per-workgroup partial moments of k_x_moments
+    int n_part;
     double N;
     int train, update;
     float eps, momentum;
@@ -77,7 +99,26 @@ struct Blk0PrepArgs {
 };
 __global__ __launch_bounds__(640) void k_blk0_prep(Blk0PrepArgs a) {
     __shared__ double wzs[64][10];
+    __shared__ double mred[54][10];
+    __shared__ double moms[54];
     const int tid = threadIdx.x;
+    if (a.train) {   // patch moments = fixed-order fp64 sum of the per-workgroup partials
+        if (tid < 540) {
+            const int k = tid / 10, j = tid % 10;
+            double acc = 0;
+            for (int w = j; w < a.n_part; w += 10) acc += a.mompart[(size_t)w * 54 + k];
+            mred[k][j] = acc;
+        }
+        __syncthreads();
+        if (tid < 54) {
+            double acc = 0;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) acc += mred[tid][j];
+            moms[tid] = acc;
+            a.mom[tid] = acc;
+        }
+        __syncthreads();
+    }
     if (tid < 64) {
         const int c = tid;
         double w[9];
@@ -88,11 +129,11 @@ __global__ __launch_bounds__(640) void k_blk0_prep(Blk0PrepArgs a) {
         if (a.train) {
             double ws = 0, wGw = 0;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) ws += w[t] * a.mom[t];
+            for (int t = 0; t < 9; ++t) ws += w[t] * moms[t];
 #pragma unroll
             for (int i = 0; i < 9; ++i)
 #pragma unroll
-                for (int j = 0; j < 9; ++j) wGw += w[i] * w[j] * a.mom[i <= j ? gidx(i, j) : gidx(j, i)];
+                for (int j = 0; j < 9; ++j) wGw += w[i] * w[j] * moms[i <= j ? gidx(i, j) : gidx(j, i)];
             const double mu = ws / a.N;
             mean = mu + b;
             var = wGw / a.N - mu * mu;
@@ -147,10 +188,16 @@ __device__ __forceinline__ void blk0_load_w(Blk0W& W, const float* __restrict__ 
     }
 }
 __device__ __forceinline__ void blk0_load_xs(float* xs, const float* __restrict__ x, int b, int T, int t0, int tid) {
-    for (int i = tid; i < XS_H * XS_W; i += 256) {
-        int r = i / XS_W, c = i % XS_W;
-        int t = t0 - 1 + r, f = c - 1;
-        xs[i] = (t >= 0 && t < T && f >= 0 && f < 64) ? x[((size_t)b * T + t) * 64 + f] : 0.f;
+    // XS_H rows of 64 contiguous floats: one float4 per thread (160 of the 256), zero rows outside the clip
+    if (tid < XS_H * 16) {
+        const int r = tid >> 4, c4 = tid & 15, t = t0 - 1 + r;
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t >= 0 && t < T) v = *(const float4*)&x[((size_t)b * T + t) * 64 + 4 * c4];
+        float* d = &xs[r * XS_W + 1 + 4 * c4];
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    } else if (tid < XS_H * 16 + 2 * XS_H) {
+        const int e = tid - XS_H * 16;
+        xs[(e >> 1) * XS_W + (e & 1) * 65] = 0.f;
     }
 }
 // computes lin (acc[0..1]) and z (acc[2..3]) of one 32-pixel row block
@@ -225,7 +272,7 @@ __global__ __launch_bounds__(256) void k_blk0_fwd(const float* __restrict__ x, c
 }
 
 // ---- backward: D[co][t] = sum_p dlin[p][co] P[p][t],  E[c][t] = sum_p dzgate[p][c] P[p][t] ------
-__global__ __launch_bounds__(256) void k_blk0_bwd(const float* __restrict__ x, const float* __restrict__ wz,
+__global__ __launch_bounds__(256, 2) void k_blk0_bwd(const float* __restrict__ x, const float* __restrict__ wz,
                                                    const float* __restrict__ wl, const float* __restrict__ dp0, int B,
                                                    int T, int H1, int tiles_per_clip, int n_tiles, int use_drop,
                                                    float p_drop, const uint16_t* __restrict__ mask_in,
@@ -277,44 +324,57 @@ __global__ __launch_bounds__(256) void k_blk0_bwd(const float* __restrict__ x, c
                 for (int jx = 0; jx < 4; ++jx) gq_c[h][jx] = gq_n[h][jx] * (0.125f * keep_scale);
             }
             if (g < 3) fetch(g + 1);
-            f32x16 acc[4];
-            blk0_rowblock(xs, W, wv, g, lane, acc);
-            // im2col of this row block for the reductions: P[m][0..8] taps, [9] = 1, [10..11] = 0
+            // patch values: MFMA A operand (this lane's pixel m, taps 2s+kh) and the im2col rows for the reductions
+            float av[5];
             {
                 const int m = n, j = m >> 3, dt = (m >> 2) & 1, df = m & 3;
                 const int base = (2 * wv + dt) * XS_W + 16 * g + 4 * j + df;
+#pragma unroll
+                for (int s5 = 0; s5 < 5; ++s5) {
+                    const int k = 2 * s5 + kh;
+                    av[s5] = (k == 9) ? 1.0f : xs[base + (k / 3) * XS_W + (k % 3)];
+                }
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
                     const int k = kh * 6 + i;
                     Pw[m * 12 + k] = (k < 9) ? xs[base + (k / 3) * XS_W + (k % 3)] : (k == 9 ? 1.0f : 0.f);
                 }
             }
-            float dl[2][16], dzg[2][16];
+            __builtin_amdgcn_wave_barrier();
+            // the two 32-channel halves one after the other: half the live accumulators / gradients, so the
+            // kernel fits 2 waves per SIMD (the all-at-once version needed 331 registers = 1 wave, and every
+            // LDS / MFMA latency of its in-order instruction stream was exposed)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
+                f32x16 al, az;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { al[r] = 0.f; az[r] = 0.f; }
+#pragma unroll
+                for (int s5 = 0; s5 < 5; ++s5) {
+                    al = mfma32(av[s5], W.bw[s5][h], al);
+                    az = mfma32(av[s5], W.bw[s5][2 + h], az);
+                }
+                float dl[16], dzg[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float gg = ((m_c[h] >> r) & 1u) ? gq_c[h][r >> 2] : 0.f;
-                    const float sg = sigmoidf_fast(acc[2 + h][r]);
-                    dl[h][r] = gg * sg;
-                    dzg[h][r] = gg * acc[h][r] * sg * (1.0f - sg);
+                    const float sg = sigmoidf_fast(az[r]);
+                    dl[r] = gg * sg;
+                    dzg[r] = gg * al[r] * sg * (1.0f - sg);
                 }
-            }
-            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = mfma32_row(r, lane);
-                const f32x4 pa = *(const f32x4*)&Pw[i * 12 + 0];
-                const f32x4 pb = *(const f32x4*)&Pw[i * 12 + 4];
-                const f32x4 pc = *(const f32x4*)&Pw[i * 12 + 8];
-                const float pv[10] = {pa[0], pa[1], pa[2], pa[3], pb[0], pb[1], pb[2], pb[3], pc[0], pc[1]};
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int r = 0; r < 16; ++r) {
+                    const int i = mfma32_row(r, lane);
+                    const f32x4 pa = *(const f32x4*)&Pw[i * 12 + 0];
+                    const f32x4 pb = *(const f32x4*)&Pw[i * 12 + 4];
+                    const f32x4 pc = *(const f32x4*)&Pw[i * 12 + 8];
+                    const float pv[10] = {pa[0], pa[1], pa[2], pa[3], pb[0], pb[1], pb[2], pb[3], pc[0], pc[1]};
 #pragma unroll
                     for (int t = 0; t < 10; ++t) {
-                        aD[h][t] = fmaf(dl[h][r], pv[t], aD[h][t]);
-                        aE[h][t] = fmaf(dzg[h][r], pv[t], aE[h][t]);
+                        aD[h][t] = fmaf(dl[r], pv[t], aD[h][t]);
+                        aE[h][t] = fmaf(dzg[r], pv[t], aE[h][t]);
                     }
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -405,19 +465,25 @@ __global__ __launch_bounds__(640) void k_blk0_bwd_finalize(Blk0BwdFinArgs a) {
 }
 
 // ---- host launchers -------------------------------------------------------------------------------
+int x_moments_parts(const Geo& g) { return ((g.T + MOM_ROWS - 1) / MOM_ROWS) * g.B; }
+int launch_x_moments(const Geo& g, const float* x, double* mompart, hipStream_t st) {
+    dim3 grid((g.T + MOM_ROWS - 1) / MOM_ROWS, g.B);
+    k_x_moments<<<grid, 256, 0, st>>>(x, g.T, mompart);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}
 int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const float* b0, const float* gamma,
                         const float* beta, const float* wglu, const float* bglu, float* run_mean, float* run_var,
-                        int64_t* tracked, int train, int update, const uint64_t* seed, double* mom, int zero_mom,
+                        int64_t* tracked, int train, int update, const uint64_t* seed, double* mom, double* mompart,
                         float* wz, float* wl, float* bn, float* p0, uint16_t* mask_out, hipStream_t st) {
     if (train) {
-        if (zero_mom) SED_CHECK_HIP(hipMemsetAsync(mom, 0, 64 * sizeof(double), st));
-        dim3 grid((g.T + MOM_ROWS - 1) / MOM_ROWS, g.B);
-        k_x_moments<<<grid, 256, 0, st>>>(x, g.T, mom, g_sed_debug & 1);
-        SED_CHECK_LAUNCH();
+        const int rc = launch_x_moments(g, x, mompart, st);
+        if (rc != SED_OK) return rc;
     }
     Blk0PrepArgs a;
     a.w0 = w0; a.b0 = b0; a.gamma = gamma; a.beta = beta; a.wglu = wglu; a.bglu = bglu;
     a.run_mean = run_mean; a.run_var = run_var; a.tracked = tracked; a.mom = mom;
+    a.mompart = mompart; a.n_part = x_moments_parts(g);
     a.N = (double)g.B * g.T * g.F; a.train = train; a.update = update; a.eps = g.eps; a.momentum = g.mom;
     a.wz = wz; a.wl = wl; a.bn = bn;
     k_blk0_prep<<<1, 640, 0, st>>>(a);

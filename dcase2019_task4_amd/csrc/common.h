@@ -69,6 +69,7 @@ ParamOff make_param_off(const Geo& g, int64_t* offsets_out /* may be null */);
 struct CtxLayout {
     size_t acc0;                       // mom0 | stat1 | stat2 contiguous (320 doubles, zeroed by ONE memset)
     size_t mom0, wz0, wl0, bn0;        // bn0: mean,invstd,scale,shift [4][64]
+    size_t mompart;                    // per-workgroup partial patch moments [parts][54] fp64
     size_t wpkT1, wpkT2;               // flipped/transposed conv weights for dgrad (train only)
     size_t p0;
     size_t wpk1, y1, stat1, bn1, p1;

@@ -84,6 +84,7 @@ CtxLayout make_ctx_layout(const Geo& g) {
     put(L.acc0, 320 * sizeof(double));
     L.mom0 = L.acc0; L.stat1 = L.acc0 + 64 * sizeof(double); L.stat2 = L.acc0 + 192 * sizeof(double);
     put(L.wz0, 64 * 12 * 4); put(L.wl0, 64 * 12 * 4); put(L.bn0, 256 * 4);
+    put(L.mompart, (size_t)x_moments_parts(g) * 54 * sizeof(double));
     put(L.p0, n0 * 4);
     put(L.wpk1, 9 * 4096 * 4); put(L.wpkT1, 9 * 4096 * 4); put(L.y1, n0 * 4); put(L.bn1, 256 * 4); put(L.p1, n1 * 4);
     put(L.wpk2, 9 * 4096 * 4); put(L.wpkT2, 9 * 4096 * 4); put(L.y2, n1 * 4); put(L.bn2, 256 * 4); put(L.p2, n2 * 4);
@@ -225,7 +226,7 @@ extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* b
     // ---- conv block 0 ---------------------------------------------------------------------------
     SED_TRY(launch_blk0_forward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
                                 params + P.glu_w[0], params + P.glu_b[0], bn_running + 0, bn_running + 64, trk[0], train,
-                                upd, seed_dev, CTXD(L.mom0), 0, CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), CTXF(L.p0),
+                                upd, seed_dev, CTXD(L.mom0), CTXD(L.mompart), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), CTXF(L.p0),
                                 use_drop ? CTXM(L.mask0) : nullptr, st));
     // ---- conv blocks 1, 2 -----------------------------------------------------------------------
     const float* in = CTXF(L.p0);
@@ -387,12 +388,13 @@ extern "C" int sed_kernel_replay(const char* name, const sed_dims* d, const floa
     const size_t dzo[3] = {0, W.dz1, W.dz2}, dpo[3] = {W.dp0, W.dp1, W.dp2}, gacc[3] = {0, W.gluacc1, W.gluacc2};
     const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};
     auto is = [&](const char* n) { return strcmp(name, n) == 0; };
+    if (is("x_moments")) return launch_x_moments(g, x, CTXD(L.mompart), st);
     if (is("blk0_fwd")) {
         const int tpc = (g.H1 + 3) / 4;
         (void)tpc;
         return launch_blk0_forward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
                                    params + P.glu_w[0], params + P.glu_b[0], WSF(W.coef[1]), WSF(W.coef[1]) + 64, nullptr, 1, 0,
-                                   seed_dev, CTXD(L.mom0), 1, CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), CTXF(L.p0),
+                                   seed_dev, CTXD(L.mom0), CTXD(L.mompart), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), CTXF(L.p0),
                                    use_drop ? CTXM(L.mask0) : nullptr, st);
     }
     for (int i = 1; i <= 2; ++i) {

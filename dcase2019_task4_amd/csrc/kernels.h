@@ -4,9 +4,11 @@
 #include "common.h"
 
 // blk0.hip
+int x_moments_parts(const Geo& g);
+int launch_x_moments(const Geo& g, const float* x, double* mompart, hipStream_t st);
 int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const float* b0, const float* gamma,
                         const float* beta, const float* wglu, const float* bglu, float* run_mean, float* run_var,
-                        int64_t* tracked, int train, int update, const uint64_t* seed, double* mom, int zero_mom,
+                        int64_t* tracked, int train, int update, const uint64_t* seed, double* mom, double* mompart,
                         float* wz, float* wl, float* bn, float* p0, uint16_t* mask_out, hipStream_t st);
 int launch_blk0_backward(const Geo& g, const float* x, const float* w0, const float* b0, const float* gamma,
                          const float* beta, const float* wglu, const uint16_t* mask_in, const double* mom,

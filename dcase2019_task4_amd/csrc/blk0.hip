@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256) void k_blk0_fwd(const float* __restrict__ x, c
     blk0_load_w(W, wz, wl, lane);
     const uint64_t seed = use_drop ? seed_ptr[0] : 0ull;
     const uint32_t thr = drop_thresh8(p_drop);
+    const bool one_bit = (thr == 128u);
     const float keep_scale = use_drop ? drop_scale8(p_drop) : 1.0f;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int b = tile / tiles_per_clip, to0 = (tile % tiles_per_clip) * 4;
@@ -238,6 +239,8 @@ __global__ __launch_bounds__(256) void k_blk0_fwd(const float* __restrict__ x, c
         __syncthreads();
         const int to = to0 + wv;
         if (to >= H1) continue;
+        u32x4 o1 = {0u, 0u, 0u, 0u};
+        if (use_drop && one_bit) o1 = philox_stream_1bit((uint32_t)(b * H1 + to) * 4u, lane, 0, seed);   // all 4 row blocks
         for (int g = 0; g < 4; ++g) {
             f32x16 acc[4];
             blk0_rowblock(xs, W, wv, g, lane, acc);
@@ -247,9 +250,14 @@ __global__ __launch_bounds__(256) void k_blk0_fwd(const float* __restrict__ x, c
                 const int c = 32 * h + n;
                 float pooled[4] = {0.f, 0.f, 0.f, 0.f};
                 if (use_drop) {
-                    // one Philox draw = 16 bytes = this lane's 16 elements (4 pooled pixels x 4 df) of channel c
-                    const u32x4 o = philox_stream((uint32_t)((q0 >> 2) * 64 + c), (uint32_t)kh, seed);
-                    const uint32_t m16 = philox_keep16(o, thr);
+                    uint32_t m16;
+                    if (one_bit) {
+                        m16 = philox_field16(o1, 2 * g + h);
+                    } else {
+                        // one Philox draw = 16 bytes = this lane's 16 elements (4 pooled pixels x 4 df) of channel c
+                        const u32x4 o = philox_stream((uint32_t)((q0 >> 2) * 64 + c), (uint32_t)kh, seed);
+                        m16 = philox_keep16(o, thr);
+                    }
                     if (mask_out) mask_out[((size_t)(q0 >> 2) * 2 + h) * 64 + lane] = (uint16_t)m16;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {

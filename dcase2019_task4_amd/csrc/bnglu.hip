@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void k_glu_pool_fwd(const float* __restrict__ 
     const float bg[2] = {bglu[n], bglu[32 + n]};
     const uint64_t seed = use_drop ? seed_ptr[0] : 0ull;
     const uint32_t thr = drop_thresh8(p_drop);
+    const bool one_bit = (thr == 128u);
     const float sc = 0.125f * (use_drop ? drop_scale8(p_drop) : 1.0f);
     const int n_rb = (Q + 3) / 4;
     for (int rb = blockIdx.x * 4 + wv; rb < n_rb; rb += gridDim.x * 4) {
@@ -120,14 +121,20 @@ __global__ __launch_bounds__(256) void k_glu_pool_fwd(const float* __restrict__ 
             acc[0] = mfma32(a, bw[s][0], acc[0]);
             acc[1] = mfma32(a, bw[s][1], acc[1]);
         }
+        u32x4 o1 = {0u, 0u, 0u, 0u};
+        if (use_drop && one_bit) o1 = philox_stream_1bit((uint32_t)rb, lane, block_id, seed);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int c = 32 * h + n;
             float pooled[4] = {0.f, 0.f, 0.f, 0.f};
             uint32_t m16 = 0xffffu;
             if (use_drop) {
-                const u32x4 o = philox_stream((uint32_t)(rb * 64 + c), (uint32_t)(2 * block_id + kh), seed);
-                m16 = philox_keep16(o, thr);
+                if (one_bit) {
+                    m16 = philox_field16(o1, 2 * (rb & 3) + h);
+                } else {
+                    const u32x4 o = philox_stream((uint32_t)(rb * 64 + c), (uint32_t)(2 * block_id + kh), seed);
+                    m16 = philox_keep16(o, thr);
+                }
                 if (mask_out) mask_out[((size_t)rb * 2 + h) * 64 + lane] = (uint16_t)m16;
             }
 #pragma unroll

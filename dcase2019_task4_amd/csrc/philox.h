@@ -47,3 +47,20 @@ __device__ __forceinline__ uint32_t philox_keep16(const u32x4& o, uint32_t thr) 
     for (int i = 0; i < 16; ++i) m |= (philox_byte(o, i) >= thr ? 1u : 0u) << i;
     return m;
 }
+
+// p == 0.5 (thresh8 == 128, the reference's dropout rate) needs ONE random bit per element, so a single draw
+// serves 8 (row block, channel half) units of a lane instead of 1:
+//   draw(index = (rb >> 2) * 64 + lane, stream = 32 + block)  ->  eight 16-bit fields,
+//   field (rb & 3) * 2 + h = the keep bits of row block rb, channels 32h..32h+31, this lane
+//   (bit r <-> pooled pixel r >> 2, df = r & 3, as in the 8-bit stream).
+// The 32-bit multiplies of Philox are quarter rate; with 8-bit draws they were ~40 % of the VALU cycles of
+// the block-0 forward kernel.
+#define PHILOX_STREAM_1BIT 32u
+__device__ __forceinline__ u32x4 philox_stream_1bit(uint32_t rb, int lane, int block, uint64_t seed) {
+    return philox_stream((rb >> 2) * 64u + (uint32_t)lane, PHILOX_STREAM_1BIT + (uint32_t)block, seed);
+}
+__device__ __forceinline__ uint32_t philox_field16(const u32x4& o, int f) {
+    const int wi = f >> 1;
+    const uint32_t w = wi == 0 ? o.x : wi == 1 ? o.y : wi == 2 ? o.z : o.w;
+    return (w >> (16 * (f & 1))) & 0xffffu;
+}

@@ -59,19 +59,33 @@ __device__ __forceinline__ int rb_pixel(int q, int dt, int df, int H, int W, int
     return (b * H + 2 * ho + dt) * W + 4 * wo + df;
 }
 
-template <bool KEEP_Y>
-__device__ __forceinline__ void stage_tile(const float* __restrict__ y, const float* __restrict__ bn, float* zt, float* yt,
-                                           int q0, int Q, int H, int W, int Ho, int Wo, int lane) {
+// A row block's conv output y (32 pixels x 64 channels) goes global -> registers -> LDS in two separately
+// callable halves, so that the loads of row block k+1 are issued BEFORE the MFMAs of row block k: these kernels
+// run one or two waves per SIMD, and a load consumed right after its issue exposes a full memory round trip
+// (~2 us per row block in the first version; MFMA pipe busy 21 % in k_glu_pool_bwd).
+struct YTile { float4 v[8]; };
+__device__ __forceinline__ void tile_load(YTile& t, const float* __restrict__ y, int q0, int Q, int H, int W, int Ho,
+                                          int Wo, int lane) {
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int m = (lane >> 4) + 4 * it, c4 = (lane & 15) * 4;
         const int q = q0 + (m >> 3);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f), z = v;
+        t.v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q < Q) {
             const int pix = rb_pixel(q, (m >> 2) & 1, m & 3, H, W, Ho, Wo);
-            v = *(const float4*)(y + (size_t)pix * 64 + c4);
-            const float4 sc = *(const float4*)(bn + 128 + c4);
-            const float4 sh = *(const float4*)(bn + 192 + c4);
+            t.v[it] = *(const float4*)(y + (size_t)pix * 64 + c4);
+        }
+    }
+}
+template <bool KEEP_Y>
+__device__ __forceinline__ void tile_store(const YTile& t, const float4& sc, const float4& sh, float* zt, float* yt,
+                                           int q0, int Q, int lane) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int m = (lane >> 4) + 4 * it, c4 = (lane & 15) * 4;
+        const float4 v = t.v[it];
+        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q0 + (m >> 3) < Q) {
             z.x = fmaf(v.x, sc.x, sh.x); z.y = fmaf(v.y, sc.y, sh.y);
             z.z = fmaf(v.z, sc.z, sh.z); z.w = fmaf(v.w, sc.w, sh.w);
         }
@@ -108,9 +122,16 @@ __global__ __launch_bounds__(256) void k_glu_pool_fwd(const float* __restrict__ 
     const bool one_bit = (thr == 128u);
     const float sc = 0.125f * (use_drop ? drop_scale8(p_drop) : 1.0f);
     const int n_rb = (Q + 3) / 4;
+    const float4 bsc = *(const float4*)(bn + 128 + (lane & 15) * 4), bsh = *(const float4*)(bn + 192 + (lane & 15) * 4);
+    YTile yt_n;
+    if (blockIdx.x * 4 + wv < n_rb) tile_load(yt_n, y, (blockIdx.x * 4 + wv) * 4, Q, H, W, Ho, Wo, lane);
     for (int rb = blockIdx.x * 4 + wv; rb < n_rb; rb += gridDim.x * 4) {
         const int q0 = rb * 4;
-        stage_tile<false>(y, bn, zt, nullptr, q0, Q, H, W, Ho, Wo, lane);
+        tile_store<false>(yt_n, bsc, bsh, zt, nullptr, q0, Q, lane);
+        {
+            const int rbn = rb + gridDim.x * 4;
+            if (rbn < n_rb) tile_load(yt_n, y, rbn * 4, Q, H, W, Ho, Wo, lane);
+        }
         f32x16 acc[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
@@ -170,14 +191,16 @@ __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ 
     float* dlt = yt + 32 * ZS;
     for (int e = tid; e < 4096; e += 256) WsT[(e & 63) * ZS + (e >> 6)] = wglu[e];
     __syncthreads();
-    float bw[32][2], bwT[32][2];
+    // forward operand B[k=c][j=co] = Wglu[co][c] lives in registers; the transposed one for dz = dlin @ Wglu,
+    // B[k=co][j=c] = WsT[c][co], is read from LDS per use (conflict-free at stride 65): its 64 registers hold
+    // the next row block's prefetched tile instead
+    float bw[32][2];
 #pragma unroll
     for (int s = 0; s < 32; ++s) {
-        bw[s][0] = WsT[(2 * s + kh) * ZS + n];           // B[k=c][j=co]  = Wglu[co][c]
+        bw[s][0] = WsT[(2 * s + kh) * ZS + n];
         bw[s][1] = WsT[(2 * s + kh) * ZS + 32 + n];
-        bwT[s][0] = wglu[(2 * s + kh) * 64 + n];         // B[k=co][j=c]  = Wglu[co][c]  (coalesced as is)
-        bwT[s][1] = wglu[(2 * s + kh) * 64 + 32 + n];
     }
+    const float* BT = WsT + n * ZS + kh;
     const float bg[2] = {bglu[n], bglu[32 + n]};
     const float sc = 0.125f * (use_drop ? drop_scale8(p_drop) : 1.0f);
     (void)block_id;
@@ -190,9 +213,32 @@ __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ 
             for (int r = 0; r < 16; ++r) dW[a][b2][r] = 0.f;
     float sdb[2] = {0.f, 0.f}, sdz[2] = {0.f, 0.f}, sdzy[2] = {0.f, 0.f};
     const int n_rb = (Q + 3) / 4;
+    const float4 bsc = *(const float4*)(bn + 128 + (lane & 15) * 4), bsh = *(const float4*)(bn + 192 + (lane & 15) * 4);
+    YTile yt_n;
+    float gq_n[2][4];
+    uint32_t m_n[2];
+    auto prefetch = [&](int rbn) {
+        tile_load(yt_n, y, rbn * 4, Q, H, W, Ho, Wo, lane);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int jx = 0; jx < 4; ++jx) gq_n[h][jx] = (rbn * 4 + jx < Q) ? dp[(size_t)(rbn * 4 + jx) * 64 + 32 * h + n] : 0.f;
+            m_n[h] = use_drop ? (uint32_t)mask_in[((size_t)rbn * 2 + h) * 64 + lane] : 0xffffu;
+        }
+    };
+    if (blockIdx.x * 4 + wv < n_rb) prefetch(blockIdx.x * 4 + wv);
     for (int rb = blockIdx.x * 4 + wv; rb < n_rb; rb += gridDim.x * 4) {
         const int q0 = rb * 4;
-        stage_tile<true>(y, bn, zt, yt, q0, Q, H, W, Ho, Wo, lane);
+        tile_store<true>(yt_n, bsc, bsh, zt, yt, q0, Q, lane);
+        float gq_c[2][4];
+        uint32_t m_c[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            m_c[h] = m_n[h];
+#pragma unroll
+            for (int jx = 0; jx < 4; ++jx) gq_c[h][jx] = gq_n[h][jx] * sc;
+        }
+        if (rb + gridDim.x * 4 < n_rb) prefetch(rb + gridDim.x * 4);
         f32x16 acc[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
@@ -209,14 +255,11 @@ __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ 
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int c = 32 * h + n;
-            float gq[4];
-#pragma unroll
-            for (int jx = 0; jx < 4; ++jx) gq[jx] = (q0 + jx < Q) ? dp[(size_t)(q0 + jx) * 64 + c] * sc : 0.f;
-            const uint32_t m16 = use_drop ? (uint32_t)mask_in[((size_t)rb * 2 + h) * 64 + lane] : 0xffffu;
+            const uint32_t m16 = m_c[h];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = mfma32_row(r, lane);
-                const float gg = ((m16 >> r) & 1u) ? gq[r >> 2] : 0.f;
+                const float gg = ((m16 >> r) & 1u) ? gq_c[h][r >> 2] : 0.f;
                 const float sg = sigmoidf_fast(zt[i * ZS + c]);
                 const float dl = gg * sg;
                 dlt[i * ZS + c] = dl;
@@ -232,8 +275,8 @@ __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ 
 #pragma unroll
             for (int s = 0; s < 32; ++s) {
                 const float a = A[2 * s];
-                acc[0] = mfma32(a, bwT[s][0], acc[0]);
-                acc[1] = mfma32(a, bwT[s][1], acc[1]);
+                acc[0] = mfma32(a, BT[2 * s], acc[0]);
+                acc[1] = mfma32(a, BT[32 * ZS + 2 * s], acc[1]);
             }
         }
 #pragma unroll

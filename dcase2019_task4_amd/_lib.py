@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdcase_sed_mi355.so")
+# SED_LIB: alternative build of the SAME library (kernel tuning experiments), never a different implementation
+LIB_PATH = os.environ.get("SED_LIB") or os.path.join(_HERE, "libdcase_sed_mi355.so")
 
 
 class SedError(RuntimeError):

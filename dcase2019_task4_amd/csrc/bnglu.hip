@@ -20,8 +20,22 @@
 #include "common.h"
 #include "philox.h"
 #include "kernels.h"
+#include <type_traits>
 
 #define ZS 65   // pixel stride of LDS tiles (floats)
+
+// Tuning aid (make EXTRA=-DSED_TS): wave 0 of every workgroup stamps the 100 MHz wall clock at phase boundaries.
+#ifdef SED_TS
+static __device__ unsigned long long g_ts[1024 * 16];
+#define TS(k) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_ts[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#define TSC(k) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_ts[blockIdx.x * 16 + (k)] = clock64(); } while (0)
+extern "C" int sed_debug_ts(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ts), sizeof(unsigned long long) * (n < 1024 * 16 ? n : 1024 * 16));
+}
+#else
+#define TS(k) do { } while (0)
+#define TSC(k) do { } while (0)
+#endif
 
 struct BnPrepArgs {
     const double* stat; double N;
@@ -189,6 +203,7 @@ __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ 
     float* zt = smem + wv * (3 * 32 * ZS);
     float* yt = zt + 32 * ZS;
     float* dlt = yt + 32 * ZS;
+    TS(0); TSC(14);
     for (int e = tid; e < 4096; e += 256) WsT[(e & 63) * ZS + (e >> 6)] = wglu[e];
     __syncthreads();
     // forward operand B[k=c][j=co] = Wglu[co][c] lives in registers; the transposed one for dz = dlin @ Wglu,
@@ -214,24 +229,68 @@ __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ 
     float sdb[2] = {0.f, 0.f}, sdz[2] = {0.f, 0.f}, sdzy[2] = {0.f, 0.f};
     const int n_rb = (Q + 3) / 4;
     const float4 bsc = *(const float4*)(bn + 128 + (lane & 15) * 4), bsh = *(const float4*)(bn + 192 + (lane & 15) * 4);
+    // Addressing without per-element divisions or 64-bit arithmetic: po[j] = BYTE offset (into y / dz, both
+    // [pixels][64] fp32 < 4 GB) of the image pixel of pooled pixel q0+j at (dt, df) = (0, 0); MFMA row i of the
+    // row block is pixel po[i>>3]/256 + ((i>>2)&1)*W + (i&3).  Pooled pixels past Q (only in the last row block,
+    // only if Q % 4 != 0) get offset 0 - a harmless load - and are masked where it matters.
+    // (integer division by a run-time value is ~50 instructions with quarter-rate multiplies - 4 of them per row
+    // block were 0.8 us of an in-order wave's time; q < 2^24, so a float reciprocal plus one correction is exact)
+    const float inv_wo = 1.0f / (float)Wo, inv_ho = 1.0f / (float)Ho;
+    auto divmod = [](int a, int d, float inv, int& rem) {
+        int qd = (int)((float)a * inv);
+        int r = a - qd * d;
+        if (r < 0) { r += d; --qd; }
+        if (r >= d) { r -= d; ++qd; }
+        rem = r;
+        return qd;
+    };
+    auto pixel_offsets = [&](int q0, uint32_t (&po)[4]) {
+        int wo, ho;
+        const int t = divmod(q0, Wo, inv_wo, wo);
+        int bb = divmod(t, Ho, inv_ho, ho);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            po[j] = (q0 + j < Q) ? (uint32_t)((bb * H + 2 * ho) * W + 4 * wo) * 256u : 0u;
+            if (++wo == Wo) { wo = 0; if (++ho == Ho) { ho = 0; ++bb; } }
+        }
+    };
+    const uint32_t ld_off = (uint32_t)((lane >> 4) * 64 + (lane & 15) * 4) * 4u;   // tile_load lane: pixel df, 4 channels
+    const uint32_t st_off = (uint32_t)(kh * W * 64 + n) * 4u;                      // D-fragment lane: row dt = kh, channel n
     YTile yt_n;
     float gq_n[2][4];
     uint32_t m_n[2];
+    uint32_t po_n[4];
     auto prefetch = [&](int rbn) {
-        tile_load(yt_n, y, rbn * 4, Q, H, W, Ho, Wo, lane);
+        pixel_offsets(rbn * 4, po_n);
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+            yt_n.v[it] = *(const float4*)((const char*)y + (po_n[it >> 1] + (uint32_t)((it & 1) * W) * 256u + ld_off));
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
-            for (int jx = 0; jx < 4; ++jx) gq_n[h][jx] = (rbn * 4 + jx < Q) ? dp[(size_t)(rbn * 4 + jx) * 64 + 32 * h + n] : 0.f;
+            for (int jx = 0; jx < 4; ++jx) {
+                const int q = rbn * 4 + jx;
+                gq_n[h][jx] = *(const float*)((const char*)dp + (uint32_t)((q < Q ? q : 0) * 64 + 32 * h + n) * 4u);
+                if (q >= Q) gq_n[h][jx] = 0.f;
+            }
             m_n[h] = use_drop ? (uint32_t)mask_in[((size_t)rbn * 2 + h) * 64 + lane] : 0xffffu;
         }
     };
     if (blockIdx.x * 4 + wv < n_rb) prefetch(blockIdx.x * 4 + wv);
-    for (int rb = blockIdx.x * 4 + wv; rb < n_rb; rb += gridDim.x * 4) {
+    TS(1);
+    int ts_k = 2;
+    (void)ts_k;
+    // one row block; FULL = all four pooled pixels exist (always, unless it is the last row block and Q % 4 != 0)
+    auto body = [&](int rb, auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
         const int q0 = rb * 4;
-        tile_store<true>(yt_n, bsc, bsh, zt, yt, q0, Q, lane);
+        tile_store<true>(yt_n, bsc, bsh, zt, yt, q0, FULL ? q0 + 4 : Q, lane);
+        TS(ts_k); ++ts_k;
         float gq_c[2][4];
         uint32_t m_c[2];
+        uint32_t po[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) po[j] = po_n[j] + st_off;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             m_c[h] = m_n[h];
@@ -239,63 +298,87 @@ __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ 
             for (int jx = 0; jx < 4; ++jx) gq_c[h][jx] = gq_n[h][jx] * sc;
         }
         if (rb + gridDim.x * 4 < n_rb) prefetch(rb + gridDim.x * 4);
+        if (ts_k == 3) TS(7);
+        // The three MFMA phases (64 x v_mfma_f32_32x32x2 each) carry the element-wise work of the row block in
+        // their shadow: one wave per SIMD issues in order, so VALU / LDS work placed BETWEEN independent MFMAs is
+        // free, while the same work in a phase of its own leaves the MFMA pipe idle (21 % busy in the first version).
+        // ---- phase 1: lin = z @ Wglu^T   ||   sigma(z), dlin = g*sigma -> LDS, t = g*sigma*(1-sigma) -------------
+        f32x16 lin[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { lin[0][r] = 0.f; lin[1][r] = 0.f; }
+        float dzg[2][16];
+        {
+            // Groups of 4 K-steps (8 MFMAs = 512 MFMA-pipe cycles) carry 4 elements' VALU work side by side: one
+            // element's mul -> exp -> add -> rcp -> mul -> ds_write is a dependent chain of ~100 cycles on a lone
+            // in-order wave, four of them interleave.  The LDS operands of group g+1 are read during group g.
+            const float* A = zt + n * ZS + kh;
+            float a_c[4], z_c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a_c[u] = A[2 * u]; z_c[u] = zt[mfma32_row(u, lane) * ZS + n]; }
+#pragma unroll
+            for (int g4 = 0; g4 < 8; ++g4) {
+                float a_n[4] = {0.f, 0.f, 0.f, 0.f}, z_n[4] = {0.f, 0.f, 0.f, 0.f};
+                if (g4 + 1 < 8) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int s1 = 4 * (g4 + 1) + u;
+                        a_n[u] = A[2 * s1];
+                        z_n[u] = zt[mfma32_row(s1 & 15, lane) * ZS + 32 * (s1 >> 4) + n];
+                    }
+                }
+                float sg[4], gg[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int s = 4 * g4 + u, h = s >> 4, r = s & 15;
+                    lin[0] = mfma32(a_c[u], bw[s][0], lin[0]);
+                    lin[1] = mfma32(a_c[u], bw[s][1], lin[1]);
+                    gg[u] = ((m_c[h] >> r) & 1u) ? gq_c[h][r >> 2] : 0.f;
+                    sg[u] = sigmoidf_fast(z_c[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int s = 4 * g4 + u, h = s >> 4, r = s & 15;
+                    const float dl = gg[u] * sg[u];
+                    dlt[mfma32_row(r, lane) * ZS + 32 * h + n] = dl;
+                    sdb[h] += dl;
+                    dzg[h][r] = dl * (1.0f - sg[u]);
+                    a_c[u] = a_n[u]; z_c[u] = z_n[u];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (ts_k == 3) TS(11);
+        // ---- phase 2: dz_lin = dlin @ Wglu   ||   gate path dzg = t * (lin + b) -----------------------------------
         f32x16 acc[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
         {
-            const float* A = zt + n * ZS + kh;
-#pragma unroll
-            for (int s = 0; s < 32; ++s) {
-                const float a = A[2 * s];
-                acc[0] = mfma32(a, bw[s][0], acc[0]);
-                acc[1] = mfma32(a, bw[s][1], acc[1]);
-            }
-        }
-        float dzg[2][16];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int c = 32 * h + n;
-            const uint32_t m16 = m_c[h];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = mfma32_row(r, lane);
-                const float gg = ((m16 >> r) & 1u) ? gq_c[h][r >> 2] : 0.f;
-                const float sg = sigmoidf_fast(zt[i * ZS + c]);
-                const float dl = gg * sg;
-                dlt[i * ZS + c] = dl;
-                sdb[h] += dl;
-                dzg[h][r] = gg * (acc[h][r] + bg[h]) * sg * (1.0f - sg);
-            }
-        }
-        // dz = dlin @ Wglu (+ gate path)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
-        {
             const float* A = dlt + n * ZS + kh;
+            float a_c = A[0], b0_c = BT[0], b1_c = BT[32 * ZS];
 #pragma unroll
             for (int s = 0; s < 32; ++s) {
-                const float a = A[2 * s];
-                acc[0] = mfma32(a, BT[2 * s], acc[0]);
-                acc[1] = mfma32(a, BT[32 * ZS + 2 * s], acc[1]);
+                const int h = s >> 4, r = s & 15;
+                float a_n = 0.f, b0_n = 0.f, b1_n = 0.f;
+                if (s + 1 < 32) { a_n = A[2 * (s + 1)]; b0_n = BT[2 * (s + 1)]; b1_n = BT[32 * ZS + 2 * (s + 1)]; }
+                acc[0] = mfma32(a_c, b0_c, acc[0]);
+                acc[1] = mfma32(a_c, b1_c, acc[1]);
+                dzg[h][r] *= lin[h][r] + bg[h];
+                a_c = a_n; b0_c = b0_n; b1_c = b1_n;
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (ts_k == 3) TS(12);
+        // vmcnt counts loads and stores alike and cannot tell them apart: claim the prefetched registers HERE, while
+        // only the (long issued) loads are outstanding - at the top of the next row block the same wait would also
+        // drain the 32 dz stores per lane that phase 3 is about to issue (a full store round trip per row block)
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+            asm volatile("" : "+v"(yt_n.v[it].x), "+v"(yt_n.v[it].y), "+v"(yt_n.v[it].z), "+v"(yt_n.v[it].w));
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int c = 32 * h + n;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = mfma32_row(r, lane);
-                const int q = q0 + (i >> 3);
-                const float v = acc[h][r] + dzg[h][r];
-                if (q < Q) {
-                    const int pix = rb_pixel(q, (i >> 2) & 1, i & 3, H, W, Ho, Wo);
-                    dz[(size_t)pix * 64 + c] = v;
-                    sdz[h] += v;
-                    sdzy[h] += v * yt[i * ZS + c];
-                }
-            }
+            asm volatile("" : "+v"(gq_n[h][0]), "+v"(gq_n[h][1]), "+v"(gq_n[h][2]), "+v"(gq_n[h][3]), "+v"(m_n[h]));
         }
-        // dWglu[co][c] += sum_m dlin[m][co] z[m][c]
+        // ---- phase 3: dWglu += dlin^T z   ||   dz = dz_lin + dzg -> global, BatchNorm-backward sums ----------------
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int mrow = 2 * s + kh;
@@ -305,10 +388,28 @@ __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ 
             dW[0][1] = mfma32(a0, b1, dW[0][1]);
             dW[1][0] = mfma32(a1, b0, dW[1][0]);
             dW[1][1] = mfma32(a1, b1, dW[1][1]);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = s, c = 32 * h + n;
+                const int i = mfma32_row(r, lane);
+                const float v = acc[h][r] + dzg[h][r];
+                if (FULL || q0 + (r >> 2) < Q) {
+                    *(float*)((char*)dz + (po[r >> 2] + (uint32_t)(((r & 3) * 64 + 32 * h) * 4))) = v;
+                    sdz[h] += v;
+                    sdzy[h] += v * yt[i * ZS + c];
+                }
+            }
         }
+        if (ts_k == 3) TS(13);
+    };
+    for (int rb = blockIdx.x * 4 + wv; rb < n_rb; rb += gridDim.x * 4) {
+        if (rb * 4 + 3 < Q) body(rb, std::true_type{});
+        else body(rb, std::false_type{});
     }
     // ---- reduce across the 4 waves through LDS, then fp64 atomics ------------------------------
+    TS(8);
     __syncthreads();
+    TS(9);
     float* red = smem;   // needs 4 * 4096 floats = 64 KB <= 4 * 3 * 32 * 65 * 4 = 99,840 B
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -339,6 +440,7 @@ __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ 
         for (int w2 = 0; w2 < 4; ++w2) v += (double)red[(w2 * 3 + which) * 64 + c];
         if (!no_atomic) atomicAdd(&accg[4096 + which * 64 + c], v);
     }
+    TS(10); TSC(15);
 }
 
 struct BnBwdPrepArgs {

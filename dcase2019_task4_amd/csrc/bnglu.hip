@@ -260,21 +260,26 @@ __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ 
     float gq_n[2][4];
     uint32_t m_n[2];
     uint32_t po_n[4];
+    // The next row block's operands are fetched in 8 slices spread over the groups of phase 1 rather than in one
+    // burst: 41 KB per CU issued at once (and by all 256 CUs at the same moment) exceeds what a CU can keep in
+    // flight, and the in-order wave sat ~1.5 us per row block in the ISSUE of those loads.
+    int q_n = 0;                       // first pooled pixel of the row block being prefetched
+    auto prefetch_begin = [&](int rbn, bool valid) {
+        q_n = valid ? rbn * 4 : 0;     // past the end: re-read row block 0 (harmless, never consumed)
+        pixel_offsets(q_n, po_n);
+    };
+    auto prefetch_slice = [&](int k) {
+        yt_n.v[k] = *(const float4*)((const char*)y + (po_n[k >> 1] + (uint32_t)((k & 1) * W) * 256u + ld_off));
+        const int h = k >> 2, jx = k & 3;
+        const int q = q_n + jx;
+        gq_n[h][jx] = *(const float*)((const char*)dp + (uint32_t)((q < Q ? q : 0) * 64 + 32 * h + n) * 4u);
+        if (q >= Q) gq_n[h][jx] = 0.f;
+        if (jx == 0) m_n[h] = use_drop ? (uint32_t)mask_in[((size_t)(q_n >> 2) * 2 + h) * 64 + lane] : 0xffffu;
+    };
     auto prefetch = [&](int rbn) {
-        pixel_offsets(rbn * 4, po_n);
+        prefetch_begin(rbn, true);
 #pragma unroll
-        for (int it = 0; it < 8; ++it)
-            yt_n.v[it] = *(const float4*)((const char*)y + (po_n[it >> 1] + (uint32_t)((it & 1) * W) * 256u + ld_off));
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int jx = 0; jx < 4; ++jx) {
-                const int q = rbn * 4 + jx;
-                gq_n[h][jx] = *(const float*)((const char*)dp + (uint32_t)((q < Q ? q : 0) * 64 + 32 * h + n) * 4u);
-                if (q >= Q) gq_n[h][jx] = 0.f;
-            }
-            m_n[h] = use_drop ? (uint32_t)mask_in[((size_t)rbn * 2 + h) * 64 + lane] : 0xffffu;
-        }
+        for (int k = 0; k < 8; ++k) prefetch_slice(k);
     };
     if (blockIdx.x * 4 + wv < n_rb) prefetch(blockIdx.x * 4 + wv);
     TS(1);
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ 
 #pragma unroll
             for (int jx = 0; jx < 4; ++jx) gq_c[h][jx] = gq_n[h][jx] * sc;
         }
-        if (rb + gridDim.x * 4 < n_rb) prefetch(rb + gridDim.x * 4);
+        prefetch_begin(rb + gridDim.x * 4, rb + gridDim.x * 4 < n_rb);
         if (ts_k == 3) TS(7);
         // The three MFMA phases (64 x v_mfma_f32_32x32x2 each) carry the element-wise work of the row block in
         // their shadow: one wave per SIMD issues in order, so VALU / LDS work placed BETWEEN independent MFMAs is
@@ -326,6 +331,7 @@ __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ 
                         z_n[u] = zt[mfma32_row(s1 & 15, lane) * ZS + 32 * (s1 >> 4) + n];
                     }
                 }
+                prefetch_slice(g4);
                 float sg[4], gg[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {

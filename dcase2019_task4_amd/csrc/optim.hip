@@ -10,6 +10,7 @@
 #include "common.h"
 #include "kernels.h"
 
+template <bool EMA>
 __global__ __launch_bounds__(256) void k_adam_ema(int64_t n, float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, float* __restrict__ pe,
                                                    const sed_step_state* __restrict__ st, float grad_scale) {
@@ -18,7 +19,8 @@ __global__ __launch_bounds__(256) void k_adam_ema(int64_t n, float* __restrict__
     const int64_t n4 = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        float4 P = ((float4*)p)[i], G = ((const float4*)g)[i], M = ((float4*)m)[i], V = ((float4*)v)[i], E = ((float4*)pe)[i];
+        float4 P = ((float4*)p)[i], G = ((const float4*)g)[i], M = ((float4*)m)[i], V = ((float4*)v)[i];
+        float4 E = EMA ? ((float4*)pe)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
 #define ADAM1(x)                                                         \
     {                                                                    \
         const float gg = G.x * grad_scale;                               \
@@ -29,7 +31,8 @@ __global__ __launch_bounds__(256) void k_adam_ema(int64_t n, float* __restrict__
     }
         ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
 #undef ADAM1
-        ((float4*)p)[i] = P; ((float4*)m)[i] = M; ((float4*)v)[i] = V; ((float4*)pe)[i] = E;
+        ((float4*)p)[i] = P; ((float4*)m)[i] = M; ((float4*)v)[i] = V;
+        if (EMA) ((float4*)pe)[i] = E;
     }
     // tail (n not a multiple of 4)
     const int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -39,7 +42,7 @@ __global__ __launch_bounds__(256) void k_adam_ema(int64_t n, float* __restrict__
         const float vv = b2 * v[i] + (1.0f - b2) * gg * gg;
         const float pp = p[i] - step_size * (mm / (sqrtf(vv) / sqrt_bc2 + eps));
         m[i] = mm; v[i] = vv; p[i] = pp;
-        pe[i] = alpha * pe[i] + (1.0f - alpha) * pp;
+        if (EMA) pe[i] = alpha * pe[i] + (1.0f - alpha) * pp;
     }
 }
 
@@ -93,13 +96,14 @@ __global__ void k_step_state_advance(sed_step_state* s) {
 
 extern "C" int sed_adam_ema(int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                             float* ema_params, const sed_step_state* state_dev, float grad_scale, void* stream) {
-    SED_CHECK_ARG(n > 0 && params && grads && exp_avg && exp_avg_sq && ema_params && state_dev, "sed_adam_ema: bad argument");
+    SED_CHECK_ARG(n > 0 && params && grads && exp_avg && exp_avg_sq && state_dev, "sed_adam_ema: bad argument");
     SED_CHECK_ARG(((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)ema_params) % 16 == 0,
                   "sed_adam_ema: buffers must be 16-byte aligned");
     int64_t blocks = (n / 4 + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
-    k_adam_ema<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(n, params, grads, exp_avg, exp_avg_sq, ema_params, state_dev, grad_scale);
+    if (ema_params) k_adam_ema<true><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(n, params, grads, exp_avg, exp_avg_sq, ema_params, state_dev, grad_scale);
+    else k_adam_ema<false><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(n, params, grads, exp_avg, exp_avg_sq, nullptr, state_dev, grad_scale);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

@@ -47,25 +47,31 @@ def _slice_range(s, B):
 
 
 class MeanTeacherStep:
-    """The body of main.train's loop (main.py:84-157) as one fused, graph-capturable device step."""
+    """The body of main.train's loop (main.py:84-157) as one fused, graph-capturable device step.
+
+    ``teacher=None`` gives the supervised loop body of main_simple_CRNN.train (main_simple_CRNN.py:39-75):
+    student forward, weak + strong BCE (either mask may be None), backward, Adam - no teacher forward, no
+    consistency terms, no EMA."""
 
     def __init__(self, student, teacher, batch_size, n_frames, rampup_length, weak_mask, strong_mask, lr=1e-3,
                  betas=(0.9, 0.999), eps=1e-8, ema_decay=0.999, max_consistency_cost=2.0, seed=0, use_graph=True,
                  process_group=None, overlap_streams=True):
-        assert isinstance(student, CRNN) and isinstance(teacher, CRNN)
+        assert isinstance(student, CRNN) and (teacher is None or isinstance(teacher, CRNN))
         self.l = _lib.lib()
         self.student, self.teacher = student, teacher
+        self.supervised = teacher is None
         dev = next(student.parameters()).device
         if dev.type != "cuda":
             raise _lib.SedError("MeanTeacherStep needs the models on the GPU (no CPU fallback)")
         self.device = dev
         student.flatten_parameters_(dev)
-        teacher.flatten_parameters_(dev)
+        if teacher is not None:
+            teacher.flatten_parameters_(dev)
         self.B, self.T = int(batch_size), int(n_frames)
         self.dims = _lib.make_dims(self.B, self.T, 64, 64, 64, student._nclass, student._n_layers, student._p_drop)
         self.T3, self.NC = self.T // 8, student._nclass
-        self.wlo, self.whi = _slice_range(weak_mask, self.B)
-        self.slo, self.shi = _slice_range(strong_mask, self.B)
+        self.wlo, self.whi = _slice_range(weak_mask, self.B) if weak_mask is not None else (0, 0)
+        self.slo, self.shi = _slice_range(strong_mask, self.B) if strong_mask is not None else (0, 0)
         n = student._flat.numel()
         self.n = n
         f32 = dict(device=dev, dtype=torch.float32)
@@ -85,15 +91,17 @@ class MeanTeacherStep:
         if self.ctx_bytes == 0 or self.ws_bytes == 0:
             raise _lib.SedError(self.l.sed_last_error().decode())
         self.ctx_s = torch.empty(self.ctx_bytes, device=dev, dtype=torch.uint8)
-        self.ctx_t = torch.empty(self.ctx_bytes, device=dev, dtype=torch.uint8)
+        self.ctx_t = torch.empty(self.ctx_bytes if teacher is not None else 0, device=dev, dtype=torch.uint8)
         self.ws = torch.empty(self.ws_bytes, device=dev, dtype=torch.uint8)
         self.x = torch.zeros(self.B, 1, self.T, 64, **f32)
         self.x_ema = torch.zeros(self.B, 1, self.T, 64, **f32)
         self.target = torch.zeros(self.B, self.T3, self.NC, **f32)
         self.strong = torch.empty(self.B, self.T3, self.NC, **f32)
         self.weak = torch.empty(self.B, self.NC, **f32)
-        self.strong_ema = torch.empty(self.B, self.T3, self.NC, **f32)
-        self.weak_ema = torch.empty(self.B, self.NC, **f32)
+        # supervised: the "teacher" outputs ARE the student's, so both consistency terms and their gradients are
+        # exactly zero and the loss kernel needs no second variant
+        self.strong_ema = torch.empty(self.B, self.T3, self.NC, **f32) if teacher is not None else self.strong
+        self.weak_ema = torch.empty(self.B, self.NC, **f32) if teacher is not None else self.weak
         self.d_strong = torch.empty(self.B, self.T3, self.NC, **f32)
         self.d_weak = torch.empty(self.B, self.NC, **f32)
         self.losses = torch.zeros(8, **f32)
@@ -103,10 +111,10 @@ class MeanTeacherStep:
             import torch.distributed as dist
             self.world = dist.get_world_size(process_group)
             # replicas must start identical (the reference has one copy; DDP convention: rank 0 wins)
-            sdist.broadcast_parameters([student._flat, teacher._flat], process_group)
+            sdist.broadcast_parameters([student._flat] + ([teacher._flat] if teacher is not None else []), process_group)
         self.use_graph = bool(use_graph)
         self.overlap = bool(overlap_streams)
-        self._side = torch.cuda.Stream(device=dev) if self.overlap else None
+        self._side = torch.cuda.Stream(device=dev) if (self.overlap and teacher is not None) else None
         self._graph_a = None
         self._graph_a2 = None
         self._graph_b = None
@@ -123,7 +131,9 @@ class MeanTeacherStep:
 
     def _fwd_bwd(self):
         """teacher forward (main.py:87-89), student forward (:91), losses (:93-145), backward (:152-153)."""
-        if self._side is not None:
+        if self.supervised:
+            self._forward(self.student, self.x, self.ctx_s, self._seed_s, self.strong, self.weak)
+        elif self._side is not None:
             # the teacher forward is independent of the student forward: run it on a second stream
             cur = torch.cuda.current_stream()
             self._side.wait_stream(cur)
@@ -153,7 +163,8 @@ class MeanTeacherStep:
         """Adam (main.py:154) + EMA teacher (:155-157) + step counters, one kernel each."""
         _lib.check(self.l.sed_adam_ema(self.n, _lib.ptr(self.student._flat), _lib.ptr(self.grads),
                                        _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
-                                       _lib.ptr(self.teacher._flat), _lib.ptr(self.state), 1.0 / self.world,
+                                       _lib.ptr(self.teacher._flat) if self.teacher is not None else None,
+                                       _lib.ptr(self.state), 1.0 / self.world,
                                        _lib.stream_ptr()), "sed_adam_ema")
         _lib.check(self.l.sed_step_state_advance(_lib.ptr(self.state), _lib.stream_ptr()), "sed_step_state_advance")
 
@@ -170,7 +181,8 @@ class MeanTeacherStep:
     # ---- public ------------------------------------------------------------------------------------
     def load_batch(self, x, x_ema, target):
         self.x.copy_(x.reshape(self.x.shape), non_blocking=True)
-        self.x_ema.copy_(x_ema.reshape(self.x.shape), non_blocking=True)
+        if x_ema is not None:
+            self.x_ema.copy_(x_ema.reshape(self.x.shape), non_blocking=True)
         self.target.copy_(target, non_blocking=True)
 
     def run(self):
@@ -198,6 +210,7 @@ class MeanTeacherStep:
         self.steps_done += 1
 
     def step(self, x, x_ema, target):
+        """``x_ema`` is ignored (may be None) in supervised mode."""
         self.load_batch(x, x_ema, target)
         self.run()
 
@@ -231,30 +244,33 @@ class MeanTeacherStep:
 
 def train(train_loader, model, optimizer, epoch, ema_model=None, weak_mask=None, strong_mask=None, n_epoch=100,
           log=print):
-    """main.train (main.py:52-165) with the loop body replaced by MeanTeacherStep.
+    """main.train (main.py:52-165) with the loop body replaced by MeanTeacherStep.  With ``ema_model=None`` and
+    two-element batches ``(batch_input, target)`` it is main_simple_CRNN.train (main_simple_CRNN.py:31-82).
 
     ``optimizer`` supplies lr / betas / eps (its per-tensor state is not used: Adam moments live in the
     step object's flat buffers, kept on ``model._mt_step`` across epochs)."""
-    if ema_model is None:
-        raise NotImplementedError("the fused step implements the mean-teacher path; use the reference "
-                                  "main_simple_CRNN.train loop with dcase2019_task4_amd.crnn.CRNN for supervised training")
     start = time.time()
     step_obj = getattr(model, "_mt_step", None)
     it = iter(train_loader)
     n_batches = len(train_loader)
     for i in range(n_batches):
-        batch_input, ema_batch_input, target = next(it)
+        batch = next(it)
+        if ema_model is None:
+            (batch_input, target), ema_batch_input = batch, None
+        else:
+            batch_input, ema_batch_input, target = batch
         if step_obj is None:
             B, T = batch_input.shape[0], batch_input.shape[-2]
             pg0 = optimizer.param_groups[0]
             dev = torch.device("cuda", torch.cuda.current_device())
             model.to(dev)
-            ema_model.to(dev)
+            if ema_model is not None:
+                ema_model.to(dev)
             step_obj = MeanTeacherStep(model, ema_model, B, T, n_batches * n_epoch // 2, weak_mask, strong_mask,
                                        lr=pg0["lr"], betas=pg0["betas"], eps=pg0["eps"])
             model._mt_step = step_obj
         step_obj.step(batch_input.to(step_obj.device, non_blocking=True),
-                      ema_batch_input.to(step_obj.device, non_blocking=True),
+                      ema_batch_input.to(step_obj.device, non_blocking=True) if ema_batch_input is not None else None,
                       target.to(step_obj.device, non_blocking=True))
     m = step_obj.meters()
     loss = m["loss"]

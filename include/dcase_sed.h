@@ -134,7 +134,8 @@ int sed_mt_loss(const sed_dims* d, const float* strong, const float* weak, const
 /* ---- optimiser + EMA -----------------------------------------------------------------------
  * Replaces optimizer.step() of torch.optim.Adam(lr, betas) (main.py:154,289-290) fused with
  * update_ema_variables (main.py:45-49,156-157) over the flat buffers. grad_scale multiplies
- * the gradient first (1/world_size after a sum all-reduce; 1 otherwise). */
+ * the gradient first (1/world_size after a sum all-reduce; 1 otherwise).  ema_params may be NULL:
+ * plain Adam, the optimizer.step() of the supervised loop (main_simple_CRNN.py:75). */
 int sed_adam_ema(int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                  float* ema_params, const sed_step_state* state_dev, float grad_scale, void* stream);
 

@@ -202,5 +202,64 @@ def main_():
     print("wrote", sorted(os.listdir(OUT)))
 
 
+def supervised_():
+    """G8: three steps of the REAL baseline/main_simple_CRNN.py train() (config 1 of BASELINE.json: the supervised
+    CRNN, weak + strong BCE only, no teacher), B=8, T=628, dropout 0."""
+    import torch
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    main, cfg, CRNN = import_reference()
+    import main_simple_CRNN as simple
+    from oracle import synth
+    kw0 = dict(cfg.crnn_kwargs)
+    kw0["dropout"] = 0
+    B, T = 8, 628
+    model = CRNN(**kw0)
+    load_params(model, synth.make_params(0))
+    model.train()
+    rec = {"grads": [], "meters": []}
+
+    class RecAdam(torch.optim.Adam):
+        def step(self, closure=None):
+            rec["grads"].append([p.grad.detach().clone() for g in self.param_groups for p in g["params"]])
+            return super().step(closure)
+
+    class RecMeters(simple.AverageMeterSet):
+        def update(self, name, value, n=1):
+            rec["meters"].append((name, float(value)))
+            return super().update(name, value, n)
+
+    simple.AverageMeterSet = RecMeters
+    opt = RecAdam(filter(lambda p: p.requires_grad, model.parameters()), lr=0.001, betas=(0.9, 0.999))
+    batches = []
+    for it in range(3):
+        x = synth.make_input(20 + it, B, T)
+        tgt, _, _ = synth.make_target(it, B, T // 8)
+        tgt = tgt.clamp(min=0)            # main_simple_CRNN has no unlabeled rows: every clip carries labels
+        batches.append((x, tgt))
+    wm, sm = slice(B // 2), slice(B // 2, B)      # main_simple_CRNN.py:185-186
+    simple.train(batches, model, opt, 0, weak_mask=wm, strong_mask=sm)
+    save = {}
+    names = [n for n, _ in model.named_parameters()]
+    for it in range(3):
+        for n, g in zip(names, rec["grads"][it]):
+            key = n.replace(".", "_")
+            save[f"s{it}_gnorm_{key}"] = np.array(float(g.double().norm()))
+            save[f"s{it}_ghead_{key}"] = g.flatten()[:16].numpy()
+    for mn in sorted(set(n for n, _ in rec["meters"])):
+        save["meter_" + mn.replace(" ", "_")] = np.array([v for n, v in rec["meters"] if n == mn])
+    for n, p in model.named_parameters():
+        save["p_sum_" + n.replace(".", "_")] = np.array(float(p.detach().double().sum()))
+        save["p_head_" + n.replace(".", "_")] = p.detach().flatten()[:16].numpy()
+    for n, b in model.named_buffers():
+        save["b_" + n.replace(".", "_")] = b.numpy()
+    np.savez_compressed(os.path.join(OUT, "g8_supervised3.npz"), **save)
+    print("wrote g8_supervised3.npz", sorted(k for k in save if k.startswith("meter_")))
+
+
 if __name__ == "__main__":
-    main_()
+    if len(sys.argv) > 1 and sys.argv[1] == "g8":
+        supervised_()
+    else:
+        main_()
+        supervised_()

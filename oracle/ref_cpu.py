@@ -246,6 +246,28 @@ class MeanTeacherOracle:
         self.global_step = 0
         self.opt_step = 0
 
+    def supervised_step(self, x, target, weak_mask, strong_mask, masks=None):
+        """Loop body of main_simple_CRNN.train (main_simple_CRNN.py:39-72): weak + strong BCE, Adam; no teacher."""
+        s, w = crnn_forward(self.p, x, True, self.bn, masks, self.n_layers_RNN)          # :44
+        loss = 0
+        meters = {}
+        if weak_mask is not None:
+            tw = target.max(-2)[0]                                                        # :50
+            meters["weak_class_loss"] = bce(w[weak_mask], tw[weak_mask])                  # :51
+            loss = loss + meters["weak_class_loss"]
+        if strong_mask is not None:
+            meters["strong_class_loss"] = bce(s[strong_mask], target[strong_mask])        # :62
+            loss = loss + meters["strong_class_loss"]
+        meters["loss"] = loss
+        grads = torch.autograd.grad(loss, list(self.p.values()), allow_unused=True)       # :73-74
+        grads = OrderedDict((k, g if g is not None else torch.zeros_like(v))
+                            for (k, v), g in zip(self.p.items(), grads))
+        self.opt_step += 1
+        with torch.no_grad():
+            adam_step(self.p, grads, self.m, self.v, self.opt_step, self.lr, self.betas)  # :75
+        meters = {k: float(v.detach()) for k, v in meters.items()}
+        return meters, grads, (s.detach(), w.detach())
+
     def step(self, x, x_ema, target, weak_mask, strong_mask, rampup_length, masks=None, masks_ema=None):
         cons_w = consistency_weight(self.global_step, rampup_length)
         with torch.no_grad():                                               # main.py:87-89 (+detach)

@@ -90,15 +90,15 @@ def test_train_forward_and_running_stats_vs_reference_goldens(golden_dir):
         np.testing.assert_allclose(v.cpu().numpy(), g[k.replace(".", "_")], rtol=3e-5, atol=3e-6)
 
 
-def _fwd_bwd_both(B, T, p, seed, n_layers=2):
+def _fwd_bwd_both(B, T, p, seed, n_layers=2, nclass=10):
     """Train-mode forward+backward of the HIP module and of the oracle on identical inputs/masks."""
-    model, params = gu.make_model(0, dropout=p, n_layers=n_layers)
+    model, params = gu.make_model(0, dropout=p, n_layers=n_layers, nclass=nclass)
     model.train()
     x = synth.make_input(40, B, T)
-    tgt, wm, sm = synth.make_target(5, B, T // 8)
+    tgt, wm, sm = synth.make_target(5, B, T // 8, nclass=nclass)
     rs = np.random.RandomState(99)
-    s_ema = torch.tensor(rs.uniform(0.05, 0.95, (B, T // 8, 10)), dtype=torch.float32)
-    w_ema = torch.tensor(rs.uniform(0.05, 0.95, (B, 10)), dtype=torch.float32)
+    s_ema = torch.tensor(rs.uniform(0.05, 0.95, (B, T // 8, nclass)), dtype=torch.float32)
+    w_ema = torch.tensor(rs.uniform(0.05, 0.95, (B, nclass)), dtype=torch.float32)
     cons_w = 0.7
 
     def loss_fn(s, w, dev):
@@ -139,12 +139,15 @@ def _check_grads(g_hip, go):
     return worst
 
 
-@pytest.mark.parametrize("B,T,p,n_layers", [(4, 128, 0.0, 2), (4, 128, 0.5, 2), (4, 628, 0.5, 2), (5, 216, 0.5, 1),
-                                            (4, 150, 0.25, 2)])
-def test_train_forward_backward_vs_oracle(B, T, p, n_layers):
+@pytest.mark.parametrize("B,T,p,n_layers,nclass", [(4, 128, 0.0, 2, 10), (4, 128, 0.5, 2, 10), (4, 628, 0.5, 2, 10),
+                                                   (5, 216, 0.5, 1, 10), (4, 150, 0.25, 2, 10), (7, 1040, 0.5, 2, 10),
+                                                   (4, 864, 0.5, 2, 10), (6, 96, 0.5, 2, 1), (5, 200, 0.5, 2, 16)])
+def test_train_forward_backward_vs_oracle(B, T, p, n_layers, nclass):
     """Posteriors, loss, every parameter gradient and the BN running stats against the oracle, with
-    dropout ON (same Philox masks on both sides).  T=150 exercises odd H (rows dropped by the pool)."""
-    hip, orc = _fwd_bwd_both(B, T, p, seed=123456789, n_layers=n_layers)
+    dropout ON (same Philox masks on both sides).  T=150 exercises odd H (rows dropped by the pool); T=1040 gives
+    130 output frames (more than one 128-frame chunk in the heads kernels) with a batch that is not a multiple of
+    4; T=864 is the reference's own frame count (config.py:17-22); nclass 1 and 16 are the ABI's limits."""
+    hip, orc = _fwd_bwd_both(B, T, p, seed=123456789, n_layers=n_layers, nclass=nclass)
     es, _ = gu.report("strong", hip[0], orc[0])
     ew, _ = gu.report("weak", hip[1], orc[1])
     assert es < POST_TOL and ew < POST_TOL
@@ -235,6 +238,41 @@ def test_three_fused_steps_vs_real_main_train_goldens(golden_dir, use_graph):
         for k, v in mdl.named_buffers():
             atol = 1e-2 if k.endswith("running_mean") else 3e-6
             np.testing.assert_allclose(v.cpu().numpy(), g[tag + k.replace(".", "_")], rtol=3e-5, atol=atol, err_msg=k)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_supervised_fused_steps_vs_real_main_simple_crnn_goldens(golden_dir, use_graph):
+    """G8 (BASELINE.json config 1): three steps of the REAL baseline/main_simple_CRNN.py train() against the
+    fused step in supervised mode (teacher=None) through dcase2019_task4_amd.train.train()."""
+    from dcase2019_task4_amd import train as tr
+    g = _golden(golden_dir, "g8_supervised3.npz")
+    B, T = 8, 628
+    model, _ = gu.make_model(0, dropout=0)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=0.001, betas=(0.9, 0.999))
+    wm, sm = slice(B // 2), slice(B // 2, B)
+    for it in range(3):          # one "epoch" of one batch each, so the meters of every step can be read
+        tgt = synth.make_target(it, B, T // 8)[0].clamp(min=0)
+        if it == 0 and use_graph:
+            from dcase2019_task4_amd.train import MeanTeacherStep
+            model._mt_step = MeanTeacherStep(model, None, B, T, 0, wm, sm, use_graph=True)
+            model._mt_step._warm = 2
+        elif it == 0:
+            model._mt_step = tr.MeanTeacherStep(model, None, B, T, 0, wm, sm, use_graph=False)
+        m = tr.train([(synth.make_input(20 + it, B, T), tgt)], model, opt, it, weak_mask=wm, strong_mask=sm,
+                     log=lambda *_: None)
+        assert m["weak_class_loss"] == pytest.approx(float(g["meter_Weak_loss"][it]), rel=1e-4)
+        assert m["strong_loss"] == pytest.approx(float(g["meter_Strong_loss"][it]), rel=1e-4)
+        assert m["loss"] == pytest.approx(float(g["meter_Loss"][it]), rel=1e-4)
+        assert m["cons_strong"] == 0.0 and m["cons_weak"] == 0.0
+    for n, p in model.named_parameters():
+        k = n.replace(".", "_")
+        tol = 1e-2 if (".conv" in n and n.endswith("bias")) else 3e-5
+        np.testing.assert_allclose(p.detach().flatten()[:16].cpu().numpy(), g["p_head_" + k], atol=tol, err_msg=n)
+        assert float(p.detach().double().sum()) == pytest.approx(float(g["p_sum_" + k]), abs=tol * p.numel())
+    for k, v in model.named_buffers():
+        atol = 1e-2 if k.endswith("running_mean") else 3e-6
+        np.testing.assert_allclose(v.cpu().numpy(), g["b_" + k.replace(".", "_")], rtol=3e-5, atol=atol, err_msg=k)
 
 
 def _assert_params_close(got, want, name, n_steps, lr=1e-3):

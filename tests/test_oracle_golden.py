@@ -182,3 +182,34 @@ def test_philox_known_answer():
     assert abs(f.mean() - 1.0) < 0.05
     n = philox.teacher_noise(3, 2, 100, 64)
     assert n.min() >= 0 and abs(n.mean() - 0.25 * np.sqrt(2 / np.pi)) < 0.01
+
+
+def test_g8_supervised_steps_vs_real_main_simple_crnn_train(golden_dir):
+    """G8: three steps of the REAL baseline/main_simple_CRNN.py train() (BASELINE.json config 1: supervised CRNN,
+    weak + strong BCE, Adam; B=8, dropout 0) against the oracle's supervised_step."""
+    g = _load(golden_dir, "g8_supervised3.npz")
+    B, T = 8, 628
+    mt = ref_cpu.MeanTeacherOracle(synth.make_params(0), synth.make_params(0))
+    names = list(mt.p.keys())
+    wm, sm = slice(B // 2), slice(B // 2, B)
+    for it in range(3):
+        x = synth.make_input(20 + it, B, T)
+        tgt = synth.make_target(it, B, T // 8)[0].clamp(min=0)
+        meters, grads, _ = mt.supervised_step(x, tgt, wm, sm)
+        assert meters["weak_class_loss"] == pytest.approx(g["meter_Weak_loss"][it], rel=2e-5)
+        assert meters["strong_class_loss"] == pytest.approx(g["meter_Strong_loss"][it], rel=2e-5)
+        assert meters["loss"] == pytest.approx(g["meter_Loss"][it], rel=2e-5)
+        for n in names:
+            key = n.replace(".", "_")
+            gn = float(grads[n].double().norm())
+            if ".conv" in n and n.endswith("bias"):
+                assert gn < 2e-5 and float(g[f"s{it}_gnorm_{key}"]) < 2e-5
+                continue
+            assert gn == pytest.approx(float(g[f"s{it}_gnorm_{key}"]), rel=5e-4), (it, n)
+    for n in names:
+        key = n.replace(".", "_")
+        tol = 1e-2 if (".conv" in n and n.endswith("bias")) else 2e-5
+        np.testing.assert_allclose(mt.p[n].detach().flatten()[:16].numpy(), g["p_head_" + key], atol=tol)
+    for k, v in mt.bn.items():
+        atol = 1e-2 if k.endswith("running_mean") else 3e-6
+        np.testing.assert_allclose(v.numpy(), g["b_" + k.replace(".", "_")], rtol=3e-5, atol=atol)

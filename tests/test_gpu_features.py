@@ -80,3 +80,46 @@ def test_waveform_to_posteriors_pipeline_runs():
     with torch.no_grad():
         s, w = model(x)
     assert s.shape == (2, 78, 10) and torch.isfinite(s).all() and torch.isfinite(w).all()
+
+
+def test_config3_raw_waveform_batch64_mean_teacher_step():
+    """BASELINE.json config 3 at its full size: 64 raw 16 kHz clips -> on-GPU STFT/mel -> noise/log/pad/normalise ->
+    one mean-teacher step (B=64, T=628), against the oracle on the SAME features (fp32 on both sides - the config
+    is quoted at bf16, fp32 is the stricter arithmetic), plus size-independent properties of a second step."""
+    from dcase2019_task4_amd.features import FeatureConfig, FeatureExtractor, LogMelTransform, Scaler
+    from dcase2019_task4_amd.train import MeanTeacherStep
+    from oracle import ref_cpu
+    from tests import gpu_util as gu
+    B, T = 64, 628
+    cfg = FeatureConfig.baseline_16k()
+    fe = FeatureExtractor(cfg)
+    waves = np.stack([synth.make_wave(i, 160000) for i in range(B)]).astype(np.float32)
+    mel = fe.calculate_mel_spec_batch(torch.tensor(waves))
+    for i in (0, 17, 63):                                   # the front-end at batch 64 against the oracle
+        want = features_np.calculate_mel_spec(waves[i].astype(np.float64), cfg.sample_rate, cfg.n_window, cfg.hop_length,
+                                              cfg.n_mels, cfg.f_min, cfg.f_max)
+        np.testing.assert_allclose(mel[i].cpu().numpy(), want, rtol=2e-6, atol=1e-6 * want.max())
+    sc = Scaler()
+    sc.calculate_scaler([features_np.transform_chain(m, T) for m in mel[:8].cpu().numpy()])
+    seed = 24681357
+    x, x_ema = LogMelTransform(T, sc, augment_type="noise")(mel, seed=seed)
+    assert x.shape == (B, 1, T, 64) and x_ema.shape == (B, 1, T, 64)
+    student, ps = gu.make_model(0, dropout=0)
+    teacher, pt = gu.make_model(1, dropout=0)
+    student.train(); teacher.train()
+    tgt, wm, sm = synth.make_target(3, B, T // 8)
+    st = MeanTeacherStep(student, teacher, B, T, 100, wm, sm, use_graph=False)
+    st.step(x, x_ema, tgt.cuda())
+    m = st.meters()
+    mt = ref_cpu.MeanTeacherOracle(ps, pt)
+    mo, _, (so, wo, _, _) = mt.step(x.cpu(), x_ema.cpu(), tgt, wm, sm, 100)
+    for k in ("loss", "weak_class_loss", "strong_loss", "cons_strong", "cons_weak", "weak_ema_loss", "strong_ema_loss"):
+        assert m[k] == pytest.approx(mo[k], rel=1e-4, abs=1e-9), k
+    np.testing.assert_allclose(st.strong.cpu().numpy(), so.numpy(), atol=1e-5)       # north_star: 1e-3; we hold 1e-5
+    np.testing.assert_allclose(st.weak.cpu().numpy(), wo.numpy(), atol=1e-5)
+    # step 2: EMA identity teacher_2 = a*teacher_1 + (1-a)*student_2 with a = 2/3 (main.py:45-49), at full size
+    t1 = teacher._flat.clone()
+    st.step(x, x_ema, tgt.cuda())
+    a = 1.0 - 1.0 / 3.0
+    np.testing.assert_allclose(teacher._flat.cpu().numpy(), (a * t1 + (1 - a) * student._flat).cpu().numpy(), atol=1e-6)
+    assert all(np.isfinite(v) for v in st.meters().values())

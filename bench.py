@@ -247,10 +247,12 @@ def main():
         dom = max(mfma_kernels, key=lambda k: kr[k]["us"])
         traffic, traffic_src = None, None
         pmc_file = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        pmc_name = {"conv1_fwd": "void k_conv3x3<16, 0, 1>", "conv1_dgrad": "void k_conv3x3<16, 1, 1>",
-                    "conv1_wgrad": "void k_conv3x3_wgrad<16, 1>"}[dom]
+        pmc_names = {"conv1_fwd": ("void k_conv16_ws<0>", "void k_conv3x3<16, 0, 1>"),
+                     "conv1_dgrad": ("void k_conv3x3<16, 1, 1>", "void k_conv16_ws<1>"),
+                     "conv1_wgrad": ("void k_conv3x3_wgrad<16, 1>",)}[dom]
         if os.path.exists(pmc_file):
-            pmc = json.load(open(pmc_file)).get(pmc_name)
+            table = json.load(open(pmc_file))
+            pmc = next((table[n] for n in pmc_names if n in table), None)
             if pmc:
                 traffic = pmc["read_bytes"] + pmc["write_bytes"]
                 traffic_src = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench "

@@ -24,18 +24,7 @@
 
 #define ZS 65   // pixel stride of LDS tiles (floats)
 
-// Tuning aid (make EXTRA=-DSED_TS): wave 0 of every workgroup stamps the 100 MHz wall clock at phase boundaries.
-#ifdef SED_TS
-static __device__ unsigned long long g_ts[1024 * 16];
-#define TS(k) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_ts[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
-#define TSC(k) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_ts[blockIdx.x * 16 + (k)] = clock64(); } while (0)
-extern "C" int sed_debug_ts(unsigned long long* out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ts), sizeof(unsigned long long) * (n < 1024 * 16 ? n : 1024 * 16));
-}
-#else
-#define TS(k) do { } while (0)
-#define TSC(k) do { } while (0)
-#endif
+SED_TS_DEFINE(bnglu)
 
 struct BnPrepArgs {
     const double* stat; double N;

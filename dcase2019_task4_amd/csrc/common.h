@@ -126,3 +126,21 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 __device__ __forceinline__ int mfma32_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // host launch helpers implemented per file; declared in kernels.h
+
+// ---- tuning aid (make EXTRA=-DSED_TS): thread 0 of every workgroup stamps the 100 MHz wall clock (TS) or the
+// shader clock (TSC) at phase boundaries into a per-translation-unit device array; tools/ts_kernel.py reads it
+// through sed_debug_ts_<tag>.  Compiles to nothing in the product build.
+#ifdef SED_TS
+#define SED_TS_DEFINE(tag)                                                                                          \
+    static __device__ unsigned long long g_ts[1024 * 16];                                                           \
+    extern "C" int sed_debug_ts_##tag(unsigned long long* out, int n) {                                             \
+        return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ts), sizeof(unsigned long long) * (n < 1024 * 16 ? n : 1024 * 16)); \
+    }
+#define TS(k) do { if (threadIdx.x == 0 && blockIdx.x < 1024 && blockIdx.y == 0) g_ts[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#define TSC(k) do { if (threadIdx.x == 0 && blockIdx.x < 1024 && blockIdx.y == 0) g_ts[blockIdx.x * 16 + (k)] = clock64(); } while (0)
+#else
+#define SED_TS_DEFINE(tag)
+#define TS(k) do { } while (0)
+#define TSC(k) do { } while (0)
+#endif
+

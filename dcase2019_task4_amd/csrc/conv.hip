@@ -19,6 +19,7 @@
 //    write one partial each, and k_wgrad_reduce sums the partials (deterministic, no atomics).
 #include "common.h"
 #include "kernels.h"
+SED_TS_DEFINE(conv)
 
 template <int TW>
 struct ConvCfg {
@@ -386,9 +387,13 @@ __global__ __launch_bounds__(256) void k_conv3x3_wgrad(const float* __restrict__
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    TS(0); TSC(14);
+    int ts_k = 1;
+    (void)ts_k;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int b = tile / tiles_per_clip, y0 = (tile % tiles_per_clip) * TH;
         __syncthreads();
+        if (ts_k < 12) { TS(ts_k); ++ts_k; }
         for (int f = tid; f < HH * HW * 16; f += 256) {
             const int pix = f >> 4, c4 = (f & 15) * 4;
             const int hy = pix / HW, hx = pix % HW;
@@ -416,6 +421,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_wgrad(const float* __restrict__
             *(float4*)(dyt + pix * 64 + c4) = v;
         }
         __syncthreads();
+        if (ts_k < 12) { TS(ts_k); ++ts_k; }
         const float* Ab = dyt + kh * 64 + 32 * cob + n;
         const float* Bb = xh + kh * 64 + 32 * cib + n;
         for (int ty = 0; ty < TH; ++ty) {
@@ -431,6 +437,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_wgrad(const float* __restrict__
             }
         }
     }
+    TS(12);
     float* dst = part + (size_t)blockIdx.x * 9 * 4096;
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl)
@@ -439,22 +446,149 @@ __global__ __launch_bounds__(256) void k_conv3x3_wgrad(const float* __restrict__
             const int co = 32 * cob + mfma32_row(r, lane);
             dst[(tap0 + tl) * 4096 + co * 64 + 32 * cib + n] = acc[tl][r];
         }
+    TS(13); TSC(15);
 }
 
-__global__ void k_wgrad_reduce(const float* __restrict__ part, int n_blocks, float* __restrict__ g_w) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;    // over [tap][co][ci]
-    if (i >= 9 * 4096) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = 0;
-    for (; k + 4 <= n_blocks; k += 4) {
-        s0 += part[(size_t)(k + 0) * 9 * 4096 + i];
-        s1 += part[(size_t)(k + 1) * 9 * 4096 + i];
-        s2 += part[(size_t)(k + 2) * 9 * 4096 + i];
-        s3 += part[(size_t)(k + 3) * 9 * 4096 + i];
+// ---- block-1 wgrad with the staging hidden under the MFMAs ---------------------------------------------------
+// Phase timestamps of the kernel above at B = 24 (tools/ts_kernel.py): 18 us of MFMAs per tile (95 % of the
+// pipe's rate) but 7.7 us of staging in front of every tile - all 256 workgroups stage at the same moment, so the
+// 28 MB burst runs at HBM speed while the memory system idles during the MFMA phases.  Here both LDS buffers
+// exist twice (2 x 77 KB = 154 KB of the CU's 160 KB) and the next tile arrives in 8 register-staged slices, one
+// per image row of MFMAs: slice c is LOADED during row c and written to the other LDS buffer (with the
+// BatchNorm-backward affine applied) at the start of row c+1, i.e. 2 us later; one LDS-only barrier per tile.
+struct Wg16 {
+    static constexpr int TH = 8, TW = 16, HW = 18, HH = 10;
+    static constexpr int XH_FLOATS = HH * HW * 64, DY_FLOATS = 128 * 64, BUF_FLOATS = XH_FLOATS + DY_FLOATS;
+    static constexpr size_t LDS_BYTES = (size_t)2 * BUF_FLOATS * 4;
+    static constexpr int HALO_F4 = HH * HW * 16, HALO_SLICE = HALO_F4 / 8;     // 2880 float4, 360 per slice
+};
+struct Wg16Slice { f32x4 h0, h1, d, y; };     // clang ext vectors: HIP's float4 struct did not stay in registers here
+__device__ __forceinline__ Wg16Slice wg16_load(const float* __restrict__ dz, const float* __restrict__ yin,
+                                               const float* __restrict__ xin, int H, int tiles_per_clip, int tile, int c, int tid) {
+    using C = Wg16;
+    Wg16Slice s;
+    const int b = tile / tiles_per_clip, y0 = (tile % tiles_per_clip) * C::TH;
+    const int c4 = (tid & 15) * 4;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    {
+        const int f = c * C::HALO_SLICE + tid;
+        const int pix = f >> 4, hy = pix / C::HW, hx = pix % C::HW;
+        const int iy = y0 - 1 + hy, ix = hx - 1;
+        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < C::TW;
+        const f32x4 v = *(const f32x4*)(xin + (ok ? (((size_t)b * H + iy) * C::TW + ix) * 64 + (f & 15) * 4 : (size_t)0));
+        s.h0 = ok ? v : z4;
     }
-    for (; k < n_blocks; ++k) s0 += part[(size_t)k * 9 * 4096 + i];
-    const int tap = i / 4096, co = (i / 64) % 64, ci = i % 64;
-    g_w[(co * 64 + ci) * 9 + tap] = (s0 + s1) + (s2 + s3);
+    {   // threads past the slice re-load its last element (never stored): no divergent assignment
+        const int f = c * C::HALO_SLICE + 256 + (tid < C::HALO_SLICE - 256 ? tid : C::HALO_SLICE - 257);
+        const int pix = f >> 4, hy = pix / C::HW, hx = pix % C::HW;
+        const int iy = y0 - 1 + hy, ix = hx - 1;
+        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < C::TW;
+        const f32x4 v = *(const f32x4*)(xin + (ok ? (((size_t)b * H + iy) * C::TW + ix) * 64 + (f & 15) * 4 : (size_t)0));
+        s.h1 = ok ? v : z4;
+    }
+    {
+        const int yy = y0 + c, xx = tid >> 4;
+        const size_t g = (yy < H) ? (((size_t)b * H + yy) * C::TW + xx) * 64 + c4 : (size_t)0;   // masked in wg16_store
+        s.d = *(const f32x4*)(dz + g);
+        s.y = *(const f32x4*)(yin + g);
+    }
+    return s;
+}
+__device__ __forceinline__ void wg16_store(const Wg16Slice& s, float* buf, int H, int tiles_per_clip, int tile, int c, int tid,
+                                           const f32x4& ca, const f32x4& cb, const f32x4& cc) {
+    using C = Wg16;
+    const int y0 = (tile % tiles_per_clip) * C::TH;
+    *(f32x4*)(buf + (size_t)(c * C::HALO_SLICE + tid) * 4) = s.h0;          // xh[pix*64 + c4] with f = pix*16 + c4/4
+    if (tid < C::HALO_SLICE - 256) *(f32x4*)(buf + (size_t)(c * C::HALO_SLICE + 256 + tid) * 4) = s.h1;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (y0 + c < H) v = ca * s.d + cb * s.y + cc;                          // rows past the image stay exactly 0
+    *(f32x4*)(buf + C::XH_FLOATS + (size_t)(c * 256 + tid) * 4) = v;        // dyt[pix*64 + c4], pix = 16c + tid/16
+}
+__global__ __launch_bounds__(256) void k_wgrad16_db(const float* __restrict__ dz, const float* __restrict__ yin,
+                                                     const float* __restrict__ coef, const float* __restrict__ xin,
+                                                     float* __restrict__ part, int H, int tiles_per_clip, int n_tiles) {
+    using C = Wg16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 31, kh = lane >> 5;
+    const int cob = wv >> 1, cib = wv & 1;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int c4 = (tid & 15) * 4;
+    const f32x4 ca = *(const f32x4*)(coef + c4), cb = *(const f32x4*)(coef + 64 + c4), cc = *(const f32x4*)(coef + 128 + c4);
+
+    Wg16Slice sl;                     // one slice in flight: 2 halo float4 (the second only for tid < 104), dz, y
+    TS(0); TSC(14);
+    int ts_k = 1;
+    (void)ts_k;
+    int tile = blockIdx.x;
+    if (tile < n_tiles) {
+        for (int c = 0; c < 8; ++c) { sl = wg16_load(dz, yin, xin, H, tiles_per_clip, tile, c, tid); wg16_store(sl, smem, H, tiles_per_clip, tile, c, tid, ca, cb, cc); }
+    }
+    __syncthreads();
+    int cur = 0;
+    for (; tile < n_tiles; tile += gridDim.x) {
+        if (ts_k < 12) { TS(ts_k); ++ts_k; }
+        const int nxt = tile + gridDim.x;
+        const bool has = nxt < n_tiles;
+        const float* xh = smem + cur * C::BUF_FLOATS;
+        float* other = smem + (cur ^ 1) * C::BUF_FLOATS;
+        const float* Ab = xh + C::XH_FLOATS + kh * 64 + 32 * cob + n;
+        const float* Bb = xh + kh * 64 + 32 * cib + n;
+        for (int ty = 0; ty < C::TH; ++ty) {
+            if (has) {
+                if (ty > 0) wg16_store(sl, other, H, tiles_per_clip, nxt, ty - 1, tid, ca, cb, cc);
+                sl = wg16_load(dz, yin, xin, H, tiles_per_clip, nxt, ty, tid);
+            }
+#pragma unroll
+            for (int txp = 0; txp < C::TW / 2; ++txp) {
+                const float a = Ab[(ty * C::TW + 2 * txp) * 64];
+#pragma unroll
+                for (int tl = 0; tl < 9; ++tl) {
+                    const int dy = tl / 3 - 1, dx = tl % 3 - 1;
+                    const float bv = Bb[((ty + 1 + dy) * C::HW + 2 * txp + 1 + dx) * 64];
+                    acc[tl] = mfma32(a, bv, acc[tl]);
+                }
+            }
+        }
+        if (has) wg16_store(sl, other, H, tiles_per_clip, nxt, C::TH - 1, tid, ca, cb, cc);
+        lds_barrier();
+        cur ^= 1;
+    }
+    TS(12);
+    float* dst = part + (size_t)blockIdx.x * 9 * 4096;
+#pragma unroll
+    for (int tl = 0; tl < 9; ++tl)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = 32 * cob + mfma32_row(r, lane);
+            dst[tl * 4096 + co * 64 + 32 * cib + n] = acc[tl][r];
+        }
+    TS(13); TSC(15);
+}
+
+// Sum of the per-workgroup partial slabs, in a fixed order (bit-reproducible).  A workgroup owns 64 consecutive
+// outputs; its 4 waves take every 4th slab (8 independent loads in flight per thread), then combine through LDS.
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, int n_blocks, float* __restrict__ g_w) {
+    __shared__ float red[4][64];
+    const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + o;                       // over [tap][co][ci]
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int k = grp;
+    for (; k + 28 < n_blocks; k += 32) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += part[(size_t)(k + 4 * u) * 9 * 4096 + i];
+    }
+    for (; k < n_blocks; k += 4) s[0] += part[(size_t)k * 9 * 4096 + i];
+    red[grp][o] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (grp == 0) {
+        const int tap = i / 4096, co = (i / 64) % 64, ci = i % 64;
+        g_w[(co * 64 + ci) * 9 + tap] = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+    }
 }
 
 // ---- host launchers ---------------------------------------------------------------------------
@@ -513,9 +647,20 @@ static int wgrad_launch_t(const float* dz, const float* yin, const float* coef, 
     }
     const int tpc = (H + Cfg::TH - 1) / Cfg::TH, nt = B * tpc;
     const int nb = nt < n_blocks ? nt : n_blocks;
-    k_conv3x3_wgrad<TW, TS><<<dim3(nb, TS), 256, Cfg::LDS_BYTES, st>>>(dz, yin, coef, xin, part, B, H, tpc, nt);
+    // block 1: the double-buffered kernel (15 % faster alone; in the step, next to dgrad on the other stream, 1.143 vs
+    // 1.162 ms per step although its 154 KB of LDS keep any other workgroup off its CU); bit 3 of the debug knob = old
+    if (TW == 16 && TS == 1 && !(g_sed_debug & 8)) {
+        static bool attr16 = false;
+        if (!attr16) {
+            SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_wgrad16_db, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wg16::LDS_BYTES));
+            attr16 = true;
+        }
+        k_wgrad16_db<<<nb, 256, Wg16::LDS_BYTES, st>>>(dz, yin, coef, xin, part, H, tpc, nt);
+    } else {
+        k_conv3x3_wgrad<TW, TS><<<dim3(nb, TS), 256, Cfg::LDS_BYTES, st>>>(dz, yin, coef, xin, part, B, H, tpc, nt);
+    }
     SED_CHECK_LAUNCH();
-    k_wgrad_reduce<<<(9 * 4096 + 255) / 256, 256, 0, st>>>(part, nb, g_w);
+    k_wgrad_reduce<<<9 * 4096 / 64, 256, 0, st>>>(part, nb, g_w);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

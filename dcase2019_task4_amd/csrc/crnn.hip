@@ -315,26 +315,31 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
         }
         d_cur = d_in;
     }
-    // weight + bias gradients of every GRU layer and direction, on the side stream, forked ONCE after the
-    // whole dX chain of the GRU has been issued (fork points inside the chain cost cross-queue latency):
+    }
+    // weight + bias gradients of every GRU layer and direction (split-K MFMA GEMMs, low occupancy):
     //   dW_ih[g][i] = sum_bt dgi[bt][g] input[bt][i],  db_ih[g] = sum_bt dgi[bt][g]
     //   dW_hh[g][j] = sum_bt dgh[bt][g] hprev[bt][j],  db_hh[g] = sum_bt dgh[bt][g]
-    if (sd.ok) { SIDE_FORK(st); forked = true; }
-    for (int l = g.L - 1; l >= 0; --l) {
-        const int nin = (l == 0) ? 64 : 128;
-        const float* input = (l == 0) ? CTXF(L.p2) : CTXF(L.out[l - 1]);
-        GemmBatch gb;
-        gb.n_prob = 4; gb.splits = SED_GRU_SPLITK; gb.part = WSF(W.gemm_part); gb.part_stride = 0;
-        for (int dir = 0; dir < 2; ++dir) {
-            gb.p[2 * dir] = gemm_prob(WSF(W.dgi[l]) + dir * 192, 1, 384, input, nin, 1, grads + P.w_ih[l][dir], nin, 192, nin, BT);
-            gb.p[2 * dir].Cones = grads + P.b_ih[l][dir];
-            gb.p[2 * dir + 1] = gemm_prob(WSF(W.dgh[l]) + dir * 192, 1, 384, WSF(W.hprev[l]) + dir * 64, 128, 1,
-                                          grads + P.w_hh[l][dir], 64, 192, 64, BT);
-            gb.p[2 * dir + 1].Cones = grads + P.b_hh[l][dir];
+    auto gru_weight_grads = [&](hipStream_t s2) -> int {
+        for (int l = g.L - 1; l >= 0; --l) {
+            const int nin = (l == 0) ? 64 : 128;
+            const float* input = (l == 0) ? CTXF(L.p2) : CTXF(L.out[l - 1]);
+            GemmBatch gb;
+            gb.n_prob = 4; gb.splits = SED_GRU_SPLITK; gb.part = WSF(W.gemm_part); gb.part_stride = 0;
+            for (int dir = 0; dir < 2; ++dir) {
+                gb.p[2 * dir] = gemm_prob(WSF(W.dgi[l]) + dir * 192, 1, 384, input, nin, 1, grads + P.w_ih[l][dir], nin, 192, nin, BT);
+                gb.p[2 * dir].Cones = grads + P.b_ih[l][dir];
+                gb.p[2 * dir + 1] = gemm_prob(WSF(W.dgh[l]) + dir * 192, 1, 384, WSF(W.hprev[l]) + dir * 64, 128, 1,
+                                              grads + P.w_hh[l][dir], 64, 192, 64, BT);
+                gb.p[2 * dir + 1].Cones = grads + P.b_hh[l][dir];
+            }
+            SED_TRY(launch_gemm_batch(gb, s2));
         }
-        SED_TRY(launch_gemm_batch(gb, ss));
-    }
-    }
+        return SED_OK;
+    };
+    // parts == 1 (data-parallel: the GRU + heads gradient bucket must be complete when this call returns so that
+    // its all-reduce can start): the GEMMs follow the dX chain on the caller's stream.  parts == 3: they are
+    // deferred to the side stream of the conv-block backward below, where they overlap k_glu_pool_bwd.
+    if (parts == 1) SED_TRY(gru_weight_grads(st));
     if (!(parts & 2)) {
         if (forked) SIDE_JOIN(st);
         return SED_OK;
@@ -346,16 +351,31 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
     const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};
     // one memset for every fp64 accumulator of the conv-block backward
     SED_CHECK_HIP(hipMemsetAsync(WSD(W.bwd_acc), 0, (2 * 4288 + 2 * 64 * 10) * sizeof(double), st));
+    // Stream schedule (kernel timeline of one step, tools/timeline.py): the dgrad chain is the critical path.
+    //   main: glu2_bwd  prep | dgrad2            | glu1_bwd  prep | dgrad1          | blk0_bwd  finalize |
+    //   side:                | wgrad2  GRU dW/db |                | wgrad1  reduce                       | join
+    // (Starting wgrad1 only after dgrad1, next to the VALU-bound k_blk0_bwd, measured the same: dgrad1 drops from
+    // 175 to 93 us but k_blk0_bwd, left with one wave per SIMD beside the wgrad wave, goes from 86 to 177 us.)
     for (int i = 2; i >= 1; --i) {
         SED_TRY(launch_glu_pool_bwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], WSF(dpo[i]),
                                     WSF(dzo[i]), WSD(gacc[i]), 0, g.B, Hs[i], Wd[i], i, use_drop, g.p, CTXM(mo[i]), st));
         SED_TRY(launch_bn_bwd_prep(WSD(gacc[i]), (double)g.B * Hs[i] * Wd[i], params + P.bn_g[i], CTXF(bo[i]), WSF(W.coef[i]),
                                    grads + P.bn_g[i], grads + P.bn_b[i], grads + P.glu_w[i], grads + P.glu_b[i],
                                    grads + P.conv_b[i], st));
-        if (sd.ok) { SIDE_FORK(st); forked = true; }
-        SED_TRY(launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(pin[i]), WSF(W.wg_part), W.wgrad_blocks,
-                                  grads + P.conv_w[i], g.B, Hs[i], Wd[i], ss));      // side stream
-        SED_TRY(launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], st));
+        if (i == 2) {
+            if (sd.ok) { SIDE_FORK(st); forked = true; }
+            SED_TRY(launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(pin[i]), WSF(W.wg_part), W.wgrad_blocks,
+                                      grads + P.conv_w[i], g.B, Hs[i], Wd[i], ss));
+            if (parts == 3) SED_TRY(gru_weight_grads(ss));
+            SED_TRY(launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], st));
+        } else {
+            const bool after = (g_sed_debug & 16) != 0;          // experiment: wgrad1 after dgrad1 (next to k_blk0_bwd)
+            if (!after && sd.ok) { SIDE_FORK(st); forked = true; }
+            SED_TRY(launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], st));
+            if (after && sd.ok) { SIDE_FORK(st); forked = true; }
+            SED_TRY(launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(pin[i]), WSF(W.wg_part), W.wgrad_blocks,
+                                      grads + P.conv_w[i], g.B, Hs[i], Wd[i], ss));
+        }
     }
     // ---- conv block 0 ---------------------------------------------------------------------------
     SED_TRY(launch_blk0_backward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],

@@ -149,9 +149,10 @@ class MeanTeacherStep:
                                       self.wlo, self.whi, self.slo, self.shi, _lib.ptr(self.state),
                                       _lib.ptr(self.losses), _lib.ptr(self.d_strong), _lib.ptr(self.d_weak),
                                       _lib.stream_ptr()), "sed_mt_loss")
-        self._backward(1)
-        if self.world == 1:
-            self._backward(2)
+        # one process: the whole backward in ONE call (parts = 3), which lets the library overlap the GRU weight
+        # gradients with the conv-block backward; data-parallel: part 1 here, part 2 after its bucket's all-reduce
+        # has been started (run())
+        self._backward(3 if self.world == 1 else 1)
 
     def _backward(self, parts):
         _lib.check(self.l.sed_crnn_backward(C.byref(self.dims), _lib.ptr(self.student._flat), _lib.ptr(self.x),

@@ -1,6 +1,6 @@
 """Phase timestamps of an instrumented kernel (library built with `make EXTRA=-DSED_TS`): replays one kernel and
 prints, per stamp index, the mean / max offset from the earliest stamp 0 over all workgroups.
-Usage (GPU box): python tools/ts_kernel.py glu1_bwd"""
+Usage (GPU box): python tools/ts_kernel.py glu1_bwd [bnglu|conv|...]   (second argument: the translation unit)"""
 import ctypes as C
 import os
 import sys
@@ -16,6 +16,7 @@ from dcase2019_task4_amd.train import MeanTeacherStep  # noqa: E402
 
 def main():
     name = sys.argv[1]
+    tag = sys.argv[2] if len(sys.argv) > 2 else "bnglu"
     dev = torch.device("cuda", 0)
     student, teacher = bench.build_models(dev, 0)
     x, xe, tgt, wm, sm = bench.synthetic_batch(bench.B_PER_GPU, bench.T_FRAMES, 1000, dev)
@@ -33,7 +34,7 @@ def main():
         torch.cuda.synchronize()
     n = 1024 * 16
     buf = (C.c_ulonglong * n)()
-    fn = l.sed_debug_ts
+    fn = getattr(l, "sed_debug_ts_" + tag)
     fn.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
     fn.restype = C.c_int
     assert fn(buf, n) == 0
@@ -44,7 +45,8 @@ def main():
     print(f"{live.sum()} workgroups; offsets in us from the first workgroup's start (100 MHz clock)")
     if (ts[:, 15] > 0).all():
         cyc = (ts[:, 15] - ts[:, 14]).astype(float)
-        us = (ts[:, 10] - ts[:, 0]) / 100.0
+        last = max(k for k in range(14) if (ts[:, k] > 0).all())
+        us = (ts[:, last] - ts[:, 0]) / 100.0
         print(f"  shader clock (clock64 delta / wall delta): {np.mean(cyc / us):.1f} counts/us")
     for k in range(14):
         col = ts[:, k]

@@ -15,26 +15,51 @@
 #define HD_TC 128     // frames per chunk (one chunk covers T/8 <= 128, i.e. clips up to 1024 frames)
 #define HD_THREADS 1024
 #define HD_F 128      // 2 * hidden
-#define HD_FS 129     // padded row stride
 #define HD_MAXO 32    // 2 * max nclass
+// The first version did the three small matrix products with scalar FMAs fed from LDS (2 ds_reads per FMA):
+// 2-4 MB of LDS traffic per workgroup, 25 us forward / 37 us backward for 0.4 MFLOP per clip, all of it on the
+// critical path of the step.  Now they are v_mfma_f32_16x16x4_f32 tiles (one or a few per wave); row strides are
+// chosen per use so that the fragment reads are bank-conflict free: a fragment indexed (row = lane & 15,
+// col = 4s + (lane >> 4)) wants stride = 4 (mod 64), one indexed (row = 4s + (lane >> 4), col = lane & 15) wants
+// stride = 16 (mod 64).
+#define HD_SF 132     // forward: x and W rows (both read as (row = lane & 15, col = k))
+#define HD_SB 144     // backward: x and W rows (both read as (row = k, col = lane & 15))
+#define HD_SD 33      // backward: dl rows (read both ways; small residual conflicts)
 
-__device__ __forceinline__ float rnn_drop(float v, int use_drop, size_t e, uint64_t seed, uint32_t thr, float ks) {
-    if (!use_drop) return v;
-    const u32x4 o = philox_stream((uint32_t)(e >> 4), 8u, seed);
-    return (philox_byte(o, (int)(e & 15)) >= thr) ? v * ks : 0.f;
-}
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-// loads a chunk of frames (dropout applied) and both weight matrices into LDS
-__device__ __forceinline__ void heads_stage(const float* __restrict__ h, float* xs, int b, int T, int t0, int use_drop,
-                                            uint64_t seed, uint32_t thr, float ks, int tid) {
-    for (int e = tid; e < HD_TC * HD_F; e += HD_THREADS) {
-        const int tl = e >> 7, f = e & 127, t = t0 + tl;
-        float v = 0.f;
-        if (t < T) {
-            const size_t ge = (size_t)(b * T + t) * HD_F + f;
-            v = rnn_drop(h[ge], use_drop, ge, seed, thr, ks);
+// Stages one chunk of <= 128 frames of the GRU output with the recurrent-output dropout applied (CRNN.py:74):
+// each thread owns 16 consecutive features of one frame = ONE Philox draw (flat stream 8: index = element >> 4,
+// byte = element & 15).  Returns the 16 keep bits (all ones without dropout, 0 for frames past T).
+template <int STRIDE>
+__device__ __forceinline__ uint32_t heads_stage(const float* __restrict__ h, float* xs, int b, int T, int t0, int use_drop,
+                                                uint64_t seed, uint32_t thr, float ks, int tid) {
+    const int tl = tid >> 3, f0 = (tid & 7) * 16, t = t0 + tl;
+    float v[16];
+    uint32_t keep = 0;
+    if (t < T) {
+        const size_t ge = (size_t)(b * T + t) * HD_F + f0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 u = *(const float4*)(h + ge + 4 * q);
+            v[4 * q] = u.x; v[4 * q + 1] = u.y; v[4 * q + 2] = u.z; v[4 * q + 3] = u.w;
         }
-        xs[tl * HD_FS + f] = v;
+        keep = 0xffffu;
+        if (use_drop) keep = philox_keep16(philox_stream((uint32_t)(ge >> 4), 8u, seed), thr);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xs[tl * STRIDE + f0 + i] = ((keep >> i) & 1u) ? v[i] * ks : 0.f;
+    return keep;
+}
+// both weight matrices as rows [0, NC) = dense, [NC, 2NC) = dense_softmax, zero rows up to HD_MAXO
+template <int STRIDE>
+__device__ __forceinline__ void heads_stage_w(const float* __restrict__ wd, const float* __restrict__ ws, float* wsm, int NC, int tid) {
+    for (int e = tid; e < HD_MAXO * HD_F; e += HD_THREADS) {
+        const int o = e >> 7, f = e & 127;
+        wsm[o * STRIDE + f] = (o < NC) ? wd[o * HD_F + f] : (o < 2 * NC ? ws[(o - NC) * HD_F + f] : 0.f);
     }
 }
 
@@ -46,35 +71,37 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_fwd(const float* __restric
                                                     float* __restrict__ den_out, int T, int NC, int use_drop, float p_drop,
                                                     const uint64_t* __restrict__ seed_ptr) {
     extern __shared__ __attribute__((aligned(16))) float hsm[];
-    float* xs = hsm;                                   // [HD_TC][HD_FS]
-    float* wsm = xs + HD_TC * HD_FS;                   // [HD_MAXO][HD_FS]
-    float* lg = wsm + HD_MAXO * HD_FS;                 // [HD_TC][HD_MAXO]
+    float* xs = hsm;                                   // [HD_TC][HD_SF]
+    float* wsm = xs + HD_TC * HD_SF;                   // [HD_MAXO][HD_SF]
+    float* lg = wsm + HD_MAXO * HD_SF;                 // [HD_TC][HD_MAXO]
     float (*nums)[16] = (float (*)[16])(lg + HD_TC * HD_MAXO);
     float (*dens)[16] = (float (*)[16])(lg + HD_TC * HD_MAXO + HD_TC * 16);
     float* num_acc = lg + HD_TC * HD_MAXO + 2 * HD_TC * 16;
     float* den_acc = num_acc + 16;
-    const int tid = threadIdx.x, b = blockIdx.x;
+    const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint64_t seed = use_drop ? seed_ptr[0] : 0ull;
     const uint32_t thr = drop_thresh8(p_drop);
     const float ks = use_drop ? drop_scale8(p_drop) : 1.0f;
-    const int NO = 2 * NC;
-    for (int e = tid; e < NO * HD_F; e += HD_THREADS) {
-        const int o = e >> 7, f = e & 127;
-        wsm[o * HD_FS + f] = (o < NC) ? wd[o * HD_F + f] : ws[(o - NC) * HD_F + f];
-    }
+    heads_stage_w<HD_SF>(wd, ws, wsm, NC, tid);
     if (tid < 16) { num_acc[tid] = 0.f; den_acc[tid] = 0.f; }
     for (int t0 = 0; t0 < T; t0 += HD_TC) {
         __syncthreads();
-        heads_stage(h, xs, b, T, t0, use_drop, seed, thr, ks, tid);
+        heads_stage<HD_SF>(h, xs, b, T, t0, use_drop, seed, thr, ks, tid);
         __syncthreads();
-        for (int e = tid; e < HD_TC * NO; e += HD_THREADS) {
-            const int tl = e / NO, o = e % NO;
-            float a = (o < NC) ? bd[o] : bs[o - NC];
-            const float* xr = xs + tl * HD_FS;
-            const float* wr = wsm + o * HD_FS;
-#pragma unroll 8
-            for (int f = 0; f < HD_F; ++f) a = fmaf(xr[f], wr[f], a);
-            lg[tl * HD_MAXO + o] = a;
+        {   // logits[t][o] = x[t][:] . W[o][:] + bias: 8 x 2 tiles of 16 x 16, one per wave, K = 128
+            const int rt = wv >> 1, ct = wv & 1, i = lane & 15, kq = lane >> 4;
+            const float* A = xs + (16 * rt + i) * HD_SF + kq;
+            const float* Bp = wsm + (16 * ct + i) * HD_SF + kq;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < 32; s4 += 2) {
+                acc0 = mfma16(A[4 * s4], Bp[4 * s4], acc0);
+                acc1 = mfma16(A[4 * s4 + 4], Bp[4 * s4 + 4], acc1);
+            }
+            const int o = 16 * ct + i;
+            const float bias = (o < NC) ? bd[o] : (o < 2 * NC ? bs[o - NC] : 0.f);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lg[(16 * rt + 4 * kq + r) * HD_MAXO + o] = acc0[r] + acc1[r] + bias;
         }
         __syncthreads();
         if (tid < HD_TC) {
@@ -101,10 +128,10 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_fwd(const float* __restric
             }
         }
         __syncthreads();
-        if (tid < NC) {
-            float a = 0.f, d2 = 0.f;
-            for (int tl = 0; tl < HD_TC; ++tl) { a += nums[tl][tid]; d2 += dens[tl][tid]; }
-            num_acc[tid] += a; den_acc[tid] += d2;
+        if (wv < NC) {          // wave c sums class c over the chunk's frames
+            float a = nums[lane][wv] + nums[lane + 64][wv], d2 = dens[lane][wv] + dens[lane + 64][wv];
+            a = wave_sum(a); d2 = wave_sum(d2);
+            if (lane == 0) { num_acc[wv] += a; den_acc[wv] += d2; }
         }
     }
     __syncthreads();
@@ -126,33 +153,30 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_bwd(const float* __restric
                                                     float* __restrict__ part, int T, int NC, int use_drop, float p_drop,
                                                     const uint64_t* __restrict__ seed_ptr) {
     extern __shared__ __attribute__((aligned(16))) float hsm[];
-    float* xs = hsm;                                   // [HD_TC][HD_FS]
-    float* wsm = xs + HD_TC * HD_FS;                   // [HD_MAXO][HD_FS]
-    float* dl = wsm + HD_MAXO * HD_FS;                 // [HD_TC][HD_MAXO]
-    float* dnum = dl + HD_TC * HD_MAXO;
+    float* xs = hsm;                                   // [HD_TC][HD_SB]
+    float* wsm = xs + HD_TC * HD_SB;                   // [HD_MAXO][HD_SB]
+    float* dl = wsm + HD_MAXO * HD_SB;                 // [HD_TC][HD_SD]
+    float* dnum = dl + HD_TC * HD_SD;
     float* dden = dnum + 16;
-    const int tid = threadIdx.x, b = blockIdx.x;
+    uint32_t* mk = (uint32_t*)(dden + 16);             // [HD_TC][8] keep bits of the staged chunk
+    const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
     const uint64_t seed = use_drop ? seed_ptr[0] : 0ull;
     const uint32_t thr = drop_thresh8(p_drop);
     const float ks = use_drop ? drop_scale8(p_drop) : 1.0f;
     const int NO = 2 * NC;
-    for (int e = tid; e < NO * HD_F; e += HD_THREADS) {
-        const int o = e >> 7, f = e & 127;
-        wsm[o * HD_FS + f] = (o < NC) ? wd[o * HD_F + f] : ws[(o - NC) * HD_F + f];
-    }
+    heads_stage_w<HD_SB>(wd, ws, wsm, NC, tid);
     if (tid < NC) {
         const float dw = d_weak[b * NC + tid], dn = den[b * NC + tid];
         dnum[tid] = dw / dn;
         dden[tid] = -dw * weak[b * NC + tid] / dn;
     }
-    // weight-gradient accumulators: outputs e = tid + 256*i over [NO][128]
-    float wacc[(HD_MAXO * HD_F) / HD_THREADS];
-#pragma unroll
-    for (int i = 0; i < (HD_MAXO * HD_F) / HD_THREADS; ++i) wacc[i] = 0.f;
+    // dW[o][f] accumulates over chunks in the MFMA accumulator of the wave that owns the (o, f) tile
+    f32x4 wacc = {0.f, 0.f, 0.f, 0.f};
     float bacc = 0.f;    // thread o < NO
     for (int t0 = 0; t0 < T; t0 += HD_TC) {
         __syncthreads();
-        heads_stage(h, xs, b, T, t0, use_drop, seed, thr, ks, tid);
+        mk[tid] = heads_stage<HD_SB>(h, xs, b, T, t0, use_drop, seed, thr, ks, tid);
         if (tid < HD_TC) {
             const int t = t0 + tid;
             if (t < T) {
@@ -172,46 +196,56 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_bwd(const float* __restric
                     sraw[c] = raw; dsof[c] = ds;
                     dot += raw * ds;
                     const float dst = d_strong[(size_t)(b * T + t) * NC + c] + dnum[c] * sof;
-                    dl[tid * HD_MAXO + c] = dst * sv * (1.0f - sv);
+                    dl[tid * HD_SD + c] = dst * sv * (1.0f - sv);
                 }
-                for (int c = 0; c < NC; ++c) dl[tid * HD_MAXO + NC + c] = sraw[c] * (dsof[c] - dot);
+                for (int c = 0; c < NC; ++c) dl[tid * HD_SD + NC + c] = sraw[c] * (dsof[c] - dot);
+                for (int o = NO; o < HD_MAXO; ++o) dl[tid * HD_SD + o] = 0.f;
             } else {
-                for (int o = 0; o < NO; ++o) dl[tid * HD_MAXO + o] = 0.f;
+                for (int o = 0; o < HD_MAXO; ++o) dl[tid * HD_SD + o] = 0.f;
             }
         }
         __syncthreads();
-        // dW[o][f] += sum_t dl[t][o] * x[t][f]
-#pragma unroll
-        for (int i = 0; i < (HD_MAXO * HD_F) / HD_THREADS; ++i) {
-            const int e = tid + HD_THREADS * i, o = e >> 7, f = e & 127;
-            if (o < NO) {
-                float a = 0.f;
-                for (int tl = 0; tl < HD_TC; ++tl) a = fmaf(dl[tl * HD_MAXO + o], xs[tl * HD_FS + f], a);
-                wacc[i] += a;
-            }
+        {   // dW[o][f] += sum_t dl[t][o] x[t][f]: 2 x 8 tiles, one per wave, K = 128 frames
+            const int ot = wv >> 3, ft = wv & 7;
+            const float* A = dl + kq * HD_SD + 16 * ot + i16;          // A[i = o][k = t]
+            const float* Bp = xs + kq * HD_SB + 16 * ft + i16;         // B[k = t][j = f]
+#pragma unroll 8
+            for (int s4 = 0; s4 < 32; ++s4) wacc = mfma16(A[4 * s4 * HD_SD], Bp[4 * s4 * HD_SB], wacc);
         }
         if (tid < NO) {
             float a = 0.f;
-            for (int tl = 0; tl < HD_TC; ++tl) a += dl[tl * HD_MAXO + tid];
+            for (int tl = 0; tl < HD_TC; ++tl) a += dl[tl * HD_SD + tid];
             bacc += a;
         }
-        // dx[t][f] = (sum_o dl[t][o] W[o][f]) * mask
-        for (int e = tid; e < HD_TC * HD_F; e += HD_THREADS) {
-            const int tl = e >> 7, f = e & 127, t = t0 + tl;
-            if (t < T) {
-                float a = 0.f;
-                for (int o = 0; o < NO; ++o) a = fmaf(dl[tl * HD_MAXO + o], wsm[o * HD_FS + f], a);
-                const size_t ge = (size_t)(b * T + t) * HD_F + f;
-                dh[ge] = rnn_drop(a, use_drop, ge, seed, thr, ks);
+        // dx[t][f] = (sum_o dl[t][o] W[o][f]) * mask: 8 x 8 tiles, four per wave, K = 32
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int tile = wv * 4 + q, tt = tile >> 3, ft = tile & 7;
+            const float* A = dl + (16 * tt + i16) * HD_SD + kq;        // A[i = t][k = o]
+            const float* Bp = wsm + kq * HD_SB + 16 * ft + i16;        // B[k = o][j = f]
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < 8; ++s4) acc = mfma16(A[4 * s4], Bp[4 * s4 * HD_SB], acc);
+            const int f = 16 * ft + i16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tl = 16 * tt + 4 * kq + r, t = t0 + tl;
+                if (t < T) {
+                    const uint32_t keep = (mk[tl * 8 + (f >> 4)] >> (f & 15)) & 1u;
+                    dh[(size_t)(b * T + t) * HD_F + f] = keep ? acc[r] * ks : 0.f;
+                }
             }
         }
     }
     float* pr = part + (size_t)b * (2 * (NC * HD_F + NC));
+    {
+        const int ot = wv >> 3, ft = wv & 7, f = 16 * ft + i16;
 #pragma unroll
-    for (int i = 0; i < (HD_MAXO * HD_F) / HD_THREADS; ++i) {
-        const int e = tid + HD_THREADS * i, o = e >> 7, f = e & 127;
-        if (o < NC) pr[o * HD_F + f] = wacc[i];
-        else if (o < NO) pr[NC * HD_F + NC + (o - NC) * HD_F + f] = wacc[i];
+        for (int r = 0; r < 4; ++r) {
+            const int o = 16 * ot + 4 * kq + r;
+            if (o < NC) pr[o * HD_F + f] = wacc[r];
+            else if (o < NO) pr[NC * HD_F + NC + (o - NC) * HD_F + f] = wacc[r];
+        }
     }
     if (tid < NC) pr[NC * HD_F + tid] = bacc;
     else if (tid < NO) pr[2 * NC * HD_F + NC + (tid - NC)] = bacc;
@@ -300,7 +334,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_mt_loss(const float* __restric
 int launch_heads_fwd(const float* h, const float* wd, const float* bd, const float* ws, const float* bs, float* strong,
                      float* weak, float* strong_sv, float* weak_sv, float* logits_s, float* den, int B, int T, int NC,
                      int use_drop, float p_drop, const uint64_t* seed, hipStream_t st) {
-    const size_t lds = (size_t)(HD_TC * HD_FS + HD_MAXO * HD_FS + HD_TC * HD_MAXO + 2 * HD_TC * 16 + 32) * sizeof(float);
+    const size_t lds = (size_t)(HD_TC * HD_SF + HD_MAXO * HD_SF + HD_TC * HD_MAXO + 2 * HD_TC * 16 + 32) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_heads_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -317,7 +351,7 @@ int launch_heads_bwd(const float* h, const float* wd, const float* ws, const flo
                      float* part, float* g_wd, float* g_bd, float* g_ws, float* g_bs, int B, int T, int NC, int use_drop,
                      float p_drop, const uint64_t* seed, hipStream_t st) {
     (void)g_bd; (void)g_ws; (void)g_bs;
-    const size_t lds = (size_t)(HD_TC * HD_FS + HD_MAXO * HD_FS + HD_TC * HD_MAXO + 32) * sizeof(float);
+    const size_t lds = (size_t)(HD_TC * HD_SB + HD_MAXO * HD_SB + HD_TC * HD_SD + 32 + HD_THREADS) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_heads_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

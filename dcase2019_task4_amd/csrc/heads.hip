@@ -259,6 +259,11 @@ __device__ __forceinline__ float bce_term(float p, float t) {
 __device__ __forceinline__ float bce_grad(float p, float t) { return (p - t) / fmaxf((1.0f - p) * p, 1e-12f); }
 
 #define LOSS_THREADS 1024
+// One workgroup per clip (the single-workgroup version walked 19 elements per thread, one exposed memory round
+// trip each: 20 us on the critical path between the forward and the backward).  Every workgroup writes its six
+// partial sums to the scratch part of `losses`; the LAST one to finish (device-scope ticket) adds them up in clip
+// order - the meters stay bit-reproducible - and re-arms the ticket for the next launch.
+// losses layout: [0,8) meters | [8, 8+8B) per-clip partials | [8+8B] ticket (uint32, zero before first use)
 __global__ __launch_bounds__(LOSS_THREADS) void k_mt_loss(const float* __restrict__ strong, const float* __restrict__ weak,
                                                   const float* __restrict__ strong_ema, const float* __restrict__ weak_ema,
                                                   const float* __restrict__ target, int B, int T, int NC, int wlo, int whi,
@@ -266,44 +271,44 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_mt_loss(const float* __restric
                                                   float* __restrict__ losses, float* __restrict__ d_strong,
                                                   float* __restrict__ d_weak) {
     __shared__ float red[LOSS_THREADS / 64][8];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ float tmax[16];
+    __shared__ int is_last;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
     const float cw = state->cons_weight;
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // weak_bce, strong_bce, mse_strong, mse_weak, weak_ema_bce, strong_ema_bce
-    const int nS = B * T * NC, nW = B * NC;
-    const float inv_nS = 1.0f / (float)nS, inv_nW = 1.0f / (float)nW;
+    const float inv_nS = 1.0f / (float)(B * T * NC), inv_nW = 1.0f / (float)(B * NC);
     const float inv_sb = (shi > slo) ? 1.0f / (float)((shi - slo) * T * NC) : 0.f;
     const float inv_wb = (whi > wlo) ? 1.0f / (float)((whi - wlo) * NC) : 0.f;
-    for (int e = tid; e < nS; e += LOSS_THREADS) {
-        const int b = e / (T * NC);
-        const float p = strong[e], pe = strong_ema[e];
+    const bool in_s = (b >= slo && b < shi), in_w = (b >= wlo && b < whi);
+    const size_t base = (size_t)b * T * NC;
+    if (in_w && wv < NC) {        // target_weak = target.max(-2) (main.py:95): wave c takes class c
+        float t = -3.0e38f;
+        for (int tt = lane; tt < T; tt += 64) t = fmaxf(t, target[base + (size_t)tt * NC + wv]);
+        t = wave_max(t);
+        if (lane == 0) tmax[wv] = t;
+    }
+    for (int e = tid; e < T * NC; e += LOSS_THREADS) {
+        const float p = strong[base + e], pe = strong_ema[base + e];
         const float diff = p - pe;
         acc[2] += diff * diff;
         float g = cw * 2.0f * diff * inv_nS;
-        if (b >= slo && b < shi) {
-            const float t = target[e];
+        if (in_s) {
+            const float t = target[base + e];
             acc[1] += bce_term(p, t);
             acc[5] += bce_term(pe, t);
             g += bce_grad(p, t) * inv_sb;
         }
-        d_strong[e] = g;
+        d_strong[base + e] = g;
     }
-    for (int e = tid; e < nW; e += LOSS_THREADS) {
-        const int b = e / NC, c = e % NC;
+    __syncthreads();
+    if (tid < NC) {
+        const int e = b * NC + tid;
         const float p = weak[e], pe = weak_ema[e];
         const float diff = p - pe;
         acc[3] += diff * diff;
         float g = cw * 2.0f * diff * inv_nW;
-        if (b >= wlo && b < whi) {
-            float t = -3.0e38f;       // target_weak = target.max(-2)  (main.py:95)
-            int tt = 0;
-            for (; tt + 16 <= T; tt += 16) {        // 16 independent loads in flight (a rolled loop waits per load)
-                float v[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = target[(size_t)(b * T + tt + i) * NC + c];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) t = fmaxf(t, v[i]);
-            }
-            for (; tt < T; ++tt) t = fmaxf(t, target[(size_t)(b * T + tt) * NC + c]);
+        if (in_w) {
+            const float t = tmax[tid];
             acc[0] += bce_term(p, t);
             acc[4] += bce_term(pe, t);
             g += bce_grad(p, t) * inv_wb;
@@ -316,17 +321,33 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_mt_loss(const float* __restric
         if (lane == 0) red[wv][k] = v;
     }
     __syncthreads();
+    float* part = losses + 8;
+    unsigned int* ticket = (unsigned int*)(losses + 8 + 8 * B);
+    if (tid < 6) {
+        float s2 = 0.f;
+        for (int w2 = 0; w2 < LOSS_THREADS / 64; ++w2) s2 += red[w2][tid];
+        part[8 * b + tid] = s2;
+        __threadfence();
+    }
+    __syncthreads();
+    if (tid == 0) is_last = (atomicAdd(ticket, 1u) == (unsigned int)(B - 1));
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    if (tid < 6) {
+        float s2 = 0.f;
+        for (int bb = 0; bb < B; ++bb) s2 += __builtin_nontemporal_load(&part[8 * bb + tid]);
+        red[0][tid] = s2;
+    }
+    __syncthreads();
     if (tid == 0) {
-        float s[6];
-        for (int k = 0; k < 6; ++k) {
-            s[k] = 0.f;
-            for (int w2 = 0; w2 < LOSS_THREADS / 64; ++w2) s[k] += red[w2][k];
-        }
-        const float wb = s[0] * inv_wb, sb = s[1] * inv_sb;
-        const float cs = cw * s[2] * inv_nS, cwk = cw * s[3] * inv_nW;
+        const float* s6 = red[0];
+        const float wb = s6[0] * inv_wb, sb = s6[1] * inv_sb;
+        const float cs = cw * s6[2] * inv_nS, cwk = cw * s6[3] * inv_nW;
         losses[0] = wb + sb + cs + cwk;
         losses[1] = wb; losses[2] = sb; losses[3] = cs; losses[4] = cwk;
-        losses[5] = s[4] * inv_wb; losses[6] = s[5] * inv_sb; losses[7] = cw;
+        losses[5] = s6[4] * inv_wb; losses[6] = s6[5] * inv_sb; losses[7] = cw;
+        *ticket = 0u;
     }
 }
 
@@ -374,7 +395,7 @@ extern "C" int sed_mt_loss(const sed_dims* d, const float* strong, const float* 
     const Geo g = make_geo(d);
     SED_CHECK_ARG(weak_lo >= 0 && weak_hi <= g.B && weak_lo <= weak_hi && strong_lo >= 0 && strong_hi <= g.B &&
                       strong_lo <= strong_hi, "sed_mt_loss: bad mask range");
-    k_mt_loss<<<1, LOSS_THREADS, 0, (hipStream_t)stream>>>(strong, weak, strong_ema, weak_ema, target, g.B, g.T3, g.NC, weak_lo,
+    k_mt_loss<<<g.B, LOSS_THREADS, 0, (hipStream_t)stream>>>(strong, weak, strong_ema, weak_ema, target, g.B, g.T3, g.NC, weak_lo,
                                                   weak_hi, strong_lo, strong_hi, state_dev, losses, d_strong, d_weak);
     SED_CHECK_LAUNCH();
     return SED_OK;

@@ -104,7 +104,7 @@ class MeanTeacherStep:
         self.weak_ema = torch.empty(self.B, self.NC, **f32) if teacher is not None else self.weak
         self.d_strong = torch.empty(self.B, self.T3, self.NC, **f32)
         self.d_weak = torch.empty(self.B, self.NC, **f32)
-        self.losses = torch.zeros(8, **f32)
+        self.losses = torch.zeros(8 + 8 * self.B + 8, **f32)          # SED_LOSS_FLOATS(B): meters | scratch
         self.pg = process_group
         self.world = 1
         if process_group is not None:
@@ -236,7 +236,7 @@ class MeanTeacherStep:
 
     def meters(self):
         """The meters main.train logs (main.py:106-149); ONE device->host copy."""
-        return dict(zip(LOSS_NAMES, self.losses.tolist()))
+        return dict(zip(LOSS_NAMES, self.losses[:8].tolist()))
 
     def read_state(self):
         raw = bytes(self.state.cpu().numpy().tobytes())

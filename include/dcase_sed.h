@@ -124,8 +124,11 @@ int sed_crnn_ctx_view(const sed_dims* d, const char* name, size_t* offset, size_
  * w = state->cons_weight, and its gradient w.r.t. the student outputs.
  *   masks are the reference's Python slices (main.py:241,247) as [lo, hi) row ranges; lo==hi
  *   disables the term (weak_mask / strong_mask = None).
- *   losses[8] = {loss, weak_bce, strong_bce, cons_strong, cons_weak, weak_ema_bce,
- *                strong_ema_bce, cons_weight}  (the meters of main.py:106-149)                */
+ *   losses: float[SED_LOSS_FLOATS(B)], ZERO-INITIALISED by the caller once (not per call):
+ *     [0,8) = {loss, weak_bce, strong_bce, cons_strong, cons_weak, weak_ema_bce, strong_ema_bce,
+ *              cons_weight}  (the meters of main.py:106-149);
+ *     the rest is scratch (per-clip partial sums + the ticket of the last-workgroup reduction). */
+#define SED_LOSS_FLOATS(B) (8 + 8 * (B) + 8)
 int sed_mt_loss(const sed_dims* d, const float* strong, const float* weak, const float* strong_ema,
                 const float* weak_ema, const float* target, int weak_lo, int weak_hi, int strong_lo,
                 int strong_hi, const sed_step_state* state_dev, float* losses, float* d_strong,

@@ -17,13 +17,15 @@
 
 #define GT_M 64
 #define GT_N 64
-#define GT_K 32
+#define GT_K 64    // these GEMMs are latency-bound (K = 64..384 per workgroup): 8 float4 loads in flight per thread and
+                   // 1-6 trips through the load -> LDS -> MFMA chain (a 128-deep tile needed 256 VGPRs and measured slower)
 
 __device__ __forceinline__ int prob_nx(const GemmProb& p) { return p.N + (p.Cones ? 1 : 0); }
 
 __global__ __launch_bounds__(256) void k_gemm_batched(GemmBatch gb) {
-    __shared__ float As[GT_M * (GT_K + 1)];
-    __shared__ float Bs[GT_K * (GT_N + 1)];
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    float* As = gsm;                                   // [GT_M][GT_K + 1]
+    float* Bs = gsm + GT_M * (GT_K + 1);               // [GT_K][GT_N + 1]
     const int pi = blockIdx.z / gb.splits, split = blockIdx.z % gb.splits;
     const GemmProb& d = gb.p[pi];
     const int Nx = prob_nx(d);
@@ -207,7 +209,13 @@ int launch_gemm_batch(GemmBatch& gb, hipStream_t st) {
         gb.part_stride = (size_t)maxM * maxNx;
     }
     dim3 grid((maxNx + GT_N - 1) / GT_N, (maxM + GT_M - 1) / GT_M, gb.n_prob * gb.splits);
-    k_gemm_batched<<<grid, 256, 0, st>>>(gb);
+    const size_t lds = (size_t)(GT_M * (GT_K + 1) + GT_K * (GT_N + 1)) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_batched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    k_gemm_batched<<<grid, 256, lds, st>>>(gb);
     SED_CHECK_LAUNCH();
     if (gb.splits > 1) {
         dim3 g2((maxM * maxNx + 255) / 256, gb.n_prob);

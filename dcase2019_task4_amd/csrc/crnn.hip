@@ -409,6 +409,14 @@ extern "C" int sed_kernel_replay(const char* name, const sed_dims* d, const floa
     const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};
     auto is = [&](const char* n) { return strcmp(name, n) == 0; };
     if (is("x_moments")) return launch_x_moments(g, x, CTXD(L.mompart), st);
+    if (is("gru_dx_gemm")) {          // dX = [dgi_fwd | dgi_rev] @ [W_ih_fwd ; W_ih_rev] of the last GRU layer
+        const int l = g.L - 1, nin = (l == 0) ? 64 : 128;
+        GemmBatch gb;
+        gb.n_prob = 1; gb.splits = 1; gb.part = nullptr; gb.part_stride = 0;
+        gb.p[0] = gemm_prob(WSF(W.dgi[l]), 384, 1, params + P.w_ih[l][0], nin, 1, WSF(W.d_in), nin, BT, nin, 384);
+        gb.p[0].B2 = params + P.w_ih[l][1]; gb.p[0].k2 = 192;
+        return launch_gemm_batch(gb, st);
+    }
     if (is("blk0_fwd")) {
         const int tpc = (g.H1 + 3) / 4;
         (void)tpc;

@@ -14,6 +14,7 @@
 //   (B2 from row k2 on) so dX = [dgi_fwd | dgi_rev] @ [W_ih_fwd ; W_ih_rev] is one launch.
 #include "common.h"
 #include "kernels.h"
+SED_TS_DEFINE(gemm)
 
 #define GT_M 64
 #define GT_N 64
@@ -151,6 +152,119 @@ __global__ __launch_bounds__(256) void k_gemm_batched(GemmBatch gb) {
     }
 }
 
+// ---- whole-K-resident variant for the GEMMs on the step's critical path ---------------------------------------
+// x @ W_ih^T + b (K = 64 / 128) in front of each GRU layer and dX = dgi @ W_ih (K = 384) behind it: 0.2 GFLOP each,
+// but the tiled kernel above took 15-25 us - six trips through load -> LDS -> MFMA, each paying a full memory round
+// trip with 60 workgroups on the chip.  Here a workgroup owns a 32 x 64 output tile and fetches its ENTIRE K extent
+// up front (up to 36 float4 per thread in flight, one round trip), then the four waves split the tile in two column
+// halves x two K halves and combine through LDS.  LDS: 32 x (K+1) + K x 65 floats (146 KB at K = 384).
+#define GP_M 32
+#define GP_N 64
+#define GP_KMAX 384
+__global__ __launch_bounds__(256) void k_gemm_panel(GemmBatch gb) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    const GemmProb& d = gb.p[blockIdx.z];
+    const int m0 = blockIdx.y * GP_M, n0 = blockIdx.x * GP_N;
+    if (m0 >= d.M || n0 >= d.N) return;
+    const int K = d.K, SA = K + 1;
+    float* As = gsm;                    // [GP_M][SA]
+    float* Bs = gsm + GP_M * SA;        // [K][GP_N + 1]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 31, kh = lane >> 5;
+    const bool a_kc = (d.sAk == 1), b_nc = (d.sBn == 1);
+    constexpr int NGA = GP_M * GP_KMAX / 4 / 256, NGB = GP_KMAX * GP_N / 4 / 256;     // 12, 24
+    const int nga = GP_M * K / 4 / 256, ngb = K * GP_N / 4 / 256;                       // K is a multiple of 32
+    f32x4 ra[NGA], rb[NGB];
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    TS(0); TSC(14);
+    // Straight-line loads, no per-group checks: the launcher only picks this kernel when every group is one aligned
+    // float4 (16-byte aligned bases, unit stride along the contiguous axis, other strides multiples of 4, N a multiple
+    // of 64); rows past M are clamped to the last row (loaded twice, never stored).  With per-group range/alignment
+    // branches the compiler put an s_waitcnt vmcnt(0) behind every load: 36 serialized round trips, 10 us.
+#pragma unroll
+    for (int it = 0; it < NGA; ++it) {
+        ra[it] = z4;
+        if (it < nga) {
+            // 8 threads per A row (k-contiguous) / per k (m-contiguous), 4 elements each
+            int m = m0 + (a_kc ? (tid >> 3) : (tid & 7) * 4);
+            const int k = a_kc ? ((tid & 7) + 8 * it) * 4 : (tid >> 3) + 32 * it;
+            if (a_kc) m = min(m, d.M - 1); else m = min(m, d.M - 4);
+            ra[it] = *(const f32x4*)(d.A + (int64_t)m * d.sAm + (int64_t)k * d.sAk);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NGB; ++it) {
+        rb[it] = z4;
+        if (it < ngb) {
+            // 16 threads per k row (n-contiguous) / 4 threads per n row (k-contiguous)
+            const int k = b_nc ? (tid >> 4) + 16 * it : ((tid & 3) + 4 * it) * 4, nn = n0 + (b_nc ? (tid & 15) * 4 : (tid >> 2));
+            const float* base = (d.B2 != nullptr && k >= d.k2) ? d.B2 - (int64_t)d.k2 * d.sBk : d.B;      // k2 % 4 == 0
+            rb[it] = *(const f32x4*)(base + (int64_t)k * d.sBk + (int64_t)nn * d.sBn);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NGA; ++it) {
+        if (it < nga) {
+            const int ml = a_kc ? (tid >> 3) : (tid & 7) * 4, k = a_kc ? ((tid & 7) + 8 * it) * 4 : (tid >> 3) + 32 * it;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) As[(a_kc ? ml : ml + q) * SA + (a_kc ? k + q : k)] = ra[it][q];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NGB; ++it) {
+        if (it < ngb) {
+            const int k = b_nc ? (tid >> 4) + 16 * it : ((tid & 3) + 4 * it) * 4, nl = b_nc ? (tid & 15) * 4 : (tid >> 2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Bs[(b_nc ? k : k + q) * (GP_N + 1) + (b_nc ? nl + q : nl)] = rb[it][q];
+        }
+    }
+    TS(1);
+    __syncthreads();
+    TS(2);
+    const int sub = wv & 1, khalf = wv >> 1;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    {
+        const int kb = khalf * (K / 2);
+        const float* Ap = As + n * SA + kb + kh;
+        const float* Bp = Bs + (kb + kh) * (GP_N + 1) + 32 * sub + n;
+        const int steps = K / 4;                          // a multiple of 8 (K % 32 == 0)
+        for (int s8 = 0; s8 < steps; s8 += 8) {
+            float av[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { av[u] = Ap[2 * (s8 + u)]; bv[u] = Bp[2 * (s8 + u) * (GP_N + 1)]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = mfma32(av[u], bv[u], acc);
+        }
+    }
+    TS(3);
+    __syncthreads();
+    float* red = gsm;                   // [2][32][33], over the A panel (dead now)
+    if (khalf == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(sub * 32 + mfma32_row(r, lane)) * 33 + n] = acc[r];
+    }
+    __syncthreads();
+    if (khalf == 0) {
+        const int col = n0 + 32 * sub + n;
+        if (col < d.N) {
+            const float bias = d.bias ? d.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = mfma32_row(r, lane), row = m0 + rl;
+                if (row < d.M) {
+                    float* c = d.C + (int64_t)row * d.ldc + col;
+                    float v = acc[r] + red[(sub * 32 + rl) * 33 + n] + bias;
+                    if (d.accumulate) v += *c;
+                    *c = v;
+                }
+            }
+        }
+    }
+    TS(4); TSC(15);
+}
+
 __global__ __launch_bounds__(256) void k_gemm_reduce(GemmBatch gb) {
     const int pi = blockIdx.y;
     const GemmProb& d = gb.p[pi];
@@ -204,6 +318,31 @@ int launch_gemm_batch(GemmBatch& gb, hipStream_t st) {
         maxNx = nx > maxNx ? nx : maxNx;
     }
     if (gb.splits < 1) gb.splits = 1;
+    bool panel = (gb.splits == 1) && !(g_sed_debug & 32);
+    int maxK = 0, maxN = 0;
+    for (int i = 0; i < gb.n_prob; ++i) {
+        const GemmProb& q = gb.p[i];
+        const bool a_kc = (q.sAk == 1), b_nc = (q.sBn == 1);
+        panel = panel && q.K <= GP_KMAX && (q.K % 32) == 0 && q.Cones == nullptr && (q.B2 == nullptr || (q.k2 % 4) == 0) &&
+                (q.N % GP_N) == 0 && q.M >= 4 && (q.M % 4) == 0 &&
+                (a_kc ? (q.sAm % 4) == 0 : (q.sAm == 1 && (q.sAk % 4) == 0)) &&
+                (b_nc ? (q.sBk % 4) == 0 : (q.sBk == 1 && (q.sBn % 4) == 0)) &&
+                ((uintptr_t)q.A % 16) == 0 && ((uintptr_t)q.B % 16) == 0 && (q.B2 == nullptr || ((uintptr_t)q.B2 % 16) == 0);
+        maxK = q.K > maxK ? q.K : maxK;
+        maxN = q.N > maxN ? q.N : maxN;
+    }
+    if (panel) {
+        const size_t lds = (size_t)(GP_M * (maxK + 1) + maxK * (GP_N + 1)) * sizeof(float);
+        static size_t lds_set = 0;
+        if (lds > lds_set) {
+            SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            lds_set = lds;
+        }
+        dim3 grid((maxN + GP_N - 1) / GP_N, (maxM + GP_M - 1) / GP_M, gb.n_prob);
+        k_gemm_panel<<<grid, 256, lds, st>>>(gb);
+        SED_CHECK_LAUNCH();
+        return SED_OK;
+    }
     if (gb.splits > 1) {
         SED_CHECK_ARG(gb.part != nullptr, "split-K gemm needs a partial buffer");
         gb.part_stride = (size_t)maxM * maxNx;

@@ -193,6 +193,13 @@ __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ 
     float* yt = zt + 32 * ZS;
     float* dlt = yt + 32 * ZS;
     TS(0); TSC(14);
+    if (H & 1) {        // the floor-mode pool drops the last row of an odd-height image: its gradient is 0
+        const int per_clip = W * 64, nb = Q / (Ho * Wo);
+        for (int i = blockIdx.x * 256 + tid; i < nb * per_clip; i += gridDim.x * 256) {
+            const int bb = i / per_clip, r = i % per_clip;
+            dz[((size_t)bb * H + (H - 1)) * W * 64 + r] = 0.f;
+        }
+    }
     for (int e = tid; e < 4096; e += 256) WsT[(e & 63) * ZS + (e >> 6)] = wglu[e];
     __syncthreads();
     // forward operand B[k=c][j=co] = Wglu[co][c] lives in registers; the transposed one for dz = dlin @ Wglu,
@@ -494,7 +501,6 @@ int launch_glu_pool_bwd(const float* y, const float* bn, const float* wglu, cons
         attr_done = true;
     }
     if (zero_acc) SED_CHECK_HIP(hipMemsetAsync(acc, 0, GLUACC_N * sizeof(double), st));
-    if (H & 1) SED_CHECK_HIP(hipMemsetAsync(dz, 0, (size_t)B * H * W * 64 * sizeof(float), st));
     const int n_rb = (Q + 3) / 4;
     int grid = (n_rb + 3) / 4;
     if (grid > 256) grid = 256;

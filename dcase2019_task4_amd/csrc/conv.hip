@@ -34,8 +34,10 @@ struct ConvCfg {
 };
 
 __global__ void k_conv_pack(const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ wpk1,
-                            float* __restrict__ wpk2, float* __restrict__ wpkT1, float* __restrict__ wpkT2) {
+                            float* __restrict__ wpk2, float* __restrict__ wpkT1, float* __restrict__ wpkT2,
+                            double* __restrict__ zero, int n_zero) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;   // over [layer][tap][ci][co]
+    if (i < n_zero) zero[i] = 0.0;                   // the forward's fp64 BatchNorm accumulators (saves a memset node)
     if (i >= 2 * 9 * 64 * 64) return;
     const int layer = i / (9 * 4096);
     i -= layer * 9 * 4096;
@@ -592,8 +594,9 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 }
 
 // ---- host launchers ---------------------------------------------------------------------------
-int launch_conv_pack(const float* w1, const float* w2, float* wpk1, float* wpk2, float* wpkT1, float* wpkT2, hipStream_t st) {
-    k_conv_pack<<<(2 * 9 * 4096 + 255) / 256, 256, 0, st>>>(w1, w2, wpk1, wpk2, wpkT1, wpkT2);
+int launch_conv_pack(const float* w1, const float* w2, float* wpk1, float* wpk2, float* wpkT1, float* wpkT2, double* zero,
+                     int n_zero, hipStream_t st) {
+    k_conv_pack<<<(2 * 9 * 4096 + 255) / 256, 256, 0, st>>>(w1, w2, wpk1, wpk2, wpkT1, wpkT2, zero, n_zero);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

@@ -218,11 +218,10 @@ extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* b
     int64_t* trk[3] = {bn_tracked ? bn_tracked + 0 : nullptr, bn_tracked ? bn_tracked + 1 : nullptr,
                        bn_tracked ? bn_tracked + 2 : nullptr};
 
-    // one memset for every fp64 accumulator of the forward (patch moments, BN sums of blocks 1 and 2)
-    if (train) SED_CHECK_HIP(hipMemsetAsync(CTXD(L.acc0), 0, 320 * sizeof(double), st));
-    // conv1 / conv2 weights -> [tap][ci][co] (+ flipped/transposed copies for dgrad), one launch
+    // conv1 / conv2 weights -> [tap][ci][co] (+ flipped/transposed copies for dgrad), one launch, which also zeroes
+    // every fp64 accumulator of the forward (patch moments, BN sums of blocks 1 and 2)
     SED_TRY(launch_conv_pack(params + P.conv_w[1], params + P.conv_w[2], CTXF(L.wpk1), CTXF(L.wpk2),
-                             train ? CTXF(L.wpkT1) : nullptr, train ? CTXF(L.wpkT2) : nullptr, st));
+                             train ? CTXF(L.wpkT1) : nullptr, train ? CTXF(L.wpkT2) : nullptr, CTXD(L.acc0), train ? 320 : 0, st));
     // ---- conv block 0 ---------------------------------------------------------------------------
     SED_TRY(launch_blk0_forward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
                                 params + P.glu_w[0], params + P.glu_b[0], bn_running + 0, bn_running + 64, trk[0], train,
@@ -297,7 +296,8 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
     SED_TRY(launch_heads_bwd(h_last, params + P.dense_w, params + P.soft_w, CTXF(L.strong_sv), CTXF(L.weak_sv),
                              CTXF(L.logits_s), CTXF(L.den_sv), d_strong, d_weak, WSF(W.d_out), WSF(W.heads_part),
                              grads + P.dense_w, grads + P.dense_b, grads + P.soft_w, grads + P.soft_b, g.B, g.T3, g.NC,
-                             use_drop, g.p, seed_dev, st));
+                             use_drop, g.p, seed_dev, (parts & 2) ? WSD(W.bwd_acc) : nullptr, 2 * 4288 + 2 * 64 * 10,
+                             (parts & 2) && sd.ok ? 1 : 0, st));
     // ---- BiGRU ----------------------------------------------------------------------------------
     const float* d_cur = WSF(W.d_out);
     for (int l = g.L - 1; l >= 0; --l) {
@@ -349,8 +349,8 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
     const size_t pin[3] = {0, L.p0, L.p1}, gacc[3] = {0, W.gluacc1, W.gluacc2}, mo[3] = {L.mask0, L.mask1, L.mask2};
     const size_t dzo[3] = {0, W.dz1, W.dz2}, dpo[3] = {W.dp0, W.dp1, W.dp2};
     const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};
-    // one memset for every fp64 accumulator of the conv-block backward
-    SED_CHECK_HIP(hipMemsetAsync(WSD(W.bwd_acc), 0, (2 * 4288 + 2 * 64 * 10) * sizeof(double), st));
+    // every fp64 accumulator of the conv-block backward: zeroed by k_heads_bwd when this call also ran part 1
+    if (!(parts & 1)) SED_CHECK_HIP(hipMemsetAsync(WSD(W.bwd_acc), 0, (2 * 4288 + 2 * 64 * 10) * sizeof(double), st));
     // Stream schedule (kernel timeline of one step, tools/timeline.py): the dgrad chain is the critical path.
     //   main: glu2_bwd  prep | dgrad2            | glu1_bwd  prep | dgrad1          | blk0_bwd  finalize |
     //   side:                | wgrad2  GRU dW/db |                | wgrad1  reduce                       | join
@@ -366,7 +366,10 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
             if (sd.ok) { SIDE_FORK(st); forked = true; }
             SED_TRY(launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(pin[i]), WSF(W.wg_part), W.wgrad_blocks,
                                       grads + P.conv_w[i], g.B, Hs[i], Wd[i], ss));
-            if (parts == 3) SED_TRY(gru_weight_grads(ss));
+            if (parts == 3) {
+                SED_TRY(gru_weight_grads(ss));
+                if (sd.ok) SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, ss));
+            }
             SED_TRY(launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], st));
         } else {
             const bool after = (g_sed_debug & 16) != 0;          // experiment: wgrad1 after dgrad1 (next to k_blk0_bwd)

@@ -151,8 +151,10 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_bwd(const float* __restric
                                                     const float* __restrict__ den, const float* __restrict__ d_strong,
                                                     const float* __restrict__ d_weak, float* __restrict__ dh,
                                                     float* __restrict__ part, int T, int NC, int use_drop, float p_drop,
-                                                    const uint64_t* __restrict__ seed_ptr) {
+                                                    const uint64_t* __restrict__ seed_ptr, double* __restrict__ zero, int n_zero) {
     extern __shared__ __attribute__((aligned(16))) float hsm[];
+    // the fp64 accumulators of the conv-block backward that follows (saves a memset node on the critical path)
+    for (int i = blockIdx.x * HD_THREADS + threadIdx.x; i < n_zero; i += gridDim.x * HD_THREADS) zero[i] = 0.0;
     float* xs = hsm;                                   // [HD_TC][HD_SB]
     float* wsm = xs + HD_TC * HD_SB;                   // [HD_MAXO][HD_SB]
     float* dl = wsm + HD_MAXO * HD_SB;                 // [HD_TC][HD_SD]
@@ -367,10 +369,16 @@ int launch_heads_fwd(const float* h, const float* wd, const float* bd, const flo
     return SED_OK;
 }
 
+int launch_heads_colsum(const float* part, float* g_wd, int B, int NC, hipStream_t st) {
+    // dense.weight, dense.bias, dense_softmax.weight, dense_softmax.bias are contiguous in the flat layout
+    return launch_colsum(part, B, 2 * (NC * HD_F + NC), 2 * (NC * HD_F + NC), g_wd, st);
+}
+
+// defer_colsum: the caller sums the per-clip partial weight gradients later (launch_heads_colsum, off the critical path)
 int launch_heads_bwd(const float* h, const float* wd, const float* ws, const float* strong, const float* weak,
                      const float* logits_s, const float* den, const float* d_strong, const float* d_weak, float* dh,
                      float* part, float* g_wd, float* g_bd, float* g_ws, float* g_bs, int B, int T, int NC, int use_drop,
-                     float p_drop, const uint64_t* seed, hipStream_t st) {
+                     float p_drop, const uint64_t* seed, double* zero, int n_zero, int defer_colsum, hipStream_t st) {
     (void)g_bd; (void)g_ws; (void)g_bs;
     const size_t lds = (size_t)(HD_TC * HD_SB + HD_MAXO * HD_SB + HD_TC * HD_SD + 32 + HD_THREADS) * sizeof(float);
     static bool attr_done = false;
@@ -379,10 +387,10 @@ int launch_heads_bwd(const float* h, const float* wd, const float* ws, const flo
         attr_done = true;
     }
     k_heads_bwd<<<B, HD_THREADS, lds, st>>>(h, wd, ws, strong, weak, logits_s, den, d_strong, d_weak, dh, part, T, NC, use_drop,
-                                            p_drop, seed);
+                                            p_drop, seed, zero, zero ? n_zero : 0);
     SED_CHECK_LAUNCH();
-    // dense.weight, dense.bias, dense_softmax.weight, dense_softmax.bias are contiguous in the flat layout
-    return launch_colsum(part, B, 2 * (NC * HD_F + NC), 2 * (NC * HD_F + NC), g_wd, st);
+    if (defer_colsum) return SED_OK;
+    return launch_heads_colsum(part, g_wd, B, NC, st);
 }
 
 extern "C" int sed_mt_loss(const sed_dims* d, const float* strong, const float* weak, const float* strong_ema,

@@ -18,7 +18,8 @@ int launch_blk0_backward(const Geo& g, const float* x, const float* w0, const fl
 
 // conv.hip : 3x3, 64 -> 64 channels, channels-last, image [B][H][W][64] with W in {16, 4}
 // packs conv1 and conv2 weights [co][ci][3][3] -> wpk [tap][ci][co] (+ flipped/transposed wpkT for dgrad, may be null)
-int launch_conv_pack(const float* w1, const float* w2, float* wpk1, float* wpk2, float* wpkT1, float* wpkT2, hipStream_t st);
+int launch_conv_pack(const float* w1, const float* w2, float* wpk1, float* wpk2, float* wpkT1, float* wpkT2, double* zero,
+                     int n_zero, hipStream_t st);
 // forward: y = conv(in) + bias; optional per-channel sum / sum-of-squares (fp64 atomics into stat[128])
 int launch_conv_fwd(const float* in, const float* wpk, const float* bias, float* y, double* stat, int zero_stat, int B,
                     int H, int W, hipStream_t st);
@@ -84,7 +85,8 @@ int launch_gru_bwd(const float* d_out, const float* out, const float* gates, con
 int launch_heads_fwd(const float* h /*[B][T][128]*/, const float* wd, const float* bd, const float* ws, const float* bs,
                      float* strong, float* weak, float* strong_sv, float* weak_sv, float* logits_s, float* den, int B, int T,
                      int NC, int use_drop, float p_drop, const uint64_t* seed, hipStream_t st);
+int launch_heads_colsum(const float* part, float* g_wd, int B, int NC, hipStream_t st);
 int launch_heads_bwd(const float* h, const float* wd, const float* ws, const float* strong, const float* weak,
                      const float* logits_s, const float* den, const float* d_strong, const float* d_weak, float* dh,
-                     float* part /*[B][2*(NC*128+NC)]*/, float* g_wd, float* g_bd, float* g_ws, float* g_bs, int B, int T,
-                     int NC, int use_drop, float p_drop, const uint64_t* seed, hipStream_t st);
+                     float* part, float* g_wd, float* g_bd, float* g_ws, float* g_bs, int B, int T, int NC, int use_drop,
+                     float p_drop, const uint64_t* seed, double* zero, int n_zero, int defer_colsum, hipStream_t st);

@@ -14,6 +14,7 @@ Two ways in:
   wraps it in the reference's epoch-loop signature.
 """
 import ctypes as C
+import os
 import time
 
 import torch

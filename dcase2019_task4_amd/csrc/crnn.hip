@@ -175,6 +175,8 @@ struct SideStream {
 static SideStream& side_stream() {
     static SideStream ss;
     if (!ss.ok) {
+        // (default priority on purpose: a lowest-priority side stream, meant to let the critical-path kernels win the
+        // CUs, made the replayed step 70 % slower - 1.79 vs 1.06 ms)
         if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess)

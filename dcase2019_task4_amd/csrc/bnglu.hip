@@ -33,27 +33,7 @@ struct BnPrepArgs {
     int train, update; float eps, momentum;
     float* bn;
 };
-__global__ __launch_bounds__(64) void k_bn_prep(BnPrepArgs a) {
-    const int c = threadIdx.x;
-    double mean, var;
-    if (a.train) {
-        mean = a.stat[c] / a.N;
-        var = a.stat[64 + c] / a.N - mean * mean;
-        if (var < 0) var = 0;
-        if (a.update) {
-            a.run_mean[c] = (float)((1.0 - a.momentum) * a.run_mean[c] + a.momentum * mean);
-            a.run_var[c] = (float)((1.0 - a.momentum) * a.run_var[c] + a.momentum * var * a.N / (a.N - 1.0));
-            if (c == 0 && a.tracked) a.tracked[0] += 1;
-        }
-    } else {
-        mean = a.run_mean[c];
-        var = a.run_var[c];
-    }
-    const double invstd = 1.0 / sqrt(var + (double)a.eps);
-    const double scale = a.gamma[c] * invstd;
-    a.bn[c] = (float)mean; a.bn[64 + c] = (float)invstd; a.bn[128 + c] = (float)scale;
-    a.bn[192 + c] = (float)(a.beta[c] - mean * scale);
-}
+__device__ __forceinline__ void bn_prep_body(const BnPrepArgs& a, int c, bool publish, float* bn_s);
 
 // pixel index (into [B][H][W]) of MFMA row m of the row block starting at pooled pixel q0
 __device__ __forceinline__ int rb_pixel(int q, int dt, int df, int H, int W, int Ho, int Wo) {
@@ -101,16 +81,45 @@ __device__ __forceinline__ void tile_store(const YTile& t, const float4& sc, con
     }
 }
 
-__global__ __launch_bounds__(256) void k_glu_pool_fwd(const float* __restrict__ y, const float* __restrict__ bn,
+// The BatchNorm statistics -> (mean, invstd, scale, shift) step of k_bn_prep runs in the prologue of every workgroup
+// (64 threads, a few fp64 operations) instead of as a 1-workgroup kernel of its own in front: one launch and one
+// dependency gap less on the forward chain per conv block.  Workgroup 0 also publishes bn[] for the backward and
+// updates the running statistics.
+__device__ __forceinline__ void bn_prep_body(const BnPrepArgs& a, int c, bool publish, float* bn_s /* LDS [256] */) {
+    double mean, var;
+    if (a.train) {
+        mean = a.stat[c] / a.N;
+        var = a.stat[64 + c] / a.N - mean * mean;
+        if (var < 0) var = 0;
+        if (a.update && publish) {
+            a.run_mean[c] = (float)((1.0 - a.momentum) * a.run_mean[c] + a.momentum * mean);
+            a.run_var[c] = (float)((1.0 - a.momentum) * a.run_var[c] + a.momentum * var * a.N / (a.N - 1.0));
+            if (c == 0 && a.tracked) a.tracked[0] += 1;
+        }
+    } else {
+        mean = a.run_mean[c];
+        var = a.run_var[c];
+    }
+    const double invstd = 1.0 / sqrt(var + (double)a.eps);
+    const double scale = a.gamma[c] * invstd;
+    const float v0 = (float)mean, v1 = (float)invstd, v2 = (float)scale, v3 = (float)(a.beta[c] - mean * scale);
+    bn_s[c] = v0; bn_s[64 + c] = v1; bn_s[128 + c] = v2; bn_s[192 + c] = v3;
+    if (publish) { a.bn[c] = v0; a.bn[64 + c] = v1; a.bn[128 + c] = v2; a.bn[192 + c] = v3; }
+}
+
+__global__ __launch_bounds__(256) void k_glu_pool_fwd(const float* __restrict__ y, BnPrepArgs bnp,
                                                        const float* __restrict__ wglu, const float* __restrict__ bglu,
                                                        float* __restrict__ p, int H, int W, int Ho, int Wo, int Q,
                                                        int block_id, int use_drop, float p_drop,
                                                        const uint64_t* __restrict__ seed_ptr, uint16_t* __restrict__ mask_out) {
     __shared__ float zts[4][32 * ZS];
     __shared__ float WsT[64 * ZS];     // Wglu transposed [c][co], stride 65: coalesced global read, conflict-free both ways
+    __shared__ __attribute__((aligned(16))) float bn_s[256];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
     float* zt = zts[wv];
+    if (tid < 64) bn_prep_body(bnp, tid, blockIdx.x == 0, bn_s);
+    const float* bn = bn_s;
     for (int e = tid; e < 4096; e += 256) WsT[(e & 63) * ZS + (e >> 6)] = wglu[e];
     __syncthreads();
     float bw[32][2];
@@ -176,16 +185,45 @@ __global__ __launch_bounds__(256) void k_glu_pool_fwd(const float* __restrict__ 
     }
 }
 
-// acc layout (doubles): [0,4096) dWglu[co][c]; [4096,4160) dbglu; [4160,4224) sum dz; [4224,4288) sum dz*y
-#define GLUACC_N 4288
+#define GLUACC_N SED_GLUACC_N     // layout: common.h
+
+struct BnBwdPrepArgs {
+    const double* acc; double N;
+    const float *gamma, *bn;
+    float *coef, *g_gamma, *g_beta, *g_wglu, *g_bglu, *g_convb;
+};
+// BatchNorm backward reduction -> per-channel affine dy = ca*dz + cb*y + cc for the conv dgrad / wgrad loaders, and the
+// parameter gradients of the block (was a 1-workgroup kernel of its own; now the epilogue of the LAST workgroup of
+// k_glu_pool_bwd).  Reads the accumulators with device-scope atomic loads: they were produced by other workgroups'
+// atomics, possibly on other XCDs.
+__device__ __forceinline__ double acc_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void bn_bwd_prep_body(const BnBwdPrepArgs& a, int tid) {
+    if (tid < 64) {
+        const int c = tid;
+        const double mean = a.bn[c], invstd = a.bn[64 + c], scale = a.bn[128 + c];
+        const double Sdz = acc_load(&a.acc[4160 + c]), Sdzy = acc_load(&a.acc[4224 + c]);
+        const double Sdzxhat = invstd * (Sdzy - mean * Sdz);
+        a.g_beta[c] = (float)Sdz;
+        a.g_gamma[c] = (float)Sdzxhat;
+        const double m1 = Sdz / a.N, m2 = Sdzxhat / a.N;
+        // dy = scale * (dz - m1 - xhat*m2),  xhat = (y - mean) * invstd
+        a.coef[c] = (float)scale;
+        a.coef[64 + c] = (float)(-scale * m2 * invstd);
+        a.coef[128 + c] = (float)(scale * (m2 * invstd * mean - m1));
+        a.g_bglu[c] = (float)acc_load(&a.acc[4096 + c]);
+        a.g_convb[c] = 0.f;   // sum_p dy == 0: a conv bias in front of a train-mode BatchNorm has zero gradient
+    }
+    for (int e = tid; e < 4096; e += 256) a.g_wglu[e] = (float)acc_load(&a.acc[e]);
+}
 
 __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ y, const float* __restrict__ bn,
                                                        const float* __restrict__ wglu, const float* __restrict__ bglu,
                                                        const float* __restrict__ dp, float* __restrict__ dz,
                                                        double* __restrict__ accg, int H, int W, int Ho, int Wo, int Q,
                                                        int block_id, int use_drop, float p_drop,
-                                                       const uint16_t* __restrict__ mask_in, int no_atomic) {
+                                                       const uint16_t* __restrict__ mask_in, int no_atomic, BnBwdPrepArgs prep) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ int is_last;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
     float* WsT = smem + 4 * (3 * 32 * ZS);               // Wglu transposed [c][co], stride 65
@@ -443,56 +481,41 @@ __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ 
         if (!no_atomic) atomicAdd(&accg[4096 + which * 64 + c], v);
     }
     TS(10); TSC(15);
-}
-
-struct BnBwdPrepArgs {
-    const double* acc; double N;
-    const float *gamma, *bn;
-    float *coef, *g_gamma, *g_beta, *g_wglu, *g_bglu, *g_convb;
-};
-__global__ __launch_bounds__(64) void k_bn_bwd_prep(BnBwdPrepArgs a) {
-    const int c = threadIdx.x;
-    const double mean = a.bn[c], invstd = a.bn[64 + c], scale = a.bn[128 + c];
-    const double Sdz = a.acc[4160 + c], Sdzy = a.acc[4224 + c];
-    const double Sdzxhat = invstd * (Sdzy - mean * Sdz);
-    a.g_beta[c] = (float)Sdz;
-    a.g_gamma[c] = (float)Sdzxhat;
-    const double m1 = Sdz / a.N, m2 = Sdzxhat / a.N;
-    // dy = scale * (dz - m1 - xhat*m2),  xhat = (y - mean) * invstd
-    a.coef[c] = (float)scale;
-    a.coef[64 + c] = (float)(-scale * m2 * invstd);
-    a.coef[128 + c] = (float)(scale * (m2 * invstd * mean - m1));
-    for (int k = 0; k < 64; ++k) a.g_wglu[c * 64 + k] = (float)a.acc[c * 64 + k];
-    a.g_bglu[c] = (float)a.acc[4096 + c];
-    a.g_convb[c] = 0.f;   // sum_p dy == 0: a conv bias in front of a train-mode BatchNorm has zero gradient
+    // ---- last workgroup: BatchNorm-backward coefficients + parameter gradients --------------------------------
+    // Ordering only needs this workgroup's accumulator ATOMICS (device scope already) to be complete before its ticket
+    // increment: a workgroup-scope release (s_waitcnt) does that.  __threadfence() would also write back the L2 -
+    // i.e. the 31 MB of dz this kernel just produced - and cost 17 us.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    unsigned int* ticket = (unsigned int*)(accg + 4288);
+    if (tid == 0) is_last = (atomicAdd(ticket, 1u) == gridDim.x - 1);
+    __syncthreads();
+    if (!is_last) return;
+    bn_bwd_prep_body(prep, tid);
+    if (tid == 0) *ticket = 0u;
 }
 
 // ---- host launchers -------------------------------------------------------------------------------
-int launch_bn_prep(const double* stat, double N, const float* gamma, const float* beta, float* run_mean, float* run_var,
-                   int64_t* tracked, int train, int update, float eps, float momentum, float* bn, hipStream_t st) {
+int launch_glu_pool_fwd(const float* y, const double* stat, double N, const float* gamma, const float* beta, float* run_mean,
+                        float* run_var, int64_t* tracked, int train, int update, float eps, float momentum, float* bn,
+                        const float* wglu, const float* bglu, float* p, int B, int H, int W, int block_id, int use_drop,
+                        float p_drop, const uint64_t* seed, uint16_t* mask_out, hipStream_t st) {
     BnPrepArgs a;
     a.stat = stat; a.N = N; a.gamma = gamma; a.beta = beta; a.run_mean = run_mean; a.run_var = run_var;
     a.tracked = tracked; a.train = train; a.update = update; a.eps = eps; a.momentum = momentum; a.bn = bn;
-    k_bn_prep<<<1, 64, 0, st>>>(a);
-    SED_CHECK_LAUNCH();
-    return SED_OK;
-}
-
-int launch_glu_pool_fwd(const float* y, const float* bn, const float* wglu, const float* bglu, float* p, int B, int H,
-                        int W, int block_id, int use_drop, float p_drop, const uint64_t* seed, uint16_t* mask_out,
-                        hipStream_t st) {
     const int Ho = H / 2, Wo = W / 4, Q = B * Ho * Wo;
     const int n_rb = (Q + 3) / 4;
     int grid = (n_rb + 3) / 4;
     if (grid > 512) grid = 512;
-    k_glu_pool_fwd<<<grid, 256, 0, st>>>(y, bn, wglu, bglu, p, H, W, Ho, Wo, Q, block_id, use_drop, p_drop, seed, mask_out);
+    k_glu_pool_fwd<<<grid, 256, 0, st>>>(y, a, wglu, bglu, p, H, W, Ho, Wo, Q, block_id, use_drop, p_drop, seed, mask_out);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
 
 int launch_glu_pool_bwd(const float* y, const float* bn, const float* wglu, const float* bglu, const float* dp, float* dz,
                         double* acc, int zero_acc, int B, int H, int W, int block_id, int use_drop, float p_drop,
-                        const uint16_t* mask_in, hipStream_t st) {
+                        const uint16_t* mask_in, const float* gamma, float* coef, float* g_gamma, float* g_beta, float* g_wglu,
+                        float* g_bglu, float* g_convb, hipStream_t st) {
     const int Ho = H / 2, Wo = W / 4, Q = B * Ho * Wo;
     const size_t lds = (size_t)(4 * 3 * 32 * ZS + 64 * ZS) * sizeof(float);
     static bool attr_done = false;
@@ -501,20 +524,14 @@ int launch_glu_pool_bwd(const float* y, const float* bn, const float* wglu, cons
         attr_done = true;
     }
     if (zero_acc) SED_CHECK_HIP(hipMemsetAsync(acc, 0, GLUACC_N * sizeof(double), st));
+    BnBwdPrepArgs a;
+    a.acc = acc; a.N = (double)B * H * W; a.gamma = gamma; a.bn = bn; a.coef = coef; a.g_gamma = g_gamma; a.g_beta = g_beta;
+    a.g_wglu = g_wglu; a.g_bglu = g_bglu; a.g_convb = g_convb;
     const int n_rb = (Q + 3) / 4;
     int grid = (n_rb + 3) / 4;
     if (grid > 256) grid = 256;
-    k_glu_pool_bwd<<<grid, 256, lds, st>>>(y, bn, wglu, bglu, dp, dz, acc, H, W, Ho, Wo, Q, block_id, use_drop, p_drop, mask_in, g_sed_debug & 1);
+    k_glu_pool_bwd<<<grid, 256, lds, st>>>(y, bn, wglu, bglu, dp, dz, acc, H, W, Ho, Wo, Q, block_id, use_drop, p_drop, mask_in, g_sed_debug & 1, a);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
 
-int launch_bn_bwd_prep(const double* acc, double N, const float* gamma, const float* bn, float* coef, float* g_gamma,
-                       float* g_beta, float* g_wglu, float* g_bglu, float* g_convb, hipStream_t st) {
-    BnBwdPrepArgs a;
-    a.acc = acc; a.N = N; a.gamma = gamma; a.bn = bn; a.coef = coef; a.g_gamma = g_gamma; a.g_beta = g_beta;
-    a.g_wglu = g_wglu; a.g_bglu = g_bglu; a.g_convb = g_convb;
-    k_bn_bwd_prep<<<1, 64, 0, st>>>(a);
-    SED_CHECK_LAUNCH();
-    return SED_OK;
-}

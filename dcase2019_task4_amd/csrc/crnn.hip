@@ -111,8 +111,8 @@ WsLayout make_ws_layout(const Geo& g) {
     put(W.d_in, bt * 128 * 4); put(W.heads_part, (size_t)g.B * 2 * (g.NC * 128 + g.NC) * 4);
     put(W.dp2, bt * 64 * 4); put(W.dz2, n1 * 4); put(W.dp1, n1 * 4); put(W.dz1, n0 * 4); put(W.dp0, n0 * 4);
     put(W.bnb, 256 * sizeof(double)); W.coef[0] = 0; put(W.coef[1], 192 * 4); put(W.coef[2], 192 * 4);
-    put(W.bwd_acc, (2 * 4288 + 2 * 64 * 10) * sizeof(double));
-    W.gluacc1 = W.bwd_acc; W.gluacc2 = W.bwd_acc + 4288 * sizeof(double); W.de0 = W.bwd_acc + 2 * 4288 * sizeof(double);
+    put(W.bwd_acc, (2 * SED_GLUACC_N + 2 * 64 * 10) * sizeof(double));
+    W.gluacc1 = W.bwd_acc; W.gluacc2 = W.bwd_acc + SED_GLUACC_N * sizeof(double); W.de0 = W.bwd_acc + 2 * SED_GLUACC_N * sizeof(double);
     W.wgrad_blocks = SED_WGRAD_MAX_BLOCKS;
     put(W.wg_part, (size_t)W.wgrad_blocks * 9 * 4096 * 4);
     put(W.gemm_part, gemm_part_floats(4, SED_GRU_SPLITK, 192, 129) * 4);
@@ -237,11 +237,10 @@ extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* b
     for (int i = 1; i <= 2; ++i) {
         SED_TRY(launch_conv_fwd(in, CTXF(wpk[i]), params + P.conv_b[i], CTXF(yo[i]), train ? CTXD(so[i]) : nullptr, 0, g.B,
                                 Hs[i], Ws[i], st));
-        SED_TRY(launch_bn_prep(CTXD(so[i]), (double)g.B * Hs[i] * Ws[i], params + P.bn_g[i], params + P.bn_b[i],
-                               bn_running + (2 * i) * 64, bn_running + (2 * i + 1) * 64, trk[i], train, upd, g.eps, g.mom,
-                               CTXF(bo[i]), st));
-        SED_TRY(launch_glu_pool_fwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], CTXF(po[i]), g.B,
-                                    Hs[i], Ws[i], i, use_drop, g.p, seed_dev, use_drop ? CTXM(mo[i]) : nullptr, st));
+        SED_TRY(launch_glu_pool_fwd(CTXF(yo[i]), CTXD(so[i]), (double)g.B * Hs[i] * Ws[i], params + P.bn_g[i], params + P.bn_b[i],
+                                    bn_running + (2 * i) * 64, bn_running + (2 * i + 1) * 64, trk[i], train, upd, g.eps, g.mom,
+                                    CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], CTXF(po[i]), g.B, Hs[i], Ws[i], i,
+                                    use_drop, g.p, seed_dev, use_drop ? CTXM(mo[i]) : nullptr, st));
         in = CTXF(po[i]);
     }
     // ---- BiGRU ----------------------------------------------------------------------------------
@@ -298,7 +297,7 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
     SED_TRY(launch_heads_bwd(h_last, params + P.dense_w, params + P.soft_w, CTXF(L.strong_sv), CTXF(L.weak_sv),
                              CTXF(L.logits_s), CTXF(L.den_sv), d_strong, d_weak, WSF(W.d_out), WSF(W.heads_part),
                              grads + P.dense_w, grads + P.dense_b, grads + P.soft_w, grads + P.soft_b, g.B, g.T3, g.NC,
-                             use_drop, g.p, seed_dev, (parts & 2) ? WSD(W.bwd_acc) : nullptr, 2 * 4288 + 2 * 64 * 10,
+                             use_drop, g.p, seed_dev, (parts & 2) ? WSD(W.bwd_acc) : nullptr, 2 * SED_GLUACC_N + 2 * 64 * 10,
                              (parts & 2) && sd.ok ? 1 : 0, st));
     // ---- BiGRU ----------------------------------------------------------------------------------
     const float* d_cur = WSF(W.d_out);
@@ -352,18 +351,19 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
     const size_t dzo[3] = {0, W.dz1, W.dz2}, dpo[3] = {W.dp0, W.dp1, W.dp2};
     const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};
     // every fp64 accumulator of the conv-block backward: zeroed by k_heads_bwd when this call also ran part 1
-    if (!(parts & 1)) SED_CHECK_HIP(hipMemsetAsync(WSD(W.bwd_acc), 0, (2 * 4288 + 2 * 64 * 10) * sizeof(double), st));
+    if (!(parts & 1)) SED_CHECK_HIP(hipMemsetAsync(WSD(W.bwd_acc), 0, (2 * SED_GLUACC_N + 2 * 64 * 10) * sizeof(double), st));
     // Stream schedule (kernel timeline of one step, tools/timeline.py): the dgrad chain is the critical path.
     //   main: glu2_bwd  prep | dgrad2            | glu1_bwd  prep | dgrad1          | blk0_bwd  finalize |
     //   side:                | wgrad2  GRU dW/db |                | wgrad1  reduce                       | join
     // (Starting wgrad1 only after dgrad1, next to the VALU-bound k_blk0_bwd, measured the same: dgrad1 drops from
     // 175 to 93 us but k_blk0_bwd, left with one wave per SIMD beside the wgrad wave, goes from 86 to 177 us.)
     for (int i = 2; i >= 1; --i) {
+        // (the BatchNorm-backward coefficients and the block's parameter gradients are produced by the last workgroup
+        // of k_glu_pool_bwd: no separate 1-workgroup kernel between it and the conv dgrad / wgrad)
         SED_TRY(launch_glu_pool_bwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], WSF(dpo[i]),
-                                    WSF(dzo[i]), WSD(gacc[i]), 0, g.B, Hs[i], Wd[i], i, use_drop, g.p, CTXM(mo[i]), st));
-        SED_TRY(launch_bn_bwd_prep(WSD(gacc[i]), (double)g.B * Hs[i] * Wd[i], params + P.bn_g[i], CTXF(bo[i]), WSF(W.coef[i]),
-                                   grads + P.bn_g[i], grads + P.bn_b[i], grads + P.glu_w[i], grads + P.glu_b[i],
-                                   grads + P.conv_b[i], st));
+                                    WSF(dzo[i]), WSD(gacc[i]), 0, g.B, Hs[i], Wd[i], i, use_drop, g.p, CTXM(mo[i]),
+                                    params + P.bn_g[i], WSF(W.coef[i]), grads + P.bn_g[i], grads + P.bn_b[i],
+                                    grads + P.glu_w[i], grads + P.glu_b[i], grads + P.conv_b[i], st));
         if (i == 2) {
             if (sd.ok) { SIDE_FORK(st); forked = true; }
             SED_TRY(launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(pin[i]), WSF(W.wg_part), W.wgrad_blocks,
@@ -435,9 +435,13 @@ extern "C" int sed_kernel_replay(const char* name, const sed_dims* d, const floa
         snprintf(nm, sizeof nm, "conv%d_fwd", i);
         if (is(nm)) return launch_conv_fwd(CTXF(po[i - 1]), CTXF(wpk[i]), params + P.conv_b[i], CTXF(yo[i]), CTXD(so[i]), 1, g.B, Hs[i], Wd[i], st);
         snprintf(nm, sizeof nm, "glu%d_fwd", i);
-        if (is(nm)) return launch_glu_pool_fwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], CTXF(po[i]), g.B, Hs[i], Wd[i], i, use_drop, g.p, seed_dev, use_drop ? CTXM(mo[i]) : nullptr, st);
+        if (is(nm)) return launch_glu_pool_fwd(CTXF(yo[i]), CTXD(so[i]), (double)g.B * Hs[i] * Wd[i], params + P.bn_g[i], params + P.bn_b[i],
+                                               WSF(W.coef[1]), WSF(W.coef[1]) + 64, nullptr, 1, 0, g.eps, g.mom, CTXF(bo[i]),
+                                               params + P.glu_w[i], params + P.glu_b[i], CTXF(po[i]), g.B, Hs[i], Wd[i], i, use_drop,
+                                               g.p, seed_dev, use_drop ? CTXM(mo[i]) : nullptr, st);
         snprintf(nm, sizeof nm, "glu%d_bwd", i);
-        if (is(nm)) return launch_glu_pool_bwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], WSF(dpo[i]), WSF(dzo[i]), WSD(gacc[i]), 1, g.B, Hs[i], Wd[i], i, use_drop, g.p, CTXM(mo[i]), st);
+        if (is(nm)) return launch_glu_pool_bwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], WSF(dpo[i]), WSF(dzo[i]), WSD(gacc[i]), 1, g.B, Hs[i], Wd[i], i, use_drop, g.p, CTXM(mo[i]),
+                                               params + P.bn_g[i], WSF(W.coef[i]), grads + P.bn_g[i], grads + P.bn_b[i], grads + P.glu_w[i], grads + P.glu_b[i], grads + P.conv_b[i], st);
         snprintf(nm, sizeof nm, "conv%d_wgrad", i);
         if (is(nm)) return launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(po[i - 1]), WSF(W.wg_part), W.wgrad_blocks, grads + P.conv_w[i], g.B, Hs[i], Wd[i], st);
         snprintf(nm, sizeof nm, "conv%d_dgrad", i);

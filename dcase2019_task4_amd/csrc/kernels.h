@@ -31,19 +31,17 @@ int launch_conv_wgrad(const float* dz, const float* yin, const float* coef, cons
                       float* g_w /*[co][ci][3][3]*/, int B, int H, int W, hipStream_t st);
 
 // bnglu.hip
-int launch_bn_prep(const double* stat, double N, const float* gamma, const float* beta, float* run_mean, float* run_var,
-                   int64_t* tracked, int train, int update, float eps, float momentum, float* bn /*[4][64]*/, hipStream_t st);
-int launch_glu_pool_fwd(const float* y, const float* bn, const float* wglu, const float* bglu, float* p, int B, int H,
-                        int W, int block_id, int use_drop, float p_drop, const uint64_t* seed, uint16_t* mask_out,
-                        hipStream_t st);
+// BN statistics -> (mean, invstd, scale, shift) (+ running-stat update) happens in the kernel's prologue
+int launch_glu_pool_fwd(const float* y, const double* stat, double N, const float* gamma, const float* beta, float* run_mean,
+                        float* run_var, int64_t* tracked, int train, int update, float eps, float momentum, float* bn /*[4][64]*/,
+                        const float* wglu, const float* bglu, float* p, int B, int H, int W, int block_id, int use_drop,
+                        float p_drop, const uint64_t* seed, uint16_t* mask_out, hipStream_t st);
 // backward pass 1: dz (full-res grad wrt BN output), GLU weight grads and BN reduction sums
 //   acc: double [64*64 (dWglu) + 64 (dbglu) + 64 (sum dz) + 64 (sum dz*y)]
 int launch_glu_pool_bwd(const float* y, const float* bn, const float* wglu, const float* bglu, const float* dp, float* dz,
                         double* acc, int zero_acc, int B, int H, int W, int block_id, int use_drop, float p_drop,
-                        const uint16_t* mask_in, hipStream_t st);
-// backward pass 1b: write GLU grads, BN grads and the coefficients of dy = ca*dz + cb*y + cc
-int launch_bn_bwd_prep(const double* acc, double N, const float* gamma, const float* bn, float* coef, float* g_gamma,
-                       float* g_beta, float* g_wglu, float* g_bglu, float* g_convb, hipStream_t st);
+                        const uint16_t* mask_in, const float* gamma, float* coef, float* g_gamma, float* g_beta, float* g_wglu,
+                        float* g_bglu, float* g_convb, hipStream_t st);
 
 // gemm.hip : batched / split-K strided GEMM  C[m][n] = sum_k A(m,k) B(k,n) (+ bias[n]) (+ C)
 struct GemmProb {

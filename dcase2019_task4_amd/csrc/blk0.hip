@@ -105,8 +105,17 @@ __global__ __launch_bounds__(640) void k_blk0_prep(Blk0PrepArgs a) {
     if (a.train) {   // patch moments = fixed-order fp64 sum of the per-workgroup partials
         if (tid < 540) {
             const int k = tid / 10, j = tid % 10;
+            // 8 independent loads in flight (a rolled loop pays one memory round trip per partial: 12 us for 24 of them)
             double acc = 0;
-            for (int w = j; w < a.n_part; w += 10) acc += a.mompart[(size_t)w * 54 + k];
+            int w = j;
+            for (; w + 70 < a.n_part; w += 80) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = a.mompart[(size_t)(w + 10 * u) * 54 + k];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+            for (; w < a.n_part; w += 10) acc += a.mompart[(size_t)w * 54 + k];
             mred[k][j] = acc;
         }
         __syncthreads();

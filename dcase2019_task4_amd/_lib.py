@@ -35,6 +35,8 @@ class SedStepState(C.Structure):
 _P = C.c_void_p
 _SIGS = {
     "sed_last_error": (C.c_char_p, []),
+    "sed_postprocess": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_int, C.c_void_p]),
     "sed_version": (C.c_int, []),
     "sed_param_count": (C.c_int, [C.POINTER(SedDims)]),
     "sed_param_layout": (C.c_int, [C.POINTER(SedDims), C.POINTER(C.c_int64)]),

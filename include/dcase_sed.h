@@ -178,6 +178,20 @@ int sed_logmel_transform(const float* mel, int n_clips, int frames, int n_mels, 
                          const double* mean, const double* std, const uint64_t* seed_dev,
                          float* out_clean, float* out_noisy, void* stream);
 
+/* ---- inference post-processing ---------------------------------------------------------------
+ * Replaces the per-clip host loop of get_predictions (evaluation_measures.py:203-231) after the
+ * forward: ProbabilityEncoder().binarization(global_threshold) -> scipy.ndimage median_filter
+ * (median_window, 1) (mode "reflect") -> ManyHotEncoder.decode_strong / DecisionEncoder
+ * .find_contiguous_regions (utils/utils.py:146-162), for a whole batch of strong posteriors.
+ *   strong     [n_clips][T][nclass] fp32 (output of sed_crnn_forward), T <= 2048
+ *   binary     [n_clips][T][nclass] uint8 filtered decisions, or NULL
+ *   ev_count   [n_clips][nclass] int32: events per (clip, class)
+ *   ev_pairs   [n_clips][nclass][max_events][2] int32: (onset, offset) in output frames, offset
+ *              exclusive, in time order; max_events >= ceil(T / 2)                               */
+int sed_postprocess(const float* strong, int n_clips, int T, int nclass, float threshold,
+                    int median_window, uint8_t* binary, int32_t* ev_count, int32_t* ev_pairs,
+                    int max_events, void* stream);
+
 /* ---- single-kernel replay (measurement) ----------------------------------------------------
  * Re-launches ONE kernel of the step on the buffers left by a finished sed_crnn_forward +
  * sed_crnn_backward (same shapes, same data; outputs are rewritten with identical values), so

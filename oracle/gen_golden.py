@@ -28,8 +28,9 @@ def import_reference():
     for n in ["librosa", "soundfile", "dcase_util", "dcase_util.data", "dcase_util.containers",
               "sed_eval", "youtube_dl", "youtube_dl.utils"]:
         sys.modules[n] = types.ModuleType(n)
-    sys.modules["dcase_util.data"].DecisionEncoder = object
-    sys.modules["dcase_util.data"].ProbabilityEncoder = object
+    from oracle import postprocess_np
+    sys.modules["dcase_util.data"].DecisionEncoder = postprocess_np.DecisionEncoder          # restatements (parity
+    sys.modules["dcase_util.data"].ProbabilityEncoder = postprocess_np.ProbabilityEncoder    # unpinned): see that file
     sys.modules["dcase_util.containers"].AudioContainer = object
     sys.modules["youtube_dl.utils"].ExtractorError = Exception
     sys.modules["youtube_dl.utils"].DownloadError = Exception
@@ -257,9 +258,72 @@ def supervised_():
     print("wrote g8_supervised3.npz", sorted(k for k in save if k.startswith("meter_")))
 
 
+def predictions_():
+    """G9: the REAL baseline/evaluation_measures.get_predictions + ManyHotEncoder.decode_strong on 6 synthetic clips
+    (eval-mode reference CRNN, T = 628 -> 78 frames): the event table, its TSV text and the filtered decisions."""
+    import io
+    import pandas as pd
+    import torch
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    main, cfg, CRNN = import_reference()
+    import evaluation_measures as em
+    from utils.utils import ManyHotEncoder
+    from oracle import synth, postprocess_np
+    if not hasattr(pd.DataFrame, "append"):          # removed in pandas 2.0; the reference still calls it (:221)
+        pd.DataFrame.append = lambda self, other: pd.concat([self, other])
+    N, T = 6, 628
+    post = synth.make_posteriors(0, N, T // 8)
+    x = synth.make_input(77, N, T)
+
+    class FixedPosteriors(torch.nn.Module):
+        """Stands in for the CRNN: get_predictions only needs model(input[None]) -> (strong, weak).  It returns the
+        prescribed posteriors of the clip it is called for (identified by its input), so that the REAL reference loop
+        runs its binarization / median filter / decode / DataFrame code on data with real temporal structure."""
+
+        def forward(self, inp):
+            i = int(torch.nonzero((x.reshape(N, -1) == inp.reshape(1, -1)).all(dim=1))[0])
+            return post[i:i + 1], post[i:i + 1].mean(1)
+
+    m = FixedPosteriors()
+
+    class DS:
+        filenames = pd.Series([f"clip_{i}.wav" for i in range(N)])
+
+        def __len__(self):
+            return N
+
+        def __getitem__(self, i):
+            return x[i], torch.zeros(T // 8, 10)
+
+        def __iter__(self):
+            return (self[i] for i in range(N))
+
+    labels = ["Alarm_bell_ringing", "Blender", "Cat", "Dishes", "Dog", "Electric_shaver_toothbrush", "Frying",
+              "Running_water", "Speech", "Vacuum_cleaner"]
+    enc = ManyHotEncoder(labels, n_frames=T // 8)
+    strong = post.numpy()
+    margin = float(np.abs(strong - 0.5)[np.abs(strong - 0.5) > 0].min())
+    assert margin > 1e-4, margin
+    buf = os.path.join("/tmp", "g9_pred.tsv")
+    df = em.get_predictions(m, DS(), enc.decode_strong, cfg.pooling_time_ratio, save_predictions=buf)
+    tsv = open(buf).read()
+    dec = np.stack([postprocess_np.filter_decisions(s) for s in strong]).astype(np.uint8)
+    np.savez_compressed(os.path.join(OUT, "g9_predictions.npz"), decisions=dec, tsv=np.array(tsv),
+                        labels=np.array(labels), onset=df.onset.to_numpy(dtype=np.float64),
+                        offset=df.offset.to_numpy(dtype=np.float64), event_label=np.array(df.event_label.tolist()),
+                        filename=np.array(df.filename.tolist()), margin=np.array(margin),
+                        sample_rate=np.array(cfg.sample_rate), hop_length=np.array(cfg.hop_length),
+                        median_window=np.array(cfg.median_window), pooling_time_ratio=np.array(cfg.pooling_time_ratio))
+    print("wrote g9_predictions.npz:", len(df), "events, margin", margin)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "g8":
+    if len(sys.argv) > 1 and sys.argv[1] == "g9":
+        predictions_()
+    elif len(sys.argv) > 1 and sys.argv[1] == "g8":
         supervised_()
     else:
         main_()
         supervised_()
+        predictions_()

@@ -66,3 +66,27 @@ def make_wave(seed, n_samples):
     y = y + 0.05 * rs.standard_normal(n_samples)
     env = 0.5 + 0.5 * np.sin(2 * np.pi * 0.7 * t + seed)
     return (y * env).astype(np.float64)
+
+
+def make_posteriors(seed, N, T_out, nclass=10):
+    """Strong posteriors with enough temporal structure to exercise the post-processing (a randomly initialised CRNN
+    emits nearly time-constant posteriors): smoothed noise pushed through a sigmoid, plus hand-placed edge cases -
+    1/2/3-frame blips and gaps around the median window, activity at both clip ends, all-on / all-off / alternating
+    columns and values exactly at the threshold."""
+    rs = np.random.RandomState(6000 + seed)
+    z = rs.standard_normal((N, T_out + 8, nclass))
+    k = np.array([1, 2, 3, 2, 1], dtype=np.float64) / 9.0
+    sm = sum(k[i] * z[:, i:i + T_out, :] for i in range(5))
+    p = 1.0 / (1.0 + np.exp(-4.0 * sm))
+    p = np.where(np.abs(p - 0.5) < 1e-3, 0.6, p)          # keep a margin that fp32 cannot flip ...
+    if nclass < 8 or T_out < 40:
+        return torch.tensor(p, dtype=torch.float32)
+    p[0, :, 0] = 0.9                                       # all on
+    p[0, :, 1] = 0.1                                       # all off
+    p[0, :, 2] = np.where(np.arange(T_out) % 2 == 0, 0.8, 0.2)     # alternating: the median filter decides everything
+    p[0, :, 3] = 0.1; p[0, 10, 3] = 0.9; p[0, 20:22, 3] = 0.9; p[0, 30:33, 3] = 0.9     # blips of 1, 2, 3 frames
+    p[0, :, 4] = 0.9; p[0, 10, 4] = 0.1; p[0, 20:22, 4] = 0.1; p[0, 30:33, 4] = 0.1     # gaps of 1, 2, 3 frames
+    p[0, :, 5] = 0.1; p[0, :2, 5] = 0.9; p[0, -2:, 5] = 0.9                               # reflect boundary, both ends
+    p[0, :, 6] = 0.1; p[0, :3, 6] = 0.9; p[0, -1:, 6] = 0.9
+    p[0, :, 7] = 0.5                                        # ... except exactly AT the threshold: p > 0.5 is False
+    return torch.tensor(p, dtype=torch.float32)

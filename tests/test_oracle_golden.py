@@ -213,3 +213,26 @@ def test_g8_supervised_steps_vs_real_main_simple_crnn_train(golden_dir):
     for k, v in mt.bn.items():
         atol = 1e-2 if k.endswith("running_mean") else 3e-6
         np.testing.assert_allclose(v.numpy(), g["b_" + k.replace(".", "_")], rtol=3e-5, atol=atol)
+
+
+def test_g9_postprocessing_vs_real_get_predictions(golden_dir):
+    """G9: the event table of the REAL evaluation_measures.get_predictions + ManyHotEncoder.decode_strong (run with
+    the oracle's two dcase_util restatements bound in) against the oracle's own predictions()."""
+    from oracle import postprocess_np as pp
+    g = _load(golden_dir, "g9_predictions.npz")
+    post = synth.make_posteriors(0, 6, 78).numpy()
+    labels = [str(x) for x in g["labels"]]
+    dec = np.stack([pp.filter_decisions(s) for s in post])
+    np.testing.assert_array_equal(dec, g["decisions"])
+    rows = pp.predictions(post, [f"clip_{i}.wav" for i in range(6)], labels, int(g["pooling_time_ratio"]),
+                          int(g["sample_rate"]), int(g["hop_length"]), 0.5, int(g["median_window"]))
+    assert len(rows) == len(g["onset"]) == 289
+    assert [r[0] for r in rows] == [str(x) for x in g["event_label"]]
+    assert [r[3] for r in rows] == [str(x) for x in g["filename"]]
+    np.testing.assert_array_equal(np.array([r[1] for r in rows]), g["onset"])
+    np.testing.assert_array_equal(np.array([r[2] for r in rows]), g["offset"])
+    # the hand-placed edge cases of clip 0 (oracle/synth.py make_posteriors)
+    d0 = dec[0]
+    assert d0[:, 0].all() and not d0[:, 1].any() and not d0[:, 7].any()          # all on / all off / p == threshold
+    assert not d0[:, 3][:25].any() and d0[30:33, 3].all()                         # 1- and 2-frame blips removed, 3 kept
+    assert d0[:, 4][:25].all() and not d0[30:33, 4].any()                         # 1- and 2-frame gaps filled, 3 kept

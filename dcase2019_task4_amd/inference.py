@@ -54,24 +54,28 @@ def get_predictions(model, valid_dataset, decoder, pooling_time_ratio=1, save_pr
         raise _lib.SedError("get_predictions needs the model on the GPU (no CPU fallback)")
     was_training = model.training
     model.eval()
-    frames = []
+    frames, cols, stage = [], [], None
     n = len(valid_dataset)
     filenames = valid_dataset.filenames
     try:
         with torch.no_grad():
             for i0 in range(0, n, batch_size):
                 idx = range(i0, min(n, i0 + batch_size))
-                x = torch.stack([torch.as_tensor(valid_dataset[i][0]) for i in idx]).to(dev, non_blocking=True).float()
+                items = [torch.as_tensor(valid_dataset[i][0]) for i in idx]
+                if stage is None or stage.shape[1:] != items[0].shape or stage.dtype != items[0].dtype:
+                    # one reusable pinned staging buffer: a fresh pageable torch.stack per batch cost more than the forward
+                    stage = torch.empty((batch_size,) + tuple(items[0].shape), dtype=items[0].dtype).pin_memory()
+                for k, it in enumerate(items):
+                    stage[k].copy_(it)
+                x = stage[:len(items)].to(dev, non_blocking=True).float()
                 strong, _ = model(x)
                 if labels is not None:
                     cnt, pairs = postprocess(strong, threshold, cfg.median_window)
-                    cnt, pairs = cnt.cpu().numpy(), pairs.cpu().numpy()
-                    for k, i in enumerate(idx):
-                        ev = [(labels[c], int(pairs[k, c, e, 0]), int(pairs[k, c, e, 1]))
-                              for c in range(len(labels)) for e in range(int(cnt[k, c]))]
-                        pred = pd.DataFrame(ev, columns=["event_label", "onset", "offset"])
-                        pred["filename"] = filenames.iloc[i]
-                        frames.append(pred)
+                    # compact on the device: rows ordered (clip, class, event) = the order of the reference's nested loops
+                    keep = torch.arange(pairs.shape[2], device=dev)[None, None, :] < cnt[:, :, None]
+                    k_idx, c_idx, _ = torch.nonzero(keep, as_tuple=True)
+                    ev = pairs[keep]                                        # [n_events, 2]
+                    cols.append((k_idx.cpu().numpy() + i0, c_idx.cpu().numpy(), ev.cpu().numpy()))
                 else:
                     _, _, binary = postprocess(strong, threshold, cfg.median_window, want_binary=True)
                     binary = binary.cpu().numpy().astype(int)
@@ -81,7 +85,20 @@ def get_predictions(model, valid_dataset, decoder, pooling_time_ratio=1, save_pr
                         frames.append(pred)
     finally:
         model.train(was_training)
-    prediction_df = pd.concat(frames) if frames else pd.DataFrame(columns=["event_label", "onset", "offset", "filename"])
+    if labels is not None:
+        # ONE DataFrame for the whole set, equal to the reference's concatenation of per-clip frames (including its
+        # per-clip 0..k-1 index); building 1 168 small DataFrames on the host cost more than all the device work
+        clip = np.concatenate([c[0] for c in cols]) if cols else np.zeros(0, dtype=np.int64)
+        cls = np.concatenate([c[1] for c in cols]) if cols else np.zeros(0, dtype=np.int64)
+        ev = np.concatenate([c[2] for c in cols]) if cols else np.zeros((0, 2), dtype=np.int32)
+        starts = np.r_[0, np.flatnonzero(np.diff(clip)) + 1] if len(clip) else np.zeros(0, dtype=np.int64)
+        index = np.arange(len(clip)) - np.repeat(starts, np.diff(np.r_[starts, len(clip)])) if len(clip) else clip
+        prediction_df = pd.DataFrame({"event_label": np.asarray(labels, dtype=object)[cls],
+                                      "onset": ev[:, 0].astype(np.int64), "offset": ev[:, 1].astype(np.int64),
+                                      "filename": np.asarray(filenames)[clip]}, index=index,
+                                     columns=["event_label", "onset", "offset", "filename"])
+    else:
+        prediction_df = pd.concat(frames) if frames else pd.DataFrame(columns=["event_label", "onset", "offset", "filename"])
     # In seconds (evaluation_measures.py:225-227)
     prediction_df.onset = prediction_df.onset * pooling_time_ratio / (cfg.sample_rate / cfg.hop_length)
     prediction_df.offset = prediction_df.offset * pooling_time_ratio / (cfg.sample_rate / cfg.hop_length)

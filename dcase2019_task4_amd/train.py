@@ -17,6 +17,7 @@ import ctypes as C
 import os
 import time
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -242,6 +243,63 @@ class MeanTeacherStep:
     def read_state(self):
         raw = bytes(self.state.cpu().numpy().tobytes())
         return _lib.SedStepState.from_buffer_copy(raw)
+
+    # ---- checkpoint / true resume (the reference can save but not resume, main.py:293-354) -------
+    def optimizer_state_dict(self):
+        """The Adam state in torch.optim.Adam's own state_dict layout (what main.py:302-305 stores under
+        state['optimizer']['state_dict']), so the checkpoint stays loadable by stock torch."""
+        st = self.read_state()
+        params = list(self.student.parameters())
+        state = {}
+        for i, ((o0, o1, shp), _) in enumerate(zip(self.student._layout, params)):
+            state[i] = {"step": torch.tensor(float(st.opt_step - 1)),
+                        "exp_avg": self.exp_avg[o0:o1].reshape(shp).detach().cpu().clone(),
+                        "exp_avg_sq": self.exp_avg_sq[o0:o1].reshape(shp).detach().cpu().clone()}
+        group = {"lr": st.lr, "betas": (st.beta1, st.beta2), "eps": st.eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        for i, (o0, o1, _) in enumerate(self.student._layout):
+            if i in sd["state"]:
+                self.exp_avg[o0:o1].copy_(sd["state"][i]["exp_avg"].reshape(-1))
+                self.exp_avg_sq[o0:o1].copy_(sd["state"][i]["exp_avg_sq"].reshape(-1))
+
+    def state_dict(self):
+        """Everything a bit-exact resume needs: both models in the reference's nested checkpoint layout (plus the
+        attention layer it drops, CRNN.py:49-53), the Adam moments, and the device step state (step counters - hence
+        the ramp-up, EMA alpha, bias corrections - and the dropout / noise seed chain)."""
+        return {"format": 1,
+                "model": {k: {n: t.detach().cpu().clone() for n, t in v.items()} for k, v in self.student.state_dict().items()},
+                "model_ema": ({k: {n: t.detach().cpu().clone() for n, t in v.items()}
+                               for k, v in self.teacher.state_dict().items()} if self.teacher is not None else None),
+                "optimizer": self.optimizer_state_dict(),
+                "step_state": bytes(self.state.cpu().numpy().tobytes()),
+                "steps_done": self.steps_done}
+
+    def load_state_dict(self, sd):
+        assert sd.get("format") == 1, "unknown checkpoint format"
+        self.student.load(parameters=sd["model"])
+        if self.teacher is not None and sd.get("model_ema") is not None:
+            self.teacher.load(parameters=sd["model_ema"])
+        self.student.flatten_parameters_(self.device)
+        if self.teacher is not None:
+            self.teacher.flatten_parameters_(self.device)
+        self.load_optimizer_state_dict(sd["optimizer"])
+        raw = np.frombuffer(sd["step_state"], dtype=np.uint8).copy()
+        assert raw.size == self.state.numel(), "step state size mismatch"
+        self.state.copy_(torch.from_numpy(raw))
+        self.steps_done = int(sd.get("steps_done", 0))
+        torch.cuda.synchronize(self.device)
+
+    def save_checkpoint(self, path, extra=None):
+        torch.save(dict(self.state_dict(), **(extra or {})), path)
+
+    def load_checkpoint(self, path):
+        sd = torch.load(path, map_location="cpu", weights_only=False)
+        self.load_state_dict(sd)
+        return sd
 
 
 def train(train_loader, model, optimizer, epoch, ema_model=None, weak_mask=None, strong_mask=None, n_epoch=100,

@@ -372,3 +372,51 @@ def test_checkpoint_roundtrip_reference_format(tmp_path):
     with torch.no_grad():
         s1, w1 = m2(x)
     assert torch.equal(s0, s1) and torch.equal(w0, w1)
+
+
+def test_checkpoint_resume_is_bit_exact(tmp_path):
+    """N4: save after 2 steps, keep training 2 more; a FRESH pair of models + step object restored from the file must
+    reproduce those 2 steps bit for bit (dropout on: the seed chain is part of the state), as eager and as hipGraph."""
+    from dcase2019_task4_amd.train import MeanTeacherStep
+    B, T = 8, 216
+    tgt, wm, sm = synth.make_target(1, B, T // 8)
+    xs = [synth.make_input(60 + i, B, T).cuda() for i in range(4)]
+    xe = [synth.make_input(70 + i, B, T).cuda() for i in range(4)]
+
+    def fresh(seed_s, seed_t, graph):
+        s, _ = gu.make_model(seed_s, dropout=0.5)
+        t, _ = gu.make_model(seed_t, dropout=0.5)
+        s.train(); t.train()
+        return MeanTeacherStep(s, t, B, T, 40, wm, sm, seed=1234, use_graph=graph)
+
+    a = fresh(0, 1, False)
+    for i in range(2):
+        a.step(xs[i], xe[i], tgt.cuda())
+    path = str(tmp_path / "ckpt.pt")
+    a.save_checkpoint(path, extra={"pooling_time_ratio": 8})
+    for i in range(2, 4):
+        a.step(xs[i], xe[i], tgt.cuda())
+    want = (a.student._flat.clone(), a.teacher._flat.clone(), a.exp_avg.clone(), a.exp_avg_sq.clone(),
+            a.student._bn_flat.clone(), a.teacher._bn_flat.clone(), a.meters())
+    for graph in (False, True):
+        b = fresh(5, 6, graph)                 # different initial weights: everything must come from the file
+        sd = b.load_checkpoint(path)
+        assert sd["pooling_time_ratio"] == 8
+        st = b.read_state()
+        assert st.global_step == 2 and st.opt_step == 3
+        if graph:
+            b._warm = 2
+        for i in range(2, 4):
+            b.step(xs[i], xe[i], tgt.cuda())
+        got = (b.student._flat, b.teacher._flat, b.exp_avg, b.exp_avg_sq, b.student._bn_flat, b.teacher._bn_flat)
+        for g_, w_ in zip(got, want[:6]):
+            assert torch.equal(g_, w_)
+        assert b.meters() == want[6]
+    # the optimiser entry is stock torch.optim.Adam's format (main.py:302-305): torch loads it
+    opt = torch.optim.Adam(a.student.parameters(), lr=0.001, betas=(0.9, 0.999))
+    opt.load_state_dict(a.optimizer_state_dict())
+    p0 = next(iter(a.student.parameters()))
+    assert torch.equal(opt.state[p0]["exp_avg"].cpu().reshape(-1), a.exp_avg[:p0.numel()].cpu())
+    # the model entries are the reference's nested layout (CRNN.py:49-53) + the attention layer it forgets
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ck["model"]) == {"cnn", "rnn", "dense", "dense_softmax"} and "conv0.weight" in ck["model"]["cnn"]

@@ -204,3 +204,41 @@ extern "C" int sed_logmel_transform(const float* mel, int n_clips, int frames, i
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
+
+// ---- Scaler statistics pass (baseline/utils/Scaler.py:34-87) ---------------------------------------------------------
+// The reference walks the whole training set on the host before training starts (main.py:249-250) and averages the
+// per-clip per-band means of x and x^2.  All clips have the same shape there (it raises otherwise), so that is the
+// plain column mean over every row of the set: one streaming pass, fp64 accumulation, per-workgroup partial sums in
+// registers -> LDS -> one fp64 atomic per column per workgroup.
+__global__ __launch_bounds__(256) void k_scaler_stats(const float* __restrict__ x, long long n_rows, int n_cols,
+                                                       double* __restrict__ sums /* [2][n_cols] */) {
+    __shared__ double red[2][256];
+    const int tid = threadIdx.x;
+    const int rows_per_pass = 256 / n_cols;              // n_cols divides 256 (checked by the launcher)
+    const int c = tid % n_cols, r0 = tid / n_cols;
+    double s = 0.0, q = 0.0;
+    for (long long r = (long long)blockIdx.x * rows_per_pass + r0; r < n_rows; r += (long long)gridDim.x * rows_per_pass) {
+        const double v = (double)x[r * n_cols + c];
+        s += v;
+        q += v * v;
+    }
+    red[0][tid] = s; red[1][tid] = q;
+    __syncthreads();
+    if (tid < n_cols) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < rows_per_pass; ++k) { a += red[0][tid + k * n_cols]; b += red[1][tid + k * n_cols]; }
+        atomicAdd(&sums[tid], a);
+        atomicAdd(&sums[n_cols + tid], b);
+    }
+}
+
+extern "C" int sed_scaler_stats(const float* x, long long n_rows, int n_cols, double* sums, void* stream) {
+    SED_CHECK_ARG(x && sums && n_rows >= 1, "sed_scaler_stats: bad argument");
+    SED_CHECK_ARG(n_cols >= 1 && n_cols <= 256 && 256 % n_cols == 0, "sed_scaler_stats: n_cols must divide 256");
+    const int rpp = 256 / n_cols;
+    long long blocks = (n_rows + rpp - 1) / rpp;
+    if (blocks > 2048) blocks = 2048;
+    k_scaler_stats<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(x, n_rows, n_cols, sums);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}

@@ -17,6 +17,7 @@ the per-clip work.
 """
 import ctypes as C
 import json
+import os
 import math
 from dataclasses import dataclass
 
@@ -121,6 +122,38 @@ class FeatureExtractor:
         return out[0].cpu().numpy()
 
 
+class FeatureCache:
+    """The reference's on-disk feature cache (DatasetDcase2019Task4.py:183-195, 233-269): one
+    ``<feature_dir>/<splitext(filename)[0]>.npy`` per audio file holding float32 [frames, n_mels] (linear mel,
+    save_log_feature=False), so that baseline/main.py consumes GPU-extracted features unchanged."""
+
+    def __init__(self, feature_dir, extractor=None):
+        self.feature_dir = feature_dir
+        self.extractor = extractor
+        os.makedirs(feature_dir, exist_ok=True)
+
+    def path(self, filename):
+        return os.path.join(self.feature_dir, os.path.splitext(filename)[0] + ".npy")
+
+    def get_feature_file(self, filename):
+        """DatasetDcase2019Task4.get_feature_file: the ``get_feature_file_func`` DataLoadDf expects."""
+        return np.load(self.path(filename))
+
+    def extract_features(self, filenames, waves, batch_size=64, overwrite=False):
+        """Compute and store the features of ``waves`` (equal-length float arrays, one per filename) ``batch_size`` clips
+        per launch; files that already exist are kept (DatasetDcase2019Task4.py:255), returns the number written."""
+        if self.extractor is None:
+            raise ValueError("FeatureCache.extract_features needs a FeatureExtractor")
+        todo = [i for i, f in enumerate(filenames) if overwrite or not os.path.exists(self.path(f))]
+        for i0 in range(0, len(todo), batch_size):
+            idx = todo[i0:i0 + batch_size]
+            mel = self.extractor.calculate_mel_spec_batch(torch.as_tensor(np.stack([np.asarray(waves[i], dtype=np.float32)
+                                                                                    for i in idx]))).cpu().numpy()
+            for k, i in enumerate(idx):
+                np.save(self.path(filenames[i]), mel[k])
+        return len(todo)
+
+
 class Scaler:
     """baseline/utils/Scaler.py: per-mel mean / mean-of-square in float64 over a dataset."""
 
@@ -143,6 +176,28 @@ class Scaler:
             n += 1
         self.mean_ = self.mean_ / n
         self.mean_of_square_ = self.mean_of_square_ / n
+        self.std_ = np.sqrt(self.mean_of_square_ - self.mean_ ** 2)
+        return self.mean_, self.std_
+
+    def calculate_scaler_device(self, batches):
+        """The same statistics from device batches: ``batches`` yields cuda float32 tensors [..., n_mels] of equal
+        clip shape (e.g. the [N, 1, T, 64] output of LogMelTransform(frames) without a scaler, as main.py:212,249
+        feeds the reference's Scaler).  One streaming fp64 pass on the GPU instead of a host loop over the set."""
+        l = _lib.lib()
+        sums, rows, n_mels = None, 0, None
+        for x in batches:
+            if x.device.type != "cuda":
+                raise _lib.SedError("calculate_scaler_device needs GPU tensors (no CPU fallback)")
+            x = x.contiguous().float()
+            if sums is None:
+                n_mels = x.shape[-1]
+                sums = torch.zeros(2 * n_mels, dtype=torch.float64, device=x.device)
+            r = x.numel() // n_mels
+            _lib.check(l.sed_scaler_stats(_lib.ptr(x), r, n_mels, _lib.ptr(sums), _lib.stream_ptr()), "sed_scaler_stats")
+            rows += r
+        sums = sums.cpu().numpy()
+        self.mean_ = sums[:n_mels] / rows
+        self.mean_of_square_ = sums[n_mels:] / rows
         self.std_ = np.sqrt(self.mean_of_square_ - self.mean_ ** 2)
         return self.mean_, self.std_
 

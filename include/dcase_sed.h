@@ -178,6 +178,12 @@ int sed_logmel_transform(const float* mel, int n_clips, int frames, int n_mels, 
                          const double* mean, const double* std, const uint64_t* seed_dev,
                          float* out_clean, float* out_noisy, void* stream);
 
+/* Scaler statistics (baseline/utils/Scaler.py:34-87 `means`): ADDS sum(x) and sum(x^2) per column of
+ * x [n_rows][n_cols] (fp32, e.g. log-mel frames x mel bands) to sums[0..n_cols) / sums[n_cols..2n_cols)
+ * (fp64, zero them before the first batch); n_cols must divide 256.  mean_ = sums[0] / rows,
+ * mean_of_square_ = sums[1] / rows over the whole set (equal clip shapes, as the reference requires). */
+int sed_scaler_stats(const float* x, long long n_rows, int n_cols, double* sums, void* stream);
+
 /* ---- inference post-processing ---------------------------------------------------------------
  * Replaces the per-clip host loop of get_predictions (evaluation_measures.py:203-231) after the
  * forward: ProbabilityEncoder().binarization(global_threshold) -> scipy.ndimage median_filter

@@ -1,6 +1,8 @@
 """-m gpu parity of the feature front-end (csrc/feat.hip through the C-ABI) against the numpy oracle.
 Tolerances: linear mel relative 1e-6 of the clip maximum (fp64 FFT, fp32 output rounding); dB-domain
 features 1e-4 dB before normalisation."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -123,3 +125,36 @@ def test_config3_raw_waveform_batch64_mean_teacher_step():
     a = 1.0 - 1.0 / 3.0
     np.testing.assert_allclose(teacher._flat.cpu().numpy(), (a * t1 + (1 - a) * student._flat).cpu().numpy(), atol=1e-6)
     assert all(np.isfinite(v) for v in st.meters().values())
+
+
+def test_feature_cache_and_device_scaler_pass(tmp_path):
+    """N2: the .npy feature cache in the reference's layout (DatasetDcase2019Task4.py:183-195,255-262) written from
+    batched GPU extraction, read back through get_feature_file; Scaler statistics from one device pass equal the
+    reference's host loop (restated in features.Scaler.calculate_scaler, pinned by G6) to fp64 round-off."""
+    from dcase2019_task4_amd.features import FeatureCache, FeatureConfig, FeatureExtractor, LogMelTransform, Scaler
+    cfg = FeatureConfig.baseline_16k()
+    fe = FeatureExtractor(cfg)
+    n = 10
+    names = [f"Y{i:03d}_0.000_10.000.wav" for i in range(n)]
+    waves = [synth.make_wave(i, 160000).astype(np.float32) for i in range(n)]
+    cache = FeatureCache(str(tmp_path / "features"), fe)
+    assert cache.extract_features(names, waves, batch_size=4) == n
+    assert cache.extract_features(names, waves, batch_size=4) == 0               # existing files are kept
+    for i in (0, 3, 9):
+        f = cache.get_feature_file(names[i])
+        assert f.dtype == np.float32 and f.shape == (628, 64)
+        assert os.path.basename(cache.path(names[i])) == f"Y{i:03d}_0.000_10.000.npy"
+        np.testing.assert_array_equal(f, fe.calculate_mel_spec(waves[i]))        # batched == the single-clip call
+        want = features_np.calculate_mel_spec(waves[i].astype(np.float64), cfg.sample_rate, cfg.n_window, cfg.hop_length,
+                                              cfg.n_mels, cfg.f_min, cfg.f_max)
+        np.testing.assert_allclose(f, want, rtol=2e-6, atol=1e-6 * want.max())
+    # Scaler: the reference computes it on log-mel, padded, un-normalised clips (main.py:212,249-250)
+    mels = np.stack([cache.get_feature_file(nm) for nm in names])
+    host = Scaler()
+    host.calculate_scaler([features_np.transform_chain(m, 628) for m in mels])
+    dev = Scaler()
+    tr = LogMelTransform(628)
+    dev.calculate_scaler_device(tr(torch.tensor(mels[i0:i0 + 4]).cuda()) for i0 in range(0, n, 4))
+    np.testing.assert_allclose(dev.mean_, host.mean_, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(dev.std_, host.std_, rtol=1e-6)
+    np.testing.assert_allclose(dev.mean_of_square_, host.mean_of_square_, rtol=1e-6)

@@ -35,6 +35,8 @@ class SedStepState(C.Structure):
 _P = C.c_void_p
 _SIGS = {
     "sed_last_error": (C.c_char_p, []),
+    "sed_resample": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                               C.c_int, C.c_void_p]),
     "sed_scaler_stats": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p]),
     "sed_postprocess": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int, C.c_void_p]),

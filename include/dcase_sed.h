@@ -178,6 +178,17 @@ int sed_logmel_transform(const float* mel, int n_clips, int frames, int n_mels, 
                          const double* mean, const double* std, const uint64_t* seed_dev,
                          float* out_clean, float* out_noisy, void* stream);
 
+/* Resampling step of read_audio (utils/utils.py:175-193: librosa.resample(audio, orig_sr, target_sr),
+ * res_type "kaiser_best" = resampy's windowed-sinc interpolation, then fix_length).
+ *   x [n_clips][n_in] fp64 (soundfile.read returns float64; channels already averaged)
+ *   ratio = target_sr / orig_sr;  interp_win [nwin] fp64 = right half of the Kaiser-windowed sinc with
+ *   num_table samples per zero crossing, already multiplied by ratio when ratio < 1 (as resampy does)
+ *   time_reg [int(n_in * ratio)] fp64 = resampy's running sum 0, 1/ratio, 1/ratio + 1/ratio, ... (exactly as a
+ *   sequential loop rounds it: numpy.cumsum), or NULL for t * (1/ratio)
+ *   y [n_clips][n_out] fp64, n_out = ceil(n_in * ratio); samples past int(n_in * ratio) are 0.       */
+int sed_resample(const double* x, int n_clips, int n_in, double ratio, const double* interp_win, int nwin,
+                 int num_table, const double* time_reg, double* y, int n_out, void* stream);
+
 /* Scaler statistics (baseline/utils/Scaler.py:34-87 `means`): ADDS sum(x) and sum(x^2) per column of
  * x [n_rows][n_cols] (fp32, e.g. log-mel frames x mel bands) to sums[0..n_cols) / sums[n_cols..2n_cols)
  * (fp64, zero them before the first batch); n_cols must divide 256.  mean_ = sums[0] / rows,

@@ -190,9 +190,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     pg = None
-    if world > 1:
+    if world > 1 or os.environ.get("SED_FORCE_DP") == "1":      # SED_FORCE_DP: one-rank RCCL group (path test on a 1-GPU box)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         pg = dist.group.WORLD
 

@@ -64,11 +64,12 @@ def grad_buckets(layout):
     return (cnn_end, total), (0, cnn_end)
 
 
-def allreduce_bucket(flat, lo, hi, group=None, async_op=False):
-    """Sum all-reduce of flat[lo:hi] in place; returns the work handle when async_op."""
+def allreduce_bucket(flat, lo, hi, group=None, async_op=False, force=False):
+    """Sum all-reduce of flat[lo:hi] in place; returns the work handle when async_op.  A one-rank group is a no-op
+    unless ``force`` (path test of the collective on a single-GPU box)."""
     if group is None and not dist.is_initialized():
         return None
-    if dist.get_world_size(group) == 1:
+    if dist.get_world_size(group) == 1 and not force:
         return None
     return dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 

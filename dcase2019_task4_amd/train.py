@@ -112,6 +112,16 @@ class MeanTeacherStep:
         if process_group is not None:
             import torch.distributed as dist
             self.world = dist.get_world_size(process_group)
+        # the data-parallel schedule (split backward, bucketed all-reduce between graph segments); SED_FORCE_DP=1 takes
+        # it with a one-rank group too, so that the whole RCCL path can be exercised on a single-GPU box
+        self.dp = process_group is not None and (self.world > 1 or os.environ.get("SED_FORCE_DP") == "1")
+        # "single" (default): whole backward in one call / graph, ONE all-reduce of the flat gradient buffer (857 KB),
+        # then the update.  "split": backward part 1 | all-reduce(GRU + heads bucket) overlapping part 2 | all-reduce
+        # (conv bucket) | update - measured slower: to finish the first bucket early the GRU weight-gradient GEMMs
+        # must run on the critical path (+70 us) instead of next to the conv backward, and the step gains a third
+        # graph segment; at these message sizes the all-reduce it hides is latency-bound (tens of us).
+        self.dp_split = os.environ.get("SED_DP_SCHEDULE", "single") == "split"
+        if process_group is not None:
             # replicas must start identical (the reference has one copy; DDP convention: rank 0 wins)
             sdist.broadcast_parameters([student._flat] + ([teacher._flat] if teacher is not None else []), process_group)
         self.use_graph = bool(use_graph)
@@ -154,7 +164,7 @@ class MeanTeacherStep:
         # one process: the whole backward in ONE call (parts = 3), which lets the library overlap the GRU weight
         # gradients with the conv-block backward; data-parallel: part 1 here, part 2 after its bucket's all-reduce
         # has been started (run())
-        self._backward(3 if self.world == 1 else 1)
+        self._backward(1 if (self.dp and self.dp_split) else 3)
 
     def _backward(self, parts):
         _lib.check(self.l.sed_crnn_backward(C.byref(self.dims), _lib.ptr(self.student._flat), _lib.ptr(self.x),
@@ -193,12 +203,19 @@ class MeanTeacherStep:
         graph = self.use_graph and self._warm >= 2
         if graph and self._graph_a is None:
             self._capture()
-        if self.world == 1:
+        if not self.dp:
             if graph:
                 self._graph_a.replay()
             else:
                 self._fwd_bwd()
                 self._update()
+        elif not self.dp_split:
+            # forward + loss + backward | all-reduce(all gradients) | update
+            self._graph_a.replay() if graph else self._fwd_bwd()
+            w = sdist.allreduce_bucket(self.grads, 0, self.n, self.pg, async_op=True, force=True)
+            if w is not None:
+                w.wait()
+            self._graph_b.replay() if graph else self._update()
         else:
             # forward + loss + backward part 1 | all-reduce(tail) || backward part 2 | all-reduce(head) | update
             self._graph_a.replay() if graph else self._fwd_bwd()
@@ -219,12 +236,13 @@ class MeanTeacherStep:
 
     def _capture(self):
         torch.cuda.synchronize(self.device)
-        if self.world > 1:
+        if self.dp:
             ga, ga2, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga):
                 self._fwd_bwd()
-            with torch.cuda.graph(ga2):
-                self._backward(2)
+            if self.dp_split:
+                with torch.cuda.graph(ga2):
+                    self._backward(2)
             with torch.cuda.graph(gb):
                 self._update()
             self._graph_a, self._graph_a2, self._graph_b = ga, ga2, gb

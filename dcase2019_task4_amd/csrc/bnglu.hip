@@ -218,8 +218,8 @@ __device__ __forceinline__ void bn_bwd_prep_body(const BnBwdPrepArgs& a, int tid
 
 __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ y, const float* __restrict__ bn,
                                                        const float* __restrict__ wglu, const float* __restrict__ bglu,
-                                                       const float* __restrict__ dp, float* __restrict__ dz,
-                                                       double* __restrict__ accg, int H, int W, int Ho, int Wo, int Q,
+                                                       const float* __restrict__ dp, const float* __restrict__ dp_b,
+                                                       float* __restrict__ dz, double* __restrict__ accg, int H, int W, int Ho, int Wo, int Q,
                                                        int block_id, int use_drop, float p_drop,
                                                        const uint16_t* __restrict__ mask_in, int no_atomic, BnBwdPrepArgs prep) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -306,7 +306,9 @@ __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ 
         yt_n.v[k] = *(const float4*)((const char*)y + (po_n[k >> 1] + (uint32_t)((k & 1) * W) * 256u + ld_off));
         const int h = k >> 2, jx = k & 3;
         const int q = q_n + jx;
-        gq_n[h][jx] = *(const float*)((const char*)dp + (uint32_t)((q < Q ? q : 0) * 64 + 32 * h + n) * 4u);
+        const uint32_t goff = (uint32_t)((q < Q ? q : 0) * 64 + 32 * h + n) * 4u;
+        gq_n[h][jx] = *(const float*)((const char*)dp + goff);
+        if (dp_b) gq_n[h][jx] += *(const float*)((const char*)dp_b + goff);     // second direction plane of the GRU's dX
         if (q >= Q) gq_n[h][jx] = 0.f;
         if (jx == 0) m_n[h] = use_drop ? (uint32_t)mask_in[((size_t)(q_n >> 2) * 2 + h) * 64 + lane] : 0xffffu;
     };
@@ -512,8 +514,8 @@ int launch_glu_pool_fwd(const float* y, const double* stat, double N, const floa
     return SED_OK;
 }
 
-int launch_glu_pool_bwd(const float* y, const float* bn, const float* wglu, const float* bglu, const float* dp, float* dz,
-                        double* acc, int zero_acc, int B, int H, int W, int block_id, int use_drop, float p_drop,
+int launch_glu_pool_bwd(const float* y, const float* bn, const float* wglu, const float* bglu, const float* dp,
+                        const float* dp_b, float* dz, double* acc, int zero_acc, int B, int H, int W, int block_id, int use_drop, float p_drop,
                         const uint16_t* mask_in, const float* gamma, float* coef, float* g_gamma, float* g_beta, float* g_wglu,
                         float* g_bglu, float* g_convb, hipStream_t st) {
     const int Ho = H / 2, Wo = W / 4, Q = B * Ho * Wo;
@@ -530,7 +532,7 @@ int launch_glu_pool_bwd(const float* y, const float* bn, const float* wglu, cons
     const int n_rb = (Q + 3) / 4;
     int grid = (n_rb + 3) / 4;
     if (grid > 256) grid = 256;
-    k_glu_pool_bwd<<<grid, 256, lds, st>>>(y, bn, wglu, bglu, dp, dz, acc, H, W, Ho, Wo, Q, block_id, use_drop, p_drop, mask_in, g_sed_debug & 1, a);
+    k_glu_pool_bwd<<<grid, 256, lds, st>>>(y, bn, wglu, bglu, dp, dp_b, dz, acc, H, W, Ho, Wo, Q, block_id, use_drop, p_drop, mask_in, g_sed_debug & 1, a);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

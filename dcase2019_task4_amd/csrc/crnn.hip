@@ -108,8 +108,8 @@ WsLayout make_ws_layout(const Geo& g) {
     const size_t n0 = (size_t)g.B * g.H1 * g.W1 * 64, n1 = (size_t)g.B * g.H2 * g.W2 * 64, bt = (size_t)g.B * g.T3;
     put(W.d_out, bt * 128 * 4);
     for (int l = 0; l < 2; ++l) { put(W.dgi[l], bt * 384 * 4); put(W.dgh[l], bt * 384 * 4); put(W.hprev[l], bt * 128 * 4); }
-    put(W.d_in, bt * 128 * 4); put(W.heads_part, (size_t)g.B * 2 * (g.NC * 128 + g.NC) * 4);
-    put(W.dp2, bt * 64 * 4); put(W.dz2, n1 * 4); put(W.dp1, n1 * 4); put(W.dz1, n0 * 4); put(W.dp0, n0 * 4);
+    put(W.d_in, 2 * bt * 128 * 4); put(W.heads_part, (size_t)g.B * 2 * (g.NC * 128 + g.NC) * 4);
+    put(W.dp2, 2 * bt * 64 * 4); put(W.dz2, n1 * 4); put(W.dp1, n1 * 4); put(W.dz1, n0 * 4); put(W.dp0, n0 * 4);
     put(W.bnb, 256 * sizeof(double)); W.coef[0] = 0; put(W.coef[1], 192 * 4); put(W.coef[2], 192 * 4);
     put(W.bwd_acc, (2 * SED_GLUACC_N + 2 * 64 * 10) * sizeof(double));
     W.gluacc1 = W.bwd_acc; W.gluacc2 = W.bwd_acc + SED_GLUACC_N * sizeof(double); W.de0 = W.bwd_acc + 2 * SED_GLUACC_N * sizeof(double);
@@ -300,21 +300,19 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
                              use_drop, g.p, seed_dev, (parts & 2) ? WSD(W.bwd_acc) : nullptr, 2 * SED_GLUACC_N + 2 * 64 * 10,
                              (parts & 2) && sd.ok ? 1 : 0, st));
     // ---- BiGRU ----------------------------------------------------------------------------------
+    // The gradient w.r.t. each layer's input is produced INSIDE the recurrence kernel (two extra waves, one block of
+    // steps behind), as two direction planes [2][B*T'][nin] that the consumer adds while loading: the layer below's
+    // recurrence kernel, or k_glu_pool_bwd for layer 0 (planes in W.dp2).
     const float* d_cur = WSF(W.d_out);
+    const float* d_cur2 = nullptr;
     for (int l = g.L - 1; l >= 0; --l) {
         const int nin = (l == 0) ? 64 : 128;
         float* d_in = (l == 0) ? WSF(W.dp2) : WSF(W.d_in);
-        SED_TRY(launch_gru_bwd(d_cur, CTXF(L.out[l]), CTXF(L.gates[l]), params + P.w_hh[l][0], params + P.w_hh[l][1],
-                               WSF(W.dgi[l]), WSF(W.dgh[l]), WSF(W.hprev[l]), g.B, g.T3, st));
-        {
-            // d_in[bt][i] = sum_{dir,g} dgi[bt][dir][g] W_ih[dir][g][i]   (K = 384 = both directions)
-            GemmBatch gb;
-            gb.n_prob = 1; gb.splits = 1; gb.part = nullptr; gb.part_stride = 0;
-            gb.p[0] = gemm_prob(WSF(W.dgi[l]), 384, 1, params + P.w_ih[l][0], nin, 1, d_in, nin, BT, nin, 384);
-            gb.p[0].B2 = params + P.w_ih[l][1]; gb.p[0].k2 = 192;
-            SED_TRY(launch_gemm_batch(gb, st));
-        }
+        SED_TRY(launch_gru_bwd(d_cur, d_cur2, CTXF(L.out[l]), CTXF(L.gates[l]), params + P.w_hh[l][0], params + P.w_hh[l][1],
+                               params + P.w_ih[l][0], params + P.w_ih[l][1], nin, WSF(W.dgi[l]), WSF(W.dgh[l]),
+                               WSF(W.hprev[l]), d_in, g.B, g.T3, st));
         d_cur = d_in;
+        d_cur2 = d_in + (size_t)BT * nin;
     }
     }
     // weight + bias gradients of every GRU layer and direction (split-K MFMA GEMMs, low occupancy):
@@ -361,6 +359,7 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
         // (the BatchNorm-backward coefficients and the block's parameter gradients are produced by the last workgroup
         // of k_glu_pool_bwd: no separate 1-workgroup kernel between it and the conv dgrad / wgrad)
         SED_TRY(launch_glu_pool_bwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], WSF(dpo[i]),
+                                    i == 2 ? WSF(dpo[i]) + (size_t)BT * 64 : nullptr,
                                     WSF(dzo[i]), WSD(gacc[i]), 0, g.B, Hs[i], Wd[i], i, use_drop, g.p, CTXM(mo[i]),
                                     params + P.bn_g[i], WSF(W.coef[i]), grads + P.bn_g[i], grads + P.bn_b[i],
                                     grads + P.glu_w[i], grads + P.glu_b[i], grads + P.conv_b[i], st));
@@ -440,7 +439,7 @@ extern "C" int sed_kernel_replay(const char* name, const sed_dims* d, const floa
                                                params + P.glu_w[i], params + P.glu_b[i], CTXF(po[i]), g.B, Hs[i], Wd[i], i, use_drop,
                                                g.p, seed_dev, use_drop ? CTXM(mo[i]) : nullptr, st);
         snprintf(nm, sizeof nm, "glu%d_bwd", i);
-        if (is(nm)) return launch_glu_pool_bwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], WSF(dpo[i]), WSF(dzo[i]), WSD(gacc[i]), 1, g.B, Hs[i], Wd[i], i, use_drop, g.p, CTXM(mo[i]),
+        if (is(nm)) return launch_glu_pool_bwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], WSF(dpo[i]), i == 2 ? WSF(dpo[i]) + (size_t)BT * 64 : nullptr, WSF(dzo[i]), WSD(gacc[i]), 1, g.B, Hs[i], Wd[i], i, use_drop, g.p, CTXM(mo[i]),
                                                params + P.bn_g[i], WSF(W.coef[i]), grads + P.bn_g[i], grads + P.bn_b[i], grads + P.glu_w[i], grads + P.glu_b[i], grads + P.conv_b[i], st);
         snprintf(nm, sizeof nm, "conv%d_wgrad", i);
         if (is(nm)) return launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(po[i - 1]), WSF(W.wg_part), W.wgrad_blocks, grads + P.conv_w[i], g.B, Hs[i], Wd[i], st);
@@ -452,7 +451,14 @@ extern "C" int sed_kernel_replay(const char* name, const sed_dims* d, const floa
         snprintf(nm, sizeof nm, "gru%d_fwd", l);
         if (is(nm)) return launch_gru_fwd(CTXF(L.gi[l]), params + P.w_hh[l][0], params + P.w_hh[l][1], params + P.b_hh[l][0], params + P.b_hh[l][1], CTXF(L.out[l]), CTXF(L.gates[l]), g.B, g.T3, st);
         snprintf(nm, sizeof nm, "gru%d_bwd", l);
-        if (is(nm)) return launch_gru_bwd(l == g.L - 1 ? WSF(W.d_out) : WSF(W.d_in), CTXF(L.out[l]), CTXF(L.gates[l]), params + P.w_hh[l][0], params + P.w_hh[l][1], WSF(W.dgi[l]), WSF(W.dgh[l]), WSF(W.hprev[l]), g.B, g.T3, st);
+        if (is(nm)) {
+            const int nin = (l == 0) ? 64 : 128;
+            const bool top = (l == g.L - 1);
+            return launch_gru_bwd(top ? WSF(W.d_out) : WSF(W.d_in), top ? nullptr : WSF(W.d_in) + (size_t)BT * 128, CTXF(L.out[l]),
+                                  CTXF(L.gates[l]), params + P.w_hh[l][0], params + P.w_hh[l][1], params + P.w_ih[l][0],
+                                  params + P.w_ih[l][1], nin, WSF(W.dgi[l]), WSF(W.dgh[l]), WSF(W.hprev[l]),
+                                  l == 0 ? WSF(W.dp2) : WSF(W.d_in), g.B, g.T3, st);
+        }
     }
     if (is("heads_fwd"))
         return launch_heads_fwd(CTXF(L.out[g.L - 1]), params + P.dense_w, params + P.dense_b, params + P.soft_w, params + P.soft_b,

@@ -152,16 +152,26 @@ __global__ __launch_bounds__(128) void k_gru_fwd(const float* __restrict__ gi, c
 // ---------------------------------------------------------------------------------------------------------
 // Backward through time.  Per step inputs: d_out, r, z, n, gh_n, h_prev (6 rows of 64); outputs: dgi (192),
 // dgh (192), h_prev (64) = 7 rows of 64.
-__global__ __launch_bounds__(128) void k_gru_bwd(const float* __restrict__ d_out, const float* __restrict__ out,
-                                                  const float* __restrict__ gates, const float* __restrict__ w_hh_f,
-                                                  const float* __restrict__ w_hh_r, float* __restrict__ dgi,
-                                                  float* __restrict__ dgh, float* __restrict__ hprev_out, int T) {
+// Waves 2 and 3 compute this direction's share of the gradient w.r.t. the layer input,
+//   dX_dir[t][i] = sum_g dgi[t][g] W_ih[dir][g][i],
+// one block of GRU_SB time steps behind the recurrence, straight from the LDS history ring the compute wave fills
+// (v_mfma_f32_16x16x4_f32, the W_ih fragments - 96 KB per direction - live in the two waves' registers).  That GEMM
+// used to be a kernel of its own after the recurrence (16 us per layer on the critical path of the step); the two
+// directions write separate planes which the consumer adds while loading.
+#define GRU_HS 452        // history row stride: 448 + 4, so that the (row = lane & 15, col = 4s + lane >> 4) reads are conflict free
+template <int NIN>
+__global__ __launch_bounds__(256) void k_gru_bwd(const float* __restrict__ d_out, const float* __restrict__ d_out2,
+                                                  const float* __restrict__ out, const float* __restrict__ gates,
+                                                  const float* __restrict__ w_hh_f, const float* __restrict__ w_hh_r,
+                                                  const float* __restrict__ w_ih_f, const float* __restrict__ w_ih_r,
+                                                  float* __restrict__ dgi, float* __restrict__ dgh,
+                                                  float* __restrict__ hprev_out, float* __restrict__ dx_planes, int B, int T) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     float* dghs = gsm;                                // [192]
     float* ops = dghs + 192;                          // [2][GRU_SB][384] : d_out, r, z, n, gh_n, h_prev
-    float* hist = ops + 2 * GRU_SB * 384;             // [2][GRU_SB][448] : dgi(192), dgh(192), h_prev(64)
+    float* hist = ops + 2 * GRU_SB * 384;             // [2][GRU_SB][GRU_HS] : dgi(192), dgh(192), h_prev(64)
     const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
-    const bool io = tid >= 64;
+    const int role = tid >> 6;                        // 0 compute, 1 I/O, 2-3 dX GEMM
     const int l = tid & 63;
     const int nblk = (T + GRU_SB - 1) / GRU_SB;
     auto t_of = [&](int step) { return dir ? step : (T - 1 - step); };     // reverse of the forward order
@@ -172,22 +182,25 @@ __global__ __launch_bounds__(128) void k_gru_bwd(const float* __restrict__ d_out
         const int tp = dir ? t + 1 : t - 1;
         const int tpc = min(max(tp, 0), T - 1);
         ok = (step < T) && (a != 5 || (tp >= 0 && tp < T));
-        const float* p = (a == 0) ? d_out + (size_t)(b * T + t) * 128 + dir * 64 + l
-                       : (a < 5)  ? gates + ((size_t)(b * T + t) * 2 + dir) * 256 + (a - 1) * 64 + l
-                                  : out + (size_t)(b * T + tpc) * 128 + dir * 64 + l;
+        if (a == 0) {
+            const size_t e = (size_t)(b * T + t) * 128 + dir * 64 + l;
+            return d_out2 ? d_out[e] + d_out2[e] : d_out[e];          // upstream gradient = sum of the two direction planes
+        }
+        const float* p = (a < 5) ? gates + ((size_t)(b * T + t) * 2 + dir) * 256 + (a - 1) * 64 + l
+                                 : out + (size_t)(b * T + tpc) * 128 + dir * 64 + l;
         return *p;
     };
     auto store_hist = [&](const float* hp, int s0, int n_steps) {
         for (int i = 0; i < 7 * n_steps; ++i) {
             const int s = i / 7, a = i % 7;
             const size_t bt = (size_t)(b * T + t_of(s0 + s)) * 2 + dir;
-            const float v = hp[s * 448 + 64 * a + l];
+            const float v = hp[s * GRU_HS + 64 * a + l];
             if (a < 3) dgi[bt * 192 + 64 * a + l] = v;
             else if (a < 6) dgh[bt * 192 + 64 * (a - 3) + l] = v;
             else hprev_out[bt * 64 + l] = v;
         }
     };
-    if (io) {
+    if (role == 1) {
         float first[6 * GRU_SB];
         unsigned long long okm = 0;
 #pragma unroll
@@ -201,7 +214,7 @@ __global__ __launch_bounds__(128) void k_gru_bwd(const float* __restrict__ d_out
     }
     __syncthreads();
 
-    if (io) {
+    if (role == 1) {
         // ================================ I/O wave ==========================================================
         for (int blk = 0; blk < nblk; ++blk) {
             const int cur = blk & 1, s0 = blk * GRU_SB;
@@ -217,12 +230,12 @@ __global__ __launch_bounds__(128) void k_gru_bwd(const float* __restrict__ d_out
                 }
             }
             if (blk > 0) {
-                const float* hp = hist + (cur ^ 1) * GRU_SB * 448;
+                const float* hp = hist + (cur ^ 1) * GRU_SB * GRU_HS;
 #pragma unroll
                 for (int i = 0; i < 7 * GRU_SB; ++i) {
                     const int s = i / 7, a = i % 7;
                     const size_t bt = (size_t)(b * T + t_of(s0 - GRU_SB + s)) * 2 + dir;
-                    const float v = hp[s * 448 + 64 * a + l];
+                    const float v = hp[s * GRU_HS + 64 * a + l];
                     if (a < 3) dgi[bt * 192 + 64 * a + l] = v;
                     else if (a < 6) dgh[bt * 192 + 64 * (a - 3) + l] = v;
                     else hprev_out[bt * 64 + l] = v;
@@ -235,7 +248,53 @@ __global__ __launch_bounds__(128) void k_gru_bwd(const float* __restrict__ d_out
             }
             lds_barrier();
         }
-        store_hist(hist + ((nblk - 1) & 1) * GRU_SB * 448, (nblk - 1) * GRU_SB, T - (nblk - 1) * GRU_SB);
+        store_hist(hist + ((nblk - 1) & 1) * GRU_SB * GRU_HS, (nblk - 1) * GRU_SB, T - (nblk - 1) * GRU_SB);
+        return;
+    }
+    if (role >= 2) {
+        // ================================ dX GEMM waves ========================================================
+        // block of GRU_SB (= 8) steps x 192 gates times W_ih[dir] (192 x NIN): rows 8..15 of the 16-row MFMA tile are
+        // zero; each wave owns NIN/32 column tiles and keeps their B fragments (k = gate, j = input feature) resident
+        constexpr int CT = NIN / 32;                      // column tiles per wave
+        const int gw = role - 2, i16 = l & 15, kq = l >> 4;
+        const float* wih = dir ? w_ih_r : w_ih_f;
+        float bw[CT][48];
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int s4 = 0; s4 < 48; ++s4) bw[c][s4] = wih[(size_t)(4 * s4 + kq) * NIN + 16 * (gw * CT + c) + i16];
+        float* plane = dx_planes + (size_t)dir * B * T * NIN;
+        auto gemm_block = [&](int blk) {
+            const int s0 = blk * GRU_SB, sb = min(GRU_SB, T - s0);
+            const float* hp = hist + (blk & 1) * GRU_SB * GRU_HS + (i16 & (GRU_SB - 1)) * GRU_HS + kq;
+            const float rowmask = (i16 < sb) ? 1.0f : 0.f;
+            v4f acc[CT];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[c] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < 48; ++s4) {             // fully unrolled: bw[][] must stay in registers
+                const float a = hp[4 * s4] * rowmask;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[c][s4], acc[c], 0, 0, 0);
+            }
+            // D: lane (j = i16, rows 4*kq + r) -> time step s0 + 4*kq + r of the block (kq < 2)
+            if (kq < GRU_SB / 4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int s = 4 * kq + r;
+                    if (s < sb) {
+                        float* dst = plane + (size_t)(b * T + t_of(s0 + s)) * NIN + 16 * gw * CT + i16;
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) dst[16 * c] = acc[c][r];
+                    }
+                }
+            }
+        };
+        for (int blk = 0; blk < nblk; ++blk) {
+            if (blk > 0) gemm_block(blk - 1);
+            lds_barrier();
+        }
+        gemm_block(nblk - 1);
         return;
     }
     // ==================================== compute wave =======================================================
@@ -252,7 +311,7 @@ __global__ __launch_bounds__(128) void k_gru_bwd(const float* __restrict__ d_out
     for (int blk = 0; blk < nblk; ++blk) {
         const int cur = blk & 1, s0 = blk * GRU_SB, sb = min(GRU_SB, T - s0);
         const float* ob = ops + cur * GRU_SB * 384;
-        float* hb = hist + cur * GRU_SB * 448;
+        float* hb = hist + cur * GRU_SB * GRU_HS;
         for (int s = 0; s < sb; ++s) {
             const float* o = ob + s * 384;
             const float dh = o[l] + dh_carry;
@@ -261,7 +320,7 @@ __global__ __launch_bounds__(128) void k_gru_bwd(const float* __restrict__ d_out
             const float dz_pre = dh * (hp - nn) * z * (1.0f - z);
             const float dr_pre = dn_pre * ghn * r * (1.0f - r);
             const float dghn = dn_pre * r;
-            float* ho = hb + s * 448;
+            float* ho = hb + s * GRU_HS;
             ho[l] = dr_pre; ho[64 + l] = dz_pre; ho[128 + l] = dn_pre;
             ho[192 + l] = dr_pre; ho[256 + l] = dz_pre; ho[320 + l] = dghn;
             ho[384 + l] = hp;
@@ -283,7 +342,7 @@ __global__ __launch_bounds__(128) void k_gru_bwd(const float* __restrict__ d_out
 }
 
 static const size_t GRU_FWD_LDS = (size_t)(64 + 2 * GRU_SB * 192 + 2 * GRU_SB * 320 + 192 * 68) * sizeof(float);
-static const size_t GRU_BWD_LDS = (size_t)(192 + 2 * GRU_SB * 384 + 2 * GRU_SB * 448) * sizeof(float);
+static const size_t GRU_BWD_LDS = (size_t)(192 + 2 * GRU_SB * 384 + 2 * GRU_SB * GRU_HS) * sizeof(float);
 
 int launch_gru_fwd(const float* gi, const float* w_hh_f, const float* w_hh_r, const float* b_hh_f, const float* b_hh_r,
                    float* out, float* gates, int B, int T, hipStream_t st) {
@@ -297,14 +356,27 @@ int launch_gru_fwd(const float* gi, const float* w_hh_f, const float* w_hh_r, co
     return SED_OK;
 }
 
-int launch_gru_bwd(const float* d_out, const float* out, const float* gates, const float* w_hh_f, const float* w_hh_r,
-                   float* dgi, float* dgh, float* hprev, int B, int T, hipStream_t st) {
+// dx_planes: [2][B*T][nin] - the two directions' shares of the gradient w.r.t. the layer input (the consumer adds
+// them); d_out2: optional second plane of the upstream gradient (the layer above's dx_planes + B*T*128), or null
+int launch_gru_bwd(const float* d_out, const float* d_out2, const float* out, const float* gates, const float* w_hh_f,
+                   const float* w_hh_r, const float* w_ih_f, const float* w_ih_r, int nin, float* dgi, float* dgh, float* hprev,
+                   float* dx_planes, int B, int T, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gru_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRU_BWD_LDS));
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gru_bwd<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRU_BWD_LDS));
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gru_bwd<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRU_BWD_LDS));
         attr_done = true;
     }
-    k_gru_bwd<<<dim3(B, 2), 128, GRU_BWD_LDS, st>>>(d_out, out, gates, w_hh_f, w_hh_r, dgi, dgh, hprev, T);
+    if (nin == 128)
+        k_gru_bwd<128><<<dim3(B, 2), 256, GRU_BWD_LDS, st>>>(d_out, d_out2, out, gates, w_hh_f, w_hh_r, w_ih_f, w_ih_r, dgi, dgh,
+                                                             hprev, dx_planes, B, T);
+    else if (nin == 64)
+        k_gru_bwd<64><<<dim3(B, 2), 256, GRU_BWD_LDS, st>>>(d_out, d_out2, out, gates, w_hh_f, w_hh_r, w_ih_f, w_ih_r, dgi, dgh,
+                                                            hprev, dx_planes, B, T);
+    else {
+        sed_set_error("gru backward: unsupported input width %d", nin);
+        return SED_ERR_UNSUPPORTED;
+    }
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

@@ -38,7 +38,7 @@ int launch_glu_pool_fwd(const float* y, const double* stat, double N, const floa
                         float p_drop, const uint64_t* seed, uint16_t* mask_out, hipStream_t st);
 // backward pass 1: dz (full-res grad wrt BN output), GLU weight grads and BN reduction sums
 //   acc: double [64*64 (dWglu) + 64 (dbglu) + 64 (sum dz) + 64 (sum dz*y)]
-int launch_glu_pool_bwd(const float* y, const float* bn, const float* wglu, const float* bglu, const float* dp, float* dz,
+int launch_glu_pool_bwd(const float* y, const float* bn, const float* wglu, const float* bglu, const float* dp, const float* dp_b, float* dz,
                         double* acc, int zero_acc, int B, int H, int W, int block_id, int use_drop, float p_drop,
                         const uint16_t* mask_in, const float* gamma, float* coef, float* g_gamma, float* g_beta, float* g_wglu,
                         float* g_bglu, float* g_convb, hipStream_t st);
@@ -76,8 +76,9 @@ int launch_colsum(const float* A, int M, int N, int64_t lda, float* out, hipStre
 int launch_gru_fwd(const float* gi /*[B][T][2][192]*/, const float* w_hh_f, const float* w_hh_r, const float* b_hh_f,
                    const float* b_hh_r, float* out /*[B][T][128]*/, float* gates /*[B][T][2][4][64] or null*/, int B,
                    int T, hipStream_t st);
-int launch_gru_bwd(const float* d_out, const float* out, const float* gates, const float* w_hh_f, const float* w_hh_r,
-                   float* dgi, float* dgh, float* hprev, int B, int T, hipStream_t st);
+int launch_gru_bwd(const float* d_out, const float* d_out2, const float* out, const float* gates, const float* w_hh_f,
+                   const float* w_hh_r, const float* w_ih_f, const float* w_ih_r, int nin, float* dgi, float* dgh, float* hprev,
+                   float* dx_planes, int B, int T, hipStream_t st);
 
 // heads.hip
 int launch_heads_fwd(const float* h /*[B][T][128]*/, const float* wd, const float* bd, const float* ws, const float* bs,

@@ -244,21 +244,12 @@ extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* b
         in = CTXF(po[i]);
     }
     // ---- BiGRU ----------------------------------------------------------------------------------
-    const int BT = g.B * g.T3;
     int nin = 64;
     for (int l = 0; l < g.L; ++l) {
-        {
-            // gi[:, dir, :] = in @ W_ih[dir]^T + b_ih[dir] for both directions in one launch
-            GemmBatch gb;
-            gb.n_prob = 2; gb.splits = 1; gb.part = nullptr; gb.part_stride = 0;
-            for (int dir = 0; dir < 2; ++dir) {
-                gb.p[dir] = gemm_prob(in, nin, 1, params + P.w_ih[l][dir], 1, nin, CTXF(L.gi[l]) + dir * 192, 384, BT, 192, nin);
-                gb.p[dir].bias = params + P.b_ih[l][dir];
-            }
-            SED_TRY(launch_gemm_batch(gb, st));
-        }
-        SED_TRY(launch_gru_fwd(CTXF(L.gi[l]), params + P.w_hh[l][0], params + P.w_hh[l][1], params + P.b_hh[l][0],
-                               params + P.b_hh[l][1], CTXF(L.out[l]), train ? CTXF(L.gates[l]) : nullptr, g.B, g.T3, st));
+        // the input projection x W_ih^T + b_ih runs inside the recurrence kernel (gi only exists in LDS)
+        SED_TRY(launch_gru_fwd(in, nin, params + P.w_ih[l][0], params + P.w_ih[l][1], params + P.b_ih[l][0], params + P.b_ih[l][1],
+                               params + P.w_hh[l][0], params + P.w_hh[l][1], params + P.b_hh[l][0], params + P.b_hh[l][1],
+                               CTXF(L.out[l]), train ? CTXF(L.gates[l]) : nullptr, g.B, g.T3, st));
         in = CTXF(L.out[l]);
         nin = 128;
     }
@@ -449,7 +440,9 @@ extern "C" int sed_kernel_replay(const char* name, const sed_dims* d, const floa
     for (int l = 0; l < g.L; ++l) {
         char nm[32];
         snprintf(nm, sizeof nm, "gru%d_fwd", l);
-        if (is(nm)) return launch_gru_fwd(CTXF(L.gi[l]), params + P.w_hh[l][0], params + P.w_hh[l][1], params + P.b_hh[l][0], params + P.b_hh[l][1], CTXF(L.out[l]), CTXF(L.gates[l]), g.B, g.T3, st);
+        if (is(nm)) return launch_gru_fwd(l == 0 ? CTXF(L.p2) : CTXF(L.out[l - 1]), l == 0 ? 64 : 128, params + P.w_ih[l][0], params + P.w_ih[l][1],
+                                          params + P.b_ih[l][0], params + P.b_ih[l][1], params + P.w_hh[l][0], params + P.w_hh[l][1],
+                                          params + P.b_hh[l][0], params + P.b_hh[l][1], CTXF(L.out[l]), CTXF(L.gates[l]), g.B, g.T3, st);
         snprintf(nm, sizeof nm, "gru%d_bwd", l);
         if (is(nm)) {
             const int nin = (l == 0) ? 64 : 128;

@@ -31,70 +31,125 @@ __device__ __forceinline__ float tanhf_fast(float x) { return 1.0f - 2.0f * rcp_
 __device__ __forceinline__ v2f pkfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_gru_fwd(const float* __restrict__ gi, const float* __restrict__ w_hh_f,
+// Forward.  Waves 2 and 3 compute the input projection gi = x W_ih^T + b_ih of the NEXT block of GRU_SBF time steps on
+// the MFMA (16 steps = one 16-row tile, W_ih fragments resident in their registers) while wave 0 runs the recurrence
+// of the current block: the projection GEMM used to be a kernel of its own in front of the recurrence (9-16 us per
+// layer on the critical path) and gi a 2.9 MB round trip through HBM per layer; now gi only ever exists in LDS.
+#define GRU_SBF 16
+template <int NIN>
+__global__ __launch_bounds__(256) void k_gru_fwd(const float* __restrict__ x, const float* __restrict__ w_ih_f,
+                                                  const float* __restrict__ w_ih_r, const float* __restrict__ b_ih_f,
+                                                  const float* __restrict__ b_ih_r, const float* __restrict__ w_hh_f,
                                                   const float* __restrict__ w_hh_r, const float* __restrict__ b_hh_f,
                                                   const float* __restrict__ b_hh_r, float* __restrict__ out,
                                                   float* __restrict__ gates, int T) {
+    constexpr int XS = NIN + 4;                        // x row stride: (row = lane & 15, col = 4s + lane >> 4) reads conflict free
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     float* hs = gsm;                                  // [64]
-    float* gi_s = hs + 64;                            // [2][GRU_SB][192]
-    float* hist = gi_s + 2 * GRU_SB * 192;            // [2][GRU_SB][320] : h, r, z, n, gh_n
-    float* Wl = hist + 2 * GRU_SB * 320;              // [192][68] staging of W_hh (coalesced global read)
+    float* gi_s = hs + 64;                            // [2][GRU_SBF][192]
+    float* hist = gi_s + 2 * GRU_SBF * 192;           // [2][GRU_SBF][320] : h, r, z, n, gh_n
+    float* xs = hist + 2 * GRU_SBF * 320;             // [2][GRU_SBF][XS]
+    float* Wl = xs + 2 * GRU_SBF * XS;                // [192][68] staging of W_hh (coalesced global read)
     const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
-    const bool io = tid >= 64;                        // wave 1
+    const int role = tid >> 6;                        // 0 compute, 1 I/O, 2-3 projection GEMM
     const int l = tid & 63;
     const float* whh = dir ? w_hh_r : w_hh_f;
     const float* bhh = dir ? b_hh_r : b_hh_f;
-    const int nblk = (T + GRU_SB - 1) / GRU_SB;
+    const int nblk = (T + GRU_SBF - 1) / GRU_SBF;
     auto t_of = [&](int step) { return dir ? (T - 1 - step) : step; };
-    const size_t gi_base = ((size_t)b * T * 2 + dir) * 192;     // + t * 384 + k
-    for (int e = tid; e < 192 * 64; e += 128) Wl[(e >> 6) * 68 + (e & 63)] = whh[e];
-    if (io) {   // inputs of block 0
-        float first[3 * GRU_SB];
+    constexpr int XPL = NIN / 64;                     // x values per lane per step
+    // x rows of block `blk` -> registers / registers -> xs[blk & 1]  (I/O wave)
+    auto x_load = [&](int blk, float (&v)[GRU_SBF * XPL]) {
 #pragma unroll
-        for (int i = 0; i < 3 * GRU_SB; ++i)
-            first[i] = gi[gi_base + (size_t)t_of(min(i / 3, T - 1)) * 384 + 64 * (i % 3) + l];
+        for (int i = 0; i < GRU_SBF * XPL; ++i) {
+            const int st = min(blk * GRU_SBF + i / XPL, T - 1);
+            v[i] = x[(size_t)(b * T + t_of(st)) * NIN + 64 * (i % XPL) + l];
+        }
+    };
+    auto x_store = [&](int blk, const float (&v)[GRU_SBF * XPL]) {
+        float* d = xs + (blk & 1) * GRU_SBF * XS;
 #pragma unroll
-        for (int i = 0; i < 3 * GRU_SB; ++i) gi_s[(i / 3) * 192 + 64 * (i % 3) + l] = first[i];
-    } else {
+        for (int i = 0; i < GRU_SBF * XPL; ++i) d[(i / XPL) * XS + 64 * (i % XPL) + l] = v[i];
+    };
+    // gi of block `blk` from xs[blk & 1] -> gi_s[blk & 1]  (GEMM waves; 6 column tiles of 16 gates each)
+    constexpr int KS = NIN / 4;
+    const int gw = role - 2, i16 = l & 15, kq = l >> 4;
+    float bw[6][KS];
+    float bi[6];
+    if (role >= 2) {
+        const float* wih = dir ? w_ih_r : w_ih_f;
+        const float* bih = dir ? b_ih_r : b_ih_f;
+        // B[k = input feature][j = gate] = W_ih[gate][feature].  Which feature a lane supplies at which MFMA step is
+        // free as long as A and B agree: lane group kq takes features 16s + 4kq + u at step 4s + u, so that its
+        // fragments are aligned float4 loads (16 gate rows x 64 contiguous bytes per instruction) - the natural
+        // 4s + kq assignment made this a scatter of 192 scalar loads per lane, ~5 us of prologue.
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int gcol = 16 * (gw * 6 + c) + i16;
+#pragma unroll
+            for (int s16 = 0; s16 < KS / 4; ++s16) {
+                const v4f w4 = *(const v4f*)(wih + (size_t)gcol * NIN + 16 * s16 + 4 * kq);
+                bw[c][4 * s16] = w4.x; bw[c][4 * s16 + 1] = w4.y; bw[c][4 * s16 + 2] = w4.z; bw[c][4 * s16 + 3] = w4.w;
+            }
+            bi[c] = bih[gcol];
+        }
+    }
+    auto proj_block = [&](int blk) {
+        const float* A = xs + (blk & 1) * GRU_SBF * XS + i16 * XS + 4 * kq;
+        v4f acc[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc[c] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s16 = 0; s16 < KS / 4; ++s16) {          // fully unrolled: bw[][] must stay in registers
+            const v4f a4 = *(const v4f*)(A + 16 * s16);   // features 16s + 4kq + (0..3), same assignment as bw
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u], bw[c][4 * s16 + u], acc[c], 0, 0, 0);
+        }
+        float* gd = gi_s + (blk & 1) * GRU_SBF * 192;
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gd[(4 * kq + r) * 192 + 16 * (gw * 6 + c) + i16] = acc[c][r] + bi[c];
+    };
+
+    for (int e = tid; e < 192 * 64; e += 256) Wl[(e >> 6) * 68 + (e & 63)] = whh[e];
+    if (role == 1) {   // x of blocks 0 and 1
+        float v[GRU_SBF * XPL];
+        x_load(0, v); x_store(0, v);
+        if (nblk > 1) { x_load(1, v); x_store(1, v); }
+    } else if (role == 0) {
         hs[l] = 0.f;
     }
     __syncthreads();
+    if (role >= 2) proj_block(0);
+    __syncthreads();
 
-    if (io) {
+    if (role == 1) {
         // ================================ I/O wave ==========================================================
         for (int blk = 0; blk < nblk; ++blk) {
-            const int cur = blk & 1, s0 = blk * GRU_SB;
-            float nxt[3 * GRU_SB];
-            const bool more = s0 + GRU_SB < T;
-            if (more) {
-#pragma unroll
-                for (int i = 0; i < 3 * GRU_SB; ++i) {
-                    const int st = min(s0 + GRU_SB + i / 3, T - 1);
-                    nxt[i] = gi[gi_base + (size_t)t_of(st) * 384 + 64 * (i % 3) + l];
-                }
-            }
+            const int cur = blk & 1, s0 = blk * GRU_SBF;
+            float nxt[GRU_SBF * XPL];
+            const bool more = blk + 2 < nblk;            // x of block blk+2 (the GEMM waves work on blk+1 meanwhile)
+            if (more) x_load(blk + 2, nxt);
             if (blk > 0) {      // outputs of the previous block
-                const float* hp = hist + (cur ^ 1) * GRU_SB * 320;
+                const float* hp = hist + (cur ^ 1) * GRU_SBF * 320;
 #pragma unroll
-                for (int i = 0; i < 5 * GRU_SB; ++i) {
+                for (int i = 0; i < 5 * GRU_SBF; ++i) {
                     const int s = i / 5, a = i % 5;
-                    const int t = t_of(s0 - GRU_SB + s);
+                    const int t = t_of(s0 - GRU_SBF + s);
                     const float v = hp[s * 320 + 64 * a + l];
                     if (a == 0) out[(size_t)(b * T + t) * 128 + dir * 64 + l] = v;
                     else if (gates) gates[((size_t)(b * T + t) * 2 + dir) * 256 + 64 * (a - 1) + l] = v;
                 }
             }
-            if (more) {
-                float* gin = gi_s + (cur ^ 1) * GRU_SB * 192;
-#pragma unroll
-                for (int i = 0; i < 3 * GRU_SB; ++i) gin[(i / 3) * 192 + 64 * (i % 3) + l] = nxt[i];
-            }
+            if (more) x_store(blk + 2, nxt);             // into xs[blk & 1]: block blk's rows were consumed a block ago
             lds_barrier();      // block boundary
         }
         {   // outputs of the last block
-            const int blk = nblk - 1, s0 = blk * GRU_SB, sb = T - s0;
-            const float* hp = hist + (blk & 1) * GRU_SB * 320;
+            const int blk = nblk - 1, s0 = blk * GRU_SBF, sb = T - s0;
+            const float* hp = hist + (blk & 1) * GRU_SBF * 320;
             for (int i = 0; i < 5 * sb; ++i) {
                 const int s = i / 5, a = i % 5;
                 const int t = t_of(s0 + s);
@@ -102,6 +157,14 @@ __global__ __launch_bounds__(128) void k_gru_fwd(const float* __restrict__ gi, c
                 if (a == 0) out[(size_t)(b * T + t) * 128 + dir * 64 + l] = v;
                 else if (gates) gates[((size_t)(b * T + t) * 2 + dir) * 256 + 64 * (a - 1) + l] = v;
             }
+        }
+        return;
+    }
+    if (role >= 2) {
+        // ================================ projection waves ==================================================
+        for (int blk = 0; blk < nblk; ++blk) {
+            if (blk + 1 < nblk) proj_block(blk + 1);
+            lds_barrier();
         }
         return;
     }
@@ -120,9 +183,9 @@ __global__ __launch_bounds__(128) void k_gru_fwd(const float* __restrict__ gi, c
     asm volatile("" : "+v"(bh_r), "+v"(bh_z), "+v"(bh_n));      // pin the waits for these loads before the loop
     float hprev = 0.f;
     for (int blk = 0; blk < nblk; ++blk) {
-        const int cur = blk & 1, s0 = blk * GRU_SB, sb = min(GRU_SB, T - s0);
-        const float* gib = gi_s + cur * GRU_SB * 192;
-        float* hb = hist + cur * GRU_SB * 320;
+        const int cur = blk & 1, s0 = blk * GRU_SBF, sb = min(GRU_SBF, T - s0);
+        const float* gib = gi_s + cur * GRU_SBF * 192;
+        float* hb = hist + cur * GRU_SBF * 320;
         for (int s = 0; s < sb; ++s) {
             v2f ar0 = {bh_r, 0.f}, ar1 = {0.f, 0.f}, az0 = {bh_z, 0.f}, az1 = {0.f, 0.f}, an0 = {bh_n, 0.f}, an1 = {0.f, 0.f};
 #pragma unroll
@@ -341,17 +404,27 @@ __global__ __launch_bounds__(256) void k_gru_bwd(const float* __restrict__ d_out
     }
 }
 
-static const size_t GRU_FWD_LDS = (size_t)(64 + 2 * GRU_SB * 192 + 2 * GRU_SB * 320 + 192 * 68) * sizeof(float);
+template <int NIN> static constexpr size_t gru_fwd_lds() { return (size_t)(64 + 2 * GRU_SBF * 192 + 2 * GRU_SBF * 320 + 2 * GRU_SBF * (NIN + 4) + 192 * 68) * sizeof(float); }
 static const size_t GRU_BWD_LDS = (size_t)(192 + 2 * GRU_SB * 384 + 2 * GRU_SB * GRU_HS) * sizeof(float);
 
-int launch_gru_fwd(const float* gi, const float* w_hh_f, const float* w_hh_r, const float* b_hh_f, const float* b_hh_r,
-                   float* out, float* gates, int B, int T, hipStream_t st) {
+// x: the layer input [B*T][nin] (the input projection runs inside the kernel)
+int launch_gru_fwd(const float* x, int nin, const float* w_ih_f, const float* w_ih_r, const float* b_ih_f, const float* b_ih_r,
+                   const float* w_hh_f, const float* w_hh_r, const float* b_hh_f, const float* b_hh_r, float* out, float* gates,
+                   int B, int T, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gru_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRU_FWD_LDS));
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gru_fwd<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gru_fwd_lds<64>()));
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gru_fwd<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gru_fwd_lds<128>()));
         attr_done = true;
     }
-    k_gru_fwd<<<dim3(B, 2), 128, GRU_FWD_LDS, st>>>(gi, w_hh_f, w_hh_r, b_hh_f, b_hh_r, out, gates, T);
+    if (nin == 128)
+        k_gru_fwd<128><<<dim3(B, 2), 256, gru_fwd_lds<128>(), st>>>(x, w_ih_f, w_ih_r, b_ih_f, b_ih_r, w_hh_f, w_hh_r, b_hh_f, b_hh_r, out, gates, T);
+    else if (nin == 64)
+        k_gru_fwd<64><<<dim3(B, 2), 256, gru_fwd_lds<64>(), st>>>(x, w_ih_f, w_ih_r, b_ih_f, b_ih_r, w_hh_f, w_hh_r, b_hh_f, b_hh_r, out, gates, T);
+    else {
+        sed_set_error("gru forward: unsupported input width %d", nin);
+        return SED_ERR_UNSUPPORTED;
+    }
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

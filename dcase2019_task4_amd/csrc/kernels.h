@@ -73,9 +73,9 @@ int launch_gemm_batch(GemmBatch& gb, hipStream_t st);
 int launch_colsum(const float* A, int M, int N, int64_t lda, float* out, hipStream_t st);
 
 // gru.hip
-int launch_gru_fwd(const float* gi /*[B][T][2][192]*/, const float* w_hh_f, const float* w_hh_r, const float* b_hh_f,
-                   const float* b_hh_r, float* out /*[B][T][128]*/, float* gates /*[B][T][2][4][64] or null*/, int B,
-                   int T, hipStream_t st);
+int launch_gru_fwd(const float* x, int nin, const float* w_ih_f, const float* w_ih_r, const float* b_ih_f, const float* b_ih_r,
+                   const float* w_hh_f, const float* w_hh_r, const float* b_hh_f, const float* b_hh_r, float* out, float* gates,
+                   int B, int T, hipStream_t st);
 int launch_gru_bwd(const float* d_out, const float* d_out2, const float* out, const float* gates, const float* w_hh_f,
                    const float* w_hh_r, const float* w_ih_f, const float* w_ih_r, int nin, float* dgi, float* dgh, float* hprev,
                    float* dx_planes, int B, int T, hipStream_t st);

@@ -344,6 +344,8 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
     // Stream schedule (kernel timeline of one step, tools/timeline.py): the dgrad chain is the critical path.
     //   main: glu2_bwd  prep | dgrad2            | glu1_bwd  prep | dgrad1          | blk0_bwd  finalize |
     //   side:                | wgrad2  GRU dW/db |                | wgrad1  reduce                       | join
+    // (Forking before glu2_bwd so that the GRU GEMMs run first and wgrad1 starts on time measured slower, 1.061 vs
+    // 1.029 ms: they then compete with the critical-path kernels glu2_bwd / dgrad2 / glu1_bwd.)
     // (Starting wgrad1 only after dgrad1, next to the VALU-bound k_blk0_bwd, measured the same: dgrad1 drops from
     // 175 to 93 us but k_blk0_bwd, left with one wave per SIMD beside the wgrad wave, goes from 86 to 177 us.)
     for (int i = 2; i >= 1; --i) {

@@ -58,7 +58,21 @@ __global__ __launch_bounds__(256) void k_gemm_batched(GemmBatch gb) {
         if (b_nc) { bk[it] = e4 / GT_N; bn[it] = e4 % GT_N; } else { bk[it] = e4 % GT_K; bn[it] = e4 / GT_K; }
     }
     float ra[NG][4], rb[NG][4];
+    // interior tiles of vector-friendly problems take straight-line float4 loads: with the per-group range / alignment
+    // branches below the compiler waits (s_waitcnt vmcnt(0)) behind every single load
+    const bool interior = d.vec_ok && m0 + GT_M <= d.M && n0 + GT_N <= d.N;
     auto load_tile = [&](int k0) {
+        if (interior && k0 + GT_K <= kend && (d.B2 == nullptr || k0 >= d.k2 || k0 + GT_K <= d.k2)) {
+            const float* bbase = (d.B2 != nullptr && k0 >= d.k2) ? d.B2 - (int64_t)d.k2 * d.sBk : d.B;
+#pragma unroll
+            for (int it = 0; it < NG; ++it) {
+                const f32x4 va = *(const f32x4*)(d.A + (int64_t)(m0 + am[it]) * d.sAm + (int64_t)(k0 + ak[it]) * d.sAk);
+                const f32x4 vb = *(const f32x4*)(bbase + (int64_t)(k0 + bk[it]) * d.sBk + (int64_t)(n0 + bn[it]) * d.sBn);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ra[it][q] = va[q]; rb[it][q] = vb[q]; }
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < NG; ++it) {
             // ---- A group: 4 consecutive k (a_kc) or 4 consecutive m ----
@@ -342,6 +356,13 @@ int launch_gemm_batch(GemmBatch& gb, hipStream_t st) {
         k_gemm_panel<<<grid, 256, lds, st>>>(gb);
         SED_CHECK_LAUNCH();
         return SED_OK;
+    }
+    for (int i = 0; i < gb.n_prob; ++i) {
+        GemmProb& q = gb.p[i];
+        const bool a_kc = (q.sAk == 1), b_nc = (q.sBn == 1);
+        q.vec_ok = (a_kc ? (q.sAm % 4) == 0 : (q.sAm == 1 && (q.sAk % 4) == 0)) &&
+                   (b_nc ? (q.sBk % 4) == 0 : (q.sBk == 1 && (q.sBn % 4) == 0)) &&
+                   ((uintptr_t)q.A % 16) == 0 && ((uintptr_t)q.B % 16) == 0 && (q.B2 == nullptr || ((uintptr_t)q.B2 % 16) == 0);
     }
     if (gb.splits > 1) {
         SED_CHECK_ARG(gb.part != nullptr, "split-K gemm needs a partial buffer");

@@ -53,6 +53,7 @@ struct GemmProb {
     float* Cones;                 // optional: receives sum_k A(m,k) (virtual all-ones column n == N)
     int M, N, K;
     int accumulate;
+    int vec_ok;                   // set by launch_gemm_batch: every in-range group of 4 is one aligned float4
 };
 struct GemmBatch {
     GemmProb p[4];
@@ -65,7 +66,7 @@ static inline GemmProb gemm_prob(const float* A, int64_t sAm, int64_t sAk, const
                                  int64_t ldc, int M, int N, int K) {
     GemmProb q;
     q.A = A; q.sAm = sAm; q.sAk = sAk; q.B = B; q.sBk = sBk; q.sBn = sBn; q.B2 = nullptr; q.k2 = 0;
-    q.C = C; q.ldc = ldc; q.bias = nullptr; q.Cones = nullptr; q.M = M; q.N = N; q.K = K; q.accumulate = 0;
+    q.C = C; q.ldc = ldc; q.bias = nullptr; q.Cones = nullptr; q.M = M; q.N = N; q.K = K; q.accumulate = 0; q.vec_ok = 0;
     return q;
 }
 size_t gemm_part_floats(int n_prob, int splits, int max_m, int max_nx);

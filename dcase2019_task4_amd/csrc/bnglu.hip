@@ -193,10 +193,8 @@ struct BnBwdPrepArgs {
     float *coef, *g_gamma, *g_beta, *g_wglu, *g_bglu, *g_convb;
 };
 // BatchNorm backward reduction -> per-channel affine dy = ca*dz + cb*y + cc for the conv dgrad / wgrad loaders, and the
-// parameter gradients of the block (was a 1-workgroup kernel of its own; now the epilogue of the LAST workgroup of
-// k_glu_pool_bwd).  Reads the accumulators with device-scope atomic loads: they were produced by other workgroups'
-// atomics, possibly on other XCDs.
-__device__ __forceinline__ double acc_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// parameter gradients of the block (k_bn_bwd_prep, launched right behind k_glu_pool_bwd).
+__device__ __forceinline__ double acc_load(const double* p) { return *p; }
 __device__ __forceinline__ void bn_bwd_prep_body(const BnBwdPrepArgs& a, int tid) {
     if (tid < 64) {
         const int c = tid;
@@ -221,9 +219,8 @@ __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ 
                                                        const float* __restrict__ dp, const float* __restrict__ dp_b,
                                                        float* __restrict__ dz, double* __restrict__ accg, int H, int W, int Ho, int Wo, int Q,
                                                        int block_id, int use_drop, float p_drop,
-                                                       const uint16_t* __restrict__ mask_in, int no_atomic, BnBwdPrepArgs prep) {
+                                                       const uint16_t* __restrict__ mask_in, int no_atomic) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ int is_last;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
     float* WsT = smem + 4 * (3 * 32 * ZS);               // Wglu transposed [c][co], stride 65
@@ -483,19 +480,14 @@ __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ 
         if (!no_atomic) atomicAdd(&accg[4096 + which * 64 + c], v);
     }
     TS(10); TSC(15);
-    // ---- last workgroup: BatchNorm-backward coefficients + parameter gradients --------------------------------
-    // Ordering only needs this workgroup's accumulator ATOMICS (device scope already) to be complete before its ticket
-    // increment: a workgroup-scope release (s_waitcnt) does that.  __threadfence() would also write back the L2 -
-    // i.e. the 31 MB of dz this kernel just produced - and cost 17 us.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    unsigned int* ticket = (unsigned int*)(accg + 4288);
-    if (tid == 0) is_last = (atomicAdd(ticket, 1u) == gridDim.x - 1);
-    __syncthreads();
-    if (!is_last) return;
-    bn_bwd_prep_body(prep, tid);
-    if (tid == 0) *ticket = 0u;
 }
+
+// BatchNorm-backward coefficients + the block's parameter gradients: a kernel of its own again.  Folding it into the
+// last workgroup of k_glu_pool_bwd (ticket after a workgroup-scope release) was a RACE: about 1 step in 10 the last
+// workgroup read the Sdz / Sdzy accumulators before every other workgroup's fp64 atomics had been performed
+// (tools/determinism.py: bn1 / conv1 / block-0 gradients off by up to 7e-3); ordering those atomics device-wide needs
+// __threadfence(), whose L2 write-back of the 31 MB of dz just produced costs more (17 us) than this launch (5 us).
+__global__ __launch_bounds__(256) void k_bn_bwd_prep(BnBwdPrepArgs a) { bn_bwd_prep_body(a, threadIdx.x); }
 
 // ---- host launchers -------------------------------------------------------------------------------
 int launch_glu_pool_fwd(const float* y, const double* stat, double N, const float* gamma, const float* beta, float* run_mean,
@@ -532,7 +524,9 @@ int launch_glu_pool_bwd(const float* y, const float* bn, const float* wglu, cons
     const int n_rb = (Q + 3) / 4;
     int grid = (n_rb + 3) / 4;
     if (grid > 256) grid = 256;
-    k_glu_pool_bwd<<<grid, 256, lds, st>>>(y, bn, wglu, bglu, dp, dp_b, dz, acc, H, W, Ho, Wo, Q, block_id, use_drop, p_drop, mask_in, g_sed_debug & 1, a);
+    k_glu_pool_bwd<<<grid, 256, lds, st>>>(y, bn, wglu, bglu, dp, dp_b, dz, acc, H, W, Ho, Wo, Q, block_id, use_drop, p_drop, mask_in, g_sed_debug & 1);
+    SED_CHECK_LAUNCH();
+    k_bn_bwd_prep<<<1, 256, 0, st>>>(a);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

@@ -420,3 +420,32 @@ def test_checkpoint_resume_is_bit_exact(tmp_path):
     # the model entries are the reference's nested layout (CRNN.py:49-53) + the attention layer it forgets
     ck = torch.load(path, map_location="cpu", weights_only=False)
     assert set(ck["model"]) == {"cnn", "rnn", "dense", "dense_softmax"} and "conv0.weight" in ck["model"]["cnn"]
+
+
+@pytest.mark.parametrize("B,T,graph,reps", [(8, 216, False, 25), (8, 216, True, 25), (24, 628, True, 15)])
+def test_step_is_bitwise_reproducible_run_to_run(B, T, graph, reps):
+    """The same step from the same state, many times: gradients, parameters, posteriors and BatchNorm buffers must be
+    bit-identical.  Catches cross-workgroup races (this found one: an accumulator read before all atomics had landed,
+    ~1 step in 10, gradients off by 7e-3) and any order-dependent floating-point reduction."""
+    from dcase2019_task4_amd.train import MeanTeacherStep
+    tgt, wm, sm = synth.make_target(1, B, T // 8)
+    s, _ = gu.make_model(0, dropout=0.5)
+    t, _ = gu.make_model(1, dropout=0.5)
+    s.train(); t.train()
+    st = MeanTeacherStep(s, t, B, T, 40, wm, sm, seed=99, use_graph=graph)
+    st.load_batch(synth.make_input(60, B, T).cuda(), synth.make_input(70, B, T).cuda(), tgt.cuda())
+    if graph:
+        st._warm = 2
+    sd = st.state_dict()
+    ref = None
+    for rep in range(reps):
+        st.load_state_dict(sd)
+        st.run()
+        torch.cuda.synchronize()
+        cur = [st.grads.clone(), st.strong.clone(), st.strong_ema.clone(), s._flat.clone(), t._flat.clone(),
+               s._bn_flat.clone(), t._bn_flat.clone(), st.losses[:8].clone()]
+        if ref is None:
+            ref = cur
+            continue
+        for k, (a, b) in enumerate(zip(cur, ref)):
+            assert torch.equal(a, b), (rep, k, float((a - b).abs().max()))

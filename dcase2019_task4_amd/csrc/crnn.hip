@@ -366,10 +366,8 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
             }
             SED_TRY(launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], st));
         } else {
-            const bool after = (g_sed_debug & 16) != 0;          // experiment: wgrad1 after dgrad1 (next to k_blk0_bwd)
-            if (!after && sd.ok) { SIDE_FORK(st); forked = true; }
+            if (sd.ok) { SIDE_FORK(st); forked = true; }
             SED_TRY(launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], st));
-            if (after && sd.ok) { SIDE_FORK(st); forked = true; }
             SED_TRY(launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(pin[i]), WSF(W.wg_part), W.wgrad_blocks,
                                       grads + P.conv_w[i], g.B, Hs[i], Wd[i], ss));
         }
@@ -406,14 +404,6 @@ extern "C" int sed_kernel_replay(const char* name, const sed_dims* d, const floa
     const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};
     auto is = [&](const char* n) { return strcmp(name, n) == 0; };
     if (is("x_moments")) return launch_x_moments(g, x, CTXD(L.mompart), st);
-    if (is("gru_dx_gemm")) {          // dX = [dgi_fwd | dgi_rev] @ [W_ih_fwd ; W_ih_rev] of the last GRU layer
-        const int l = g.L - 1, nin = (l == 0) ? 64 : 128;
-        GemmBatch gb;
-        gb.n_prob = 1; gb.splits = 1; gb.part = nullptr; gb.part_stride = 0;
-        gb.p[0] = gemm_prob(WSF(W.dgi[l]), 384, 1, params + P.w_ih[l][0], nin, 1, WSF(W.d_in), nin, BT, nin, 384);
-        gb.p[0].B2 = params + P.w_ih[l][1]; gb.p[0].k2 = 192;
-        return launch_gemm_batch(gb, st);
-    }
     if (is("blk0_fwd")) {
         const int tpc = (g.H1 + 3) / 4;
         (void)tpc;

@@ -332,7 +332,7 @@ int launch_gemm_batch(GemmBatch& gb, hipStream_t st) {
         maxNx = nx > maxNx ? nx : maxNx;
     }
     if (gb.splits < 1) gb.splits = 1;
-    bool panel = (gb.splits == 1) && !(g_sed_debug & 32);
+    bool panel = (gb.splits == 1);
     int maxK = 0, maxN = 0;
     for (int i = 0; i < gb.n_prob; ++i) {
         const GemmProb& q = gb.p[i];

@@ -221,8 +221,11 @@ int sed_kernel_replay(const char* name, const sed_dims* d, const float* params, 
                       const uint64_t* seed_dev, void* ctx, size_t ctx_bytes, float* grads, void* ws,
                       size_t ws_bytes, void* stream);
 
-/* Debug knob for timing experiments (returns the previous value). bit 0: skip the fp64 atomics of
- * the reduction epilogues (results are then WRONG); 0 restores normal operation. */
+/* Debug knob for timing experiments (returns the previous value); 0 = normal operation.
+ *   bit 0: skip the fp64 atomics of the reduction epilogues (results are then WRONG);
+ *   bit 1 / 2 / 3: block-1 conv forward / dgrad / wgrad use their alternative kernel (tile kernel instead of the
+ *   weight-stationary one, weight-stationary instead of tile, single- instead of double-buffered): same results,
+ *   kept for A/B timing (profiles/README.md). */
 int sed_debug_set(int flags);
 
 /* ---- self tests (run on the GPU box by tests/) ---------------------------------------------

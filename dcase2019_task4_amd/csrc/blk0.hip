@@ -228,7 +228,9 @@ __device__ __forceinline__ void blk0_rowblock(const float* xs, const Blk0W& W, i
 }
 
 // ---- forward --------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_blk0_fwd(const float* __restrict__ x, const float* __restrict__ wz,
+// (256, 3): with a register budget below 256 the compiler selects the VGPR form of the MFMAs - with the default budget it
+// put the accumulators in AGPRs and paid 64 v_accvgpr_read per row block (12 % of this VALU-bound kernel's instructions)
+__global__ __launch_bounds__(256, 3) void k_blk0_fwd(const float* __restrict__ x, const float* __restrict__ wz,
                                                    const float* __restrict__ wl, float* __restrict__ p0, int B, int T,
                                                    int H1, int tiles_per_clip, int n_tiles, int use_drop, float p_drop,
                                                    const uint64_t* __restrict__ seed_ptr, uint16_t* __restrict__ mask_out) {

@@ -107,7 +107,7 @@ __device__ __forceinline__ void bn_prep_body(const BnPrepArgs& a, int c, bool pu
     if (publish) { a.bn[c] = v0; a.bn[64 + c] = v1; a.bn[128 + c] = v2; a.bn[192 + c] = v3; }
 }
 
-__global__ __launch_bounds__(256) void k_glu_pool_fwd(const float* __restrict__ y, BnPrepArgs bnp,
+__global__ __launch_bounds__(256, 2) void k_glu_pool_fwd(const float* __restrict__ y, BnPrepArgs bnp,
                                                        const float* __restrict__ wglu, const float* __restrict__ bglu,
                                                        float* __restrict__ p, int H, int W, int Ho, int Wo, int Q,
                                                        int block_id, int use_drop, float p_drop,

@@ -192,8 +192,10 @@ __device__ __forceinline__ void blk0_load_w(Blk0W& W, const float* __restrict__ 
         const int k = 2 * s + kh;
         W.bw[s][0] = wl[n * 12 + k];
         W.bw[s][1] = wl[(32 + n) * 12 + k];
-        W.bw[s][2] = wz[n * 12 + k];
-        W.bw[s][3] = wz[(32 + n) * 12 + k];
+        // the z columns carry -log2(e): the MFMA then delivers the argument of exp2 in sigmoid(z) = 1 / (1 + 2^(-log2e z))
+        // directly (these kernels are VALU-bound; z itself is never needed, only sigmoid(z))
+        W.bw[s][2] = wz[n * 12 + k] * SED_NEG_LOG2E;
+        W.bw[s][3] = wz[(32 + n) * 12 + k] * SED_NEG_LOG2E;
     }
 }
 __device__ __forceinline__ void blk0_load_xs(float* xs, const float* __restrict__ x, int b, int T, int t0, int tid) {
@@ -209,28 +211,10 @@ __device__ __forceinline__ void blk0_load_xs(float* xs, const float* __restrict_
         xs[(e >> 1) * XS_W + (e & 1) * 65] = 0.f;
     }
 }
-// computes lin (acc[0..1]) and z (acc[2..3]) of one 32-pixel row block
-__device__ __forceinline__ void blk0_rowblock(const float* xs, const Blk0W& W, int tl, int g, int lane, f32x16 acc[4]) {
-    const int m = lane & 31, kh = lane >> 5;
-    const int j = m >> 3, dt = (m >> 2) & 1, df = m & 3;
-    const int base = (2 * tl + dt) * XS_W + 16 * g + 4 * j + df;
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
-#pragma unroll
-    for (int s = 0; s < 5; ++s) {
-        const int k = 2 * s + kh;
-        const float a = (k == 9) ? 1.0f : xs[base + (k / 3) * XS_W + (k % 3)];
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) acc[cb] = mfma32(a, W.bw[s][cb], acc[cb]);
-    }
-}
-
 // ---- forward --------------------------------------------------------------------------------
 // (256, 3): with a register budget below 256 the compiler selects the VGPR form of the MFMAs - with the default budget it
 // put the accumulators in AGPRs and paid 64 v_accvgpr_read per row block (12 % of this VALU-bound kernel's instructions)
-__global__ __launch_bounds__(256, 3) void k_blk0_fwd(const float* __restrict__ x, const float* __restrict__ wz,
+__global__ __launch_bounds__(256, 4) void k_blk0_fwd(const float* __restrict__ x, const float* __restrict__ wz,
                                                    const float* __restrict__ wl, float* __restrict__ p0, int B, int T,
                                                    int H1, int tiles_per_clip, int n_tiles, int use_drop, float p_drop,
                                                    const uint64_t* __restrict__ seed_ptr, uint16_t* __restrict__ mask_out) {
@@ -253,11 +237,30 @@ __global__ __launch_bounds__(256, 3) void k_blk0_fwd(const float* __restrict__ x
         u32x4 o1 = {0u, 0u, 0u, 0u};
         if (use_drop && one_bit) o1 = philox_stream_1bit((uint32_t)(b * H1 + to) * 4u, lane, 0, seed);   // all 4 row blocks
         for (int g = 0; g < 4; ++g) {
-            f32x16 acc[4];
-            blk0_rowblock(xs, W, wv, g, lane, acc);
+            // MFMA A operand of this row block: this lane's pixel m, taps 2s + kh (shared by both channel halves)
+            float av[5];
+            {
+                const int m = n, j = m >> 3, dt = (m >> 2) & 1, df = m & 3;
+                const int base = (2 * wv + dt) * XS_W + 16 * g + 4 * j + df;
+#pragma unroll
+                for (int s5 = 0; s5 < 5; ++s5) {
+                    const int k = 2 * s5 + kh;
+                    av[s5] = (k == 9) ? 1.0f : xs[base + (k / 3) * XS_W + (k % 3)];
+                }
+            }
             const int q0 = (b * H1 + to) * 16 + 4 * g;
+            // the two 32-channel halves one after the other (lin_h and z_h: 2 x 16 accumulator registers live instead of
+            // 4 x 16): 4 waves per SIMD instead of 3 for this VALU-bound kernel
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
+                f32x16 acc[4];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc[h][r] = 0.f; acc[2 + h][r] = 0.f; }
+#pragma unroll
+                for (int s5 = 0; s5 < 5; ++s5) {
+                    acc[h] = mfma32(av[s5], W.bw[s5][h], acc[h]);
+                    acc[2 + h] = mfma32(av[s5], W.bw[s5][2 + h], acc[2 + h]);
+                }
                 const int c = 32 * h + n;
                 float pooled[4] = {0.f, 0.f, 0.f, 0.f};
                 if (use_drop) {
@@ -272,12 +275,12 @@ __global__ __launch_bounds__(256, 3) void k_blk0_fwd(const float* __restrict__ x
                     if (mask_out) mask_out[((size_t)(q0 >> 2) * 2 + h) * 64 + lane] = (uint16_t)m16;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float v = acc[h][r] * sigmoidf_fast(acc[2 + h][r]);
-                        pooled[r >> 2] += ((m16 >> r) & 1u) ? v : 0.f;
+                        const float lm = ((m16 >> r) & 1u) ? acc[h][r] : 0.f;
+                        pooled[r >> 2] = fmaf(lm, sigmoid_from_scaled(acc[2 + h][r]), pooled[r >> 2]);
                     }
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) pooled[r >> 2] += acc[h][r] * sigmoidf_fast(acc[2 + h][r]);
+                    for (int r = 0; r < 16; ++r) pooled[r >> 2] = fmaf(acc[h][r], sigmoid_from_scaled(acc[2 + h][r]), pooled[r >> 2]);
                 }
 #pragma unroll
                 for (int jx = 0; jx < 4; ++jx) pooled[jx] += __shfl_xor(pooled[jx], 32);
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void k_blk0_bwd(const float* __restrict__ x
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float gg = ((m_c[h] >> r) & 1u) ? gq_c[h][r >> 2] : 0.f;
-                    const float sg = sigmoidf_fast(az[r]);
+                    const float sg = sigmoid_from_scaled(az[r]);
                     dl[r] = gg * sg;
                     dzg[r] = gg * al[r] * sg * (1.0f - sg);
                 }

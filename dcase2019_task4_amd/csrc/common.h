@@ -116,6 +116,9 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // sequence, which made the sigmoid the dominant VALU cost of the fused GLU epilogues.
 __device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float sigmoidf_fast(float x) { return rcp_fast(1.0f + __expf(-x)); }
+// sigmoid of z given e = -log2(e) * z (the scale folded into the producer's weights): one multiply less per element
+#define SED_NEG_LOG2E (-1.4426950408889634f)
+__device__ __forceinline__ float sigmoid_from_scaled(float e) { return rcp_fast(1.0f + __builtin_amdgcn_exp2f(e)); }
 // debug knob (sed_debug_set): bit 0 = skip the fp64 atomics of the reduction epilogues (timing experiments only)
 extern int g_sed_debug;
 

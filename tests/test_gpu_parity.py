@@ -449,3 +449,45 @@ def test_step_is_bitwise_reproducible_run_to_run(B, T, graph, reps):
             continue
         for k, (a, b) in enumerate(zip(cur, ref)):
             assert torch.equal(a, b), (rep, k, float((a - b).abs().max()))
+
+
+def test_data_parallel_schedule_on_rccl_one_rank_matches_single_process(monkeypatch):
+    """The data-parallel schedule (graph: forward + loss + backward | RCCL all-reduce of the flat gradient buffer |
+    graph: Adam + EMA) on the real nccl (= RCCL) backend with a one-rank group: must reproduce the single-process fused
+    step bit for bit, eager and as hipGraph replays.  (World sizes > 1 are covered on CPU/gloo in test_dist_cpu.py.)"""
+    import torch.distributed as dist
+    from dcase2019_task4_amd.train import MeanTeacherStep
+    monkeypatch.setenv("SED_FORCE_DP", "1")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29577")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        B, T = 8, 216
+        tgt, wm, sm = synth.make_target(2, B, T // 8)
+        xs = [synth.make_input(80 + i, B, T).cuda() for i in range(3)]
+        xe = [synth.make_input(90 + i, B, T).cuda() for i in range(3)]
+
+        def run(pg, graph):
+            s, _ = gu.make_model(0, dropout=0.5)
+            t, _ = gu.make_model(1, dropout=0.5)
+            s.train(); t.train()
+            st = MeanTeacherStep(s, t, B, T, 40, wm, sm, seed=7, use_graph=graph, process_group=pg)
+            assert st.dp == (pg is not None)
+            if graph:
+                st._warm = 2
+            for i in range(3):
+                st.step(xs[i], xe[i], tgt.cuda())
+            torch.cuda.synchronize()
+            return s._flat.clone(), t._flat.clone(), st.grads.clone(), st.meters()
+
+        ref = run(None, False)
+        for graph in (False, True):
+            got = run(dist.group.WORLD, graph)
+            for a, b in zip(got[:3], ref[:3]):
+                assert torch.equal(a, b)
+            assert got[3] == ref[3]
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -108,7 +108,10 @@ int sed_crnn_forward(const sed_dims* d, const float* params, float* bn_running, 
  *   parts            bit 0: heads + BiGRU (writes the rnn/dense tail of grads), bit 1: conv blocks
  *                    (writes the cnn head of grads; needs bit 0 to have run on the same ws).
  *                    3 = whole backward.  Splitting lets a data-parallel caller start the
- *                    all-reduce of the tail bucket while the conv blocks are still running.     */
+ *                    all-reduce of the tail bucket while the conv blocks are still running.
+ * Concurrency: the library forks its weight-gradient kernels onto ONE process-wide side stream (created on first
+ * use on the current device, event fork/join, capturable); use it from one caller stream at a time per process -
+ * the one-process-per-GPU model of the host side. */
 size_t sed_crnn_bwd_ws_bytes(const sed_dims* d);
 int sed_crnn_backward(const sed_dims* d, const float* params, const float* x, const uint64_t* seed_dev,
                       void* ctx, size_t ctx_bytes, const float* d_strong, const float* d_weak,

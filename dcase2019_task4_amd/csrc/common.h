@@ -74,7 +74,7 @@ struct CtxLayout {
     size_t p0;
     size_t wpk1, y1, stat1, bn1, p1;
     size_t wpk2, y2, stat2, bn2, p2;
-    size_t gi[2], gates[2], out[2];
+    size_t gates[2], out[2];
     size_t logits_s, strong_sv, weak_sv, den_sv;
     size_t mask0, mask1, mask2;        // 16 dropout keep bits per (row block, half, lane), written by forward
     size_t total;

@@ -2,7 +2,7 @@
 //
 // Mirrors the operator sequence of CRNN.forward (baseline/models/CRNN.py:59-84):
 //   conv block 0 (blk0.hip, fully fused) -> [conv3x3 + BN stats (conv.hip) -> BN/GLU/dropout/pool
-//   (bnglu.hip)] x 2 -> 2-layer BiGRU (gemm.hip + gru.hip) -> heads (heads.hip)
+//   (bnglu.hip)] x 2 -> 2-layer BiGRU (gru.hip: input projection + recurrence per layer) -> heads (heads.hip)
 // All launches go to the caller's stream; no allocation, no synchronisation.
 #include <stdarg.h>
 #include <stdio.h>
@@ -90,7 +90,7 @@ CtxLayout make_ctx_layout(const Geo& g) {
     put(L.wpk2, 9 * 4096 * 4); put(L.wpkT2, 9 * 4096 * 4); put(L.y2, n1 * 4); put(L.bn2, 256 * 4); put(L.p2, n2 * 4);
     const size_t bt = (size_t)g.B * g.T3;
     for (int l = 0; l < 2; ++l) {
-        put(L.gi[l], bt * 384 * 4); put(L.gates[l], bt * 512 * 4); put(L.out[l], bt * 128 * 4);
+        put(L.gates[l], bt * 512 * 4); put(L.out[l], bt * 128 * 4);      // (gi only exists in LDS, gru.hip)
     }
     put(L.logits_s, bt * g.NC * 4); put(L.strong_sv, bt * g.NC * 4);
     put(L.weak_sv, (size_t)g.B * g.NC * 4); put(L.den_sv, (size_t)g.B * g.NC * 4);
@@ -151,7 +151,6 @@ extern "C" int sed_crnn_ctx_view(const sed_dims* d, const char* name, size_t* of
         {"mom0", L.mom0, 64 * 8}, {"wz0", L.wz0, 64 * 12 * 4}, {"wl0", L.wl0, 64 * 12 * 4}, {"bn0", L.bn0, 1024},
         {"p0", L.p0, n0}, {"y1", L.y1, n0}, {"stat1", L.stat1, 1024}, {"bn1", L.bn1, 1024}, {"p1", L.p1, n1},
         {"y2", L.y2, n1}, {"stat2", L.stat2, 1024}, {"bn2", L.bn2, 1024}, {"p2", L.p2, bt * 64 * 4},
-        {"gi0", L.gi[0], bt * 384 * 4}, {"gi1", L.gi[1], bt * 384 * 4},
         {"gates0", L.gates[0], bt * 512 * 4}, {"gates1", L.gates[1], bt * 512 * 4},
         {"gru0", L.out[0], bt * 128 * 4}, {"gru1", L.out[1], bt * 128 * 4},
         {"logits_s", L.logits_s, bt * g.NC * 4}, {"den", L.den_sv, (size_t)g.B * g.NC * 4},

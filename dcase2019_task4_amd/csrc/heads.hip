@@ -6,7 +6,7 @@
 //   sof    = clamp(softmax(dense_softmax(x), dim=-1), 1e-7, 1)   (softmax over CLASSES)
 //   weak   = (strong * sof).sum(1) / sof.sum(1)                  [B, nclass]
 // and the loss block of main.train (baseline/main.py:93-145).  One workgroup per clip; the work is
-// tiny (0.4 MFLOP / clip) so everything is fused: dropout mask (Philox, recomputed in backward),
+// tiny (0.4 MFLOP / clip) so everything is fused: dropout mask (Philox; backward re-draws it, one draw per 16 features),
 // both Linear layers, sigmoid, softmax, clamp and the attention pooling.
 #include "common.h"
 #include "philox.h"

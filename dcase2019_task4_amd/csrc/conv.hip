@@ -252,6 +252,7 @@ __global__ __launch_bounds__(256, 1) void k_conv16_ws(const float* __restrict__ 
         }
     };
 
+    if (MODE == 0) { TS(0); TSC(14); }
     int tile = blockIdx.x;
     if (tile < n_tiles) load_halo(tile);           // first halo in flight while the weight panel is fetched
     // ---- this wave's weight panel -> registers --------------------------------------------------------
@@ -263,10 +264,14 @@ __global__ __launch_bounds__(256, 1) void k_conv16_ws(const float* __restrict__ 
     const float bia = (MODE == 0) ? bias[16 * wv + p16] : 0.f;
     if (tile < n_tiles) store_halo(smem, tile);
     __syncthreads();
+    TS(1);
+    int ts_k = 2;
+    (void)ts_k;
     int cur = 0;
     for (; tile < n_tiles; tile += gridDim.x) {
         const int nxt_tile = tile + gridDim.x;
         if (nxt_tile < n_tiles) load_halo(nxt_tile);          // in flight during this tile's MFMAs
+        if (MODE == 0 && ts_k < 12) { TS(ts_k); ++ts_k; }
         const float* halo = smem + cur * C::HALO_FLOATS;
         const float* Ab = halo + C::RS + (1 + p16) * C::PS + kq;   // pixel (row 0, x = p16), channel kq
         f32x4_t acc[8];
@@ -307,7 +312,9 @@ __global__ __launch_bounds__(256, 1) void k_conv16_ws(const float* __restrict__ 
         // next tile's halo -> the other LDS buffer BEFORE this tile's output stores are issued: its loads were
         // issued a whole tile ago, and no store is outstanding yet, so the vmcnt(0) this needs costs nothing
         // (vmcnt counts stores too; after the epilogue it would drain 32 fresh stores per lane)
+        if (MODE == 0 && ts_k < 12) { TS(ts_k); ++ts_k; }
         if (nxt_tile < n_tiles) store_halo(smem + (cur ^ 1) * C::HALO_FLOATS, nxt_tile);
+        if (MODE == 0 && ts_k < 12) { TS(ts_k); ++ts_k; }
         // ---- epilogue: D[i][j]: j = lane & 15 -> channel 16*wv + j, i = 4*(lane>>4) + r -> pixel x ------
         {
             const int b = tile / tiles_per_clip, y0 = (tile % tiles_per_clip) * C::TH;
@@ -328,6 +335,7 @@ __global__ __launch_bounds__(256, 1) void k_conv16_ws(const float* __restrict__ 
         lds_barrier();          // LDS-only: the output stores stay in flight across the tile boundary
         cur ^= 1;
     }
+    if (MODE == 0) { TS(12); }
     if (MODE == 0 && stat != nullptr) {
         st1 += __shfl_xor(st1, 16); st1 += __shfl_xor(st1, 32);
         st2 += __shfl_xor(st2, 16); st2 += __shfl_xor(st2, 32);

@@ -343,6 +343,8 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
     // Stream schedule (kernel timeline of one step, tools/timeline.py): the dgrad chain is the critical path.
     //   main: glu2_bwd  prep | dgrad2            | glu1_bwd  prep | dgrad1          | blk0_bwd  finalize |
     //   side:                | wgrad2  GRU dW/db |                | wgrad1  reduce                       | join
+    // (Forking right behind each recurrence kernel - the upper layer's GEMMs next to the lower layer's 48-workgroup
+    // recurrence - measured slower still, 1.043 ms: every event record splits the critical chain.)
     // (Forking before glu2_bwd so that the GRU GEMMs run first and wgrad1 starts on time measured slower, 1.061 vs
     // 1.029 ms: they then compete with the critical-path kernels glu2_bwd / dgrad2 / glu1_bwd.)
     // (Starting wgrad1 only after dgrad1, next to the VALU-bound k_blk0_bwd, measured the same: dgrad1 drops from

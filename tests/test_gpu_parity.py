@@ -117,7 +117,7 @@ def _fwd_bwd_both(B, T, p, seed, n_layers=2, nclass=10):
     so, wo = ref_cpu.crnn_forward(po, x, True, bn, gu.oracle_masks(seed, B, T, p), n_layers_RNN=n_layers)
     lo = loss_fn(so, wo, "cpu")
     go = dict(zip(po.keys(), torch.autograd.grad(lo, list(po.values()))))
-    return (s.detach().cpu(), w.detach().cpu(), float(loss), g_hip, bn_hip), (so.detach(), wo.detach(), float(lo), go, bn)
+    return (s.detach().cpu(), w.detach().cpu(), float(loss.detach()), g_hip, bn_hip), (so.detach(), wo.detach(), float(lo.detach()), go, bn)
 
 
 def _check_grads(g_hip, go):
@@ -141,12 +141,14 @@ def _check_grads(g_hip, go):
 
 @pytest.mark.parametrize("B,T,p,n_layers,nclass", [(4, 128, 0.0, 2, 10), (4, 128, 0.5, 2, 10), (4, 628, 0.5, 2, 10),
                                                    (5, 216, 0.5, 1, 10), (4, 150, 0.25, 2, 10), (7, 1040, 0.5, 2, 10),
-                                                   (4, 864, 0.5, 2, 10), (6, 96, 0.5, 2, 1), (5, 200, 0.5, 2, 16)])
+                                                   (4, 864, 0.5, 2, 10), (6, 96, 0.5, 2, 1), (5, 200, 0.5, 2, 16),
+                                                   (4, 630, 0.5, 2, 10), (9, 100, 0.5, 2, 10), (4, 22, 0.5, 2, 10)])
 def test_train_forward_backward_vs_oracle(B, T, p, n_layers, nclass):
     """Posteriors, loss, every parameter gradient and the BN running stats against the oracle, with
     dropout ON (same Philox masks on both sides).  T=150 exercises odd H (rows dropped by the pool); T=1040 gives
     130 output frames (more than one 128-frame chunk in the heads kernels) with a batch that is not a multiple of
-    4; T=864 is the reference's own frame count (config.py:17-22); nclass 1 and 16 are the ABI's limits."""
+    4; T=864 is the reference's own frame count (config.py:17-22); nclass 1 and 16 are the ABI's limits; T=630 / 100 / 22
+    are not multiples of 8 (every pooling floor drops rows; 22 frames leave 2 GRU steps - less than one step block)."""
     hip, orc = _fwd_bwd_both(B, T, p, seed=123456789, n_layers=n_layers, nclass=nclass)
     es, _ = gu.report("strong", hip[0], orc[0])
     ew, _ = gu.report("weak", hip[1], orc[1])
@@ -491,3 +493,27 @@ def test_data_parallel_schedule_on_rccl_one_rank_matches_single_process(monkeypa
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B,T", [(1, 628), (3, 864), (1, 16)])
+def test_eval_forward_small_batches_vs_oracle(B, T):
+    """Eval mode (running statistics, no dropout) at the batch sizes the reference's evaluation loop uses (one clip per
+    forward, evaluation_measures.py:204-207) and at the shortest clip the ABI accepts."""
+    model, params = gu.make_model(3, dropout=0.5)
+    bn = gu.synth_bn(3) if hasattr(gu, "synth_bn") else None
+    st = ref_cpu.new_bn_state()
+    rs = np.random.RandomState(17)
+    for k in st:
+        if k.endswith("running_mean"):
+            st[k] = torch.tensor(rs.normal(0, 0.2, st[k].shape), dtype=torch.float32)
+        elif k.endswith("running_var"):
+            st[k] = torch.tensor(rs.uniform(0.5, 1.5, st[k].shape), dtype=torch.float32)
+    gu.set_bn(model, st)
+    model.eval()
+    x = synth.make_input(50 + B, B, T)
+    with torch.no_grad():
+        s, w = model(x.cuda())
+    so, wo = ref_cpu.crnn_forward(params, x, False, st, None, n_layers_RNN=2)
+    assert s.shape == (B, T // 8, 10) and w.shape == (B, 10)
+    np.testing.assert_allclose(s.cpu().numpy(), so.detach().numpy(), atol=POST_TOL)
+    np.testing.assert_allclose(w.cpu().numpy(), wo.detach().numpy(), atol=POST_TOL)

@@ -188,6 +188,10 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in0, 
 //     bank-conflict free;
 //   * BatchNorm sums are accumulated in registers across all tiles of the workgroup: 32 atomics per wave
 //     per launch.
+// Phase timestamps (tools/ts_kernel.py conv1_fwd conv): 18.6 us of MFMAs per tile (94 % of the pipe's rate) + 2.8 us of
+// halo loads / LDS stores / output stores between tiles + 4.4 us prologue.  Moving those 2.8 us INTO the MFMA groups (one
+// load / store item per group, previous tile's accumulators kept in spare registers) was tried and lost: 23.3 us per
+// tile - the waits the compiler attaches to the interleaved memory operations stall the in-order MFMA stream.
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 struct Ws16 {
     static constexpr int TH = 8, TW = 16, HW = 18, HH = 10, PS = 66, RS = HW * PS;

@@ -264,7 +264,9 @@ def main():
             "traffic_source": traffic_src, "algorithmic_bytes": kr[dom]["bytes"], "algorithmic_flops": kr[dom]["flops"],
             "avg_launch_us": kr[dom]["us"],
             "timing": "HIP events on the launch stream around 20 re-launches of this kernel on the step's own "
-                      "buffers (sed_kernel_replay) right after the timed region",
+                      "buffers (sed_kernel_replay) right after the timed region; conv1_wgrad = k_wgrad16_db + its "
+                      "k_wgrad_reduce (the whole operator); the rocprofv3 table's 'last-20 avg' column shows the same "
+                      "launches kernel by kernel",
             "whole_step": {"algorithmic_tflops": round(STEP_FLOP_PER_CLIP / t_clip_us * 1e-6, 2),
                            "frac_of_f32_mfma_peak": round(STEP_FLOP_PER_CLIP / t_clip_us * 1e-6 / PEAK_F32_MFMA_TFLOPS, 4),
                            "algorithmic_gbs": round(STEP_BYTES_PER_CLIP / t_clip_us * 1e-3, 1)},

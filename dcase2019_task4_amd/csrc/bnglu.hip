@@ -482,6 +482,232 @@ __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ 
     TS(10); TSC(15);
 }
 
+// ---- 8-wave variant: two waves per SIMD share one row block, split by channel half ---------------------------------
+// k_glu_pool_bwd above runs one wave per SIMD (415 registers) and that wave issues in order: whatever VALU / LDS /
+// global work is not perfectly interleaved with its MFMAs leaves the MFMA pipe idle (phase timestamps: 9.5 us per row
+// block for 5.7 us of MFMAs).  Here waves w and w+4 - same SIMD - work on the SAME row block: wave half h owns the 32
+// channels [32h, 32h+32) everywhere a channel index is an OUTPUT (lin columns, dz columns, dW rows), so each wave has
+// half the accumulators (<= 256 registers: two waves per SIMD) and, while one wave of the pair is in VALU / LDS /
+// memory instructions, the other's MFMAs keep the pipe busy.  The tile (z, y, dlin) is shared through LDS; three
+// LDS-only workgroup barriers per row block (tile staged | dlin complete | tile free).
+__global__ __launch_bounds__(512, 1) void k_glu_pool_bwd8(const float* __restrict__ y, const float* __restrict__ bn,
+                                                          const float* __restrict__ wglu, const float* __restrict__ bglu,
+                                                          const float* __restrict__ dp, const float* __restrict__ dp_b,
+                                                          float* __restrict__ dz, double* __restrict__ accg, int H, int W, int Ho,
+                                                          int Wo, int Q, int use_drop, float p_drop,
+                                                          const uint16_t* __restrict__ mask_in) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pr = wave & 3, hf = wave >> 2;                 // pair (row-block slot), channel half
+    const int n = lane & 31, kh = lane >> 5;
+    const int c_own = 32 * hf + n;                           // the channel this lane owns as an output column
+    float* WsT = smem + 4 * (3 * 32 * ZS);                   // Wglu transposed [c][co], stride 65
+    float* zt = smem + pr * (3 * 32 * ZS);
+    float* yt = zt + 32 * ZS;
+    float* dlt = yt + 32 * ZS;
+    if (H & 1) {        // the floor-mode pool drops the last row of an odd-height image: its gradient is 0
+        const int per_clip = W * 64, nb = Q / (Ho * Wo);
+        for (int i = blockIdx.x * 512 + tid; i < nb * per_clip; i += gridDim.x * 512) {
+            const int bb = i / per_clip, r = i % per_clip;
+            dz[((size_t)bb * H + (H - 1)) * W * 64 + r] = 0.f;
+        }
+    }
+    for (int e = tid; e < 4096; e += 512) WsT[(e & 63) * ZS + (e >> 6)] = wglu[e];
+    __syncthreads();
+    float bw[32];                                            // phase 1: B[k = c][j = co own half] = Wglu[co][c]
+#pragma unroll
+    for (int s = 0; s < 32; ++s) bw[s] = WsT[(2 * s + kh) * ZS + c_own];
+    const float* BT = WsT + c_own * ZS + kh;                 // phase 2: B[k = co][j = c own half] = WsT[c][co]
+    const float bgl = bglu[c_own];
+    const float sc = 0.125f * (use_drop ? drop_scale8(p_drop) : 1.0f);
+    f32x16 dW[2];                                            // dW[co own half][c block b2]
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dW[b2][r] = 0.f;
+    float sdb = 0.f, sdz = 0.f, sdzy = 0.f;
+    const int n_rb = (Q + 3) / 4;
+    const float4 bsc = *(const float4*)(bn + 128 + (lane & 15) * 4), bsh = *(const float4*)(bn + 192 + (lane & 15) * 4);
+    const float inv_wo = 1.0f / (float)Wo, inv_ho = 1.0f / (float)Ho;
+    auto divmod = [](int a, int d, float inv, int& rem) {
+        int qd = (int)((float)a * inv);
+        int r = a - qd * d;
+        if (r < 0) { r += d; --qd; }
+        if (r >= d) { r -= d; ++qd; }
+        rem = r;
+        return qd;
+    };
+    auto pixel_offsets = [&](int q0, uint32_t (&po)[4]) {     // byte offsets of the 4 pooled pixels' image pixels (dt = df = 0)
+        int wo, ho;
+        const int t = divmod(q0, Wo, inv_wo, wo);
+        int bb = divmod(t, Ho, inv_ho, ho);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            po[j] = (q0 + j < Q) ? (uint32_t)((bb * H + 2 * ho) * W + 4 * wo) * 256u : 0u;
+            if (++wo == Wo) { wo = 0; if (++ho == Ho) { ho = 0; ++bb; } }
+        }
+    };
+    const uint32_t ld_off = (uint32_t)((lane >> 4) * 64 + (lane & 15) * 4) * 4u;
+    const uint32_t st_off = (uint32_t)(kh * W * 64 + c_own) * 4u;
+    // this wave stages rows m = (lane >> 4) + 4 * it for it in [4 hf, 4 hf + 4) of the pair's tile
+    f32x4 yv[4];
+    float gq_n[4];
+    uint32_t m_n = 0xffffu, po_n[4];
+    int q_n = 0;
+    auto prefetch_begin = [&](int rbn, bool valid) {
+        q_n = valid ? rbn * 4 : 0;
+        pixel_offsets(q_n, po_n);
+    };
+    auto prefetch_slice = [&](int k) {                         // k in 0..3
+        // rows it = 4 hf + k: pooled pixel 2 hf + (k >> 1) (selected without indexing po_n by a run-time value, which
+        // would put the array in scratch), image row dt = k & 1
+        const uint32_t pbase = (k >> 1) ? (hf ? po_n[3] : po_n[1]) : (hf ? po_n[2] : po_n[0]);
+        yv[k] = *(const f32x4*)((const char*)y + (pbase + (uint32_t)((k & 1) * W) * 256u + ld_off));
+        const int q = q_n + k;
+        const uint32_t goff = (uint32_t)((q < Q ? q : 0) * 64 + c_own) * 4u;
+        gq_n[k] = *(const float*)((const char*)dp + goff);
+        if (dp_b) gq_n[k] += *(const float*)((const char*)dp_b + goff);
+        if (q >= Q) gq_n[k] = 0.f;
+        if (k == 0) m_n = use_drop ? (uint32_t)mask_in[((size_t)(q_n >> 2) * 2 + hf) * 64 + lane] : 0xffffu;
+    };
+    const int rb0 = blockIdx.x * 4 + pr;
+    prefetch_begin(rb0, rb0 < n_rb);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) prefetch_slice(k);
+    // every pair runs the same number of trips (the barriers are workgroup-wide); pairs past the end idle through them
+    const int trips = (n_rb - blockIdx.x * 4 + gridDim.x * 4 - 1) / (gridDim.x * 4);
+    for (int trip = 0; trip < trips; ++trip) {
+        const int rb = rb0 + trip * gridDim.x * 4;
+        const bool live = rb < n_rb;
+        const int q0 = rb * 4;
+        if (live) {
+            // ---- stage this wave's 4 of the 8 row groups: z = scale * y + shift, and y itself --------------------
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int it = 4 * hf + k, m = (lane >> 4) + 4 * it, c4 = (lane & 15) * 4;
+                const f32x4 v = yv[k];
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                if (q0 + (m >> 3) < Q) { z.x = fmaf(v.x, bsc.x, bsh.x); z.y = fmaf(v.y, bsc.y, bsh.y); z.z = fmaf(v.z, bsc.z, bsh.z); z.w = fmaf(v.w, bsc.w, bsh.w); }
+                float* d = zt + m * ZS + c4;
+                d[0] = z.x; d[1] = z.y; d[2] = z.z; d[3] = z.w;
+                float* e = yt + m * ZS + c4;
+                e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w;
+            }
+        }
+        float gq_c[4];
+        uint32_t po[4];
+        const uint32_t m_c = m_n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { po[j] = po_n[j] + st_off; gq_c[j] = gq_n[j] * sc; }
+        prefetch_begin(rb + gridDim.x * 4, rb + gridDim.x * 4 < n_rb);
+        lds_barrier();                                        // A: the pair's tile is complete
+        f32x16 lin, acc;
+        float dzg[16];
+        if (live) {
+            // ---- phase 1: lin[:, own half] = z @ Wglu^T   ||   sigma(z), dlin = g * sigma -> LDS -------------------
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lin[r] = 0.f;
+            const float* A = zt + n * ZS + kh;
+            float a_c[4], z_c[2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a_c[u] = A[2 * u];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) z_c[u] = zt[mfma32_row(u, lane) * ZS + c_own];
+#pragma unroll
+            for (int g4 = 0; g4 < 8; ++g4) {                  // 4 K-steps + 2 elements per group
+                float a_n[4] = {0.f, 0.f, 0.f, 0.f}, z_n[2] = {0.f, 0.f};
+                if (g4 + 1 < 8) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a_n[u] = A[2 * (4 * (g4 + 1) + u)];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) z_n[u] = zt[mfma32_row(2 * (g4 + 1) + u, lane) * ZS + c_own];
+                }
+                if (g4 < 4) prefetch_slice(g4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) lin = mfma32(a_c[u], bw[4 * g4 + u], lin);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int r = 2 * g4 + u;
+                    const float gg = ((m_c >> r) & 1u) ? gq_c[r >> 2] : 0.f;
+                    const float sg = sigmoidf_fast(z_c[u]);
+                    const float dl = gg * sg;
+                    dlt[mfma32_row(r, lane) * ZS + c_own] = dl;
+                    sdb += dl;
+                    dzg[r] = dl * (1.0f - sg);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a_c[u] = a_n[u];
+                z_c[0] = z_n[0]; z_c[1] = z_n[1];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        lds_barrier();                                        // B: dlin of both halves is in LDS
+        if (live) {
+            // ---- phase 2: dz_lin[:, own half] = dlin @ Wglu   ||   gate path dzg = t * (lin + b) -------------------
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* A = dlt + n * ZS + kh;
+            float a_c = A[0], b_c = BT[0];
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                float a_n = 0.f, b_n = 0.f;
+                if (s + 1 < 32) { a_n = A[2 * (s + 1)]; b_n = BT[2 * (s + 1)]; }
+                acc = mfma32(a_c, b_c, acc);
+                if (s < 16) dzg[s] *= lin[s] + bgl;
+                a_c = a_n; b_c = b_n;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // claim the prefetched registers while only loads are outstanding (vmcnt cannot tell loads from stores)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(yv[k]), "+v"(gq_n[k]));
+            asm volatile("" : "+v"(m_n));
+            // ---- phase 3: dW[own co half][:] += dlin^T z   ||   dz = dz_lin + dzg -> global, BN-backward sums ------
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int mrow = 2 * s + kh;
+                const float a0 = dlt[mrow * ZS + c_own];
+                const float b0 = zt[mrow * ZS + n], b1 = zt[mrow * ZS + 32 + n];
+                dW[0] = mfma32(a0, b0, dW[0]);
+                dW[1] = mfma32(a0, b1, dW[1]);
+                const int r = s, i = mfma32_row(r, lane);
+                const float v = acc[r] + dzg[r];
+                if (q0 + (r >> 2) < Q) {
+                    *(float*)((char*)dz + (po[r >> 2] + (uint32_t)((r & 3) * 64 * 4))) = v;
+                    sdz += v;
+                    sdzy += v * yt[i * ZS + c_own];
+                }
+            }
+        }
+        lds_barrier();                                        // C: the tile may be overwritten
+    }
+    // ---- reduce over the 4 pairs through LDS (each (co, c) lives in exactly one half), then fp64 atomics ---------------
+    float* red = smem;   // [4 pairs][64][64]: 64 KB of the 100 KB of tiles
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[pr * 4096 + (32 * hf + mfma32_row(r, lane)) * 64 + 32 * b2 + n] = dW[b2][r];
+    __syncthreads();
+    for (int i = tid; i < 4096; i += 512)
+        atomicAdd(&accg[i], (double)red[i] + (double)red[4096 + i] + (double)red[8192 + i] + (double)red[12288 + i]);
+    __syncthreads();
+    {
+        const float v0 = sdb + __shfl_xor(sdb, 32), v1 = sdz + __shfl_xor(sdz, 32), v2 = sdzy + __shfl_xor(sdzy, 32);
+        if (kh == 0) {
+            red[(pr * 3 + 0) * 64 + c_own] = v0;
+            red[(pr * 3 + 1) * 64 + c_own] = v1;
+            red[(pr * 3 + 2) * 64 + c_own] = v2;
+        }
+    }
+    __syncthreads();
+    if (tid < 192) {
+        const int which = tid >> 6, c = tid & 63;
+        double v = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) v += (double)red[(w2 * 3 + which) * 64 + c];
+        atomicAdd(&accg[4096 + which * 64 + c], v);
+    }
+}
+
 // BatchNorm-backward coefficients + the block's parameter gradients: a kernel of its own again.  Folding it into the
 // last workgroup of k_glu_pool_bwd (ticket after a workgroup-scope release) was a RACE: about 1 step in 10 the last
 // workgroup read the Sdz / Sdzy accumulators before every other workgroup's fp64 atomics had been performed
@@ -524,7 +750,16 @@ int launch_glu_pool_bwd(const float* y, const float* bn, const float* wglu, cons
     const int n_rb = (Q + 3) / 4;
     int grid = (n_rb + 3) / 4;
     if (grid > 256) grid = 256;
-    k_glu_pool_bwd<<<grid, 256, lds, st>>>(y, bn, wglu, bglu, dp, dp_b, dz, acc, H, W, Ho, Wo, Q, block_id, use_drop, p_drop, mask_in, g_sed_debug & 1);
+    if (g_sed_debug & 16) {          // single-wave-per-SIMD variant (A/B timing)
+        k_glu_pool_bwd<<<grid, 256, lds, st>>>(y, bn, wglu, bglu, dp, dp_b, dz, acc, H, W, Ho, Wo, Q, block_id, use_drop, p_drop, mask_in, g_sed_debug & 1);
+    } else {
+        static bool attr8 = false;
+        if (!attr8) {
+            SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_glu_pool_bwd8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr8 = true;
+        }
+        k_glu_pool_bwd8<<<grid, 512, lds, st>>>(y, bn, wglu, bglu, dp, dp_b, dz, acc, H, W, Ho, Wo, Q, use_drop, p_drop, mask_in);
+    }
     SED_CHECK_LAUNCH();
     k_bn_bwd_prep<<<1, 256, 0, st>>>(a);
     SED_CHECK_LAUNCH();

@@ -228,7 +228,8 @@ int sed_kernel_replay(const char* name, const sed_dims* d, const float* params, 
  *   bit 0: skip the fp64 atomics of the reduction epilogues (results are then WRONG);
  *   bit 1 / 2 / 3: block-1 conv forward / dgrad / wgrad use their alternative kernel (tile kernel instead of the
  *   weight-stationary one, weight-stationary instead of tile, single- instead of double-buffered): same results,
- *   kept for A/B timing (profiles/README.md). */
+ *   kept for A/B timing (profiles/README.md);
+ *   bit 4: GLU backward with one wave per SIMD instead of two channel-half waves sharing a row block. */
 int sed_debug_set(int flags);
 
 /* ---- self tests (run on the GPU box by tests/) ---------------------------------------------

@@ -350,6 +350,150 @@ __global__ __launch_bounds__(256, 1) void k_conv16_ws(const float* __restrict__ 
     }
 }
 
+// ---- 8-wave weight-stationary variant: two waves per SIMD, staggered epilogues ----------------------------------------
+// k_conv16_ws spends 18.6 us of a 21.4 us tile period in MFMAs; the rest (output stores, halo staging) is the lone wave of
+// each SIMD doing something else.  Here every SIMD hosts TWO waves with the same 16-channel weight panel (144 VGPRs
+// each, <= 256 registers per wave): the "early" wave owns image rows 0-3 of the tile and stores its outputs right after
+// its MFMAs, the "late" wave owns rows 4-7 and stores its outputs at the START of the next tile - so whenever one of the
+// two is in its epilogue the other one is issuing MFMAs.  Halo staging is shared by all 512 threads (6 items each).
+struct Ws16x2 {
+    static constexpr int NLD = (Ws16::HH * Ws16::HW * 16 + 511) / 512;     // float4 loads per thread per halo (6)
+};
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void k_conv16_ws2(const float* __restrict__ in0, const float* __restrict__ in1,
+                                                       const float* __restrict__ coef, const float* __restrict__ wpk,
+                                                       const float* __restrict__ bias, float* __restrict__ out,
+                                                       double* __restrict__ stat, int H, int tiles_per_clip, int n_tiles) {
+    using C = Ws16;
+    constexpr int NLD = Ws16x2::NLD;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = wave & 3, rh = wave >> 2;                 // channel group (16 channels), row half (4 image rows)
+    const int p16 = lane & 15, kq = lane >> 4;
+    float st1 = 0.f, st2 = 0.f;
+    f32x4_t pre0[NLD], pre1[NLD];
+    auto load_halo = [&](int tile) {
+        const int b = tile / tiles_per_clip, y0 = (tile % tiles_per_clip) * C::TH;
+        const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int f = tid + 512 * it;
+            const int pix = f >> 4, c4 = (f & 15) * 4;
+            const int hy = pix / C::HW, hx = pix % C::HW;
+            const int iy = y0 - 1 + hy, ix = hx - 1;
+            const bool ok = (f < C::HH * C::HW * 16) && iy >= 0 && iy < H && ix >= 0 && ix < C::TW;
+            const size_t g = ok ? (((size_t)b * H + iy) * C::TW + ix) * 64 + c4 : 0;
+            const f32x4_t v = *(const f32x4_t*)(in0 + g);
+            pre0[it] = ok ? v : z4;
+            if (MODE == 1) { const f32x4_t w = *(const f32x4_t*)(in1 + g); pre1[it] = ok ? w : z4; }
+        }
+    };
+    auto store_halo = [&](float* halo, int tile) {
+        const int y0 = (tile % tiles_per_clip) * C::TH;
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int f = tid + 512 * it;
+            if (f >= C::HH * C::HW * 16) continue;
+            const int pix = f >> 4, c4 = (f & 15) * 4;
+            const int hy = pix / C::HW, hx = pix % C::HW;
+            f32x4_t v = pre0[it];
+            if (MODE == 1) {
+                const int iy = y0 - 1 + hy, ix = hx - 1;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < C::TW) {      // padding stays exactly 0
+                    const f32x4_t ca = *(const f32x4_t*)(coef + c4), cb = *(const f32x4_t*)(coef + 64 + c4), cc = *(const f32x4_t*)(coef + 128 + c4);
+                    v = ca * v + cb * pre1[it] + cc;
+                }
+            }
+            float* d = halo + hy * C::RS + hx * C::PS + c4;          // 8-byte aligned (PS even, c4 % 4 == 0)
+            *(float2*)d = make_float2(v[0], v[1]);
+            *(float2*)(d + 2) = make_float2(v[2], v[3]);
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < n_tiles) load_halo(tile);           // first halo in flight while the weight panel is fetched
+    float bw[9][16];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int s4 = 0; s4 < 16; ++s4) bw[t][s4] = wpk[t * 4096 + (4 * s4 + kq) * 64 + 16 * cg + p16];
+    const float bia = (MODE == 0) ? bias[16 * cg + p16] : 0.f;
+    if (tile < n_tiles) store_halo(smem, tile);
+    __syncthreads();
+    // output rows 4 rh .. 4 rh + 3 of a tile; D[i][j]: j = lane & 15 -> channel 16 cg + j, i = 4 (lane >> 4) + r -> pixel x
+    auto epilogue = [&](const f32x4_t (&a)[4], int t2) {
+        const int b = t2 / tiles_per_clip, y0 = (t2 % tiles_per_clip) * C::TH + 4 * rh;
+#pragma unroll
+        for (int rbl = 0; rbl < 4; ++rbl) {
+            const int yy = y0 + rbl;
+            if (yy < H) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = a[rbl][r] + bia;
+                    out[(((size_t)b * H + yy) * C::TW + 4 * kq + r) * 64 + 16 * cg + p16] = v;
+                    if (MODE == 0) { st1 += v; st2 += v * v; }
+                }
+            }
+        }
+    };
+    f32x4_t acc[4];                                          // lives across iterations: the late wave stores it one tile later
+    int ptile = -1;
+    int cur = 0;
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int nxt_tile = tile + gridDim.x;
+        if (rh == 1 && ptile >= 0) epilogue(acc, ptile);     // late wave: previous tile's outputs, under the early wave's MFMAs
+        if (nxt_tile < n_tiles) load_halo(nxt_tile);
+        const float* halo = smem + cur * C::HALO_FLOATS;
+        const float* Ab = halo + (1 + 4 * rh) * C::RS + (1 + p16) * C::PS + kq;   // pixel (row 4 rh, x = p16), channel kq
+#pragma unroll
+        for (int rbl = 0; rbl < 4; ++rbl) acc[rbl] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        // 72 groups of 8 MFMAs (one tap, two 4-channel K steps, 4 image rows); A fragments of group g+1 are read from
+        // LDS before the MFMAs of group g are issued (register double buffer pinned with sched_barrier)
+        auto load_a = [&](float (&a)[8], int gi) {
+            const int t = gi / 8, sp = gi % 8;
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int rbl = 0; rbl < 4; ++rbl) a[q * 4 + rbl] = Ab[(rbl + dy) * C::RS + dx * C::PS + 4 * (2 * sp + q)];
+        };
+        auto mma = [&](const float (&a)[8], int gi) {
+            const int t = gi / 8, sp = gi % 8;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int rbl = 0; rbl < 4; ++rbl)
+                    acc[rbl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q * 4 + rbl], bw[t][2 * sp + q], acc[rbl], 0, 0, 0);
+        };
+        float a0[8], a1[8];
+        load_a(a0, 0);
+#pragma unroll
+        for (int gi = 0; gi < 72; gi += 2) {
+            load_a(a1, gi + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, gi);
+            __builtin_amdgcn_sched_barrier(0);
+            if (gi + 2 < 72) load_a(a0, gi + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, gi + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (nxt_tile < n_tiles) store_halo(smem + (cur ^ 1) * C::HALO_FLOATS, nxt_tile);
+        if (rh == 0) epilogue(acc, tile);                     // early wave: now, under the late wave's MFMAs
+        ptile = tile;
+        lds_barrier();
+        cur ^= 1;
+    }
+    if (rh == 1 && ptile >= 0) epilogue(acc, ptile);
+    if (MODE == 0 && stat != nullptr) {
+        st1 += __shfl_xor(st1, 16); st1 += __shfl_xor(st1, 32);
+        st2 += __shfl_xor(st2, 16); st2 += __shfl_xor(st2, 32);
+        if (kq == 0) {
+            atomicAdd(&stat[16 * cg + p16], (double)st1);
+            atomicAdd(&stat[64 + 16 * cg + p16], (double)st2);
+        }
+    }
+}
+
 template <int MODE>
 static int conv16_ws_launch(const float* in0, const float* in1, const float* coef, const float* wpk, const float* bias,
                             float* out, double* stat, int B, int H, hipStream_t st) {
@@ -357,11 +501,14 @@ static int conv16_ws_launch(const float* in0, const float* in1, const float* coe
     if (!attr_done) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv16_ws<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)Ws16::LDS_BYTES));
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv16_ws2<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)Ws16::LDS_BYTES));
         attr_done = true;
     }
     const int tpc = (H + Ws16::TH - 1) / Ws16::TH, nt = B * tpc;
     const int grid = nt < 256 ? nt : 256;          // one persistent workgroup per CU
-    k_conv16_ws<MODE><<<grid, 256, Ws16::LDS_BYTES, st>>>(in0, in1, coef, wpk, bias, out, stat, H, tpc, nt);
+    if (g_sed_debug & 32) k_conv16_ws<MODE><<<grid, 256, Ws16::LDS_BYTES, st>>>(in0, in1, coef, wpk, bias, out, stat, H, tpc, nt);
+    else k_conv16_ws2<MODE><<<grid, 512, Ws16::LDS_BYTES, st>>>(in0, in1, coef, wpk, bias, out, stat, H, tpc, nt);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

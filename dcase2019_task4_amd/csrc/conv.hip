@@ -371,12 +371,16 @@ __global__ __launch_bounds__(512, 1) void k_conv16_ws2(const float* __restrict__
     const int cg = wave & 3, rh = wave >> 2;                 // channel group (16 channels), row half (4 image rows)
     const int p16 = lane & 15, kq = lane >> 4;
     float st1 = 0.f, st2 = 0.f;
-    f32x4_t pre0[NLD], pre1[NLD];
-    auto load_halo = [&](int tile) {
+    // dgrad stages two tensors (dz, y) per halo: it fetches the halo in two halves (items [0, NLD/2) before the MFMA loop,
+    // the rest from its middle) so that only NLD/2 float4 pairs are live at a time - all at once spilled (80 B of scratch)
+    constexpr int NH = (MODE == 1) ? NLD / 2 : NLD;
+    f32x4_t pre0[NH], pre1[MODE == 1 ? NH : 1];
+    auto load_halo = [&](int tile, int part) {
         const int b = tile / tiles_per_clip, y0 = (tile % tiles_per_clip) * C::TH;
         const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int it = 0; it < NLD; ++it) {
+        for (int k2 = 0; k2 < NH; ++k2) {
+            const int it = part * NH + k2;
             const int f = tid + 512 * it;
             const int pix = f >> 4, c4 = (f & 15) * 4;
             const int hy = pix / C::HW, hx = pix % C::HW;
@@ -384,24 +388,25 @@ __global__ __launch_bounds__(512, 1) void k_conv16_ws2(const float* __restrict__
             const bool ok = (f < C::HH * C::HW * 16) && iy >= 0 && iy < H && ix >= 0 && ix < C::TW;
             const size_t g = ok ? (((size_t)b * H + iy) * C::TW + ix) * 64 + c4 : 0;
             const f32x4_t v = *(const f32x4_t*)(in0 + g);
-            pre0[it] = ok ? v : z4;
-            if (MODE == 1) { const f32x4_t w = *(const f32x4_t*)(in1 + g); pre1[it] = ok ? w : z4; }
+            pre0[k2] = ok ? v : z4;
+            if (MODE == 1) { const f32x4_t w = *(const f32x4_t*)(in1 + g); pre1[k2] = ok ? w : z4; }
         }
     };
-    auto store_halo = [&](float* halo, int tile) {
+    auto store_halo = [&](float* halo, int tile, int part) {
         const int y0 = (tile % tiles_per_clip) * C::TH;
 #pragma unroll
-        for (int it = 0; it < NLD; ++it) {
+        for (int k2 = 0; k2 < NH; ++k2) {
+            const int it = part * NH + k2;
             const int f = tid + 512 * it;
             if (f >= C::HH * C::HW * 16) continue;
             const int pix = f >> 4, c4 = (f & 15) * 4;
             const int hy = pix / C::HW, hx = pix % C::HW;
-            f32x4_t v = pre0[it];
+            f32x4_t v = pre0[k2];
             if (MODE == 1) {
                 const int iy = y0 - 1 + hy, ix = hx - 1;
                 if (iy >= 0 && iy < H && ix >= 0 && ix < C::TW) {      // padding stays exactly 0
                     const f32x4_t ca = *(const f32x4_t*)(coef + c4), cb = *(const f32x4_t*)(coef + 64 + c4), cc = *(const f32x4_t*)(coef + 128 + c4);
-                    v = ca * v + cb * pre1[it] + cc;
+                    v = ca * v + cb * pre1[k2] + cc;
                 }
             }
             float* d = halo + hy * C::RS + hx * C::PS + c4;          // 8-byte aligned (PS even, c4 % 4 == 0)
@@ -410,14 +415,17 @@ __global__ __launch_bounds__(512, 1) void k_conv16_ws2(const float* __restrict__
         }
     };
     int tile = blockIdx.x;
-    if (tile < n_tiles) load_halo(tile);           // first halo in flight while the weight panel is fetched
+    if (tile < n_tiles) load_halo(tile, 0);        // first halo in flight while the weight panel is fetched
     float bw[9][16];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int s4 = 0; s4 < 16; ++s4) bw[t][s4] = wpk[t * 4096 + (4 * s4 + kq) * 64 + 16 * cg + p16];
     const float bia = (MODE == 0) ? bias[16 * cg + p16] : 0.f;
-    if (tile < n_tiles) store_halo(smem, tile);
+    if (tile < n_tiles) {
+        store_halo(smem, tile, 0);
+        if (MODE == 1) { load_halo(tile, 1); store_halo(smem, tile, 1); }
+    }
     __syncthreads();
     // output rows 4 rh .. 4 rh + 3 of a tile; D[i][j]: j = lane & 15 -> channel 16 cg + j, i = 4 (lane >> 4) + r -> pixel x
     auto epilogue = [&](const f32x4_t (&a)[4], int t2) {
@@ -441,7 +449,7 @@ __global__ __launch_bounds__(512, 1) void k_conv16_ws2(const float* __restrict__
     for (; tile < n_tiles; tile += gridDim.x) {
         const int nxt_tile = tile + gridDim.x;
         if (rh == 1 && ptile >= 0) epilogue(acc, ptile);     // late wave: previous tile's outputs, under the early wave's MFMAs
-        if (nxt_tile < n_tiles) load_halo(nxt_tile);
+        if (nxt_tile < n_tiles) load_halo(nxt_tile, 0);
         const float* halo = smem + cur * C::HALO_FLOATS;
         const float* Ab = halo + (1 + 4 * rh) * C::RS + (1 + p16) * C::PS + kq;   // pixel (row 4 rh, x = p16), channel kq
 #pragma unroll
@@ -471,13 +479,17 @@ __global__ __launch_bounds__(512, 1) void k_conv16_ws2(const float* __restrict__
             load_a(a1, gi + 1);
             __builtin_amdgcn_sched_barrier(0);
             mma(a0, gi);
+            if (MODE == 1 && gi == 36 && nxt_tile < n_tiles) {      // first half of the next halo -> LDS, second half in flight
+                store_halo(smem + (cur ^ 1) * C::HALO_FLOATS, nxt_tile, 0);
+                load_halo(nxt_tile, 1);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (gi + 2 < 72) load_a(a0, gi + 2);
             __builtin_amdgcn_sched_barrier(0);
             mma(a1, gi + 1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (nxt_tile < n_tiles) store_halo(smem + (cur ^ 1) * C::HALO_FLOATS, nxt_tile);
+        if (nxt_tile < n_tiles) store_halo(smem + (cur ^ 1) * C::HALO_FLOATS, nxt_tile, MODE == 1 ? 1 : 0);
         if (rh == 0) epilogue(acc, tile);                     // early wave: now, under the late wave's MFMAs
         ptile = tile;
         lds_barrier();
@@ -794,10 +806,10 @@ int launch_conv_fwd(const float* in, const float* wpk, const float* bias, float*
 
 int launch_conv_dgrad(const float* dz, const float* yin, const float* coef, const float* wpkT, float* dx, int B, int H,
                       int W, hipStream_t st) {
-    // dgrad: the tile kernel measures the same as the weight-stationary one here (the two extra prefetch
-    // registers sets of the affine loader push the WS variant into AGPR shuffling); bit 2 of the debug knob flips it
-    if (W == 16) return (g_sed_debug & 4) ? conv16_ws_launch<1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st)
-                                          : conv_launch_t<16, 1, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st);
+    // dgrad: the 8-wave weight-stationary kernel and the tile kernel measure the same alone (101 us); inside the step the
+    // former is 3 us better; bit 2 of the debug knob selects the tile kernel
+    if (W == 16) return (g_sed_debug & 4) ? conv_launch_t<16, 1, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st)
+                                          : conv16_ws_launch<1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st);
     if (W == 4) return conv_launch_t<4, 1, 2>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st);
     sed_set_error("conv dgrad: unsupported width %d", W);
     return SED_ERR_UNSUPPORTED;

@@ -227,8 +227,8 @@ int sed_kernel_replay(const char* name, const sed_dims* d, const float* params, 
 /* Debug knob for timing experiments (returns the previous value); 0 = normal operation.
  *   bit 0: skip the fp64 atomics of the reduction epilogues (results are then WRONG);
  *   bit 1 / 2 / 3: block-1 conv forward / dgrad / wgrad use their alternative kernel (tile kernel instead of the
- *   weight-stationary one, weight-stationary instead of tile, single- instead of double-buffered): same results,
- *   kept for A/B timing (profiles/README.md);
+ *   weight-stationary one for forward and dgrad; single- instead of double-buffered wgrad); bit 5: the 4-wave instead
+ *   of the 8-wave weight-stationary kernel.  Same results, kept for A/B timing (profiles/README.md);
  *   bit 4: GLU backward with one wave per SIMD instead of two channel-half waves sharing a row block. */
 int sed_debug_set(int flags);
 

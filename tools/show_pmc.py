@@ -1,3 +1,6 @@
+"""Per-kernel MFMA-pipe utilisation and wait fractions from tools/pmc_conv.sh's rocprofv3 --pmc run (SQ counters on
+solo kernel replays): mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 8 ... ) normalised as in MI355X_MICROARCH.md
+(busy cycles / 32 / GRBM_GUI_ACTIVE).  Usage: python tools/show_pmc.py [--md] > profiles/xxx_pmc_mfma_busy.md"""
 import sqlite3, collections, glob, sys
 res = collections.defaultdict(dict)
 for db in glob.glob('/root/repo/gpurun_out/pmcq_*/r01_results.db'):
@@ -6,9 +9,16 @@ for db in glob.glob('/root/repo/gpurun_out/pmcq_*/r01_results.db'):
         k = name.split('(')[0]
         res[k][cn] = avg
         res[k]['dur_us'] = dur / 1000
-for k, r in res.items():
+md = '--md' in sys.argv
+if md:
+    print('| kernel (solo replay) | us | clock GHz | MFMA pipe busy | wave cycles waiting (any) | waiting on instruction issue | LDS bank-conflict cycles |')
+    print('|---|---:|---:|---:|---:|---:|---:|')
+for k, r in sorted(res.items(), key=lambda kv: -kv[1].get('dur_us', 0)):
     if 'SQ_VALU_MFMA_BUSY_CYCLES' not in r or r['dur_us'] < 10:
         continue
     clk = r.get('GRBM_GUI_ACTIVE', 0) / r['dur_us'] / 1e3
     mf = r['SQ_VALU_MFMA_BUSY_CYCLES'] / 32 / max(r.get('GRBM_GUI_ACTIVE', 1), 1)
+    if md:
+        print(f"| `{k}` | {r['dur_us']:.1f} | {clk:.2f} | {mf:.3f} | {r.get('SQ_WAIT_ANY',0)/max(r.get('SQ_WAVE_CYCLES',1),1):.2f} | {r.get('SQ_WAIT_INST_ANY',0)/max(r.get('SQ_WAVE_CYCLES',1),1):.2f} | {r.get('SQ_LDS_BANK_CONFLICT',0):.0f} |")
+        continue
     print(f"{k:40s} {r['dur_us']:8.1f} us  clk {clk:.2f} GHz  mfma_util {mf:.3f}  wait_any/wave {r.get('SQ_WAIT_ANY',0)/max(r.get('SQ_WAVE_CYCLES',1),1):.2f}  wait_inst/wave {r.get('SQ_WAIT_INST_ANY',0)/max(r.get('SQ_WAVE_CYCLES',1),1):.2f}  bankconf {r.get('SQ_LDS_BANK_CONFLICT',0):.0f}")

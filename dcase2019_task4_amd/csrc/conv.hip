@@ -629,6 +629,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_wgrad(const float* __restrict__
 // exist twice (2 x 77 KB = 154 KB of the CU's 160 KB) and the next tile arrives in 8 register-staged slices, one
 // per image row of MFMAs: slice c is LOADED during row c and written to the other LDS buffer (with the
 // BatchNorm-backward affine applied) at the start of row c+1, i.e. 2 us later; one LDS-only barrier per tile.
+// (An 8-wave variant - two waves per SIMD splitting the 9 taps 5 + 4, the recipe that helped the forward / dgrad kernels -
+// measured exactly the same, alone and in the step, and was dropped.)
 struct Wg16 {
     static constexpr int TH = 8, TW = 16, HW = 18, HH = 10;
     static constexpr int XH_FLOATS = HH * HW * 64, DY_FLOATS = 128 * 64, BUF_FLOATS = XH_FLOATS + DY_FLOATS;

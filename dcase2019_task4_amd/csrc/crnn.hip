@@ -363,7 +363,6 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
                                       grads + P.conv_w[i], g.B, Hs[i], Wd[i], ss));
             if (parts == 3) {
                 SED_TRY(gru_weight_grads(ss));
-                if (sd.ok) SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, ss));
             }
             SED_TRY(launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], st));
         } else {
@@ -371,6 +370,9 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
             SED_TRY(launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], st));
             SED_TRY(launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(pin[i]), WSF(W.wg_part), W.wgrad_blocks,
                                       grads + P.conv_w[i], g.B, Hs[i], Wd[i], ss));
+            // the head weight-gradient column sum (deferred from part 1) last: queued in front of wgrad1 it sat 60 us behind
+            // the persistent dgrad kernel and held wgrad1 back
+            if (parts == 3 && sd.ok) SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, ss));
         }
     }
     // ---- conv block 0 ---------------------------------------------------------------------------

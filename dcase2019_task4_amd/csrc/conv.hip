@@ -33,11 +33,46 @@ struct ConvCfg {
     static constexpr size_t LDS_BYTES = (size_t)(HALO_FLOATS + 2 * W_FLOATS) * 4;
 };
 
+// U = G g G^T of one 3x3 kernel (Winograd F(2x2, 3x3)), written to U[pos][k][n] (pos = 4 i + j)
+__device__ __forceinline__ void wino_u(const float (&g)[3][3], float* __restrict__ U, int kn) {
+    float t[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        t[0][b] = g[0][b];
+        t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+        t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+        t[3][b] = g[2][b];
+    }
+#pragma unroll
+    for (int i2 = 0; i2 < 4; ++i2) {
+        U[(4 * i2 + 0) * 4096 + kn] = t[i2][0];
+        U[(4 * i2 + 1) * 4096 + kn] = 0.5f * (t[i2][0] + t[i2][1] + t[i2][2]);
+        U[(4 * i2 + 2) * 4096 + kn] = 0.5f * (t[i2][0] - t[i2][1] + t[i2][2]);
+        U[(4 * i2 + 3) * 4096 + kn] = t[i2][2];
+    }
+}
 __global__ void k_conv_pack(const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ wpk1,
                             float* __restrict__ wpk2, float* __restrict__ wpkT1, float* __restrict__ wpkT2,
-                            double* __restrict__ zero, int n_zero) {
+                            float* __restrict__ wino1, float* __restrict__ winoT1, double* __restrict__ zero, int n_zero) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;   // over [layer][tap][ci][co]
     if (i < n_zero) zero[i] = 0.0;                   // the forward's fp64 BatchNorm accumulators (saves a memset node)
+    if (wino1 && i < 4096) {                         // layer 1, forward: U[pos][k = ci][n = co] from g[a][b] = W[co][ci][a][b]
+        const int k = i >> 6, n2 = i & 63;
+        float g[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = w1[(n2 * 64 + k) * 9 + 3 * a + b];
+        wino_u(g, wino1, i);
+    } else if (winoT1 && i >= 4096 && i < 8192) {    // layer 1, dgrad: U[pos][k = co][n = ci] from the flipped kernel
+        const int kn = i - 4096, k = kn >> 6, n2 = kn & 63;
+        float g[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = w1[(k * 64 + n2) * 9 + 3 * (2 - a) + (2 - b)];
+        wino_u(g, winoT1, kn);
+    }
     if (i >= 2 * 9 * 64 * 64) return;
     const int layer = i / (9 * 4096);
     i -= layer * 9 * 4096;
@@ -506,6 +541,192 @@ __global__ __launch_bounds__(512, 1) void k_conv16_ws2(const float* __restrict__
     }
 }
 
+// ---- Winograd F(2x2, 3x3) variant of the 8-wave weight-stationary kernel -------------------------------------------------
+// The MFMA pipe is what bounds the block-1 convolutions, so do fewer multiplies: Y = A^T [ sum_ci (G g G^T) . (B^T d B) ] A
+// needs 16 multiplies per 2x2 output block and (ci, co) pair instead of 36 - 2.25x less MFMA work, at the price of 12 LDS
+// reads + ~30 adds per 8 MFMAs for the input transform (done on the fly from the raw halo tile in LDS) and a 4-value
+// inverse transform per block in the epilogue.  Layout of the work:
+//   * tile = 8 image rows x 16 columns = 32 blocks of 2x2; an MFMA tile (16x16x4) is 16 blocks x 16 output channels,
+//     K = 4 input channels; there is one such product per transform position (16 of them);
+//   * 8 waves: wave (cg, ph) owns output channels [16 cg, 16 cg + 16) and the 8 positions of transform rows 2 ph, 2 ph + 1
+//     - its share of the transformed weights is 8 x 64 x 16 floats = 128 VGPRs, loaded once (weight-stationary);
+//   * the two waves of a channel group (same SIMD) each inverse-transform their own positions into a PARTIAL 2x2 output
+//     (the transform is linear); the ph = 1 wave hands its partial over through LDS and moves on to the next tile, the
+//     ph = 0 wave adds, applies the bias, accumulates the BatchNorm sums and stores.
+// Rounding: the transforms use only additions and halvings; results differ from the direct kernel at the 1e-7 level
+// (parity tests unchanged).
+struct Wino16 {
+    static constexpr int XCH_FLOATS = 4 * 32 * 64;                       // [cg][32 partial outputs][lane]
+    static constexpr size_t LDS_BYTES = Ws16::LDS_BYTES + (size_t)XCH_FLOATS * 4;
+};
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void k_conv16_wino(const float* __restrict__ in0, const float* __restrict__ in1,
+                                                        const float* __restrict__ coef, const float* __restrict__ U,
+                                                        const float* __restrict__ bias, float* __restrict__ out,
+                                                        double* __restrict__ stat, int H, int tiles_per_clip, int n_tiles) {
+    using C = Ws16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xch = smem + 2 * C::HALO_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = wave & 3, ph = wave >> 2;
+    const int i16 = lane & 15, kq = lane >> 4;
+    float st1 = 0.f, st2 = 0.f;
+    // the next tile's halo is fetched in PARTS pieces (registers are the scarce resource here): 2880 float4 = 5.6 per thread
+    constexpr int PARTS = (MODE == 1) ? 4 : 2, NH = (MODE == 1) ? 2 : 3;
+    f32x4_t pre0[NH], pre1[MODE == 1 ? NH : 1];
+    auto load_halo = [&](int tile, int part) {
+        const int b = tile / tiles_per_clip, y0 = (tile % tiles_per_clip) * C::TH;
+        const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k2 = 0; k2 < NH; ++k2) {
+            const int f = tid + 512 * (part * NH + k2);
+            const int pix = f >> 4, c4 = (f & 15) * 4;
+            const int hy = pix / C::HW, hx = pix % C::HW;
+            const int iy = y0 - 1 + hy, ix = hx - 1;
+            const bool ok = (f < C::HH * C::HW * 16) && iy >= 0 && iy < H && ix >= 0 && ix < C::TW;
+            const size_t g = ok ? (((size_t)b * H + iy) * C::TW + ix) * 64 + c4 : 0;
+            const f32x4_t v = *(const f32x4_t*)(in0 + g);
+            pre0[k2] = ok ? v : z4;
+            if (MODE == 1) { const f32x4_t w = *(const f32x4_t*)(in1 + g); pre1[k2] = ok ? w : z4; }
+        }
+    };
+    auto store_halo = [&](float* halo, int tile, int part) {
+        const int y0 = (tile % tiles_per_clip) * C::TH;
+#pragma unroll
+        for (int k2 = 0; k2 < NH; ++k2) {
+            const int f = tid + 512 * (part * NH + k2);
+            if (f >= C::HH * C::HW * 16) continue;
+            const int pix = f >> 4, c4 = (f & 15) * 4;
+            const int hy = pix / C::HW, hx = pix % C::HW;
+            f32x4_t v = pre0[k2];
+            if (MODE == 1) {
+                const int iy = y0 - 1 + hy, ix = hx - 1;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < C::TW) {      // padding stays exactly 0
+                    const f32x4_t ca = *(const f32x4_t*)(coef + c4), cb = *(const f32x4_t*)(coef + 64 + c4), cc = *(const f32x4_t*)(coef + 128 + c4);
+                    v = ca * v + cb * pre1[k2] + cc;
+                }
+            }
+            float* d = halo + hy * C::RS + hx * C::PS + c4;
+            *(float2*)d = make_float2(v[0], v[1]);
+            *(float2*)(d + 2) = make_float2(v[2], v[3]);
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < n_tiles) load_halo(tile, 0);
+    // this wave's transformed weights: positions p8 = 4 il + j <-> (i = 2 ph + il, j); B[k = ci][n = co]
+    float uw[8][16];
+#pragma unroll
+    for (int p8 = 0; p8 < 8; ++p8)
+#pragma unroll
+        for (int s4 = 0; s4 < 16; ++s4) uw[p8][s4] = U[(size_t)(8 * ph + p8) * 4096 + (4 * s4 + kq) * 64 + 16 * cg + i16];
+    const float bia = (MODE == 0) ? bias[16 * cg + i16] : 0.f;
+    if (tile < n_tiles) {
+        store_halo(smem, tile, 0);
+#pragma unroll
+        for (int p2 = 1; p2 < PARTS; ++p2) { load_halo(tile, p2); store_halo(smem, tile, p2); }
+    }
+    __syncthreads();
+    // input-transform rows of this wave: T_a = ta0 r0 + ta1 r1 + ta2 r2, T_b likewise, with r = patch rows ph .. ph + 2
+    //   ph = 0: T0 = d0 - d2, T1 = d1 + d2;   ph = 1 (r = d1, d2, d3): T2 = d2 - d1, T3 = d1 - d3
+    const float ta0 = ph ? -1.f : 1.f, ta1 = ph ? 1.f : 0.f, ta2 = ph ? 0.f : -1.f;
+    const float tb0 = ph ? 1.f : 0.f, tb1 = ph ? 0.f : 1.f, tb2 = ph ? -1.f : 1.f;
+    // inverse-transform rows: Y0 = q_a + e q_b, Y1 = f0 q_a + f1 q_b   (A^T = [1 1 1 0; 0 1 -1 -1], rows 2 ph, 2 ph + 1)
+    const float ye = ph ? 0.f : 1.f, yf0 = ph ? -1.f : 0.f, yf1 = ph ? -1.f : 1.f;
+    int cur = 0;
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int nxt_tile = tile + gridDim.x;
+        const bool has_next = nxt_tile < n_tiles;
+        const float* halo = smem + cur * C::HALO_FLOATS;
+        float* halo_nxt = smem + (cur ^ 1) * C::HALO_FLOATS;
+        const int b = tile / tiles_per_clip, y0 = (tile % tiles_per_clip) * C::TH;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            if (has_next) load_halo(nxt_tile, mt * (PARTS / 2));
+            // block of this lane as an MFMA row: blk = 16 mt + i16 -> (br, bc); rows ph .. ph + 2 of its 4 x 4 patch
+            const int blk = 16 * mt + i16, br = blk >> 3, bc = blk & 7;
+            const float* Pb = halo + (2 * br + ph) * C::RS + (2 * bc) * C::PS + kq;
+            f32x4_t acc[8];
+#pragma unroll
+            for (int p8 = 0; p8 < 8; ++p8) acc[p8] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            float r[12];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) r[q] = Pb[(q >> 2) * C::RS + (q & 3) * C::PS];
+#pragma unroll
+            for (int s4 = 0; s4 < 16; ++s4) {
+                float va[4], vb[4];
+                {
+                    float Ta[4], Tb[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        Ta[q] = fmaf(ta0, r[q], fmaf(ta1, r[4 + q], ta2 * r[8 + q]));
+                        Tb[q] = fmaf(tb0, r[q], fmaf(tb1, r[4 + q], tb2 * r[8 + q]));
+                    }
+                    va[0] = Ta[0] - Ta[2]; va[1] = Ta[1] + Ta[2]; va[2] = Ta[2] - Ta[1]; va[3] = Ta[1] - Ta[3];
+                    vb[0] = Tb[0] - Tb[2]; vb[1] = Tb[1] + Tb[2]; vb[2] = Tb[2] - Tb[1]; vb[3] = Tb[1] - Tb[3];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (s4 + 1 < 16) {
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) r[q] = Pb[(q >> 2) * C::RS + (q & 3) * C::PS + 4 * (s4 + 1)];
+                }
+                if (MODE == 1 && s4 == 8 && has_next) {          // dgrad: four quarter-halos per tile
+                    store_halo(halo_nxt, nxt_tile, 2 * mt);
+                    load_halo(nxt_tile, 2 * mt + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[j], uw[j][s4], acc[j], 0, 0, 0);
+                    acc[4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vb[j], uw[4 + j][s4], acc[4 + j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (has_next) store_halo(halo_nxt, nxt_tile, MODE == 1 ? 2 * mt + 1 : mt);
+            // partial inverse transform of this wave's 8 positions: D register r <-> block 4 kq + r of the MFMA tile
+            float yp[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float qa0 = acc[0][q] + acc[1][q] + acc[2][q], qa1 = acc[1][q] - acc[2][q] - acc[3][q];
+                const float qb0 = acc[4][q] + acc[5][q] + acc[6][q], qb1 = acc[5][q] - acc[6][q] - acc[7][q];
+                yp[q][0] = fmaf(ye, qb0, qa0);                 // Y[0][0]
+                yp[q][1] = fmaf(ye, qb1, qa1);                 // Y[0][1]
+                yp[q][2] = fmaf(yf0, qa0, yf1 * qb0);          // Y[1][0]
+                yp[q][3] = fmaf(yf0, qa1, yf1 * qb1);          // Y[1][1]
+            }
+            float* xw = xch + ((cg * 2 + mt) * 16) * 64 + lane;
+            if (ph == 1) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) xw[q * 64] = yp[q >> 2][q & 3];
+            }
+            lds_barrier();            // partials of the ph = 1 waves visible (mt = 1: next halo complete as well)
+            if (ph == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ob = 16 * mt + 4 * kq + q, obr = ob >> 3, obc = ob & 7;
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        const int yy = y0 + 2 * obr + (o >> 1), xx = 2 * obc + (o & 1);
+                        if (yy < H) {
+                            const float v = yp[q][o] + xw[(q * 4 + o) * 64] + bia;
+                            out[(((size_t)b * H + yy) * C::TW + xx) * 64 + 16 * cg + i16] = v;
+                            if (MODE == 0) { st1 += v; st2 += v * v; }
+                        }
+                    }
+                }
+            }
+        }
+        cur ^= 1;
+    }
+    if (MODE == 0 && stat != nullptr && ph == 0) {
+        st1 += __shfl_xor(st1, 16); st1 += __shfl_xor(st1, 32);
+        st2 += __shfl_xor(st2, 16); st2 += __shfl_xor(st2, 32);
+        if (kq == 0) {
+            atomicAdd(&stat[16 * cg + i16], (double)st1);
+            atomicAdd(&stat[64 + 16 * cg + i16], (double)st2);
+        }
+    }
+}
+
 template <int MODE>
 static int conv16_ws_launch(const float* in0, const float* in1, const float* coef, const float* wpk, const float* bias,
                             float* out, double* stat, int B, int H, hipStream_t st) {
@@ -515,11 +736,14 @@ static int conv16_ws_launch(const float* in0, const float* in1, const float* coe
                                           (int)Ws16::LDS_BYTES));
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv16_ws2<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)Ws16::LDS_BYTES));
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv16_wino<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)Wino16::LDS_BYTES));
         attr_done = true;
     }
     const int tpc = (H + Ws16::TH - 1) / Ws16::TH, nt = B * tpc;
     const int grid = nt < 256 ? nt : 256;          // one persistent workgroup per CU
     if (g_sed_debug & 32) k_conv16_ws<MODE><<<grid, 256, Ws16::LDS_BYTES, st>>>(in0, in1, coef, wpk, bias, out, stat, H, tpc, nt);
+    else if (g_sed_debug & 64) k_conv16_wino<MODE><<<grid, 512, Wino16::LDS_BYTES, st>>>(in0, in1, coef, wpk + SED_WINO_OFF, bias, out, stat, H, tpc, nt);
     else k_conv16_ws2<MODE><<<grid, 512, Ws16::LDS_BYTES, st>>>(in0, in1, coef, wpk, bias, out, stat, H, tpc, nt);
     SED_CHECK_LAUNCH();
     return SED_OK;
@@ -775,7 +999,9 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 // ---- host launchers ---------------------------------------------------------------------------
 int launch_conv_pack(const float* w1, const float* w2, float* wpk1, float* wpk2, float* wpkT1, float* wpkT2, double* zero,
                      int n_zero, hipStream_t st) {
-    k_conv_pack<<<(2 * 9 * 4096 + 255) / 256, 256, 0, st>>>(w1, w2, wpk1, wpk2, wpkT1, wpkT2, zero, n_zero);
+    // the layer-1 panels are followed by their Winograd-transformed form (SED_WINO_OFF floats in)
+    k_conv_pack<<<(2 * 9 * 4096 + 255) / 256, 256, 0, st>>>(w1, w2, wpk1, wpk2, wpkT1, wpkT2, wpk1 + SED_WINO_OFF,
+                                                             wpkT1 ? wpkT1 + SED_WINO_OFF : nullptr, zero, n_zero);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

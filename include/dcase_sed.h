@@ -229,7 +229,9 @@ int sed_kernel_replay(const char* name, const sed_dims* d, const float* params, 
  *   bit 1 / 2 / 3: block-1 conv forward / dgrad / wgrad use their alternative kernel (tile kernel instead of the
  *   weight-stationary one for forward and dgrad; single- instead of double-buffered wgrad); bit 5: the 4-wave instead
  *   of the 8-wave weight-stationary kernel.  Same results, kept for A/B timing (profiles/README.md);
- *   bit 4: GLU backward with one wave per SIMD instead of two channel-half waves sharing a row block. */
+ *   bit 4: GLU backward with one wave per SIMD instead of two channel-half waves sharing a row block;
+ *   bit 6: block-1 conv forward / dgrad by the direct (9-tap) 8-wave kernel instead of the Winograd F(2x2, 3x3) one
+ *   (results differ at the 1e-7 level). */
 int sed_debug_set(int flags);
 
 /* ---- self tests (run on the GPU box by tests/) ---------------------------------------------

@@ -95,7 +95,7 @@ WsLayout make_ws_layout(const Geo& g);
 // fp64 accumulators of k_glu_pool_bwd: [0,4096) dWglu[co][c]; [4096,4160) dbglu; [4160,4224) sum dz; [4224,4288) sum dz*y;
 // [4288] ticket of the last-workgroup epilogue (uint32 in a double slot); padded to a multiple of 8
 #define SED_GLUACC_N 4296
-#define SED_WINO_OFF (9 * 4096)   // layer-1 weight panels: [9 taps][64][64] followed by [16 Winograd positions][64][64]
+#define SED_WINO_OFF (9 * 4096)   // conv weight panels: [9 taps][64][64] followed by the 16 x 64 x 64 Winograd-domain weights
 
 // ---- device helpers ------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

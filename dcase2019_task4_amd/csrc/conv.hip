@@ -61,27 +61,24 @@ __device__ __forceinline__ void wino_u(const float (&g)[3][3], float* __restrict
 }
 __global__ void k_conv_pack(const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ wpk1,
                             float* __restrict__ wpk2, float* __restrict__ wpkT1, float* __restrict__ wpkT2,
-                            float* __restrict__ wino1, float* __restrict__ winoT1, double* __restrict__ zero, int n_zero) {
+                            double* __restrict__ zero, int n_zero) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;   // over [layer][tap][ci][co]
     if (i < n_zero) zero[i] = 0.0;                   // the forward's fp64 BatchNorm accumulators (saves a memset node)
-    if (wino1 && i < 4096) {                         // layer 1, forward: U[pos][k = ci][n = co] from g[a][b] = W[co][ci][a][b]
-        const int k = i >> 6, n2 = i & 63;
-        float g[3][3];
+    if (i < 4 * 4096) {                              // Winograd panels: [layer][forward | dgrad]
+        const int which = i >> 12, kn = i & 4095, k = kn >> 6, n2 = kn & 63;
+        const float* w = (which >> 1) ? w2 : w1;
+        float* dst = (which >> 1) ? ((which & 1) ? wpkT2 : wpk2) : ((which & 1) ? wpkT1 : wpk1);
+        if (dst != nullptr) {
+            float g[3][3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+            for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) g[a][b] = w1[(n2 * 64 + k) * 9 + 3 * a + b];
-        wino_u(g, wino1, k, n2);
-    } else if (winoT1 && i >= 4096 && i < 8192) {    // layer 1, dgrad: U[pos][k = co][n = ci] from the flipped kernel
-        const int kn = i - 4096, k = kn >> 6, n2 = kn & 63;
-        float g[3][3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) g[a][b] = w1[(k * 64 + n2) * 9 + 3 * (2 - a) + (2 - b)];
-        wino_u(g, winoT1, k, n2);
+                for (int b = 0; b < 3; ++b)
+                    // forward: B[k = ci][n = co] from g[a][b] = W[co][ci][a][b]; dgrad: B[k = co][n = ci] from the flipped kernel
+                    g[a][b] = (which & 1) ? w[(k * 64 + n2) * 9 + 3 * (2 - a) + (2 - b)] : w[(n2 * 64 + k) * 9 + 3 * a + b];
+            wino_u(g, dst + SED_WINO_OFF, k, n2);
+        }
     }
-    if (i >= 2 * 9 * 64 * 64) return;
     const int layer = i / (9 * 4096);
     i -= layer * 9 * 4096;
     const float* w = layer ? w2 : w1;
@@ -563,20 +560,35 @@ __global__ __launch_bounds__(512, 1) void k_conv16_ws2(const float* __restrict__
 //     ph = 0 wave adds, applies the bias, accumulates the BatchNorm sums and stores.
 // Rounding: the transforms use only additions and halvings; results differ from the direct kernel at the 1e-7 level
 // (parity tests unchanged).
-struct Wino16 {
-    static constexpr int XCH_FLOATS = 4 * 32 * 64;                       // [cg][32 partial outputs][lane]
-    static constexpr size_t LDS_BYTES = Ws16::LDS_BYTES + (size_t)(XCH_FLOATS + 192 + 4) * 4;   // + coefficients + dump slot
+//   * TW = 4 (block 2: 157 x 4 images): one MFMA tile per workgroup tile (16 image rows x 4 columns), 240 tiles at
+//     B = 24 - one per workgroup, so the launch is mostly the weight prologue; still 2.5x faster than the 9-tap tile kernel.
+template <int TW_>
+struct Wino {
+    static constexpr int TW = TW_, BC = TW / 2;                          // blocks per image row
+    static constexpr int NMT = (TW == 16) ? 2 : 1;                       // MFMA tiles (16 blocks) per workgroup tile
+    static constexpr int TH = 2 * (16 * NMT / BC);                       // image rows per tile: 8 (TW 16), 16 (TW 4)
+    static constexpr int HW = TW + 2, HH = TH + 2, PS = 66, RS = HW * PS;
+    static constexpr int HALO_FLOATS = HH * RS, HALO_F4 = HH * HW * 16;
+    static constexpr int XCH_FLOATS = 4 * NMT * 16 * 64;                 // [cg][mtile][16 partial outputs][lane]
+    static constexpr size_t LDS_BYTES = (size_t)(2 * HALO_FLOATS + XCH_FLOATS + 192 + 4) * 4;   // + coefficients + dump slot
+    static constexpr int STEPS = 16 * NMT;                               // k-steps (4 input channels each) per tile
 };
-template <int MODE>
-__global__ __launch_bounds__(512, 1) void k_conv16_wino(const float* __restrict__ in0, const float* __restrict__ in1,
+// piece p of the halo prefetch is issued at k-step p * STEPS / PARTS of the tile and stored to LDS right before the next one
+__host__ __device__ constexpr int wino_piece_at(int gs, int steps, int parts) {
+    for (int p2 = 1; p2 < parts; ++p2)
+        if (p2 * steps / parts == gs) return p2;
+    return 0;
+}
+template <int TW, int MODE>
+__global__ __launch_bounds__(512, 1) void k_conv_wino(const float* __restrict__ in0, const float* __restrict__ in1,
                                                         const float* __restrict__ coef, const float* __restrict__ U,
                                                         const float* __restrict__ bias, float* __restrict__ out,
                                                         double* __restrict__ stat, int H, int tiles_per_clip, int n_tiles) {
-    using C = Ws16;
+    using C = Wino<TW>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xch = smem + 2 * C::HALO_FLOATS;
-    float* dump = xch + Wino16::XCH_FLOATS + 192;
-    float* cfs = xch + Wino16::XCH_FLOATS;                   // dgrad: the three BatchNorm-backward coefficient rows
+    float* dump = xch + C::XCH_FLOATS + 192;
+    float* cfs = xch + C::XCH_FLOATS;                   // dgrad: the three BatchNorm-backward coefficient rows
     if (MODE == 1) {
         if (threadIdx.x < 192) cfs[threadIdx.x] = coef[threadIdx.x];
         __syncthreads();
@@ -585,8 +597,10 @@ __global__ __launch_bounds__(512, 1) void k_conv16_wino(const float* __restrict_
     const int cg = wave & 3, ph = wave >> 2;
     const int i16 = lane & 15, kq = lane >> 4;
     float st1 = 0.f, st2 = 0.f;
-    // the next tile's halo is fetched in PARTS pieces (registers are the scarce resource here): 2880 float4 = 5.6 per thread
-    constexpr int PARTS = (MODE == 1) ? 6 : 2, NH = (MODE == 1) ? 1 : 3, PPM = PARTS / 2;
+    // the next tile's halo is fetched in PARTS pieces of NH float4 per thread (registers are the scarce resource here;
+    // dgrad fetches two arrays): 2880 float4 = 5.6 per thread for TW = 16, 1728 = 3.4 for TW = 4
+    constexpr int NLD = (C::HALO_F4 + 511) / 512;
+    constexpr int NH = (MODE == 1) ? 1 : (NLD + 1) / 2, PARTS = (NLD + NH - 1) / NH;
     f32x4_t pre0[NH], pre1[MODE == 1 ? NH : 1];
     // raw loads only (padding is applied when the values go to LDS: a select here would make the compiler wait for the
     // loads on the spot)
@@ -598,7 +612,7 @@ __global__ __launch_bounds__(512, 1) void k_conv16_wino(const float* __restrict_
             const int pix = f >> 4, c4 = (f & 15) * 4;
             const int hy = pix / C::HW, hx = pix % C::HW;
             const int iy = y0 - 1 + hy, ix = hx - 1;
-            const bool ok = (f < C::HH * C::HW * 16) && iy >= 0 && iy < H && ix >= 0 && ix < C::TW;
+            const bool ok = (f < C::HALO_F4) && iy >= 0 && iy < H && ix >= 0 && ix < C::TW;
             const uint32_t g = ok ? (uint32_t)(((b * H + iy) * C::TW + ix) * 64 + c4) : 0u;   // < 2^31 floats (checked by the launcher)
             pre0[k2] = *(const f32x4_t*)(in0 + g);
             if (MODE == 1) pre1[k2] = *(const f32x4_t*)(in1 + g);
@@ -609,7 +623,7 @@ __global__ __launch_bounds__(512, 1) void k_conv16_wino(const float* __restrict_
 #pragma unroll
         for (int k2 = 0; k2 < NH; ++k2) {
             const int f = tid + 512 * (part * NH + k2);
-            if (512 * (part * NH + k2) >= C::HH * C::HW * 16) continue;      // (compile-time) nothing left
+            if (512 * (part * NH + k2) >= C::HALO_F4) continue;      // (compile-time) nothing left
             const int pix = f >> 4, c4 = (f & 15) * 4;
             const int hy = pix / C::HW, hx = pix % C::HW;
             const int iy = y0 - 1 + hy, ix = hx - 1;
@@ -623,7 +637,7 @@ __global__ __launch_bounds__(512, 1) void k_conv16_wino(const float* __restrict_
             v = ok ? v : z4;                                           // padding stays exactly 0
             // lanes past the end of the halo write to a dump slot: a conditional store would let the compiler sink the
             // global load into the branch, i.e. issue it here and wait for it on the spot
-            float* d = (f < C::HH * C::HW * 16) ? halo + hy * C::RS + hx * C::PS + c4 : dump;
+            float* d = (f < C::HALO_F4) ? halo + hy * C::RS + hx * C::PS + c4 : dump;
             *(float2*)d = make_float2(v[0], v[1]);
             *(float2*)(d + 2) = make_float2(v[2], v[3]);
         }
@@ -670,11 +684,11 @@ __global__ __launch_bounds__(512, 1) void k_conv16_wino(const float* __restrict_
         const float* halo = smem + cur * C::HALO_FLOATS;
         float* halo_nxt = smem + (cur ^ 1) * C::HALO_FLOATS;
         const int b = tile / tiles_per_clip, y0 = (tile % tiles_per_clip) * C::TH;
+        load_halo(nxt_tile, 0);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            load_halo(nxt_tile, mt * PPM);
-            // block of this lane as an MFMA row: blk = 16 mt + i16 -> (br, bc); rows ph .. ph + 2 of its 4 x 4 patch
-            const int blk = 16 * mt + i16, br = blk >> 3, bc = blk & 7;
+        for (int mt = 0; mt < C::NMT; ++mt) {
+            // block of this lane as an MFMA row: blk = 16 mt + i16 -> (br, bc)
+            const int blk = 16 * mt + i16, br = blk / C::BC, bc = blk % C::BC;
             const float* Pa = halo + (2 * br + 3 * ph) * C::RS + (2 * bc) * C::PS + kq;
             const float* Pm = halo + (2 * br + 1 + ph) * C::RS + (2 * bc) * C::PS + kq;
             const float* Pc = halo + (2 * br + 2 - ph) * C::RS + (2 * bc) * C::PS + kq;
@@ -704,9 +718,12 @@ __global__ __launch_bounds__(512, 1) void k_conv16_wino(const float* __restrict_
                         r[q] = Pa[q * C::PS + 4 * (s4 + 1)]; r[4 + q] = Pm[q * C::PS + 4 * (s4 + 1)]; r[8 + q] = Pc[q * C::PS + 4 * (s4 + 1)];
                     }
                 }
-                if (MODE == 1 && (s4 == 5 || s4 == 10)) {   // dgrad: the halo comes in six pieces (two arrays per piece)
-                    store_halo(halo_nxt, nxt_tile, PPM * mt + s4 / 5 - 1);
-                    load_halo(nxt_tile, PPM * mt + s4 / 5);
+                {
+                    const int piece = wino_piece_at(16 * mt + s4 + 1, C::STEPS, PARTS);   // (folds: mt, s4 are unrolled)
+                    if (piece > 0) {
+                        store_halo(halo_nxt, nxt_tile, piece - 1);
+                        load_halo(nxt_tile, piece);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -717,7 +734,7 @@ __global__ __launch_bounds__(512, 1) void k_conv16_wino(const float* __restrict_
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (it_ts == 0) TS(3 + 4 * mt);
-            store_halo(halo_nxt, nxt_tile, PPM * mt + PPM - 1);
+            if (mt == C::NMT - 1) store_halo(halo_nxt, nxt_tile, PARTS - 1);
             // partial inverse transform of this wave's 8 positions: D register q <-> block 4 kq + q of the MFMA tile
             float yp[4][4];
 #pragma unroll
@@ -729,7 +746,7 @@ __global__ __launch_bounds__(512, 1) void k_conv16_wino(const float* __restrict_
                 yp[q][2] = ph ? qx0 - qy0 : qy0;                // out[1][0]
                 yp[q][3] = ph ? qx1 - qy1 : qy1;                // out[1][1]
             }
-            float* xw = xch + ((cg * 2 + mt) * 16) * 64 + lane;
+            float* xw = xch + ((cg * C::NMT + mt) * 16) * 64 + lane;
             if (ph == 1) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) xw[q * 64] = yp[q >> 2][q & 3];
@@ -741,7 +758,7 @@ __global__ __launch_bounds__(512, 1) void k_conv16_wino(const float* __restrict_
                 auto emit = [&](auto checked) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int ob = 16 * mt + 4 * kq + q, obr = ob >> 3, obc = ob & 7;
+                        const int ob = 16 * mt + 4 * kq + q, obr = ob / C::BC, obc = ob % C::BC;
 #pragma unroll
                         for (int o = 0; o < 4; ++o) {
                             const int yy = y0 + 2 * obr + (o >> 1), xx = 2 * obc + (o & 1);
@@ -783,19 +800,32 @@ static int conv16_ws_launch(const float* in0, const float* in1, const float* coe
                                           (int)Ws16::LDS_BYTES));
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv16_ws2<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)Ws16::LDS_BYTES));
-        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv16_wino<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)Wino16::LDS_BYTES));
         attr_done = true;
     }
     const int tpc = (H + Ws16::TH - 1) / Ws16::TH, nt = B * tpc;
     const int grid = nt < 256 ? nt : 256;          // one persistent workgroup per CU
     if (g_sed_debug & 32) k_conv16_ws<MODE><<<grid, 256, Ws16::LDS_BYTES, st>>>(in0, in1, coef, wpk, bias, out, stat, H, tpc, nt);
-    else if (g_sed_debug & 64) k_conv16_ws2<MODE><<<grid, 512, Ws16::LDS_BYTES, st>>>(in0, in1, coef, wpk, bias, out, stat, H, tpc, nt);
-    else {
-        // default: Winograd F(2x2, 3x3) - 59 / 57 us per launch (forward / dgrad) against 91 / 90 us for the direct 8-wave kernel
-        SED_CHECK_ARG((size_t)B * H * Ws16::TW * 64 < ((size_t)1 << 31), "conv: image too large for 32-bit offsets");
-        k_conv16_wino<MODE><<<grid, 512, Wino16::LDS_BYTES, st>>>(in0, in1, coef, wpk + SED_WINO_OFF, bias, out, stat, H, tpc, nt);
+    else k_conv16_ws2<MODE><<<grid, 512, Ws16::LDS_BYTES, st>>>(in0, in1, coef, wpk, bias, out, stat, H, tpc, nt);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}
+
+// Winograd F(2x2, 3x3): the default for both 64 -> 64 convolutions.  Block 1: 59 / 57 us per launch (forward / dgrad)
+// against 91 / 90 us for the direct 8-wave kernel; bit 6 of the debug knob selects the direct kernels.
+template <int TW, int MODE>
+static int conv_wino_launch(const float* in0, const float* in1, const float* coef, const float* wpk, const float* bias,
+                            float* out, double* stat, int B, int H, hipStream_t st) {
+    using C = Wino<TW>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_wino<TW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)C::LDS_BYTES));
+        attr_done = true;
     }
+    SED_CHECK_ARG((size_t)B * H * TW * 64 < ((size_t)1 << 31), "conv: image too large for 32-bit offsets");
+    const int tpc = (H + C::TH - 1) / C::TH, nt = B * tpc;
+    const int grid = nt < 256 ? nt : 256;          // one persistent workgroup per CU
+    k_conv_wino<TW, MODE><<<grid, 512, C::LDS_BYTES, st>>>(in0, in1, coef, wpk + SED_WINO_OFF, bias, out, stat, H, tpc, nt);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
@@ -1050,9 +1080,8 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 // ---- host launchers ---------------------------------------------------------------------------
 int launch_conv_pack(const float* w1, const float* w2, float* wpk1, float* wpk2, float* wpkT1, float* wpkT2, double* zero,
                      int n_zero, hipStream_t st) {
-    // the layer-1 panels are followed by their Winograd-transformed form (SED_WINO_OFF floats in)
-    k_conv_pack<<<(2 * 9 * 4096 + 255) / 256, 256, 0, st>>>(w1, w2, wpk1, wpk2, wpkT1, wpkT2, wpk1 + SED_WINO_OFF,
-                                                             wpkT1 ? wpkT1 + SED_WINO_OFF : nullptr, zero, n_zero);
+    // every panel is followed by its Winograd-transformed form (SED_WINO_OFF floats in)
+    k_conv_pack<<<(2 * 9 * 4096 + 255) / 256, 256, 0, st>>>(w1, w2, wpk1, wpk2, wpkT1, wpkT2, zero, n_zero);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
@@ -1076,20 +1105,24 @@ static int conv_launch_t(const float* in0, const float* in1, const float* coef, 
 int launch_conv_fwd(const float* in, const float* wpk, const float* bias, float* y, double* stat, int zero_stat, int B,
                     int H, int W, hipStream_t st) {
     if (stat && zero_stat) SED_CHECK_HIP(hipMemsetAsync(stat, 0, 128 * sizeof(double), st));
-    if (W == 16) return (g_sed_debug & 2) ? conv_launch_t<16, 0, 1>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st)
-                                          : conv16_ws_launch<0>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st);
-    if (W == 4) return conv_launch_t<4, 0, 2>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st);
+    const bool direct = (g_sed_debug & (2 | 32 | 64)) != 0;          // A/B timing only: the 9-tap kernels
+    if (W == 16) return !direct ? conv_wino_launch<16, 0>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st)
+               : (g_sed_debug & 2) ? conv_launch_t<16, 0, 1>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st)
+                                   : conv16_ws_launch<0>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st);
+    if (W == 4) return !direct ? conv_wino_launch<4, 0>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st)
+                               : conv_launch_t<4, 0, 2>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st);
     sed_set_error("conv: unsupported width %d", W);
     return SED_ERR_UNSUPPORTED;
 }
 
 int launch_conv_dgrad(const float* dz, const float* yin, const float* coef, const float* wpkT, float* dx, int B, int H,
                       int W, hipStream_t st) {
-    // dgrad: the 8-wave weight-stationary kernel and the tile kernel measure the same alone (101 us); inside the step the
-    // former is 3 us better; bit 2 of the debug knob selects the tile kernel
-    if (W == 16) return (g_sed_debug & 4) ? conv_launch_t<16, 1, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st)
-                                          : conv16_ws_launch<1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st);
-    if (W == 4) return conv_launch_t<4, 1, 2>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st);
+    const bool direct = (g_sed_debug & (4 | 32 | 64)) != 0;          // A/B timing only: the 9-tap kernels
+    if (W == 16) return !direct ? conv_wino_launch<16, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st)
+               : (g_sed_debug & 4) ? conv_launch_t<16, 1, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st)
+                                   : conv16_ws_launch<1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st);
+    if (W == 4) return !direct ? conv_wino_launch<4, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st)
+                               : conv_launch_t<4, 1, 2>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st);
     sed_set_error("conv dgrad: unsupported width %d", W);
     return SED_ERR_UNSUPPORTED;
 }

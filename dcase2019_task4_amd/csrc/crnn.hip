@@ -87,7 +87,7 @@ CtxLayout make_ctx_layout(const Geo& g) {
     put(L.mompart, (size_t)x_moments_parts(g) * 54 * sizeof(double));
     put(L.p0, n0 * 4);
     put(L.wpk1, (9 + 16) * 4096 * 4); put(L.wpkT1, (9 + 16) * 4096 * 4); put(L.y1, n0 * 4); put(L.bn1, 256 * 4); put(L.p1, n1 * 4);
-    put(L.wpk2, 9 * 4096 * 4); put(L.wpkT2, 9 * 4096 * 4); put(L.y2, n1 * 4); put(L.bn2, 256 * 4); put(L.p2, n2 * 4);
+    put(L.wpk2, (9 + 16) * 4096 * 4); put(L.wpkT2, (9 + 16) * 4096 * 4); put(L.y2, n1 * 4); put(L.bn2, 256 * 4); put(L.p2, n2 * 4);
     const size_t bt = (size_t)g.B * g.T3;
     for (int l = 0; l < 2; ++l) {
         put(L.gates[l], bt * 512 * 4); put(L.out[l], bt * 128 * 4);      // (gi only exists in LDS, gru.hip)

@@ -569,6 +569,10 @@ struct Wino {
     static constexpr int TH = 2 * (16 * NMT / BC);                       // image rows per tile: 8 (TW 16), 16 (TW 4)
     static constexpr int HW = TW + 2, HH = TH + 2, PS = 66, RS = HW * PS;
     static constexpr int HALO_FLOATS = HH * RS, HALO_F4 = HH * HW * 16;
+    // (The A-operand reads are 2-way bank-conflicted within a half-wave: bank = kq + 4 bc + 8 br.  A 2-float skew on
+    // alternate row pairs makes them conflict-free - PMC 198 k -> 14 k conflict cycles - but the kernel is not LDS-bound:
+    // same duration, and the extra address arithmetic spilled the dgrad variant.  Not kept.)
+    __host__ __device__ static constexpr int row_off(int hy) { return hy * RS; }
     static constexpr int XCH_FLOATS = 4 * NMT * 16 * 64;                 // [cg][mtile][16 partial outputs][lane]
     static constexpr size_t LDS_BYTES = (size_t)(2 * HALO_FLOATS + XCH_FLOATS + 192 + 4) * 4;   // + coefficients + dump slot
     static constexpr int STEPS = 16 * NMT;                               // k-steps (4 input channels each) per tile
@@ -603,48 +607,58 @@ __global__ __launch_bounds__(512, 1) void k_conv_wino(const float* __restrict__ 
     constexpr int NH = (MODE == 1) ? 1 : (NLD + 1) / 2, PARTS = (NLD + NH - 1) / NH;
     f32x4_t pre0[NH], pre1[MODE == 1 ? NH : 1];
     // raw loads only (padding is applied when the values go to LDS: a select here would make the compiler wait for the
-    // loads on the spot)
-    auto load_halo = [&](int tile, int part) {
+    // loads on the spot); item it = float4 number tid + 512 it of the halo
+    auto load_item = [&](int tile, int it, f32x4_t& d0, f32x4_t& d1) {
         const int b = tile / tiles_per_clip, y0 = (tile % tiles_per_clip) * C::TH;
-#pragma unroll
-        for (int k2 = 0; k2 < NH; ++k2) {
-            const int f = tid + 512 * (part * NH + k2);
-            const int pix = f >> 4, c4 = (f & 15) * 4;
-            const int hy = pix / C::HW, hx = pix % C::HW;
-            const int iy = y0 - 1 + hy, ix = hx - 1;
-            const bool ok = (f < C::HALO_F4) && iy >= 0 && iy < H && ix >= 0 && ix < C::TW;
-            const uint32_t g = ok ? (uint32_t)(((b * H + iy) * C::TW + ix) * 64 + c4) : 0u;   // < 2^31 floats (checked by the launcher)
-            pre0[k2] = *(const f32x4_t*)(in0 + g);
-            if (MODE == 1) pre1[k2] = *(const f32x4_t*)(in1 + g);
+        const int f = tid + 512 * it;
+        const int pix = f >> 4, c4 = (f & 15) * 4;
+        const int hy = pix / C::HW, hx = pix % C::HW;
+        const int iy = y0 - 1 + hy, ix = hx - 1;
+        const bool ok = (f < C::HALO_F4) && iy >= 0 && iy < H && ix >= 0 && ix < C::TW;
+        const uint32_t g = ok ? (uint32_t)(((b * H + iy) * C::TW + ix) * 64 + c4) : 0u;   // < 2^31 floats (checked by the launcher)
+        d0 = *(const f32x4_t*)(in0 + g);
+        if (MODE == 1) d1 = *(const f32x4_t*)(in1 + g);
+    };
+    auto store_item = [&](float* halo, int tile, int it, const f32x4_t& s0, const f32x4_t& s1) {
+        if (512 * it >= C::HALO_F4) return;                            // (compile-time) nothing left
+        const int y0 = (tile % tiles_per_clip) * C::TH;
+        const int f = tid + 512 * it;
+        const int pix = f >> 4, c4 = (f & 15) * 4;
+        const int hy = pix / C::HW, hx = pix % C::HW;
+        const int iy = y0 - 1 + hy, ix = hx - 1;
+        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < C::TW;
+        f32x4_t v = s0;
+        if (MODE == 1) {
+            const f32x4_t ca = *(const f32x4_t*)(cfs + c4), cb = *(const f32x4_t*)(cfs + 64 + c4), cc = *(const f32x4_t*)(cfs + 128 + c4);
+            v = ca * v + cb * s1 + cc;
         }
+        const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
+        v = ok ? v : z4;                                               // padding stays exactly 0
+        // lanes past the end of the halo write to a dump slot: a conditional store would let the compiler sink the
+        // global load into the branch, i.e. issue it here and wait for it on the spot
+        float* d = (f < C::HALO_F4) ? halo + C::row_off(hy) + hx * C::PS + c4 : dump;
+        *(float2*)d = make_float2(v[0], v[1]);
+        *(float2*)(d + 2) = make_float2(v[2], v[3]);
+    };
+    auto load_halo = [&](int tile, int part) {
+#pragma unroll
+        for (int k2 = 0; k2 < NH; ++k2) load_item(tile, part * NH + k2, pre0[k2], pre1[MODE == 1 ? k2 : 0]);
     };
     auto store_halo = [&](float* halo, int tile, int part) {
-        const int y0 = (tile % tiles_per_clip) * C::TH;
 #pragma unroll
-        for (int k2 = 0; k2 < NH; ++k2) {
-            const int f = tid + 512 * (part * NH + k2);
-            if (512 * (part * NH + k2) >= C::HALO_F4) continue;      // (compile-time) nothing left
-            const int pix = f >> 4, c4 = (f & 15) * 4;
-            const int hy = pix / C::HW, hx = pix % C::HW;
-            const int iy = y0 - 1 + hy, ix = hx - 1;
-            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < C::TW;
-            f32x4_t v = pre0[k2];
-            if (MODE == 1) {
-                const f32x4_t ca = *(const f32x4_t*)(cfs + c4), cb = *(const f32x4_t*)(cfs + 64 + c4), cc = *(const f32x4_t*)(cfs + 128 + c4);
-                v = ca * v + cb * pre1[k2] + cc;
-            }
-            const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
-            v = ok ? v : z4;                                           // padding stays exactly 0
-            // lanes past the end of the halo write to a dump slot: a conditional store would let the compiler sink the
-            // global load into the branch, i.e. issue it here and wait for it on the spot
-            float* d = (f < C::HALO_F4) ? halo + hy * C::RS + hx * C::PS + c4 : dump;
-            *(float2*)d = make_float2(v[0], v[1]);
-            *(float2*)(d + 2) = make_float2(v[2], v[3]);
-        }
+        for (int k2 = 0; k2 < NH; ++k2) store_item(halo, tile, part * NH + k2, pre0[k2], pre1[MODE == 1 ? k2 : 0]);
     };
     int tile = blockIdx.x;
     TS(0);
-    if (tile < n_tiles) load_halo(tile, 0);
+    // the first halo is fetched whole, together with the weights (the accumulators are not live yet, so there are
+    // registers for all of it; piecewise it cost PARTS load round trips - 7 us of prologue for dgrad)
+    // (dgrad, two arrays: in two rounds - all 12 float4 at once pushed loop-invariant values into scratch)
+    constexpr int FR = (MODE == 1) ? 2 : 1, FN = (NLD + FR - 1) / FR;
+    f32x4_t first0[FN], first1[MODE == 1 ? FN : 1];
+    if (tile < n_tiles) {
+#pragma unroll
+        for (int it = 0; it < FN; ++it) load_item(tile, it, first0[it], first1[MODE == 1 ? it : 0]);
+    }
     // this wave's transformed weights, B[k = ci][n = co]: p8 = 0..3 <-> transform row 3 ph (the "X" row below), column p8;
     // p8 = 4..7 <-> row 1 + ph (the "Y" row), column p8 - 4; k_conv_pack wrote them in register order (float4 per lane)
     float uw[8][16];
@@ -661,13 +675,20 @@ __global__ __launch_bounds__(512, 1) void k_conv_wino(const float* __restrict__ 
     }
     const float bia = (MODE == 0) ? bias[16 * cg + i16] : 0.f;
     if (tile < n_tiles) {
-        store_halo(smem, tile, 0);
 #pragma unroll
-        for (int p2 = 1; p2 < PARTS; ++p2) { load_halo(tile, p2); store_halo(smem, tile, p2); }
+        for (int fr = 0; fr < FR; ++fr) {
+            if (fr > 0) {
+#pragma unroll
+                for (int it = 0; it < FN; ++it) load_item(tile, fr * FN + it, first0[it], first1[MODE == 1 ? it : 0]);
+            }
+#pragma unroll
+            for (int it = 0; it < FN; ++it) store_item(smem, tile, fr * FN + it, first0[it], first1[MODE == 1 ? it : 0]);
+        }
     }
     TS(1);
     __syncthreads();
     TS(2);
+    TSC(14);
     int it_ts = 0;
     // input transform, rows: with patch rows (A, B, C) = (d0, d1, d2) for ph = 0 and (d3, d2, d1) for ph = 1
     //   X = A - C      = T0 = d0 - d2            |  d3 - d1 = -T3
@@ -689,9 +710,9 @@ __global__ __launch_bounds__(512, 1) void k_conv_wino(const float* __restrict__ 
         for (int mt = 0; mt < C::NMT; ++mt) {
             // block of this lane as an MFMA row: blk = 16 mt + i16 -> (br, bc)
             const int blk = 16 * mt + i16, br = blk / C::BC, bc = blk % C::BC;
-            const float* Pa = halo + (2 * br + 3 * ph) * C::RS + (2 * bc) * C::PS + kq;
-            const float* Pm = halo + (2 * br + 1 + ph) * C::RS + (2 * bc) * C::PS + kq;
-            const float* Pc = halo + (2 * br + 2 - ph) * C::RS + (2 * bc) * C::PS + kq;
+            const float* Pa = halo + C::row_off(2 * br + 3 * ph) + (2 * bc) * C::PS + kq;
+            const float* Pm = halo + C::row_off(2 * br + 1 + ph) + (2 * bc) * C::PS + kq;
+            const float* Pc = halo + C::row_off(2 * br + 2 - ph) + (2 * bc) * C::PS + kq;
             f32x4_t acc[8];
 #pragma unroll
             for (int p8 = 0; p8 < 8; ++p8) acc[p8] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -734,6 +755,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wino(const float* __restrict__ 
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (it_ts == 0) TS(3 + 4 * mt);
+            if (it_ts == 0 && mt == 0) TSC(15);
             if (mt == C::NMT - 1) store_halo(halo_nxt, nxt_tile, PARTS - 1);
             // partial inverse transform of this wave's 8 positions: D register q <-> block 4 kq + q of the MFMA tile
             float yp[4][4];

@@ -47,7 +47,10 @@ def main():
         cyc = (ts[:, 15] - ts[:, 14]).astype(float)
         last = max(k for k in range(14) if (ts[:, k] > 0).all())
         us = (ts[:, last] - ts[:, 0]) / 100.0
-        print(f"  shader clock (clock64 delta / wall delta): {np.mean(cyc / us):.1f} counts/us")
+        if os.environ.get("TS_PAIR"):            # the TSC pair brackets these two wall stamps instead of the whole kernel
+            k0, k1 = (int(v) for v in os.environ["TS_PAIR"].split(","))
+            us = (ts[:, k1] - ts[:, k0]) / 100.0
+        print(f"  shader clock (clock64 delta / wall delta): {np.mean(cyc / us):.1f} counts/us; mean delta {cyc.mean():.0f} cycles")
     for k in range(14):
         col = ts[:, k]
         ok = col > 0

@@ -213,189 +213,29 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in0, 
 }
 
 
-// ---- weight-stationary persistent variant for W = 16 (conv block 1: 88 % of the conv FLOPs) ------------------
-// PMC on the tile kernel above (k_conv3x3<16,..>): MFMA pipe busy 55 % of the kernel, waves parked in
-// s_waitcnt / s_barrier 38 % of their cycles - the per-tap weight slab hand-over (LDS double buffer + barrier)
-// and the un-overlapped halo staging keep the 2 resident waves per SIMD from covering each other.  Here the
-// WEIGHTS stay in registers for the whole life of a persistent workgroup instead:
-//   * wave w owns output channels [16w, 16w+16) and holds their full K = 9 x 64 weight panel as
-//     v_mfma_f32_16x16x4_f32 B fragments: 144 VGPRs, loaded once;
-//   * a tile is 8 image rows x 16 pixels; each wave computes all 128 pixels x its 16 channels
-//     (8 independent 16x16 accumulators -> back-to-back MFMA issue from one wave per SIMD);
-//   * no LDS weight traffic and NO barrier inside a tile; the next tile's halo is prefetched into registers
-//     while the current tile computes and is written to the other LDS halo buffer afterwards (one barrier
-//     per tile); halo pixel stride 66 floats makes the A-fragment reads (lane = pixel x 4 channels)
-//     bank-conflict free;
-//   * BatchNorm sums are accumulated in registers across all tiles of the workgroup: 32 atomics per wave
-//     per launch.
-// Phase timestamps (tools/ts_kernel.py conv1_fwd conv): 18.6 us of MFMAs per tile (94 % of the pipe's rate) + 2.8 us of
-// halo loads / LDS stores / output stores between tiles + 4.4 us prologue.  Moving those 2.8 us INTO the MFMA groups (one
-// load / store item per group, previous tile's accumulators kept in spare registers) was tried and lost: 23.3 us per
-// tile - the waits the compiler attaches to the interleaved memory operations stall the in-order MFMA stream.
+// ---- direct (9-tap) weight-stationary persistent kernel for W = 16 -------------------------------------------
+// Kept as the A/B baseline of the Winograd kernel below (debug bit 6); it was the block-1 forward / dgrad kernel until
+// r01_i.  PMC on the tile kernel above (k_conv3x3<16,..>): MFMA pipe busy 55 % of the kernel, waves parked in
+// s_waitcnt / s_barrier 38 % of their cycles - the per-tap weight slab hand-over (LDS double buffer + barrier) and the
+// un-overlapped halo staging.  Here the WEIGHTS stay in registers for the whole life of a persistent workgroup:
+//   * a wave owns 16 output channels and holds their full K = 9 x 64 weight panel as v_mfma_f32_16x16x4_f32 B
+//     fragments: 144 VGPRs, loaded once; no LDS weight traffic and no barrier inside a tile;
+//   * a tile is 8 image rows x 16 pixels; the next tile's halo is prefetched into registers while the current tile
+//     computes and is written to the other LDS halo buffer afterwards (one barrier per tile); halo pixel stride 66
+//     floats makes the A-fragment reads (lane = pixel x 4 channels) bank-conflict free;
+//   * BatchNorm sums are accumulated in registers across all tiles of the workgroup: 32 atomics per wave per launch;
+//   * every SIMD hosts TWO waves with the same 16-channel panel (<= 256 registers per wave): the "early" wave owns
+//     image rows 0-3 of the tile and stores its outputs right after its MFMAs, the "late" wave owns rows 4-7 and
+//     stores its outputs at the START of the next tile - whenever one of the two is in its epilogue the other one
+//     is issuing MFMAs (a 4-wave version with one wave per SIMD spent 2.8 us of every 21.4 us tile outside MFMAs;
+//     moving that work into the MFMA groups lost: the waits the compiler attaches to interleaved memory operations
+//     stall the in-order MFMA stream).  Halo staging is shared by all 512 threads (6 items each).
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 struct Ws16 {
     static constexpr int TH = 8, TW = 16, HW = 18, HH = 10, PS = 66, RS = HW * PS;
     static constexpr int HALO_FLOATS = HH * RS;
     static constexpr size_t LDS_BYTES = (size_t)2 * HALO_FLOATS * 4;
-    static constexpr int NLD = (HH * HW * 16 + 255) / 256;     // float4 loads per thread per halo
 };
-
-template <int MODE>
-__global__ __launch_bounds__(256, 1) void k_conv16_ws(const float* __restrict__ in0, const float* __restrict__ in1,
-                                                       const float* __restrict__ coef, const float* __restrict__ wpk,
-                                                       const float* __restrict__ bias, float* __restrict__ out,
-                                                       double* __restrict__ stat, int H, int tiles_per_clip, int n_tiles) {
-    using C = Ws16;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int p16 = lane & 15, kq = lane >> 4;
-    float st1 = 0.f, st2 = 0.f;
-
-    float4 pre0[C::NLD], pre1[C::NLD];
-    auto load_halo = [&](int tile) {
-        const int b = tile / tiles_per_clip, y0 = (tile % tiles_per_clip) * C::TH;
-#pragma unroll
-        for (int it = 0; it < C::NLD; ++it) {
-            const int f = tid + 256 * it;
-            const int pix = f >> 4, c4 = (f & 15) * 4;
-            const int hy = pix / C::HW, hx = pix % C::HW;
-            const int iy = y0 - 1 + hy, ix = hx - 1;
-            const bool ok = (f < C::HH * C::HW * 16) && iy >= 0 && iy < H && ix >= 0 && ix < C::TW;
-            const size_t g = ok ? (((size_t)b * H + iy) * C::TW + ix) * 64 + c4 : 0;
-            float4 v = *(const float4*)(in0 + g);
-            if (MODE == 1) pre1[it] = *(const float4*)(in1 + g);
-            if (!ok) { v = make_float4(0.f, 0.f, 0.f, 0.f); if (MODE == 1) pre1[it] = v; }
-            pre0[it] = v;
-        }
-    };
-    auto store_halo = [&](float* halo, int tile) {
-        const int y0 = (tile % tiles_per_clip) * C::TH;
-#pragma unroll
-        for (int it = 0; it < C::NLD; ++it) {
-            const int f = tid + 256 * it;
-            if (f >= C::HH * C::HW * 16) continue;
-            const int pix = f >> 4, c4 = (f & 15) * 4;
-            const int hy = pix / C::HW, hx = pix % C::HW;
-            float4 v = pre0[it];
-            if (MODE == 1) {
-                const int iy = y0 - 1 + hy, ix = hx - 1;
-                if (iy >= 0 && iy < H && ix >= 0 && ix < C::TW) {      // padding stays exactly 0
-                    const float4 yv = pre1[it];
-                    const float4 ca = *(const float4*)(coef + c4);
-                    const float4 cb = *(const float4*)(coef + 64 + c4);
-                    const float4 cc = *(const float4*)(coef + 128 + c4);
-                    v.x = ca.x * v.x + cb.x * yv.x + cc.x;
-                    v.y = ca.y * v.y + cb.y * yv.y + cc.y;
-                    v.z = ca.z * v.z + cb.z * yv.z + cc.z;
-                    v.w = ca.w * v.w + cb.w * yv.w + cc.w;
-                }
-            }
-            float* d = halo + hy * C::RS + hx * C::PS + c4;          // 8-byte aligned (PS even, c4 % 4 == 0)
-            *(float2*)d = make_float2(v.x, v.y);
-            *(float2*)(d + 2) = make_float2(v.z, v.w);
-        }
-    };
-
-    if (MODE == 0) { TS(0); TSC(14); }
-    int tile = blockIdx.x;
-    if (tile < n_tiles) load_halo(tile);           // first halo in flight while the weight panel is fetched
-    // ---- this wave's weight panel -> registers --------------------------------------------------------
-    float bw[9][16];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int s4 = 0; s4 < 16; ++s4) bw[t][s4] = wpk[t * 4096 + (4 * s4 + kq) * 64 + 16 * wv + p16];
-    const float bia = (MODE == 0) ? bias[16 * wv + p16] : 0.f;
-    if (tile < n_tiles) store_halo(smem, tile);
-    __syncthreads();
-    TS(1);
-    int ts_k = 2;
-    (void)ts_k;
-    int cur = 0;
-    for (; tile < n_tiles; tile += gridDim.x) {
-        const int nxt_tile = tile + gridDim.x;
-        if (nxt_tile < n_tiles) load_halo(nxt_tile);          // in flight during this tile's MFMAs
-        if (MODE == 0 && ts_k < 12) { TS(ts_k); ++ts_k; }
-        const float* halo = smem + cur * C::HALO_FLOATS;
-        const float* Ab = halo + C::RS + (1 + p16) * C::PS + kq;   // pixel (row 0, x = p16), channel kq
-        f32x4_t acc[8];
-#pragma unroll
-        for (int rb = 0; rb < 8; ++rb) acc[rb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        // 72 groups of 16 MFMAs (one tap, two 4-channel K steps, 8 image rows).  The A fragments of group
-        // g+1 are read from LDS BEFORE the MFMAs of group g are issued (explicit register double buffer,
-        // pinned with sched_barrier): with one wave per SIMD nothing else would cover the LDS latency.
-        auto load_a = [&](float (&a)[16], int gi) {
-            const int t = gi / 8, sp = gi % 8;
-            const int dy = t / 3 - 1, dx = t % 3 - 1;
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int rb = 0; rb < 8; ++rb) a[q * 8 + rb] = Ab[(rb + dy) * C::RS + dx * C::PS + 4 * (2 * sp + q)];
-        };
-        auto mma = [&](const float (&a)[16], int gi) {
-            const int t = gi / 8, sp = gi % 8;
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int rb = 0; rb < 8; ++rb)
-                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q * 8 + rb], bw[t][2 * sp + q], acc[rb], 0, 0, 0);
-        };
-        float a0[16], a1[16];
-        load_a(a0, 0);
-#pragma unroll
-        for (int gi = 0; gi < 72; gi += 2) {
-            load_a(a1, gi + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a0, gi);
-            __builtin_amdgcn_sched_barrier(0);
-            if (gi + 2 < 72) load_a(a0, gi + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a1, gi + 1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // next tile's halo -> the other LDS buffer BEFORE this tile's output stores are issued: its loads were
-        // issued a whole tile ago, and no store is outstanding yet, so the vmcnt(0) this needs costs nothing
-        // (vmcnt counts stores too; after the epilogue it would drain 32 fresh stores per lane)
-        if (MODE == 0 && ts_k < 12) { TS(ts_k); ++ts_k; }
-        if (nxt_tile < n_tiles) store_halo(smem + (cur ^ 1) * C::HALO_FLOATS, nxt_tile);
-        if (MODE == 0 && ts_k < 12) { TS(ts_k); ++ts_k; }
-        // ---- epilogue: D[i][j]: j = lane & 15 -> channel 16*wv + j, i = 4*(lane>>4) + r -> pixel x ------
-        {
-            const int b = tile / tiles_per_clip, y0 = (tile % tiles_per_clip) * C::TH;
-#pragma unroll
-            for (int rb = 0; rb < 8; ++rb) {
-                const int yy = y0 + rb;
-                if (yy < H) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int xx = 4 * kq + r;
-                        const float v = acc[rb][r] + bia;
-                        out[(((size_t)b * H + yy) * C::TW + xx) * 64 + 16 * wv + p16] = v;
-                        if (MODE == 0) { st1 += v; st2 += v * v; }
-                    }
-                }
-            }
-        }
-        lds_barrier();          // LDS-only: the output stores stay in flight across the tile boundary
-        cur ^= 1;
-    }
-    if (MODE == 0) { TS(12); }
-    if (MODE == 0 && stat != nullptr) {
-        st1 += __shfl_xor(st1, 16); st1 += __shfl_xor(st1, 32);
-        st2 += __shfl_xor(st2, 16); st2 += __shfl_xor(st2, 32);
-        if (kq == 0) {
-            atomicAdd(&stat[16 * wv + p16], (double)st1);
-            atomicAdd(&stat[64 + 16 * wv + p16], (double)st2);
-        }
-    }
-}
-
-// ---- 8-wave weight-stationary variant: two waves per SIMD, staggered epilogues ----------------------------------------
-// k_conv16_ws spends 18.6 us of a 21.4 us tile period in MFMAs; the rest (output stores, halo staging) is the lone wave of
-// each SIMD doing something else.  Here every SIMD hosts TWO waves with the same 16-channel weight panel (144 VGPRs
-// each, <= 256 registers per wave): the "early" wave owns image rows 0-3 of the tile and stores its outputs right after
-// its MFMAs, the "late" wave owns rows 4-7 and stores its outputs at the START of the next tile - so whenever one of the
-// two is in its epilogue the other one is issuing MFMAs.  Halo staging is shared by all 512 threads (6 items each).
 struct Ws16x2 {
     static constexpr int NLD = (Ws16::HH * Ws16::HW * 16 + 511) / 512;     // float4 loads per thread per halo (6)
 };
@@ -818,16 +658,13 @@ static int conv16_ws_launch(const float* in0, const float* in1, const float* coe
                             float* out, double* stat, int B, int H, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv16_ws<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)Ws16::LDS_BYTES));
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv16_ws2<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)Ws16::LDS_BYTES));
         attr_done = true;
     }
     const int tpc = (H + Ws16::TH - 1) / Ws16::TH, nt = B * tpc;
     const int grid = nt < 256 ? nt : 256;          // one persistent workgroup per CU
-    if (g_sed_debug & 32) k_conv16_ws<MODE><<<grid, 256, Ws16::LDS_BYTES, st>>>(in0, in1, coef, wpk, bias, out, stat, H, tpc, nt);
-    else k_conv16_ws2<MODE><<<grid, 512, Ws16::LDS_BYTES, st>>>(in0, in1, coef, wpk, bias, out, stat, H, tpc, nt);
+    k_conv16_ws2<MODE><<<grid, 512, Ws16::LDS_BYTES, st>>>(in0, in1, coef, wpk, bias, out, stat, H, tpc, nt);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
@@ -1078,6 +915,218 @@ __global__ __launch_bounds__(256) void k_wgrad16_db(const float* __restrict__ dz
     TS(13); TSC(15);
 }
 
+// ---- block-1 wgrad in the Winograd domain -----------------------------------------------------------------------------
+// dW = G^T [ sum over 2x2 output blocks of (B^T d B) (.) (A dY A^T) ] G: 16 multiplies per block and (ci, co) pair instead
+// of 36, like the forward kernel.  Here BOTH operands need a transform, so they are transformed once per block row into
+// LDS (no redundancy between waves) and the MFMA phase reads ready-made fragments:
+//   * tile = 8 image rows x 16 columns = 4 block rows of 8 blocks; per block row ("sub-step"):
+//       transform phase: wave w takes block w of the row, lane = channel: V = B^T d B of the input patch (from the LDS
+//       halo of x) -> Vs[blk][pos][ci]; dY = ca dz + cb y + cc straight from global memory (its 2x2 blocks do not
+//       overlap, so no staging; prefetched one sub-step ahead), dM = A dY A^T -> Ms[blk][pos][co'];
+//       MFMA phase (K = 8 blocks = two 16x16x4 k-steps): wave (cg, ph) accumulates dU[pos][co][ci] for its 8 positions
+//       (transform rows 3 ph and 1 + ph), all 64 co (4 M tiles, one ds_read_b128 per position thanks to the co' = 4 (co &
+//       15) + (co >> 4) order) and its 16 ci (N tile cg): 128 accumulator registers, 32 MFMAs per k-step for 8 + 8 LDS reads;
+//   * epilogue: G^T dU G per wave for its two transform rows (linear, so the two partial results just add up), summed in
+//     LDS into the same [tap][co][ci] slab format as the direct kernel - k_wgrad_reduce is shared.
+struct WgW {
+    static constexpr int TH = 8, TW = 16, HW = 18, HH = 10, PS = 66, RS = HW * PS;
+    static constexpr int HALO_FLOATS = HH * RS, HALO_F4 = HH * HW * 16;
+    static constexpr int SV = 1040, SM = 1024;      // block strides: the b32 B reads of a half-wave (2 blocks) need SV = 16 mod 32
+    static constexpr int OUT_STRIDE = 68;           // epilogue staging [tap][co][68]: 4 co rows apart = 16 banks apart
+    static constexpr size_t MAIN_BYTES = (size_t)(2 * HALO_FLOATS + 8 * SV + 8 * SM) * 4;
+    static constexpr size_t OUT_BYTES = (size_t)9 * 64 * OUT_STRIDE * 4;
+    static constexpr size_t LDS_BYTES = MAIN_BYTES > OUT_BYTES ? MAIN_BYTES : OUT_BYTES;
+};
+__global__ __launch_bounds__(512, 1) void k_wgrad16_wino(const float* __restrict__ dz, const float* __restrict__ yin,
+                                                         const float* __restrict__ coef, const float* __restrict__ xin,
+                                                         float* __restrict__ part, int H, int tiles_per_clip, int n_tiles) {
+    using C = WgW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Vs = smem + 2 * C::HALO_FLOATS;
+    float* Ms = Vs + 8 * C::SV;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = wave & 3, ph = wave >> 2;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const float ca = coef[lane], cb = coef[64 + lane], cc = coef[128 + lane];      // transform role: lane = channel
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int p8 = 0; p8 < 8; ++p8)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[p8][m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    constexpr int NLD = (C::HALO_F4 + 511) / 512, NH = NLD / 2;                    // 6 float4 per thread, in two pieces
+    f32x4_t pre[NH];
+    // (the opaque copy of tid keeps the compiler from hoisting every item's address arithmetic out of the tile loop -
+    // a dozen loop-invariant registers per item that the 128 accumulators leave no room for)
+    auto load_item = [&](int tile, int it, f32x4_t& d0) {
+        const int b = tile / tiles_per_clip, y0 = (tile % tiles_per_clip) * C::TH;
+        int t2 = tid;
+        asm volatile("" : "+v"(t2));
+        const int f = t2 + 512 * it;
+        const int pix = f >> 4, c4 = (f & 15) * 4;
+        const int hy = pix / C::HW, hx = pix % C::HW;
+        const int iy = y0 - 1 + hy, ix = hx - 1;
+        const bool ok = (f < C::HALO_F4) && iy >= 0 && iy < H && ix >= 0 && ix < C::TW;
+        const uint32_t g = ok ? (uint32_t)(((b * H + iy) * C::TW + ix) * 64 + c4) : 0u;
+        d0 = *(const f32x4_t*)(xin + g);
+    };
+    auto store_item = [&](float* halo, int tile, int it, const f32x4_t& s0) {
+        const int y0 = (tile % tiles_per_clip) * C::TH;
+        int t2 = tid;
+        asm volatile("" : "+v"(t2));
+        const int f = t2 + 512 * it;
+        const int pix = f >> 4, c4 = (f & 15) * 4;
+        const int hy = pix / C::HW, hx = pix % C::HW;
+        const int iy = y0 - 1 + hy, ix = hx - 1;
+        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < C::TW;
+        const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
+        const f32x4_t v = ok ? s0 : z4;
+        if (f < C::HALO_F4) {
+            float* d = halo + hy * C::RS + hx * C::PS + c4;
+            *(float2*)d = make_float2(v[0], v[1]);
+            *(float2*)(d + 2) = make_float2(v[2], v[3]);
+        }
+    };
+    float dzr[4], yr[4];                                       // the 2x2 output-gradient block of the next sub-step (raw)
+    auto load_dy = [&](int tile, int sub) {
+        const int b = tile / tiles_per_clip, y0 = (tile % tiles_per_clip) * C::TH;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int yy = y0 + 2 * sub + (q >> 1), xx = 2 * wave + (q & 1);
+            const uint32_t g = (yy < H) ? (uint32_t)(((b * H + yy) * C::TW + xx) * 64 + lane) : 0u;
+            dzr[q] = dz[g];
+            yr[q] = yin[g];
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < n_tiles) {
+        f32x4_t first[NLD];
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) load_item(tile, it, first[it]);
+        load_dy(tile, 0);
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) store_item(smem, tile, it, first[it]);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int nxt = (tile + (int)gridDim.x < n_tiles) ? tile + (int)gridDim.x : tile;    // (unconditional prefetch, see k_conv_wino)
+        const float* halo = smem + cur * C::HALO_FLOATS;
+        float* halo_nxt = smem + (cur ^ 1) * C::HALO_FLOATS;
+        const int y0 = (tile % tiles_per_clip) * C::TH;
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            if (sub == 0 || sub == 2) {
+#pragma unroll
+                for (int k2 = 0; k2 < NH; ++k2) load_item(nxt, (sub >> 1) * NH + k2, pre[k2]);
+            }
+            // ---- input transform of block (row sub, column wave), channel lane: V = B^T d B
+            {
+                const float* P = halo + (2 * sub) * C::RS + (2 * wave) * C::PS + lane;
+                float T[4][4];
+#pragma unroll
+                for (int b2 = 0; b2 < 4; ++b2) {
+                    const float d0 = P[b2 * C::PS], d1 = P[C::RS + b2 * C::PS], d2 = P[2 * C::RS + b2 * C::PS], d3 = P[3 * C::RS + b2 * C::PS];
+                    T[0][b2] = d0 - d2; T[1][b2] = d1 + d2; T[2][b2] = d2 - d1; T[3][b2] = d1 - d3;
+                }
+                float* Vd = Vs + wave * C::SV + lane;
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) {
+                    Vd[(4 * i2 + 0) * 64] = T[i2][0] - T[i2][2];
+                    Vd[(4 * i2 + 1) * 64] = T[i2][1] + T[i2][2];
+                    Vd[(4 * i2 + 2) * 64] = T[i2][2] - T[i2][1];
+                    Vd[(4 * i2 + 3) * 64] = T[i2][1] - T[i2][3];
+                }
+            }
+            // ---- output-gradient transform of the same block, channel lane: dM = A dY A^T, A = [1 0; 1 1; 1 -1; 0 -1]
+            {
+                float dy[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v = fmaf(ca, dzr[q], fmaf(cb, yr[q], cc));
+                    dy[q] = (y0 + 2 * sub + (q >> 1) < H) ? v : 0.f;             // rows past the image contribute nothing
+                }
+                // R[i][x] = sum_y A[i][y] dY[y][x]
+                const float R[4][2] = {{dy[0], dy[1]}, {dy[0] + dy[2], dy[1] + dy[3]}, {dy[0] - dy[2], dy[1] - dy[3]}, {-dy[2], -dy[3]}};
+                float* Md = Ms + wave * C::SM + 4 * (lane & 15) + (lane >> 4);
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) {
+                    Md[(4 * i2 + 0) * 64] = R[i2][0];
+                    Md[(4 * i2 + 1) * 64] = R[i2][0] + R[i2][1];
+                    Md[(4 * i2 + 2) * 64] = R[i2][0] - R[i2][1];
+                    Md[(4 * i2 + 3) * 64] = -R[i2][1];
+                }
+            }
+            if (sub < 3) load_dy(tile, sub + 1); else load_dy(nxt, 0);
+            lds_barrier();
+            // ---- MFMA phase: K = 8 blocks; A = dM (M = co, 4 tiles per b128), B = V (N = ci)
+#pragma unroll
+            for (int ksl = 0; ksl < 2; ++ksl) {
+                const float* Ab = Ms + (4 * ksl + kq) * C::SM + 4 * i16;
+                const float* Bb = Vs + (4 * ksl + kq) * C::SV + 16 * cg + i16;
+#pragma unroll
+                for (int p8 = 0; p8 < 8; ++p8) {
+                    const int pos = (p8 < 4 ? 12 * ph : 4 * (1 + ph)) + (p8 & 3);
+                    const f32x4_t a4 = *(const f32x4_t*)(Ab + pos * 64);
+                    const float bv = Bb[pos * 64];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[p8][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m], bv, acc[p8][m], 0, 0, 0);
+                }
+            }
+            if (sub == 1 || sub == 3) {
+#pragma unroll
+                for (int k2 = 0; k2 < NH; ++k2) store_item(halo_nxt, nxt, (sub >> 1) * NH + k2, pre[k2]);
+            }
+            lds_barrier();                 // V / dM free again; after sub 3: the next halo is complete
+        }
+        cur ^= 1;
+    }
+    // ---- epilogue: dg = G^T dU G for this wave's two transform rows, the two wave rows summed in LDS ----------------
+    // per row: W[b] = sum_j dU[.][j] G[j][b] = (u0 + (u1 + u2)/2, (u1 - u2)/2, (u1 + u2)/2 + u3); then over the rows
+    // i with G[i][a]: rows 0, 1 (ph = 0): dg[0][b] = Wx + Wy/2, dg[1][b] = dg[2][b] = Wy/2;
+    //                 rows 3, 2 (ph = 1): dg[0][b] = Wy/2, dg[1][b] = -Wy/2, dg[2][b] = Wx + Wy/2   (x = row 3 ph, y = row 1 + ph)
+    __syncthreads();
+    float* ob = smem;
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        if (ph == round) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float wx[3], wy[3];
+                    {
+                        const float u0 = acc[0][m][r], u1 = acc[1][m][r], u2 = acc[2][m][r], u3 = acc[3][m][r];
+                        const float h = 0.5f * (u1 + u2);
+                        wx[0] = u0 + h; wx[1] = 0.5f * (u1 - u2); wx[2] = h + u3;
+                    }
+                    {
+                        const float u0 = acc[4][m][r], u1 = acc[5][m][r], u2 = acc[6][m][r], u3 = acc[7][m][r];
+                        const float h = 0.5f * (u1 + u2);
+                        wy[0] = 0.5f * (u0 + h); wy[1] = 0.25f * (u1 - u2); wy[2] = 0.5f * (h + u3);     // Wy / 2
+                    }
+                    float* o = ob + (16 * m + 4 * kq + r) * C::OUT_STRIDE + 16 * cg + i16;          // + tap * 64 * OUT_STRIDE
+#pragma unroll
+                    for (int b2 = 0; b2 < 3; ++b2) {
+                        const float g0 = ph ? wy[b2] : wx[b2] + wy[b2];
+                        const float g1 = ph ? -wy[b2] : wy[b2];
+                        const float g2 = ph ? wx[b2] + wy[b2] : wy[b2];
+                        if (round == 0) {
+                            o[(0 + b2) * 64 * C::OUT_STRIDE] = g0; o[(3 + b2) * 64 * C::OUT_STRIDE] = g1; o[(6 + b2) * 64 * C::OUT_STRIDE] = g2;
+                        } else {
+                            o[(0 + b2) * 64 * C::OUT_STRIDE] += g0; o[(3 + b2) * 64 * C::OUT_STRIDE] += g1; o[(6 + b2) * 64 * C::OUT_STRIDE] += g2;
+                        }
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    float* dst = part + (size_t)blockIdx.x * 9 * 4096;
+    for (int idx = tid; idx < 9 * 64 * 16; idx += 512) {
+        const int row = idx >> 4, c4 = (idx & 15) * 4;
+        *(f32x4_t*)(dst + row * 64 + c4) = *(const f32x4_t*)(ob + row * C::OUT_STRIDE + c4);
+    }
+}
+
 // Sum of the per-workgroup partial slabs, in a fixed order (bit-reproducible).  A workgroup owns 64 consecutive
 // outputs; its 4 waves take every 4th slab (8 independent loads in flight per thread), then combine through LDS.
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, int n_blocks, float* __restrict__ g_w) {
@@ -1127,7 +1176,7 @@ static int conv_launch_t(const float* in0, const float* in1, const float* coef, 
 int launch_conv_fwd(const float* in, const float* wpk, const float* bias, float* y, double* stat, int zero_stat, int B,
                     int H, int W, hipStream_t st) {
     if (stat && zero_stat) SED_CHECK_HIP(hipMemsetAsync(stat, 0, 128 * sizeof(double), st));
-    const bool direct = (g_sed_debug & (2 | 32 | 64)) != 0;          // A/B timing only: the 9-tap kernels
+    const bool direct = (g_sed_debug & (2 | 64)) != 0;          // A/B timing only: the 9-tap kernels
     if (W == 16) return !direct ? conv_wino_launch<16, 0>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st)
                : (g_sed_debug & 2) ? conv_launch_t<16, 0, 1>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st)
                                    : conv16_ws_launch<0>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st);
@@ -1139,7 +1188,7 @@ int launch_conv_fwd(const float* in, const float* wpk, const float* bias, float*
 
 int launch_conv_dgrad(const float* dz, const float* yin, const float* coef, const float* wpkT, float* dx, int B, int H,
                       int W, hipStream_t st) {
-    const bool direct = (g_sed_debug & (4 | 32 | 64)) != 0;          // A/B timing only: the 9-tap kernels
+    const bool direct = (g_sed_debug & (4 | 64)) != 0;          // A/B timing only: the 9-tap kernels
     if (W == 16) return !direct ? conv_wino_launch<16, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st)
                : (g_sed_debug & 4) ? conv_launch_t<16, 1, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st)
                                    : conv16_ws_launch<1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st);
@@ -1163,7 +1212,17 @@ static int wgrad_launch_t(const float* dz, const float* yin, const float* coef, 
     const int nb = nt < n_blocks ? nt : n_blocks;
     // block 1: the double-buffered kernel (15 % faster alone; in the step, next to dgrad on the other stream, 1.143 vs
     // 1.162 ms per step although its 154 KB of LDS keep any other workgroup off its CU); bit 3 of the debug knob = old
-    if (TW == 16 && TS == 1 && !(g_sed_debug & 8)) {
+    // block 1: Winograd-domain kernel (operator 76 us against 105 us for the direct double-buffered kernel, which bits 3 / 7
+    // of the debug knob bring back: bit 7 = k_wgrad16_db, bit 3 = the single-buffered tile kernel)
+    if (TW == 16 && TS == 1 && !(g_sed_debug & (8 | 128))) {
+        static bool attrw = false;
+        if (!attrw) {
+            SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_wgrad16_wino, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WgW::LDS_BYTES));
+            attrw = true;
+        }
+        SED_CHECK_ARG((size_t)B * H * TW * 64 < ((size_t)1 << 31), "wgrad: image too large for 32-bit offsets");
+        k_wgrad16_wino<<<nb, 512, WgW::LDS_BYTES, st>>>(dz, yin, coef, xin, part, H, tpc, nt);
+    } else if (TW == 16 && TS == 1 && !(g_sed_debug & 8)) {
         static bool attr16 = false;
         if (!attr16) {
             SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_wgrad16_db, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wg16::LDS_BYTES));

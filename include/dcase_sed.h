@@ -226,12 +226,11 @@ int sed_kernel_replay(const char* name, const sed_dims* d, const float* params, 
 
 /* Debug knob for timing experiments (returns the previous value); 0 = normal operation.
  *   bit 0: skip the fp64 atomics of the reduction epilogues (results are then WRONG);
- *   bit 1 / 2 / 3: block-1 conv forward / dgrad / wgrad use their alternative kernel (tile kernel instead of the
- *   weight-stationary one for forward and dgrad; single- instead of double-buffered wgrad); bit 5: the 4-wave instead
- *   of the 8-wave weight-stationary kernel.  Same results, kept for A/B timing (profiles/README.md);
- *   bit 4: GLU backward with one wave per SIMD instead of two channel-half waves sharing a row block;
- *   bit 6: block-1 conv forward / dgrad by the direct (9-tap) 8-wave kernel instead of the Winograd F(2x2, 3x3) one
- *   (results differ at the 1e-7 level). */
+ *   bit 1 / 2: block-1 conv forward / dgrad by the 9-tap tile kernel; bit 6: both 64 -> 64 convolutions (forward and
+ *   dgrad) by the direct 9-tap kernels (8-wave weight-stationary for block 1, tile kernel for block 2) instead of the
+ *   Winograd F(2x2, 3x3) kernel - results differ at the 1e-7 level; bit 7: block-1 wgrad by the direct double-buffered
+ *   kernel instead of the Winograd-domain one; bit 3: by the single-buffered tile kernel; bit 4: GLU backward with one wave per SIMD instead of two channel-half waves sharing a row block.
+ *   Kept for A/B timing (profiles/README.md). */
 int sed_debug_set(int flags);
 
 /* ---- self tests (run on the GPU box by tests/) ---------------------------------------------

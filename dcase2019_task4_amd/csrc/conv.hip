@@ -917,23 +917,33 @@ __global__ __launch_bounds__(256) void k_wgrad16_db(const float* __restrict__ dz
 
 // ---- block-1 wgrad in the Winograd domain -----------------------------------------------------------------------------
 // dW = G^T [ sum over 2x2 output blocks of (B^T d B) (.) (A dY A^T) ] G: 16 multiplies per block and (ci, co) pair instead
-// of 36, like the forward kernel.  Here BOTH operands need a transform, so they are transformed once per block row into
-// LDS (no redundancy between waves) and the MFMA phase reads ready-made fragments:
-//   * tile = 8 image rows x 16 columns = 4 block rows of 8 blocks; per block row ("sub-step"):
-//       transform phase: wave w takes block w of the row, lane = channel: V = B^T d B of the input patch (from the LDS
-//       halo of x) -> Vs[blk][pos][ci]; dY = ca dz + cb y + cc straight from global memory (its 2x2 blocks do not
-//       overlap, so no staging; prefetched one sub-step ahead), dM = A dY A^T -> Ms[blk][pos][co'];
-//       MFMA phase (K = 8 blocks = two 16x16x4 k-steps): wave (cg, ph) accumulates dU[pos][co][ci] for its 8 positions
-//       (transform rows 3 ph and 1 + ph), all 64 co (4 M tiles, one ds_read_b128 per position thanks to the co' = 4 (co &
-//       15) + (co >> 4) order) and its 16 ci (N tile cg): 128 accumulator registers, 32 MFMAs per k-step for 8 + 8 LDS reads;
+// of 36, like the forward kernel.  Here BOTH operands need a transform, so they are transformed once into LDS (no
+// redundancy between waves) and the MFMAs read ready-made fragments:
+//   * tile = 8 image rows x 16 columns = 32 blocks = 8 k-steps of 4 blocks (K of v_mfma_f32_16x16x4_f32);
+//   * wave (cg, ph) accumulates dU[pos][co][ci] for its 8 positions (transform rows 3 ph and 1 + ph), all 64 co (4 M
+//     tiles, one ds_read_b128 per position thanks to the co' = 4 (co & 15) + (co >> 4) order) and its 16 ci (N tile cg):
+//     128 accumulator registers, 32 MFMAs per k-step for 8 + 8 LDS reads;
+//   * the operands of k-step s + 1 are produced while k-step s is multiplied (double-buffered Vs / Ms): the ph = 0 waves
+//     transform the inputs of its 4 blocks (lane = channel: V = B^T d B from the LDS halo of x -> Vs[blk][pos][ci]), the
+//     ph = 1 waves the output gradients (dY = ca dz + cb y + cc straight from global memory - 2x2 blocks do not overlap,
+//     so no staging, prefetched one k-step ahead; dM = A dY A^T -> Ms[blk][pos][co']).  The two waves of a SIMD do
+//     these in OPPOSITE order (ph = 0: transform, then MFMAs; ph = 1: MFMAs, then transform), so one of them always
+//     has MFMAs to issue; one barrier per k-step;
 //   * epilogue: G^T dU G per wave for its two transform rows (linear, so the two partial results just add up), summed in
 //     LDS into the same [tap][co][ci] slab format as the direct kernel - k_wgrad_reduce is shared.
+// (A first version transformed 8 blocks at a time in a phase of its own: 0.8 us of every 3.35 us with the MFMA pipe idle.)
+#ifdef SED_TS
+#define TSW4(k) do { if (threadIdx.x == 256 && blockIdx.x < 1024) g_ts[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define TSW4(k) do { } while (0)
+#endif
 struct WgW {
     static constexpr int TH = 8, TW = 16, HW = 18, HH = 10, PS = 66, RS = HW * PS;
     static constexpr int HALO_FLOATS = HH * RS, HALO_F4 = HH * HW * 16;
     static constexpr int SV = 1040, SM = 1024;      // block strides: the b32 B reads of a half-wave (2 blocks) need SV = 16 mod 32
+    static constexpr int OPS_FLOATS = 4 * SV + 4 * SM;                 // one k-step's operands
     static constexpr int OUT_STRIDE = 68;           // epilogue staging [tap][co][68]: 4 co rows apart = 16 banks apart
-    static constexpr size_t MAIN_BYTES = (size_t)(2 * HALO_FLOATS + 8 * SV + 8 * SM) * 4;
+    static constexpr size_t MAIN_BYTES = (size_t)(2 * HALO_FLOATS + 2 * OPS_FLOATS) * 4;
     static constexpr size_t OUT_BYTES = (size_t)9 * 64 * OUT_STRIDE * 4;
     static constexpr size_t LDS_BYTES = MAIN_BYTES > OUT_BYTES ? MAIN_BYTES : OUT_BYTES;
 };
@@ -942,144 +952,182 @@ __global__ __launch_bounds__(512, 1) void k_wgrad16_wino(const float* __restrict
                                                          float* __restrict__ part, int H, int tiles_per_clip, int n_tiles) {
     using C = WgW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Vs = smem + 2 * C::HALO_FLOATS;
-    float* Ms = Vs + 8 * C::SV;
+    float* ops = smem + 2 * C::HALO_FLOATS;          // [2 buffers][Vs: 4 blocks x SV | Ms: 4 blocks x SM]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cg = wave & 3, ph = wave >> 2;
     const int i16 = lane & 15, kq = lane >> 4;
     const float ca = coef[lane], cb = coef[64 + lane], cc = coef[128 + lane];      // transform role: lane = channel
+    // halo staging by image rows: thread -> (column hx = tid >> 4, channels 4 (tid & 15) ..), one float4 per halo row and
+    // thread, so everything but the row is a per-lane constant (a flat "item = tid + 512 i" split cost ~25 VALU per item
+    // in div / mod / bounds arithmetic - 0.35 us per k-step that carried one).  Threads 288..511 duplicate columns 2..15
+    // (same data to the same LDS address) instead of being masked: no divergent store for the compiler to sink the load into.
+    constexpr int NROW = C::HH, NH = 2;                                            // 10 rows, fetched two at a time
+    f32x4_t pre[NH];
+    const int hxl = tid >> 4, hx = hxl < C::HW ? hxl : hxl - 16, c4 = (tid & 15) * 4;
+    const int ixc = hx - 1 < 0 ? 0 : (hx - 1 > C::TW - 1 ? C::TW - 1 : hx - 1);
+    const uint32_t goff4 = (uint32_t)(ixc * 64 + c4) * 4u;                         // byte offset inside an image row
+    const bool colok = hx >= 1 && hx <= C::TW;
+    const int lds_off = hx * C::PS + c4;
+    auto load_row = [&](int b, int y0, int hy, f32x4_t& d0) {
+        const int iy = y0 - 1 + hy;
+        const int iyc = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);                    // (uniform) always a valid row; masked when stored
+        const float* rowp = xin + (size_t)(b * H + iyc) * (C::TW * 64);
+        d0 = *(const f32x4_t*)((const char*)rowp + goff4);
+    };
+    auto store_row = [&](float* halo, int y0, int hy, const f32x4_t& s0) {
+        const int iy = y0 - 1 + hy;
+        const bool ok = colok && iy >= 0 && iy < H;
+        const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
+        const f32x4_t v = ok ? s0 : z4;
+        float* d = halo + hy * C::RS + lds_off;
+        *(float2*)d = make_float2(v[0], v[1]);
+        *(float2*)(d + 2) = make_float2(v[2], v[3]);
+    };
+    // k-step ks of a tile = block row ks >> 1, block columns 4 (ks & 1) .. + 3; transform role: block (wave & 3) of them
     f32x4_t acc[8][4];
+    // ph = 1 waves: raw 2x2 output-gradient blocks, fetched TWO k-steps ahead (one k-step is ~1 us: not enough to cover the
+    // load latency under load - the first version waited ~1 us per k-step here); slot = k-step parity
+    float dzr[2][4], yr[2][4];
+    // buffer loads: descriptor + uniform pixel offset (soffset) + 4 * lane (voffset) - no per-load address arithmetic
+    const int img_bytes = (n_tiles / tiles_per_clip) * H * (C::TW * 64 * 4);
+    const auto rs_dz = __builtin_amdgcn_make_buffer_rsrc((void*)dz, (short)0, img_bytes, 0x00020000);
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)yin, (short)0, img_bytes, 0x00020000);
+    const int lane4 = 4 * lane;
+    auto load_dy = [&](int b, int y0, int ks, int slot) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int yy = y0 + 2 * (ks >> 1) + (q >> 1), xx = 2 * (4 * (ks & 1) + cg) + (q & 1);
+            // rows past the image re-read the last row and are zeroed in the transform - by a multiplication: with a
+            // select there the compiler threads the (uniform) condition back to here and branches around the loads, and
+            // the control flow inside the unrolled loop made it shuffle the accumulators between registers
+            const int yc = yy < H ? yy : H - 1;
+            const int so = ((b * H + yc) * C::TW + xx) * 256;
+            dzr[slot][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_dz, lane4, so, 0));
+            yr[slot][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_y, lane4, so, 0));
+        }
+    };
+    // input transform of block cg of k-step ks, channel lane: V = B^T d B -> Vs[cg][pos][lane]
+    auto transform_v = [&](const float* halo, int ks, float* Vs) {
+        const float* P = halo + (2 * cg) * C::PS + lane + ((2 * (ks >> 1)) * C::RS + 8 * (ks & 1) * C::PS);   // (constant part -> instruction offset)
+        float T[4][4];
+#pragma unroll
+        for (int b2 = 0; b2 < 4; ++b2) {
+            const float d0 = P[b2 * C::PS], d1 = P[C::RS + b2 * C::PS], d2 = P[2 * C::RS + b2 * C::PS], d3 = P[3 * C::RS + b2 * C::PS];
+            T[0][b2] = d0 - d2; T[1][b2] = d1 + d2; T[2][b2] = d2 - d1; T[3][b2] = d1 - d3;
+        }
+        float* Vd = Vs + cg * C::SV + lane;
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) {
+            Vd[(4 * i2 + 0) * 64] = T[i2][0] - T[i2][2];
+            Vd[(4 * i2 + 1) * 64] = T[i2][1] + T[i2][2];
+            Vd[(4 * i2 + 2) * 64] = T[i2][2] - T[i2][1];
+            Vd[(4 * i2 + 3) * 64] = T[i2][1] - T[i2][3];
+        }
+    };
+    // output-gradient transform of the same block, channel lane: dM = A dY A^T, A = [1 0; 1 1; 1 -1; 0 -1] -> Ms[cg][pos][co']
+    auto transform_m = [&](int y0, int ks, int slot, float* Ms) {
+        float dy[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float v = fmaf(ca, dzr[slot][q], fmaf(cb, yr[slot][q], cc));
+            dy[q] = v * ((y0 + 2 * (ks >> 1) + (q >> 1) < H) ? 1.f : 0.f);     // rows past the image contribute nothing
+        }
+        // R[i][x] = sum_y A[i][y] dY[y][x]
+        const float R[4][2] = {{dy[0], dy[1]}, {dy[0] + dy[2], dy[1] + dy[3]}, {dy[0] - dy[2], dy[1] - dy[3]}, {-dy[2], -dy[3]}};
+        float* Md = Ms + cg * C::SM + 4 * (lane & 15) + (lane >> 4);
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) {
+            Md[(4 * i2 + 0) * 64] = R[i2][0];
+            Md[(4 * i2 + 1) * 64] = R[i2][0] + R[i2][1];
+            Md[(4 * i2 + 2) * 64] = R[i2][0] - R[i2][1];
+            Md[(4 * i2 + 3) * 64] = -R[i2][1];
+        }
+    };
+    // the 32 MFMAs of one k-step: A = dM (M = co, 4 tiles per b128), B = V (N = ci)
+    auto mma = [&](const float* Vs, const float* Ms) {
+        const float* Ab = Ms + kq * C::SM + 4 * i16 + 256 * (1 + ph);       // this wave's Y row (1 + ph); X row = 3 ph
+        const float* Bb = Vs + kq * C::SV + 16 * cg + i16 + 256 * (1 + ph);
+        const int xo = ph ? 256 : -256;                                     // (uniform) X row (3 ph) relative to the Y row
+#pragma unroll
+        for (int p8 = 0; p8 < 8; ++p8) {
+            const int po = (p8 < 4 ? xo : 0) + (p8 & 3) * 64;
+            const f32x4_t a4 = *(const f32x4_t*)(Ab + po);
+            const float bv = Bb[po];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[p8][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m], bv, acc[p8][m], 0, 0, 0);
+        }
+    };
+    int tile = blockIdx.x;
+    TS(0);
+    int it_ts = 0;
+    int tb = tile / tiles_per_clip, ty0 = (tile % tiles_per_clip) * C::TH;
+    if (tile < n_tiles) {
+        f32x4_t first[NROW];
+#pragma unroll
+        for (int hy = 0; hy < NROW; ++hy) load_row(tb, ty0, hy, first[hy]);
+        if (ph) { load_dy(tb, ty0, 0, 0); load_dy(tb, ty0, 1, 1); }
+#pragma unroll
+        for (int hy = 0; hy < NROW; ++hy) store_row(smem, ty0, hy, first[hy]);
+    }
+    __syncthreads();
+    if (tile < n_tiles) {                                    // operands of k-step 0 -> buffer 0
+        if (ph == 0) transform_v(smem, 0, ops);
+        else transform_m(ty0, 0, 0, ops + 4 * C::SV);
+    }
+    __syncthreads();
+    TS(1);
 #pragma unroll
     for (int p8 = 0; p8 < 8; ++p8)
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[p8][m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    constexpr int NLD = (C::HALO_F4 + 511) / 512, NH = NLD / 2;                    // 6 float4 per thread, in two pieces
-    f32x4_t pre[NH];
-    // (the opaque copy of tid keeps the compiler from hoisting every item's address arithmetic out of the tile loop -
-    // a dozen loop-invariant registers per item that the 128 accumulators leave no room for)
-    auto load_item = [&](int tile, int it, f32x4_t& d0) {
-        const int b = tile / tiles_per_clip, y0 = (tile % tiles_per_clip) * C::TH;
-        int t2 = tid;
-        asm volatile("" : "+v"(t2));
-        const int f = t2 + 512 * it;
-        const int pix = f >> 4, c4 = (f & 15) * 4;
-        const int hy = pix / C::HW, hx = pix % C::HW;
-        const int iy = y0 - 1 + hy, ix = hx - 1;
-        const bool ok = (f < C::HALO_F4) && iy >= 0 && iy < H && ix >= 0 && ix < C::TW;
-        const uint32_t g = ok ? (uint32_t)(((b * H + iy) * C::TW + ix) * 64 + c4) : 0u;
-        d0 = *(const f32x4_t*)(xin + g);
-    };
-    auto store_item = [&](float* halo, int tile, int it, const f32x4_t& s0) {
-        const int y0 = (tile % tiles_per_clip) * C::TH;
-        int t2 = tid;
-        asm volatile("" : "+v"(t2));
-        const int f = t2 + 512 * it;
-        const int pix = f >> 4, c4 = (f & 15) * 4;
-        const int hy = pix / C::HW, hx = pix % C::HW;
-        const int iy = y0 - 1 + hy, ix = hx - 1;
-        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < C::TW;
-        const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
-        const f32x4_t v = ok ? s0 : z4;
-        if (f < C::HALO_F4) {
-            float* d = halo + hy * C::RS + hx * C::PS + c4;
-            *(float2*)d = make_float2(v[0], v[1]);
-            *(float2*)(d + 2) = make_float2(v[2], v[3]);
-        }
-    };
-    float dzr[4], yr[4];                                       // the 2x2 output-gradient block of the next sub-step (raw)
-    auto load_dy = [&](int tile, int sub) {
-        const int b = tile / tiles_per_clip, y0 = (tile % tiles_per_clip) * C::TH;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int yy = y0 + 2 * sub + (q >> 1), xx = 2 * wave + (q & 1);
-            const uint32_t g = (yy < H) ? (uint32_t)(((b * H + yy) * C::TW + xx) * 64 + lane) : 0u;
-            dzr[q] = dz[g];
-            yr[q] = yin[g];
-        }
-    };
-    int tile = blockIdx.x;
-    if (tile < n_tiles) {
-        f32x4_t first[NLD];
-#pragma unroll
-        for (int it = 0; it < NLD; ++it) load_item(tile, it, first[it]);
-        load_dy(tile, 0);
-#pragma unroll
-        for (int it = 0; it < NLD; ++it) store_item(smem, tile, it, first[it]);
-    }
-    __syncthreads();
     int cur = 0;
     for (; tile < n_tiles; tile += gridDim.x) {
         const int nxt = (tile + (int)gridDim.x < n_tiles) ? tile + (int)gridDim.x : tile;    // (unconditional prefetch, see k_conv_wino)
+        const int nb_ = nxt / tiles_per_clip, ny0 = (nxt % tiles_per_clip) * C::TH;
         const float* halo = smem + cur * C::HALO_FLOATS;
         float* halo_nxt = smem + (cur ^ 1) * C::HALO_FLOATS;
-        const int y0 = (tile % tiles_per_clip) * C::TH;
 #pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {
-            if (sub == 0 || sub == 2) {
+        for (int ks = 0; ks < 8; ++ks) {
+            // next tile's halo, two rows per k-step: rows 2 ks, 2 ks + 1 are fetched at the start of k-step ks (0..4) and stored
+            // at the end of k-step ks + 1; complete before the barrier of k-step 6, because k-step 7 already transforms the
+            // next tile's first blocks
+            f32x4_t held[NH];
+            if (ks >= 1 && ks <= 5) {
 #pragma unroll
-                for (int k2 = 0; k2 < NH; ++k2) load_item(nxt, (sub >> 1) * NH + k2, pre[k2]);
+                for (int k2 = 0; k2 < NH; ++k2) held[k2] = pre[k2];
             }
-            // ---- input transform of block (row sub, column wave), channel lane: V = B^T d B
-            {
-                const float* P = halo + (2 * sub) * C::RS + (2 * wave) * C::PS + lane;
-                float T[4][4];
+            if (ks <= 4) {
 #pragma unroll
-                for (int b2 = 0; b2 < 4; ++b2) {
-                    const float d0 = P[b2 * C::PS], d1 = P[C::RS + b2 * C::PS], d2 = P[2 * C::RS + b2 * C::PS], d3 = P[3 * C::RS + b2 * C::PS];
-                    T[0][b2] = d0 - d2; T[1][b2] = d1 + d2; T[2][b2] = d2 - d1; T[3][b2] = d1 - d3;
-                }
-                float* Vd = Vs + wave * C::SV + lane;
-#pragma unroll
-                for (int i2 = 0; i2 < 4; ++i2) {
-                    Vd[(4 * i2 + 0) * 64] = T[i2][0] - T[i2][2];
-                    Vd[(4 * i2 + 1) * 64] = T[i2][1] + T[i2][2];
-                    Vd[(4 * i2 + 2) * 64] = T[i2][2] - T[i2][1];
-                    Vd[(4 * i2 + 3) * 64] = T[i2][1] - T[i2][3];
-                }
+                for (int k2 = 0; k2 < NH; ++k2) load_row(nb_, ny0, 2 * ks + k2, pre[k2]);
             }
-            // ---- output-gradient transform of the same block, channel lane: dM = A dY A^T, A = [1 0; 1 1; 1 -1; 0 -1]
-            {
-                float dy[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float v = fmaf(ca, dzr[q], fmaf(cb, yr[q], cc));
-                    dy[q] = (y0 + 2 * sub + (q >> 1) < H) ? v : 0.f;             // rows past the image contribute nothing
-                }
-                // R[i][x] = sum_y A[i][y] dY[y][x]
-                const float R[4][2] = {{dy[0], dy[1]}, {dy[0] + dy[2], dy[1] + dy[3]}, {dy[0] - dy[2], dy[1] - dy[3]}, {-dy[2], -dy[3]}};
-                float* Md = Ms + wave * C::SM + 4 * (lane & 15) + (lane >> 4);
-#pragma unroll
-                for (int i2 = 0; i2 < 4; ++i2) {
-                    Md[(4 * i2 + 0) * 64] = R[i2][0];
-                    Md[(4 * i2 + 1) * 64] = R[i2][0] + R[i2][1];
-                    Md[(4 * i2 + 2) * 64] = R[i2][0] - R[i2][1];
-                    Md[(4 * i2 + 3) * 64] = -R[i2][1];
-                }
+            float* nb = ops + ((ks + 1) & 1) * C::OPS_FLOATS;                   // operands of the next k-step
+            const float* cb2 = ops + (ks & 1) * C::OPS_FLOATS;
+            // (one copy of the MFMA code between two uniform branches: with it inside both arms of an if / else the register
+            // allocator spilled the accumulators)
+            if (ph == 0) {
+                if (ks < 7) transform_v(halo, ks + 1, nb); else transform_v(halo_nxt, 0, nb);
             }
-            if (sub < 3) load_dy(tile, sub + 1); else load_dy(nxt, 0);
+            if (it_ts == 0 && ks == 2) { TS(3); TSW4(7); }
+            mma(cb2, cb2 + 4 * C::SV);
+            if (it_ts == 0 && ks == 2) { TS(4); TSW4(8); }
+            if (ph == 1) {                                     // slot ks & 1 was consumed by the previous k-step's transform
+                if (ks < 6) load_dy(tb, ty0, ks + 2, ks & 1); else load_dy(nb_, ny0, ks - 6, ks & 1);
+                if (ks < 7) transform_m(ty0, ks + 1, (ks + 1) & 1, nb + 4 * C::SV); else transform_m(ny0, 0, 0, nb + 4 * C::SV);
+            }
+            if (ks >= 1 && ks <= 5) {
+#pragma unroll
+                for (int k2 = 0; k2 < NH; ++k2) store_row(halo_nxt, ny0, 2 * (ks - 1) + k2, held[k2]);
+            }
+            if (it_ts == 0 && ks == 2) { TS(5); TSW4(9); }
             lds_barrier();
-            // ---- MFMA phase: K = 8 blocks; A = dM (M = co, 4 tiles per b128), B = V (N = ci)
-#pragma unroll
-            for (int ksl = 0; ksl < 2; ++ksl) {
-                const float* Ab = Ms + (4 * ksl + kq) * C::SM + 4 * i16;
-                const float* Bb = Vs + (4 * ksl + kq) * C::SV + 16 * cg + i16;
-#pragma unroll
-                for (int p8 = 0; p8 < 8; ++p8) {
-                    const int pos = (p8 < 4 ? 12 * ph : 4 * (1 + ph)) + (p8 & 3);
-                    const f32x4_t a4 = *(const f32x4_t*)(Ab + pos * 64);
-                    const float bv = Bb[pos * 64];
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) acc[p8][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m], bv, acc[p8][m], 0, 0, 0);
-                }
-            }
-            if (sub == 1 || sub == 3) {
-#pragma unroll
-                for (int k2 = 0; k2 < NH; ++k2) store_item(halo_nxt, nxt, (sub >> 1) * NH + k2, pre[k2]);
-            }
-            lds_barrier();                 // V / dM free again; after sub 3: the next halo is complete
+            if (it_ts == 0 && ks == 1) { TS(2); TSW4(6); }
         }
+        if (it_ts == 0) TS(10);
+        ++it_ts;
         cur ^= 1;
+        tb = nb_; ty0 = ny0;
     }
+    TS(11);
     // ---- epilogue: dg = G^T dU G for this wave's two transform rows, the two wave rows summed in LDS ----------------
     // per row: W[b] = sum_j dU[.][j] G[j][b] = (u0 + (u1 + u2)/2, (u1 - u2)/2, (u1 + u2)/2 + u3); then over the rows
     // i with G[i][a]: rows 0, 1 (ph = 0): dg[0][b] = Wx + Wy/2, dg[1][b] = dg[2][b] = Wy/2;
@@ -1120,11 +1168,13 @@ __global__ __launch_bounds__(512, 1) void k_wgrad16_wino(const float* __restrict
         }
         __syncthreads();
     }
+    TS(12);
     float* dst = part + (size_t)blockIdx.x * 9 * 4096;
     for (int idx = tid; idx < 9 * 64 * 16; idx += 512) {
         const int row = idx >> 4, c4 = (idx & 15) * 4;
         *(f32x4_t*)(dst + row * 64 + c4) = *(const f32x4_t*)(ob + row * C::OUT_STRIDE + c4);
     }
+    TS(13);
 }
 
 // Sum of the per-workgroup partial slabs, in a fixed order (bit-reproducible).  A workgroup owns 64 consecutive

@@ -248,9 +248,9 @@ def main():
         dom = max(mfma_kernels, key=lambda k: kr[k]["us"])
         traffic, traffic_src = None, None
         pmc_file = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        pmc_names = {"conv1_fwd": ("void k_conv16_ws<0>", "void k_conv3x3<16, 0, 1>"),
-                     "conv1_dgrad": ("void k_conv3x3<16, 1, 1>", "void k_conv16_ws<1>"),
-                     "conv1_wgrad": ("k_wgrad16_db", "void k_conv3x3_wgrad<16, 1>")}[dom]
+        pmc_names = {"conv1_fwd": ("void k_conv_wino<16, 0>", "void k_conv16_ws2<0>", "void k_conv3x3<16, 0, 1>"),
+                     "conv1_dgrad": ("void k_conv_wino<16, 1>", "void k_conv16_ws2<1>", "void k_conv3x3<16, 1, 1>"),
+                     "conv1_wgrad": ("k_wgrad16_wino", "k_wgrad16_db", "void k_conv3x3_wgrad<16, 1>")}[dom]
         if os.path.exists(pmc_file):
             table = json.load(open(pmc_file))
             pmc = next((table[n] for n in pmc_names if n in table), None)
@@ -263,6 +263,9 @@ def main():
             "unit": "TFLOP/s", "frac": round(kr[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
             "traffic_source": traffic_src, "algorithmic_bytes": kr[dom]["bytes"], "algorithmic_flops": kr[dom]["flops"],
             "avg_launch_us": kr[dom]["us"],
+            "flop_convention": "algorithmic = the reference's direct 3x3 convolution FLOPs (2 x 9 x 64 x 64 per output pixel); "
+                               "the three block-1 convolution kernels run in the Winograd F(2x2,3x3) domain and issue 16/36 of those "
+                               "multiplies on the MFMA pipe, so 'achieved' is effective throughput against the f32 MFMA peak",
             "timing": "HIP events on the launch stream around 20 re-launches of this kernel on the step's own "
                       "buffers (sed_kernel_replay) right after the timed region; conv1_wgrad = k_wgrad16_db + its "
                       "k_wgrad_reduce (the whole operator); the rocprofv3 table's 'last-20 avg' column shows the same "

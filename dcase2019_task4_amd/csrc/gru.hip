@@ -20,6 +20,13 @@
 //     loads and stores per step would drain its stores (full write latency) before every use of a load.
 //   The two waves meet at ONE LDS-only barrier per block of GRU_SB steps.
 // Backward is the same structure with lane j owning COLUMN j of W_hh (dh_prev = W_hh^T dgh).
+// Where a step's ~1500 cycles go (forward, measured by leaving parts out, tools/kbench.py gru0_fwd): the mat-vec (96
+// v_pk_fma_f32 + 16 broadcast LDS reads issued by a lone wave, ~6 cycles per instruction) 19 of 42 us, the gate
+// transcendentals < 2 us, the rest is the LDS write -> read turn-around of h, the gi / history traffic and the block
+// hand-over.  Tried and rejected: scalar v_fmac_f32 instead of the packed form (55 us); the mat-vec split over four
+// waves on the four SIMDs (quad-lane partial dot products, h exchanged through LDS, the four waves meeting at an LDS
+// step counter with release / acquire instead of s_barrier): correct, but the per-step rendezvous costs more than
+// the split saves - 52 / 61 us (layer 0 / 1) against 42 / 44 us.
 #include "common.h"
 #include "kernels.h"
 

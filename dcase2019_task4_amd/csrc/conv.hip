@@ -446,6 +446,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_wino(const float* __restrict__ 
     constexpr int NLD = (C::HALO_F4 + 511) / 512;
     constexpr int NH = (MODE == 1) ? 1 : (NLD + 1) / 2, PARTS = (NLD + NH - 1) / NH;
     f32x4_t pre0[NH], pre1[MODE == 1 ? NH : 1];
+    // (Row-wise staging as in k_wgrad16_wino - thread = column x 4 channels, ~10 instead of ~25 VALU per item, scalar-base
+    // loads, but 10 one-row items in 5 pieces instead of 6 in 2 - measured no better here: 60 / 58.5 vs 59 / 56.5 us.)
     // raw loads only (padding is applied when the values go to LDS: a select here would make the compiler wait for the
     // loads on the spot); item it = float4 number tid + 512 it of the halo
     auto load_item = [&](int tile, int it, f32x4_t& d0, f32x4_t& d1) {

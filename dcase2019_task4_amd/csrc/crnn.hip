@@ -347,6 +347,8 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
     // recurrence - measured slower still, 1.043 ms: every event record splits the critical chain.)
     // (Forking before glu2_bwd so that the GRU GEMMs run first and wgrad1 starts on time measured slower, 1.061 vs
     // 1.029 ms: they then compete with the critical-path kernels glu2_bwd / dgrad2 / glu1_bwd.)
+    // (Same experiment again with the Winograd convolutions, where the side stream has become the tail of the step: still
+    // slower, 28.0 vs 28.3 k clips/s.)
     // (Starting wgrad1 only after dgrad1, next to the VALU-bound k_blk0_bwd, measured the same: dgrad1 drops from
     // 175 to 93 us but k_blk0_bwd, left with one wave per SIMD beside the wgrad wave, goes from 86 to 177 us.)
     for (int i = 2; i >= 1; --i) {

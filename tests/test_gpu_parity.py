@@ -139,6 +139,38 @@ def _check_grads(g_hip, go):
     return worst
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(4, 628), (3, 150), (2, 22)])
+def test_winograd_kernels_match_the_direct_convolution_kernels(B, T):
+    """The 64 -> 64 convolutions run in the Winograd F(2x2,3x3) domain (forward, dgrad, block-1 wgrad); the direct 9-tap
+    kernels stay in the library behind sed_debug_set (bits 6 and 7).  Same inputs through both: posteriors and every
+    gradient must agree to fp32 rounding (the transforms only add and halve) - far inside the 1e-3 parity bound.
+    T = 150 / 22: odd image heights, tiles cut by the image border, fewer tiles than workgroups."""
+    from dcase2019_task4_amd import _lib
+    l = _lib.lib()
+    outs = []
+    for flags in (0, 64 | 128):
+        prev = l.sed_debug_set(flags)
+        try:
+            model, _ = gu.make_model(0, dropout=0.5)
+            model.train()
+            x = synth.make_input(41, B, T)
+            s, w = model(x.cuda(), seed=gu.seed_tensor(777))
+            loss = (s * s).mean() + (w * w).mean() + s.mean()
+            loss.backward()
+            torch.cuda.synchronize()
+            outs.append((s.detach().cpu(), w.detach().cpu(), gu.grads_dict(model)))
+        finally:
+            l.sed_debug_set(prev)
+    (s0, w0, g0), (s1, w1, g1) = outs
+    assert float((s0 - s1).abs().max()) < 2e-6 and float((w0 - w1).abs().max()) < 2e-6
+    for n in g0:
+        scale = float(g1[n].double().norm()) / np.sqrt(g1[n].numel()) + 1e-30
+        err = float((g0[n] - g1[n]).abs().max())
+        print(f"[wino vs direct] {n:40s} err/typ {err / scale:.2e}")
+        assert err < 2e-4 * scale + 1e-7, n           # (+1e-7: gradients that cancel to ~0, e.g. the softmax bias)
+
+
 @pytest.mark.parametrize("B,T,p,n_layers,nclass", [(4, 128, 0.0, 2, 10), (4, 128, 0.5, 2, 10), (4, 628, 0.5, 2, 10),
                                                    (5, 216, 0.5, 1, 10), (4, 150, 0.25, 2, 10), (7, 1040, 0.5, 2, 10),
                                                    (4, 864, 0.5, 2, 10), (6, 96, 0.5, 2, 1), (5, 200, 0.5, 2, 16),

@@ -259,11 +259,11 @@ extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* b
     return SED_OK;
 }
 
-extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const float* x, const uint64_t* seed_dev,
-                                 void* ctx, size_t ctx_bytes, const float* d_strong, const float* d_weak, float* grads,
-                                 void* ws, size_t ws_bytes, int parts, void* stream) {
+static int crnn_backward_impl(const sed_dims* d, const float* params, const float* x, const uint64_t* seed_dev,
+                              void* ctx, size_t ctx_bytes, const float* d_strong, const float* d_weak, float* grads,
+                              void* ws, size_t ws_bytes, int parts, void* stream, const HeadsLoss* hl) {
     SED_TRY(sed_validate_dims(d));
-    SED_CHECK_ARG(params && x && ctx && d_strong && d_weak && grads && ws, "sed_crnn_backward: null argument");
+    SED_CHECK_ARG(params && x && ctx && (hl || (d_strong && d_weak)) && grads && ws, "sed_crnn_backward: null argument");
     SED_CHECK_ARG(parts >= 1 && parts <= 3, "sed_crnn_backward: parts must be 1, 2 or 3");
     const Geo g = make_geo(d);
     const ParamOff P = make_param_off(g, nullptr);
@@ -288,7 +288,7 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
                              CTXF(L.logits_s), CTXF(L.den_sv), d_strong, d_weak, WSF(W.d_out), WSF(W.heads_part),
                              grads + P.dense_w, grads + P.dense_b, grads + P.soft_w, grads + P.soft_b, g.B, g.T3, g.NC,
                              use_drop, g.p, seed_dev, (parts & 2) ? WSD(W.bwd_acc) : nullptr, 2 * SED_GLUACC_N + 2 * 64 * 10,
-                             (parts & 2) && sd.ok ? 1 : 0, st));
+                             (parts & 2) && sd.ok ? 1 : 0, hl, st));
     // ---- BiGRU ----------------------------------------------------------------------------------
     // The gradient w.r.t. each layer's input is produced INSIDE the recurrence kernel (two extra waves, one block of
     // steps behind), as two direction planes [2][B*T'][nin] that the consumer adds while loading: the layer below's
@@ -384,6 +384,25 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
                                  grads + P.bn_b[0], grads + P.glu_w[0], grads + P.glu_b[0], st));
     if (forked) SIDE_JOIN(st);
     return SED_OK;
+}
+
+extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const float* x, const uint64_t* seed_dev,
+                                 void* ctx, size_t ctx_bytes, const float* d_strong, const float* d_weak, float* grads,
+                                 void* ws, size_t ws_bytes, int parts, void* stream) {
+    return crnn_backward_impl(d, params, x, seed_dev, ctx, ctx_bytes, d_strong, d_weak, grads, ws, ws_bytes, parts, stream, nullptr);
+}
+
+extern "C" int sed_mt_loss_backward(const sed_dims* d, const float* params, const float* x, const uint64_t* seed_dev,
+                                    void* ctx, size_t ctx_bytes, const float* strong_ema, const float* weak_ema,
+                                    const float* target, int weak_lo, int weak_hi, int strong_lo, int strong_hi,
+                                    const sed_step_state* state_dev, float* losses, float* d_strong, float* d_weak,
+                                    float* grads, void* ws, size_t ws_bytes, int parts, void* stream) {
+    SED_CHECK_ARG(d && strong_ema && weak_ema && target && state_dev && losses, "sed_mt_loss_backward: null argument");
+    SED_CHECK_ARG(parts == 1 || parts == 3, "sed_mt_loss_backward: parts must include the heads (1 or 3)");
+    SED_CHECK_ARG(weak_lo >= 0 && weak_hi <= d->B && weak_lo <= weak_hi && strong_lo >= 0 && strong_hi <= d->B &&
+                      strong_lo <= strong_hi, "sed_mt_loss_backward: bad mask range");
+    HeadsLoss hl = {strong_ema, weak_ema, target, weak_lo, weak_hi, strong_lo, strong_hi, state_dev, losses, d_strong, d_weak};
+    return crnn_backward_impl(d, params, x, seed_dev, ctx, ctx_bytes, nullptr, nullptr, grads, ws, ws_bytes, parts, stream, &hl);
 }
 
 extern "C" int sed_kernel_replay(const char* name, const sed_dims* d, const float* params, const float* x,

@@ -143,15 +143,28 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_fwd(const float* __restric
     }
 }
 
+// ---- mean-teacher loss terms (main.py:93-145) -----------------------------------------------------
+__device__ __forceinline__ float bce_term(float p, float t) {
+    const float lp = fmaxf(logf(p), -100.0f), l1p = fmaxf(logf(1.0f - p), -100.0f);
+    return -(t * lp + (1.0f - t) * l1p);
+}
+__device__ __forceinline__ float bce_grad(float p, float t) { return (p - t) / fmaxf((1.0f - p) * p, 1e-12f); }
+
 // part row layout (matches the flat parameter order dense.weight, dense.bias, dense_softmax.weight,
 // dense_softmax.bias): [NC*128 dWd][NC dbd][NC*128 dWs][NC dbs]
+// With hl.strong_ema != null the kernel also IS the loss (sed_mt_loss_backward): the gradient of the mean-teacher loss
+// w.r.t. the student's posteriors needs no reduction over the batch (the BCE / MSE normalisers are known constants), so
+// each clip's workgroup forms it on the fly instead of reading it from a separate kernel's output - k_mt_loss was 12 us
+// on the critical path between the forward and the backward.  The six loss sums go the same way as there: per-clip
+// partials, the last workgroup (device-scope ticket) adds them up in clip order.
 __global__ __launch_bounds__(HD_THREADS) void k_heads_bwd(const float* __restrict__ h, const float* __restrict__ wd,
                                                     const float* __restrict__ ws, const float* __restrict__ strong,
                                                     const float* __restrict__ weak, const float* __restrict__ logits_s,
                                                     const float* __restrict__ den, const float* __restrict__ d_strong,
                                                     const float* __restrict__ d_weak, float* __restrict__ dh,
                                                     float* __restrict__ part, int T, int NC, int use_drop, float p_drop,
-                                                    const uint64_t* __restrict__ seed_ptr, double* __restrict__ zero, int n_zero) {
+                                                    const uint64_t* __restrict__ seed_ptr, double* __restrict__ zero, int n_zero,
+                                                    HeadsLoss hl) {
     extern __shared__ __attribute__((aligned(16))) float hsm[];
     // the fp64 accumulators of the conv-block backward that follows (saves a memset node on the critical path)
     for (int i = blockIdx.x * HD_THREADS + threadIdx.x; i < n_zero; i += gridDim.x * HD_THREADS) zero[i] = 0.0;
@@ -168,8 +181,40 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_bwd(const float* __restric
     const float ks = use_drop ? drop_scale8(p_drop) : 1.0f;
     const int NO = 2 * NC;
     heads_stage_w<HD_SB>(wd, ws, wsm, NC, tid);
+    const bool fused = hl.strong_ema != nullptr;
+    const int B = gridDim.x;
+    float lacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // weak_bce, strong_bce, mse_strong, mse_weak, weak_ema_bce, strong_ema_bce
+    const float cw = fused ? hl.state->cons_weight : 0.f;
+    const float inv_nS = 1.0f / (float)(B * T * NC), inv_nW = 1.0f / (float)(B * NC);
+    const float inv_sb = (hl.shi > hl.slo) ? 1.0f / (float)((hl.shi - hl.slo) * T * NC) : 0.f;
+    const float inv_wb = (hl.whi > hl.wlo) ? 1.0f / (float)((hl.whi - hl.wlo) * NC) : 0.f;
+    const bool in_s = fused && b >= hl.slo && b < hl.shi, in_w = fused && b >= hl.wlo && b < hl.whi;
+    float* tmaxs = dden + 16;                          // (aliases the mask words, which are first written inside the loop)
+    if (in_w && wv < NC) {                             // target_weak = target.max(-2) (main.py:95): wave c takes class c
+        float t = -3.0e38f;
+        for (int tt = lane; tt < T; tt += 64) t = fmaxf(t, hl.target[((size_t)b * T + tt) * NC + wv]);
+        t = wave_max(t);
+        if (lane == 0) tmaxs[wv] = t;
+    }
+    if (fused) __syncthreads();
     if (tid < NC) {
-        const float dw = d_weak[b * NC + tid], dn = den[b * NC + tid];
+        float dw;
+        if (fused) {
+            const float p = weak[b * NC + tid], pe = hl.weak_ema[b * NC + tid];
+            const float diff = p - pe;
+            lacc[3] = diff * diff;
+            dw = cw * 2.0f * diff * inv_nW;
+            if (in_w) {
+                const float t = tmaxs[tid];
+                lacc[0] = bce_term(p, t);
+                lacc[4] = bce_term(pe, t);
+                dw += bce_grad(p, t) * inv_wb;
+            }
+            if (hl.d_weak_out) hl.d_weak_out[b * NC + tid] = dw;
+        } else {
+            dw = d_weak[b * NC + tid];
+        }
+        const float dn = den[b * NC + tid];
         dnum[tid] = dw / dn;
         dden[tid] = -dw * weak[b * NC + tid] / dn;
     }
@@ -197,7 +242,24 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_bwd(const float* __restric
                     const float ds = (dnum[c] * sv + dden[c]) * pass;
                     sraw[c] = raw; dsof[c] = ds;
                     dot += raw * ds;
-                    const float dst = d_strong[(size_t)(b * T + t) * NC + c] + dnum[c] * sof;
+                    float gin;
+                    if (fused) {
+                        const size_t e = (size_t)(b * T + t) * NC + c;
+                        const float pe = hl.strong_ema[e];
+                        const float diff = sv - pe;
+                        lacc[2] += diff * diff;
+                        gin = cw * 2.0f * diff * inv_nS;
+                        if (in_s) {
+                            const float tg = hl.target[e];
+                            lacc[1] += bce_term(sv, tg);
+                            lacc[5] += bce_term(pe, tg);
+                            gin += bce_grad(sv, tg) * inv_sb;
+                        }
+                        if (hl.d_strong_out) hl.d_strong_out[e] = gin;
+                    } else {
+                        gin = d_strong[(size_t)(b * T + t) * NC + c];
+                    }
+                    const float dst = gin + dnum[c] * sof;
                     dl[tid * HD_SD + c] = dst * sv * (1.0f - sv);
                 }
                 for (int c = 0; c < NC; ++c) dl[tid * HD_SD + NC + c] = sraw[c] * (dsof[c] - dot);
@@ -251,14 +313,47 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_bwd(const float* __restric
     }
     if (tid < NC) pr[NC * HD_F + tid] = bacc;
     else if (tid < NO) pr[2 * NC * HD_F + NC + (tid - NC)] = bacc;
+    if (!fused) return;
+    // ---- the loss values: workgroup sums -> per-clip partials -> the last workgroup adds them in clip order ----
+    __syncthreads();
+    float* red = dl;                                    // [16 waves][8]
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float v = wave_sum(lacc[k]);
+        if (lane == 0) red[wv * 8 + k] = v;
+    }
+    __syncthreads();
+    float* lpart = hl.losses + 8;
+    unsigned int* ticket = (unsigned int*)(hl.losses + 8 + 8 * B);
+    __shared__ int is_last;
+    if (tid < 6) {
+        float s2 = 0.f;
+        for (int w2 = 0; w2 < HD_THREADS / 64; ++w2) s2 += red[w2 * 8 + tid];
+        lpart[8 * b + tid] = s2;
+        __threadfence();
+    }
+    __syncthreads();
+    if (tid == 0) is_last = (atomicAdd(ticket, 1u) == (unsigned int)(B - 1));
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    if (tid < 6) {
+        float s2 = 0.f;
+        for (int bb = 0; bb < B; ++bb) s2 += __builtin_nontemporal_load(&lpart[8 * bb + tid]);
+        red[tid] = s2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float wb = red[0] * inv_wb, sb = red[1] * inv_sb;
+        const float cs = cw * red[2] * inv_nS, cwk = cw * red[3] * inv_nW;
+        hl.losses[0] = wb + sb + cs + cwk;
+        hl.losses[1] = wb; hl.losses[2] = sb; hl.losses[3] = cs; hl.losses[4] = cwk;
+        hl.losses[5] = red[4] * inv_wb; hl.losses[6] = red[5] * inv_sb; hl.losses[7] = cw;
+        *ticket = 0u;
+    }
 }
 
-// ---- mean-teacher loss (main.py:93-145) -----------------------------------------------------------
-__device__ __forceinline__ float bce_term(float p, float t) {
-    const float lp = fmaxf(logf(p), -100.0f), l1p = fmaxf(logf(1.0f - p), -100.0f);
-    return -(t * lp + (1.0f - t) * l1p);
-}
-__device__ __forceinline__ float bce_grad(float p, float t) { return (p - t) / fmaxf((1.0f - p) * p, 1e-12f); }
+// ---- mean-teacher loss as a kernel of its own (sed_mt_loss) --------------------------------------------
 
 #define LOSS_THREADS 1024
 // One workgroup per clip (the single-workgroup version walked 19 elements per thread, one exposed memory round
@@ -378,8 +473,11 @@ int launch_heads_colsum(const float* part, float* g_wd, int B, int NC, hipStream
 int launch_heads_bwd(const float* h, const float* wd, const float* ws, const float* strong, const float* weak,
                      const float* logits_s, const float* den, const float* d_strong, const float* d_weak, float* dh,
                      float* part, float* g_wd, float* g_bd, float* g_ws, float* g_bs, int B, int T, int NC, int use_drop,
-                     float p_drop, const uint64_t* seed, double* zero, int n_zero, int defer_colsum, hipStream_t st) {
+                     float p_drop, const uint64_t* seed, double* zero, int n_zero, int defer_colsum, const HeadsLoss* hl,
+                     hipStream_t st) {
     (void)g_bd; (void)g_ws; (void)g_bs;
+    HeadsLoss hl0 = {};
+    if (hl) hl0 = *hl;
     const size_t lds = (size_t)(HD_TC * HD_SB + HD_MAXO * HD_SB + HD_TC * HD_SD + 32 + HD_THREADS) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
@@ -387,7 +485,7 @@ int launch_heads_bwd(const float* h, const float* wd, const float* ws, const flo
         attr_done = true;
     }
     k_heads_bwd<<<B, HD_THREADS, lds, st>>>(h, wd, ws, strong, weak, logits_s, den, d_strong, d_weak, dh, part, T, NC, use_drop,
-                                            p_drop, seed, zero, zero ? n_zero : 0);
+                                            p_drop, seed, zero, zero ? n_zero : 0, hl0);
     SED_CHECK_LAUNCH();
     if (defer_colsum) return SED_OK;
     return launch_heads_colsum(part, g_wd, B, NC, st);

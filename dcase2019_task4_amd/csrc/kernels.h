@@ -86,7 +86,14 @@ int launch_heads_fwd(const float* h /*[B][T][128]*/, const float* wd, const floa
                      float* strong, float* weak, float* strong_sv, float* weak_sv, float* logits_s, float* den, int B, int T,
                      int NC, int use_drop, float p_drop, const uint64_t* seed, hipStream_t st);
 int launch_heads_colsum(const float* part, float* g_wd, int B, int NC, hipStream_t st);
+// loss inputs of the fused loss + heads backward (sed_mt_loss_backward); strong_ema == null: gradients come from the caller
+struct HeadsLoss {
+    const float* strong_ema; const float* weak_ema; const float* target;
+    int wlo, whi, slo, shi;
+    const sed_step_state* state;
+    float* losses; float* d_strong_out; float* d_weak_out;
+};
 int launch_heads_bwd(const float* h, const float* wd, const float* ws, const float* strong, const float* weak,
                      const float* logits_s, const float* den, const float* d_strong, const float* d_weak, float* dh,
                      float* part, float* g_wd, float* g_bd, float* g_ws, float* g_bs, int B, int T, int NC, int use_drop,
-                     float p_drop, const uint64_t* seed, double* zero, int n_zero, int defer_colsum, hipStream_t st);
+                     float p_drop, const uint64_t* seed, double* zero, int n_zero, int defer_colsum, const HeadsLoss* hl, hipStream_t st);

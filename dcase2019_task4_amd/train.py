@@ -156,15 +156,18 @@ class MeanTeacherStep:
         else:
             self._forward(self.teacher, self.x_ema, self.ctx_t, self._seed_t, self.strong_ema, self.weak_ema)
             self._forward(self.student, self.x, self.ctx_s, self._seed_s, self.strong, self.weak)
-        _lib.check(self.l.sed_mt_loss(C.byref(self.dims), _lib.ptr(self.strong), _lib.ptr(self.weak),
-                                      _lib.ptr(self.strong_ema), _lib.ptr(self.weak_ema), _lib.ptr(self.target),
-                                      self.wlo, self.whi, self.slo, self.shi, _lib.ptr(self.state),
-                                      _lib.ptr(self.losses), _lib.ptr(self.d_strong), _lib.ptr(self.d_weak),
-                                      _lib.stream_ptr()), "sed_mt_loss")
-        # one process: the whole backward in ONE call (parts = 3), which lets the library overlap the GRU weight
-        # gradients with the conv-block backward; data-parallel: part 1 here, part 2 after its bucket's all-reduce
-        # has been started (run())
-        self._backward(1 if (self.dp and self.dp_split) else 3)
+        # losses (main.py:93-145) + backward in one call: the heads-backward kernel forms the loss gradient per clip itself
+        # (sed_mt_loss as a kernel of its own was 12 us on the critical path).  One process: the whole backward
+        # (parts = 3), which lets the library overlap the GRU weight gradients with the conv-block backward;
+        # data-parallel "split": part 1 here, part 2 after its bucket's all-reduce has been started (run())
+        parts = 1 if (self.dp and self.dp_split) else 3
+        _lib.check(self.l.sed_mt_loss_backward(C.byref(self.dims), _lib.ptr(self.student._flat), _lib.ptr(self.x),
+                                               self._seed_s, _lib.ptr(self.ctx_s), self.ctx_bytes,
+                                               _lib.ptr(self.strong_ema), _lib.ptr(self.weak_ema), _lib.ptr(self.target),
+                                               self.wlo, self.whi, self.slo, self.shi, _lib.ptr(self.state),
+                                               _lib.ptr(self.losses), None, None, _lib.ptr(self.grads),
+                                               _lib.ptr(self.ws), self.ws_bytes, parts, _lib.stream_ptr()),
+                   "sed_mt_loss_backward")
 
     def _backward(self, parts):
         _lib.check(self.l.sed_crnn_backward(C.byref(self.dims), _lib.ptr(self.student._flat), _lib.ptr(self.x),

@@ -137,6 +137,17 @@ int sed_mt_loss(const sed_dims* d, const float* strong, const float* weak, const
                 int strong_hi, const sed_step_state* state_dev, float* losses, float* d_strong,
                 float* d_weak, void* stream);
 
+/* sed_mt_loss + sed_crnn_backward in one call (what MeanTeacherStep uses): the loss gradient w.r.t. the student's
+ * posteriors needs no reduction over the batch, so the heads-backward kernel forms it per clip on the fly and the
+ * separate loss kernel (12 us on the critical path between forward and backward) disappears.  The student's
+ * posteriors are the ones sed_crnn_forward(train=1) left in ctx; `losses` as for sed_mt_loss (same meters; summed in
+ * a different order, so equal to rounding); d_strong / d_weak: optional outputs (may be NULL); parts: 1 or 3. */
+int sed_mt_loss_backward(const sed_dims* d, const float* params, const float* x, const uint64_t* seed_dev,
+                         void* ctx, size_t ctx_bytes, const float* strong_ema, const float* weak_ema,
+                         const float* target, int weak_lo, int weak_hi, int strong_lo, int strong_hi,
+                         const sed_step_state* state_dev, float* losses, float* d_strong, float* d_weak,
+                         float* grads, void* ws, size_t ws_bytes, int parts, void* stream);
+
 /* ---- optimiser + EMA -----------------------------------------------------------------------
  * Replaces optimizer.step() of torch.optim.Adam(lr, betas) (main.py:154,289-290) fused with
  * update_ema_variables (main.py:45-49,156-157) over the flat buffers. grad_scale multiplies

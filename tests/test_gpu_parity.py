@@ -236,6 +236,44 @@ def test_mt_loss_kernel_vs_oracle():
     np.testing.assert_allclose(st.d_weak.cpu().numpy(), dw.numpy(), rtol=1e-4, atol=1e-9)
 
 
+def test_fused_loss_backward_matches_loss_kernel_then_backward():
+    """sed_mt_loss_backward (the loss gradient formed inside the heads-backward kernel) against sed_mt_loss followed by
+    sed_crnn_backward on the same forward: identical gradients w.r.t. the posteriors, the same meters to rounding, bitwise
+    identical parameter gradients."""
+    from dcase2019_task4_amd import _lib
+    from dcase2019_task4_amd.train import MeanTeacherStep
+    B, T = 8, 216
+    student, _ = gu.make_model(0, dropout=0.5)
+    teacher, _ = gu.make_model(1, dropout=0.5)
+    student.train(); teacher.train()
+    tgt, wm, sm = synth.make_target(3, B, T // 8)
+    st = MeanTeacherStep(student, teacher, B, T, 150, wm, sm, seed=99, use_graph=False)
+    st.load_batch(synth.make_input(60, B, T).cuda(), synth.make_input(70, B, T).cuda(), tgt.cuda())
+    st._forward(st.teacher, st.x_ema, st.ctx_t, st._seed_t, st.strong_ema, st.weak_ema)
+    st._forward(st.student, st.x, st.ctx_s, st._seed_s, st.strong, st.weak)
+    # (a) separate kernels
+    _lib.check(st.l.sed_mt_loss(C.byref(st.dims), _lib.ptr(st.strong), _lib.ptr(st.weak), _lib.ptr(st.strong_ema),
+                                _lib.ptr(st.weak_ema), _lib.ptr(st.target), st.wlo, st.whi, st.slo, st.shi,
+                                _lib.ptr(st.state), _lib.ptr(st.losses), _lib.ptr(st.d_strong), _lib.ptr(st.d_weak),
+                                _lib.stream_ptr()), "sed_mt_loss")
+    st._backward(3)
+    torch.cuda.synchronize()
+    ds_a, dw_a, g_a, m_a = st.d_strong.clone(), st.d_weak.clone(), st.grads.clone(), dict(st.meters())
+    # (b) fused
+    st.grads.zero_(); st.d_strong.zero_(); st.d_weak.zero_()
+    _lib.check(st.l.sed_mt_loss_backward(C.byref(st.dims), _lib.ptr(st.student._flat), _lib.ptr(st.x), st._seed_s,
+                                         _lib.ptr(st.ctx_s), st.ctx_bytes, _lib.ptr(st.strong_ema), _lib.ptr(st.weak_ema),
+                                         _lib.ptr(st.target), st.wlo, st.whi, st.slo, st.shi, _lib.ptr(st.state),
+                                         _lib.ptr(st.losses), _lib.ptr(st.d_strong), _lib.ptr(st.d_weak), _lib.ptr(st.grads),
+                                         _lib.ptr(st.ws), st.ws_bytes, 3, _lib.stream_ptr()), "sed_mt_loss_backward")
+    torch.cuda.synchronize()
+    assert torch.equal(st.d_strong, ds_a) and torch.equal(st.d_weak, dw_a)
+    assert torch.equal(st.grads, g_a)
+    m_b = st.meters()
+    for k, v in m_a.items():
+        assert m_b[k] == pytest.approx(v, rel=2e-6, abs=1e-9), k
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_three_fused_steps_vs_real_main_train_goldens(golden_dir, use_graph):
     """G5: three steps of the REAL baseline/main.py train() (B=8, dropout 0): meters, student and

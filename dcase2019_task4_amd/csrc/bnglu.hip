@@ -187,32 +187,7 @@ __global__ __launch_bounds__(256, 2) void k_glu_pool_fwd(const float* __restrict
 
 #define GLUACC_N SED_GLUACC_N     // layout: common.h
 
-struct BnBwdPrepArgs {
-    const double* acc; double N;
-    const float *gamma, *bn;
-    float *coef, *g_gamma, *g_beta, *g_wglu, *g_bglu, *g_convb;
-};
-// BatchNorm backward reduction -> per-channel affine dy = ca*dz + cb*y + cc for the conv dgrad / wgrad loaders, and the
-// parameter gradients of the block (k_bn_bwd_prep, launched right behind k_glu_pool_bwd).
-__device__ __forceinline__ double acc_load(const double* p) { return *p; }
-__device__ __forceinline__ void bn_bwd_prep_body(const BnBwdPrepArgs& a, int tid) {
-    if (tid < 64) {
-        const int c = tid;
-        const double mean = a.bn[c], invstd = a.bn[64 + c], scale = a.bn[128 + c];
-        const double Sdz = acc_load(&a.acc[4160 + c]), Sdzy = acc_load(&a.acc[4224 + c]);
-        const double Sdzxhat = invstd * (Sdzy - mean * Sdz);
-        a.g_beta[c] = (float)Sdz;
-        a.g_gamma[c] = (float)Sdzxhat;
-        const double m1 = Sdz / a.N, m2 = Sdzxhat / a.N;
-        // dy = scale * (dz - m1 - xhat*m2),  xhat = (y - mean) * invstd
-        a.coef[c] = (float)scale;
-        a.coef[64 + c] = (float)(-scale * m2 * invstd);
-        a.coef[128 + c] = (float)(scale * (m2 * invstd * mean - m1));
-        a.g_bglu[c] = (float)acc_load(&a.acc[4096 + c]);
-        a.g_convb[c] = 0.f;   // sum_p dy == 0: a conv bias in front of a train-mode BatchNorm has zero gradient
-    }
-    for (int e = tid; e < 4096; e += 256) a.g_wglu[e] = (float)acc_load(&a.acc[e]);
-}
+// (BnBwdPrepArgs, bn_bwd_coef, bn_bwd_prep_body: kernels.h - shared with the conv kernels that consume the result)
 
 __global__ __launch_bounds__(256) void k_glu_pool_bwd(const float* __restrict__ y, const float* __restrict__ bn,
                                                        const float* __restrict__ wglu, const float* __restrict__ bglu,
@@ -713,7 +688,7 @@ __global__ __launch_bounds__(512, 1) void k_glu_pool_bwd8(const float* __restric
 // workgroup read the Sdz / Sdzy accumulators before every other workgroup's fp64 atomics had been performed
 // (tools/determinism.py: bn1 / conv1 / block-0 gradients off by up to 7e-3); ordering those atomics device-wide needs
 // __threadfence(), whose L2 write-back of the 31 MB of dz just produced costs more (17 us) than this launch (5 us).
-__global__ __launch_bounds__(256) void k_bn_bwd_prep(BnBwdPrepArgs a) { bn_bwd_prep_body(a, threadIdx.x); }
+__global__ __launch_bounds__(256) void k_bn_bwd_prep(BnBwdPrepArgs a) { bn_bwd_prep_body(a, threadIdx.x, 256); }
 
 // ---- host launchers -------------------------------------------------------------------------------
 int launch_glu_pool_fwd(const float* y, const double* stat, double N, const float* gamma, const float* beta, float* run_mean,
@@ -735,7 +710,7 @@ int launch_glu_pool_fwd(const float* y, const double* stat, double N, const floa
 int launch_glu_pool_bwd(const float* y, const float* bn, const float* wglu, const float* bglu, const float* dp,
                         const float* dp_b, float* dz, double* acc, int zero_acc, int B, int H, int W, int block_id, int use_drop, float p_drop,
                         const uint16_t* mask_in, const float* gamma, float* coef, float* g_gamma, float* g_beta, float* g_wglu,
-                        float* g_bglu, float* g_convb, hipStream_t st) {
+                        float* g_bglu, float* g_convb, BnBwdPrepArgs* prep_out, hipStream_t st) {
     const int Ho = H / 2, Wo = W / 4, Q = B * Ho * Wo;
     const size_t lds = (size_t)(4 * 3 * 32 * ZS + 64 * ZS) * sizeof(float);
     static bool attr_done = false;
@@ -761,6 +736,10 @@ int launch_glu_pool_bwd(const float* y, const float* bn, const float* wglu, cons
         k_glu_pool_bwd8<<<grid, 512, lds, st>>>(y, bn, wglu, bglu, dp, dp_b, dz, acc, H, W, Ho, Wo, Q, use_drop, p_drop, mask_in);
     }
     SED_CHECK_LAUNCH();
+    if (prep_out) {             // the conv dgrad / wgrad kernels derive the coefficients themselves
+        *prep_out = a;
+        return SED_OK;
+    }
     k_bn_bwd_prep<<<1, 256, 0, st>>>(a);
     SED_CHECK_LAUNCH();
     return SED_OK;

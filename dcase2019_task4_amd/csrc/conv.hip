@@ -427,14 +427,24 @@ template <int TW, int MODE>
 __global__ __launch_bounds__(512, 1) void k_conv_wino(const float* __restrict__ in0, const float* __restrict__ in1,
                                                         const float* __restrict__ coef, const float* __restrict__ U,
                                                         const float* __restrict__ bias, float* __restrict__ out,
-                                                        double* __restrict__ stat, int H, int tiles_per_clip, int n_tiles) {
+                                                        double* __restrict__ stat, int H, int tiles_per_clip, int n_tiles,
+                                                        BnBwdPrepArgs prep) {
     using C = Wino<TW>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xch = smem + 2 * C::HALO_FLOATS;
     float* dump = xch + C::XCH_FLOATS + 192;
     float* cfs = xch + C::XCH_FLOATS;                   // dgrad: the three BatchNorm-backward coefficient rows
     if (MODE == 1) {
-        if (threadIdx.x < 192) cfs[threadIdx.x] = coef[threadIdx.x];
+        if (prep.acc != nullptr) {     // BatchNorm-backward coefficients straight from the reduction sums (no k_bn_bwd_prep)
+            if (threadIdx.x < 64) {
+                float ca, cb, cc;
+                bn_bwd_coef(prep, threadIdx.x, ca, cb, cc);
+                cfs[threadIdx.x] = ca; cfs[64 + threadIdx.x] = cb; cfs[128 + threadIdx.x] = cc;
+            }
+            if (blockIdx.x == 0) bn_bwd_prep_body(prep, threadIdx.x, 512);      // the block's parameter gradients (+ coef)
+        } else if (threadIdx.x < 192) {
+            cfs[threadIdx.x] = coef[threadIdx.x];
+        }
         __syncthreads();
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -675,7 +685,9 @@ static int conv16_ws_launch(const float* in0, const float* in1, const float* coe
 // against 91 / 90 us for the direct 8-wave kernel; bit 6 of the debug knob selects the direct kernels.
 template <int TW, int MODE>
 static int conv_wino_launch(const float* in0, const float* in1, const float* coef, const float* wpk, const float* bias,
-                            float* out, double* stat, int B, int H, hipStream_t st) {
+                            float* out, double* stat, int B, int H, const BnBwdPrepArgs* prep, hipStream_t st) {
+    BnBwdPrepArgs pa = {};
+    if (prep) pa = *prep;
     using C = Wino<TW>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -686,7 +698,7 @@ static int conv_wino_launch(const float* in0, const float* in1, const float* coe
     SED_CHECK_ARG((size_t)B * H * TW * 64 < ((size_t)1 << 31), "conv: image too large for 32-bit offsets");
     const int tpc = (H + C::TH - 1) / C::TH, nt = B * tpc;
     const int grid = nt < 256 ? nt : 256;          // one persistent workgroup per CU
-    k_conv_wino<TW, MODE><<<grid, 512, C::LDS_BYTES, st>>>(in0, in1, coef, wpk + SED_WINO_OFF, bias, out, stat, H, tpc, nt);
+    k_conv_wino<TW, MODE><<<grid, 512, C::LDS_BYTES, st>>>(in0, in1, coef, wpk + SED_WINO_OFF, bias, out, stat, H, tpc, nt, pa);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
@@ -708,10 +720,20 @@ template <int TW, int TS>
 __global__ __launch_bounds__(256) void k_conv3x3_wgrad(const float* __restrict__ dz, const float* __restrict__ yin,
                                                         const float* __restrict__ coef, const float* __restrict__ xin,
                                                         float* __restrict__ part, int B, int H, int tiles_per_clip,
-                                                        int n_tiles) {
+                                                        int n_tiles, BnBwdPrepArgs prep) {
     using Cfg = WgCfg<TW>;
     constexpr int TH = Cfg::TH, HW = Cfg::HW, HH = Cfg::HH;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ __attribute__((aligned(16))) float cfl[192];       // BatchNorm-backward coefficients (from `coef` or derived here)
+    if (prep.acc != nullptr) {
+        if (threadIdx.x < 64) {
+            float ca, cb, cc;
+            bn_bwd_coef(prep, threadIdx.x, ca, cb, cc);
+            cfl[threadIdx.x] = ca; cfl[64 + threadIdx.x] = cb; cfl[128 + threadIdx.x] = cc;
+        }
+    } else if (threadIdx.x < 192) {
+        cfl[threadIdx.x] = coef[threadIdx.x];
+    }
     float* xh = smem;
     float* dyt = smem + Cfg::XH_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -749,9 +771,9 @@ __global__ __launch_bounds__(256) void k_conv3x3_wgrad(const float* __restrict__
                 const size_t g = (((size_t)b * H + yy) * W + xx) * 64 + c4;
                 const float4 d = *(const float4*)(dz + g);
                 const float4 yv = *(const float4*)(yin + g);
-                const float4 ca = *(const float4*)(coef + c4);
-                const float4 cb = *(const float4*)(coef + 64 + c4);
-                const float4 cc = *(const float4*)(coef + 128 + c4);
+                const float4 ca = *(const float4*)(cfl + c4);
+                const float4 cb = *(const float4*)(cfl + 64 + c4);
+                const float4 cc = *(const float4*)(cfl + 128 + c4);
                 v.x = ca.x * d.x + cb.x * yv.x + cc.x;
                 v.y = ca.y * d.y + cb.y * yv.y + cc.y;
                 v.z = ca.z * d.z + cb.z * yv.z + cc.z;
@@ -951,14 +973,17 @@ struct WgW {
 };
 __global__ __launch_bounds__(512, 1) void k_wgrad16_wino(const float* __restrict__ dz, const float* __restrict__ yin,
                                                          const float* __restrict__ coef, const float* __restrict__ xin,
-                                                         float* __restrict__ part, int H, int tiles_per_clip, int n_tiles) {
+                                                         float* __restrict__ part, int H, int tiles_per_clip, int n_tiles,
+                                                         BnBwdPrepArgs prep) {
     using C = WgW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* ops = smem + 2 * C::HALO_FLOATS;          // [2 buffers][Vs: 4 blocks x SV | Ms: 4 blocks x SM]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cg = wave & 3, ph = wave >> 2;
     const int i16 = lane & 15, kq = lane >> 4;
-    const float ca = coef[lane], cb = coef[64 + lane], cc = coef[128 + lane];      // transform role: lane = channel
+    float ca, cb, cc;                                                              // transform role: lane = channel
+    if (prep.acc != nullptr) bn_bwd_coef(prep, lane, ca, cb, cc);                  // (no k_bn_bwd_prep: see BnBwdPrepArgs)
+    else { ca = coef[lane]; cb = coef[64 + lane]; cc = coef[128 + lane]; }
     // halo staging by image rows: thread -> (column hx = tid >> 4, channels 4 (tid & 15) ..), one float4 per halo row and
     // thread, so everything but the row is a per-lane constant (a flat "item = tid + 512 i" split cost ~25 VALU per item
     // in div / mod / bounds arithmetic - 0.35 us per k-step that carried one).  Threads 288..511 duplicate columns 2..15
@@ -1238,22 +1263,23 @@ int launch_conv_fwd(const float* in, const float* wpk, const float* bias, float*
                     int H, int W, hipStream_t st) {
     if (stat && zero_stat) SED_CHECK_HIP(hipMemsetAsync(stat, 0, 128 * sizeof(double), st));
     const bool direct = (g_sed_debug & (2 | 64)) != 0;          // A/B timing only: the 9-tap kernels
-    if (W == 16) return !direct ? conv_wino_launch<16, 0>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st)
+    if (W == 16) return !direct ? conv_wino_launch<16, 0>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, nullptr, st)
                : (g_sed_debug & 2) ? conv_launch_t<16, 0, 1>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st)
                                    : conv16_ws_launch<0>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st);
-    if (W == 4) return !direct ? conv_wino_launch<4, 0>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st)
+    if (W == 4) return !direct ? conv_wino_launch<4, 0>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, nullptr, st)
                                : conv_launch_t<4, 0, 2>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st);
     sed_set_error("conv: unsupported width %d", W);
     return SED_ERR_UNSUPPORTED;
 }
 
 int launch_conv_dgrad(const float* dz, const float* yin, const float* coef, const float* wpkT, float* dx, int B, int H,
-                      int W, hipStream_t st) {
+                      int W, const BnBwdPrepArgs* prep, hipStream_t st) {
     const bool direct = (g_sed_debug & (4 | 64)) != 0;          // A/B timing only: the 9-tap kernels
-    if (W == 16) return !direct ? conv_wino_launch<16, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st)
+    SED_CHECK_ARG(!(direct && prep), "conv dgrad: in-kernel BatchNorm-backward coefficients need the Winograd kernel");
+    if (W == 16) return !direct ? conv_wino_launch<16, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, prep, st)
                : (g_sed_debug & 4) ? conv_launch_t<16, 1, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st)
                                    : conv16_ws_launch<1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st);
-    if (W == 4) return !direct ? conv_wino_launch<4, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st)
+    if (W == 4) return !direct ? conv_wino_launch<4, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, prep, st)
                                : conv_launch_t<4, 1, 2>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st);
     sed_set_error("conv dgrad: unsupported width %d", W);
     return SED_ERR_UNSUPPORTED;
@@ -1261,7 +1287,9 @@ int launch_conv_dgrad(const float* dz, const float* yin, const float* coef, cons
 
 template <int TW, int TS>
 static int wgrad_launch_t(const float* dz, const float* yin, const float* coef, const float* xin, float* part,
-                          int n_blocks, float* g_w, int B, int H, hipStream_t st) {
+                          int n_blocks, float* g_w, int B, int H, const BnBwdPrepArgs* prep, hipStream_t st) {
+    BnBwdPrepArgs pa = {};
+    if (prep) pa = *prep;
     using Cfg = WgCfg<TW>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -1282,7 +1310,7 @@ static int wgrad_launch_t(const float* dz, const float* yin, const float* coef, 
             attrw = true;
         }
         SED_CHECK_ARG((size_t)B * H * TW * 64 < ((size_t)1 << 31), "wgrad: image too large for 32-bit offsets");
-        k_wgrad16_wino<<<nb, 512, WgW::LDS_BYTES, st>>>(dz, yin, coef, xin, part, H, tpc, nt);
+        k_wgrad16_wino<<<nb, 512, WgW::LDS_BYTES, st>>>(dz, yin, coef, xin, part, H, tpc, nt, pa);
     } else if (TW == 16 && TS == 1 && !(g_sed_debug & 8)) {
         static bool attr16 = false;
         if (!attr16) {
@@ -1291,7 +1319,7 @@ static int wgrad_launch_t(const float* dz, const float* yin, const float* coef, 
         }
         k_wgrad16_db<<<nb, 256, Wg16::LDS_BYTES, st>>>(dz, yin, coef, xin, part, H, tpc, nt);
     } else {
-        k_conv3x3_wgrad<TW, TS><<<dim3(nb, TS), 256, Cfg::LDS_BYTES, st>>>(dz, yin, coef, xin, part, B, H, tpc, nt);
+        k_conv3x3_wgrad<TW, TS><<<dim3(nb, TS), 256, Cfg::LDS_BYTES, st>>>(dz, yin, coef, xin, part, B, H, tpc, nt, pa);
     }
     SED_CHECK_LAUNCH();
     k_wgrad_reduce<<<9 * 4096 / 64, 256, 0, st>>>(part, nb, g_w);
@@ -1300,9 +1328,10 @@ static int wgrad_launch_t(const float* dz, const float* yin, const float* coef, 
 }
 
 int launch_conv_wgrad(const float* dz, const float* yin, const float* coef, const float* xin, float* part, int n_blocks,
-                      float* g_w, int B, int H, int W, hipStream_t st) {
-    if (W == 16) return wgrad_launch_t<16, 1>(dz, yin, coef, xin, part, n_blocks, g_w, B, H, st);
-    if (W == 4) return wgrad_launch_t<4, 3>(dz, yin, coef, xin, part, n_blocks, g_w, B, H, st);
+                      float* g_w, int B, int H, int W, const BnBwdPrepArgs* prep, hipStream_t st) {
+    SED_CHECK_ARG(!(prep && W == 16 && (g_sed_debug & (8 | 128))), "conv wgrad: in-kernel BatchNorm-backward coefficients need the default kernels");
+    if (W == 16) return wgrad_launch_t<16, 1>(dz, yin, coef, xin, part, n_blocks, g_w, B, H, prep, st);
+    if (W == 4) return wgrad_launch_t<4, 3>(dz, yin, coef, xin, part, n_blocks, g_w, B, H, prep, st);
     sed_set_error("conv wgrad: unsupported width %d", W);
     return SED_ERR_UNSUPPORTED;
 }

@@ -351,27 +351,33 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
     // slower, 28.0 vs 28.3 k clips/s.)
     // (Starting wgrad1 only after dgrad1, next to the VALU-bound k_blk0_bwd, measured the same: dgrad1 drops from
     // 175 to 93 us but k_blk0_bwd, left with one wave per SIMD beside the wgrad wave, goes from 86 to 177 us.)
+    // BatchNorm-backward coefficients: derived by the conv dgrad / wgrad kernels themselves from the reduction sums (no
+    // 1-workgroup k_bn_bwd_prep + launch gap between k_glu_pool_bwd and the dgrad, twice per step); bit 9 of the debug
+    // knob, or any of the A/B conv kernels, brings the separate kernel back
+    const bool fuse_prep = (g_sed_debug & (4 | 8 | 64 | 128 | 512)) == 0;
+    BnBwdPrepArgs prep[3] = {};
     for (int i = 2; i >= 1; --i) {
+        const BnBwdPrepArgs* pp = fuse_prep ? &prep[i] : nullptr;
         // (the BatchNorm-backward coefficients and the block's parameter gradients are produced by the last workgroup
         // of k_glu_pool_bwd: no separate 1-workgroup kernel between it and the conv dgrad / wgrad)
         SED_TRY(launch_glu_pool_bwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], WSF(dpo[i]),
                                     i == 2 ? WSF(dpo[i]) + (size_t)BT * 64 : nullptr,
                                     WSF(dzo[i]), WSD(gacc[i]), 0, g.B, Hs[i], Wd[i], i, use_drop, g.p, CTXM(mo[i]),
                                     params + P.bn_g[i], WSF(W.coef[i]), grads + P.bn_g[i], grads + P.bn_b[i],
-                                    grads + P.glu_w[i], grads + P.glu_b[i], grads + P.conv_b[i], st));
+                                    grads + P.glu_w[i], grads + P.glu_b[i], grads + P.conv_b[i], fuse_prep ? &prep[i] : nullptr, st));
         if (i == 2) {
             if (sd.ok) { SIDE_FORK(st); forked = true; }
             SED_TRY(launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(pin[i]), WSF(W.wg_part), W.wgrad_blocks,
-                                      grads + P.conv_w[i], g.B, Hs[i], Wd[i], ss));
+                                      grads + P.conv_w[i], g.B, Hs[i], Wd[i], pp, ss));
             if (parts == 3) {
                 SED_TRY(gru_weight_grads(ss));
             }
-            SED_TRY(launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], st));
+            SED_TRY(launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], pp, st));
         } else {
             if (sd.ok) { SIDE_FORK(st); forked = true; }
-            SED_TRY(launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], st));
+            SED_TRY(launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], pp, st));
             SED_TRY(launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(pin[i]), WSF(W.wg_part), W.wgrad_blocks,
-                                      grads + P.conv_w[i], g.B, Hs[i], Wd[i], ss));
+                                      grads + P.conv_w[i], g.B, Hs[i], Wd[i], pp, ss));
             // the head weight-gradient column sum (deferred from part 1) last: queued in front of wgrad1 it sat 60 us behind
             // the persistent dgrad kernel and held wgrad1 back
             if (parts == 3 && sd.ok) SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, ss));
@@ -447,11 +453,11 @@ extern "C" int sed_kernel_replay(const char* name, const sed_dims* d, const floa
                                                g.p, seed_dev, use_drop ? CTXM(mo[i]) : nullptr, st);
         snprintf(nm, sizeof nm, "glu%d_bwd", i);
         if (is(nm)) return launch_glu_pool_bwd(CTXF(yo[i]), CTXF(bo[i]), params + P.glu_w[i], params + P.glu_b[i], WSF(dpo[i]), i == 2 ? WSF(dpo[i]) + (size_t)BT * 64 : nullptr, WSF(dzo[i]), WSD(gacc[i]), 1, g.B, Hs[i], Wd[i], i, use_drop, g.p, CTXM(mo[i]),
-                                               params + P.bn_g[i], WSF(W.coef[i]), grads + P.bn_g[i], grads + P.bn_b[i], grads + P.glu_w[i], grads + P.glu_b[i], grads + P.conv_b[i], st);
+                                               params + P.bn_g[i], WSF(W.coef[i]), grads + P.bn_g[i], grads + P.bn_b[i], grads + P.glu_w[i], grads + P.glu_b[i], grads + P.conv_b[i], nullptr, st);
         snprintf(nm, sizeof nm, "conv%d_wgrad", i);
-        if (is(nm)) return launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(po[i - 1]), WSF(W.wg_part), W.wgrad_blocks, grads + P.conv_w[i], g.B, Hs[i], Wd[i], st);
+        if (is(nm)) return launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(po[i - 1]), WSF(W.wg_part), W.wgrad_blocks, grads + P.conv_w[i], g.B, Hs[i], Wd[i], nullptr, st);
         snprintf(nm, sizeof nm, "conv%d_dgrad", i);
-        if (is(nm)) return launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], st);
+        if (is(nm)) return launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], nullptr, st);
     }
     for (int l = 0; l < g.L; ++l) {
         char nm[32];

@@ -23,12 +23,51 @@ int launch_conv_pack(const float* w1, const float* w2, float* wpk1, float* wpk2,
 // forward: y = conv(in) + bias; optional per-channel sum / sum-of-squares (fp64 atomics into stat[128])
 int launch_conv_fwd(const float* in, const float* wpk, const float* bias, float* y, double* stat, int zero_stat, int B,
                     int H, int W, hipStream_t st);
+// BatchNorm-backward reduction results of one conv block (filled by launch_glu_pool_bwd) -> per-channel affine
+// dy = ca*dz + cb*y + cc for the conv dgrad / wgrad loaders, and the block's parameter gradients.  Either a 1-workgroup
+// kernel of its own turns them into `coef` (k_bn_bwd_prep: 5 us + a launch gap on the critical chain, twice per step),
+// or - default - the consumers do it themselves in their prologue: they get this struct (`prep`, acc != null), every
+// workgroup derives the 192 coefficients from the fp64 sums (a few double operations per channel), and workgroup 0 of
+// the dgrad kernel also writes the parameter gradients and `coef`.
+struct BnBwdPrepArgs {
+    const double* acc; double N;
+    const float *gamma, *bn;
+    float *coef, *g_gamma, *g_beta, *g_wglu, *g_bglu, *g_convb;
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ void bn_bwd_coef(const BnBwdPrepArgs& a, int c, float& ca, float& cb, float& cc) {
+    const double mean = a.bn[c], invstd = a.bn[64 + c], scale = a.bn[128 + c];
+    const double Sdz = a.acc[4160 + c], Sdzy = a.acc[4224 + c];
+    const double Sdzxhat = invstd * (Sdzy - mean * Sdz);
+    const double m1 = Sdz / a.N, m2 = Sdzxhat / a.N;
+    // dy = scale * (dz - m1 - xhat*m2),  xhat = (y - mean) * invstd
+    ca = (float)scale;
+    cb = (float)(-scale * m2 * invstd);
+    cc = (float)(scale * (m2 * invstd * mean - m1));
+}
+__device__ __forceinline__ void bn_bwd_prep_body(const BnBwdPrepArgs& a, int tid, int nthreads) {
+    if (tid < 64) {
+        const int c = tid;
+        const double mean = a.bn[c], invstd = a.bn[64 + c];
+        const double Sdz = a.acc[4160 + c], Sdzy = a.acc[4224 + c];
+        a.g_beta[c] = (float)Sdz;
+        a.g_gamma[c] = (float)(invstd * (Sdzy - mean * Sdz));
+        float ca, cb, cc;
+        bn_bwd_coef(a, c, ca, cb, cc);
+        a.coef[c] = ca; a.coef[64 + c] = cb; a.coef[128 + c] = cc;
+        a.g_bglu[c] = (float)a.acc[4096 + c];
+        a.g_convb[c] = 0.f;   // sum_p dy == 0: a conv bias in front of a train-mode BatchNorm has zero gradient
+    }
+    for (int e = tid; e < 4096; e += nthreads) a.g_wglu[e] = (float)a.acc[e];
+}
+#endif
 // dgrad: dx = conv_flipped(dy), dy = ca*dz + cb*yin + cc (per channel) inside the image, 0 outside
+//   prep != null (Winograd kernels only): the coefficients are derived in the kernel (see BnBwdPrepArgs)
 int launch_conv_dgrad(const float* dz, const float* yin, const float* coef /*[3][64]*/, const float* wpkT, float* dx,
-                      int B, int H, int W, hipStream_t st);
+                      int B, int H, int W, const BnBwdPrepArgs* prep, hipStream_t st);
 // wgrad: dW[co][ci][tap] = sum_p dy[p][co] * xin[p+tap][ci]; dy as above
 int launch_conv_wgrad(const float* dz, const float* yin, const float* coef, const float* xin, float* part, int n_blocks,
-                      float* g_w /*[co][ci][3][3]*/, int B, int H, int W, hipStream_t st);
+                      float* g_w /*[co][ci][3][3]*/, int B, int H, int W, const BnBwdPrepArgs* prep, hipStream_t st);
 
 // bnglu.hip
 // BN statistics -> (mean, invstd, scale, shift) (+ running-stat update) happens in the kernel's prologue
@@ -41,7 +80,8 @@ int launch_glu_pool_fwd(const float* y, const double* stat, double N, const floa
 int launch_glu_pool_bwd(const float* y, const float* bn, const float* wglu, const float* bglu, const float* dp, const float* dp_b, float* dz,
                         double* acc, int zero_acc, int B, int H, int W, int block_id, int use_drop, float p_drop,
                         const uint16_t* mask_in, const float* gamma, float* coef, float* g_gamma, float* g_beta, float* g_wglu,
-                        float* g_bglu, float* g_convb, hipStream_t st);
+                        float* g_bglu, float* g_convb, BnBwdPrepArgs* prep_out /* non-null: no k_bn_bwd_prep, see BnBwdPrepArgs */,
+                        hipStream_t st);
 
 // gemm.hip : batched / split-K strided GEMM  C[m][n] = sum_k A(m,k) B(k,n) (+ bias[n]) (+ C)
 struct GemmProb {

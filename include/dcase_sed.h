@@ -241,7 +241,8 @@ int sed_kernel_replay(const char* name, const sed_dims* d, const float* params, 
  *   dgrad) by the direct 9-tap kernels (8-wave weight-stationary for block 1, tile kernel for block 2) instead of the
  *   Winograd F(2x2, 3x3) kernel - results differ at the 1e-7 level; bit 7: block-1 wgrad by the direct double-buffered
  *   kernel instead of the Winograd-domain one; bit 3: by the single-buffered tile kernel; bit 4: GLU backward with one wave per SIMD instead of two channel-half waves sharing a row block.
- *   Kept for A/B timing (profiles/README.md). */
+ *   bit 9: BatchNorm-backward coefficients by the 1-workgroup kernel k_bn_bwd_prep instead of in the prologue of the conv
+ *   dgrad / wgrad kernels (also implied by bits 2, 3, 6, 7).  Kept for A/B timing (profiles/README.md). */
 int sed_debug_set(int flags);
 
 /* ---- self tests (run on the GPU box by tests/) ---------------------------------------------

@@ -219,15 +219,17 @@ extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* b
     int64_t* trk[3] = {bn_tracked ? bn_tracked + 0 : nullptr, bn_tracked ? bn_tracked + 1 : nullptr,
                        bn_tracked ? bn_tracked + 2 : nullptr};
 
-    // conv1 / conv2 weights -> [tap][ci][co] (+ flipped/transposed copies for dgrad), one launch, which also zeroes
-    // every fp64 accumulator of the forward (patch moments, BN sums of blocks 1 and 2)
-    SED_TRY(launch_conv_pack(params + P.conv_w[1], params + P.conv_w[2], CTXF(L.wpk1), CTXF(L.wpk2),
-                             train ? CTXF(L.wpkT1) : nullptr, train ? CTXF(L.wpkT2) : nullptr, CTXD(L.acc0), train ? 320 : 0, st));
     // ---- conv block 0 ---------------------------------------------------------------------------
     SED_TRY(launch_blk0_forward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
                                 params + P.glu_w[0], params + P.glu_b[0], bn_running + 0, bn_running + 64, trk[0], train,
                                 upd, seed_dev, CTXD(L.mom0), CTXD(L.mompart), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), CTXF(L.p0),
                                 use_drop ? CTXM(L.mask0) : nullptr, st));
+    // conv1 / conv2 weights -> [tap][ci][co] + Winograd panels (+ flipped/transposed copies for dgrad), one launch, which
+    // also zeroes the fp64 BatchNorm sums of blocks 1 and 2.  Launched BEHIND block 0, not at the head of the chain: by
+    // then the GPU is busy with the other model's kernels, so these 6 us no longer add to the (nearly idle) step prologue
+    // of pack -> moments -> prep.
+    SED_TRY(launch_conv_pack(params + P.conv_w[1], params + P.conv_w[2], CTXF(L.wpk1), CTXF(L.wpk2),
+                             train ? CTXF(L.wpkT1) : nullptr, train ? CTXF(L.wpkT2) : nullptr, CTXD(L.stat1), train ? 256 : 0, st));   // (not mom0: block 0 just wrote it)
     // ---- conv blocks 1, 2 -----------------------------------------------------------------------
     const float* in = CTXF(L.p0);
     const size_t wpk[3] = {0, L.wpk1, L.wpk2}, yo[3] = {0, L.y1, L.y2}, so[3] = {0, L.stat1, L.stat2},

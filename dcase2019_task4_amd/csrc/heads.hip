@@ -224,48 +224,75 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_bwd(const float* __restric
     for (int t0 = 0; t0 < T; t0 += HD_TC) {
         __syncthreads();
         mk[tid] = heads_stage<HD_SB>(h, xs, b, T, t0, use_drop, seed, thr, ks, tid);
-        if (tid < HD_TC) {
-            const int t = t0 + tid;
+        {   // softmax / sigmoid backward of the chunk's frames: 8 threads per frame, thread `sub` takes classes sub and sub + 8
+            // (one thread per frame walking all classes left 7/8 of the workgroup idle for the longest serial stretch of
+            // the kernel); the three per-frame reductions (max, sum of exponentials, dot) are DPP butterflies inside the
+            // 8-lane group: quad_perm xor 1, xor 2, then row_half_mirror
+            const int tl = tid >> 3, sub = tid & 7, t = t0 + tl;
+            auto red8_sum = [](float v) {
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+                return v;
+            };
+            auto red8_max = [](float v) {
+                v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+                v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+                v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+                return v;
+            };
+            float* dlr = dl + tl * HD_SD;
             if (t < T) {
-                float mx = -3.0e38f;
-                for (int c = 0; c < NC; ++c) mx = fmaxf(mx, logits_s[(size_t)(b * T + t) * NC + c]);
-                float se = 0.f;
-                for (int c = 0; c < NC; ++c) se += __expf(logits_s[(size_t)(b * T + t) * NC + c] - mx);
-                const float inv = rcp_fast(se);
-                float dot = 0.f;
-                float sraw[16], dsof[16];
-                for (int c = 0; c < NC; ++c) {
-                    const float sv = strong[(size_t)(b * T + t) * NC + c];
-                    const float raw = __expf(logits_s[(size_t)(b * T + t) * NC + c] - mx) * inv;
-                    const float sof = fminf(fmaxf(raw, 1e-7f), 1.0f);
-                    const float pass = (raw >= 1e-7f && raw <= 1.0f) ? 1.f : 0.f;
-                    const float ds = (dnum[c] * sv + dden[c]) * pass;
-                    sraw[c] = raw; dsof[c] = ds;
-                    dot += raw * ds;
-                    float gin;
-                    if (fused) {
-                        const size_t e = (size_t)(b * T + t) * NC + c;
-                        const float pe = hl.strong_ema[e];
-                        const float diff = sv - pe;
-                        lacc[2] += diff * diff;
-                        gin = cw * 2.0f * diff * inv_nS;
-                        if (in_s) {
-                            const float tg = hl.target[e];
-                            lacc[1] += bce_term(sv, tg);
-                            lacc[5] += bce_term(pe, tg);
-                            gin += bce_grad(sv, tg) * inv_sb;
+                const size_t e0 = (size_t)(b * T + t) * NC;
+                const bool has[2] = {sub < NC, sub + 8 < NC};
+                float lg[2], ex[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) lg[q] = has[q] ? logits_s[e0 + sub + 8 * q] : -3.0e38f;
+                const float mx = red8_max(fmaxf(lg[0], lg[1]));
+#pragma unroll
+                for (int q = 0; q < 2; ++q) ex[q] = has[q] ? __expf(lg[q] - mx) : 0.f;
+                const float inv = rcp_fast(red8_sum(ex[0] + ex[1]));
+                float raw[2], ds[2], dsig[2], dpart = 0.f;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    raw[q] = 0.f; ds[q] = 0.f; dsig[q] = 0.f;
+                    if (has[q]) {
+                        const int c = sub + 8 * q;
+                        const float sv = strong[e0 + c];
+                        raw[q] = ex[q] * inv;
+                        const float sof = fminf(fmaxf(raw[q], 1e-7f), 1.0f);
+                        const float pass = (raw[q] >= 1e-7f && raw[q] <= 1.0f) ? 1.f : 0.f;
+                        ds[q] = (dnum[c] * sv + dden[c]) * pass;
+                        dpart += raw[q] * ds[q];
+                        float gin;
+                        if (fused) {
+                            const float pe = hl.strong_ema[e0 + c];
+                            const float diff = sv - pe;
+                            lacc[2] += diff * diff;
+                            gin = cw * 2.0f * diff * inv_nS;
+                            if (in_s) {
+                                const float tg = hl.target[e0 + c];
+                                lacc[1] += bce_term(sv, tg);
+                                lacc[5] += bce_term(pe, tg);
+                                gin += bce_grad(sv, tg) * inv_sb;
+                            }
+                            if (hl.d_strong_out) hl.d_strong_out[e0 + c] = gin;
+                        } else {
+                            gin = d_strong[e0 + c];
                         }
-                        if (hl.d_strong_out) hl.d_strong_out[e] = gin;
-                    } else {
-                        gin = d_strong[(size_t)(b * T + t) * NC + c];
+                        dsig[q] = (gin + dnum[c] * sof) * sv * (1.0f - sv);
                     }
-                    const float dst = gin + dnum[c] * sof;
-                    dl[tid * HD_SD + c] = dst * sv * (1.0f - sv);
                 }
-                for (int c = 0; c < NC; ++c) dl[tid * HD_SD + NC + c] = sraw[c] * (dsof[c] - dot);
-                for (int o = NO; o < HD_MAXO; ++o) dl[tid * HD_SD + o] = 0.f;
+                const float dot = red8_sum(dpart);
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    if (has[q]) {
+                        dlr[sub + 8 * q] = dsig[q];
+                        dlr[NC + sub + 8 * q] = raw[q] * (ds[q] - dot);
+                    }
+                for (int o = NO + sub; o < HD_MAXO; o += 8) dlr[o] = 0.f;
             } else {
-                for (int o = 0; o < HD_MAXO; ++o) dl[tid * HD_SD + o] = 0.f;
+                for (int o = sub; o < HD_MAXO; o += 8) dlr[o] = 0.f;
             }
         }
         __syncthreads();

@@ -104,27 +104,46 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_fwd(const float* __restric
             for (int r = 0; r < 4; ++r) lg[(16 * rt + 4 * kq + r) * HD_MAXO + o] = acc0[r] + acc1[r] + bias;
         }
         __syncthreads();
-        if (tid < HD_TC) {
-            const int t = t0 + tid;
+        {   // softmax over classes + sigmoid, 8 threads per frame (thread `sub`: classes sub, sub + 8; DPP reductions inside
+            // the 8-lane group) - one thread per frame left 7/8 of the workgroup idle here
+            const int tl = tid >> 3, sub = tid & 7, t = t0 + tl;
+            auto red8_sum = [](float v) {
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+                return v;
+            };
+            auto red8_max = [](float v) {
+                v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+                v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+                v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+                return v;
+            };
+            const bool has[2] = {sub < NC, sub + 8 < NC};
             if (t < T) {
-                float mx = -3.0e38f;
-                for (int c = 0; c < NC; ++c) mx = fmaxf(mx, lg[tid * HD_MAXO + NC + c]);
-                float se = 0.f;
-                for (int c = 0; c < NC; ++c) se += __expf(lg[tid * HD_MAXO + NC + c] - mx);
-                const float inv = rcp_fast(se);
-                for (int c = 0; c < NC; ++c) {
-                    const float ls = lg[tid * HD_MAXO + NC + c];
-                    float sof = __expf(ls - mx) * inv;
-                    sof = fminf(fmaxf(sof, 1e-7f), 1.0f);
-                    const float sv = sigmoidf_fast(lg[tid * HD_MAXO + c]);
-                    strong[(size_t)(b * T + t) * NC + c] = sv;
-                    if (strong_sv) strong_sv[(size_t)(b * T + t) * NC + c] = sv;
-                    logits_s[(size_t)(b * T + t) * NC + c] = ls;
-                    nums[tid][c] = sv * sof;
-                    dens[tid][c] = sof;
-                }
+                float ls[2], ex[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) ls[q] = has[q] ? lg[tl * HD_MAXO + NC + sub + 8 * q] : -3.0e38f;
+                const float mx = red8_max(fmaxf(ls[0], ls[1]));
+#pragma unroll
+                for (int q = 0; q < 2; ++q) ex[q] = has[q] ? __expf(ls[q] - mx) : 0.f;
+                const float inv = rcp_fast(red8_sum(ex[0] + ex[1]));
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    if (has[q]) {
+                        const int c = sub + 8 * q;
+                        const float sof = fminf(fmaxf(ex[q] * inv, 1e-7f), 1.0f);
+                        const float sv = sigmoidf_fast(lg[tl * HD_MAXO + c]);
+                        strong[(size_t)(b * T + t) * NC + c] = sv;
+                        if (strong_sv) strong_sv[(size_t)(b * T + t) * NC + c] = sv;
+                        logits_s[(size_t)(b * T + t) * NC + c] = ls[q];
+                        nums[tl][c] = sv * sof;
+                        dens[tl][c] = sof;
+                    }
             } else {
-                for (int c = 0; c < NC; ++c) { nums[tid][c] = 0.f; dens[tid][c] = 0.f; }
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    if (has[q]) { nums[tl][sub + 8 * q] = 0.f; dens[tl][sub + 8 * q] = 0.f; }
             }
         }
         __syncthreads();

@@ -97,32 +97,40 @@ struct Blk0PrepArgs {
     float eps, momentum;
     float *wz, *wl, *bn;   // wz/wl [64][12], bn [4][64] = mean, invstd, scale, shift
 };
-__global__ __launch_bounds__(640) void k_blk0_prep(Blk0PrepArgs a) {
+#define PREP_THREADS 896      // 54 moments x 16 partial-sum lanes = 864 threads for the reduction; >= 640 for the GLU fold
+__global__ __launch_bounds__(PREP_THREADS) void k_blk0_prep(Blk0PrepArgs a) {
     __shared__ double wzs[64][10];
-    __shared__ double mred[54][10];
+    __shared__ double mred[54][16];
     __shared__ double moms[54];
     const int tid = threadIdx.x;
     if (a.train) {   // patch moments = fixed-order fp64 sum of the per-workgroup partials
-        if (tid < 540) {
-            const int k = tid / 10, j = tid % 10;
-            // 8 independent loads in flight (a rolled loop pays one memory round trip per partial: 12 us for 24 of them)
+        if (tid < 864) {
+            const int k = tid / 16, j = tid % 16;
+            // thread (k, j) takes partials j, j + 16, ...: up to 16 independent loads in flight, so the 240 partials of the
+            // BASELINE shape are ONE memory round trip (10 lanes x 8 loads were three: 6 of this kernel's 10 us)
             double acc = 0;
             int w = j;
-            for (; w + 70 < a.n_part; w += 80) {
-                double v[8];
+            for (; w + 16 * 15 < a.n_part; w += 16 * 16) {
+                double v[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = a.mompart[(size_t)(w + 10 * u) * 54 + k];
+                for (int u = 0; u < 16; ++u) v[u] = a.mompart[(size_t)(w + 16 * u) * 54 + k];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc += v[u];
+                for (int u = 0; u < 16; ++u) acc += v[u];
             }
-            for (; w < a.n_part; w += 10) acc += a.mompart[(size_t)w * 54 + k];
+            {   // the remaining (< 16) partials of this lane, still issued together
+                double v[15];
+#pragma unroll
+                for (int u = 0; u < 15; ++u) v[u] = (w + 16 * u < a.n_part) ? a.mompart[(size_t)(w + 16 * u) * 54 + k] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 15; ++u) acc += v[u];
+            }
             mred[k][j] = acc;
         }
         __syncthreads();
         if (tid < 54) {
             double acc = 0;
 #pragma unroll
-            for (int j = 0; j < 10; ++j) acc += mred[tid][j];
+            for (int j = 0; j < 16; ++j) acc += mred[tid][j];
             moms[tid] = acc;
             a.mom[tid] = acc;
         }
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(640) void k_blk0_prep(Blk0PrepArgs a) {
         a.bn[c] = (float)mean; a.bn[64 + c] = (float)invstd; a.bn[128 + c] = (float)scale; a.bn[192 + c] = (float)shift;
     }
     __syncthreads();
-    {   // wl[c][t] = sum_k Wglu[c][k] wz[k][t] (+ bglu at t = 9): one thread per (c, t)
+    if (tid < 640) {   // wl[c][t] = sum_k Wglu[c][k] wz[k][t] (+ bglu at t = 9): one thread per (c, t)
         const int c = tid / 10, t = tid % 10;
         double acc = (t == 9) ? (double)a.bglu[c] : 0.0;
         for (int k = 0; k < 64; ++k) acc += (double)a.wglu[c * 64 + k] * wzs[k][t];
@@ -508,7 +516,7 @@ int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const flo
     a.mompart = mompart; a.n_part = x_moments_parts(g);
     a.N = (double)g.B * g.T * g.F; a.train = train; a.update = update; a.eps = g.eps; a.momentum = g.mom;
     a.wz = wz; a.wl = wl; a.bn = bn;
-    k_blk0_prep<<<1, 640, 0, st>>>(a);
+    k_blk0_prep<<<1, PREP_THREADS, 0, st>>>(a);
     SED_CHECK_LAUNCH();
     const int tpc = (g.H1 + 3) / 4, nt = tpc * g.B;
     const int use_drop = (train && g.p > 0.f) ? 1 : 0;

@@ -403,13 +403,14 @@ extern "C" int sed_crnn_backward(const sed_dims* d, const float* params, const f
 extern "C" int sed_mt_loss_backward(const sed_dims* d, const float* params, const float* x, const uint64_t* seed_dev,
                                     void* ctx, size_t ctx_bytes, const float* strong_ema, const float* weak_ema,
                                     const float* target, int weak_lo, int weak_hi, int strong_lo, int strong_hi,
-                                    const sed_step_state* state_dev, float* losses, float* d_strong, float* d_weak,
-                                    float* grads, void* ws, size_t ws_bytes, int parts, void* stream) {
+                                    sed_step_state* state_dev, int advance_state, float* losses, float* d_strong,
+                                    float* d_weak, float* grads, void* ws, size_t ws_bytes, int parts, void* stream) {
     SED_CHECK_ARG(d && strong_ema && weak_ema && target && state_dev && losses, "sed_mt_loss_backward: null argument");
     SED_CHECK_ARG(parts == 1 || parts == 3, "sed_mt_loss_backward: parts must include the heads (1 or 3)");
     SED_CHECK_ARG(weak_lo >= 0 && weak_hi <= d->B && weak_lo <= weak_hi && strong_lo >= 0 && strong_hi <= d->B &&
                       strong_lo <= strong_hi, "sed_mt_loss_backward: bad mask range");
-    HeadsLoss hl = {strong_ema, weak_ema, target, weak_lo, weak_hi, strong_lo, strong_hi, state_dev, losses, d_strong, d_weak};
+    HeadsLoss hl = {strong_ema, weak_ema, target, weak_lo, weak_hi, strong_lo, strong_hi, state_dev, losses, d_strong, d_weak,
+                    advance_state ? state_dev : nullptr};
     return crnn_backward_impl(d, params, x, seed_dev, ctx, ctx_bytes, nullptr, nullptr, grads, ws, ws_bytes, parts, stream, &hl);
 }
 

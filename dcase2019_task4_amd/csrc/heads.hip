@@ -396,6 +396,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_bwd(const float* __restric
         hl.losses[1] = wb; hl.losses[2] = sb; hl.losses[3] = cs; hl.losses[4] = cwk;
         hl.losses[5] = red[4] * inv_wb; hl.losses[6] = red[5] * inv_sb; hl.losses[7] = cw;
         *ticket = 0u;
+        if (hl.advance) step_state_advance_early(hl.advance);   // every workgroup has read its fields of this step by now
     }
 }
 

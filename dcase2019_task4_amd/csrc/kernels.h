@@ -126,12 +126,64 @@ int launch_heads_fwd(const float* h /*[B][T][128]*/, const float* wd, const floa
                      float* strong, float* weak, float* strong_sv, float* weak_sv, float* logits_s, float* den, int B, int T,
                      int NC, int use_drop, float p_drop, const uint64_t* seed, hipStream_t st);
 int launch_heads_colsum(const float* part, float* g_wd, int B, int NC, hipStream_t st);
+// ---- device-side step state (sed_step_state): derived fields ------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+// what the forward passes and the loss of step `global_step` read
+__device__ __forceinline__ void step_state_derive_forward(sed_step_state* s) {
+    const int64_t gs = s->global_step;
+    // sigmoid_rampup (utils/ramps.py:20-27) behind the `global_step < rampup_length` test of main.py:74-78
+    double r = 1.0;
+    if (gs < s->rampup_length && s->rampup_length > 0) {
+        double cur = (double)gs;
+        if (cur < 0) cur = 0;
+        const double phase = 1.0 - cur / (double)s->rampup_length;
+        r = exp(-5.0 * phase * phase);
+    }
+    s->cons_weight = (float)(s->max_cons_cost * r);
+    s->seed_student = splitmix64(s->base_seed + 2ull * (uint64_t)gs * 0x9E3779B97F4A7C15ull + 1ull);
+    s->seed_teacher = splitmix64(s->base_seed + (2ull * (uint64_t)gs + 1ull) * 0x9E3779B97F4A7C15ull + 1ull);
+}
+// what the Adam + EMA update of step `global_step` (Adam step `opt_step`) reads
+__device__ __forceinline__ void step_state_derive_update(sed_step_state* s) {
+    const int64_t gs = s->global_step;
+    // update_ema_variables is called with global_step already incremented (main.py:155-157)
+    const double a = 1.0 - 1.0 / ((double)(gs + 1) + 1.0);
+    s->ema_alpha = (float)(a < s->ema_decay ? a : s->ema_decay);
+    const double bc1 = 1.0 - pow(s->beta1, (double)s->opt_step);
+    const double bc2 = 1.0 - pow(s->beta2, (double)s->opt_step);
+    s->adam_step_size = (float)(s->lr / bc1);
+    s->adam_sqrt_bc2 = (float)sqrt(bc2);
+}
+__device__ __forceinline__ void step_state_derive(sed_step_state* s) {
+    step_state_derive_forward(s);
+    step_state_derive_update(s);
+}
+// The advance of the fused step, done by the last workgroup of the loss / heads-backward kernel instead of a 1-thread
+// kernel at the end of the step (4.6 us on the tail): at that point every forward kernel and the loss have read their
+// fields of this step, and the update has not run yet - so the update's fields are (re)derived for THIS step, then the
+// counters move on and the forward's fields are derived for the NEXT step.  At step boundaries the counters and the
+// forward fields are the same as with sed_step_state_advance; the update fields lag by one step until they are needed.
+__device__ __forceinline__ void step_state_advance_early(sed_step_state* s) {
+    step_state_derive_update(s);
+    s->global_step += 1;
+    s->opt_step += 1;
+    step_state_derive_forward(s);
+}
+#endif
+
 // loss inputs of the fused loss + heads backward (sed_mt_loss_backward); strong_ema == null: gradients come from the caller
 struct HeadsLoss {
     const float* strong_ema; const float* weak_ema; const float* target;
     int wlo, whi, slo, shi;
     const sed_step_state* state;
     float* losses; float* d_strong_out; float* d_weak_out;
+    sed_step_state* advance;      // non-null: the last workgroup also advances the step state (step_state_advance_early)
 };
 int launch_heads_bwd(const float* h, const float* wd, const float* ws, const float* strong, const float* weak,
                      const float* logits_s, const float* den, const float* d_strong, const float* d_weak, float* dh,

@@ -52,35 +52,7 @@ __global__ __launch_bounds__(256) void k_ema(int64_t n, const float* __restrict_
         pe[i] = alpha * pe[i] + (1.0f - alpha) * p[i];
 }
 
-__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
-
-// derived fields of the step whose counters are already stored in *s
-__device__ void step_state_derive(sed_step_state* s) {
-    const int64_t gs = s->global_step;
-    // sigmoid_rampup (utils/ramps.py:20-27) behind the `global_step < rampup_length` test of main.py:74-78
-    double r = 1.0;
-    if (gs < s->rampup_length && s->rampup_length > 0) {
-        double cur = (double)gs;
-        if (cur < 0) cur = 0;
-        const double phase = 1.0 - cur / (double)s->rampup_length;
-        r = exp(-5.0 * phase * phase);
-    }
-    s->cons_weight = (float)(s->max_cons_cost * r);
-    // update_ema_variables is called with global_step already incremented (main.py:155-157)
-    const double a = 1.0 - 1.0 / ((double)(gs + 1) + 1.0);
-    s->ema_alpha = (float)(a < s->ema_decay ? a : s->ema_decay);
-    const double bc1 = 1.0 - pow(s->beta1, (double)s->opt_step);
-    const double bc2 = 1.0 - pow(s->beta2, (double)s->opt_step);
-    s->adam_step_size = (float)(s->lr / bc1);
-    s->adam_sqrt_bc2 = (float)sqrt(bc2);
-    s->seed_student = splitmix64(s->base_seed + 2ull * (uint64_t)gs * 0x9E3779B97F4A7C15ull + 1ull);
-    s->seed_teacher = splitmix64(s->base_seed + (2ull * (uint64_t)gs + 1ull) * 0x9E3779B97F4A7C15ull + 1ull);
-}
+// (splitmix64, step_state_derive*, step_state_advance_early: kernels.h - the heads backward advances the state too)
 
 __global__ void k_step_state_init(sed_step_state* s, uint64_t base_seed, int64_t rampup_length, double lr, double beta1,
                                   double beta2, double eps, double ema_decay, double max_cons_cost) {

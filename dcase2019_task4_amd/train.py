@@ -164,7 +164,7 @@ class MeanTeacherStep:
         _lib.check(self.l.sed_mt_loss_backward(C.byref(self.dims), _lib.ptr(self.student._flat), _lib.ptr(self.x),
                                                self._seed_s, _lib.ptr(self.ctx_s), self.ctx_bytes,
                                                _lib.ptr(self.strong_ema), _lib.ptr(self.weak_ema), _lib.ptr(self.target),
-                                               self.wlo, self.whi, self.slo, self.shi, _lib.ptr(self.state),
+                                               self.wlo, self.whi, self.slo, self.shi, _lib.ptr(self.state), 1,
                                                _lib.ptr(self.losses), None, None, _lib.ptr(self.grads),
                                                _lib.ptr(self.ws), self.ws_bytes, parts, _lib.stream_ptr()),
                    "sed_mt_loss_backward")
@@ -176,13 +176,14 @@ class MeanTeacherStep:
                                             _lib.ptr(self.ws), self.ws_bytes, parts, _lib.stream_ptr()), "sed_crnn_backward")
 
     def _update(self):
-        """Adam (main.py:154) + EMA teacher (:155-157) + step counters, one kernel each."""
+        """Adam (main.py:154) + EMA teacher (:155-157), one kernel."""
         _lib.check(self.l.sed_adam_ema(self.n, _lib.ptr(self.student._flat), _lib.ptr(self.grads),
                                        _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
                                        _lib.ptr(self.teacher._flat) if self.teacher is not None else None,
                                        _lib.ptr(self.state), 1.0 / self.world,
                                        _lib.stream_ptr()), "sed_adam_ema")
-        _lib.check(self.l.sed_step_state_advance(_lib.ptr(self.state), _lib.stream_ptr()), "sed_step_state_advance")
+        # (no sed_step_state_advance: the loss / heads-backward kernel of this step already moved the counters on and
+        # left the update's own fields derived for this step - sed_mt_loss_backward(advance_state = 1))
 
     def _allreduce_tail(self):
         """GRU + heads gradients are complete after backward part 1: start their all-reduce now so it

@@ -142,10 +142,14 @@ int sed_mt_loss(const sed_dims* d, const float* strong, const float* weak, const
  * separate loss kernel (12 us on the critical path between forward and backward) disappears.  The student's
  * posteriors are the ones sed_crnn_forward(train=1) left in ctx; `losses` as for sed_mt_loss (same meters; summed in
  * a different order, so equal to rounding); d_strong / d_weak: optional outputs (may be NULL); parts: 1 or 3. */
+/* advance_state != 0: the kernel that finishes the loss also advances *state_dev to the next step - what
+ * sed_step_state_advance would do after the update, minus the update's own derived fields (ema_alpha, adam_step_size,
+ * adam_sqrt_bc2), which are (re)derived here for THIS step and are therefore valid for the sed_adam_ema call that
+ * follows.  A caller that passes advance_state must not call sed_step_state_advance for this step as well. */
 int sed_mt_loss_backward(const sed_dims* d, const float* params, const float* x, const uint64_t* seed_dev,
                          void* ctx, size_t ctx_bytes, const float* strong_ema, const float* weak_ema,
                          const float* target, int weak_lo, int weak_hi, int strong_lo, int strong_hi,
-                         const sed_step_state* state_dev, float* losses, float* d_strong, float* d_weak,
+                         sed_step_state* state_dev, int advance_state, float* losses, float* d_strong, float* d_weak,
                          float* grads, void* ws, size_t ws_bytes, int parts, void* stream);
 
 /* ---- optimiser + EMA -----------------------------------------------------------------------

@@ -263,7 +263,7 @@ def test_fused_loss_backward_matches_loss_kernel_then_backward():
     st.grads.zero_(); st.d_strong.zero_(); st.d_weak.zero_()
     _lib.check(st.l.sed_mt_loss_backward(C.byref(st.dims), _lib.ptr(st.student._flat), _lib.ptr(st.x), st._seed_s,
                                          _lib.ptr(st.ctx_s), st.ctx_bytes, _lib.ptr(st.strong_ema), _lib.ptr(st.weak_ema),
-                                         _lib.ptr(st.target), st.wlo, st.whi, st.slo, st.shi, _lib.ptr(st.state),
+                                         _lib.ptr(st.target), st.wlo, st.whi, st.slo, st.shi, _lib.ptr(st.state), 0,
                                          _lib.ptr(st.losses), _lib.ptr(st.d_strong), _lib.ptr(st.d_weak), _lib.ptr(st.grads),
                                          _lib.ptr(st.ws), st.ws_bytes, 3, _lib.stream_ptr()), "sed_mt_loss_backward")
     torch.cuda.synchronize()

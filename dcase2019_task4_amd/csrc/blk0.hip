@@ -33,7 +33,15 @@ __device__ __forceinline__ int gidx(int a, int b) { return 9 + a * 9 - (a * (a -
 // partial row which k_blk0_prep (the next kernel anyway) adds up in fixed order: no memset, no same-address
 // fp64 atomics (240 of them per address cost 7.5 us), bit-reproducible statistics.
 #define MOM_ROWS 64
-__global__ __launch_bounds__(256) void k_x_moments(const float* __restrict__ x, int T, double* __restrict__ part) {
+// Workgroups with blockIdx.x >= nx do the conv1 / conv2 weight packing of the same step instead (conv_pack_body,
+// kernels.h): independent work that used to be a 6 us launch of its own on the forward chain.
+__global__ __launch_bounds__(256) void k_x_moments(const float* __restrict__ x, int T, double* __restrict__ part, int nx,
+                                                    ConvPackArgs pack) {
+    if ((int)blockIdx.x >= nx) {
+        const int pb = ((int)blockIdx.x - nx) * (int)gridDim.y + (int)blockIdx.y;
+        if (pb < SED_PACK_BLOCKS) conv_pack_body(pack, pb * 256 + (int)threadIdx.x);
+        return;
+    }
     __shared__ float xs[(MOM_ROWS + 2) * XS_W];
     __shared__ float red[4][10][10];
     const int tid = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * MOM_ROWS;
@@ -79,7 +87,7 @@ __global__ __launch_bounds__(256) void k_x_moments(const float* __restrict__ x, 
         const int a = tid / 10, c = tid % 10;
         if (a <= c && a < 9) {
             const double v = (double)red[0][a][c] + (double)red[1][a][c] + (double)red[2][a][c] + (double)red[3][a][c];
-            part[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 54 + (c == 9 ? a : gidx(a, c))] = v;
+            part[(size_t)(blockIdx.y * nx + blockIdx.x) * 54 + (c == 9 ? a : gidx(a, c))] = v;
         }
     }
 }
@@ -496,18 +504,21 @@ __global__ __launch_bounds__(640) void k_blk0_bwd_finalize(Blk0BwdFinArgs a) {
 
 // ---- host launchers -------------------------------------------------------------------------------
 int x_moments_parts(const Geo& g) { return ((g.T + MOM_ROWS - 1) / MOM_ROWS) * g.B; }
-int launch_x_moments(const Geo& g, const float* x, double* mompart, hipStream_t st) {
-    dim3 grid((g.T + MOM_ROWS - 1) / MOM_ROWS, g.B);
-    k_x_moments<<<grid, 256, 0, st>>>(x, g.T, mompart);
+int launch_x_moments(const Geo& g, const float* x, double* mompart, const ConvPackArgs* pack, hipStream_t st) {
+    const int nx = (g.T + MOM_ROWS - 1) / MOM_ROWS;
+    ConvPackArgs pa = {};
+    if (pack) pa = *pack;
+    dim3 grid(nx + (pack ? (SED_PACK_BLOCKS + g.B - 1) / g.B : 0), g.B);
+    k_x_moments<<<grid, 256, 0, st>>>(x, g.T, mompart, nx, pa);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
 int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const float* b0, const float* gamma,
                         const float* beta, const float* wglu, const float* bglu, float* run_mean, float* run_var,
                         int64_t* tracked, int train, int update, const uint64_t* seed, double* mom, double* mompart,
-                        float* wz, float* wl, float* bn, float* p0, uint16_t* mask_out, hipStream_t st) {
+                        float* wz, float* wl, float* bn, float* p0, uint16_t* mask_out, const ConvPackArgs* pack, hipStream_t st) {
     if (train) {
-        const int rc = launch_x_moments(g, x, mompart, st);
+        const int rc = launch_x_moments(g, x, mompart, pack, st);
         if (rc != SED_OK) return rc;
     }
     Blk0PrepArgs a;

@@ -34,64 +34,8 @@ struct ConvCfg {
     static constexpr size_t LDS_BYTES = (size_t)(HALO_FLOATS + 2 * W_FLOATS) * 4;
 };
 
-// U = G g G^T of one 3x3 kernel (Winograd F(2x2, 3x3)) for the pair (k, n) of the B operand [k][n], written in the order
-// the 8 waves of k_conv16_wino hold it in registers: Uf[ph][cg][p8][sq][lane][e] with lane = 16 kq + i16,
-// k = 4 (4 sq + e) + kq, n = 16 cg + i16; wave row ph: p8 < 4 <-> transform row 3 ph, p8 >= 4 <-> row 1 + ph; column p8 & 3
-__device__ __forceinline__ void wino_u(const float (&g)[3][3], float* __restrict__ U, int k, int n) {
-    float t[4][3];
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-        t[0][b] = g[0][b];
-        t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
-        t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
-        t[3][b] = g[2][b];
-    }
-    const int kq = k & 3, s4 = k >> 2, sq = s4 >> 2, e = s4 & 3, cg = n >> 4, i16 = n & 15;
-#pragma unroll
-    for (int i2 = 0; i2 < 4; ++i2) {
-        // transform row i2 lives in wave row ph = (i2 >= 2), as its X row (i2 = 0, 3) or its Y row (i2 = 1, 2)
-        const int ph = i2 >> 1, p8b = (i2 == 0 || i2 == 3) ? 0 : 4;
-        float* d = U + ((((size_t)(ph * 4 + cg) * 8 + p8b) * 4 + sq) * 64 + 16 * kq + i16) * 4 + e;
-        const size_t pstride = 4 * 64 * 4;          // p8 -> p8 + 1
-        d[0 * pstride] = t[i2][0];
-        d[1 * pstride] = 0.5f * (t[i2][0] + t[i2][1] + t[i2][2]);
-        d[2 * pstride] = 0.5f * (t[i2][0] - t[i2][1] + t[i2][2]);
-        d[3 * pstride] = t[i2][2];
-    }
-}
-__global__ void k_conv_pack(const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ wpk1,
-                            float* __restrict__ wpk2, float* __restrict__ wpkT1, float* __restrict__ wpkT2,
-                            double* __restrict__ zero, int n_zero) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;   // over [layer][tap][ci][co]
-    if (i < n_zero) zero[i] = 0.0;                   // the forward's fp64 BatchNorm accumulators (saves a memset node)
-    if (i < 4 * 4096) {                              // Winograd panels: [layer][forward | dgrad]
-        const int which = i >> 12, kn = i & 4095, k = kn >> 6, n2 = kn & 63;
-        const float* w = (which >> 1) ? w2 : w1;
-        float* dst = (which >> 1) ? ((which & 1) ? wpkT2 : wpk2) : ((which & 1) ? wpkT1 : wpk1);
-        if (dst != nullptr) {
-            float g[3][3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b)
-                    // forward: B[k = ci][n = co] from g[a][b] = W[co][ci][a][b]; dgrad: B[k = co][n = ci] from the flipped kernel
-                    g[a][b] = (which & 1) ? w[(k * 64 + n2) * 9 + 3 * (2 - a) + (2 - b)] : w[(n2 * 64 + k) * 9 + 3 * a + b];
-            wino_u(g, dst + SED_WINO_OFF, k, n2);
-        }
-    }
-    const int layer = i / (9 * 4096);
-    i -= layer * 9 * 4096;
-    const float* w = layer ? w2 : w1;
-    float* wpk = layer ? wpk2 : wpk1;
-    float* wpkT = layer ? wpkT2 : wpkT1;
-    const int tap = i / 4096, ci = (i / 64) % 64, co = i % 64;
-    wpk[i] = w[(co * 64 + ci) * 9 + tap];
-    if (wpkT) {
-        // transposed conv for dgrad: wpkT[tap'][k = co][n = ci] = W[co][ci][8 - tap']
-        const int k = ci, n = co;      // reuse the index split: (i/64)%64 -> k, i%64 -> n
-        wpkT[i] = w[(k * 64 + n) * 9 + (8 - tap)];
-    }
-}
+// (wino_u, conv_pack_body: kernels.h - the packing also rides along in the k_x_moments launch of a training forward)
+__global__ __launch_bounds__(256) void k_conv_pack(ConvPackArgs a) { conv_pack_body(a, blockIdx.x * 256 + threadIdx.x); }
 
 // MODE 0: forward (in = activations, epilogue bias + stats).  MODE 1: dgrad (in = affine(dz, y)).
 // NS = 2 splits the 64 output channels over two workgroups (blockIdx.y): used for the narrow block-2
@@ -1235,10 +1179,9 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 }
 
 // ---- host launchers ---------------------------------------------------------------------------
-int launch_conv_pack(const float* w1, const float* w2, float* wpk1, float* wpk2, float* wpkT1, float* wpkT2, double* zero,
-                     int n_zero, hipStream_t st) {
+int launch_conv_pack(const ConvPackArgs& a, hipStream_t st) {
     // every panel is followed by its Winograd-transformed form (SED_WINO_OFF floats in)
-    k_conv_pack<<<(2 * 9 * 4096 + 255) / 256, 256, 0, st>>>(w1, w2, wpk1, wpk2, wpkT1, wpkT2, zero, n_zero);
+    k_conv_pack<<<SED_PACK_BLOCKS, 256, 0, st>>>(a);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

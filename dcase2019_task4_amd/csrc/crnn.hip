@@ -219,17 +219,17 @@ extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* b
     int64_t* trk[3] = {bn_tracked ? bn_tracked + 0 : nullptr, bn_tracked ? bn_tracked + 1 : nullptr,
                        bn_tracked ? bn_tracked + 2 : nullptr};
 
+    // conv1 / conv2 weights -> [tap][ci][co] + Winograd panels (+ flipped/transposed copies for dgrad); the same threads
+    // also zero the fp64 BatchNorm sums of blocks 1 and 2.  In a training forward this rides along in the k_x_moments
+    // launch (independent work, extra workgroups) instead of being a launch of its own on the chain.
+    const ConvPackArgs pack = {params + P.conv_w[1], params + P.conv_w[2], CTXF(L.wpk1), CTXF(L.wpk2),
+                               train ? CTXF(L.wpkT1) : nullptr, train ? CTXF(L.wpkT2) : nullptr, CTXD(L.stat1), train ? 256 : 0};
     // ---- conv block 0 ---------------------------------------------------------------------------
     SED_TRY(launch_blk0_forward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
                                 params + P.glu_w[0], params + P.glu_b[0], bn_running + 0, bn_running + 64, trk[0], train,
                                 upd, seed_dev, CTXD(L.mom0), CTXD(L.mompart), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), CTXF(L.p0),
-                                use_drop ? CTXM(L.mask0) : nullptr, st));
-    // conv1 / conv2 weights -> [tap][ci][co] + Winograd panels (+ flipped/transposed copies for dgrad), one launch, which
-    // also zeroes the fp64 BatchNorm sums of blocks 1 and 2.  Launched BEHIND block 0, not at the head of the chain: by
-    // then the GPU is busy with the other model's kernels, so these 6 us no longer add to the (nearly idle) step prologue
-    // of pack -> moments -> prep.
-    SED_TRY(launch_conv_pack(params + P.conv_w[1], params + P.conv_w[2], CTXF(L.wpk1), CTXF(L.wpk2),
-                             train ? CTXF(L.wpkT1) : nullptr, train ? CTXF(L.wpkT2) : nullptr, CTXD(L.stat1), train ? 256 : 0, st));   // (not mom0: block 0 just wrote it)
+                                use_drop ? CTXM(L.mask0) : nullptr, train ? &pack : nullptr, st));
+    if (!train) SED_TRY(launch_conv_pack(pack, st));      // (training: done by extra workgroups of k_x_moments)
     // ---- conv blocks 1, 2 -----------------------------------------------------------------------
     const float* in = CTXF(L.p0);
     const size_t wpk[3] = {0, L.wpk1, L.wpk2}, yo[3] = {0, L.y1, L.y2}, so[3] = {0, L.stat1, L.stat2},
@@ -436,14 +436,14 @@ extern "C" int sed_kernel_replay(const char* name, const sed_dims* d, const floa
     const size_t dzo[3] = {0, W.dz1, W.dz2}, dpo[3] = {W.dp0, W.dp1, W.dp2}, gacc[3] = {0, W.gluacc1, W.gluacc2};
     const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};
     auto is = [&](const char* n) { return strcmp(name, n) == 0; };
-    if (is("x_moments")) return launch_x_moments(g, x, CTXD(L.mompart), st);
+    if (is("x_moments")) return launch_x_moments(g, x, CTXD(L.mompart), nullptr, st);
     if (is("blk0_fwd")) {
         const int tpc = (g.H1 + 3) / 4;
         (void)tpc;
         return launch_blk0_forward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
                                    params + P.glu_w[0], params + P.glu_b[0], WSF(W.coef[1]), WSF(W.coef[1]) + 64, nullptr, 1, 0,
                                    seed_dev, CTXD(L.mom0), CTXD(L.mompart), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), CTXF(L.p0),
-                                   use_drop ? CTXM(L.mask0) : nullptr, st);
+                                   use_drop ? CTXM(L.mask0) : nullptr, nullptr, st);
     }
     for (int i = 1; i <= 2; ++i) {
         char nm[32];

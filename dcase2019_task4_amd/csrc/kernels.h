@@ -4,12 +4,15 @@
 #include "common.h"
 
 // blk0.hip
+struct ConvPackArgs;
 int x_moments_parts(const Geo& g);
-int launch_x_moments(const Geo& g, const float* x, double* mompart, hipStream_t st);
+// pack != null: the conv1 / conv2 weight packing (independent work of the same step) rides along as extra workgroups
+int launch_x_moments(const Geo& g, const float* x, double* mompart, const ConvPackArgs* pack, hipStream_t st);
 int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const float* b0, const float* gamma,
                         const float* beta, const float* wglu, const float* bglu, float* run_mean, float* run_var,
                         int64_t* tracked, int train, int update, const uint64_t* seed, double* mom, double* mompart,
-                        float* wz, float* wl, float* bn, float* p0, uint16_t* mask_out, hipStream_t st);
+                        float* wz, float* wl, float* bn, float* p0, uint16_t* mask_out, const ConvPackArgs* pack /* train only */,
+                        hipStream_t st);
 int launch_blk0_backward(const Geo& g, const float* x, const float* w0, const float* b0, const float* gamma,
                          const float* beta, const float* wglu, const uint16_t* mask_in, const double* mom,
                          const float* wz, const float* wl, const float* bn, const float* dp0, double* de, int zero_de,
@@ -17,9 +20,75 @@ int launch_blk0_backward(const Geo& g, const float* x, const float* w0, const fl
                          hipStream_t st);
 
 // conv.hip : 3x3, 64 -> 64 channels, channels-last, image [B][H][W][64] with W in {16, 4}
-// packs conv1 and conv2 weights [co][ci][3][3] -> wpk [tap][ci][co] (+ flipped/transposed wpkT for dgrad, may be null)
-int launch_conv_pack(const float* w1, const float* w2, float* wpk1, float* wpk2, float* wpkT1, float* wpkT2, double* zero,
-                     int n_zero, hipStream_t st);
+// ---- conv weight packing (conv.hip; also called from k_x_moments, blk0.hip) -----------------------------------------
+struct ConvPackArgs {
+    const float *w1, *w2;            // conv1 / conv2 weights [co][ci][3][3]
+    float *wpk1, *wpk2;              // [tap][ci][co] | Winograd panel (SED_WINO_OFF floats in)
+    float *wpkT1, *wpkT2;            // the same for dgrad (flipped / transposed), may be null
+    double* zero; int n_zero;        // fp64 accumulators to clear (the forward's BatchNorm sums)
+};
+#define SED_PACK_BLOCKS ((2 * 9 * 4096 + 255) / 256)
+#ifdef __HIPCC__
+// U = G g G^T of one 3x3 kernel (Winograd F(2x2, 3x3)) for the pair (k, n) of the B operand [k][n], written in the order
+// the 8 waves of k_conv16_wino hold it in registers: Uf[ph][cg][p8][sq][lane][e] with lane = 16 kq + i16,
+// k = 4 (4 sq + e) + kq, n = 16 cg + i16; wave row ph: p8 < 4 <-> transform row 3 ph, p8 >= 4 <-> row 1 + ph; column p8 & 3
+__device__ __forceinline__ void wino_u(const float (&g)[3][3], float* __restrict__ U, int k, int n) {
+    float t[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        t[0][b] = g[0][b];
+        t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+        t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+        t[3][b] = g[2][b];
+    }
+    const int kq = k & 3, s4 = k >> 2, sq = s4 >> 2, e = s4 & 3, cg = n >> 4, i16 = n & 15;
+#pragma unroll
+    for (int i2 = 0; i2 < 4; ++i2) {
+        // transform row i2 lives in wave row ph = (i2 >= 2), as its X row (i2 = 0, 3) or its Y row (i2 = 1, 2)
+        const int ph = i2 >> 1, p8b = (i2 == 0 || i2 == 3) ? 0 : 4;
+        float* d = U + ((((size_t)(ph * 4 + cg) * 8 + p8b) * 4 + sq) * 64 + 16 * kq + i16) * 4 + e;
+        const size_t pstride = 4 * 64 * 4;          // p8 -> p8 + 1
+        d[0 * pstride] = t[i2][0];
+        d[1 * pstride] = 0.5f * (t[i2][0] + t[i2][1] + t[i2][2]);
+        d[2 * pstride] = 0.5f * (t[i2][0] - t[i2][1] + t[i2][2]);
+        d[3 * pstride] = t[i2][2];
+    }
+}
+// thread i of SED_PACK_BLOCKS x 256: one element of [layer][tap][ci][co] (+ one (k, n) pair of the Winograd panels)
+__device__ __forceinline__ void conv_pack_body(const ConvPackArgs& a, int i) {
+    if (i < a.n_zero) a.zero[i] = 0.0;                   // the forward's fp64 BatchNorm accumulators (saves a memset node)
+    if (i < 4 * 4096) {                              // Winograd panels: [layer][forward | dgrad]
+        const int which = i >> 12, kn = i & 4095, k = kn >> 6, n2 = kn & 63;
+        const float* w = (which >> 1) ? a.w2 : a.w1;
+        float* dst = (which >> 1) ? ((which & 1) ? a.wpkT2 : a.wpk2) : ((which & 1) ? a.wpkT1 : a.wpk1);
+        if (dst != nullptr) {
+            float g[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+                    // forward: B[k = ci][n = co] from g[a][b] = W[co][ci][a][b]; dgrad: B[k = co][n = ci] from the flipped kernel
+                    g[a][b] = (which & 1) ? w[(k * 64 + n2) * 9 + 3 * (2 - a) + (2 - b)] : w[(n2 * 64 + k) * 9 + 3 * a + b];
+            wino_u(g, dst + SED_WINO_OFF, k, n2);
+        }
+    }
+    const int layer = i / (9 * 4096);
+    i -= layer * 9 * 4096;
+    const float* w = layer ? a.w2 : a.w1;
+    float* wpk = layer ? a.wpk2 : a.wpk1;
+    float* wpkT = layer ? a.wpkT2 : a.wpkT1;
+    const int tap = i / 4096, ci = (i / 64) % 64, co = i % 64;
+    wpk[i] = w[(co * 64 + ci) * 9 + tap];
+    if (wpkT) {
+        // transposed conv for dgrad: wpkT[tap'][k = co][n = ci] = W[co][ci][8 - tap']
+        const int k = ci, n = co;      // reuse the index split: (i/64)%64 -> k, i%64 -> n
+        wpkT[i] = w[(k * 64 + n) * 9 + (8 - tap)];
+    }
+}
+#endif
+
+// packs conv1 and conv2 weights [co][ci][3][3] -> wpk [tap][ci][co] (+ flipped/transposed wpkT for dgrad) + Winograd panels
+int launch_conv_pack(const ConvPackArgs& a, hipStream_t st);
 // forward: y = conv(in) + bias; optional per-channel sum / sum-of-squares (fp64 atomics into stat[128])
 int launch_conv_fwd(const float* in, const float* wpk, const float* bias, float* y, double* stat, int zero_stat, int B,
                     int H, int W, hipStream_t st);

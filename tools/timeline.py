@@ -11,8 +11,8 @@ def main():
     back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     cur = sqlite3.connect(db).cursor()
     rows = list(cur.execute("select name, start, end, queue_id, stream_id from kernels order by start"))
-    # a step starts at each k_x_moments pair's first launch after a k_step_state_advance
-    adv = [i for i, r in enumerate(rows) if r[0].startswith("k_step_state_advance")]
+    # a step ends with its Adam + EMA kernel (the step state is advanced inside the loss / heads-backward kernel)
+    adv = [i for i, r in enumerate(rows) if "k_adam_ema" in r[0]]
     a, b = adv[-back - 1] + 1, adv[-back] + 1
     t0 = rows[a][1]
     print(f"step of {b - a} kernels, {(rows[b - 1][2] - t0) / 1e3:.1f} us")

@@ -372,6 +372,10 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
             SED_TRY(launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(pin[i]), WSF(W.wg_part), W.wgrad_blocks,
                                       grads + P.conv_w[i], g.B, Hs[i], Wd[i], pp, ss));
             if (parts == 3) {
+                // the head weight-gradient column sum (deferred from part 1): behind wgrad2, long before the tail of the step
+                // (queued right in front of wgrad1 it sat 60 us behind the persistent dgrad kernel and held wgrad1 back; at
+                // the very end of the side stream it was 4 us on the step's tail)
+                if (sd.ok) SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, ss));
                 SED_TRY(gru_weight_grads(ss));
             }
             SED_TRY(launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], pp, st));
@@ -380,9 +384,6 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
             SED_TRY(launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], pp, st));
             SED_TRY(launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(pin[i]), WSF(W.wg_part), W.wgrad_blocks,
                                       grads + P.conv_w[i], g.B, Hs[i], Wd[i], pp, ss));
-            // the head weight-gradient column sum (deferred from part 1) last: queued in front of wgrad1 it sat 60 us behind
-            // the persistent dgrad kernel and held wgrad1 back
-            if (parts == 3 && sd.ok) SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, ss));
         }
     }
     // ---- conv block 0 ---------------------------------------------------------------------------

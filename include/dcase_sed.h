@@ -232,9 +232,9 @@ int sed_postprocess(const float* strong, int n_clips, int T, int nclass, float t
  * sed_crnn_backward (same shapes, same data; outputs are rewritten with identical values), so
  * that a caller can bracket it with HIP events on `stream` (bench.py's roofline leg) and so that
  * tests can exercise one kernel at a time.  name is one of
- *   "blk0_fwd" "conv1_fwd" "glu1_fwd" "conv2_fwd" "glu2_fwd" "gru0_fwd" "gru1_fwd" "heads_fwd"
- *   "heads_bwd" "gru1_bwd" "gru0_bwd" "glu2_bwd" "conv2_wgrad" "conv2_dgrad" "glu1_bwd"
- *   "conv1_wgrad" "conv1_dgrad" "blk0_bwd". */
+ *   "x_moments" "blk0_fwd" "conv1_fwd" "glu1_fwd" "conv2_fwd" "glu2_fwd" "gru0_fwd" "gru1_fwd" "heads_fwd"
+ *   "gru1_bwd" "gru0_bwd" "glu2_bwd" "conv2_wgrad" "conv2_dgrad" "glu1_bwd" "conv1_wgrad" "conv1_dgrad" "blk0_bwd"
+ *   (the heads backward needs the loss inputs and is not replayable on its own). */
 int sed_kernel_replay(const char* name, const sed_dims* d, const float* params, const float* x,
                       const uint64_t* seed_dev, void* ctx, size_t ctx_bytes, float* grads, void* ws,
                       size_t ws_bytes, void* stream);

@@ -11,7 +11,7 @@ import bench  # noqa: E402
 from dcase2019_task4_amd import _lib  # noqa: E402
 from dcase2019_task4_amd.train import MeanTeacherStep  # noqa: E402
 
-ALL = ["blk0_fwd", "conv1_fwd", "glu1_fwd", "conv2_fwd", "glu2_fwd", "gru0_fwd", "gru1_fwd", "heads_fwd",
+ALL = ["x_moments", "blk0_fwd", "conv1_fwd", "glu1_fwd", "conv2_fwd", "glu2_fwd", "gru0_fwd", "gru1_fwd", "heads_fwd",
        "gru1_bwd", "gru0_bwd", "glu2_bwd", "conv2_wgrad", "conv2_dgrad", "glu1_bwd", "conv1_wgrad", "conv1_dgrad",
        "blk0_bwd"]
 

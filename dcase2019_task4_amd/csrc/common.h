@@ -91,7 +91,9 @@ struct WsLayout {
 };
 WsLayout make_ws_layout(const Geo& g);
 #define SED_WGRAD_MAX_BLOCKS 256
+#ifndef SED_GRU_SPLITK
 #define SED_GRU_SPLITK 16
+#endif
 // fp64 accumulators of k_glu_pool_bwd: [0,4096) dWglu[co][c]; [4096,4160) dbglu; [4160,4224) sum dz; [4224,4288) sum dz*y;
 // [4288] ticket of the last-workgroup epilogue (uint32 in a double slot); padded to a multiple of 8
 #define SED_GLUACC_N 4296

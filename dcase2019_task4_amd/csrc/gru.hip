@@ -121,16 +121,40 @@ __global__ __launch_bounds__(256) void k_gru_fwd(const float* __restrict__ x, co
             for (int r = 0; r < 4; ++r) gd[(4 * kq + r) * 192 + 16 * (gw * 6 + c) + i16] = acc[c][r] + bi[c];
     };
 
-    for (int e = tid; e < 192 * 64; e += 256) Wl[(e >> 6) * 68 + (e & 63)] = whh[e];
-    if (role == 1) {   // x of blocks 0 and 1
-        float v[GRU_SBF * XPL];
-        x_load(0, v); x_store(0, v);
-        if (nblk > 1) { x_load(1, v); x_store(1, v); }
+    // Prologue (10 us of fixed cost per launch, tools/gru_prologue.py, on the step's critical path four times): every wave
+    // issues ITS loads first - the I/O wave the x rows of blocks 0 and 1 (both before it stores either), the projection
+    // waves their W_ih fragments (above), the recurrence wave its biases - and only then do all of them stage W_hh
+    // (float4 loads); the recurrence wave gathers its weight rows from LDS while the projection waves compute block 0.
+    float xv0[GRU_SBF * XPL], xv1[GRU_SBF * XPL];
+    float bh_r = 0.f, bh_z = 0.f, bh_n = 0.f;
+    if (role == 1) {
+        x_load(0, xv0);
+        if (nblk > 1) x_load(1, xv1);
+    } else if (role == 0) {
+        bh_r = bhh[l]; bh_z = bhh[64 + l]; bh_n = bhh[128 + l];
+    }
+    for (int e4 = tid; e4 < 192 * 16; e4 += 256) *(v4f*)(Wl + (e4 >> 4) * 68 + 4 * (e4 & 15)) = *(const v4f*)(whh + 4 * e4);
+    if (role == 1) {
+        x_store(0, xv0);
+        if (nblk > 1) x_store(1, xv1);
     } else if (role == 0) {
         hs[l] = 0.f;
     }
     __syncthreads();
-    if (role >= 2) proj_block(0);
+    v2f wr[32], wz[32], wn[32];       // recurrence wave: rows l, 64+l, 128+l of W_hh
+    if (role >= 2) {
+        proj_block(0);
+    } else if (role == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const v4f a = *(const v4f*)(Wl + l * 68 + 4 * q);
+            const v4f c = *(const v4f*)(Wl + (64 + l) * 68 + 4 * q);
+            const v4f d = *(const v4f*)(Wl + (128 + l) * 68 + 4 * q);
+            wr[2 * q] = a.xy; wr[2 * q + 1] = a.zw;
+            wz[2 * q] = c.xy; wz[2 * q + 1] = c.zw;
+            wn[2 * q] = d.xy; wn[2 * q + 1] = d.zw;
+        }
+    }
     __syncthreads();
 
     if (role == 1) {
@@ -176,17 +200,6 @@ __global__ __launch_bounds__(256) void k_gru_fwd(const float* __restrict__ x, co
         return;
     }
     // ==================================== compute wave =======================================================
-    v2f wr[32], wz[32], wn[32];       // rows l, 64+l, 128+l of W_hh
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const v4f a = *(const v4f*)(Wl + l * 68 + 4 * q);
-        const v4f c = *(const v4f*)(Wl + (64 + l) * 68 + 4 * q);
-        const v4f d = *(const v4f*)(Wl + (128 + l) * 68 + 4 * q);
-        wr[2 * q] = a.xy; wr[2 * q + 1] = a.zw;
-        wz[2 * q] = c.xy; wz[2 * q + 1] = c.zw;
-        wn[2 * q] = d.xy; wn[2 * q + 1] = d.zw;
-    }
-    float bh_r = bhh[l], bh_z = bhh[64 + l], bh_n = bhh[128 + l];
     asm volatile("" : "+v"(bh_r), "+v"(bh_z), "+v"(bh_n));      // pin the waits for these loads before the loop
     float hprev = 0.f;
     for (int blk = 0; blk < nblk; ++blk) {
@@ -283,6 +296,10 @@ __global__ __launch_bounds__(256) void k_gru_bwd(const float* __restrict__ d_out
         for (int i = 0; i < 6 * GRU_SB; ++i) ops[(i / 6) * 384 + 64 * (i % 6) + l] = ((okm >> i) & 1ull) ? first[i] : 0.f;
     }
     __syncthreads();
+    // (Moving this barrier behind each role's own prologue loads - the W_hh column of the recurrence wave, the W_ih
+    // fragments of the dX waves - so that all of them are in flight together did not pay: fixed cost 9.0 -> 9.0 us,
+    // 10-17 ns more per step; tools/gru_prologue.py.  The fixed ~9 us per launch are launch + one load round trip +
+    // the fill and drain of the one-block-behind I/O and dX pipelines.)
 
     if (role == 1) {
         // ================================ I/O wave ==========================================================

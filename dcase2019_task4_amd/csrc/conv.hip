@@ -344,6 +344,10 @@ __global__ __launch_bounds__(512, 1) void k_conv16_ws2(const float* __restrict__
 //     ph = 0 wave adds, applies the bias, accumulates the BatchNorm sums and stores.
 // Rounding: the transforms use only additions and halvings; results differ from the direct kernel at the 1e-7 level
 // (parity tests unchanged).
+// Tried: wave = one transform row (4 positions) x 32 output channels instead of 8 positions x 16 channels - half the
+// input-transform work per wave (8 VALU + 8 LDS reads per 8 MFMAs; tools/ubench/wino_loop.cpp: 105 -> 119 TFLOP/s for the
+// bare loop) and the epilogue split evenly over the 8 waves, at the price of a 4-way exchange of the inverse-transform
+// partials (12 values out, 12 in per lane and MFMA tile).  Bit-correct, but no faster: 58.9 / 57.0 us vs 59.3 / 56.8 us.
 //   * TW = 4 (block 2: 157 x 4 images): one MFMA tile per workgroup tile (16 image rows x 4 columns), 240 tiles at
 //     B = 24 - one per workgroup, so the launch is mostly the weight prologue; still 2.5x faster than the 9-tap tile kernel.
 template <int TW_>

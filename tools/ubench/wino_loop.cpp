@@ -6,7 +6,7 @@
 #include <cstdlib>
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-template <int LDSR, int VALU, int MOVS>
+template <int LDSR, int VALU, int MOVS, int HALF = 0>
 __global__ __launch_bounds__(512, 1) void k(const float* __restrict__ U, const float* __restrict__ X, float* out,
                                             long long* cyc, int iters) {
     extern __shared__ float smem[];
@@ -31,7 +31,14 @@ __global__ __launch_bounds__(512, 1) void k(const float* __restrict__ U, const f
 #pragma unroll
         for (int s4 = 0; s4 < 16; ++s4) {
             float va[4], vb[4];
-            if (VALU) {
+            if (VALU && HALF) {       // one transform row per wave (4 positions x 32 output channels): 8 VALU, 8 LDS reads
+                float Xr[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Xr[q] = fmaf(sg, r[8 + q], r[q]);
+                va[0] = Xr[0] - Xr[2]; va[1] = Xr[1] + Xr[2]; va[2] = Xr[2] - Xr[1]; va[3] = Xr[1] - Xr[3];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) vb[q] = va[q];
+            } else if (VALU) {
                 float Xr[4], Yr[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { Xr[q] = r[q] - r[8 + q]; Yr[q] = fmaf(sg, r[8 + q], r[4 + q]); }
@@ -45,7 +52,8 @@ __global__ __launch_bounds__(512, 1) void k(const float* __restrict__ U, const f
             if (LDSR) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    r[q] = Pa[q * 66 + 4 * ((s4 + 1) & 15)]; r[4 + q] = Pm[q * 66 + 4 * ((s4 + 1) & 15)]; r[8 + q] = Pc[q * 66 + 4 * ((s4 + 1) & 15)];
+                    r[q] = Pa[q * 66 + 4 * ((s4 + 1) & 15)]; r[8 + q] = Pc[q * 66 + 4 * ((s4 + 1) & 15)];
+                    if (!HALF) r[4 + q] = Pm[q * 66 + 4 * ((s4 + 1) & 15)];
                 }
             } else if (MOVS) {
 #pragma unroll
@@ -103,5 +111,6 @@ int main() {
     run("MFMA + VALU", k<0, 1, 1>, U, X, out, cyc);
     run("MFMA + LDS reads", k<1, 0, 0>, U, X, out, cyc);
     run("MFMA + LDS reads + VALU (real)", k<1, 1, 0>, U, X, out, cyc);
+    run("MFMA + 8 LDS reads + 8 VALU", k<1, 1, 0, 1>, U, X, out, cyc);
     return 0;
 }

@@ -383,10 +383,19 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_bwd(const float* __restric
     __syncthreads();
     if (!is_last) return;
     __threadfence();
-    if (tid < 6) {
-        float s2 = 0.f;
-        for (int bb = 0; bb < B; ++bb) s2 += __builtin_nontemporal_load(&lpart[8 * bb + tid]);
-        red[tid] = s2;
+    {   // all per-clip partials in ONE round trip (a 6-thread loop over the clips paid one memory latency per clip), then
+        // six threads add them up in clip order
+        float* stage = dl + 128;                             // [8 * B] behind the wave partials (B <= 512; larger batches: loop)
+        const bool staged = 8 * B <= HD_TC * HD_SD - 128;
+        if (staged)
+            for (int e = tid; e < 8 * B; e += HD_THREADS) stage[e] = __builtin_nontemporal_load(&lpart[e]);
+        __syncthreads();
+        if (tid < 6) {
+            float s2 = 0.f;
+            if (staged) for (int bb = 0; bb < B; ++bb) s2 += stage[8 * bb + tid];
+            else for (int bb = 0; bb < B; ++bb) s2 += __builtin_nontemporal_load(&lpart[8 * bb + tid]);
+            red[tid] = s2;
+        }
     }
     __syncthreads();
     if (tid == 0) {

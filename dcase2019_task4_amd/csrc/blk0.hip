@@ -111,13 +111,6 @@ __global__ __launch_bounds__(PREP_THREADS) void k_blk0_prep(Blk0PrepArgs a) {
     __shared__ double mred[54][16];
     __shared__ double moms[54];
     const int tid = threadIdx.x;
-    // this thread's row of Wglu for the fold at the end, fetched NOW (16 float4 in flight under the partial-sum round trip;
-    // loaded inside the 64-step fold loop they were several more round trips of this one-workgroup kernel)
-    float4 wrow[16];
-    if (tid < 640) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) wrow[q] = *(const float4*)(a.wglu + (tid / 10) * 64 + 4 * q);
-    }
     if (a.train) {   // patch moments = fixed-order fp64 sum of the per-workgroup partials
         if (tid < 864) {
             const int k = tid / 16, j = tid % 16;
@@ -195,13 +188,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_blk0_prep(Blk0PrepArgs a) {
     if (tid < 640) {   // wl[c][t] = sum_k Wglu[c][k] wz[k][t] (+ bglu at t = 9): one thread per (c, t)
         const int c = tid / 10, t = tid % 10;
         double acc = (t == 9) ? (double)a.bglu[c] : 0.0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            acc += (double)wrow[q].x * wzs[4 * q][t];
-            acc += (double)wrow[q].y * wzs[4 * q + 1][t];
-            acc += (double)wrow[q].z * wzs[4 * q + 2][t];
-            acc += (double)wrow[q].w * wzs[4 * q + 3][t];
-        }
+        for (int k = 0; k < 64; ++k) acc += (double)a.wglu[c * 64 + k] * wzs[k][t];
         a.wl[c * 12 + t] = (float)acc;
     }
 }

@@ -250,7 +250,7 @@ def main():
         pmc_file = os.path.join(REPO, "profiles", "pmc_traffic.json")
         pmc_names = {"conv1_fwd": ("void k_conv_wino<16, 0>", "void k_conv16_ws2<0>", "void k_conv3x3<16, 0, 1>"),
                      "conv1_dgrad": ("void k_conv_wino<16, 1>", "void k_conv16_ws2<1>", "void k_conv3x3<16, 1, 1>"),
-                     "conv1_wgrad": ("k_wgrad16_wino", "k_wgrad16_db", "void k_conv3x3_wgrad<16, 1>")}[dom]
+                     "conv1_wgrad": ("void k_wgrad_wino<16>", "k_wgrad16_wino", "k_wgrad16_db", "void k_conv3x3_wgrad<16, 1>")}[dom]
         if os.path.exists(pmc_file):
             table = json.load(open(pmc_file))
             pmc = next((table[n] for n in pmc_names if n in table), None)

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wino(const float* __restrict__ 
     constexpr int NLD = (C::HALO_F4 + 511) / 512;
     constexpr int NH = (MODE == 1) ? 1 : (NLD + 1) / 2, PARTS = (NLD + NH - 1) / NH;
     f32x4_t pre0[NH], pre1[MODE == 1 ? NH : 1];
-    // (Row-wise staging as in k_wgrad16_wino - thread = column x 4 channels, ~10 instead of ~25 VALU per item, scalar-base
+    // (Row-wise staging as in k_wgrad_wino - thread = column x 4 channels, ~10 instead of ~25 VALU per item, scalar-base
     // loads, but 10 one-row items in 5 pieces instead of 6 in 2 - measured no better here: 60 / 58.5 vs 59 / 56.5 us.)
     // raw loads only (padding is applied when the values go to LDS: a select here would make the compiler wait for the
     // loads on the spot); item it = float4 number tid + 512 it of the halo
@@ -891,7 +891,8 @@ __global__ __launch_bounds__(256) void k_wgrad16_db(const float* __restrict__ dz
 // dW = G^T [ sum over 2x2 output blocks of (B^T d B) (.) (A dY A^T) ] G: 16 multiplies per block and (ci, co) pair instead
 // of 36, like the forward kernel.  Here BOTH operands need a transform, so they are transformed once into LDS (no
 // redundancy between waves) and the MFMAs read ready-made fragments:
-//   * tile = 8 image rows x 16 columns = 32 blocks = 8 k-steps of 4 blocks (K of v_mfma_f32_16x16x4_f32);
+//   * tile = 8 image rows x 16 columns = 32 blocks = 8 k-steps of 4 blocks (K of v_mfma_f32_16x16x4_f32); block 2 (TW = 4):
+//     16 rows x 4 columns = 16 blocks = 4 k-steps, one tile per workgroup at B = 24;
 //   * wave (cg, ph) accumulates dU[pos][co][ci] for its 8 positions (transform rows 3 ph and 1 + ph), all 64 co (4 M
 //     tiles, one ds_read_b128 per position thanks to the co' = 4 (co & 15) + (co >> 4) order) and its 16 ci (N tile cg):
 //     128 accumulator registers, 32 MFMAs per k-step for 8 + 8 LDS reads;
@@ -909,25 +910,37 @@ __global__ __launch_bounds__(256) void k_wgrad16_db(const float* __restrict__ dz
 #else
 #define TSW4(k) do { } while (0)
 #endif
+template <int TW_>
 struct WgW {
-    static constexpr int TH = 8, TW = 16, HW = 18, HH = 10, PS = 66, RS = HW * PS;
-    static constexpr int HALO_FLOATS = HH * RS, HALO_F4 = HH * HW * 16;
+    static constexpr int TW = TW_, BC = TW / 2;                        // block columns per image row
+    static constexpr int NKS = (TW == 16) ? 8 : 4;                     // k-steps (4 blocks each) per tile
+    static constexpr int TH = 2 * (4 * NKS / BC);                      // image rows per tile: 8 (TW 16), 16 (TW 4)
+    static constexpr int HW = TW + 2, HH = TH + 2, PS = 66, RS = HW * PS;
+    static constexpr int HALO_FLOATS = HH * RS;
+    static constexpr int RW = HW * 16, RPI = 512 / RW, NITEMS = (HH + RPI - 1) / RPI;   // row staging: TW 16: 288, 1, 10; TW 4: 96, 5, 4
     static constexpr int SV = 1040, SM = 1024;      // block strides: the b32 B reads of a half-wave (2 blocks) need SV = 16 mod 32
     static constexpr int OPS_FLOATS = 4 * SV + 4 * SM;                 // one k-step's operands
     static constexpr int OUT_STRIDE = 68;           // epilogue staging [tap][co][68]: 4 co rows apart = 16 banks apart
     static constexpr size_t MAIN_BYTES = (size_t)(2 * HALO_FLOATS + 2 * OPS_FLOATS) * 4;
     static constexpr size_t OUT_BYTES = (size_t)9 * 64 * OUT_STRIDE * 4;
     static constexpr size_t LDS_BYTES = MAIN_BYTES > OUT_BYTES ? MAIN_BYTES : OUT_BYTES;
+    // block cg (0..3) of k-step ks: blk = 4 ks + cg -> block row / column; split into a compile-time part (ks) and a
+    // wave-uniform part (cg)
+    __host__ __device__ static constexpr int br_ks(int ks) { return (4 * ks) / BC; }
+    __host__ __device__ static constexpr int bc_ks(int ks) { return (4 * ks) % BC; }
 };
-__global__ __launch_bounds__(512, 1) void k_wgrad16_wino(const float* __restrict__ dz, const float* __restrict__ yin,
+template <int TW>
+__global__ __launch_bounds__(512, 1) void k_wgrad_wino(const float* __restrict__ dz, const float* __restrict__ yin,
                                                          const float* __restrict__ coef, const float* __restrict__ xin,
                                                          float* __restrict__ part, int H, int tiles_per_clip, int n_tiles,
                                                          BnBwdPrepArgs prep) {
-    using C = WgW;
+    using C = WgW<TW>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* ops = smem + 2 * C::HALO_FLOATS;          // [2 buffers][Vs: 4 blocks x SV | Ms: 4 blocks x SM]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cg = wave & 3, ph = wave >> 2;
+    // block cg of a k-step relative to the k-step's first block: (row, column) offsets (wave-uniform)
+    const int cg_br = (TW == 16) ? 0 : (cg >> 1), cg_bc = (TW == 16) ? cg : (cg & 1);
     const int i16 = lane & 15, kq = lane >> 4;
     float ca, cb, cc;                                                              // transform role: lane = channel
     if (prep.acc != nullptr) bn_bwd_coef(prep, lane, ca, cb, cc);                  // (no k_bn_bwd_prep: see BnBwdPrepArgs)
@@ -936,20 +949,23 @@ __global__ __launch_bounds__(512, 1) void k_wgrad16_wino(const float* __restrict
     // thread, so everything but the row is a per-lane constant (a flat "item = tid + 512 i" split cost ~25 VALU per item
     // in div / mod / bounds arithmetic - 0.35 us per k-step that carried one).  Threads 288..511 duplicate columns 2..15
     // (same data to the same LDS address) instead of being masked: no divergent store for the compiler to sink the load into.
-    constexpr int NROW = C::HH, NH = 2;                                            // 10 rows, fetched two at a time
+    constexpr int NITEMS = C::NITEMS, NH = 2;                                      // items (1 or 5 halo rows each), fetched two at a time
     f32x4_t pre[NH];
-    const int hxl = tid >> 4, hx = hxl < C::HW ? hxl : hxl - 16, c4 = (tid & 15) * 4;
+    const int td = tid < C::RPI * C::RW ? tid : tid - (TW == 16 ? 256 : 480);      // left-over threads duplicate others
+    const int r_in = (C::RPI == 1) ? 0 : td / C::RW, hx = ((C::RPI == 1) ? td : td % C::RW) >> 4, c4 = (td & 15) * 4;
     const int ixc = hx - 1 < 0 ? 0 : (hx - 1 > C::TW - 1 ? C::TW - 1 : hx - 1);
     const uint32_t goff4 = (uint32_t)(ixc * 64 + c4) * 4u;                         // byte offset inside an image row
     const bool colok = hx >= 1 && hx <= C::TW;
     const int lds_off = hx * C::PS + c4;
-    auto load_row = [&](int b, int y0, int hy, f32x4_t& d0) {
+    auto load_row = [&](int b, int y0, int it, f32x4_t& d0) {
+        const int hy = it * C::RPI + r_in < C::HH ? it * C::RPI + r_in : C::HH - 1;  // rows past the halo: its last row again
         const int iy = y0 - 1 + hy;
-        const int iyc = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);                    // (uniform) always a valid row; masked when stored
+        const int iyc = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);                    // always a valid row; masked when stored
         const float* rowp = xin + (size_t)(b * H + iyc) * (C::TW * 64);
         d0 = *(const f32x4_t*)((const char*)rowp + goff4);
     };
-    auto store_row = [&](float* halo, int y0, int hy, const f32x4_t& s0) {
+    auto store_row = [&](float* halo, int y0, int it, const f32x4_t& s0) {
+        const int hy = it * C::RPI + r_in < C::HH ? it * C::RPI + r_in : C::HH - 1;
         const int iy = y0 - 1 + hy;
         const bool ok = colok && iy >= 0 && iy < H;
         const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
@@ -971,7 +987,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad16_wino(const float* __restrict
     auto load_dy = [&](int b, int y0, int ks, int slot) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int yy = y0 + 2 * (ks >> 1) + (q >> 1), xx = 2 * (4 * (ks & 1) + cg) + (q & 1);
+            const int yy = y0 + 2 * (C::br_ks(ks) + cg_br) + (q >> 1), xx = 2 * (C::bc_ks(ks) + cg_bc) + (q & 1);
             // rows past the image re-read the last row and are zeroed in the transform - by a multiplication: with a
             // select there the compiler threads the (uniform) condition back to here and branches around the loads, and
             // the control flow inside the unrolled loop made it shuffle the accumulators between registers
@@ -983,7 +999,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad16_wino(const float* __restrict
     };
     // input transform of block cg of k-step ks, channel lane: V = B^T d B -> Vs[cg][pos][lane]
     auto transform_v = [&](const float* halo, int ks, float* Vs) {
-        const float* P = halo + (2 * cg) * C::PS + lane + ((2 * (ks >> 1)) * C::RS + 8 * (ks & 1) * C::PS);   // (constant part -> instruction offset)
+        const float* P = halo + (2 * cg_br) * C::RS + (2 * cg_bc) * C::PS + lane + ((2 * C::br_ks(ks)) * C::RS + (2 * C::bc_ks(ks)) * C::PS);   // (constant part -> instruction offset)
         float T[4][4];
 #pragma unroll
         for (int b2 = 0; b2 < 4; ++b2) {
@@ -1005,7 +1021,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad16_wino(const float* __restrict
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float v = fmaf(ca, dzr[slot][q], fmaf(cb, yr[slot][q], cc));
-            dy[q] = v * ((y0 + 2 * (ks >> 1) + (q >> 1) < H) ? 1.f : 0.f);     // rows past the image contribute nothing
+            dy[q] = v * ((y0 + 2 * (C::br_ks(ks) + cg_br) + (q >> 1) < H) ? 1.f : 0.f);     // rows past the image contribute nothing
         }
         // R[i][x] = sum_y A[i][y] dY[y][x]
         const float R[4][2] = {{dy[0], dy[1]}, {dy[0] + dy[2], dy[1] + dy[3]}, {dy[0] - dy[2], dy[1] - dy[3]}, {-dy[2], -dy[3]}};
@@ -1037,12 +1053,12 @@ __global__ __launch_bounds__(512, 1) void k_wgrad16_wino(const float* __restrict
     int it_ts = 0;
     int tb = tile / tiles_per_clip, ty0 = (tile % tiles_per_clip) * C::TH;
     if (tile < n_tiles) {
-        f32x4_t first[NROW];
+        f32x4_t first[NITEMS];
 #pragma unroll
-        for (int hy = 0; hy < NROW; ++hy) load_row(tb, ty0, hy, first[hy]);
+        for (int hy = 0; hy < NITEMS; ++hy) load_row(tb, ty0, hy, first[hy]);
         if (ph) { load_dy(tb, ty0, 0, 0); load_dy(tb, ty0, 1, 1); }
 #pragma unroll
-        for (int hy = 0; hy < NROW; ++hy) store_row(smem, ty0, hy, first[hy]);
+        for (int hy = 0; hy < NITEMS; ++hy) store_row(smem, ty0, hy, first[hy]);
     }
     __syncthreads();
     if (tile < n_tiles) {                                    // operands of k-step 0 -> buffer 0
@@ -1061,37 +1077,40 @@ __global__ __launch_bounds__(512, 1) void k_wgrad16_wino(const float* __restrict
         const int nb_ = nxt / tiles_per_clip, ny0 = (nxt % tiles_per_clip) * C::TH;
         const float* halo = smem + cur * C::HALO_FLOATS;
         float* halo_nxt = smem + (cur ^ 1) * C::HALO_FLOATS;
+        constexpr int NKS = C::NKS, NPIECE = (NITEMS + NH - 1) / NH;       // NPIECE <= NKS - 2
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
+        for (int ks = 0; ks < NKS; ++ks) {
             // next tile's halo, two rows per k-step: rows 2 ks, 2 ks + 1 are fetched at the start of k-step ks (0..4) and stored
             // at the end of k-step ks + 1; complete before the barrier of k-step 6, because k-step 7 already transforms the
             // next tile's first blocks
             f32x4_t held[NH];
-            if (ks >= 1 && ks <= 5) {
+            if (ks >= 1 && ks <= NPIECE) {
 #pragma unroll
                 for (int k2 = 0; k2 < NH; ++k2) held[k2] = pre[k2];
             }
-            if (ks <= 4) {
+            if (ks < NPIECE) {
 #pragma unroll
-                for (int k2 = 0; k2 < NH; ++k2) load_row(nb_, ny0, 2 * ks + k2, pre[k2]);
+                for (int k2 = 0; k2 < NH; ++k2)
+                    if (NH * ks + k2 < NITEMS) load_row(nb_, ny0, NH * ks + k2, pre[k2]);
             }
             float* nb = ops + ((ks + 1) & 1) * C::OPS_FLOATS;                   // operands of the next k-step
             const float* cb2 = ops + (ks & 1) * C::OPS_FLOATS;
             // (one copy of the MFMA code between two uniform branches: with it inside both arms of an if / else the register
             // allocator spilled the accumulators)
             if (ph == 0) {
-                if (ks < 7) transform_v(halo, ks + 1, nb); else transform_v(halo_nxt, 0, nb);
+                if (ks < NKS - 1) transform_v(halo, ks + 1, nb); else transform_v(halo_nxt, 0, nb);
             }
             if (it_ts == 0 && ks == 2) { TS(3); TSW4(7); }
             mma(cb2, cb2 + 4 * C::SV);
             if (it_ts == 0 && ks == 2) { TS(4); TSW4(8); }
             if (ph == 1) {                                     // slot ks & 1 was consumed by the previous k-step's transform
-                if (ks < 6) load_dy(tb, ty0, ks + 2, ks & 1); else load_dy(nb_, ny0, ks - 6, ks & 1);
-                if (ks < 7) transform_m(ty0, ks + 1, (ks + 1) & 1, nb + 4 * C::SV); else transform_m(ny0, 0, 0, nb + 4 * C::SV);
+                if (ks < NKS - 2) load_dy(tb, ty0, ks + 2, ks & 1); else load_dy(nb_, ny0, ks - (NKS - 2), ks & 1);
+                if (ks < NKS - 1) transform_m(ty0, ks + 1, (ks + 1) & 1, nb + 4 * C::SV); else transform_m(ny0, 0, 0, nb + 4 * C::SV);
             }
-            if (ks >= 1 && ks <= 5) {
+            if (ks >= 1 && ks <= NPIECE) {
 #pragma unroll
-                for (int k2 = 0; k2 < NH; ++k2) store_row(halo_nxt, ny0, 2 * (ks - 1) + k2, held[k2]);
+                for (int k2 = 0; k2 < NH; ++k2)
+                    if (NH * (ks - 1) + k2 < NITEMS) store_row(halo_nxt, ny0, NH * (ks - 1) + k2, held[k2]);
             }
             if (it_ts == 0 && ks == 2) { TS(5); TSW4(9); }
             lds_barrier();
@@ -1245,19 +1264,22 @@ static int wgrad_launch_t(const float* dz, const float* yin, const float* coef, 
         attr_done = true;
     }
     const int tpc = (H + Cfg::TH - 1) / Cfg::TH, nt = B * tpc;
-    const int nb = nt < n_blocks ? nt : n_blocks;
+    int nb = nt < n_blocks ? nt : n_blocks;
     // block 1: the double-buffered kernel (15 % faster alone; in the step, next to dgrad on the other stream, 1.143 vs
     // 1.162 ms per step although its 154 KB of LDS keep any other workgroup off its CU); bit 3 of the debug knob = old
-    // block 1: Winograd-domain kernel (operator 76 us against 105 us for the direct double-buffered kernel, which bits 3 / 7
-    // of the debug knob bring back: bit 7 = k_wgrad16_db, bit 3 = the single-buffered tile kernel)
-    if (TW == 16 && TS == 1 && !(g_sed_debug & (8 | 128))) {
+    // default: Winograd-domain kernel (block 1: operator 65 us against 105 us for the direct double-buffered kernel); bits 3 / 7
+    // of the debug knob bring the direct kernels back (bit 7 = k_wgrad16_db for block 1, bit 3 = the tile kernel)
+    if (!(g_sed_debug & (8 | 128))) {
+        using CW = WgW<TW>;
         static bool attrw = false;
         if (!attrw) {
-            SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_wgrad16_wino, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WgW::LDS_BYTES));
+            SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_wgrad_wino<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CW::LDS_BYTES));
             attrw = true;
         }
         SED_CHECK_ARG((size_t)B * H * TW * 64 < ((size_t)1 << 31), "wgrad: image too large for 32-bit offsets");
-        k_wgrad16_wino<<<nb, 512, WgW::LDS_BYTES, st>>>(dz, yin, coef, xin, part, H, tpc, nt, pa);
+        const int tpcw = (H + CW::TH - 1) / CW::TH, ntw = B * tpcw;
+        nb = ntw < n_blocks ? ntw : n_blocks;
+        k_wgrad_wino<TW><<<nb, 512, CW::LDS_BYTES, st>>>(dz, yin, coef, xin, part, H, tpcw, ntw, pa);
     } else if (TW == 16 && TS == 1 && !(g_sed_debug & 8)) {
         static bool attr16 = false;
         if (!attr16) {

@@ -216,9 +216,9 @@ class MeanTeacherStep:
         elif not self.dp_split:
             # forward + loss + backward | all-reduce(all gradients) | update
             self._graph_a.replay() if graph else self._fwd_bwd()
-            w = sdist.allreduce_bucket(self.grads, 0, self.n, self.pg, async_op=True, force=True)
-            if w is not None:
-                w.wait()
+            # synchronous form: this torch runs it on the CURRENT stream (no hop to the process group's own stream and
+            # back: 28.9 vs 28.2 k clips/s with a one-rank group); there is nothing to overlap it with anyway
+            sdist.allreduce_bucket(self.grads, 0, self.n, self.pg, async_op=False, force=True)
             self._graph_b.replay() if graph else self._update()
         else:
             # forward + loss + backward part 1 | all-reduce(tail) || backward part 2 | all-reduce(head) | update

@@ -1,21 +1,26 @@
 """bench.py - 10-s clips/s of one mean-teacher train step on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1 without a launcher: spawns its own ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path over one synthetic batch already resident in HBM:
 teacher forward + student forward + BCE/MSE losses + student backward (+ gradient all-reduce over
 RCCL when N > 1) + fused Adam + EMA, exactly what baseline/main.py:84-157 does per batch.
-Workload (N=1): BASELINE.json configs[1] - mean-teacher CRNN of baseline/config.py:53-58, batch 24,
-precomputed log-mel [24,1,628,64] fp32 in HBM, dropout 0.5, BatchNorm in train mode for both models.
-N > 1: weak scaling, 24 clips per GPU, each rank keeps the [weak|unlabeled|strong] = [6|12|6]
-composition (main.py:238-247) and the flat gradient buffer is all-reduced once per step.
 
+Workloads (--config):
+  mt-f32 (default)  BASELINE.json configs[1]: mean-teacher CRNN of baseline/config.py:53-58, batch 24 per GPU,
+                    precomputed log-mel [24,1,628,64] fp32 in HBM, dropout 0.5, BatchNorm in train mode for both
+                    models.  N > 1: weak scaling, 24 clips per GPU, every rank keeps the [weak|unlabeled|strong] =
+                    [6|12|6] composition (main.py:238-247); the same run also times configs[3]'s 64 clips per GPU
+                    (global 512 at N = 8) and reports it under "config3_ddp".
+  waveform          configs[2]'s workload: the step from raw 16 kHz waveforms (STFT + mel + log + normalise on the
+                    GPU inside the timed region), batch 64.
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,19 +32,31 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 B_PER_GPU = 24
+B_CONFIG3 = 64
 T_FRAMES = 628
 N_MELS = 64
 
-# algorithmic work per clip: forward GEMM-shaped FLOPs and block-boundary bytes
-FWD_FLOP_PER_CLIP = {  # 2 * MACs
+# algorithmic work per clip: forward GEMM-shaped FLOPs (2 x MACs of the reference's operators)
+FWD_FLOP_PER_CLIP = {
     "conv0": 2 * 64 * 9 * 628 * 64, "glu0": 2 * 64 * 64 * 628 * 64,
     "conv1": 2 * 64 * 576 * 314 * 16, "glu1": 2 * 64 * 64 * 314 * 16,
     "conv2": 2 * 64 * 576 * 157 * 4, "glu2": 2 * 64 * 64 * 157 * 4,
 }
 STEP_FLOP_PER_CLIP = 3.432e9      # 4 x forward (teacher fwd + student fwd + 2x for backward)
 STEP_BYTES_PER_CLIP = 12.0e6      # 7 passes over the block-boundary tensors, fp32
-PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= the f32 vector peak)
 PEAK_HBM_GBS = 8000.0
+
+# kernel launches per mean-teacher step (profiles/r01_j_step_timeline.txt) - used to add the committed per-launch PMC
+# traffic figures up to a per-step figure
+LAUNCHES_PER_STEP = {
+    "k_x_moments": 2, "k_blk0_prep": 2, "k_blk0_fwd": 2, "void k_conv_wino<16, 0>": 2, "void k_conv_wino<4, 0>": 2,
+    "k_glu_pool_fwd": 4, "void k_gru_fwd<64>": 2, "void k_gru_fwd<128>": 2, "k_heads_fwd": 2, "k_heads_bwd": 1,
+    "void k_gru_bwd<128>": 1, "void k_gru_bwd<64>": 1, "k_glu_pool_bwd8": 2, "void k_wgrad_wino<4>": 1,
+    "void k_conv_wino<4, 1>": 1, "k_wgrad_reduce": 2, "k_colsum": 1, "k_gemm_batched": 2, "k_gemm_reduce": 2,
+    "void k_conv_wino<16, 1>": 1, "k_blk0_bwd": 1, "k_blk0_bwd_finalize": 1, "void k_wgrad_wino<16>": 1,
+    "void k_adam_ema<true>": 1,
+}
 
 
 def synthetic_batch(B, T, seed, device):
@@ -57,27 +74,32 @@ def synthetic_batch(B, T, seed, device):
     return x.to(device), xe.to(device), tgt.to(device), slice(nw), slice(B - nw, B)
 
 
-def build_models(device, seed):
+def weights_init_(m):
+    """weights_init (baseline/utils/utils.py:205-224): random init of the reference architecture."""
+    for mod in m.modules():
+        name = mod.__class__.__name__
+        if name.find('Conv2d') != -1:
+            torch.nn.init.xavier_uniform_(mod.weight, gain=np.sqrt(2)); mod.bias.data.fill_(0)
+        elif name.find('BatchNorm') != -1:
+            mod.weight.data.normal_(1.0, 0.02); mod.bias.data.fill_(0)
+        elif name.find('GRU') != -1:
+            for w in mod.parameters():
+                if len(w.size()) > 1:
+                    torch.nn.init.orthogonal_(w.data)
+        elif name.find('Linear') != -1:
+            mod.weight.data.normal_(0, 0.01); mod.bias.data.zero_()
+
+
+def build_models(device, seed, **over):
     from dcase2019_task4_amd.crnn import CRNN
     kw = dict(n_in_channel=1, nclass=10, attention=True, n_RNN_cell=64, n_layers_RNN=2, activation="glu", dropout=0.5,
               kernel_size=3 * [3], padding=3 * [1], stride=3 * [1], nb_filters=[64, 64, 64], pooling=list(3 * ((2, 4),)))
+    kw.update(over)
     torch.manual_seed(seed)
     models = []
     for _ in range(2):
         m = CRNN(**kw)
-        # weights_init (baseline/utils/utils.py:205-224): random init of the reference architecture
-        for mod in m.modules():
-            name = mod.__class__.__name__
-            if name.find('Conv2d') != -1:
-                torch.nn.init.xavier_uniform_(mod.weight, gain=np.sqrt(2)); mod.bias.data.fill_(0)
-            elif name.find('BatchNorm') != -1:
-                mod.weight.data.normal_(1.0, 0.02); mod.bias.data.fill_(0)
-            elif name.find('GRU') != -1:
-                for w in mod.parameters():
-                    if len(w.size()) > 1:
-                        torch.nn.init.orthogonal_(w.data)
-            elif name.find('Linear') != -1:
-                mod.weight.data.normal_(0, 0.01); mod.bias.data.zero_()
+        weights_init_(m)
         models.append(m.to(device).train())
     return models
 
@@ -98,9 +120,9 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(budget_s=45.0, max_steps=3):
-    """The oracle (oracle/ref_cpu.py, a torch-CPU port of the reference step) on this box's host
-    cores: B=24, T=628, one warm-up step + timed steps until `budget_s` is spent (a bounded sample)."""
+def cpu_baseline(budget_s=60.0, warm=2, timed_steps=5):
+    """The oracle (oracle/ref_cpu.py, a torch-CPU port of the reference step) on this box's host cores: B=24, T=628,
+    2 warm-up + 5 timed steps (SURVEY 8(d) / BASELINE.md section 3), cut short only if `budget_s` runs out."""
     from oracle import ref_cpu, synth
     cores = usable_cores()
     torch.set_num_threads(cores)
@@ -115,43 +137,92 @@ def cpu_baseline(budget_s=45.0, max_steps=3):
                 "drop_rnn": mk(B, T // 8, 128)}
     times = []
     t_start = time.perf_counter()
-    for it in range(max_steps + 1):
+    for it in range(warm + timed_steps):
         t0 = time.perf_counter()
         mt.step(x, xe, tgt, wm, sm, 10500, masks(2 * it), masks(2 * it + 1))     # mask draw timed like nn.Dropout's
         times.append(time.perf_counter() - t0)
         print(f"[cpu_baseline] step {it}: {times[-1]:.2f} s ({cores} threads)", file=sys.stderr, flush=True)
-        if it >= 1 and time.perf_counter() - t_start > budget_s:
+        if it >= warm and time.perf_counter() - t_start > budget_s:
             break
-    timed = times[1:] if len(times) > 1 else times
+    timed = times[warm:] if len(times) > warm else times[-1:]
     dt = float(np.mean(timed))
     return {"value": round(B / dt, 3), "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/ref_cpu.MeanTeacherOracle, B={B} T={T}, 1 warm-up + {len(timed)} timed steps, "
+            "sample": f"oracle/ref_cpu.MeanTeacherOracle, B={B} T={T}, {warm} warm-up + {len(timed)} timed steps, "
                       f"{dt:.2f} s/step, torch {torch.__version__} CPU threads={torch.get_num_threads()}"}
 
 
+def feature_path(device, n_clips=32):
+    """BASELINE.md section 3's feature-path line: waveform -> linear mel (sed_mel_spec) -> log / pad / normalise
+    (sed_logmel_transform) for 32 clips of 160 000 samples at 16 kHz, HIP-event timed on the launch stream, beside the
+    numpy restatement of the same path (oracle/features_np.py) on the host cores (bounded: 4 clips)."""
+    from dcase2019_task4_amd.features import FeatureConfig, FeatureExtractor, LogMelTransform
+    from oracle import features_np
+    fx = FeatureExtractor(FeatureConfig.baseline_16k(), device=device)
+    g = torch.Generator().manual_seed(5)
+    wave = (0.1 * torch.randn(n_clips, 160000, generator=g)).to(device)
+    tr = LogMelTransform(T_FRAMES, scaler=None, device=device)
+
+    def run():
+        return tr(fx.calculate_mel_spec_batch(wave))
+    run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    iters = 20
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    # algorithmic bytes: the waveform read once (fp32) + the feature tensor written once; the linear mel in between is
+    # written and read once more (two kernels)
+    by = n_clips * (160000 * 4 + 3 * T_FRAMES * N_MELS * 4)
+    w = wave[:4].cpu().numpy().astype(np.float64)
+    t0 = time.perf_counter()
+    for i in range(w.shape[0]):
+        m = features_np.calculate_mel_spec(w[i], 16000, 2048, 255, 64, 0.0, 8000.0)
+        features_np.transform_chain(m, T_FRAMES)
+    cpu_s = (time.perf_counter() - t0) / w.shape[0]
+    return {"gpu_clips_per_s": round(n_clips / ms * 1e3, 1), "ms_per_32_clips": round(ms, 3),
+            "hbm_gbs_algorithmic": round(by / ms * 1e-6, 1), "frac_of_hbm_peak": round(by / ms * 1e-6 / PEAK_HBM_GBS, 4),
+            "bound": "LDS/VALU (fp64 radix-4 FFT in LDS: 0.12 GFLOP fp64 per clip), far from the HBM roofline by design",
+            "cpu_clips_per_s": round(1.0 / cpu_s, 2), "cpu_kind": "port (oracle/features_np.py, numpy, 1 process)",
+            "cpu_sample": "4 clips of 160 000 samples"}
+
+
 def kernel_roofline(step, iters=20):
-    """HIP-event timing of the dominant kernels, each re-launched on the step's own buffers (same
-    shapes and data as in the timed region) on the current stream."""
+    """HIP-event timing of the step's main kernels, each re-launched on the step's own buffers (same shapes and data
+    as in the timed region) on the current stream.  Per kernel: reference ("effective") FLOPs - what the reference's
+    operator costs - AND executed FLOPs - what this kernel actually issues on the MFMA pipe (the Winograd kernels
+    issue 16/36 of a direct 3x3 convolution's multiplies; block 0 folds conv0 + BatchNorm + the GLU's Linear into
+    one K = 10 convolution)."""
     import ctypes as C
     from dcase2019_task4_amd import _lib
     l = _lib.lib()
     B = step.B
-    px1, px2 = B * 314 * 16, B * 157 * 4
-    algo = {  # name -> (flops, hbm bytes) per launch: algorithmic (reads of inputs + writes of outputs, once each)
-        "conv1_fwd": (B * FWD_FLOP_PER_CLIP["conv1"], 2 * px1 * 64 * 4 + 9 * 4096 * 4),
-        "conv1_dgrad": (B * FWD_FLOP_PER_CLIP["conv1"], 3 * px1 * 64 * 4 + 9 * 4096 * 4),
-        "conv1_wgrad": (B * FWD_FLOP_PER_CLIP["conv1"], 3 * px1 * 64 * 4),
-        "glu1_fwd": (B * FWD_FLOP_PER_CLIP["glu1"], px1 * 64 * 4 + px1 * 8 * 4),
-        "glu1_bwd": (3 * B * FWD_FLOP_PER_CLIP["glu1"], 2 * px1 * 64 * 4 + px1 * 8 * 4),
-        "blk0_fwd": (2 * B * FWD_FLOP_PER_CLIP["conv0"], B * 628 * 64 * 4 + px1 * 64 * 4),
-        "blk0_bwd": (4 * B * FWD_FLOP_PER_CLIP["conv0"], B * 628 * 64 * 4 + px1 * 64 * 4),
-        "conv2_fwd": (B * FWD_FLOP_PER_CLIP["conv2"], 2 * px2 * 64 * 4 + 9 * 4096 * 4),
-        "gru1_fwd": (B * 78 * 2 * 2 * 192 * 64, B * 78 * (384 + 128 + 512) * 4),
-        "gru1_bwd": (B * 78 * 2 * 2 * 192 * 64, B * 78 * (128 + 512 + 384 * 2 + 128) * 4),
+    px0, px1, px2 = B * 628 * 64, B * 314 * 16, B * 157 * 4
+    c1, c2 = B * FWD_FLOP_PER_CLIP["conv1"], B * FWD_FLOP_PER_CLIP["conv2"]
+    blk0_ref = B * (FWD_FLOP_PER_CLIP["conv0"] + FWD_FLOP_PER_CLIP["glu0"])
+    blk0_exec = px0 * 2 * 10 * 128             # one K = 10 convolution to 128 channels (lin | z) on the MFMA
+    gru_ref = lambda nin: B * 78 * 2 * 2 * 192 * (nin + 64)
+    algo = {  # name -> (reference flops, executed MFMA flops, algorithmic hbm bytes, bound, per-step launches, steps)
+        "conv1_fwd": (c1, c1 * 16 / 36, 2 * px1 * 64 * 4 + 9 * 4096 * 4, "mfma", 2),
+        "conv1_dgrad": (c1, c1 * 16 / 36, 3 * px1 * 64 * 4 + 9 * 4096 * 4, "mfma", 1),
+        "conv1_wgrad": (c1, c1 * 16 / 36, 3 * px1 * 64 * 4, "mfma", 1),
+        "conv2_fwd": (c2, c2 * 16 / 36, 2 * px2 * 64 * 4 + 9 * 4096 * 4, "mfma", 2),
+        "conv2_dgrad": (c2, c2 * 16 / 36, 3 * px2 * 64 * 4 + 9 * 4096 * 4, "mfma", 1),
+        "conv2_wgrad": (c2, c2 * 16 / 36, 3 * px2 * 64 * 4, "mfma", 1),
+        "glu1_fwd": (B * FWD_FLOP_PER_CLIP["glu1"], B * FWD_FLOP_PER_CLIP["glu1"], px1 * 64 * 4 + px1 * 8 * 4, "mfma+valu", 2),
+        "glu1_bwd": (3 * B * FWD_FLOP_PER_CLIP["glu1"], 3 * B * FWD_FLOP_PER_CLIP["glu1"], 2 * px1 * 64 * 4 + px1 * 8 * 4, "mfma+valu", 1),
+        "blk0_fwd": (blk0_ref, blk0_exec, B * 628 * 64 * 4 + px1 * 64 * 4, "valu", 2),
+        "blk0_bwd": (2 * blk0_ref, blk0_exec, B * 628 * 64 * 4 + px1 * 64 * 4, "valu", 1),
+        "gru0_fwd": (gru_ref(64), B * 78 * 2 * 2 * 192 * 64, B * 78 * (64 + 128 + 512) * 4, "latency", 2),
+        "gru1_fwd": (gru_ref(128), B * 78 * 2 * 2 * 192 * 128, B * 78 * (128 + 128 + 512) * 4, "latency", 2),
+        "gru1_bwd": (2 * gru_ref(128), B * 78 * 2 * 2 * 192 * 128, B * 78 * (128 + 512 + 384 * 2 + 128 + 256) * 4, "latency", 1),
+        "gru0_bwd": (2 * gru_ref(64), B * 78 * 2 * 2 * 192 * 64, B * 78 * (128 + 512 + 384 * 2 + 128 + 128) * 4, "latency", 1),
     }
     out = {}
     st = _lib.stream_ptr()
-    for name, (fl, by) in algo.items():
+    for name, (fl, fx, by, bound, per_step) in algo.items():
         def call():
             _lib.check(l.sed_kernel_replay(name.encode(), C.byref(step.dims), _lib.ptr(step.student._flat), _lib.ptr(step.x),
                                            step._seed_s, _lib.ptr(step.ctx_s), step.ctx_bytes, _lib.ptr(step.grads),
@@ -164,58 +235,54 @@ def kernel_roofline(step, iters=20):
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / iters
-        out[name] = {"us": round(us, 2), "tflops": round(fl / us * 1e-6, 2), "gbs": round(by / us * 1e-3, 1),
-                     "flops": int(fl), "bytes": int(by)}
+        row = {"us": round(us, 2), "launches_per_step": per_step, "bound": bound,
+               "effective_tflops": round(fl / us * 1e-6, 2), "executed_mfma_tflops": round(fx / us * 1e-6, 2),
+               "effective_frac_of_f32_peak": round(fl / us * 1e-6 / PEAK_F32_MFMA_TFLOPS, 4),
+               "executed_frac_of_f32_peak": round(fx / us * 1e-6 / PEAK_F32_MFMA_TFLOPS, 4),
+               "gbs": round(by / us * 1e-3, 1), "flops": int(fl), "executed_flops": int(fx), "bytes": int(by)}
+        if bound == "latency":
+            row["us_per_time_step"] = round(us / 78.0, 3)
+        out[name] = row
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch", type=int, default=B_PER_GPU)
-    args = ap.parse_args()
+def pmc_step_traffic():
+    """HBM bytes per step from the committed PMC passes (profiles/pmc_traffic.json, per launch: 2 x FETCH_SIZE +
+    WRITE_SIZE as MI355X_MICROARCH.md prescribes) times the launches per step."""
+    pmc_file = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if not os.path.exists(pmc_file):
+        return None, None
+    table = json.load(open(pmc_file))
+    total = 0
+    for k, n in LAUNCHES_PER_STEP.items():
+        if k in table:
+            total += n * (table[k]["read_bytes"] + table[k]["write_bytes"])
+    return total, table
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs a launcher providing WORLD_SIZE={args.gpus} "
-                         "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...)")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path is the only product path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    pg = None
-    if world > 1 or os.environ.get("SED_FORCE_DP") == "1":      # SED_FORCE_DP: one-rank RCCL group (path test on a 1-GPU box)
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        pg = dist.group.WORLD
 
-    from dcase2019_task4_amd.train import MeanTeacherStep
-    B = args.batch
-    student, teacher = build_models(device, seed=0)        # identical replicas on every rank
-    x, xe, tgt, wm, sm = synthetic_batch(B, T_FRAMES, 1000 + rank, device)
-    step = MeanTeacherStep(student, teacher, B, T_FRAMES, rampup_length=210 * 100 // 2, weak_mask=wm, strong_mask=sm,
-                           seed=1234 + rank, use_graph=not args.no_graph, process_group=pg)
-    step.load_batch(x, xe, tgt)
-    for _ in range(max(args.warmup, 3)):       # >= 3: two eager warm-ups + graph capture/first replay
-        step.run()
+def self_launch(args):
+    """--gpus N without a launcher: re-exec through torch.distributed.run (one rank per GPU, RCCL)."""
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but only {n_dev} GPU(s) are visible")
+    port = int(os.environ.get("MASTER_PORT", "0")) or (29500 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print(f"[bench] spawning {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd, env=env))
 
+
+def time_steps(step, steps, world, device):
     def barrier():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize(device)
-
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step.run()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
@@ -225,60 +292,144 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    return elapsed
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="mt-f32", choices=["mt-f32", "waveform"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the kernel table, feature-path and config3 legs")
+    ap.add_argument("--batch", type=int, default=None)
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path is the only product path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    pg = None
+    dist_info = None
+    if world > 1 or os.environ.get("SED_FORCE_DP") == "1":      # SED_FORCE_DP: one-rank RCCL group (path test on a 1-GPU box)
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        pg = dist.group.WORLD
+        dist_info = {"backend": dist.get_backend(pg), "world_size": dist.get_world_size(pg),
+                     "rccl": ".".join(str(v) for v in torch.cuda.nccl.version())}
+        if rank == 0:
+            print(f"[bench] process group up: {dist_info}", file=sys.stderr, flush=True)
+
+    from dcase2019_task4_amd.train import MeanTeacherStep
+    waveform = args.config == "waveform"
+    B = args.batch or (64 if waveform else B_PER_GPU)
+    student, teacher = build_models(device, seed=0)        # identical replicas on every rank
+    x, xe, tgt, wm, sm = synthetic_batch(B, T_FRAMES, 1000 + rank, device)
+    step = MeanTeacherStep(student, teacher, B, T_FRAMES, rampup_length=210 * 100 // 2, weak_mask=wm, strong_mask=sm,
+                           seed=1234, use_graph=not args.no_graph, process_group=pg)
+    step.load_batch(x, xe, tgt)
+    runner = step
+    if waveform:
+        from dcase2019_task4_amd.features import WaveformFrontEnd
+        g = torch.Generator().manual_seed(77 + rank)
+        wave = (0.1 * torch.randn(B, 160000, generator=g)).to(device)
+        from dcase2019_task4_amd.features import FeatureConfig
+        runner = WaveformFrontEnd(step, wave, FeatureConfig.baseline_16k())
+    for _ in range(max(args.warmup, 3)):       # >= 3: two eager warm-ups + graph capture/first replay
+        runner.run()
+    elapsed = time_steps(runner, args.steps, world, device)
     meters = step.meters()
     assert np.isfinite(meters["loss"]), meters
+
+    config3 = None
+    if world > 1 and not waveform and not args.no_extras and args.batch is None:
+        # BASELINE.json configs[3]: global batch 512 at N = 8 = 64 clips per GPU ([16|32|16] per rank)
+        s3, t3 = build_models(device, seed=0)
+        x3, xe3, tg3, wm3, sm3 = synthetic_batch(B_CONFIG3, T_FRAMES, 2000 + rank, device)
+        step3 = MeanTeacherStep(s3, t3, B_CONFIG3, T_FRAMES, rampup_length=210 * 100 // 2, weak_mask=wm3, strong_mask=sm3,
+                                seed=4321, use_graph=not args.no_graph, process_group=pg)
+        step3.load_batch(x3, xe3, tg3)
+        for _ in range(5):
+            step3.run()
+        n3 = max(50, args.steps // 4)
+        el3 = time_steps(step3, n3, world, device)
+        config3 = {"workload": "BASELINE.json configs[3]: 64 clips per GPU", "global_batch": B_CONFIG3 * world,
+                   "value": round(B_CONFIG3 * world * n3 / el3, 1), "unit": "clips/s", "ms_per_step": round(el3 / n3 * 1e3, 4),
+                   "steps": n3}
+        del step3
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         clips = B * world * args.steps / elapsed
         t_clip_us = elapsed / args.steps / B * 1e6
+        wl = ("mean-teacher CRNN train step from raw 16 kHz waveforms (STFT + mel + log + normalise on the GPU inside the "
+              f"timed region), batch {B} per GPU, fp32" if waveform else
+              f"mean-teacher CRNN train step (baseline/main.py config), batch {B} per GPU, precomputed log-mel "
+              f"[{B},1,628,64] fp32 resident in HBM, dropout 0.5")
         res = {
             "metric": "10-s clips/sec mean-teacher train step (64-mel x 628)",
             "value": round(clips, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "mean-teacher CRNN train step (baseline/main.py config), batch 24 per GPU, "
-                                   "precomputed log-mel [24,1,628,64] fp32 resident in HBM, dropout 0.5",
-                       "global_batch": B * world, "frames": T_FRAMES, "n_mels": N_MELS,
-                       "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
+            "config": {"workload": wl, "global_batch": B * world, "frames": T_FRAMES, "n_mels": N_MELS,
+                       "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
+                       "dp_schedule": step.dp_schedule if step.dp else None},
             "loss": round(meters["loss"], 5),
         }
-        kr = kernel_roofline(step)
-        mfma_kernels = ("conv1_fwd", "conv1_dgrad", "conv1_wgrad")       # the genuinely dense GEMM kernels
-        dom = max(mfma_kernels, key=lambda k: kr[k]["us"])
-        traffic, traffic_src = None, None
-        pmc_file = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        pmc_names = {"conv1_fwd": ("void k_conv_wino<16, 0>", "void k_conv16_ws2<0>", "void k_conv3x3<16, 0, 1>"),
-                     "conv1_dgrad": ("void k_conv_wino<16, 1>", "void k_conv16_ws2<1>", "void k_conv3x3<16, 1, 1>"),
-                     "conv1_wgrad": ("void k_wgrad_wino<16>", "k_wgrad16_wino", "k_wgrad16_db", "void k_conv3x3_wgrad<16, 1>")}[dom]
-        if os.path.exists(pmc_file):
-            table = json.load(open(pmc_file))
-            pmc = next((table[n] for n in pmc_names if n in table), None)
-            if pmc:
-                traffic = pmc["read_bytes"] + pmc["write_bytes"]
-                traffic_src = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench "
-                               "(2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes), per launch; measured offline, not in this run")
-        res["roofline"] = {
-            "bound": "mfma", "kernel": dom, "achieved": kr[dom]["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(kr[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-            "traffic_source": traffic_src, "algorithmic_bytes": kr[dom]["bytes"], "algorithmic_flops": kr[dom]["flops"],
-            "avg_launch_us": kr[dom]["us"],
-            "flop_convention": "algorithmic = the reference's direct 3x3 convolution FLOPs (2 x 9 x 64 x 64 per output pixel); "
-                               "the three block-1 convolution kernels run in the Winograd F(2x2,3x3) domain and issue 16/36 of those "
-                               "multiplies on the MFMA pipe, so 'achieved' is effective throughput against the f32 MFMA peak",
-            "timing": "HIP events on the launch stream around 20 re-launches of this kernel on the step's own "
-                      "buffers (sed_kernel_replay) right after the timed region; conv1_wgrad = k_wgrad16_db + its "
-                      "k_wgrad_reduce (the whole operator); the rocprofv3 table's 'last-20 avg' column shows the same "
-                      "launches kernel by kernel",
-            "whole_step": {"algorithmic_tflops": round(STEP_FLOP_PER_CLIP / t_clip_us * 1e-6, 2),
-                           "frac_of_f32_mfma_peak": round(STEP_FLOP_PER_CLIP / t_clip_us * 1e-6 / PEAK_F32_MFMA_TFLOPS, 4),
-                           "algorithmic_gbs": round(STEP_BYTES_PER_CLIP / t_clip_us * 1e-3, 1)},
-            "kernels": kr,
+        if dist_info:
+            res["distributed"] = dist_info
+        if config3:
+            res["config3_ddp"] = config3
+        whole_tflops = STEP_FLOP_PER_CLIP / t_clip_us * 1e-6
+        traffic, table = pmc_step_traffic()
+        roof = {
+            "bound": "mfma", "kernel": "whole step (39 kernels in one hipGraph)",
+            "achieved": round(whole_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(whole_tflops / PEAK_F32_MFMA_TFLOPS, 4),
+            "traffic": traffic if (world == 1 and not waveform and B == B_PER_GPU) else None,
+            "algorithmic_flops": int(STEP_FLOP_PER_CLIP * B), "algorithmic_bytes": int(STEP_BYTES_PER_CLIP * B),
+            "algorithmic_gbs": round(STEP_BYTES_PER_CLIP / t_clip_us * 1e-3, 1),
+            "definition": "SURVEY 8(d): 3.432 GFLOP per clip of reference GEMM-shaped work (4 x forward) / measured time per "
+                          "clip, against the f32 MFMA peak (the step is compute-bound: 286 FLOP/B); `traffic` = HBM bytes per "
+                          "step, per-launch PMC figures (profiles/pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, separate "
+                          "rocprofv3 --pmc passes of this bench, measured offline) x launches per step",
+            "flop_convention": "effective = the reference's operator FLOPs (direct 3x3 convolution, 64x64 GLU Linear per "
+                               "pixel); executed = what the kernel issues on the MFMA pipe (Winograd F(2x2,3x3): 16/36 of a "
+                               "direct convolution's multiplies; block 0: one K = 10 convolution to 128 channels). An "
+                               "effective fraction above 1 is an algorithmic saving, not MFMA utilisation - the executed "
+                               "fraction beside it is.",
         }
+        if not args.no_extras and not waveform:
+            kr = kernel_roofline(step)
+            dom = max(kr, key=lambda k: kr[k]["us"] * kr[k]["launches_per_step"])
+            roof["dominant_kernel"] = dict(kr[dom], name=dom,
+                                           chosen_by="largest (solo launch time x launches per step) of the table below")
+            roof["kernels"] = kr
+            roof["timing"] = ("whole step: wall clock around the K timed steps (barrier + synchronize on both sides); "
+                              "kernel table: HIP events on the launch stream around 20 re-launches of each kernel on the "
+                              "step's own buffers (sed_kernel_replay) after the timed region; conv*_wgrad = the Winograd "
+                              "wgrad kernel + its ordered partial-sum reduction (the whole operator)")
+        res["roofline"] = roof
+        if world == 1 and not args.no_extras:
+            try:
+                res["feature_path"] = feature_path(device)
+            except Exception as e:                      # the headline number must not depend on the extra leg
+                res["feature_path"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if pg is not None:
         import torch.distributed as dist
         dist.destroy_process_group()
 

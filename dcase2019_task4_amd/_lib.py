@@ -56,11 +56,14 @@ _SIGS = {
     "sed_step_state_init": (C.c_int, [_P, C.c_uint64, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
                                       C.c_double, C.c_double, _P]),
     "sed_step_state_advance": (C.c_int, [_P, _P]),
+    "sed_step_state_update": (C.c_int, [_P, C.c_uint64, C.c_double, C.c_int, _P]),
+    "sed_stream_prepare": (C.c_int, [_P]),
     "sed_mel_spec_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "sed_mel_spec": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_size_t, _P]),
     "sed_logmel_transform": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
     "sed_selftest": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "sed_debug_set": (C.c_int, [C.c_int]),
+    "sed_build_flags": (C.c_int, []),
     "sed_kernel_replay": (C.c_int, [C.c_char_p, C.POINTER(SedDims), _P, _P, _P, _P, C.c_size_t, _P, _P, C.c_size_t, _P]),
 }
 

@@ -106,6 +106,13 @@ class _CRNNFunction(torch.autograd.Function):
                                       _lib.ptr(cbuf), ctx_bytes, _lib.ptr(strong), _lib.ptr(weak), _lib.stream_ptr()),
                    "sed_crnn_forward")
         module._last_ctx = (cbuf, dims)          # test/debug hook (sed_crnn_ctx_view)
+        if ctx.needs_input_grad[1]:
+            raise _lib.SedError("the gradient w.r.t. the input features is not implemented (the reference never asks for "
+                                "it: main.py:91 feeds a plain batch tensor)")
+        if not train and any(ctx.needs_input_grad[4:]) and torch.is_grad_enabled():
+            # eval-mode autograd (running BatchNorm statistics, no dropout) is not on the hot path: refuse loudly rather
+            # than fail later in backward with a missing context
+            ctx.eval_mode = True
         need = train and any(ctx.needs_input_grad[4:])
         if need:
             ctx.module, ctx.dims, ctx.cbuf, ctx.seed_t = module, dims, cbuf, seed_t
@@ -116,6 +123,9 @@ class _CRNNFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_strong, d_weak):
         l = _lib.lib()
+        if getattr(ctx, "eval_mode", False):
+            raise _lib.SedError("backward through CRNN.forward needs module.train(): the eval-mode backward (running "
+                                "BatchNorm statistics) is not implemented")
         module, dims = ctx.module, ctx.dims
         (x,) = ctx.saved_tensors
         if ctx.flat_version != module._flat_gen:

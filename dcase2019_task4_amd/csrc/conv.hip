@@ -758,6 +758,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_wgrad(const float* __restrict__
     TS(13); TSC(15);
 }
 
+#ifdef SED_AB   // A/B baseline kernels: only in `make EXTRA=-DSED_AB` builds (the shipped library carries the product path only)
 // ---- block-1 wgrad with the staging hidden under the MFMAs ---------------------------------------------------
 // Phase timestamps of the kernel above at B = 24 (tools/ts_kernel.py): 18 us of MFMAs per tile (95 % of the
 // pipe's rate) but 7.7 us of staging in front of every tile - all 256 workgroups stage at the same moment, so the
@@ -886,6 +887,8 @@ __global__ __launch_bounds__(256) void k_wgrad16_db(const float* __restrict__ dz
         }
     TS(13); TSC(15);
 }
+
+#endif  // SED_AB
 
 // ---- block-1 wgrad in the Winograd domain -----------------------------------------------------------------------------
 // dW = G^T [ sum over 2x2 output blocks of (B^T d B) (.) (A dY A^T) ] G: 16 multiplies per block and (ci, co) pair instead
@@ -1225,28 +1228,45 @@ static int conv_launch_t(const float* in0, const float* in1, const float* coef, 
     return SED_OK;
 }
 
+#ifdef SED_AB
+#define SED_AB_FLAGS(mask) (g_sed_debug & (mask))
+#else
+#define SED_AB_FLAGS(mask) 0      // the direct (9-tap) A/B kernels are not compiled into the product library
+#endif
+extern "C" int sed_build_flags(void) {
+#ifdef SED_AB
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 int launch_conv_fwd(const float* in, const float* wpk, const float* bias, float* y, double* stat, int zero_stat, int B,
                     int H, int W, hipStream_t st) {
     if (stat && zero_stat) SED_CHECK_HIP(hipMemsetAsync(stat, 0, 128 * sizeof(double), st));
+#ifdef SED_AB
     const bool direct = (g_sed_debug & (2 | 64)) != 0;          // A/B timing only: the 9-tap kernels
-    if (W == 16) return !direct ? conv_wino_launch<16, 0>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, nullptr, st)
-               : (g_sed_debug & 2) ? conv_launch_t<16, 0, 1>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st)
-                                   : conv16_ws_launch<0>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st);
-    if (W == 4) return !direct ? conv_wino_launch<4, 0>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, nullptr, st)
-                               : conv_launch_t<4, 0, 2>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st);
+    if (direct && W == 16) return (g_sed_debug & 2) ? conv_launch_t<16, 0, 1>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st)
+                                                    : conv16_ws_launch<0>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st);
+    if (direct && W == 4) return conv_launch_t<4, 0, 2>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, st);
+#endif
+    if (W == 16) return conv_wino_launch<16, 0>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, nullptr, st);
+    if (W == 4) return conv_wino_launch<4, 0>(in, nullptr, nullptr, wpk, bias, y, stat, B, H, nullptr, st);
     sed_set_error("conv: unsupported width %d", W);
     return SED_ERR_UNSUPPORTED;
 }
 
 int launch_conv_dgrad(const float* dz, const float* yin, const float* coef, const float* wpkT, float* dx, int B, int H,
                       int W, const BnBwdPrepArgs* prep, hipStream_t st) {
+#ifdef SED_AB
     const bool direct = (g_sed_debug & (4 | 64)) != 0;          // A/B timing only: the 9-tap kernels
     SED_CHECK_ARG(!(direct && prep), "conv dgrad: in-kernel BatchNorm-backward coefficients need the Winograd kernel");
-    if (W == 16) return !direct ? conv_wino_launch<16, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, prep, st)
-               : (g_sed_debug & 4) ? conv_launch_t<16, 1, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st)
-                                   : conv16_ws_launch<1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st);
-    if (W == 4) return !direct ? conv_wino_launch<4, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, prep, st)
-                               : conv_launch_t<4, 1, 2>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st);
+    if (direct && W == 16) return (g_sed_debug & 4) ? conv_launch_t<16, 1, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st)
+                                                    : conv16_ws_launch<1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st);
+    if (direct && W == 4) return conv_launch_t<4, 1, 2>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st);
+#endif
+    if (W == 16) return conv_wino_launch<16, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, prep, st);
+    if (W == 4) return conv_wino_launch<4, 1>(dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, prep, st);
     sed_set_error("conv dgrad: unsupported width %d", W);
     return SED_ERR_UNSUPPORTED;
 }
@@ -1256,6 +1276,7 @@ static int wgrad_launch_t(const float* dz, const float* yin, const float* coef, 
                           int n_blocks, float* g_w, int B, int H, const BnBwdPrepArgs* prep, hipStream_t st) {
     BnBwdPrepArgs pa = {};
     if (prep) pa = *prep;
+#ifdef SED_AB
     using Cfg = WgCfg<TW>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -1265,11 +1286,14 @@ static int wgrad_launch_t(const float* dz, const float* yin, const float* coef, 
     }
     const int tpc = (H + Cfg::TH - 1) / Cfg::TH, nt = B * tpc;
     int nb = nt < n_blocks ? nt : n_blocks;
+#else
+    int nb = 0;
+#endif
     // block 1: the double-buffered kernel (15 % faster alone; in the step, next to dgrad on the other stream, 1.143 vs
     // 1.162 ms per step although its 154 KB of LDS keep any other workgroup off its CU); bit 3 of the debug knob = old
     // default: Winograd-domain kernel (block 1: operator 65 us against 105 us for the direct double-buffered kernel); bits 3 / 7
     // of the debug knob bring the direct kernels back (bit 7 = k_wgrad16_db for block 1, bit 3 = the tile kernel)
-    if (!(g_sed_debug & (8 | 128))) {
+    if (!SED_AB_FLAGS(8 | 128)) {
         using CW = WgW<TW>;
         static bool attrw = false;
         if (!attrw) {
@@ -1280,7 +1304,9 @@ static int wgrad_launch_t(const float* dz, const float* yin, const float* coef, 
         const int tpcw = (H + CW::TH - 1) / CW::TH, ntw = B * tpcw;
         nb = ntw < n_blocks ? ntw : n_blocks;
         k_wgrad_wino<TW><<<nb, 512, CW::LDS_BYTES, st>>>(dz, yin, coef, xin, part, H, tpcw, ntw, pa);
-    } else if (TW == 16 && TS == 1 && !(g_sed_debug & 8)) {
+    }
+#ifdef SED_AB
+    else if (TW == 16 && TS == 1 && !(g_sed_debug & 8)) {
         static bool attr16 = false;
         if (!attr16) {
             SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_wgrad16_db, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wg16::LDS_BYTES));
@@ -1290,6 +1316,7 @@ static int wgrad_launch_t(const float* dz, const float* yin, const float* coef, 
     } else {
         k_conv3x3_wgrad<TW, TS><<<dim3(nb, TS), 256, Cfg::LDS_BYTES, st>>>(dz, yin, coef, xin, part, B, H, tpc, nt, pa);
     }
+#endif
     SED_CHECK_LAUNCH();
     k_wgrad_reduce<<<9 * 4096 / 64, 256, 0, st>>>(part, nb, g_w);
     SED_CHECK_LAUNCH();
@@ -1298,7 +1325,7 @@ static int wgrad_launch_t(const float* dz, const float* yin, const float* coef, 
 
 int launch_conv_wgrad(const float* dz, const float* yin, const float* coef, const float* xin, float* part, int n_blocks,
                       float* g_w, int B, int H, int W, const BnBwdPrepArgs* prep, hipStream_t st) {
-    SED_CHECK_ARG(!(prep && W == 16 && (g_sed_debug & (8 | 128))), "conv wgrad: in-kernel BatchNorm-backward coefficients need the default kernels");
+    SED_CHECK_ARG(!(prep && W == 16 && SED_AB_FLAGS(8 | 128)), "conv wgrad: in-kernel BatchNorm-backward coefficients need the default kernels");
     if (W == 16) return wgrad_launch_t<16, 1>(dz, yin, coef, xin, part, n_blocks, g_w, B, H, prep, st);
     if (W == 4) return wgrad_launch_t<4, 3>(dz, yin, coef, xin, part, n_blocks, g_w, B, H, prep, st);
     sed_set_error("conv wgrad: unsupported width %d", W);

@@ -5,6 +5,9 @@
 //   (bnglu.hip)] x 2 -> 2-layer BiGRU (gru.hip: input projection + recurrence per layer) -> heads (heads.hip)
 // All launches go to the caller's stream; no allocation, no synchronisation.
 #include <stdarg.h>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <stdio.h>
 #include <string.h>
 #include "common.h"
@@ -163,25 +166,43 @@ extern "C" int sed_crnn_ctx_view(const sed_dims* d, const char* name, size_t* of
 
 // ---- side stream: weight-gradient work that is off the backward critical path ---------------------
 // The dX chain (heads -> GRU -> dgrad2 -> dgrad1 -> block 0) is serial; the GRU dW/db GEMMs and the conv
-// wgrads only feed the optimiser.  They are forked onto a second stream (created once, on the first
-// eager call) and joined before the call returns, so the caller still sees one stream-ordered op and a
-// hipGraph capture records the fork/join as graph edges.
+// wgrads only feed the optimiser.  They are forked onto a helper stream and joined before the call returns, so
+// the caller still sees one stream-ordered op and a hipGraph capture records the fork/join as graph edges.
+// One helper stream + fork/join event pair exists per (device, caller stream): two host threads (or two models on two
+// GPUs of one process) that call in on different streams never share events.  The pool is created under a mutex, on
+// first use or - preferably, so that nothing is created while the caller's stream is being captured -
+// by sed_stream_prepare(stream).
 struct SideStream {
     hipStream_t s = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
     bool ok = false;
 };
-static SideStream& side_stream() {
-    static SideStream ss;
-    if (!ss.ok) {
+static std::mutex g_side_mu;
+static std::map<std::pair<int, hipStream_t>, SideStream*> g_side;
+static SideStream& side_stream(hipStream_t caller) {
+    static SideStream none;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return none;
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    SideStream*& slot = g_side[std::make_pair(dev, caller)];
+    if (slot == nullptr) {
+        slot = new SideStream();
         // (default priority on purpose: a lowest-priority side stream, meant to let the critical-path kernels win the
         // CUs, made the replayed step 70 % slower - 1.79 vs 1.06 ms)
-        if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess &&
-            hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess)
-            ss.ok = true;
+        if (hipStreamCreateWithFlags(&slot->s, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&slot->fork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&slot->join, hipEventDisableTiming) == hipSuccess)
+            slot->ok = true;
     }
-    return ss;
+    return *slot;
+}
+extern "C" int sed_stream_prepare(void* stream) {
+    SideStream& sd = side_stream((hipStream_t)stream);
+    if (!sd.ok) {
+        sed_set_error("sed_stream_prepare: could not create the helper stream / events");
+        return SED_ERR_LAUNCH;
+    }
+    return SED_OK;
 }
 #define SIDE_FORK(main_st)                                          \
     do {                                                            \
@@ -266,7 +287,8 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
                               void* ws, size_t ws_bytes, int parts, void* stream, const HeadsLoss* hl) {
     SED_TRY(sed_validate_dims(d));
     SED_CHECK_ARG(params && x && ctx && (hl || (d_strong && d_weak)) && grads && ws, "sed_crnn_backward: null argument");
-    SED_CHECK_ARG(parts >= 1 && parts <= 3, "sed_crnn_backward: parts must be 1, 2 or 3");
+    SED_CHECK_ARG(parts == 1 || parts == 2 || parts == 3 || parts == 5 || parts == 8,
+                  "sed_crnn_backward: parts must be 1, 2, 3, 5 or 8");
     const Geo g = make_geo(d);
     const ParamOff P = make_param_off(g, nullptr);
     const CtxLayout L = make_ctx_layout(g);
@@ -279,8 +301,9 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
     SED_CHECK_ARG(!use_drop || seed_dev, "sed_crnn_backward: dropout enabled but seed_dev is null");
     hipStream_t st = (hipStream_t)stream;
     const int BT = g.B * g.T3;
-    SideStream& sd = side_stream();
+    SideStream& sd = side_stream(st);
     hipStream_t ss = sd.ok ? sd.s : st;       // without a side stream everything stays on the caller's
+    const bool defer_gru_w = (parts & 4) != 0;           // parts == 5: the caller runs them later (parts == 8)
     bool forked = false;
 
     if (parts & 1) {
@@ -290,7 +313,7 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
                              CTXF(L.logits_s), CTXF(L.den_sv), d_strong, d_weak, WSF(W.d_out), WSF(W.heads_part),
                              grads + P.dense_w, grads + P.dense_b, grads + P.soft_w, grads + P.soft_b, g.B, g.T3, g.NC,
                              use_drop, g.p, seed_dev, (parts & 2) ? WSD(W.bwd_acc) : nullptr, 2 * SED_GLUACC_N + 2 * 64 * 10,
-                             (parts & 2) && sd.ok ? 1 : 0, hl, st));
+                             ((parts & 2) && sd.ok) || defer_gru_w ? 1 : 0, hl, st));
     // ---- BiGRU ----------------------------------------------------------------------------------
     // The gradient w.r.t. each layer's input is produced INSIDE the recurrence kernel (two extra waves, one block of
     // steps behind), as two direction planes [2][B*T'][nin] that the consumer adds while loading: the layer below's
@@ -331,6 +354,13 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
     // its all-reduce can start): the GEMMs follow the dX chain on the caller's stream.  parts == 3: they are
     // deferred to the side stream of the conv-block backward below, where they overlap k_glu_pool_bwd.
     if (parts == 1) SED_TRY(gru_weight_grads(st));
+    if (parts == 8) {
+        // the weight-gradient tail of a parts == 5 call: head column sum + every GRU dW / db, on the CALLER's stream (which
+        // a data-parallel host makes a second stream, so that this bucket and its all-reduce overlap the conv backward)
+        SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, st));
+        SED_TRY(gru_weight_grads(st));
+        return SED_OK;
+    }
     if (!(parts & 2)) {
         if (forked) SIDE_JOIN(st);
         return SED_OK;
@@ -356,7 +386,11 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
     // BatchNorm-backward coefficients: derived by the conv dgrad / wgrad kernels themselves from the reduction sums (no
     // 1-workgroup k_bn_bwd_prep + launch gap between k_glu_pool_bwd and the dgrad, twice per step); bit 9 of the debug
     // knob, or any of the A/B conv kernels, brings the separate kernel back
+#ifdef SED_AB
     const bool fuse_prep = (g_sed_debug & (4 | 8 | 64 | 128 | 512)) == 0;
+#else
+    const bool fuse_prep = (g_sed_debug & 512) == 0;
+#endif
     BnBwdPrepArgs prep[3] = {};
     for (int i = 2; i >= 1; --i) {
         const BnBwdPrepArgs* pp = fuse_prep ? &prep[i] : nullptr;
@@ -407,7 +441,7 @@ extern "C" int sed_mt_loss_backward(const sed_dims* d, const float* params, cons
                                     sed_step_state* state_dev, int advance_state, float* losses, float* d_strong,
                                     float* d_weak, float* grads, void* ws, size_t ws_bytes, int parts, void* stream) {
     SED_CHECK_ARG(d && strong_ema && weak_ema && target && state_dev && losses, "sed_mt_loss_backward: null argument");
-    SED_CHECK_ARG(parts == 1 || parts == 3, "sed_mt_loss_backward: parts must include the heads (1 or 3)");
+    SED_CHECK_ARG(parts == 1 || parts == 3 || parts == 5, "sed_mt_loss_backward: parts must include the heads (1, 3 or 5)");
     SED_CHECK_ARG(weak_lo >= 0 && weak_hi <= d->B && weak_lo <= weak_hi && strong_lo >= 0 && strong_hi <= d->B &&
                       strong_lo <= strong_hi, "sed_mt_loss_backward: bad mask range");
     HeadsLoss hl = {strong_ema, weak_ema, target, weak_lo, weak_hi, strong_lo, strong_hi, state_dev, losses, d_strong, d_weak,

@@ -66,6 +66,13 @@ __global__ void k_step_state_advance(sed_step_state* s) {
     step_state_derive(s);
 }
 
+// flags bit 0: replace base_seed (and re-derive this step's dropout keys); bit 1: replace lr
+__global__ void k_step_state_update(sed_step_state* s, uint64_t base_seed, double lr, int flags) {
+    if (flags & 1) s->base_seed = base_seed;
+    if (flags & 2) s->lr = lr;
+    step_state_derive(s);
+}
+
 extern "C" int sed_adam_ema(int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                             float* ema_params, const sed_step_state* state_dev, float grad_scale, void* stream) {
     SED_CHECK_ARG(n > 0 && params && grads && exp_avg && exp_avg_sq && state_dev, "sed_adam_ema: bad argument");
@@ -95,6 +102,13 @@ extern "C" int sed_step_state_init(sed_step_state* state_dev, uint64_t base_seed
     SED_CHECK_ARG(state_dev, "sed_step_state_init: null state");
     k_step_state_init<<<1, 1, 0, (hipStream_t)stream>>>(state_dev, base_seed, rampup_length, lr, beta1, beta2, eps, ema_decay,
                                                         max_cons_cost);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}
+
+extern "C" int sed_step_state_update(sed_step_state* state_dev, uint64_t base_seed, double lr, int flags, void* stream) {
+    SED_CHECK_ARG(state_dev, "sed_step_state_update: null state");
+    k_step_state_update<<<1, 1, 0, (hipStream_t)stream>>>(state_dev, base_seed, lr, flags);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

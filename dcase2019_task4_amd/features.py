@@ -256,3 +256,44 @@ class LogMelTransform:
                                           _lib.ptr(seed_t), _lib.ptr(clean), _lib.ptr(noisy), _lib.stream_ptr()),
                    "sed_logmel_transform")
         return (clean, noisy) if self.noise else clean
+
+
+class WaveformFrontEnd:
+    """BASELINE.json configs[2]: the mean-teacher step fed from raw waveforms resident in HBM.  ``run()`` =
+    calculate_mel_spec for the whole batch (sed_mel_spec) -> the train-time transform chain with the teacher's noisy copy
+    (sed_logmel_transform, utils.py:397-412 with augment_type="noise") written straight into the step's input buffers
+    -> ``step.run()``.  Persistent buffers, no allocation and no host value inside ``run``: the noise key is the step's
+    device-side teacher seed, which advances with the step counter."""
+
+    def __init__(self, step, waves, cfg=None, scaler=None):
+        self.step = step
+        self.l = _lib.lib()
+        self.fx = FeatureExtractor(cfg or FeatureConfig.baseline_16k(), device=step.device)
+        c = self.fx.cfg
+        self.waves = torch.as_tensor(waves).to(step.device, torch.float32).contiguous()
+        n, ns = self.waves.shape
+        if n != step.B:
+            raise ValueError(f"{n} waveforms for a step of batch {step.B}")
+        self.n, self.ns, self.frames = n, ns, self.fx.n_frames(ns)
+        self.mel = torch.empty(n, self.frames, c.n_mels, device=step.device, dtype=torch.float32)
+        self.ws = torch.empty(self.l.sed_mel_spec_ws_bytes(n, ns, c.hop_length, c.n_window, c.n_mels), device=step.device,
+                              dtype=torch.uint8)
+        self.mean = self.std = None
+        if scaler is not None:
+            self.mean = torch.tensor(np.asarray(scaler.mean_), dtype=torch.float64, device=step.device)
+            self.std = torch.tensor(np.asarray(scaler.std_), dtype=torch.float64, device=step.device)
+
+    def features(self):
+        c = self.fx.cfg
+        st = self.step
+        _lib.check(self.l.sed_mel_spec(_lib.ptr(self.waves), self.n, self.ns, c.hop_length, c.n_window, None,
+                                       _lib.ptr(self.fx.mel_basis), c.n_mels, _lib.ptr(self.mel), _lib.ptr(self.ws),
+                                       self.ws.numel(), _lib.stream_ptr()), "sed_mel_spec")
+        _lib.check(self.l.sed_logmel_transform(_lib.ptr(self.mel), self.n, self.frames, c.n_mels, st.T, _lib.ptr(self.mean),
+                                               _lib.ptr(self.std), st._seed_t, _lib.ptr(st.x),
+                                               _lib.ptr(st.x_ema) if st.teacher is not None else None, _lib.stream_ptr()),
+                   "sed_logmel_transform")
+
+    def run(self):
+        self.features()
+        self.step.run()

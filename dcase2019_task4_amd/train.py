@@ -57,7 +57,7 @@ class MeanTeacherStep:
 
     def __init__(self, student, teacher, batch_size, n_frames, rampup_length, weak_mask, strong_mask, lr=1e-3,
                  betas=(0.9, 0.999), eps=1e-8, ema_decay=0.999, max_consistency_cost=2.0, seed=0, use_graph=True,
-                 process_group=None, overlap_streams=True):
+                 process_group=None, overlap_streams=True, dp_schedule=None):
         assert isinstance(student, CRNN) and (teacher is None or isinstance(teacher, CRNN))
         self.l = _lib.lib()
         self.student, self.teacher = student, teacher
@@ -81,10 +81,20 @@ class MeanTeacherStep:
         self.exp_avg = torch.zeros(n, **f32)
         self.exp_avg_sq = torch.zeros(n, **f32)
         self.state = torch.zeros(C.sizeof(_lib.SedStepState), device=dev, dtype=torch.uint8)
-        _lib.check(self.l.sed_step_state_init(_lib.ptr(self.state), int(seed) & (2 ** 64 - 1), int(rampup_length),
+        self.pg = process_group
+        self.world, self.rank = 1, 0
+        if process_group is not None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(process_group)
+            self.rank = dist.get_rank(process_group)
+        # every replica draws its OWN dropout masks / teacher noise: the rank is folded into the Philox base seed here
+        # (rank 0 keeps the user's seed, so a one-process run and rank 0 of a data-parallel run see the same stream)
+        self.seed_user = int(seed) & (2 ** 64 - 1)
+        _lib.check(self.l.sed_step_state_init(_lib.ptr(self.state), self._folded_seed(), int(rampup_length),
                                               float(lr), float(betas[0]), float(betas[1]), float(eps),
                                               float(ema_decay), float(max_consistency_cost), _lib.stream_ptr()),
                    "sed_step_state_init")
+        self.lr = float(lr)
         base = self.state.data_ptr()
         self._seed_s = C.c_void_p(base + _lib.SedStepState.seed_student.offset)
         self._seed_t = C.c_void_p(base + _lib.SedStepState.seed_teacher.offset)
@@ -107,29 +117,46 @@ class MeanTeacherStep:
         self.d_strong = torch.empty(self.B, self.T3, self.NC, **f32)
         self.d_weak = torch.empty(self.B, self.NC, **f32)
         self.losses = torch.zeros(8 + 8 * self.B + 8, **f32)          # SED_LOSS_FLOATS(B): meters | scratch
-        self.pg = process_group
-        self.world = 1
-        if process_group is not None:
-            import torch.distributed as dist
-            self.world = dist.get_world_size(process_group)
-        # the data-parallel schedule (split backward, bucketed all-reduce between graph segments); SED_FORCE_DP=1 takes
-        # it with a one-rank group too, so that the whole RCCL path can be exercised on a single-GPU box
+        # Data-parallel schedule (SED_FORCE_DP=1 takes it with a one-rank group too, so that the whole RCCL path can be
+        # exercised on a single-GPU box).
+        #   "overlap" (default): forward + loss + backward of heads/GRU (parts 5) | on a second stream: the tail bucket's
+        #       weight-gradient GEMMs (parts 8) then its all-reduce, OVERLAPPING | the conv-block backward (parts 2) on the
+        #       main stream | all-reduce of the conv bucket | Adam + EMA.  The GRU weight-gradient GEMMs stay off the
+        #       critical path (they used to be on it in round 1's "split" schedule: +70 us), and 60 % of the gradient
+        #       bytes cross xGMI while the conv backward (the longest part of the backward) is still computing.
+        #   "single": whole backward (parts 3) | ONE all-reduce of the flat gradient buffer | update.  Nothing overlaps.
+        #   SED_DP_CAPTURE=1 (RCCL only): the collectives are captured INTO the hipGraph, the whole step is one replay.
         self.dp = process_group is not None and (self.world > 1 or os.environ.get("SED_FORCE_DP") == "1")
-        # "single" (default): whole backward in one call / graph, ONE all-reduce of the flat gradient buffer (857 KB),
-        # then the update.  "split": backward part 1 | all-reduce(GRU + heads bucket) overlapping part 2 | all-reduce
-        # (conv bucket) | update - measured slower: to finish the first bucket early the GRU weight-gradient GEMMs
-        # must run on the critical path (+70 us) instead of next to the conv backward, and the step gains a third
-        # graph segment; at these message sizes the all-reduce it hides is latency-bound (tens of us).
-        self.dp_split = os.environ.get("SED_DP_SCHEDULE", "single") == "split"
+        sched = dp_schedule or os.environ.get("SED_DP_SCHEDULE", "overlap")
+        if sched == "split":
+            sched = "overlap"
+        if sched not in ("overlap", "single"):
+            raise ValueError(f"unknown data-parallel schedule {sched!r}")
+        self.dp_schedule = sched
+        self.dp_capture = self.dp and os.environ.get("SED_DP_CAPTURE") == "1"
+        self._dp_stream = torch.cuda.Stream(device=dev) if self.dp else None
+        # train_cnn=False (CRNN.py:18-20, main.py:289-290 filters the optimiser's parameters on requires_grad): the conv
+        # blocks' backward is skipped and their gradient stays zero, which makes Adam's update of those entries exactly
+        # zero (zero moments, no weight decay) while the EMA still covers every parameter (main.py:45-49 zips ALL of them)
+        frozen = [not p.requires_grad for p in student.parameters()]
+        self.cnn_frozen = all(frozen[:18]) and not any(frozen[18:])
+        if any(frozen) and not self.cnn_frozen:
+            raise NotImplementedError("MeanTeacherStep supports all parameters trainable, or the whole CNN frozen "
+                                      "(train_cnn=False); other requires_grad patterns are not implemented")
         if process_group is not None:
-            # replicas must start identical (the reference has one copy; DDP convention: rank 0 wins)
-            sdist.broadcast_parameters([student._flat] + ([teacher._flat] if teacher is not None else []), process_group)
+            self.sync_replicas()
         self.use_graph = bool(use_graph)
         self.overlap = bool(overlap_streams)
         self._side = torch.cuda.Stream(device=dev) if (self.overlap and teacher is not None) else None
         self._graph_a = None
-        self._graph_a2 = None
+        self._graph_w = None
+        self._graph_c = None
         self._graph_b = None
+        # graphs are captured on a stream of our own whose library helper stream exists BEFORE the capture starts
+        self._cap_stream = torch.cuda.Stream(device=dev)
+        for st in (torch.cuda.current_stream(dev), self._cap_stream, self._side, self._dp_stream):
+            if st is not None:
+                _lib.check(self.l.sed_stream_prepare(C.c_void_p(st.cuda_stream)), "sed_stream_prepare")
         self._buckets = sdist.grad_buckets(student._layout)
         self._warm = 0
         self.steps_done = 0
@@ -160,7 +187,12 @@ class MeanTeacherStep:
         # (sed_mt_loss as a kernel of its own was 12 us on the critical path).  One process: the whole backward
         # (parts = 3), which lets the library overlap the GRU weight gradients with the conv-block backward;
         # data-parallel "split": part 1 here, part 2 after its bucket's all-reduce has been started (run())
-        parts = 1 if (self.dp and self.dp_split) else 3
+        if self.cnn_frozen:
+            parts = 1
+        elif self.dp and self.dp_schedule == "overlap":
+            parts = 5
+        else:
+            parts = 3
         _lib.check(self.l.sed_mt_loss_backward(C.byref(self.dims), _lib.ptr(self.student._flat), _lib.ptr(self.x),
                                                self._seed_s, _lib.ptr(self.ctx_s), self.ctx_bytes,
                                                _lib.ptr(self.strong_ema), _lib.ptr(self.weak_ema), _lib.ptr(self.target),
@@ -185,15 +217,82 @@ class MeanTeacherStep:
         # (no sed_step_state_advance: the loss / heads-backward kernel of this step already moved the counters on and
         # left the update's own fields derived for this step - sed_mt_loss_backward(advance_state = 1))
 
-    def _allreduce_tail(self):
-        """GRU + heads gradients are complete after backward part 1: start their all-reduce now so it
-        runs over xGMI while the conv-block backward (part 2) is still computing."""
-        (lo, hi), _ = self._buckets
-        return sdist.allreduce_bucket(self.grads, lo, hi, self.pg, async_op=True)
+    def _folded_seed(self):
+        return (self.seed_user + self.rank * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
 
-    def _allreduce_head(self):
-        _, (lo, hi) = self._buckets
-        return sdist.allreduce_bucket(self.grads, lo, hi, self.pg, async_op=True)
+    def sync_replicas(self, src=0):
+        """Every replica starts from rank ``src``'s parameters, BatchNorm buffers, Adam moments and step counters (the
+        reference has one copy of each; DDP convention: rank 0 wins) - e.g. after rank 0 loaded a checkpoint - and
+        then re-folds its own rank into the dropout seed."""
+        ts = [self.student._flat, self.student._bn_flat, self.student._bn_tracked, self.exp_avg, self.exp_avg_sq, self.state]
+        if self.teacher is not None:
+            ts += [self.teacher._flat, self.teacher._bn_flat, self.teacher._bn_tracked]
+        sdist.broadcast_parameters(ts, self.pg, src=src)
+        _lib.check(self.l.sed_step_state_update(_lib.ptr(self.state), self._folded_seed(), 0.0, 1, _lib.stream_ptr()),
+                   "sed_step_state_update")
+
+    def set_lr(self, lr):
+        """Honour an optimiser whose lr changed between epochs (main.py never does; utils.adjust_learning_rate exists)."""
+        if float(lr) != self.lr:
+            self.lr = float(lr)
+            _lib.check(self.l.sed_step_state_update(_lib.ptr(self.state), 0, self.lr, 2, _lib.stream_ptr()),
+                       "sed_step_state_update")
+
+    def _allreduce(self, lo, hi, async_op):
+        return sdist.allreduce_bucket(self.grads, lo, hi, self.pg, async_op=async_op, force=True)
+
+    def _dp_tail(self):
+        """Second stream: weight gradients of the GRU + heads bucket (parts 8), then that bucket's all-reduce - both
+        while the main stream runs the conv-block backward."""
+        _lib.check(self.l.sed_crnn_backward(C.byref(self.dims), _lib.ptr(self.student._flat), _lib.ptr(self.x),
+                                            self._seed_s, _lib.ptr(self.ctx_s), self.ctx_bytes,
+                                            _lib.ptr(self.d_strong), _lib.ptr(self.d_weak), _lib.ptr(self.grads),
+                                            _lib.ptr(self.ws), self.ws_bytes, 8, _lib.stream_ptr()), "sed_crnn_backward")
+
+    def _dp_step_eager_collectives(self, graph):
+        """One data-parallel step with the collectives issued between graph segments (any backend)."""
+        (tlo, thi), (hlo, hhi) = self._buckets
+        if self.dp_schedule == "single" or self.cnn_frozen:
+            self._graph_a.replay() if graph else self._fwd_bwd()
+            # synchronous form: this torch runs it on the CURRENT stream (no hop to the process group's own stream and back)
+            if self.cnn_frozen:
+                self._allreduce(tlo, thi, False)
+            else:
+                self._allreduce(0, self.n, False)
+            self._graph_b.replay() if graph else self._update()
+            return
+        cur = torch.cuda.current_stream()
+        self._graph_a.replay() if graph else self._fwd_bwd()                  # ... backward of heads + GRU (parts 5)
+        self._dp_stream.wait_stream(cur)
+        with torch.cuda.stream(self._dp_stream):
+            self._graph_w.replay() if graph else self._dp_tail()              # tail weight gradients (parts 8)
+            w1 = self._allreduce(tlo, thi, True)                              # tail bucket over xGMI ...
+        self._graph_c.replay() if graph else self._backward(2)                # ... while the conv blocks run backward
+        w2 = self._allreduce(hlo, hhi, True)
+        if w2 is not None:
+            w2.wait()
+        with torch.cuda.stream(self._dp_stream):
+            if w1 is not None:
+                w1.wait()
+        cur.wait_stream(self._dp_stream)
+        self._graph_b.replay() if graph else self._update()
+
+    def _dp_step_body(self):
+        """The same schedule as straight-line stream code (what SED_DP_CAPTURE=1 captures into ONE graph)."""
+        (tlo, thi), (hlo, hhi) = self._buckets
+        self._fwd_bwd()
+        if self.dp_schedule == "single" or self.cnn_frozen:
+            self._allreduce(tlo if self.cnn_frozen else 0, thi if self.cnn_frozen else self.n, False)
+        else:
+            cur = torch.cuda.current_stream()
+            self._dp_stream.wait_stream(cur)
+            with torch.cuda.stream(self._dp_stream):
+                self._dp_tail()
+                self._allreduce(tlo, thi, False)
+            self._backward(2)
+            self._allreduce(hlo, hhi, False)
+            cur.wait_stream(self._dp_stream)
+        self._update()
 
     # ---- public ------------------------------------------------------------------------------------
     def load_batch(self, x, x_ema, target):
@@ -213,23 +312,10 @@ class MeanTeacherStep:
             else:
                 self._fwd_bwd()
                 self._update()
-        elif not self.dp_split:
-            # forward + loss + backward | all-reduce(all gradients) | update
-            self._graph_a.replay() if graph else self._fwd_bwd()
-            # synchronous form: this torch runs it on the CURRENT stream (no hop to the process group's own stream and
-            # back: 28.9 vs 28.2 k clips/s with a one-rank group); there is nothing to overlap it with anyway
-            sdist.allreduce_bucket(self.grads, 0, self.n, self.pg, async_op=False, force=True)
-            self._graph_b.replay() if graph else self._update()
+        elif self.dp_capture:
+            self._graph_a.replay() if graph else self._dp_step_body()
         else:
-            # forward + loss + backward part 1 | all-reduce(tail) || backward part 2 | all-reduce(head) | update
-            self._graph_a.replay() if graph else self._fwd_bwd()
-            w1 = self._allreduce_tail()
-            self._graph_a2.replay() if graph else self._backward(2)
-            w2 = self._allreduce_head()
-            for w in (w1, w2):
-                if w is not None:
-                    w.wait()
-            self._graph_b.replay() if graph else self._update()
+            self._dp_step_eager_collectives(graph)
         self._warm += 1
         self.steps_done += 1
 
@@ -240,27 +326,43 @@ class MeanTeacherStep:
 
     def _capture(self):
         torch.cuda.synchronize(self.device)
-        if self.dp:
-            ga, ga2, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
+        cap = dict(stream=self._cap_stream)
+        if self.dp and not self.dp_capture:
+            overlap = self.dp_schedule == "overlap" and not self.cnn_frozen
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga, **cap):
                 self._fwd_bwd()
-            if self.dp_split:
-                with torch.cuda.graph(ga2):
+            if overlap:
+                gw, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gw, **cap):
+                    self._dp_tail()
+                with torch.cuda.graph(gc, **cap):
                     self._backward(2)
-            with torch.cuda.graph(gb):
+                self._graph_w, self._graph_c = gw, gc
+            with torch.cuda.graph(gb, **cap):
                 self._update()
-            self._graph_a, self._graph_a2, self._graph_b = ga, ga2, gb
+            self._graph_a, self._graph_b = ga, gb
         else:
             ga = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
-                self._fwd_bwd()
-                self._update()
+            with torch.cuda.graph(ga, **cap):
+                if self.dp:
+                    self._dp_step_body()
+                else:
+                    self._fwd_bwd()
+                    self._update()
             self._graph_a = ga
         # capture executes nothing: the captured work runs on replay
 
-    def meters(self):
-        """The meters main.train logs (main.py:106-149); ONE device->host copy."""
-        return dict(zip(LOSS_NAMES, self.losses[:8].tolist()))
+    def meters(self, reduce=False):
+        """The meters main.train logs (main.py:106-149); ONE device->host copy.  They are rank-local (each rank's share
+        of the batch); ``reduce=True`` averages them over the process group - equal shares, so this is the meter of the
+        global batch."""
+        m = self.losses[:8].clone()
+        if reduce and self.pg is not None and self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(m, op=dist.ReduceOp.SUM, group=self.pg)
+            m /= self.world
+        return dict(zip(LOSS_NAMES, m.tolist()))
 
     def read_state(self):
         raw = bytes(self.state.cpu().numpy().tobytes())
@@ -298,6 +400,7 @@ class MeanTeacherStep:
                                for k, v in self.teacher.state_dict().items()} if self.teacher is not None else None),
                 "optimizer": self.optimizer_state_dict(),
                 "step_state": bytes(self.state.cpu().numpy().tobytes()),
+                "seed_user": self.seed_user,
                 "steps_done": self.steps_done}
 
     def load_state_dict(self, sd):
@@ -312,7 +415,11 @@ class MeanTeacherStep:
         raw = np.frombuffer(sd["step_state"], dtype=np.uint8).copy()
         assert raw.size == self.state.numel(), "step state size mismatch"
         self.state.copy_(torch.from_numpy(raw))
+        self.seed_user = int(sd.get("seed_user", self.seed_user))
         self.steps_done = int(sd.get("steps_done", 0))
+        if self.rank != 0:       # the file holds rank 0's stream; every other rank re-folds its own rank into the seed
+            _lib.check(self.l.sed_step_state_update(_lib.ptr(self.state), self._folded_seed(), 0.0, 1, _lib.stream_ptr()),
+                       "sed_step_state_update")
         torch.cuda.synchronize(self.device)
 
     def save_checkpoint(self, path, extra=None):
@@ -325,7 +432,7 @@ class MeanTeacherStep:
 
 
 def train(train_loader, model, optimizer, epoch, ema_model=None, weak_mask=None, strong_mask=None, n_epoch=100,
-          log=print):
+          log=print, check_every=50):
     """main.train (main.py:52-165) with the loop body replaced by MeanTeacherStep.  With ``ema_model=None`` and
     two-element batches ``(batch_input, target)`` it is main_simple_CRNN.train (main_simple_CRNN.py:31-82).
 
@@ -335,6 +442,13 @@ def train(train_loader, model, optimizer, epoch, ema_model=None, weak_mask=None,
     step_obj = getattr(model, "_mt_step", None)
     it = iter(train_loader)
     n_batches = len(train_loader)
+    pg0 = optimizer.param_groups[0]
+
+    def check(m):
+        loss = m["loss"]
+        assert not (loss != loss or loss > 1e5), 'Loss explosion: {}'.format(loss)       # main.py:147
+        assert not loss < 0, 'Loss problem, cannot be negative'                            # main.py:148
+
     for i in range(n_batches):
         batch = next(it)
         if ema_model is None:
@@ -343,7 +457,6 @@ def train(train_loader, model, optimizer, epoch, ema_model=None, weak_mask=None,
             batch_input, ema_batch_input, target = batch
         if step_obj is None:
             B, T = batch_input.shape[0], batch_input.shape[-2]
-            pg0 = optimizer.param_groups[0]
             dev = torch.device("cuda", torch.cuda.current_device())
             model.to(dev)
             if ema_model is not None:
@@ -351,13 +464,17 @@ def train(train_loader, model, optimizer, epoch, ema_model=None, weak_mask=None,
             step_obj = MeanTeacherStep(model, ema_model, B, T, n_batches * n_epoch // 2, weak_mask, strong_mask,
                                        lr=pg0["lr"], betas=pg0["betas"], eps=pg0["eps"])
             model._mt_step = step_obj
+        if i == 0:
+            step_obj.set_lr(pg0["lr"])        # an lr the caller changed between epochs is honoured (utils.py:227-241)
         step_obj.step(batch_input.to(step_obj.device, non_blocking=True),
                       ema_batch_input.to(step_obj.device, non_blocking=True) if ema_batch_input is not None else None,
                       target.to(step_obj.device, non_blocking=True))
+        # the reference asserts on the loss after EVERY batch (main.py:147-148), which costs it a host sync per step;
+        # here the meters are read back every `check_every` steps and after the last one
+        if (i + 1) % check_every == 0:
+            check(step_obj.meters())
     m = step_obj.meters()
-    loss = m["loss"]
-    assert not (loss != loss or loss > 1e5), 'Loss explosion: {}'.format(loss)       # main.py:147
-    assert not loss < 0, 'Loss problem, cannot be negative'                            # main.py:148
+    check(m)
     log('Epoch: {}\tTime {:.2f}\t{}'.format(epoch, time.time() - start,
                                             "\t".join(f"{k} {v:.4g}" for k, v in m.items())))
     return m

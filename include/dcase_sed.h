@@ -105,13 +105,18 @@ int sed_crnn_forward(const sed_dims* d, const float* params, float* bn_running, 
  *   d_strong/d_weak  gradients w.r.t. the two outputs
  *   grads            flat, same layout as params; OVERWRITTEN with dLoss/dparams
  *   ws               scratch, sed_crnn_bwd_ws_bytes(d)
- *   parts            bit 0: heads + BiGRU (writes the rnn/dense tail of grads), bit 1: conv blocks
- *                    (writes the cnn head of grads; needs bit 0 to have run on the same ws).
- *                    3 = whole backward.  Splitting lets a data-parallel caller start the
- *                    all-reduce of the tail bucket while the conv blocks are still running.
- * Concurrency: the library forks its weight-gradient kernels onto ONE process-wide side stream (created on first
- * use on the current device, event fork/join, capturable); use it from one caller stream at a time per process -
- * the one-process-per-GPU model of the host side. */
+ *   parts            3 = whole backward (what a single-GPU caller uses).  A data-parallel caller splits it so that
+ *                    the all-reduce of the GRU + heads gradient bucket overlaps the conv-block backward:
+ *                      1  heads + BiGRU incl. their weight gradients (the rnn/dense tail of grads is complete)
+ *                      5  heads + BiGRU data-gradient chain only; the tail's weight gradients are left to a
+ *                         later parts = 8 call on the same ws (any stream ordered after this call)
+ *                      8  the weight gradients deferred by 5 (head column sum + GRU dW/db GEMMs)
+ *                      2  conv blocks (the cnn head of grads; needs 1 or 5 to have run on the same ws)
+ * Concurrency: the library forks its weight-gradient kernels onto a helper stream it owns - one helper stream and one
+ * fork/join event pair per (device, caller stream), created under a mutex by sed_stream_prepare(stream) or on first
+ * use (event fork/join, capturable) - so calls on different caller streams, from different host threads or on
+ * different devices never share state.  Call sed_stream_prepare for a stream BEFORE capturing it into a hipGraph. */
+int sed_stream_prepare(void* stream);
 size_t sed_crnn_bwd_ws_bytes(const sed_dims* d);
 int sed_crnn_backward(const sed_dims* d, const float* params, const float* x, const uint64_t* seed_dev,
                       void* ctx, size_t ctx_bytes, const float* d_strong, const float* d_weak,
@@ -170,6 +175,11 @@ int sed_step_state_init(sed_step_state* state_dev, uint64_t base_seed, int64_t r
                         double lr, double beta1, double beta2, double eps, double ema_decay,
                         double max_cons_cost, void* stream);
 int sed_step_state_advance(sed_step_state* state_dev, void* stream);
+/* Change the user-settable fields of a live state and re-derive the fields of the CURRENT step: flags bit 0 = base_seed
+ * (a data-parallel rank folds its rank into the seed so that replicas draw different dropout masks, also after a
+ * checkpoint written by rank 0 was loaded), bit 1 = lr (baseline/main.py:289 sets it once; adjust_learning_rate,
+ * utils/utils.py:227-241, is dead code in main.py:81 but an optimizer whose lr changed between epochs is honoured). */
+int sed_step_state_update(sed_step_state* state_dev, uint64_t base_seed, double lr, int flags, void* stream);
 
 /* ---- feature front-end ---------------------------------------------------------------------
  * sed_mel_spec replaces DatasetDcase2019Task4.calculate_mel_spec (DatasetDcase2019Task4.py:
@@ -248,6 +258,9 @@ int sed_kernel_replay(const char* name, const sed_dims* d, const float* params, 
  *   bit 9: BatchNorm-backward coefficients by the 1-workgroup kernel k_bn_bwd_prep instead of in the prologue of the conv
  *   dgrad / wgrad kernels (also implied by bits 2, 3, 6, 7).  Kept for A/B timing (profiles/README.md). */
 int sed_debug_set(int flags);
+/* bit 0: the library was built with the A/B baseline kernels (make EXTRA=-DSED_AB); without it debug bits 1, 2, 3, 6, 7
+ * are ignored - the shipped library carries the product path only. */
+int sed_build_flags(void);
 
 /* ---- self tests (run on the GPU box by tests/) ---------------------------------------------
  * Checks the MFMA fragment mapping and Philox stream this build assumes. out[0..3] receives

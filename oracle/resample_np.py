@@ -7,6 +7,13 @@ is in this image, so this file restates resampy's published algorithm (resampy/f
 resampy/interpn.py ``resample_f``, resampy/core.py ``resample``) - **parity unpinned**; the kaiser_best parameters are
 the ones resampy generated its shipped table with (num_zeros 64, precision 9, rolloff 0.9475937167399596, Kaiser beta
 14.769656459379492).
+
+Which librosa uses which resampler (from librosa's changelog; matters to anyone re-generating features today):
+  * librosa 0.6.x - 0.9.x: ``resample(..., res_type='kaiser_best')`` is the default  -> this file.
+  * librosa >= 0.10.0: the default became ``res_type='soxr_hq'`` (libsoxr); ``kaiser_best`` is still available on
+    request (and needs resampy installed).  A reference checkout run against librosa >= 0.10 therefore resamples with
+    a DIFFERENT filter than the one restated here; the reference's README ("librosa >= 0.6.3", 2019) predates 0.10.
+The STFT / mel / dB restatements in features_np.py are unaffected by this version split.
 """
 import numpy as np
 import scipy.signal

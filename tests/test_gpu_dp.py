@@ -1,0 +1,127 @@
+"""-m gpu: the data-parallel mean-teacher step at WORLD SIZE 2 - two processes, MeanTeacherStep itself on each.
+
+On the one-GPU box both ranks share cuda:0 and talk over gloo (which moves CUDA tensors through host memory); on a box
+with >= 2 GPUs they take one GPU each and talk over nccl (= RCCL).  Checks, for both schedules, eager and hipGraph:
+  * the all-reduced gradient equals the SUM of the two ranks' single-process gradients (each rank also runs a plain
+    single-process step on its own shard with the same rank-folded dropout seed), i.e. the update uses their mean;
+  * the replicas (student, teacher, Adam moments) stay bit-identical over 5 steps although every rank sees different
+    clips and different dropout masks;
+  * the batch is sharded stream-wise (dist.shard_batch: main.py:238-247's [weak|unlabeled|strong] contract).
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, schedule, graph, out):
+    if REPO not in sys.path:
+        sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    from dcase2019_task4_amd import dist as sdist
+    from dcase2019_task4_amd.train import MeanTeacherStep
+    from oracle import synth
+    from tests import gpu_util as gu
+    n_dev = torch.cuda.device_count()
+    backend = "nccl" if n_dev >= world else "gloo"
+    dev = torch.device("cuda", rank if n_dev >= world else 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        Bg, T = 16, 128
+        sizes = [Bg // 4, Bg // 2, Bg // 4]
+        tgt_g, _, _ = synth.make_target(1, Bg, T // 8)
+        wm, sm = sdist.local_masks(sizes, world)
+        B = Bg // world
+        steps = 5
+        batches = []
+        for i in range(steps):
+            xg, xeg = synth.make_input(60 + i, Bg, T), synth.make_input(70 + i, Bg, T)
+            batches.append([t.to(dev) for t in sdist.shard_batch([xg, xeg, tgt_g], sizes, rank, world)])
+
+        def models(s0, s1):
+            s, _ = gu.make_model(s0, dropout=0.5, device=dev)
+            t, _ = gu.make_model(s1, dropout=0.5, device=dev)
+            s.train(); t.train()
+            return s, t
+        # single-process step on this rank's shard, same folded seed as the data-parallel rank will use
+        s1, t1 = models(0, 1)
+        fold = (1234 + rank * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
+        ref = MeanTeacherStep(s1, t1, B, T, 40, wm, sm, seed=fold, use_graph=False)
+        ref.step(*batches[0])
+        torch.cuda.synchronize()
+        g_local = ref.grads.clone()
+        gl = [torch.zeros_like(g_local) for _ in range(world)]
+        dist.all_gather(gl, g_local)
+        g_sum = sum(gl[1:], gl[0].clone())
+        # data-parallel: rank 1 starts from DIFFERENT weights - the constructor must broadcast rank 0's
+        s2, t2 = models(0, 1) if rank == 0 else models(7, 8)
+        dp = MeanTeacherStep(s2, t2, B, T, 40, wm, sm, seed=1234, use_graph=graph, process_group=dist.group.WORLD,
+                             dp_schedule=schedule)
+        assert dp.dp and dp.world == world and dp.rank == rank
+        if graph:
+            dp._warm = 2
+        dp.step(*batches[0])
+        torch.cuda.synchronize()
+        err = float((dp.grads - g_sum).abs().max())
+        scale = float(g_sum.abs().max())
+        assert err <= 2e-6 * scale + 1e-9, ("all-reduced gradient != sum of the single-rank gradients", err, scale)
+        # after step 1 the student is what the single-process update would be with the MEAN gradient
+        for i in range(1, steps):
+            dp.step(*batches[i])
+        torch.cuda.synchronize()
+        for name, t in (("student", s2._flat), ("teacher", t2._flat), ("exp_avg", dp.exp_avg), ("exp_avg_sq", dp.exp_avg_sq)):
+            tl = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(tl, t.contiguous())
+            for r in range(1, world):
+                assert torch.equal(tl[0], tl[r]), f"replicas diverged: {name}"
+        st = dp.read_state()
+        assert st.global_step == steps
+        m_loc, m_glob = dp.meters(), dp.meters(reduce=True)
+        ml = [None] * world
+        dist.all_gather_object(ml, m_loc["loss"])
+        assert abs(m_glob["loss"] - sum(ml) / world) < 1e-6
+        # different ranks really drew different masks / saw different clips
+        sl = [torch.zeros_like(dp.strong) for _ in range(world)]
+        dist.all_gather(sl, dp.strong)
+        assert not torch.equal(sl[0], sl[1])
+        if rank == 0:
+            out.put(("ok", backend, err / (scale + 1e-30)))
+    except Exception as e:      # surface the failure in the parent
+        import traceback
+        out.put(("fail", rank, traceback.format_exc()))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("schedule,graph", [("overlap", False), ("overlap", True), ("single", True)])
+def test_mean_teacher_step_world2(schedule, graph):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    port = 29600 + (os.getpid() + hash((schedule, graph))) % 300
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, schedule, graph, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    alive = [p for p in procs if p.is_alive()]
+    for p in alive:
+        p.kill()
+    assert not alive, "data-parallel worker hung"
+    msgs = []
+    while not out.empty():
+        msgs.append(out.get())
+    fails = [m for m in msgs if m[0] == "fail"]
+    assert not fails, fails[0][2]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    ok = [m for m in msgs if m[0] == "ok"]
+    assert ok, "rank 0 reported nothing"
+    print(f"[dp world 2] backend {ok[0][1]} schedule {schedule} graph {graph}: |allreduce - sum| / max = {ok[0][2]:.2e}")

@@ -135,7 +135,8 @@ def _check_grads(g_hip, go):
         worst = max(worst, rel)
         print(f"[grad] {n:40s} |g| {gn:.3e}  max|err| {err:.3e}  err/typ {rel:.3e}")
         assert float(g_hip[n].double().norm()) == pytest.approx(gn, rel=2e-3), n
-        np.testing.assert_allclose(g_hip[n].numpy(), g.numpy(), rtol=5e-3, atol=5e-3 * scale, err_msg=n)
+        # measured <= 2e-4 of the typical magnitude; the bound leaves 5x
+        np.testing.assert_allclose(g_hip[n].numpy(), g.numpy(), rtol=1e-3, atol=1e-3 * scale, err_msg=n)
     return worst
 
 
@@ -148,6 +149,8 @@ def test_winograd_kernels_match_the_direct_convolution_kernels(B, T):
     T = 150 / 22: odd image heights, tiles cut by the image border, fewer tiles than workgroups."""
     from dcase2019_task4_amd import _lib
     l = _lib.lib()
+    if not (l.sed_build_flags() & 1):
+        pytest.skip("A/B baseline kernels are not in the product build (make EXTRA=-DSED_AB)")
     outs = []
     for flags in (0, 64 | 128):
         prev = l.sed_debug_set(flags)
@@ -174,13 +177,16 @@ def test_winograd_kernels_match_the_direct_convolution_kernels(B, T):
 @pytest.mark.parametrize("B,T,p,n_layers,nclass", [(4, 128, 0.0, 2, 10), (4, 128, 0.5, 2, 10), (4, 628, 0.5, 2, 10),
                                                    (5, 216, 0.5, 1, 10), (4, 150, 0.25, 2, 10), (7, 1040, 0.5, 2, 10),
                                                    (4, 864, 0.5, 2, 10), (6, 96, 0.5, 2, 1), (5, 200, 0.5, 2, 16),
-                                                   (4, 630, 0.5, 2, 10), (9, 100, 0.5, 2, 10), (4, 22, 0.5, 2, 10)])
+                                                   (4, 630, 0.5, 2, 10), (9, 100, 0.5, 2, 10), (4, 22, 0.5, 2, 10),
+                                                   (24, 628, 0.5, 2, 10), (4, 629, 0.5, 2, 10), (3, 151, 0.5, 2, 10)])
 def test_train_forward_backward_vs_oracle(B, T, p, n_layers, nclass):
     """Posteriors, loss, every parameter gradient and the BN running stats against the oracle, with
     dropout ON (same Philox masks on both sides).  T=150 exercises odd H (rows dropped by the pool); T=1040 gives
     130 output frames (more than one 128-frame chunk in the heads kernels) with a batch that is not a multiple of
     4; T=864 is the reference's own frame count (config.py:17-22); nclass 1 and 16 are the ABI's limits; T=630 / 100 / 22
-    are not multiples of 8 (every pooling floor drops rows; 22 frames leave 2 GRU steps - less than one step block)."""
+    are not multiples of 8 (every pooling floor drops rows; 22 frames leave 2 GRU steps - less than one step block);
+    (24, 628) is the headline shape of BASELINE.json configs[1] itself; T = 629 / 151 are ODD frame counts (the first
+    pool already drops an input row)."""
     hip, orc = _fwd_bwd_both(B, T, p, seed=123456789, n_layers=n_layers, nclass=nclass)
     es, _ = gu.report("strong", hip[0], orc[0])
     ew, _ = gu.report("weak", hip[1], orc[1])
@@ -523,15 +529,21 @@ def test_step_is_bitwise_reproducible_run_to_run(B, T, graph, reps):
             assert torch.equal(a, b), (rep, k, float((a - b).abs().max()))
 
 
-def test_data_parallel_schedule_on_rccl_one_rank_matches_single_process(monkeypatch):
-    """The data-parallel schedule (graph: forward + loss + backward | RCCL all-reduce of the flat gradient buffer |
-    graph: Adam + EMA) on the real nccl (= RCCL) backend with a one-rank group: must reproduce the single-process fused
-    step bit for bit, eager and as hipGraph replays.  (World sizes > 1 are covered on CPU/gloo in test_dist_cpu.py.)"""
+@pytest.mark.parametrize("schedule,capture", [("overlap", False), ("single", False), ("overlap", True)])
+def test_data_parallel_schedule_on_rccl_one_rank_matches_single_process(monkeypatch, schedule, capture):
+    """The data-parallel schedules on the real nccl (= RCCL) backend with a one-rank group must reproduce the
+    single-process fused step bit for bit, eager and as hipGraph replays:
+      overlap: backward of heads + GRU | second stream: tail weight gradients + all-reduce(tail) || conv backward |
+               all-reduce(conv bucket) | Adam + EMA;   single: whole backward | one all-reduce | update;
+      capture: the overlap schedule with the RCCL collectives captured INTO the hipGraph (one replay per step).
+    (World size 2 runs in tests/test_gpu_dp.py.)"""
     import torch.distributed as dist
     from dcase2019_task4_amd.train import MeanTeacherStep
     monkeypatch.setenv("SED_FORCE_DP", "1")
     monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
     monkeypatch.setenv("MASTER_PORT", "29577")
+    if capture:
+        monkeypatch.setenv("SED_DP_CAPTURE", "1")
     created = not dist.is_initialized()
     if created:
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
@@ -545,7 +557,7 @@ def test_data_parallel_schedule_on_rccl_one_rank_matches_single_process(monkeypa
             s, _ = gu.make_model(0, dropout=0.5)
             t, _ = gu.make_model(1, dropout=0.5)
             s.train(); t.train()
-            st = MeanTeacherStep(s, t, B, T, 40, wm, sm, seed=7, use_graph=graph, process_group=pg)
+            st = MeanTeacherStep(s, t, B, T, 40, wm, sm, seed=7, use_graph=graph, process_group=pg, dp_schedule=schedule)
             assert st.dp == (pg is not None)
             if graph:
                 st._warm = 2
@@ -555,7 +567,7 @@ def test_data_parallel_schedule_on_rccl_one_rank_matches_single_process(monkeypa
             return s._flat.clone(), t._flat.clone(), st.grads.clone(), st.meters()
 
         ref = run(None, False)
-        for graph in (False, True):
+        for graph in ((True,) if capture else (False, True)):
             got = run(dist.group.WORLD, graph)
             for a, b in zip(got[:3], ref[:3]):
                 assert torch.equal(a, b)
@@ -563,6 +575,107 @@ def test_data_parallel_schedule_on_rccl_one_rank_matches_single_process(monkeypa
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_weights_init_apply_reaches_the_flat_buffer():
+    """main.py:282-283 calls crnn.apply(weights_init) (utils/utils.py:205-224: dispatch on class-name substrings, in-place
+    writes through .weight / .bias / .parameters()).  On a module that is ALREADY on the GPU and flattened, those writes
+    must land in the flat buffer the kernels read."""
+    model, _ = gu.make_model(0, dropout=0)
+    model.eval()
+    x = synth.make_input(3, 2, 64).cuda()
+    with torch.no_grad():
+        s0, _ = model(x)                     # flattens
+    flat0 = model._flat.clone()
+
+    def weights_init(m):                     # the reference's function, restated (same dispatch, same initialisers)
+        classname = m.__class__.__name__
+        if classname.find('Conv2d') != -1:
+            torch.nn.init.xavier_uniform_(m.weight, gain=np.sqrt(2))
+            m.bias.data.fill_(0)
+        elif classname.find('BatchNorm') != -1:
+            m.weight.data.normal_(1.0, 0.02)
+            m.bias.data.fill_(0)
+        elif classname.find('GRU') != -1:
+            for weight in m.parameters():
+                if len(weight.size()) > 1:
+                    torch.nn.init.orthogonal_(weight.data)
+        elif classname.find('Linear') != -1:
+            m.weight.data.normal_(0, 0.01)
+            m.bias.data.zero_()
+
+    torch.manual_seed(11)
+    model.apply(weights_init)
+    torch.cuda.synchronize()
+    base = model._flat.data_ptr()
+    for (o0, o1, shp), (n, p) in zip(model._layout, model.named_parameters()):
+        assert p.data_ptr() == base + 4 * o0, n                      # still views of the flat buffer
+        assert torch.equal(model._flat[o0:o1].view(shp), p.detach()), n
+    changed = (model._flat != flat0).float().mean().item()
+    assert changed > 0.9
+    o0, o1, _ = model._layout[1]                                      # cnn.cnn.conv0.bias -> zeros
+    assert float(model._flat[o0:o1].abs().max()) == 0.0
+    with torch.no_grad():
+        s1, _ = model(x)
+    assert not torch.equal(s0, s1)
+    # and the kernels really read the new values: same module rebuilt from its own state_dict gives the same output
+    from dcase2019_task4_amd.crnn import CRNN
+    m2 = CRNN(**dict(gu.CRNN_KW, dropout=0))
+    m2.load(parameters={k: {n: t.cpu() for n, t in v.items()} for k, v in model.state_dict().items()})
+    m2 = m2.cuda().eval()
+    with torch.no_grad():
+        s2, _ = m2(x)
+    assert torch.equal(s1, s2)
+
+
+def test_frozen_cnn_step_train_cnn_false():
+    """train_cnn=False (CRNN.py:18-20; main.py:289-290 hands only requires_grad parameters to Adam): the fused step
+    must leave the conv blocks untouched, update the GRU + heads exactly as the unfrozen step does on its first step
+    (same gradients there), and still EMA every parameter into the teacher (main.py:45-49)."""
+    from dcase2019_task4_amd.crnn import CRNN
+    from dcase2019_task4_amd.train import MeanTeacherStep
+    B, T = 4, 128
+    tgt, wm, sm = synth.make_target(1, B, T // 8)
+    x, xe = synth.make_input(60, B, T).cuda(), synth.make_input(70, B, T).cuda()
+
+    def build(train_cnn):
+        out = []
+        for seed in (0, 1):
+            m = CRNN(**dict(gu.CRNN_KW, dropout=0.5, train_cnn=train_cnn))
+            params = synth.make_params(seed)
+            with torch.no_grad():
+                for n, p in m.named_parameters():
+                    p.copy_(params[n])
+            out.append(m.cuda().train())
+        return out
+    sf, tf = build(False)
+    su, tu = build(True)
+    a = MeanTeacherStep(sf, tf, B, T, 40, wm, sm, seed=5, use_graph=False)
+    b = MeanTeacherStep(su, tu, B, T, 40, wm, sm, seed=5, use_graph=False)
+    assert a.cnn_frozen and not b.cnn_frozen
+    init = sf._flat.clone()
+    t_init = tf._flat.clone()
+    a.step(x, xe, tgt.cuda()); b.step(x, xe, tgt.cuda())
+    torch.cuda.synchronize()
+    cnn_end = sf._layout[17][1]
+    assert torch.equal(sf._flat[:cnn_end], init[:cnn_end])                     # conv blocks untouched
+    assert torch.equal(sf._flat[cnn_end:], su._flat[cnn_end:])                 # tail: identical first step
+    assert torch.equal(a.grads[cnn_end:], b.grads[cnn_end:])
+    assert float(a.grads[:cnn_end].abs().max()) == 0.0
+    assert not torch.equal(tf._flat[:cnn_end], t_init[:cnn_end])               # EMA still covers the conv blocks
+
+
+def test_module_refuses_unsupported_autograd_requests():
+    model, _ = gu.make_model(0, dropout=0)
+    from dcase2019_task4_amd import _lib
+    x = synth.make_input(3, 2, 64).cuda()
+    model.train()
+    with pytest.raises(_lib.SedError):
+        model(x.clone().requires_grad_(True))
+    model.eval()
+    s, w = model(x)
+    with pytest.raises(_lib.SedError):
+        (s.sum() + w.sum()).backward()
 
 
 @pytest.mark.parametrize("B,T", [(1, 628), (3, 864), (1, 16)])

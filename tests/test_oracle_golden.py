@@ -158,6 +158,61 @@ def test_mel_filterbank_properties():
     assert features_np.mel_to_hz_slaney(features_np.hz_to_mel_slaney(4321.0)) == pytest.approx(4321.0)
 
 
+def test_stft_matches_scipy_signal_stft():
+    """Second independent source for the (unpinned) STFT restatement: scipy.signal.stft with the reflect ("even")
+    boundary extension, hop = nperseg - noverlap; scipy normalises by the window sum ("spectrum" scaling), undone here."""
+    import scipy.signal
+    for sr, hop, n in ((16000, 255, 16000), (44100, 511, 30000)):
+        y = synth.make_wave(3, n)
+        win = features_np.hamming_window(2048)
+        ours = features_np.stft_mag(y, 2048, hop, win)
+        _, _, Z = scipy.signal.stft(y, fs=sr, window=win, nperseg=2048, noverlap=2048 - hop, nfft=2048, boundary="even",
+                                    padded=False, return_onesided=True)
+        ref = np.abs(Z) * win.sum()
+        assert ours.shape == ref.shape == (1025, 1 + n // hop)
+        np.testing.assert_allclose(ours, ref, rtol=1e-9, atol=1e-9)
+
+
+def test_mel_scale_matches_librosa_documented_values():
+    """Anchors from librosa's own documentation (docstring examples of librosa.hz_to_mel, mel_to_hz, mel_frequencies;
+    identical in 0.6 - 0.10): the only librosa-produced numbers available without the package.  Both the oracle's
+    and the product's mel scale must reproduce them."""
+    from dcase2019_task4_amd import features as prod
+    doc_mel_freqs_40 = np.array([
+        0., 85.317, 170.635, 255.952, 341.269, 426.586, 511.904, 597.221, 682.538, 767.855, 853.173, 938.49, 1024.856,
+        1119.114, 1222.042, 1334.436, 1457.167, 1591.187, 1737.532, 1897.337, 2071.84, 2262.393, 2470.47, 2697.686,
+        2945.799, 3216.731, 3512.582, 3835.643, 4188.417, 4573.636, 4994.285, 5453.621, 5955.205, 6502.92, 7101.009,
+        7754.107, 8467.272, 9246.028, 10096.408, 11025.])
+    for h2m, m2h in ((features_np.hz_to_mel_slaney, features_np.mel_to_hz_slaney), (prod._hz_to_mel, prod._mel_to_hz)):
+        assert float(h2m(60)) == pytest.approx(0.9, abs=1e-12)                                   # librosa.hz_to_mel(60)
+        np.testing.assert_allclose(h2m([110, 220, 440]), [1.65, 3.3, 6.6], rtol=1e-12)           # librosa.hz_to_mel([110, 220, 440])
+        assert float(m2h(3)) == pytest.approx(200.0, rel=1e-12)                                  # librosa.mel_to_hz(3)
+        np.testing.assert_allclose(m2h([1, 2, 3, 4, 5]), [66.667, 133.333, 200., 266.667, 333.333], atol=5e-4)
+        # librosa.mel_frequencies(n_mels=40) (fmin 0, fmax 11025)
+        mf = m2h(np.linspace(h2m(0.0), h2m(11025.0), 40))
+        np.testing.assert_allclose(mf, doc_mel_freqs_40, atol=6e-4)
+
+
+def test_mel_filterbank_against_direct_triangle_definition():
+    """The filterbank rebuilt from the textbook definition - weight of FFT bin f in band i = the triangle with corners
+    (m_i, m_i+1, m_i+2) evaluated at f, peak 1 (norm=None) - with scalar loops and none of the oracle's vectorised
+    ramps: an implementation-independent check of librosa.filters.mel's construction (product and oracle)."""
+    from dcase2019_task4_amd import features as prod
+    sr, n_fft, n_mels, fmin, fmax = 16000, 2048, 64, 0.0, 8000.0
+    pts = features_np.mel_to_hz_slaney(np.linspace(features_np.hz_to_mel_slaney(fmin), features_np.hz_to_mel_slaney(fmax), n_mels + 2))
+    want = np.zeros((n_mels, 1 + n_fft // 2))
+    for i in range(n_mels):
+        lo, ce, hi = pts[i], pts[i + 1], pts[i + 2]
+        for k in range(1 + n_fft // 2):
+            f = k * (sr / 2.0) / (n_fft // 2)
+            if lo < f <= ce:
+                want[i, k] = (f - lo) / (ce - lo)
+            elif ce < f < hi:
+                want[i, k] = (hi - f) / (hi - ce)
+    for fb in (features_np.mel_filterbank(sr, n_fft, n_mels, fmin, fmax), prod.mel_filterbank(sr, n_fft, n_mels, fmin, fmax)):
+        np.testing.assert_allclose(fb, want.astype(np.float32), atol=2e-7)
+
+
 def test_amplitude_to_db_definition():
     a = np.array([[1.0, 10.0, 1e-7, 0.0]])
     db = features_np.amplitude_to_db(a)

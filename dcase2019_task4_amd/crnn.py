@@ -109,7 +109,7 @@ class _CRNNFunction(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             raise _lib.SedError("the gradient w.r.t. the input features is not implemented (the reference never asks for "
                                 "it: main.py:91 feeds a plain batch tensor)")
-        if not train and any(ctx.needs_input_grad[4:]) and torch.is_grad_enabled():
+        if not train and any(ctx.needs_input_grad[4:]):
             # eval-mode autograd (running BatchNorm statistics, no dropout) is not on the hot path: refuse loudly rather
             # than fail later in backward with a missing context
             ctx.eval_mode = True

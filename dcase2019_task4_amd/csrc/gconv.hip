@@ -1,0 +1,341 @@
+// gconv.hip - generic 3x3 convolution family (C -> C channels, C in {64, 128}, images [B][H][W][C] with W in {16, 4}),
+// forward / dgrad / wgrad, MFMA operands in fp32 (MODE 0) or bf16 (MODE 1).  See gen.h for the shared structure.
+//
+// Reference ops: Conv2d(C, C, 3, 1, 1) of conv blocks 1 and 2 (baseline/models/CNN.py:46-47) with
+// nb_filters = [C, C, C] (CNN.py:35-38 takes any list; BASELINE.json configs[4] uses 128) and its autograd.
+//   forward : y[p][co]  = bias[co] + sum_{tap, ci} x[p + tap][ci] W[co][ci][tap]          (+ BatchNorm sum / sum^2)
+//   dgrad   : dx[p][ci] = sum_{tap, co} dy[p - tap][co] W[co][ci][tap],  dy = ca*dz + cb*y + cc inside the image
+//   wgrad   : dW[co][ci][tap] = sum_p dy[p][co] x[p + tap][ci]
+// Forward and dgrad are ONE implicit GEMM kernel (M = 128 output pixels per workgroup, N = C, K = 9 C): the halo tile
+// of the input lives in LDS, k-contiguous per pixel; the packed weights [n][tap * C + k] stream through LDS.
+#include "gen.h"
+#include "kernels.h"
+#include "gkernels.h"
+
+// ---- weight packing (once per forward) ----------------------------------------------------------------------------------
+// conv i (1, 2):  wpk [co][tap * C + ci] = W[co][ci][tap]                 (forward B operand, n = co)
+//                 wpkT[ci][tap * C + co] = W[co][ci][8 - tap]             (dgrad   B operand, n = ci: flipped kernel)
+// GLU i (1, 2), folded with the BatchNorm affine so that the kernels work on xhat = (y - mean) * invstd:
+//                 wg  [co][c] = Wglu[co][c] * gamma[c]      bg[co] = bglu[co] + sum_c Wglu[co][c] beta[c]   (fp32)
+//                 wgT [c][co] = Wglu[co][c]                               (dz_lin = dlin @ Wglu, n = c)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_gen_pack(GenPackArgs a) {
+    using M = MM<MODE>;
+    using E = typename M::E;
+    const int C = a.C, CC = C * C;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < a.n_zero) a.zero[i] = 0.0;
+    if (i < 2 * 9 * CC) {
+        const int layer = i / (9 * CC), e = i % (9 * CC);
+        const int n = e / (9 * C), r = e % (9 * C), tap = r / C, k = r % C;
+        const float* w = layer ? a.w2 : a.w1;
+        E* wpk = (E*)(layer ? a.wpk2 : a.wpk1);
+        E* wpkT = (E*)(layer ? a.wpkT2 : a.wpkT1);
+        wpk[e] = M::cvt(w[((size_t)n * C + k) * 9 + tap]);
+        if (wpkT) wpkT[e] = M::cvt(w[((size_t)k * C + n) * 9 + (8 - tap)]);
+    }
+    if (i < 2 * CC) {
+        const int layer = i / CC, e = i % CC, co = e / C, c = e % C;
+        const float* wg = layer ? a.glu_w2 : a.glu_w1;
+        const float* gam = layer ? a.gamma2 : a.gamma1;
+        E* o = (E*)(layer ? a.wg2 : a.wg1);
+        E* oT = (E*)(layer ? a.wgT2 : a.wgT1);
+        o[e] = M::cvt(wg[e] * gam[c]);
+        if (oT) oT[(size_t)c * C + co] = M::cvt(wg[e]);
+    }
+    if (i < 2 * C) {
+        const int layer = i / C, co = i % C;
+        const float* wg = layer ? a.glu_w2 : a.glu_w1;
+        const float* bet = layer ? a.beta2 : a.beta1;
+        const float* bgl = layer ? a.glu_b2 : a.glu_b1;
+        double acc = bgl[co];
+        for (int c = 0; c < C; ++c) acc += (double)wg[(size_t)co * C + c] * (double)bet[c];
+        (layer ? a.bg2 : a.bg1)[co] = (float)acc;
+    }
+}
+
+int launch_gen_pack(const GenPackArgs& a, int mode, hipStream_t st) {
+    const int n = 2 * 9 * a.C * a.C;
+    const int blocks = ((n > a.n_zero ? n : a.n_zero) + 255) / 256;
+    if (mode == 1) k_gen_pack<1><<<blocks, 256, 0, st>>>(a);
+    else k_gen_pack<0><<<blocks, 256, 0, st>>>(a);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}
+
+// ---- forward / dgrad ---------------------------------------------------------------------------------------------------
+template <int MODE, int C, int TW>
+struct GConvCfg {
+    using M = MM<MODE>;
+    static constexpr int TH = 128 / TW, HW = TW + 2, HH = TH + 2;
+    static constexpr int CS = C + M::PAD;                                   // halo pixel stride (elements)
+    static constexpr int HALO_E = HH * HW * CS;
+    static constexpr int WBUF_E = 2 * C * (M::KC + M::PAD);
+    static constexpr size_t HALO_BYTES = ((size_t)HALO_E * sizeof(typename M::E) + 15) & ~(size_t)15;
+    static constexpr size_t LDS_BYTES = HALO_BYTES + (size_t)WBUF_E * sizeof(typename M::E) + 3 * C * 4 + 4 * 2 * C * 4;
+};
+
+// DIR 0: forward (in0 = activations; epilogue: bias, BatchNorm sums).  DIR 1: dgrad (in0 = dz, in1 = y, coef = ca | cb | cc).
+template <int MODE, int C, int TW, int DIR>
+__global__ __launch_bounds__(256) void k_gconv(const float* __restrict__ in0, const float* __restrict__ in1,
+                                                const float* __restrict__ coef, const void* __restrict__ wpk_v,
+                                                const float* __restrict__ bias, float* __restrict__ out,
+                                                double* __restrict__ stat, int H, int tiles_per_clip, int n_tiles) {
+    using Cfg = GConvCfg<MODE, C, TW>;
+    using M = MM<MODE>;
+    using E = typename M::E;
+    constexpr int NB = C / 32, TH = Cfg::TH, HW = Cfg::HW, HH = Cfg::HH, CS = Cfg::CS, C4 = C / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+    E* halo = (E*)gsm;
+    E* wbuf = (E*)(gsm + Cfg::HALO_BYTES);
+    float* cf = (float*)(wbuf + Cfg::WBUF_E);            // [3][C] dgrad affine
+    float* red = cf + 3 * C;                             // [4 waves][2][C] BatchNorm partial sums
+    const E* wpk = (const E*)wpk_v;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 31, kh = lane >> 5;
+    if (DIR == 1) {
+        for (int e = tid; e < 3 * C; e += 256) cf[e] = coef[e];
+    }
+    // this lane's MFMA row m = n: pixel (r, c) of the tile
+    const int pr = (TW == 16) ? 2 * wv + (n >> 4) : 8 * wv + (n >> 2);
+    const int pc = (TW == 16) ? (n & 15) : (n & 3);
+    const E* a_row = halo + (pr * HW + pc) * CS;
+    float s1[NB], s2[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { s1[nb] = 0.f; s2[nb] = 0.f; }
+    float bv[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) bv[nb] = (DIR == 0) ? bias[32 * nb + n] : 0.f;
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_clip, r0 = (tile % tiles_per_clip) * TH;
+        // ---- halo: rows r0 - 1 .. r0 + TH, columns -1 .. TW, all C channels; zero outside the image ----------------
+        for (int g = tid; g < HH * HW * C4; g += 256) {
+            const int hp = g / C4, c4 = g % C4;
+            const int hy = hp / HW, hx = hp % HW;
+            const int row = r0 - 1 + hy, col = hx - 1;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row >= 0 && row < H && col >= 0 && col < TW) {
+                const size_t off = ((size_t)(b * H + row) * TW + col) * C + 4 * c4;
+                v = *(const f32x4*)(in0 + off);
+                if (DIR == 1) {
+                    const f32x4 y = *(const f32x4*)(in1 + off);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = cf[4 * c4 + q] * v[q] + cf[C + 4 * c4 + q] * y[q] + cf[2 * C + 4 * c4 + q];
+                }
+            }
+            M::st4(halo + hp * CS + 4 * c4, v[0], v[1], v[2], v[3]);
+        }
+        __syncthreads();
+        f32x16 acc[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+        constexpr int CPT = C / M::KC;                    // chunks per tap
+        auto aoff = [&](int ch) {
+            const int tap = ch / CPT, dr = tap / 3, dc = tap % 3;
+            return (dr * HW + dc) * CS + (ch % CPT) * M::KC;
+        };
+        stream_gemm<MODE, NB, NB, M::KC>(a_row, aoff, wpk, 9 * C, 9 * C, wbuf, acc, 0, tid);
+        // (stream_gemm ends with a barrier: the halo may be overwritten by the next tile's staging)
+        // ---- epilogue: D register r of lane (n, kh) is MFMA row m = (r & 3) + 8 (r >> 2) + 4 kh, column n ------------
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mfma32_row(r, lane);
+            const int rr = (TW == 16) ? 2 * wv + (m >> 4) : 8 * wv + (m >> 2);
+            const int cc = (TW == 16) ? (m & 15) : (m & 3);
+            const int row = r0 + rr;
+            if (row < H) {
+                float* o = out + ((size_t)(b * H + row) * TW + cc) * C + n;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const float v = acc[nb][r] + bv[nb];
+                    o[32 * nb] = v;
+                    if (DIR == 0) { s1[nb] += v; s2[nb] += v * v; }
+                }
+            }
+        }
+    }
+    if (DIR == 0 && stat != nullptr) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const float a1 = s1[nb] + __shfl_xor(s1[nb], 32), a2 = s2[nb] + __shfl_xor(s2[nb], 32);
+            if (kh == 0) { red[(wv * 2 + 0) * C + 32 * nb + n] = a1; red[(wv * 2 + 1) * C + 32 * nb + n] = a2; }
+        }
+        __syncthreads();
+        for (int e = tid; e < 2 * C; e += 256) {
+            const int which = e / C, c = e % C;
+            const double v = (double)red[(0 * 2 + which) * C + c] + (double)red[(1 * 2 + which) * C + c] +
+                             (double)red[(2 * 2 + which) * C + c] + (double)red[(3 * 2 + which) * C + c];
+            atomicAdd(&stat[which * C + c], v);
+        }
+    }
+}
+
+template <int MODE, int C, int TW, int DIR>
+static int gconv_launch(const float* in0, const float* in1, const float* coef, const void* wpk, const float* bias, float* out,
+                        double* stat, int B, int H, hipStream_t st) {
+    using Cfg = GConvCfg<MODE, C, TW>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gconv<MODE, C, TW, DIR>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)Cfg::LDS_BYTES));
+        attr_done = true;
+    }
+    SED_CHECK_ARG((size_t)B * H * TW * C < ((size_t)1 << 31), "gconv: image too large for 32-bit offsets");
+    const int tpc = (H + Cfg::TH - 1) / Cfg::TH, nt = B * tpc;
+    const int grid = nt < 256 ? nt : 256;
+    k_gconv<MODE, C, TW, DIR><<<grid, 256, Cfg::LDS_BYTES, st>>>(in0, in1, coef, wpk, bias, out, stat, H, tpc, nt);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}
+
+template <int DIR>
+static int gconv_dispatch(int mode, int C, int W, const float* in0, const float* in1, const float* coef, const void* wpk,
+                          const float* bias, float* out, double* stat, int B, int H, hipStream_t st) {
+#define GCONV_CASE(MD, CC, WW) \
+    if (mode == MD && C == CC && W == WW) return gconv_launch<MD, CC, WW, DIR>(in0, in1, coef, wpk, bias, out, stat, B, H, st)
+    GCONV_CASE(0, 64, 16); GCONV_CASE(0, 64, 4); GCONV_CASE(0, 128, 16); GCONV_CASE(0, 128, 4);
+    GCONV_CASE(1, 64, 16); GCONV_CASE(1, 64, 4); GCONV_CASE(1, 128, 16); GCONV_CASE(1, 128, 4);
+#undef GCONV_CASE
+    sed_set_error("gconv: unsupported mode %d / channels %d / width %d", mode, C, W);
+    return SED_ERR_UNSUPPORTED;
+}
+
+int launch_gconv_fwd(int mode, int C, const float* in, const void* wpk, const float* bias, float* y, double* stat, int B, int H,
+                     int W, hipStream_t st) {
+    return gconv_dispatch<0>(mode, C, W, in, nullptr, nullptr, wpk, bias, y, stat, B, H, st);
+}
+int launch_gconv_dgrad(int mode, int C, const float* dz, const float* yin, const float* coef, const void* wpkT, float* dx, int B,
+                       int H, int W, hipStream_t st) {
+    return gconv_dispatch<1>(mode, C, W, dz, yin, coef, wpkT, nullptr, dx, nullptr, B, H, st);
+}
+
+// ---- wgrad ---------------------------------------------------------------------------------------------------------------
+// dW[co][ci][tap] = sum_p dy[p][co] x[p + tap][ci]: the contraction runs over PIXELS, which is the slow axis of both
+// channels-last operands.  The f32 MFMA takes one float per lane per operand, so lane = channel reads of the natural
+// [pixel][channel] tiles are already the right fragments (the bf16 MFMA would need both tiles transposed on the way into
+// LDS); this kernel therefore computes in fp32 in BOTH modes.  A workgroup owns a 64 x 64 (co, ci) quadrant for all 9 taps
+// (9 accumulators of 32 x 32 per wave, 144 registers) over a slab of 128-pixel tiles and writes ONE partial
+// [9][64][64] slab; k_gwgrad_reduce adds the slabs in fixed order (bit-reproducible, no float atomics).
+template <int TW>
+struct GWgCfg {
+    static constexpr int TH = 128 / TW, HW = TW + 2, HH = TH + 2, PS = 65;
+    static constexpr int X_F = HH * HW * PS, DY_F = 128 * PS;
+    static constexpr size_t LDS_BYTES = (size_t)(X_F + DY_F + 3 * 64) * 4;
+};
+template <int TW>
+__global__ __launch_bounds__(256) void k_gwgrad(const float* __restrict__ dz, const float* __restrict__ yin,
+                                                 const float* __restrict__ coef, const float* __restrict__ xin,
+                                                 float* __restrict__ part, int C, int H, int tiles_per_clip, int n_tiles) {
+    using Cfg = GWgCfg<TW>;
+    constexpr int TH = Cfg::TH, HW = Cfg::HW, HH = Cfg::HH, PS = Cfg::PS;
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    float* xs = wsm;                       // halo of x: [HH * HW][PS] (this quadrant's 64 input channels)
+    float* dys = xs + Cfg::X_F;            // dy: [128][PS] (this quadrant's 64 output channels)
+    float* cf = dys + Cfg::DY_F;           // ca | cb | cc of this quadrant's output channels
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 31, kh = lane >> 5;
+    const int nq = C / 64, quad = blockIdx.y, co0 = (quad / nq) * 64, ci0 = (quad % nq) * 64;
+    const int wa = wv >> 1, wb = wv & 1;   // wave's 32 x 32 sub-quadrant: co 32 wa.., ci 32 wb..
+    if (tid < 192) cf[tid] = coef[(tid / 64) * C + co0 + (tid % 64)];
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_clip, r0 = (tile % tiles_per_clip) * TH;
+        __syncthreads();
+        for (int g = tid; g < HH * HW * 16; g += 256) {
+            const int hp = g >> 4, c4 = g & 15;
+            const int hy = hp / HW, hx = hp % HW, row = r0 - 1 + hy, col = hx - 1;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row >= 0 && row < H && col >= 0 && col < TW)
+                v = *(const f32x4*)(xin + ((size_t)(b * H + row) * TW + col) * C + ci0 + 4 * c4);
+            float* d = xs + hp * PS + 4 * c4;
+            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        }
+        for (int g = tid; g < 128 * 16; g += 256) {
+            const int p = g >> 4, c4 = g & 15;
+            const int rr = p / TW, cc = p % TW, row = r0 + rr;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < H) {
+                const size_t off = ((size_t)(b * H + row) * TW + cc) * C + co0 + 4 * c4;
+                const f32x4 z = *(const f32x4*)(dz + off), y = *(const f32x4*)(yin + off);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = cf[4 * c4 + q] * z[q] + cf[64 + 4 * c4 + q] * y[q] + cf[128 + 4 * c4 + q];
+            }
+            float* d = dys + p * PS + 4 * c4;
+            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        }
+        __syncthreads();
+        // K = 128 pixels, 2 per MFMA: A[i = co][k = pixel] = dy[pixel][co], B[k = pixel][j = ci] = x[pixel + tap][ci]
+        const float* Ap = dys + 32 * wa + n;
+        const float* Bp = xs + 32 * wb + n;
+#pragma unroll 2
+        for (int s = 0; s < 64; ++s) {
+            const int p = 2 * s + kh, rr = p / TW, cc = p % TW;
+            const float a = Ap[p * PS];
+            const float* bx = Bp + (rr * HW + cc) * PS;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = mfma32(a, bx[((t / 3) * HW + (t % 3)) * PS], acc[t]);
+        }
+    }
+    // partial slab [tap][co (C)][ci (C)] of this workgroup's slab index
+    float* ps = part + (size_t)blockIdx.x * 9 * C * C;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            ps[((size_t)t * C + co0 + 32 * wa + mfma32_row(r, lane)) * C + ci0 + 32 * wb + n] = acc[t][r];
+}
+
+// g_w[co][ci][tap] = sum over slabs, fixed order
+__global__ __launch_bounds__(256) void k_gwgrad_reduce(const float* __restrict__ part, int n_slabs, int C, float* __restrict__ g_w) {
+    const int e = blockIdx.x * 256 + threadIdx.x;        // e = (tap * C + co) * C + ci
+    const int n = 9 * C * C;
+    if (e >= n) return;
+    float s = 0.f;
+    int k = 0;
+    for (; k + 4 <= n_slabs; k += 4) {
+        const float v0 = part[(size_t)k * n + e], v1 = part[(size_t)(k + 1) * n + e], v2 = part[(size_t)(k + 2) * n + e],
+                    v3 = part[(size_t)(k + 3) * n + e];
+        s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; k < n_slabs; ++k) s += part[(size_t)k * n + e];
+    const int tap = e / (C * C), co = (e / C) % C, ci = e % C;
+    g_w[((size_t)co * C + ci) * 9 + tap] = s;
+}
+
+int gwgrad_slabs(int C) { return 256 / ((C / 64) * (C / 64)); }
+
+int launch_gwgrad(int C, const float* dz, const float* yin, const float* coef, const float* xin, float* part, float* g_w, int B,
+                  int H, int W, hipStream_t st) {
+    SED_CHECK_ARG(C == 64 || C == 128, "gwgrad: C must be 64 or 128");
+    const int nq = (C / 64) * (C / 64);
+    int slabs = gwgrad_slabs(C);
+    int nt, tpc;
+    if (W == 16) {
+        using Cfg = GWgCfg<16>;
+        static bool attr = false;
+        if (!attr) { SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES)); attr = true; }
+        tpc = (H + Cfg::TH - 1) / Cfg::TH; nt = B * tpc;
+        if (slabs > nt) slabs = nt;
+        k_gwgrad<16><<<dim3(slabs, nq), 256, Cfg::LDS_BYTES, st>>>(dz, yin, coef, xin, part, C, H, tpc, nt);
+    } else if (W == 4) {
+        using Cfg = GWgCfg<4>;
+        static bool attr = false;
+        if (!attr) { SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES)); attr = true; }
+        tpc = (H + Cfg::TH - 1) / Cfg::TH; nt = B * tpc;
+        if (slabs > nt) slabs = nt;
+        k_gwgrad<4><<<dim3(slabs, nq), 256, Cfg::LDS_BYTES, st>>>(dz, yin, coef, xin, part, C, H, tpc, nt);
+    } else {
+        sed_set_error("gwgrad: unsupported width %d", W);
+        return SED_ERR_UNSUPPORTED;
+    }
+    SED_CHECK_LAUNCH();
+    k_gwgrad_reduce<<<(9 * C * C + 255) / 256, 256, 0, st>>>(part, slabs, C, g_w);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}

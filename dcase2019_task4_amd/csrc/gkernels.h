@@ -1,0 +1,55 @@
+// gkernels.h - host-side launchers of the generic kernel family (gen.h); internal.
+#pragma once
+#include "common.h"
+
+// gconv.hip ---------------------------------------------------------------------------------------------------------------
+struct GenPackArgs {
+    int C;
+    const float *w1, *w2;                       // conv1 / conv2 weights [co][ci][3][3]
+    void *wpk1, *wpk2, *wpkT1, *wpkT2;          // packed (element type by mode) [n][9 C]; wpkT may be null (eval)
+    const float *glu_w1, *glu_w2, *glu_b1, *glu_b2, *gamma1, *gamma2, *beta1, *beta2;
+    void *wg1, *wg2, *wgT1, *wgT2;              // GLU weights folded with gamma [co][c]; transposed raw [c][co] (may be null)
+    float *bg1, *bg2;                           // GLU bias folded with beta [C]
+    double* zero; int n_zero;                   // fp64 accumulators to clear
+};
+int launch_gen_pack(const GenPackArgs& a, int mode, hipStream_t st);
+int launch_gconv_fwd(int mode, int C, const float* in, const void* wpk, const float* bias, float* y, double* stat, int B, int H,
+                     int W, hipStream_t st);
+int launch_gconv_dgrad(int mode, int C, const float* dz, const float* yin, const float* coef, const void* wpkT, float* dx, int B,
+                       int H, int W, hipStream_t st);
+int gwgrad_slabs(int C);
+int launch_gwgrad(int C, const float* dz, const float* yin, const float* coef, const float* xin, float* part, float* g_w, int B,
+                  int H, int W, hipStream_t st);
+
+// gglu.hip ----------------------------------------------------------------------------------------------------------------
+struct GBnArgs {
+    const double* stat; double N;               // [2][C] sum, sum of squares of the conv output; element count
+    const float *gamma, *beta;
+    float *run_mean, *run_var; int64_t* tracked;
+    int train, update; float eps, momentum;
+    float* bn;                                  // out [4][C]: mean, invstd, scale, shift
+};
+int launch_gglu_fwd(int mode, int C, const float* y, const GBnArgs& bn, const void* wg, const float* bg, float* p, int B, int H,
+                    int W, int block_id, int use_drop, float p_drop, const uint64_t* seed, uint16_t* mask_out, hipStream_t st);
+int gglu_bwd_grid(int B, int H, int W);
+// part: [grid][C * C + 3 * C] floats (per-workgroup partial sums: dWx | sdb | sdz | sdzx)
+int launch_gglu_bwd(int mode, int C, const float* y, const float* bn, const float* gamma, const float* beta, const void* wg,
+                    const void* wgT, const float* bg, const float* dp, float* dz, float* part, int B, int H, int W, int use_drop,
+                    float p_drop, const uint16_t* mask_in, hipStream_t st);
+struct GBnBwdArgs {
+    const float* part; int n_part; int C; double N;
+    const float *gamma, *beta, *bn;
+    float *coef, *g_gamma, *g_beta, *g_wglu, *g_bglu, *g_convb;
+};
+int launch_gbn_bwd_prep(const GBnBwdArgs& a, hipStream_t st);
+
+// ggru.hip ----------------------------------------------------------------------------------------------------------------
+// W_hh re-laid for coalesced streaming: fwd [k / 4][3H rows][4], bwd (transposed) [g / 4][H columns][4]
+int launch_ggru_pack(const float* w_hh_f, const float* w_hh_r, float* wp /*[2][3H*H]*/, float* wpT /*[2][3H*H] or null*/, int H,
+                     hipStream_t st);
+// gi: [B*T][2][3H] (input projection incl. b_ih, both directions); out [B*T][2H]; gates [B*T][2][4H] (r, z, n, gh_n) or null
+int launch_ggru_fwd(int H, const float* gi, const float* wp, const float* b_hh_f, const float* b_hh_r, float* out, float* gates,
+                    int B, int T, hipStream_t st);
+// d_out [B*T][2H]; dgi / dgh [B*T][2][3H]; hprev [B*T][2][H]
+int launch_ggru_bwd(int H, const float* d_out, const float* out, const float* gates, const float* wpT, float* dgi, float* dgh,
+                    float* hprev, int B, int T, hipStream_t st);

@@ -134,9 +134,10 @@ def _check_grads(g_hip, go):
         rel = err / (scale + 1e-30)
         worst = max(worst, rel)
         print(f"[grad] {n:40s} |g| {gn:.3e}  max|err| {err:.3e}  err/typ {rel:.3e}")
-        assert float(g_hip[n].double().norm()) == pytest.approx(gn, rel=2e-3), n
-        # measured <= 2e-4 of the typical magnitude; the bound leaves 5x
-        np.testing.assert_allclose(g_hip[n].numpy(), g.numpy(), rtol=1e-3, atol=1e-3 * scale, err_msg=n)
+        assert float(g_hip[n].double().norm()) == pytest.approx(gn, rel=2e-3, abs=1e-6), n
+        # measured <= 2e-4 of the typical magnitude; the bound leaves 5x (+1e-7 absolute: gradients that cancel to ~0 -
+        # the softmax bias, whose terms sum to zero over the classes - carry fp32 rounding noise of their O(1e-2) summands)
+        np.testing.assert_allclose(g_hip[n].numpy(), g.numpy(), rtol=1e-3, atol=1e-3 * scale + 1e-7, err_msg=n)
     return worst
 
 
@@ -178,7 +179,7 @@ def test_winograd_kernels_match_the_direct_convolution_kernels(B, T):
                                                    (5, 216, 0.5, 1, 10), (4, 150, 0.25, 2, 10), (7, 1040, 0.5, 2, 10),
                                                    (4, 864, 0.5, 2, 10), (6, 96, 0.5, 2, 1), (5, 200, 0.5, 2, 16),
                                                    (4, 630, 0.5, 2, 10), (9, 100, 0.5, 2, 10), (4, 22, 0.5, 2, 10),
-                                                   (24, 628, 0.5, 2, 10), (4, 629, 0.5, 2, 10), (3, 151, 0.5, 2, 10)])
+                                                   (24, 628, 0.5, 2, 10), (4, 629, 0.5, 2, 10), (5, 151, 0.5, 2, 10)])
 def test_train_forward_backward_vs_oracle(B, T, p, n_layers, nclass):
     """Posteriors, loss, every parameter gradient and the BN running stats against the oracle, with
     dropout ON (same Philox masks on both sides).  T=150 exercises odd H (rows dropped by the pool); T=1040 gives

@@ -19,7 +19,11 @@ class SedDims(C.Structure):
     """sed_dims (include/dcase_sed.h) - mirrors cfg.crnn_kwargs, baseline/config.py:53-58."""
     _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("F", C.c_int32), ("C", C.c_int32), ("H", C.c_int32),
                 ("nclass", C.c_int32), ("n_layers_rnn", C.c_int32), ("p_drop", C.c_float),
-                ("bn_eps", C.c_float), ("bn_momentum", C.c_float)]
+                ("bn_eps", C.c_float), ("bn_momentum", C.c_float), ("dtype", C.c_int32)]
+
+
+DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPES = {"f32": DTYPE_F32, "fp32": DTYPE_F32, "float32": DTYPE_F32, "bf16": DTYPE_BF16, "bfloat16": DTYPE_BF16}
 
 
 class SedStepState(C.Structure):
@@ -112,8 +116,8 @@ def stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def make_dims(B, T, F=64, C_=64, H=64, nclass=10, n_layers_rnn=2, p_drop=0.5, bn_eps=1e-3, bn_momentum=0.99):
-    return SedDims(B, T, F, C_, H, nclass, n_layers_rnn, p_drop, bn_eps, bn_momentum)
+def make_dims(B, T, F=64, C_=64, H=64, nclass=10, n_layers_rnn=2, p_drop=0.5, bn_eps=1e-3, bn_momentum=0.99, dtype=DTYPE_F32):
+    return SedDims(B, T, F, C_, H, nclass, n_layers_rnn, p_drop, bn_eps, bn_momentum, dtype)
 
 
 def param_layout(dims):

@@ -9,9 +9,12 @@ only: ``forward`` never calls them.  All arithmetic runs in the hand-written HIP
 the C-ABI (include/dcase_sed.h) on one flat fp32 parameter buffer the containers' parameters are
 views of.  No CPU / stock-torch fallback exists: without the library (or on a CPU tensor) it raises.
 
-Only the configuration on the hot path is implemented (cfg.crnn_kwargs, baseline/config.py:53-58):
-activation="glu", attention=True, BGRU, n_in_channel=1, three 64-filter 3x3 blocks with (2,4)
-pooling, n_RNN_cell=64, 1 or 2 GRU layers.  Anything else raises NotImplementedError.
+Implemented (anything else raises NotImplementedError): activation="glu", attention=True, BGRU, n_in_channel=1,
+three 3x3 conv blocks of EQUAL width with (2,4) pooling, 1 or 2 GRU layers, and
+  * nb_filters 3 x 64, n_RNN_cell 64 - cfg.crnn_kwargs (baseline/config.py:53-58), the specialised fp32 kernel set;
+  * nb_filters 3 x 64 or 3 x 128, n_RNN_cell 64 or 256 - the generic kernel set (BASELINE.json configs[4]'s wide CRNN).
+``mfma_dtype`` (extra keyword, or ``set_mfma_dtype``) states the arithmetic of the GEMM-shaped operators of conv blocks
+1 and 2: "f32" (default, exact fp32 MFMA) or "bf16" (bf16 operands, fp32 accumulation - include/dcase_sed.h sed_dims.dtype).
 """
 import ctypes as C
 import warnings
@@ -42,10 +45,10 @@ class CNN(nn.Module):
         super().__init__()
         if activation.lower() != "glu":
             raise NotImplementedError(f"hot path implements activation='glu' only (config.py:55), got {activation!r}")
-        if n_in_channel != 1 or list(nb_filters) != [64, 64, 64] or list(kernel_size) != [3, 3, 3] or \
+        if n_in_channel != 1 or list(nb_filters) not in ([64, 64, 64], [128, 128, 128]) or list(kernel_size) != [3, 3, 3] or \
                 list(padding) != [1, 1, 1] or list(stride) != [1, 1, 1] or [tuple(p) for p in pooling] != [(2, 4)] * 3:
-            raise NotImplementedError("hot path implements the cfg.crnn_kwargs geometry only: n_in_channel=1, "
-                                      "3x(64 filters, k3/s1/p1), pooling (2,4)x3 (config.py:53-58)")
+            raise NotImplementedError("hot path implements n_in_channel=1, 3x(64 or 128 filters, k3/s1/p1), pooling (2,4)x3 "
+                                      "(config.py:53-58; BASELINE.json configs[4] for 128)")
         self.nb_filters = list(nb_filters)
         cnn = nn.Sequential()
         for i in range(3):
@@ -151,12 +154,13 @@ class CRNN(nn.Module):
     def __init__(self, n_in_channel, nclass, attention=False, activation="Relu", dropout=0, train_cnn=True,
                  rnn_type='BGRU', n_RNN_cell=64, n_layers_RNN=1, dropout_recurrent=0, **kwargs):
         super().__init__()
+        mfma_dtype = kwargs.pop("mfma_dtype", "f32")
         if not attention:
             raise NotImplementedError("hot path implements attention=True only (config.py:53)")
         if rnn_type != 'BGRU':
             raise NotImplementedError("Only BGRU supported for CRNN for now")
-        if n_RNN_cell != 64 or n_layers_RNN not in (1, 2) or dropout_recurrent != 0:
-            raise NotImplementedError("hot path implements n_RNN_cell=64, n_layers_RNN in (1,2), dropout_recurrent=0")
+        if n_RNN_cell not in (64, 256) or n_layers_RNN not in (1, 2) or dropout_recurrent != 0:
+            raise NotImplementedError("hot path implements n_RNN_cell in (64, 256), n_layers_RNN in (1,2), dropout_recurrent=0")
         if not (1 <= nclass <= 16):
             raise NotImplementedError("nclass must be in [1, 16]")
         self.attention = attention
@@ -173,6 +177,9 @@ class CRNN(nn.Module):
         self.dense_softmax = nn.Linear(n_RNN_cell * 2, nclass)
         self.softmax = nn.Softmax(dim=-1)
         self._nclass, self._n_layers, self._p_drop = nclass, n_layers_RNN, float(dropout)
+        self._C, self._H = int(self.cnn.nb_filters[-1]), int(n_RNN_cell)
+        self._dtype = _lib.DTYPE_F32
+        self.set_mfma_dtype(mfma_dtype)
         # flat storage (built lazily on the first forward / after every .to()/.cuda())
         self._flat = None
         self._bn_flat = None
@@ -211,10 +218,21 @@ class CRNN(nn.Module):
     def save(self, filename):
         torch.save({k: v for k, v in self.state_dict().items()}, filename)
 
+    def set_mfma_dtype(self, name):
+        """"f32" (exact fp32 MFMA) or "bf16" (bf16 operands / fp32 accumulation in the conv-block GEMMs): sed_dims.dtype."""
+        if name not in _lib.DTYPES:
+            raise ValueError(f"mfma_dtype must be one of {sorted(_lib.DTYPES)}, got {name!r}")
+        self._dtype = _lib.DTYPES[name]
+        return self
+
     # ---- flat storage -----------------------------------------------------------------------------
+    def make_dims(self, B, T, F=64, p_drop=None):
+        return _lib.make_dims(B, T, F, self._C, self._H, self._nclass, self._n_layers,
+                              self._p_drop if p_drop is None else p_drop, 1e-3, 0.99, self._dtype)
+
     def _dims(self, x):
         B, _, T, F = x.shape
-        return _lib.make_dims(B, T, F, 64, 64, self._nclass, self._n_layers, self._p_drop, 1e-3, 0.99)
+        return self.make_dims(B, T, F)
 
     def _bn_modules(self):
         return [getattr(self.cnn.cnn, f"batchnorm{i}") for i in range(3)]
@@ -226,7 +244,7 @@ class CRNN(nn.Module):
         params = list(self.parameters())
         device = device if device is not None else params[0].device
         if self._layout is None:
-            offs = _lib.param_layout(_lib.make_dims(1, 16, 64, 64, 64, self._nclass, self._n_layers, 0.0))
+            offs = _lib.param_layout(self.make_dims(1, 16, 64, 0.0))
             assert len(offs) == len(params) + 1, "parameter order does not match sed_param_layout"
             self._layout = [(offs[i], offs[i + 1], tuple(p.shape)) for i, p in enumerate(params)]
             for (o0, o1, shp), p in zip(self._layout, params):
@@ -239,9 +257,10 @@ class CRNN(nn.Module):
                     ok = False
                     break
             bns = self._bn_modules()
+            Cn = self._C
             for i, bn in enumerate(bns):
-                if bn.running_mean.data_ptr() != self._bn_flat.data_ptr() + 4 * (2 * i) * 64 or \
-                        bn.running_var.data_ptr() != self._bn_flat.data_ptr() + 4 * (2 * i + 1) * 64 or \
+                if bn.running_mean.data_ptr() != self._bn_flat.data_ptr() + 4 * (2 * i) * Cn or \
+                        bn.running_var.data_ptr() != self._bn_flat.data_ptr() + 4 * (2 * i + 1) * Cn or \
                         bn.num_batches_tracked.data_ptr() != self._bn_tracked.data_ptr() + 8 * i:
                     ok = False
                     break
@@ -254,14 +273,15 @@ class CRNN(nn.Module):
                 flat[o0:o1].copy_(p.data.reshape(-1).to(device=device, dtype=torch.float32))
                 p.data = flat[o0:o1].view(shp)
                 p.grad = None
-            bn_flat = torch.empty(3 * 2 * 64, device=device, dtype=torch.float32)
+            Cn = self._C
+            bn_flat = torch.empty(3 * 2 * Cn, device=device, dtype=torch.float32)
             trk = torch.empty(3, device=device, dtype=torch.int64)
             for i, bn in enumerate(self._bn_modules()):
-                bn_flat[(2 * i) * 64:(2 * i + 1) * 64].copy_(bn.running_mean.to(device))
-                bn_flat[(2 * i + 1) * 64:(2 * i + 2) * 64].copy_(bn.running_var.to(device))
+                bn_flat[(2 * i) * Cn:(2 * i + 1) * Cn].copy_(bn.running_mean.to(device))
+                bn_flat[(2 * i + 1) * Cn:(2 * i + 2) * Cn].copy_(bn.running_var.to(device))
                 trk[i] = bn.num_batches_tracked.to(device)
-                bn._buffers["running_mean"] = bn_flat[(2 * i) * 64:(2 * i + 1) * 64]
-                bn._buffers["running_var"] = bn_flat[(2 * i + 1) * 64:(2 * i + 2) * 64]
+                bn._buffers["running_mean"] = bn_flat[(2 * i) * Cn:(2 * i + 1) * Cn]
+                bn._buffers["running_var"] = bn_flat[(2 * i + 1) * Cn:(2 * i + 2) * Cn]
                 bn._buffers["num_batches_tracked"] = trk[i]
             self._flat, self._bn_flat, self._bn_tracked = flat, bn_flat, trk
             self._flat_gen += 1

@@ -103,11 +103,13 @@ struct Blk0PrepArgs {
     double N;
     int train, update;
     float eps, momentum;
-    float *wz, *wl, *bn;   // wz/wl [64][12], bn [4][64] = mean, invstd, scale, shift
+    float *wz, *wl, *bn;   // wz/wl [C][12], bn [4][C] = mean, invstd, scale, shift
+    int C;                 // conv filters of block 0 (64 on the reference's configuration, 128 for the wide one)
 };
 #define PREP_THREADS 896      // 54 moments x 16 partial-sum lanes = 864 threads for the reduction; >= 640 for the GLU fold
 __global__ __launch_bounds__(PREP_THREADS) void k_blk0_prep(Blk0PrepArgs a) {
-    __shared__ double wzs[64][10];
+    __shared__ double wzs[128][10];
+    const int C = a.C;
     __shared__ double mred[54][16];
     __shared__ double moms[54];
     const int tid = threadIdx.x;
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_blk0_prep(Blk0PrepArgs a) {
         }
         __syncthreads();
     }
-    if (tid < 64) {
+    if (tid < C) {
         const int c = tid;
         double w[9];
 #pragma unroll
@@ -182,13 +184,13 @@ __global__ __launch_bounds__(PREP_THREADS) void k_blk0_prep(Blk0PrepArgs a) {
         for (int t = 0; t < 10; ++t) a.wz[c * 12 + t] = (float)wzs[c][t];
         a.wz[c * 12 + 10] = 0.f; a.wz[c * 12 + 11] = 0.f;
         a.wl[c * 12 + 10] = 0.f; a.wl[c * 12 + 11] = 0.f;
-        a.bn[c] = (float)mean; a.bn[64 + c] = (float)invstd; a.bn[128 + c] = (float)scale; a.bn[192 + c] = (float)shift;
+        a.bn[c] = (float)mean; a.bn[C + c] = (float)invstd; a.bn[2 * C + c] = (float)scale; a.bn[3 * C + c] = (float)shift;
     }
     __syncthreads();
-    if (tid < 640) {   // wl[c][t] = sum_k Wglu[c][k] wz[k][t] (+ bglu at t = 9): one thread per (c, t)
-        const int c = tid / 10, t = tid % 10;
+    for (int e = tid; e < C * 10; e += PREP_THREADS) {   // wl[c][t] = sum_k Wglu[c][k] wz[k][t] (+ bglu at t = 9): one thread per (c, t)
+        const int c = e / 10, t = e % 10;
         double acc = (t == 9) ? (double)a.bglu[c] : 0.0;
-        for (int k = 0; k < 64; ++k) acc += (double)a.wglu[c * 64 + k] * wzs[k][t];
+        for (int k = 0; k < C; ++k) acc += (double)a.wglu[c * C + k] * wzs[k][t];
         a.wl[c * 12 + t] = (float)acc;
     }
 }
@@ -198,20 +200,23 @@ __global__ __launch_bounds__(PREP_THREADS) void k_blk0_prep(Blk0PrepArgs a) {
 // Wave w owns pooled row w; it walks 4 "row blocks" g of 32 pixels = pooled cols 4g..4g+3.
 // MFMA row m of a row block: j = m>>3 (pooled col 4g+j), dt = (m>>2)&1, df = m&3, so that
 // D-fragment register r of lane l (row (r&3)+8(r>>2)+4(l>>5)) is pooled col r>>2, dt = l>>5, df = r&3.
+template <int NH>      // NH = C / 32 channel slices
 struct Blk0W {
-    float bw[5][4];   // B fragments: [k-step][col block]; col blocks 0,1 = lin, 2,3 = z
+    float bw[5][2 * NH];   // B fragments: [k-step][col block]; col blocks 0 .. NH-1 = lin, NH .. 2NH-1 = z
 };
-__device__ __forceinline__ void blk0_load_w(Blk0W& W, const float* __restrict__ wz, const float* __restrict__ wl, int lane) {
+template <int NH>
+__device__ __forceinline__ void blk0_load_w(Blk0W<NH>& W, const float* __restrict__ wz, const float* __restrict__ wl, int lane) {
     const int n = lane & 31, kh = lane >> 5;
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
         const int k = 2 * s + kh;
-        W.bw[s][0] = wl[n * 12 + k];
-        W.bw[s][1] = wl[(32 + n) * 12 + k];
-        // the z columns carry -log2(e): the MFMA then delivers the argument of exp2 in sigmoid(z) = 1 / (1 + 2^(-log2e z))
-        // directly (these kernels are VALU-bound; z itself is never needed, only sigmoid(z))
-        W.bw[s][2] = wz[n * 12 + k] * SED_NEG_LOG2E;
-        W.bw[s][3] = wz[(32 + n) * 12 + k] * SED_NEG_LOG2E;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            W.bw[s][h] = wl[(32 * h + n) * 12 + k];
+            // the z columns carry -log2(e): the MFMA then delivers the argument of exp2 in sigmoid(z) = 1 / (1 + 2^(-log2e z))
+            // directly (these kernels are VALU-bound; z itself is never needed, only sigmoid(z))
+            W.bw[s][NH + h] = wz[(32 * h + n) * 12 + k] * SED_NEG_LOG2E;
+        }
     }
 }
 __device__ __forceinline__ void blk0_load_xs(float* xs, const float* __restrict__ x, int b, int T, int t0, int tid) {
@@ -230,15 +235,17 @@ __device__ __forceinline__ void blk0_load_xs(float* xs, const float* __restrict_
 // ---- forward --------------------------------------------------------------------------------
 // (256, 3): with a register budget below 256 the compiler selects the VGPR form of the MFMAs - with the default budget it
 // put the accumulators in AGPRs and paid 64 v_accvgpr_read per row block (12 % of this VALU-bound kernel's instructions)
-__global__ __launch_bounds__(256, 4) void k_blk0_fwd(const float* __restrict__ x, const float* __restrict__ wz,
+template <int NH>
+__global__ __launch_bounds__(256, (NH == 2 ? 4 : 2)) void k_blk0_fwd(const float* __restrict__ x, const float* __restrict__ wz,
                                                    const float* __restrict__ wl, float* __restrict__ p0, int B, int T,
                                                    int H1, int tiles_per_clip, int n_tiles, int use_drop, float p_drop,
                                                    const uint64_t* __restrict__ seed_ptr, uint16_t* __restrict__ mask_out) {
     __shared__ float xs[XS_H * XS_W];
+    constexpr int C = 32 * NH;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
-    Blk0W W;
-    blk0_load_w(W, wz, wl, lane);
+    Blk0W<NH> W;
+    blk0_load_w<NH>(W, wz, wl, lane);
     const uint64_t seed = use_drop ? seed_ptr[0] : 0ull;
     const uint32_t thr = drop_thresh8(p_drop);
     const bool one_bit = (thr == 128u);
@@ -250,8 +257,16 @@ __global__ __launch_bounds__(256, 4) void k_blk0_fwd(const float* __restrict__ x
         __syncthreads();
         const int to = to0 + wv;
         if (to >= H1) continue;
-        u32x4 o1 = {0u, 0u, 0u, 0u};
-        if (use_drop && one_bit) o1 = philox_stream_1bit((uint32_t)(b * H1 + to) * 4u, lane, 0, seed);   // all 4 row blocks
+        // p = 0.5: one Philox draw carries the 16-bit keep fields of 8 consecutive (row block, channel slice) units
+        // u = rb * NH + h (philox.h / gen.h): the 4 row blocks of this pooled row are units [4 NH rb0, 4 NH rb0 + 4 NH), i.e.
+        // NH / 2 whole draws, made here once (C = 64: one draw, exactly philox_stream_1bit of the first version)
+        u32x4 o1[NH / 2];
+#pragma unroll
+        for (int d = 0; d < NH / 2; ++d) {
+            o1[d] = (u32x4){0u, 0u, 0u, 0u};
+            if (use_drop && one_bit)
+                o1[d] = philox_stream(((uint32_t)(b * H1 + to) * (NH / 2) + d) * 64u + (uint32_t)lane, PHILOX_STREAM_1BIT, seed);
+        }
         for (int g = 0; g < 4; ++g) {
             // MFMA A operand of this row block: this lane's pixel m, taps 2s + kh (shared by both channel halves)
             float av[5];
@@ -265,67 +280,71 @@ __global__ __launch_bounds__(256, 4) void k_blk0_fwd(const float* __restrict__ x
                 }
             }
             const int q0 = (b * H1 + to) * 16 + 4 * g;
-            // the two 32-channel halves one after the other (lin_h and z_h: 2 x 16 accumulator registers live instead of
-            // 4 x 16): 4 waves per SIMD instead of 3 for this VALU-bound kernel
+            // the 32-channel slices one after the other (lin_h and z_h: 2 x 16 accumulator registers live instead of
+            // 2 NH x 16): 4 waves per SIMD instead of 3 for this VALU-bound kernel
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                f32x16 acc[4];
+            for (int h = 0; h < NH; ++h) {
+                f32x16 al, az;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { acc[h][r] = 0.f; acc[2 + h][r] = 0.f; }
+                for (int r = 0; r < 16; ++r) { al[r] = 0.f; az[r] = 0.f; }
 #pragma unroll
                 for (int s5 = 0; s5 < 5; ++s5) {
-                    acc[h] = mfma32(av[s5], W.bw[s5][h], acc[h]);
-                    acc[2 + h] = mfma32(av[s5], W.bw[s5][2 + h], acc[2 + h]);
+                    al = mfma32(av[s5], W.bw[s5][h], al);
+                    az = mfma32(av[s5], W.bw[s5][NH + h], az);
                 }
                 const int c = 32 * h + n;
                 float pooled[4] = {0.f, 0.f, 0.f, 0.f};
                 if (use_drop) {
                     uint32_t m16;
                     if (one_bit) {
-                        m16 = philox_field16(o1, 2 * g + h);
+                        // local unit g * NH + h: draw (g * NH + h) >> 3, field (g * NH + h) & 7
+                        if (NH == 2) m16 = philox_field16(o1[0], 2 * g + h);
+                        else m16 = philox_field16((g >> 1) ? o1[NH / 2 - 1] : o1[0], 4 * (g & 1) + h);
                     } else {
                         // one Philox draw = 16 bytes = this lane's 16 elements (4 pooled pixels x 4 df) of channel c
-                        const u32x4 o = philox_stream((uint32_t)((q0 >> 2) * 64 + c), (uint32_t)kh, seed);
+                        const u32x4 o = philox_stream((uint32_t)((q0 >> 2) * C + c), (uint32_t)kh, seed);
                         m16 = philox_keep16(o, thr);
                     }
-                    if (mask_out) mask_out[((size_t)(q0 >> 2) * 2 + h) * 64 + lane] = (uint16_t)m16;
+                    if (mask_out) mask_out[((size_t)(q0 >> 2) * NH + h) * 64 + lane] = (uint16_t)m16;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float lm = ((m16 >> r) & 1u) ? acc[h][r] : 0.f;
-                        pooled[r >> 2] = fmaf(lm, sigmoid_from_scaled(acc[2 + h][r]), pooled[r >> 2]);
+                        const float lm = ((m16 >> r) & 1u) ? al[r] : 0.f;
+                        pooled[r >> 2] = fmaf(lm, sigmoid_from_scaled(az[r]), pooled[r >> 2]);
                     }
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) pooled[r >> 2] = fmaf(acc[h][r], sigmoid_from_scaled(acc[2 + h][r]), pooled[r >> 2]);
+                    for (int r = 0; r < 16; ++r) pooled[r >> 2] = fmaf(al[r], sigmoid_from_scaled(az[r]), pooled[r >> 2]);
                 }
 #pragma unroll
                 for (int jx = 0; jx < 4; ++jx) pooled[jx] += __shfl_xor(pooled[jx], 32);
                 const float sc = 0.125f * keep_scale;
                 const int j0 = 2 * kh;
-                p0[(size_t)(q0 + j0) * 64 + c] = (kh ? pooled[2] : pooled[0]) * sc;
-                p0[(size_t)(q0 + j0 + 1) * 64 + c] = (kh ? pooled[3] : pooled[1]) * sc;
+                p0[(size_t)(q0 + j0) * C + c] = (kh ? pooled[2] : pooled[0]) * sc;
+                p0[(size_t)(q0 + j0 + 1) * C + c] = (kh ? pooled[3] : pooled[1]) * sc;
             }
         }
     }
 }
 
 // ---- backward: D[co][t] = sum_p dlin[p][co] P[p][t],  E[c][t] = sum_p dzgate[p][c] P[p][t] ------
-__global__ __launch_bounds__(256, 2) void k_blk0_bwd(const float* __restrict__ x, const float* __restrict__ wz,
+template <int NH>
+__global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float* __restrict__ x, const float* __restrict__ wz,
                                                    const float* __restrict__ wl, const float* __restrict__ dp0, int B,
                                                    int T, int H1, int tiles_per_clip, int n_tiles, int use_drop,
                                                    float p_drop, const uint16_t* __restrict__ mask_in,
-                                                   double* __restrict__ de /* [2][64][10] */, int no_atomic) {
+                                                   double* __restrict__ de /* [2][C][10] */, int no_atomic) {
     __shared__ float xs[XS_H * XS_W];
     __shared__ __attribute__((aligned(16))) float P[4][32 * 12];
-    __shared__ float red[4][2][2][32][10];
+    __shared__ float red[4][2][NH][32][10];
+    constexpr int C = 32 * NH;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
-    Blk0W W;
-    blk0_load_w(W, wz, wl, lane);
+    Blk0W<NH> W;
+    blk0_load_w<NH>(W, wz, wl, lane);
     const float keep_scale = use_drop ? drop_scale8(p_drop) : 1.0f;
-    float aD[2][10], aE[2][10];
+    float aD[NH][10], aE[NH][10];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < NH; ++h)
 #pragma unroll
         for (int t = 0; t < 10; ++t) { aD[h][t] = 0.f; aE[h][t] = 0.f; }
     float* Pw = P[wv];
@@ -339,24 +358,24 @@ __global__ __launch_bounds__(256, 2) void k_blk0_bwd(const float* __restrict__ x
         // pooled gradients + keep bits of a row block are fetched one row block AHEAD: this kernel runs one
         // wave per SIMD (256 VGPRs), so a load issued right before its use stalls the whole SIMD for a full
         // HBM/L2 round trip (~1 us per row block in the first version)
-        float gq_n[2][4];
-        uint32_t m_n[2];
+        float gq_n[NH][4];
+        uint32_t m_n[NH];
         auto fetch = [&](int g) {
             const int q0 = (b * H1 + to) * 16 + 4 * g;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < NH; ++h) {
                 const int c = 32 * h + n;
 #pragma unroll
-                for (int jx = 0; jx < 4; ++jx) gq_n[h][jx] = dp0[(size_t)(q0 + jx) * 64 + c];
-                m_n[h] = use_drop ? (uint32_t)mask_in[((size_t)(q0 >> 2) * 2 + h) * 64 + lane] : 0xffffu;
+                for (int jx = 0; jx < 4; ++jx) gq_n[h][jx] = dp0[(size_t)(q0 + jx) * C + c];
+                m_n[h] = use_drop ? (uint32_t)mask_in[((size_t)(q0 >> 2) * NH + h) * 64 + lane] : 0xffffu;
             }
         };
         fetch(0);
         for (int g = 0; g < 4; ++g) {
-            float gq_c[2][4];
-            uint32_t m_c[2];
+            float gq_c[NH][4];
+            uint32_t m_c[NH];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < NH; ++h) {
                 m_c[h] = m_n[h];
 #pragma unroll
                 for (int jx = 0; jx < 4; ++jx) gq_c[h][jx] = gq_n[h][jx] * (0.125f * keep_scale);
@@ -383,14 +402,14 @@ __global__ __launch_bounds__(256, 2) void k_blk0_bwd(const float* __restrict__ x
             // kernel fits 2 waves per SIMD (the all-at-once version needed 331 registers = 1 wave, and every
             // LDS / MFMA latency of its in-order instruction stream was exposed)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < NH; ++h) {
                 f32x16 al, az;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { al[r] = 0.f; az[r] = 0.f; }
 #pragma unroll
                 for (int s5 = 0; s5 < 5; ++s5) {
                     al = mfma32(av[s5], W.bw[s5][h], al);
-                    az = mfma32(av[s5], W.bw[s5][2 + h], az);
+                    az = mfma32(av[s5], W.bw[s5][NH + h], az);
                 }
                 float dl[16], dzg[16];
 #pragma unroll
@@ -419,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void k_blk0_bwd(const float* __restrict__ x
     }
     // reduce: half-waves share the channel; then waves; then fp64 atomics
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < NH; ++h)
 #pragma unroll
         for (int t = 0; t < 10; ++t) {
             float vD = aD[h][t] + __shfl_xor(aD[h][t], 32);
@@ -427,8 +446,8 @@ __global__ __launch_bounds__(256, 2) void k_blk0_bwd(const float* __restrict__ x
             if (kh == 0) { red[wv][0][h][n][t] = vD; red[wv][1][h][n][t] = vE; }
         }
     __syncthreads();
-    for (int i = tid; i < 2 * 64 * 10; i += 256) {
-        const int which = i / 640, c = (i % 640) / 10, t = i % 10;
+    for (int i = tid; i < 2 * C * 10; i += 256) {
+        const int which = i / (C * 10), c = (i % (C * 10)) / 10, t = i % 10;
         const int h = c >> 5, nn = c & 31;
         double v = (double)red[0][which][h][nn][t] + (double)red[1][which][h][nn][t] + (double)red[2][which][h][nn][t] +
                    (double)red[3][which][h][nn][t];
@@ -444,37 +463,38 @@ struct Blk0BwdFinArgs {
     const double* de;      // D[64][10], E[64][10]
     double N;
     float *g_w0, *g_b0, *g_gamma, *g_beta, *g_wglu, *g_bglu;
+    int C;
 };
 __global__ __launch_bounds__(640) void k_blk0_bwd_finalize(Blk0BwdFinArgs a) {
-    __shared__ double wzs[64][10];
-    __shared__ double Ds[64][10];
-    __shared__ double Ss[64][10];
-    const int tid = threadIdx.x;
-    {   // thread per (c, t)
-        const int c = tid / 10, t = tid % 10;
-        const double scale = a.bn[128 + c], shift = a.bn[192 + c];
+    __shared__ double wzs[128][10];
+    __shared__ double Ds[128][10];
+    __shared__ double Ss[128][10];
+    const int tid = threadIdx.x, C = a.C;
+    for (int e = tid; e < C * 10; e += 640) {   // (c, t)
+        const int c = e / 10, t = e % 10;
+        const double scale = a.bn[2 * C + c], shift = a.bn[3 * C + c];
         wzs[c][t] = (t < 9) ? scale * (double)a.w0[c * 9 + t] : scale * (double)a.b0[c] + shift;
         Ds[c][t] = a.de[c * 10 + t];
     }
     __syncthreads();
     // GLU linear: dWglu[co][k] = sum_t D[co][t] wz[k][t];  dbglu[co] = D[co][9]
-    for (int e = tid; e < 4096; e += 640) {
-        const int co = e >> 6, k = e & 63;
+    for (int e = tid; e < C * C; e += 640) {
+        const int co = e / C, k = e % C;
         double acc = 0;
 #pragma unroll
         for (int t = 0; t < 10; ++t) acc += Ds[co][t] * wzs[k][t];
         a.g_wglu[e] = (float)acc;
     }
-    {   // total dz against the patch: S[c][t] = sum_co Wglu[co][c] D[co][t] + E[c][t]
-        const int c = tid / 10, t = tid % 10;
-        double acc = a.de[640 + c * 10 + t];
-        for (int co = 0; co < 64; ++co) acc += (double)a.wglu[co * 64 + c] * Ds[co][t];
+    for (int e = tid; e < C * 10; e += 640) {   // total dz against the patch: S[c][t] = sum_co Wglu[co][c] D[co][t] + E[c][t]
+        const int c = e / 10, t = e % 10;
+        double acc = a.de[C * 10 + c * 10 + t];
+        for (int co = 0; co < C; ++co) acc += (double)a.wglu[co * C + c] * Ds[co][t];
         Ss[c][t] = acc;
     }
     __syncthreads();
-    if (tid < 64) {
+    if (tid < C) {
         const int c = tid;
-        const double mean = a.bn[c], invstd = a.bn[64 + c], scale = a.bn[128 + c];
+        const double mean = a.bn[c], invstd = a.bn[C + c], scale = a.bn[2 * C + c];
         double w[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) w[t] = a.w0[c * 9 + t];
@@ -526,12 +546,14 @@ int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const flo
     a.run_mean = run_mean; a.run_var = run_var; a.tracked = tracked; a.mom = mom;
     a.mompart = mompart; a.n_part = x_moments_parts(g);
     a.N = (double)g.B * g.T * g.F; a.train = train; a.update = update; a.eps = g.eps; a.momentum = g.mom;
-    a.wz = wz; a.wl = wl; a.bn = bn;
+    a.wz = wz; a.wl = wl; a.bn = bn; a.C = g.C;
     k_blk0_prep<<<1, PREP_THREADS, 0, st>>>(a);
     SED_CHECK_LAUNCH();
     const int tpc = (g.H1 + 3) / 4, nt = tpc * g.B;
     const int use_drop = (train && g.p > 0.f) ? 1 : 0;
-    k_blk0_fwd<<<nt < 2048 ? nt : 2048, 256, 0, st>>>(x, wz, wl, p0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, seed, mask_out);
+    if (g.C == 64) k_blk0_fwd<2><<<nt < 2048 ? nt : 2048, 256, 0, st>>>(x, wz, wl, p0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, seed, mask_out);
+    else if (g.C == 128) k_blk0_fwd<4><<<nt < 1024 ? nt : 1024, 256, 0, st>>>(x, wz, wl, p0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, seed, mask_out);
+    else { sed_set_error("block 0: unsupported filter count %d", g.C); return SED_ERR_UNSUPPORTED; }
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
@@ -541,15 +563,17 @@ int launch_blk0_backward(const Geo& g, const float* x, const float* w0, const fl
                          const float* wz, const float* wl, const float* bn, const float* dp0, double* de, int zero_de,
                          float* g_w0, float* g_b0, float* g_gamma, float* g_beta, float* g_wglu, float* g_bglu,
                          hipStream_t st) {
-    if (zero_de) SED_CHECK_HIP(hipMemsetAsync(de, 0, 2 * 64 * 10 * sizeof(double), st));
+    if (zero_de) SED_CHECK_HIP(hipMemsetAsync(de, 0, 2 * g.C * 10 * sizeof(double), st));
     const int tpc = (g.H1 + 3) / 4, nt = tpc * g.B;
     const int use_drop = (g.p > 0.f) ? 1 : 0;
-    k_blk0_bwd<<<nt < 512 ? nt : 512, 256, 0, st>>>(x, wz, wl, dp0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, mask_in, de, g_sed_debug & 1);
+    if (g.C == 64) k_blk0_bwd<2><<<nt < 512 ? nt : 512, 256, 0, st>>>(x, wz, wl, dp0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, mask_in, de, g_sed_debug & 1);
+    else if (g.C == 128) k_blk0_bwd<4><<<nt < 256 ? nt : 256, 256, 0, st>>>(x, wz, wl, dp0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, mask_in, de, g_sed_debug & 1);
+    else { sed_set_error("block 0: unsupported filter count %d", g.C); return SED_ERR_UNSUPPORTED; }
     SED_CHECK_LAUNCH();
     Blk0BwdFinArgs a;
     a.w0 = w0; a.b0 = b0; a.gamma = gamma; a.beta = beta; a.wglu = wglu; a.bn = bn; a.mom = mom; a.de = de;
     a.N = (double)g.B * g.T * g.F;
-    a.g_w0 = g_w0; a.g_b0 = g_b0; a.g_gamma = g_gamma; a.g_beta = g_beta; a.g_wglu = g_wglu; a.g_bglu = g_bglu;
+    a.g_w0 = g_w0; a.g_b0 = g_b0; a.g_gamma = g_gamma; a.g_beta = g_beta; a.g_wglu = g_wglu; a.g_bglu = g_bglu; a.C = g.C;
     k_blk0_bwd_finalize<<<1, 640, 0, st>>>(a);
     SED_CHECK_LAUNCH();
     return SED_OK;

@@ -12,6 +12,7 @@
 #include <string.h>
 #include "common.h"
 #include "kernels.h"
+#include "gkernels.h"
 
 static thread_local char g_err[512] = "";
 void sed_set_error(const char* fmt, ...) {
@@ -27,8 +28,10 @@ extern "C" int sed_debug_set(int flags) { const int old = g_sed_debug; g_sed_deb
 
 int sed_validate_dims(const sed_dims* d) {
     SED_CHECK_ARG(d != nullptr, "null dims");
-    if (d->F != 64 || d->C != 64 || d->H != 64) {
-        sed_set_error("hot path supports F = C = H = 64 only (got F=%d C=%d H=%d)", d->F, d->C, d->H);
+    if (d->F != 64 || (d->C != 64 && d->C != 128) || (d->H != 64 && d->H != 256) ||
+        (d->dtype != SED_DTYPE_F32 && d->dtype != SED_DTYPE_BF16)) {
+        sed_set_error("supported: F = 64, C in {64, 128}, H in {64, 256}, dtype in {f32, bf16} (got F=%d C=%d H=%d dtype=%d)",
+                      d->F, d->C, d->H, d->dtype);
         return SED_ERR_UNSUPPORTED;
     }
     SED_CHECK_ARG(d->B >= 1 && d->T >= 16, "need B >= 1 and T >= 16");
@@ -137,17 +140,20 @@ extern "C" int sed_param_layout(const sed_dims* d, int64_t* offsets) {
 }
 extern "C" size_t sed_crnn_ctx_bytes(const sed_dims* d) {
     if (sed_validate_dims(d) != SED_OK) return 0;
-    return make_ctx_layout(make_geo(d)).total;
+    const Geo g = make_geo(d);
+    return g.generic ? gen_ctx_bytes(g) : make_ctx_layout(g).total;
 }
 extern "C" size_t sed_crnn_bwd_ws_bytes(const sed_dims* d) {
     if (sed_validate_dims(d) != SED_OK) return 0;
-    return make_ws_layout(make_geo(d)).total;
+    const Geo g = make_geo(d);
+    return g.generic ? gen_ws_bytes(g) : make_ws_layout(g).total;
 }
 
 extern "C" int sed_crnn_ctx_view(const sed_dims* d, const char* name, size_t* offset, size_t* bytes) {
     SED_TRY(sed_validate_dims(d));
     SED_CHECK_ARG(name && offset && bytes, "null argument");
     const Geo g = make_geo(d);
+    if (g.generic) return gen_ctx_view(g, name, offset, bytes);
     const CtxLayout L = make_ctx_layout(g);
     const size_t n0 = (size_t)g.B * g.H1 * g.W1 * 64 * 4, n1 = (size_t)g.B * g.H2 * g.W2 * 64 * 4, bt = (size_t)g.B * g.T3;
     struct { const char* n; size_t o, b; } tab[] = {
@@ -228,6 +234,11 @@ extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* b
     SED_CHECK_ARG(params && bn_running && x && ctx && strong && weak, "sed_crnn_forward: null argument");
     const Geo g = make_geo(d);
     const ParamOff P = make_param_off(g, nullptr);
+    if (g.generic) {
+        SED_CHECK_ARG(!(train && g.p > 0.f) || seed_dev, "sed_crnn_forward: dropout enabled but seed_dev is null");
+        return gen_forward(g, P, params, bn_running, bn_tracked, x, train, update_bn, seed_dev, ctx, ctx_bytes, strong, weak,
+                           (hipStream_t)stream);
+    }
     const CtxLayout L = make_ctx_layout(g);
     if (ctx_bytes < L.total) {
         sed_set_error("sed_crnn_forward: ctx has %zu bytes, needs %zu", ctx_bytes, L.total);
@@ -291,6 +302,13 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
                   "sed_crnn_backward: parts must be 1, 2, 3, 5 or 8");
     const Geo g = make_geo(d);
     const ParamOff P = make_param_off(g, nullptr);
+    if (g.generic) {
+        SED_CHECK_ARG(!(g.p > 0.f) || seed_dev, "sed_crnn_backward: dropout enabled but seed_dev is null");
+        hipStream_t st0 = (hipStream_t)stream;
+        SideStream& sd0 = side_stream(st0);
+        return gen_backward(g, P, params, x, seed_dev, ctx, ctx_bytes, d_strong, d_weak, grads, ws, ws_bytes, parts, st0,
+                            sd0.ok ? sd0.s : st0, sd0.fork, sd0.join, hl);
+    }
     const CtxLayout L = make_ctx_layout(g);
     const WsLayout W = make_ws_layout(g);
     if (ctx_bytes < L.total || ws_bytes < W.total) {
@@ -455,6 +473,10 @@ extern "C" int sed_kernel_replay(const char* name, const sed_dims* d, const floa
     SED_TRY(sed_validate_dims(d));
     SED_CHECK_ARG(name && params && x && ctx && grads && ws, "sed_kernel_replay: null argument");
     const Geo g = make_geo(d);
+    if (g.generic) {
+        sed_set_error("sed_kernel_replay: only the C = 64 / H = 64 / fp32 kernel set is replayable");
+        return SED_ERR_UNSUPPORTED;
+    }
     const ParamOff P = make_param_off(g, nullptr);
     const CtxLayout L = make_ctx_layout(g);
     const WsLayout W = make_ws_layout(g);

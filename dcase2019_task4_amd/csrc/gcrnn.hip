@@ -1,0 +1,326 @@
+// gcrnn.hip - CRNN forward / backward orchestration of the GENERIC kernel set (gen.h) behind the same C-ABI entry
+// points as crnn.hip (which dispatches here for every configuration other than C = 64 / H = 64 / fp32).
+//
+// Operator sequence = CRNN.forward (baseline/models/CRNN.py:59-84) with nb_filters = [C, C, C], n_RNN_cell = H:
+//   block 0 (blk0.hip, templated on C; always fp32) -> [conv3x3 + BN sums (gconv.hip) -> BN / GLU / dropout / pool
+//   (gglu.hip)] x 2 -> BiGRU: input projection (gemm.hip) + recurrence (ggru.hip for H = 256, gru.hip for H = 64)
+//   -> heads (heads.hip, templated on 2 H).
+#include <string.h>
+#include "common.h"
+#include "kernels.h"
+#include "gkernels.h"
+
+static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+static inline size_t esz(const Geo& g) { return g.mode == SED_DTYPE_BF16 ? 2 : 4; }
+static inline int gru_splitk(const Geo& g) { return g.H == 64 ? SED_GRU_SPLITK : 4; }
+
+struct GCtx {
+    size_t acc0, mom0, stat1, stat2;          // fp64: patch moments of block 0 | BatchNorm sums of blocks 1, 2
+    size_t wz0, wl0, bn0, mompart, p0;
+    size_t wpk[3], wpkT[3], wg[3], wgT[3], bg[3], y[3], bn[3], p[3];      // index 1, 2
+    size_t gi[2], gates[2], out[2], whh[2], whhT[2];
+    size_t logits_s, strong_sv, weak_sv, den_sv;
+    size_t mask[3];
+    size_t total;
+};
+static size_t mask_bytes(size_t Q, int C) { return ((Q + 3) / 4) * (size_t)(C / 32) * 64 * sizeof(uint16_t); }
+
+static GCtx make_gctx(const Geo& g) {
+    GCtx L;
+    size_t o = 0;
+    auto put = [&](size_t& f, size_t bytes) { f = o; o = al(o + bytes); };
+    const size_t C = g.C, H = g.H, E = esz(g);
+    const size_t n0 = (size_t)g.B * g.H1 * g.W1 * C, n1 = (size_t)g.B * g.H2 * g.W2 * C, n2 = (size_t)g.B * g.T3 * C;
+    put(L.acc0, (64 + 4 * C) * sizeof(double));
+    L.mom0 = L.acc0; L.stat1 = L.acc0 + 64 * sizeof(double); L.stat2 = L.stat1 + 2 * C * sizeof(double);
+    put(L.wz0, C * 12 * 4); put(L.wl0, C * 12 * 4); put(L.bn0, 4 * C * 4);
+    put(L.mompart, (size_t)x_moments_parts(g) * 54 * sizeof(double));
+    put(L.p0, n0 * 4);
+    L.p[0] = L.p0;
+    const size_t nn[3] = {0, n0, n1}, np[3] = {n0, n1, n2};
+    for (int i = 1; i <= 2; ++i) {
+        put(L.wpk[i], 9 * C * C * E); put(L.wpkT[i], 9 * C * C * E); put(L.wg[i], C * C * E); put(L.wgT[i], C * C * E);
+        put(L.bg[i], C * 4); put(L.y[i], nn[i] * 4); put(L.bn[i], 4 * C * 4); put(L.p[i], np[i] * 4);
+    }
+    const size_t bt = (size_t)g.B * g.T3;
+    for (int l = 0; l < 2; ++l) {
+        put(L.gi[l], g.H == 64 ? 0 : bt * 6 * H * 4);          // (H = 64: the projection runs inside gru.hip's kernel)
+        put(L.gates[l], bt * 8 * H * 4); put(L.out[l], bt * 2 * H * 4);
+        put(L.whh[l], g.H == 64 ? 0 : 2 * 3 * H * H * 4); put(L.whhT[l], g.H == 64 ? 0 : 2 * 3 * H * H * 4);
+    }
+    put(L.logits_s, bt * g.NC * 4); put(L.strong_sv, bt * g.NC * 4);
+    put(L.weak_sv, (size_t)g.B * g.NC * 4); put(L.den_sv, (size_t)g.B * g.NC * 4);
+    put(L.mask[0], mask_bytes((size_t)g.B * g.H1 * g.W1, g.C)); put(L.mask[1], mask_bytes((size_t)g.B * g.H2 * g.W2, g.C));
+    put(L.mask[2], mask_bytes((size_t)g.B * g.T3, g.C));
+    L.total = o;
+    return L;
+}
+
+struct GWs {
+    size_t d_out, dgi[2], dgh[2], hprev[2], d_in, heads_part;
+    size_t dp[3], dz[3], coef[3];             // dp[i]: gradient w.r.t. block i's pooled output; dz / coef: blocks 1, 2
+    size_t glu_part, de0, wg_part, gemm_part;
+    size_t total;
+};
+static GWs make_gws(const Geo& g) {
+    GWs W;
+    size_t o = 0;
+    auto put = [&](size_t& f, size_t bytes) { f = o; o = al(o + bytes); };
+    const size_t C = g.C, H = g.H, bt = (size_t)g.B * g.T3;
+    const size_t n0 = (size_t)g.B * g.H1 * g.W1 * C, n1 = (size_t)g.B * g.H2 * g.W2 * C;
+    put(W.d_out, bt * 2 * H * 4);
+    for (int l = 0; l < 2; ++l) { put(W.dgi[l], bt * 6 * H * 4); put(W.dgh[l], bt * 6 * H * 4); put(W.hprev[l], bt * 2 * H * 4); }
+    put(W.d_in, 2 * bt * 2 * H * 4);          // (H = 64: two direction planes, gru.hip; generic: one tensor)
+    put(W.heads_part, (size_t)g.B * 2 * (g.NC * 2 * H + g.NC) * 4);
+    put(W.dp[2], 2 * bt * C * 4); put(W.dz[2], n1 * 4); put(W.dp[1], n1 * 4); put(W.dz[1], n0 * 4); put(W.dp[0], n0 * 4);
+    W.dz[0] = 0; W.coef[0] = 0;
+    put(W.coef[1], 3 * C * 4); put(W.coef[2], 3 * C * 4);
+    put(W.glu_part, (size_t)gglu_bwd_grid(g.B, g.H1, g.W1) * (C * C + 3 * C) * 4);
+    put(W.de0, 2 * C * 10 * sizeof(double));
+    put(W.wg_part, (size_t)gwgrad_slabs(g.C) * 9 * C * C * 4);
+    const size_t max_nin = (size_t)(g.L > 1 ? (2 * H > C ? 2 * H : C) : C);
+    put(W.gemm_part, gemm_part_floats(4, gru_splitk(g), 3 * (int)H, (int)max_nin + 1) * 4);
+    W.total = o;
+    return W;
+}
+
+size_t gen_ctx_bytes(const Geo& g) { return make_gctx(g).total; }
+size_t gen_ws_bytes(const Geo& g) { return make_gws(g).total; }
+
+int gen_ctx_view(const Geo& g, const char* name, size_t* offset, size_t* bytes) {
+    const GCtx L = make_gctx(g);
+    const size_t C = g.C, H = g.H, bt = (size_t)g.B * g.T3;
+    const size_t n0 = (size_t)g.B * g.H1 * g.W1 * C * 4, n1 = (size_t)g.B * g.H2 * g.W2 * C * 4;
+    struct { const char* n; size_t o, b; } tab[] = {
+        {"mom0", L.mom0, 64 * 8}, {"bn0", L.bn0, 4 * C * 4}, {"p0", L.p[0], n0}, {"y1", L.y[1], n0}, {"stat1", L.stat1, 2 * C * 8},
+        {"bn1", L.bn[1], 4 * C * 4}, {"p1", L.p[1], n1}, {"y2", L.y[2], n1}, {"stat2", L.stat2, 2 * C * 8}, {"bn2", L.bn[2], 4 * C * 4},
+        {"p2", L.p[2], bt * C * 4}, {"gates0", L.gates[0], bt * 8 * H * 4}, {"gates1", L.gates[1], bt * 8 * H * 4},
+        {"gru0", L.out[0], bt * 2 * H * 4}, {"gru1", L.out[1], bt * 2 * H * 4}, {"logits_s", L.logits_s, bt * g.NC * 4},
+        {"den", L.den_sv, (size_t)g.B * g.NC * 4},
+    };
+    for (auto& t : tab)
+        if (strcmp(t.n, name) == 0) { *offset = t.o; *bytes = t.b; return SED_OK; }
+    sed_set_error("sed_crnn_ctx_view: unknown buffer '%s'", name);
+    return SED_ERR_BAD_ARG;
+}
+
+#define CTXF(off) ((float*)((char*)ctx + (off)))
+#define CTXD(off) ((double*)((char*)ctx + (off)))
+#define CTXV(off) ((void*)((char*)ctx + (off)))
+#define CTXM(off) ((uint16_t*)((char*)ctx + (off)))
+#define WSF(off) ((float*)((char*)ws + (off)))
+#define WSD(off) ((double*)((char*)ws + (off)))
+
+int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_running, int64_t* bn_tracked, const float* x,
+                int train, int update_bn, const uint64_t* seed_dev, void* ctx, size_t ctx_bytes, float* strong, float* weak,
+                hipStream_t st) {
+    const GCtx L = make_gctx(g);
+    if (ctx_bytes < L.total) {
+        sed_set_error("sed_crnn_forward: ctx has %zu bytes, needs %zu", ctx_bytes, L.total);
+        return SED_ERR_WORKSPACE;
+    }
+    const int C = g.C, H = g.H;
+    const int use_drop = (train && g.p > 0.f) ? 1 : 0;
+    const int upd = (train && update_bn) ? 1 : 0;
+    int64_t* trk[3] = {bn_tracked ? bn_tracked + 0 : nullptr, bn_tracked ? bn_tracked + 1 : nullptr,
+                       bn_tracked ? bn_tracked + 2 : nullptr};
+    // ---- weight packing (conv panels, GLU weights folded with the BatchNorm affine, GRU streaming layout) + the fp64
+    //      BatchNorm accumulators of blocks 1 and 2 ----------------------------------------------------------------------
+    GenPackArgs pk = {};
+    pk.C = C;
+    pk.w1 = params + P.conv_w[1]; pk.w2 = params + P.conv_w[2];
+    pk.wpk1 = CTXV(L.wpk[1]); pk.wpk2 = CTXV(L.wpk[2]);
+    pk.wpkT1 = train ? CTXV(L.wpkT[1]) : nullptr; pk.wpkT2 = train ? CTXV(L.wpkT[2]) : nullptr;
+    pk.glu_w1 = params + P.glu_w[1]; pk.glu_w2 = params + P.glu_w[2]; pk.glu_b1 = params + P.glu_b[1]; pk.glu_b2 = params + P.glu_b[2];
+    pk.gamma1 = params + P.bn_g[1]; pk.gamma2 = params + P.bn_g[2]; pk.beta1 = params + P.bn_b[1]; pk.beta2 = params + P.bn_b[2];
+    pk.wg1 = CTXV(L.wg[1]); pk.wg2 = CTXV(L.wg[2]);
+    pk.wgT1 = train ? CTXV(L.wgT[1]) : nullptr; pk.wgT2 = train ? CTXV(L.wgT[2]) : nullptr;
+    pk.bg1 = CTXF(L.bg[1]); pk.bg2 = CTXF(L.bg[2]);
+    pk.zero = CTXD(L.stat1); pk.n_zero = train ? 4 * C : 0;
+    SED_TRY(launch_gen_pack(pk, g.mode, st));
+    if (H != 64)
+        for (int l = 0; l < g.L; ++l)
+            SED_TRY(launch_ggru_pack(params + P.w_hh[l][0], params + P.w_hh[l][1], CTXF(L.whh[l]), train ? CTXF(L.whhT[l]) : nullptr, H, st));
+    // ---- conv block 0 -------------------------------------------------------------------------------------------------
+    SED_TRY(launch_blk0_forward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
+                                params + P.glu_w[0], params + P.glu_b[0], bn_running + 0, bn_running + C, trk[0], train, upd,
+                                seed_dev, CTXD(L.mom0), CTXD(L.mompart), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), CTXF(L.p[0]),
+                                use_drop ? CTXM(L.mask[0]) : nullptr, nullptr, st));
+    // ---- conv blocks 1, 2 -----------------------------------------------------------------------------------------------
+    const size_t so[3] = {0, L.stat1, L.stat2};
+    const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};
+    for (int i = 1; i <= 2; ++i) {
+        SED_TRY(launch_gconv_fwd(g.mode, C, CTXF(L.p[i - 1]), CTXV(L.wpk[i]), params + P.conv_b[i], CTXF(L.y[i]),
+                                 train ? CTXD(so[i]) : nullptr, g.B, Hs[i], Wd[i], st));
+        GBnArgs bn;
+        bn.stat = CTXD(so[i]); bn.N = (double)g.B * Hs[i] * Wd[i]; bn.gamma = params + P.bn_g[i]; bn.beta = params + P.bn_b[i];
+        bn.run_mean = bn_running + (2 * i) * C; bn.run_var = bn_running + (2 * i + 1) * C; bn.tracked = trk[i];
+        bn.train = train; bn.update = upd; bn.eps = g.eps; bn.momentum = g.mom; bn.bn = CTXF(L.bn[i]);
+        SED_TRY(launch_gglu_fwd(g.mode, C, CTXF(L.y[i]), bn, CTXV(L.wg[i]), CTXF(L.bg[i]), CTXF(L.p[i]), g.B, Hs[i], Wd[i], i,
+                                use_drop, g.p, seed_dev, use_drop ? CTXM(L.mask[i]) : nullptr, st));
+    }
+    // ---- BiGRU ----------------------------------------------------------------------------------------------------------
+    const float* in = CTXF(L.p[2]);
+    int nin = C;
+    const int BT = g.B * g.T3;
+    for (int l = 0; l < g.L; ++l) {
+        if (H == 64) {
+            SED_TRY(launch_gru_fwd(in, nin, params + P.w_ih[l][0], params + P.w_ih[l][1], params + P.b_ih[l][0], params + P.b_ih[l][1],
+                                   params + P.w_hh[l][0], params + P.w_hh[l][1], params + P.b_hh[l][0], params + P.b_hh[l][1],
+                                   CTXF(L.out[l]), train ? CTXF(L.gates[l]) : nullptr, g.B, g.T3, st));
+        } else {
+            // gi[bt][dir][3H] = x W_ih[dir]^T + b_ih[dir]: both directions in one batched launch
+            GemmBatch gb;
+            gb.n_prob = 2; gb.splits = 1; gb.part = nullptr; gb.part_stride = 0;
+            for (int dir = 0; dir < 2; ++dir) {
+                gb.p[dir] = gemm_prob(in, nin, 1, params + P.w_ih[l][dir], 1, nin, CTXF(L.gi[l]) + dir * 3 * H, 6 * H, BT, 3 * H, nin);
+                gb.p[dir].bias = params + P.b_ih[l][dir];
+            }
+            SED_TRY(launch_gemm_batch(gb, st));
+            SED_TRY(launch_ggru_fwd(H, CTXF(L.gi[l]), CTXF(L.whh[l]), params + P.b_hh[l][0], params + P.b_hh[l][1], CTXF(L.out[l]),
+                                    train ? CTXF(L.gates[l]) : nullptr, g.B, g.T3, st));
+        }
+        in = CTXF(L.out[l]);
+        nin = 2 * H;
+    }
+    // ---- heads ----------------------------------------------------------------------------------------------------------
+    SED_TRY(launch_heads_fwd(in, params + P.dense_w, params + P.dense_b, params + P.soft_w, params + P.soft_b, strong, weak,
+                             train ? CTXF(L.strong_sv) : nullptr, train ? CTXF(L.weak_sv) : nullptr, CTXF(L.logits_s),
+                             CTXF(L.den_sv), g.B, g.T3, g.NC, use_drop, g.p, seed_dev, st, 2 * H));
+    return SED_OK;
+}
+
+// Backward.  `side`: the helper stream of the caller's stream (fork / join events owned by crnn.hip), or the caller's own.
+int gen_backward(const Geo& g, const ParamOff& P, const float* params, const float* x, const uint64_t* seed_dev, void* ctx,
+                 size_t ctx_bytes, const float* d_strong, const float* d_weak, float* grads, void* ws, size_t ws_bytes, int parts,
+                 hipStream_t st, hipStream_t ss, hipEvent_t ev_fork, hipEvent_t ev_join, const HeadsLoss* hl) {
+    const GCtx L = make_gctx(g);
+    const GWs W = make_gws(g);
+    if (ctx_bytes < L.total || ws_bytes < W.total) {
+        sed_set_error("sed_crnn_backward: ctx %zu/%zu bytes, ws %zu/%zu bytes", ctx_bytes, L.total, ws_bytes, W.total);
+        return SED_ERR_WORKSPACE;
+    }
+    const int C = g.C, H = g.H, BT = g.B * g.T3;
+    const int use_drop = (g.p > 0.f) ? 1 : 0;
+    const bool have_side = (ss != st);
+    const bool defer_gru_w = (parts & 4) != 0;
+    bool forked = false;
+    auto fork = [&]() -> int {
+        if (!have_side) return SED_OK;
+        SED_CHECK_HIP(hipEventRecord(ev_fork, st));
+        SED_CHECK_HIP(hipStreamWaitEvent(ss, ev_fork, 0));
+        forked = true;
+        return SED_OK;
+    };
+    if (parts & 1) {
+        // ---- heads ------------------------------------------------------------------------------------------------------
+        SED_TRY(launch_heads_bwd(CTXF(L.out[g.L - 1]), params + P.dense_w, params + P.soft_w, CTXF(L.strong_sv), CTXF(L.weak_sv),
+                                 CTXF(L.logits_s), CTXF(L.den_sv), d_strong, d_weak, WSF(W.d_out), WSF(W.heads_part),
+                                 grads + P.dense_w, grads + P.dense_b, grads + P.soft_w, grads + P.soft_b, g.B, g.T3, g.NC, use_drop,
+                                 g.p, seed_dev, (parts & 2) ? WSD(W.de0) : nullptr, 2 * C * 10,
+                                 ((parts & 2) && have_side) || defer_gru_w ? 1 : 0, hl, st, 2 * H));
+        // ---- BiGRU --------------------------------------------------------------------------------------------------------
+        const float* d_cur = WSF(W.d_out);
+        const float* d_cur2 = nullptr;
+        for (int l = g.L - 1; l >= 0; --l) {
+            const int nin = (l == 0) ? C : 2 * H;
+            float* d_in = (l == 0) ? WSF(W.dp[2]) : WSF(W.d_in);
+            if (H == 64) {
+                SED_TRY(launch_gru_bwd(d_cur, d_cur2, CTXF(L.out[l]), CTXF(L.gates[l]), params + P.w_hh[l][0], params + P.w_hh[l][1],
+                                       params + P.w_ih[l][0], params + P.w_ih[l][1], nin, WSF(W.dgi[l]), WSF(W.dgh[l]), WSF(W.hprev[l]),
+                                       d_in, g.B, g.T3, st));
+                d_cur = d_in;
+                d_cur2 = d_in + (size_t)BT * nin;
+            } else {
+                SED_TRY(launch_ggru_bwd(H, d_cur, CTXF(L.out[l]), CTXF(L.gates[l]), CTXF(L.whhT[l]), WSF(W.dgi[l]), WSF(W.dgh[l]),
+                                        WSF(W.hprev[l]), g.B, g.T3, st));
+                // dX[bt][i] = sum_dir sum_g dgi[bt][dir][g] W_ih[dir][g][i]: K = 6H, the two W_ih stacked along K
+                GemmBatch gb;
+                gb.n_prob = 1; gb.splits = 1; gb.part = nullptr; gb.part_stride = 0;
+                gb.p[0] = gemm_prob(WSF(W.dgi[l]), 6 * H, 1, params + P.w_ih[l][0], nin, 1, d_in, nin, BT, nin, 6 * H);
+                gb.p[0].B2 = params + P.w_ih[l][1]; gb.p[0].k2 = 3 * H;
+                SED_TRY(launch_gemm_batch(gb, st));
+                d_cur = d_in;
+                d_cur2 = nullptr;
+            }
+        }
+    }
+    // weight + bias gradients of every GRU layer and direction (split-K MFMA GEMMs)
+    auto gru_weight_grads = [&](hipStream_t s2) -> int {
+        for (int l = g.L - 1; l >= 0; --l) {
+            const int nin = (l == 0) ? C : 2 * H;
+            const float* input = (l == 0) ? CTXF(L.p[2]) : CTXF(L.out[l - 1]);
+            GemmBatch gb;
+            gb.n_prob = 4; gb.splits = gru_splitk(g); gb.part = WSF(W.gemm_part); gb.part_stride = 0;
+            for (int dir = 0; dir < 2; ++dir) {
+                gb.p[2 * dir] = gemm_prob(WSF(W.dgi[l]) + dir * 3 * H, 1, 6 * H, input, nin, 1, grads + P.w_ih[l][dir], nin, 3 * H, nin, BT);
+                gb.p[2 * dir].Cones = grads + P.b_ih[l][dir];
+                gb.p[2 * dir + 1] = gemm_prob(WSF(W.dgh[l]) + dir * 3 * H, 1, 6 * H, WSF(W.hprev[l]) + dir * H, 2 * H, 1,
+                                              grads + P.w_hh[l][dir], H, 3 * H, H, BT);
+                gb.p[2 * dir + 1].Cones = grads + P.b_hh[l][dir];
+            }
+            SED_TRY(launch_gemm_batch(gb, s2));
+        }
+        return SED_OK;
+    };
+    if (parts == 1) SED_TRY(gru_weight_grads(st));
+    if (parts == 8) {
+        SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, st, 2 * H));
+        SED_TRY(gru_weight_grads(st));
+        return SED_OK;
+    }
+    if (!(parts & 2)) return SED_OK;
+    // ---- conv blocks 2, 1 -------------------------------------------------------------------------------------------------
+    if (!(parts & 1)) SED_CHECK_HIP(hipMemsetAsync(WSD(W.de0), 0, 2 * C * 10 * sizeof(double), st));
+    const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};
+    for (int i = 2; i >= 1; --i) {
+        // (H = 64: the GRU's dX arrives as two direction planes; the generic GLU backward takes one tensor)
+        if (i == 2 && H == 64) SED_TRY(launch_gen_add2(WSF(W.dp[2]), WSF(W.dp[2]) + (size_t)BT * C, (size_t)BT * C, st));
+        SED_TRY(launch_gglu_bwd(g.mode, C, CTXF(L.y[i]), CTXF(L.bn[i]), params + P.bn_g[i], params + P.bn_b[i], CTXV(L.wg[i]),
+                                CTXV(L.wgT[i]), CTXF(L.bg[i]), WSF(W.dp[i]), WSF(W.dz[i]), WSF(W.glu_part), g.B, Hs[i], Wd[i], use_drop,
+                                g.p, CTXM(L.mask[i]), st));
+        GBnBwdArgs pa;
+        pa.part = WSF(W.glu_part); pa.n_part = gglu_bwd_grid(g.B, Hs[i], Wd[i]); pa.C = C; pa.N = (double)g.B * Hs[i] * Wd[i];
+        pa.gamma = params + P.bn_g[i]; pa.beta = params + P.bn_b[i]; pa.bn = CTXF(L.bn[i]); pa.coef = WSF(W.coef[i]);
+        pa.g_gamma = grads + P.bn_g[i]; pa.g_beta = grads + P.bn_b[i]; pa.g_wglu = grads + P.glu_w[i]; pa.g_bglu = grads + P.glu_b[i];
+        pa.g_convb = grads + P.conv_b[i];
+        SED_TRY(launch_gbn_bwd_prep(pa, st));
+        SED_TRY(fork());
+        SED_TRY(launch_gwgrad(C, WSF(W.dz[i]), CTXF(L.y[i]), WSF(W.coef[i]), CTXF(L.p[i - 1]), WSF(W.wg_part), grads + P.conv_w[i], g.B,
+                              Hs[i], Wd[i], ss));
+        if (i == 2 && parts == 3) {
+            if (have_side) SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, ss, 2 * H));
+            SED_TRY(gru_weight_grads(ss));
+        }
+        SED_TRY(launch_gconv_dgrad(g.mode, C, WSF(W.dz[i]), CTXF(L.y[i]), WSF(W.coef[i]), CTXV(L.wpkT[i]), WSF(W.dp[i - 1]), g.B, Hs[i],
+                                   Wd[i], st));
+    }
+    // ---- conv block 0 -----------------------------------------------------------------------------------------------------
+    SED_TRY(launch_blk0_backward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
+                                 params + P.glu_w[0], CTXM(L.mask[0]), CTXD(L.mom0), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), WSF(W.dp[0]),
+                                 WSD(W.de0), 0, grads + P.conv_w[0], grads + P.conv_b[0], grads + P.bn_g[0], grads + P.bn_b[0],
+                                 grads + P.glu_w[0], grads + P.glu_b[0], st));
+    if (forked) {
+        SED_CHECK_HIP(hipEventRecord(ev_join, ss));
+        SED_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
+    }
+    return SED_OK;
+}
+
+// dst += src (n floats, n % 4 == 0): the two direction planes of gru.hip's dX
+__global__ __launch_bounds__(256) void k_gen_add2(float* __restrict__ dst, const float* __restrict__ src, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 a = ((const f32x4*)dst)[i];
+        const f32x4 b = ((const f32x4*)src)[i];
+        a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+        ((f32x4*)dst)[i] = a;
+    }
+}
+int launch_gen_add2(float* dst, const float* src, size_t n, hipStream_t st) {
+    const size_t n4 = n / 4;
+    int grid = (int)((n4 + 255) / 256);
+    if (grid > 1024) grid = 1024;
+    k_gen_add2<<<grid, 256, 0, st>>>(dst, src, n4);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}

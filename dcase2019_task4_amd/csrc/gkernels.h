@@ -53,3 +53,16 @@ int launch_ggru_fwd(int H, const float* gi, const float* wp, const float* b_hh_f
 // d_out [B*T][2H]; dgi / dgh [B*T][2][3H]; hprev [B*T][2][H]
 int launch_ggru_bwd(int H, const float* d_out, const float* out, const float* gates, const float* wpT, float* dgi, float* dgh,
                     float* hprev, int B, int T, hipStream_t st);
+
+// gcrnn.hip ---------------------------------------------------------------------------------------------------------------
+struct HeadsLoss;
+int launch_gen_add2(float* dst, const float* src, size_t n, hipStream_t st);
+size_t gen_ctx_bytes(const Geo& g);
+size_t gen_ws_bytes(const Geo& g);
+int gen_ctx_view(const Geo& g, const char* name, size_t* offset, size_t* bytes);
+int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_running, int64_t* bn_tracked, const float* x,
+                int train, int update_bn, const uint64_t* seed_dev, void* ctx, size_t ctx_bytes, float* strong, float* weak,
+                hipStream_t st);
+int gen_backward(const Geo& g, const ParamOff& P, const float* params, const float* x, const uint64_t* seed_dev, void* ctx,
+                 size_t ctx_bytes, const float* d_strong, const float* d_weak, float* grads, void* ws, size_t ws_bytes, int parts,
+                 hipStream_t st, hipStream_t ss, hipEvent_t ev_fork, hipEvent_t ev_join, const HeadsLoss* hl);

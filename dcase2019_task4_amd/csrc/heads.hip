@@ -12,9 +12,13 @@
 #include "philox.h"
 #include "kernels.h"
 
-#define HD_TC 128     // frames per chunk (one chunk covers T/8 <= 128, i.e. clips up to 1024 frames)
 #define HD_THREADS 1024
-#define HD_F 128      // 2 * hidden
+// Templated on HF = 2 * n_RNN_cell (128 for the reference's 64 cells, 512 for BASELINE.json configs[4]'s 256):
+//   HD_TC  frames per chunk: 1024 threads = HD_TC frames x HF / 16 feature groups (128 frames at HF = 128, 32 at HF = 512)
+//   HD_SF  forward row stride of x and W (both read as (row = lane & 15, col = k)): HF + 4
+//   HD_SB  backward row stride of x and W (both read as (row = k, col = lane & 15)): HF + 16
+#define HD_CONSTS(HF) constexpr int HD_F = (HF), HD_TC = ((HF) == 128 ? 128 : 32), HD_SF = (HF) + 4, HD_SB = (HF) + 16, HD_GPF = (HF) / 16; \
+    (void)HD_F; (void)HD_TC; (void)HD_SF; (void)HD_SB; (void)HD_GPF
 #define HD_MAXO 32    // 2 * max nclass
 // The first version did the three small matrix products with scalar FMAs fed from LDS (2 ds_reads per FMA):
 // 2-4 MB of LDS traffic per workgroup, 25 us forward / 37 us backward for 0.4 MFLOP per clip, all of it on the
@@ -22,8 +26,6 @@
 // chosen per use so that the fragment reads are bank-conflict free: a fragment indexed (row = lane & 15,
 // col = 4s + (lane >> 4)) wants stride = 4 (mod 64), one indexed (row = 4s + (lane >> 4), col = lane & 15) wants
 // stride = 16 (mod 64).
-#define HD_SF 132     // forward: x and W rows (both read as (row = lane & 15, col = k))
-#define HD_SB 144     // backward: x and W rows (both read as (row = k, col = lane & 15))
 #define HD_SD 33      // backward: dl rows (read both ways; small residual conflicts)
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -31,10 +33,11 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __bu
 // Stages one chunk of <= 128 frames of the GRU output with the recurrent-output dropout applied (CRNN.py:74):
 // each thread owns 16 consecutive features of one frame = ONE Philox draw (flat stream 8: index = element >> 4,
 // byte = element & 15).  Returns the 16 keep bits (all ones without dropout, 0 for frames past T).
-template <int STRIDE>
+template <int HF, int STRIDE>
 __device__ __forceinline__ uint32_t heads_stage(const float* __restrict__ h, float* xs, int b, int T, int t0, int use_drop,
                                                 uint64_t seed, uint32_t thr, float ks, int tid) {
-    const int tl = tid >> 3, f0 = (tid & 7) * 16, t = t0 + tl;
+    HD_CONSTS(HF);
+    const int tl = tid / HD_GPF, f0 = (tid % HD_GPF) * 16, t = t0 + tl;
     float v[16];
     uint32_t keep = 0;
     if (t < T) {
@@ -55,14 +58,16 @@ __device__ __forceinline__ uint32_t heads_stage(const float* __restrict__ h, flo
     return keep;
 }
 // both weight matrices as rows [0, NC) = dense, [NC, 2NC) = dense_softmax, zero rows up to HD_MAXO
-template <int STRIDE>
+template <int HF, int STRIDE>
 __device__ __forceinline__ void heads_stage_w(const float* __restrict__ wd, const float* __restrict__ ws, float* wsm, int NC, int tid) {
+    HD_CONSTS(HF);
     for (int e = tid; e < HD_MAXO * HD_F; e += HD_THREADS) {
-        const int o = e >> 7, f = e & 127;
+        const int o = e / HD_F, f = e % HD_F;
         wsm[o * STRIDE + f] = (o < NC) ? wd[o * HD_F + f] : (o < 2 * NC ? ws[(o - NC) * HD_F + f] : 0.f);
     }
 }
 
+template <int HF>
 __global__ __launch_bounds__(HD_THREADS) void k_heads_fwd(const float* __restrict__ h, const float* __restrict__ wd,
                                                     const float* __restrict__ bd, const float* __restrict__ ws,
                                                     const float* __restrict__ bs, float* __restrict__ strong,
@@ -70,6 +75,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_fwd(const float* __restric
                                                     float* __restrict__ weak_sv, float* __restrict__ logits_s,
                                                     float* __restrict__ den_out, int T, int NC, int use_drop, float p_drop,
                                                     const uint64_t* __restrict__ seed_ptr) {
+    HD_CONSTS(HF);
     extern __shared__ __attribute__((aligned(16))) float hsm[];
     float* xs = hsm;                                   // [HD_TC][HD_SF]
     float* wsm = xs + HD_TC * HD_SF;                   // [HD_MAXO][HD_SF]
@@ -82,19 +88,19 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_fwd(const float* __restric
     const uint64_t seed = use_drop ? seed_ptr[0] : 0ull;
     const uint32_t thr = drop_thresh8(p_drop);
     const float ks = use_drop ? drop_scale8(p_drop) : 1.0f;
-    heads_stage_w<HD_SF>(wd, ws, wsm, NC, tid);
+    heads_stage_w<HF, HD_SF>(wd, ws, wsm, NC, tid);
     if (tid < 16) { num_acc[tid] = 0.f; den_acc[tid] = 0.f; }
     for (int t0 = 0; t0 < T; t0 += HD_TC) {
         __syncthreads();
-        heads_stage<HD_SF>(h, xs, b, T, t0, use_drop, seed, thr, ks, tid);
+        heads_stage<HF, HD_SF>(h, xs, b, T, t0, use_drop, seed, thr, ks, tid);
         __syncthreads();
-        {   // logits[t][o] = x[t][:] . W[o][:] + bias: 8 x 2 tiles of 16 x 16, one per wave, K = 128
+        if (wv < 2 * (HD_TC / 16)) {   // logits[t][o] = x[t][:] . W[o][:] + bias: (HD_TC / 16) x 2 tiles of 16 x 16, one per wave, K = HF
             const int rt = wv >> 1, ct = wv & 1, i = lane & 15, kq = lane >> 4;
             const float* A = xs + (16 * rt + i) * HD_SF + kq;
             const float* Bp = wsm + (16 * ct + i) * HD_SF + kq;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s4 = 0; s4 < 32; s4 += 2) {
+#pragma unroll 16
+            for (int s4 = 0; s4 < HD_F / 4; s4 += 2) {
                 acc0 = mfma16(A[4 * s4], Bp[4 * s4], acc0);
                 acc1 = mfma16(A[4 * s4 + 4], Bp[4 * s4 + 4], acc1);
             }
@@ -120,7 +126,9 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_fwd(const float* __restric
                 return v;
             };
             const bool has[2] = {sub < NC, sub + 8 < NC};
-            if (t < T) {
+            if (tl >= HD_TC) {
+                // (HF = 512: only the first HD_TC * 8 threads own a frame of the chunk)
+            } else if (t < T) {
                 float ls[2], ex[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) ls[q] = has[q] ? lg[tl * HD_MAXO + NC + sub + 8 * q] : -3.0e38f;
@@ -148,7 +156,9 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_fwd(const float* __restric
         }
         __syncthreads();
         if (wv < NC) {          // wave c sums class c over the chunk's frames
-            float a = nums[lane][wv] + nums[lane + 64][wv], d2 = dens[lane][wv] + dens[lane + 64][wv];
+            float a = 0.f, d2 = 0.f;
+#pragma unroll
+            for (int tl2 = lane; tl2 < HD_TC; tl2 += 64) { a += nums[tl2][wv]; d2 += dens[tl2][wv]; }
             a = wave_sum(a); d2 = wave_sum(d2);
             if (lane == 0) { num_acc[wv] += a; den_acc[wv] += d2; }
         }
@@ -179,6 +189,7 @@ __device__ __forceinline__ float bce_grad(float p, float t) { return (p - t) / f
 // each clip's workgroup forms it on the fly instead of reading it from a separate kernel's output - k_mt_loss was 12 us
 // on the critical path between the forward and the backward.  The six loss sums go the same way as there: per-clip
 // partials, the last workgroup (device-scope ticket) adds them up in clip order.
+template <int HF>
 __global__ __launch_bounds__(HD_THREADS) void k_heads_bwd(const float* __restrict__ h, const float* __restrict__ wd,
                                                     const float* __restrict__ ws, const float* __restrict__ strong,
                                                     const float* __restrict__ weak, const float* __restrict__ logits_s,
@@ -187,6 +198,8 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_bwd(const float* __restric
                                                     float* __restrict__ part, int T, int NC, int use_drop, float p_drop,
                                                     const uint64_t* __restrict__ seed_ptr, double* __restrict__ zero, int n_zero,
                                                     HeadsLoss hl) {
+    HD_CONSTS(HF);
+    constexpr int TPW = HF / 128;                      // dW tiles (16 outputs x 16 features) per wave: 2 x HF / 16 tiles, 16 waves
     extern __shared__ __attribute__((aligned(16))) float hsm[];
     // the fp64 accumulators of the conv-block backward that follows (saves a memset node on the critical path)
     for (int i = blockIdx.x * HD_THREADS + threadIdx.x; i < n_zero; i += gridDim.x * HD_THREADS) zero[i] = 0.0;
@@ -195,14 +208,14 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_bwd(const float* __restric
     float* dl = wsm + HD_MAXO * HD_SB;                 // [HD_TC][HD_SD]
     float* dnum = dl + HD_TC * HD_SD;
     float* dden = dnum + 16;
-    uint32_t* mk = (uint32_t*)(dden + 16);             // [HD_TC][8] keep bits of the staged chunk
+    uint32_t* mk = (uint32_t*)(dden + 16);             // [HD_TC][HF / 16] keep bits of the staged chunk
     const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wv = tid >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
     const uint64_t seed = use_drop ? seed_ptr[0] : 0ull;
     const uint32_t thr = drop_thresh8(p_drop);
     const float ks = use_drop ? drop_scale8(p_drop) : 1.0f;
     const int NO = 2 * NC;
-    heads_stage_w<HD_SB>(wd, ws, wsm, NC, tid);
+    heads_stage_w<HF, HD_SB>(wd, ws, wsm, NC, tid);
     const bool fused = hl.strong_ema != nullptr;
     const int B = gridDim.x;
     float lacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // weak_bce, strong_bce, mse_strong, mse_weak, weak_ema_bce, strong_ema_bce
@@ -241,11 +254,13 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_bwd(const float* __restric
         dden[tid] = -dw * weak[b * NC + tid] / dn;
     }
     // dW[o][f] accumulates over chunks in the MFMA accumulator of the wave that owns the (o, f) tile
-    f32x4 wacc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 wacc[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) wacc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float bacc = 0.f;    // thread o < NO
     for (int t0 = 0; t0 < T; t0 += HD_TC) {
         __syncthreads();
-        mk[tid] = heads_stage<HD_SB>(h, xs, b, T, t0, use_drop, seed, thr, ks, tid);
+        mk[tid] = heads_stage<HF, HD_SB>(h, xs, b, T, t0, use_drop, seed, thr, ks, tid);
         {   // softmax / sigmoid backward of the chunk's frames: 8 threads per frame, thread `sub` takes classes sub and sub + 8
             // (one thread per frame walking all classes left 7/8 of the workgroup idle for the longest serial stretch of
             // the kernel); the three per-frame reductions (max, sum of exponentials, dot) are DPP butterflies inside the
@@ -264,7 +279,9 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_bwd(const float* __restric
                 return v;
             };
             float* dlr = dl + tl * HD_SD;
-            if (t < T) {
+            if (tl >= HD_TC) {
+                // (HF = 512: only the first HD_TC * 8 threads own a frame of the chunk)
+            } else if (t < T) {
                 const size_t e0 = (size_t)(b * T + t) * NC;
                 const bool has[2] = {sub < NC, sub + 8 < NC};
                 float lg[2], ex[2];
@@ -318,22 +335,23 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_bwd(const float* __restric
             }
         }
         __syncthreads();
-        {   // dW[o][f] += sum_t dl[t][o] x[t][f]: 2 x 8 tiles, one per wave, K = 128 frames
-            const int ot = wv >> 3, ft = wv & 7;
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {   // dW[o][f] += sum_t dl[t][o] x[t][f]: 2 x HF / 16 tiles, TPW per wave, K = HD_TC frames
+            const int tile = wv * TPW + q, ot = tile / HD_GPF, ft = tile % HD_GPF;
             const float* A = dl + kq * HD_SD + 16 * ot + i16;          // A[i = o][k = t]
             const float* Bp = xs + kq * HD_SB + 16 * ft + i16;         // B[k = t][j = f]
 #pragma unroll 8
-            for (int s4 = 0; s4 < 32; ++s4) wacc = mfma16(A[4 * s4 * HD_SD], Bp[4 * s4 * HD_SB], wacc);
+            for (int s4 = 0; s4 < HD_TC / 4; ++s4) wacc[q] = mfma16(A[4 * s4 * HD_SD], Bp[4 * s4 * HD_SB], wacc[q]);
         }
         if (tid < NO) {
             float a = 0.f;
             for (int tl = 0; tl < HD_TC; ++tl) a += dl[tl * HD_SD + tid];
             bacc += a;
         }
-        // dx[t][f] = (sum_o dl[t][o] W[o][f]) * mask: 8 x 8 tiles, four per wave, K = 32
+        // dx[t][f] = (sum_o dl[t][o] W[o][f]) * mask: (HD_TC / 16) x (HF / 16) = 64 tiles, four per wave, K = 32
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int tile = wv * 4 + q, tt = tile >> 3, ft = tile & 7;
+            const int tile = wv * 4 + q, tt = tile / HD_GPF, ft = tile % HD_GPF;
             const float* A = dl + (16 * tt + i16) * HD_SD + kq;        // A[i = t][k = o]
             const float* Bp = wsm + kq * HD_SB + 16 * ft + i16;        // B[k = o][j = f]
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -344,20 +362,21 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_bwd(const float* __restric
             for (int r = 0; r < 4; ++r) {
                 const int tl = 16 * tt + 4 * kq + r, t = t0 + tl;
                 if (t < T) {
-                    const uint32_t keep = (mk[tl * 8 + (f >> 4)] >> (f & 15)) & 1u;
+                    const uint32_t keep = (mk[tl * HD_GPF + (f >> 4)] >> (f & 15)) & 1u;
                     dh[(size_t)(b * T + t) * HD_F + f] = keep ? acc[r] * ks : 0.f;
                 }
             }
         }
     }
     float* pr = part + (size_t)b * (2 * (NC * HD_F + NC));
-    {
-        const int ot = wv >> 3, ft = wv & 7, f = 16 * ft + i16;
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int tile = wv * TPW + q, ot = tile / HD_GPF, ft = tile % HD_GPF, f = 16 * ft + i16;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int o = 16 * ot + 4 * kq + r;
-            if (o < NC) pr[o * HD_F + f] = wacc[r];
-            else if (o < NO) pr[NC * HD_F + NC + (o - NC) * HD_F + f] = wacc[r];
+            if (o < NC) pr[o * HD_F + f] = wacc[q][r];
+            else if (o < NO) pr[NC * HD_F + NC + (o - NC) * HD_F + f] = wacc[q][r];
         }
     }
     if (tid < NC) pr[NC * HD_F + tid] = bacc;
@@ -508,24 +527,52 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_mt_loss(const float* __restric
 }
 
 // ---- host launchers -------------------------------------------------------------------------------
-int launch_heads_fwd(const float* h, const float* wd, const float* bd, const float* ws, const float* bs, float* strong,
-                     float* weak, float* strong_sv, float* weak_sv, float* logits_s, float* den, int B, int T, int NC,
-                     int use_drop, float p_drop, const uint64_t* seed, hipStream_t st) {
+template <int HF>
+static int heads_fwd_launch(const float* h, const float* wd, const float* bd, const float* ws, const float* bs, float* strong,
+                            float* weak, float* strong_sv, float* weak_sv, float* logits_s, float* den, int B, int T, int NC,
+                            int use_drop, float p_drop, const uint64_t* seed, hipStream_t st) {
+    HD_CONSTS(HF);
     const size_t lds = (size_t)(HD_TC * HD_SF + HD_MAXO * HD_SF + HD_TC * HD_MAXO + 2 * HD_TC * 16 + 32) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_heads_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_heads_fwd<HF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    k_heads_fwd<<<B, HD_THREADS, lds, st>>>(h, wd, bd, ws, bs, strong, weak, strong_sv, weak_sv, logits_s, den, T, NC, use_drop,
-                                            p_drop, seed);
+    k_heads_fwd<HF><<<B, HD_THREADS, lds, st>>>(h, wd, bd, ws, bs, strong, weak, strong_sv, weak_sv, logits_s, den, T, NC, use_drop,
+                                                p_drop, seed);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
+int launch_heads_fwd(const float* h, const float* wd, const float* bd, const float* ws, const float* bs, float* strong,
+                     float* weak, float* strong_sv, float* weak_sv, float* logits_s, float* den, int B, int T, int NC,
+                     int use_drop, float p_drop, const uint64_t* seed, hipStream_t st, int HF) {
+    if (HF == 128) return heads_fwd_launch<128>(h, wd, bd, ws, bs, strong, weak, strong_sv, weak_sv, logits_s, den, B, T, NC, use_drop, p_drop, seed, st);
+    if (HF == 512) return heads_fwd_launch<512>(h, wd, bd, ws, bs, strong, weak, strong_sv, weak_sv, logits_s, den, B, T, NC, use_drop, p_drop, seed, st);
+    sed_set_error("heads: unsupported feature width %d (2 x n_RNN_cell must be 128 or 512)", HF);
+    return SED_ERR_UNSUPPORTED;
+}
 
-int launch_heads_colsum(const float* part, float* g_wd, int B, int NC, hipStream_t st) {
+int launch_heads_colsum(const float* part, float* g_wd, int B, int NC, hipStream_t st, int HF) {
     // dense.weight, dense.bias, dense_softmax.weight, dense_softmax.bias are contiguous in the flat layout
-    return launch_colsum(part, B, 2 * (NC * HD_F + NC), 2 * (NC * HD_F + NC), g_wd, st);
+    return launch_colsum(part, B, 2 * (NC * HF + NC), 2 * (NC * HF + NC), g_wd, st);
+}
+
+template <int HF>
+static int heads_bwd_launch(const float* h, const float* wd, const float* ws, const float* strong, const float* weak,
+                            const float* logits_s, const float* den, const float* d_strong, const float* d_weak, float* dh,
+                            float* part, int B, int T, int NC, int use_drop, float p_drop, const uint64_t* seed, double* zero,
+                            int n_zero, const HeadsLoss& hl0, hipStream_t st) {
+    HD_CONSTS(HF);
+    const size_t lds = (size_t)(HD_TC * HD_SB + HD_MAXO * HD_SB + HD_TC * HD_SD + 32 + HD_THREADS) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_heads_bwd<HF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    k_heads_bwd<HF><<<B, HD_THREADS, lds, st>>>(h, wd, ws, strong, weak, logits_s, den, d_strong, d_weak, dh, part, T, NC, use_drop,
+                                                p_drop, seed, zero, zero ? n_zero : 0, hl0);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
 }
 
 // defer_colsum: the caller sums the per-clip partial weight gradients later (launch_heads_colsum, off the critical path)
@@ -533,21 +580,19 @@ int launch_heads_bwd(const float* h, const float* wd, const float* ws, const flo
                      const float* logits_s, const float* den, const float* d_strong, const float* d_weak, float* dh,
                      float* part, float* g_wd, float* g_bd, float* g_ws, float* g_bs, int B, int T, int NC, int use_drop,
                      float p_drop, const uint64_t* seed, double* zero, int n_zero, int defer_colsum, const HeadsLoss* hl,
-                     hipStream_t st) {
+                     hipStream_t st, int HF) {
     (void)g_bd; (void)g_ws; (void)g_bs;
     HeadsLoss hl0 = {};
     if (hl) hl0 = *hl;
-    const size_t lds = (size_t)(HD_TC * HD_SB + HD_MAXO * HD_SB + HD_TC * HD_SD + 32 + HD_THREADS) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_heads_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+    int rc;
+    if (HF == 128) rc = heads_bwd_launch<128>(h, wd, ws, strong, weak, logits_s, den, d_strong, d_weak, dh, part, B, T, NC, use_drop, p_drop, seed, zero, n_zero, hl0, st);
+    else if (HF == 512) rc = heads_bwd_launch<512>(h, wd, ws, strong, weak, logits_s, den, d_strong, d_weak, dh, part, B, T, NC, use_drop, p_drop, seed, zero, n_zero, hl0, st);
+    else {
+        sed_set_error("heads: unsupported feature width %d (2 x n_RNN_cell must be 128 or 512)", HF);
+        return SED_ERR_UNSUPPORTED;
     }
-    k_heads_bwd<<<B, HD_THREADS, lds, st>>>(h, wd, ws, strong, weak, logits_s, den, d_strong, d_weak, dh, part, T, NC, use_drop,
-                                            p_drop, seed, zero, zero ? n_zero : 0, hl0);
-    SED_CHECK_LAUNCH();
-    if (defer_colsum) return SED_OK;
-    return launch_heads_colsum(part, g_wd, B, NC, st);
+    if (rc != SED_OK || defer_colsum) return rc;
+    return launch_heads_colsum(part, g_wd, B, NC, st, HF);
 }
 
 extern "C" int sed_mt_loss(const sed_dims* d, const float* strong, const float* weak, const float* strong_ema,

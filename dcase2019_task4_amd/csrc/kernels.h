@@ -193,8 +193,8 @@ int launch_gru_bwd(const float* d_out, const float* d_out2, const float* out, co
 // heads.hip
 int launch_heads_fwd(const float* h /*[B][T][128]*/, const float* wd, const float* bd, const float* ws, const float* bs,
                      float* strong, float* weak, float* strong_sv, float* weak_sv, float* logits_s, float* den, int B, int T,
-                     int NC, int use_drop, float p_drop, const uint64_t* seed, hipStream_t st);
-int launch_heads_colsum(const float* part, float* g_wd, int B, int NC, hipStream_t st);
+                     int NC, int use_drop, float p_drop, const uint64_t* seed, hipStream_t st, int HF = 128);
+int launch_heads_colsum(const float* part, float* g_wd, int B, int NC, hipStream_t st, int HF = 128);
 // ---- device-side step state (sed_step_state): derived fields ------------------------------------------------------
 #ifdef __HIPCC__
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
@@ -257,4 +257,5 @@ struct HeadsLoss {
 int launch_heads_bwd(const float* h, const float* wd, const float* ws, const float* strong, const float* weak,
                      const float* logits_s, const float* den, const float* d_strong, const float* d_weak, float* dh,
                      float* part, float* g_wd, float* g_bd, float* g_ws, float* g_bs, int B, int T, int NC, int use_drop,
-                     float p_drop, const uint64_t* seed, double* zero, int n_zero, int defer_colsum, const HeadsLoss* hl, hipStream_t st);
+                     float p_drop, const uint64_t* seed, double* zero, int n_zero, int defer_colsum, const HeadsLoss* hl, hipStream_t st,
+                     int HF = 128);

@@ -70,7 +70,9 @@ class MeanTeacherStep:
         if teacher is not None:
             teacher.flatten_parameters_(dev)
         self.B, self.T = int(batch_size), int(n_frames)
-        self.dims = _lib.make_dims(self.B, self.T, 64, 64, 64, student._nclass, student._n_layers, student._p_drop)
+        if teacher is not None and (teacher._C, teacher._H, teacher._dtype) != (student._C, student._H, student._dtype):
+            raise ValueError("student and teacher must have the same geometry and mfma_dtype")
+        self.dims = student.make_dims(self.B, self.T)
         self.T3, self.NC = self.T // 8, student._nclass
         self.wlo, self.whi = _slice_range(weak_mask, self.B) if weak_mask is not None else (0, 0)
         self.slo, self.shi = _slice_range(strong_mask, self.B) if strong_mask is not None else (0, 0)

@@ -34,20 +34,31 @@ typedef enum {
     SED_ERR_UNSUPPORTED = -4     /* configuration outside the hot path */
 } sed_status;
 
-/* Model + batch geometry.  Mirrors cfg.crnn_kwargs (baseline/config.py:53-58) for the one
- * configuration on the hot path: activation="glu", attention=True, BGRU, 3 conv blocks,
- * kernel 3 / stride 1 / pad 1, pooling (2,4) x3 (so F must be 64), n_in_channel = 1. */
+/* Model + batch geometry.  Mirrors the CRNN / CNN constructor arguments (baseline/models/CRNN.py:12-16,
+ * CNN.py:35-38) on the hot path: activation="glu", attention=True, BGRU, 3 conv blocks with equal filter counts,
+ * kernel 3 / stride 1 / pad 1, pooling (2,4) x3 (so F must be 64), n_in_channel = 1.
+ *   C = 64,  H = 64,  SED_DTYPE_F32   cfg.crnn_kwargs (baseline/config.py:53-58): the specialised kernel set
+ *   C in {64, 128}, H in {64, 256}, either dtype: the generic kernel set (gen.h) - BASELINE.json configs[4]'s wide CRNN
+ *   (nb_filters 3 x 128, n_RNN_cell 256) and the bf16-operand variants of configs[2] / [4].
+ * dtype selects the arithmetic of the GEMM-shaped operators of conv blocks 1 and 2 (3x3 convolutions forward / dgrad,
+ * the GLU's Linear forward / backward): SED_DTYPE_F32 = exact fp32 MFMA; SED_DTYPE_BF16 = operands rounded to bf16
+ * (round-to-nearest-even) when they are staged on chip, fp32 accumulation.  Everything else - all tensors in HBM, conv
+ * block 0, BatchNorm statistics, the gates, every weight gradient, the GRU, the heads, the loss, Adam - is fp32 in both.
+ * It is never chosen silently: the caller states it here. */
+#define SED_DTYPE_F32 0
+#define SED_DTYPE_BF16 1
 typedef struct {
     int32_t B;            /* clips in the batch                                  */
     int32_t T;            /* input frames (628 for BASELINE, 864 for config.py)  */
     int32_t F;            /* mel bins; must be 64                                */
-    int32_t C;            /* conv filters per block; must be 64                  */
-    int32_t H;            /* n_RNN_cell; must be 64                              */
+    int32_t C;            /* conv filters per block: 64 or 128                   */
+    int32_t H;            /* n_RNN_cell: 64 or 256                               */
     int32_t nclass;       /* <= 16 (10 in the reference)                         */
     int32_t n_layers_rnn; /* 1 or 2                                              */
     float   p_drop;       /* dropout probability (config.py:56), 0 disables      */
     float   bn_eps;       /* 1e-3 (models/CNN.py:49)                             */
     float   bn_momentum;  /* 0.99 (models/CNN.py:49)                             */
+    int32_t dtype;        /* SED_DTYPE_F32 / SED_DTYPE_BF16                      */
 } sed_dims;
 
 /* Per-step scalars kept in DEVICE memory so that a captured hipGraph can be replayed while the

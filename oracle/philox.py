@@ -20,9 +20,10 @@ Stream definition (mirrored in dcase2019_task4_amd/csrc/philox.h):
               index = (q >> 2)*C + c,  stream_id = 2*l + dt,  byte = (q & 3)*4 + df.
   Rows h >= 2*Ho (odd H, dropped by the floor-mode pool) get no mask (value irrelevant; 0 here).
   p == 0.5 (thr == 128, the reference's rate) uses ONE bit per element instead: with rb = q >> 2,
-              lane = dt*32 + (c & 31),  index = (rb >> 2)*64 + lane,  stream_id = 32 + l,
-              field = (rb & 3)*2 + (c >> 5)  (16-bit field f = (word[f>>1] >> 16*(f&1)) & 0xffff),
+              lane = dt*32 + (c & 31),  unit u = rb*(C/32) + (c >> 5),  index = (u >> 3)*64 + lane,  stream_id = 32 + l,
+              field = u & 7  (16-bit field f = (word[f>>1] >> 16*(f&1)) & 0xffff),
               keep = bit (q & 3)*4 + df of the field; kept values are scaled by 2.
+              (C = 64: index = (rb >> 2)*64 + lane, field = (rb & 3)*2 + (c >> 5).)
 * recurrent-output dropout, tensor [B][T][2H] flattened to e: index = e >> 4, stream_id = 8,
   byte = e & 15.
 * teacher noise, tensor [frames][n_mels] flattened to e per clip b: two 32-bit uniforms from
@@ -116,21 +117,25 @@ def dropout_mask_pooled(seed, block, B, H, W, C, p):
 
 
 def _mask_pooled_1bit(seed, block, B, Ho, Wo, C):
-    """p = 0.5 stream: one bit per element, 8 (row block, half) fields per draw. Returns [B, 2Ho, 4Wo, C]."""
-    assert C == 64
+    """p = 0.5 stream: one bit per element, 8 (row block, 32-channel slice) units per draw. Returns [B, 2Ho, 4Wo, C]."""
+    assert C % 32 == 0
+    NH = C // 32
     Q = B * Ho * Wo
     nrb = (Q + 3) // 4
-    n4 = (nrb + 3) // 4
-    rb4, lane = np.meshgrid(np.arange(n4), np.arange(64), indexing="ij")
+    n_units = nrb * NH
+    n_draw = (n_units + 7) // 8
+    d, lane = np.meshgrid(np.arange(n_draw), np.arange(64), indexing="ij")
     k0, k1 = _key(seed)
-    o = philox4x32_10((rb4 * 64 + lane).astype(np.uint32), 0, np.uint32(32 + block), np.uint32(TAG), k0, k1)
-    fields = np.empty((n4, 64, 8), dtype=np.uint32)
+    o = philox4x32_10((d * 64 + lane).astype(np.uint32), 0, np.uint32(32 + block), np.uint32(TAG), k0, k1)
+    fields = np.empty((n_draw, 64, 8), dtype=np.uint32)
     for f in range(8):
         fields[..., f] = (o[f >> 1] >> np.uint32(16 * (f & 1))) & np.uint32(0xFFFF)
-    # [rb4, lane=(dt, n), f=(rbl, h), bit=(j, df)] -> keep[q = (rb4*4 + rbl)*4 + j, dt, df, c = h*32 + n]
+    # [draw, lane = (dt, n), f] -> units u = draw*8 + f = rb*NH + h
     bits = ((fields[..., None] >> np.arange(16, dtype=np.uint32)) & np.uint32(1)).astype(np.float32) * np.float32(2.0)
-    bits = bits.reshape(n4, 2, 32, 4, 2, 4, 4)            # rb4, dt, n, rbl, h, j, df
-    keep = bits.transpose(0, 3, 5, 1, 6, 4, 2).reshape(n4 * 16, 2, 4, 64)[:Q]      # q, dt, df, c
+    bits = bits.reshape(n_draw, 2, 32, 8, 4, 4)            # draw, dt, n, f, j, df
+    units = bits.transpose(0, 3, 1, 2, 4, 5).reshape(n_draw * 8, 2, 32, 4, 4)[:n_units]      # u, dt, n, j, df
+    units = units.reshape(nrb, NH, 2, 32, 4, 4)            # rb, h, dt, n, j, df
+    keep = units.transpose(0, 4, 2, 5, 1, 3).reshape(nrb * 4, 2, 4, C)[:Q]                    # q = rb*4 + j, dt, df, c = h*32 + n
     return keep.reshape(B, Ho, Wo, 2, 4, C).transpose(0, 1, 3, 2, 4, 5).reshape(B, 2 * Ho, 4 * Wo, C)
 
 

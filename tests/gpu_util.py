@@ -10,11 +10,12 @@ CRNN_KW = dict(n_in_channel=1, nclass=10, attention=True, n_RNN_cell=64, n_layer
                pooling=list(3 * ((2, 4),)))
 
 
-def make_model(seed=0, dropout=0.5, device="cuda", n_layers=2, nclass=10):
+def make_model(seed=0, dropout=0.5, device="cuda", n_layers=2, nclass=10, C=64, H=64, mfma_dtype="f32"):
     from dcase2019_task4_amd.crnn import CRNN
-    kw = dict(CRNN_KW, dropout=dropout, n_layers_RNN=n_layers, nclass=nclass)
+    kw = dict(CRNN_KW, dropout=dropout, n_layers_RNN=n_layers, nclass=nclass, nb_filters=[C] * 3, n_RNN_cell=H,
+              mfma_dtype=mfma_dtype)
     m = CRNN(**kw)
-    params = synth.make_params(seed, n_layers_RNN=n_layers, nclass=nclass)
+    params = synth.make_params(seed, n_layers_RNN=n_layers, nclass=nclass, nb_filters=(C,) * 3, n_RNN_cell=H)
     with torch.no_grad():
         for (n, p) in m.named_parameters():
             p.copy_(params[n])
@@ -28,16 +29,16 @@ def set_bn(model, bn_state):
             bufs[k].copy_(v.to(bufs[k].device))
 
 
-def oracle_masks(seed, B, T, p):
+def oracle_masks(seed, B, T, p, C=64, H=64):
     """The four dropout masks the HIP kernels draw for Philox key ``seed`` (oracle/philox.py)."""
     if p <= 0:
         return None
     H1, H2, T3 = T // 2, T // 4, T // 8
     return {
-        "drop0": torch.tensor(philox.dropout_mask_pooled(seed, 0, B, T, 64, 64, p)),
-        "drop1": torch.tensor(philox.dropout_mask_pooled(seed, 1, B, H1, 16, 64, p)),
-        "drop2": torch.tensor(philox.dropout_mask_pooled(seed, 2, B, H2, 4, 64, p)),
-        "drop_rnn": torch.tensor(philox.dropout_mask_flat(seed, 8, (B, T3, 128), p)),
+        "drop0": torch.tensor(philox.dropout_mask_pooled(seed, 0, B, T, 64, C, p)),
+        "drop1": torch.tensor(philox.dropout_mask_pooled(seed, 1, B, H1, 16, C, p)),
+        "drop2": torch.tensor(philox.dropout_mask_pooled(seed, 2, B, H2, 4, C, p)),
+        "drop_rnn": torch.tensor(philox.dropout_mask_flat(seed, 8, (B, T3, 2 * H), p)),
     }
 
 

@@ -13,8 +13,10 @@ Workloads (--config):
                     models.  N > 1: weak scaling, 24 clips per GPU, every rank keeps the [weak|unlabeled|strong] =
                     [6|12|6] composition (main.py:238-247); the same run also times configs[3]'s 64 clips per GPU
                     (global 512 at N = 8) and reports it under "config3_ddp".
-  waveform          configs[2]'s workload: the step from raw 16 kHz waveforms (STFT + mel + log + normalise on the
-                    GPU inside the timed region), batch 64.
+  waveform          configs[2]'s workload in fp32: the step from raw 16 kHz waveforms (STFT + mel + log + normalise on
+                    the GPU inside the timed region), batch 64.   waveform-bf16: configs[2] itself (bf16 MFMA operands).
+  mt-bf16           configs[1]'s workload with bf16 MFMA operands in the conv-block GEMMs (sed_dims.dtype = bf16).
+  wide-f32 / wide-bf16   configs[4]'s model (nb_filters 3 x 128, n_RNN_cell 256), batch 24 per GPU, features in HBM.
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
 """
 import argparse
@@ -44,7 +46,15 @@ FWD_FLOP_PER_CLIP = {
 }
 STEP_FLOP_PER_CLIP = 3.432e9      # 4 x forward (teacher fwd + student fwd + 2x for backward)
 STEP_BYTES_PER_CLIP = 12.0e6      # 7 passes over the block-boundary tensors, fp32
+WIDE_STEP_FLOP_PER_CLIP = 14.157e9    # wide CRNN (3 x 128 filters, 256-cell BiGRU)
+WIDE_STEP_BYTES_PER_CLIP = 23.9e6
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= the f32 vector peak)
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak
+CONFIGS = {   # name -> (wide, mfma dtype, from waveform, default batch per GPU)
+    "mt-f32": (False, "f32", False, 24), "mt-bf16": (False, "bf16", False, 24),
+    "waveform": (False, "f32", True, 64), "waveform-bf16": (False, "bf16", True, 64),
+    "wide-f32": (True, "f32", False, 24), "wide-bf16": (True, "bf16", False, 24),
+}
 PEAK_HBM_GBS = 8000.0
 
 # kernel launches per mean-teacher step (profiles/r01_j_step_timeline.txt) - used to add the committed per-launch PMC
@@ -300,7 +310,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="mt-f32", choices=["mt-f32", "waveform"])
+    ap.add_argument("--config", default="mt-f32", choices=sorted(CONFIGS))
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the kernel table, feature-path and config3 legs")
@@ -332,9 +342,13 @@ def main():
             print(f"[bench] process group up: {dist_info}", file=sys.stderr, flush=True)
 
     from dcase2019_task4_amd.train import MeanTeacherStep
-    waveform = args.config == "waveform"
-    B = args.batch or (64 if waveform else B_PER_GPU)
-    student, teacher = build_models(device, seed=0)        # identical replicas on every rank
+    wide, mfma_dtype, waveform, b_default = CONFIGS[args.config]
+    headline = args.config == "mt-f32"
+    B = args.batch or b_default
+    model_kw = dict(mfma_dtype=mfma_dtype)
+    if wide:
+        model_kw.update(nb_filters=[128, 128, 128], n_RNN_cell=256)
+    student, teacher = build_models(device, seed=0, **model_kw)        # identical replicas on every rank
     x, xe, tgt, wm, sm = synthetic_batch(B, T_FRAMES, 1000 + rank, device)
     step = MeanTeacherStep(student, teacher, B, T_FRAMES, rampup_length=210 * 100 // 2, weak_mask=wm, strong_mask=sm,
                            seed=1234, use_graph=not args.no_graph, process_group=pg)
@@ -353,7 +367,7 @@ def main():
     assert np.isfinite(meters["loss"]), meters
 
     config3 = None
-    if world > 1 and not waveform and not args.no_extras and args.batch is None:
+    if world > 1 and headline and not args.no_extras and args.batch is None:
         # BASELINE.json configs[3]: global batch 512 at N = 8 = 64 clips per GPU ([16|32|16] per rank)
         s3, t3 = build_models(device, seed=0)
         x3, xe3, tg3, wm3, sm3 = synthetic_batch(B_CONFIG3, T_FRAMES, 2000 + rank, device)
@@ -373,15 +387,17 @@ def main():
         ms = elapsed / args.steps * 1e3
         clips = B * world * args.steps / elapsed
         t_clip_us = elapsed / args.steps / B * 1e6
-        wl = ("mean-teacher CRNN train step from raw 16 kHz waveforms (STFT + mel + log + normalise on the GPU inside the "
-              f"timed region), batch {B} per GPU, fp32" if waveform else
-              f"mean-teacher CRNN train step (baseline/main.py config), batch {B} per GPU, precomputed log-mel "
-              f"[{B},1,628,64] fp32 resident in HBM, dropout 0.5")
+        mdl = "wide CRNN (nb_filters 3 x 128, n_RNN_cell 256)" if wide else "CRNN (baseline/main.py config)"
+        arith = "fp32" if mfma_dtype == "f32" else "bf16 MFMA operands / fp32 accumulation in the conv-block GEMMs, fp32 elsewhere"
+        wl = (f"mean-teacher {mdl} train step from raw 16 kHz waveforms (STFT + mel + log + normalise on the GPU inside the "
+              f"timed region), batch {B} per GPU, {arith}" if waveform else
+              f"mean-teacher {mdl} train step, batch {B} per GPU, precomputed log-mel [{B},1,628,64] fp32 resident in HBM, "
+              f"dropout 0.5, {arith}")
         res = {
             "metric": "10-s clips/sec mean-teacher train step (64-mel x 628)",
             "value": round(clips, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": mfma_dtype, "data": "synthetic",
             "config": {"workload": wl, "global_batch": B * world, "frames": T_FRAMES, "n_mels": N_MELS,
                        "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
                        "dp_schedule": step.dp_schedule if step.dp else None},
@@ -391,15 +407,20 @@ def main():
             res["distributed"] = dist_info
         if config3:
             res["config3_ddp"] = config3
-        whole_tflops = STEP_FLOP_PER_CLIP / t_clip_us * 1e-6
+        step_flop = WIDE_STEP_FLOP_PER_CLIP if wide else STEP_FLOP_PER_CLIP
+        step_bytes = WIDE_STEP_BYTES_PER_CLIP if wide else STEP_BYTES_PER_CLIP
+        peak = PEAK_F32_MFMA_TFLOPS if mfma_dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+        whole_tflops = step_flop / t_clip_us * 1e-6
         traffic, table = pmc_step_traffic()
         roof = {
-            "bound": "mfma", "kernel": "whole step (39 kernels in one hipGraph)",
-            "achieved": round(whole_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(whole_tflops / PEAK_F32_MFMA_TFLOPS, 4),
-            "traffic": traffic if (world == 1 and not waveform and B == B_PER_GPU) else None,
-            "algorithmic_flops": int(STEP_FLOP_PER_CLIP * B), "algorithmic_bytes": int(STEP_BYTES_PER_CLIP * B),
-            "algorithmic_gbs": round(STEP_BYTES_PER_CLIP / t_clip_us * 1e-3, 1),
+            "bound": "mfma", "kernel": "whole step (one hipGraph)",
+            "achieved": round(whole_tflops, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(whole_tflops / peak, 4),
+            "frac_of_f32_mfma_peak": round(whole_tflops / PEAK_F32_MFMA_TFLOPS, 4),
+            "traffic": traffic if (world == 1 and headline and B == B_PER_GPU) else None,
+            "algorithmic_flops": int(step_flop * B), "algorithmic_bytes": int(step_bytes * B),
+            "algorithmic_gbs": round(step_bytes / t_clip_us * 1e-3, 1),
+            "hbm_frac": round(step_bytes / t_clip_us * 1e-3 / PEAK_HBM_GBS, 4),
             "definition": "SURVEY 8(d): 3.432 GFLOP per clip of reference GEMM-shaped work (4 x forward) / measured time per "
                           "clip, against the f32 MFMA peak (the step is compute-bound: 286 FLOP/B); `traffic` = HBM bytes per "
                           "step, per-launch PMC figures (profiles/pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, separate "
@@ -410,7 +431,11 @@ def main():
                                "effective fraction above 1 is an algorithmic saving, not MFMA utilisation - the executed "
                                "fraction beside it is.",
         }
-        if not args.no_extras and not waveform:
+        if mfma_dtype == "bf16":
+            roof["note"] = ("bf16 line: priced against the DENSE bf16 MFMA peak as the contract asks; only the conv-block GEMMs "
+                            "run on bf16 operands - block 0, every weight gradient, the GRU, the heads and all element-wise "
+                            "work are fp32, so this fraction is NOT an MFMA-utilisation figure (frac_of_f32_mfma_peak beside it)")
+        if not args.no_extras and headline:
             kr = kernel_roofline(step)
             dom = max(kr, key=lambda k: kr[k]["us"] * kr[k]["launches_per_step"])
             roof["dominant_kernel"] = dict(kr[dom], name=dom,
@@ -421,12 +446,12 @@ def main():
                               "step's own buffers (sed_kernel_replay) after the timed region; conv*_wgrad = the Winograd "
                               "wgrad kernel + its ordered partial-sum reduction (the whole operator)")
         res["roofline"] = roof
-        if world == 1 and not args.no_extras:
+        if world == 1 and not args.no_extras and headline:
             try:
                 res["feature_path"] = feature_path(device)
             except Exception as e:                      # the headline number must not depend on the extra leg
                 res["feature_path"] = {"error": repr(e)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and headline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
     if pg is not None:

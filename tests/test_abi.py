@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(_lib.SedDims) == 40
+    assert C.sizeof(_lib.SedDims) == 44 and _lib.SedDims.dtype.offset == 40
     assert C.sizeof(_lib.SedStepState) == 6 * 8 + 6 * 8 + 4 * 4
     assert _lib.SedStepState.seed_student.offset == 32 and _lib.SedStepState.seed_teacher.offset == 40
 
@@ -46,6 +46,12 @@ def test_param_layout_matches_reference_order():
     assert offs[-1] == 214356
     d1 = _lib.make_dims(24, 628, n_layers_rnn=1)
     assert _lib.param_layout(d1)[-1] == 214356 - 2 * (192 * 128 + 192 * 64 + 2 * 192)
+    # the wide CRNN of BASELINE.json configs[4]: nb_filters 3 x 128, n_RNN_cell 256 (2 132 628)
+    dw = _lib.make_dims(24, 628, C_=128, H=256, dtype=_lib.DTYPE_BF16)
+    offs_w = _lib.param_layout(dw)
+    shapes_w = list(ref_cpu.param_shapes(nb_filters=(128, 128, 128), n_RNN_cell=256).values())
+    assert [offs_w[i + 1] - offs_w[i] for i in range(len(shapes_w))] == [int(np.prod(s)) for s in shapes_w]
+    assert offs_w[-1] == 2132628
 
 
 def test_unsupported_configurations_fail_loudly():
@@ -57,6 +63,11 @@ def test_unsupported_configurations_fail_loudly():
     assert l.sed_mel_spec_ws_bytes(1, 160000, 255, 1024, 64) == 0
     ok = _lib.make_dims(24, 628)
     assert l.sed_crnn_ctx_bytes(C.byref(ok)) > 0 and l.sed_crnn_bwd_ws_bytes(C.byref(ok)) > 0
+    for kw in (dict(C_=128, H=256), dict(dtype=_lib.DTYPE_BF16), dict(C_=128, H=256, dtype=_lib.DTYPE_BF16)):
+        d = _lib.make_dims(24, 628, **kw)
+        assert l.sed_crnn_ctx_bytes(C.byref(d)) > 0 and l.sed_crnn_bwd_ws_bytes(C.byref(d)) > 0, kw
+    for kw in (dict(C_=96), dict(H=128), dict(dtype=7)):
+        assert l.sed_crnn_ctx_bytes(C.byref(_lib.make_dims(24, 628, **kw))) == 0, kw
 
 
 def test_module_refuses_configs_outside_the_hot_path_and_cpu_tensors():

@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256) void k_gen_pack(GenPackArgs a) {
     const int C = a.C, CC = C * C;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < a.n_zero) a.zero[i] = 0.0;
+    if (i == 0 && a.err) *a.err = 0;
     if (i < 2 * 9 * CC) {
         const int layer = i / (9 * CC), e = i % (9 * CC);
         const int n = e / (9 * C), r = e % (9 * C), tap = r / C, k = r % C;

@@ -19,6 +19,7 @@ struct GCtx {
     size_t wz0, wl0, bn0, mompart, p0;
     size_t wpk[3], wpkT[3], wg[3], wgT[3], bg[3], y[3], bn[3], p[3];      // index 1, 2
     size_t gi[2], gates[2], out[2], whh[2], whhT[2];
+    size_t xch[2], epoch[2], err;             // cluster recurrence: exchange granules, launch epochs, spin-timeout flag
     size_t logits_s, strong_sv, weak_sv, den_sv;
     size_t mask[3];
     size_t total;
@@ -47,7 +48,9 @@ static GCtx make_gctx(const Geo& g) {
         put(L.gi[l], g.H == 64 ? 0 : bt * 6 * H * 4);          // (H = 64: the projection runs inside gru.hip's kernel)
         put(L.gates[l], bt * 8 * H * 4); put(L.out[l], bt * 2 * H * 4);
         put(L.whh[l], g.H == 64 ? 0 : 2 * 3 * H * H * 4); put(L.whhT[l], g.H == 64 ? 0 : 2 * 3 * H * H * 4);
+        put(L.xch[l], g.H == 256 ? gclu_xch_bytes(g.B, g.H, 0) : 0); put(L.epoch[l], (size_t)2 * g.B * 4);
     }
+    put(L.err, 256);
     put(L.logits_s, bt * g.NC * 4); put(L.strong_sv, bt * g.NC * 4);
     put(L.weak_sv, (size_t)g.B * g.NC * 4); put(L.den_sv, (size_t)g.B * g.NC * 4);
     put(L.mask[0], mask_bytes((size_t)g.B * g.H1 * g.W1, g.C)); put(L.mask[1], mask_bytes((size_t)g.B * g.H2 * g.W2, g.C));
@@ -59,7 +62,8 @@ static GCtx make_gctx(const Geo& g) {
 struct GWs {
     size_t d_out, dgi[2], dgh[2], hprev[2], d_in, heads_part;
     size_t dp[3], dz[3], coef[3];             // dp[i]: gradient w.r.t. block i's pooled output; dz / coef: blocks 1, 2
-    size_t glu_part, de0, wg_part, gemm_part;
+    size_t glu_part, glu_part2, de0, wg_part, gemm_part;
+    size_t xch[2], epoch[2];
     size_t total;
 };
 static GWs make_gws(const Geo& g) {
@@ -76,10 +80,12 @@ static GWs make_gws(const Geo& g) {
     W.dz[0] = 0; W.coef[0] = 0;
     put(W.coef[1], 3 * C * 4); put(W.coef[2], 3 * C * 4);
     put(W.glu_part, (size_t)gglu_bwd_grid(g.B, g.H1, g.W1) * (C * C + 3 * C) * 4);
+    put(W.glu_part2, (size_t)GPART_SLICES * (C * C + 3 * C) * 4);
     put(W.de0, 2 * C * 10 * sizeof(double));
     put(W.wg_part, (size_t)gwgrad_slabs(g.C) * 9 * C * C * 4);
     const size_t max_nin = (size_t)(g.L > 1 ? (2 * H > C ? 2 * H : C) : C);
     put(W.gemm_part, gemm_part_floats(4, gru_splitk(g), 3 * (int)H, (int)max_nin + 1) * 4);
+    for (int l = 0; l < 2; ++l) { put(W.xch[l], g.H == 256 ? gclu_xch_bytes(g.B, g.H, 1) : 0); put(W.epoch[l], (size_t)2 * g.B * 4); }
     W.total = o;
     return W;
 }
@@ -96,7 +102,7 @@ int gen_ctx_view(const Geo& g, const char* name, size_t* offset, size_t* bytes) 
         {"bn1", L.bn[1], 4 * C * 4}, {"p1", L.p[1], n1}, {"y2", L.y[2], n1}, {"stat2", L.stat2, 2 * C * 8}, {"bn2", L.bn[2], 4 * C * 4},
         {"p2", L.p[2], bt * C * 4}, {"gates0", L.gates[0], bt * 8 * H * 4}, {"gates1", L.gates[1], bt * 8 * H * 4},
         {"gru0", L.out[0], bt * 2 * H * 4}, {"gru1", L.out[1], bt * 2 * H * 4}, {"logits_s", L.logits_s, bt * g.NC * 4},
-        {"den", L.den_sv, (size_t)g.B * g.NC * 4},
+        {"den", L.den_sv, (size_t)g.B * g.NC * 4}, {"gru_err", L.err, 4},
     };
     for (auto& t : tab)
         if (strcmp(t.n, name) == 0) { *offset = t.o; *bytes = t.b; return SED_OK; }
@@ -137,8 +143,11 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
     pk.wgT1 = train ? CTXV(L.wgT[1]) : nullptr; pk.wgT2 = train ? CTXV(L.wgT[2]) : nullptr;
     pk.bg1 = CTXF(L.bg[1]); pk.bg2 = CTXF(L.bg[2]);
     pk.zero = CTXD(L.stat1); pk.n_zero = train ? 4 * C : 0;
+    pk.err = (int*)CTXV(L.err);
     SED_TRY(launch_gen_pack(pk, g.mode, st));
-    if (H != 64)
+    // (debug bit 10: the streaming recurrence kernels instead of the cluster ones - A/B timing)
+    const bool cluster = (H == 256) && !(g_sed_debug & 1024);
+    if (H != 64 && !cluster)
         for (int l = 0; l < g.L; ++l)
             SED_TRY(launch_ggru_pack(params + P.w_hh[l][0], params + P.w_hh[l][1], CTXF(L.whh[l]), train ? CTXF(L.whhT[l]) : nullptr, H, st));
     // ---- conv block 0 -------------------------------------------------------------------------------------------------
@@ -177,8 +186,13 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
                 gb.p[dir].bias = params + P.b_ih[l][dir];
             }
             SED_TRY(launch_gemm_batch(gb, st));
-            SED_TRY(launch_ggru_fwd(H, CTXF(L.gi[l]), CTXF(L.whh[l]), params + P.b_hh[l][0], params + P.b_hh[l][1], CTXF(L.out[l]),
-                                    train ? CTXF(L.gates[l]) : nullptr, g.B, g.T3, st));
+            if (cluster)
+                SED_TRY(launch_gclu_fwd(CTXF(L.gi[l]), params + P.w_hh[l][0], params + P.w_hh[l][1], params + P.b_hh[l][0],
+                                        params + P.b_hh[l][1], CTXF(L.out[l]), train ? CTXF(L.gates[l]) : nullptr, CTXV(L.xch[l]),
+                                        (unsigned int*)CTXV(L.epoch[l]), (int*)CTXV(L.err), g.B, g.T3, st));
+            else
+                SED_TRY(launch_ggru_fwd(H, CTXF(L.gi[l]), CTXF(L.whh[l]), params + P.b_hh[l][0], params + P.b_hh[l][1], CTXF(L.out[l]),
+                                        train ? CTXF(L.gates[l]) : nullptr, g.B, g.T3, st));
         }
         in = CTXF(L.out[l]);
         nin = 2 * H;
@@ -232,8 +246,13 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
                 d_cur = d_in;
                 d_cur2 = d_in + (size_t)BT * nin;
             } else {
-                SED_TRY(launch_ggru_bwd(H, d_cur, CTXF(L.out[l]), CTXF(L.gates[l]), CTXF(L.whhT[l]), WSF(W.dgi[l]), WSF(W.dgh[l]),
-                                        WSF(W.hprev[l]), g.B, g.T3, st));
+                if (H == 256 && !(g_sed_debug & 1024))
+                    SED_TRY(launch_gclu_bwd(d_cur, CTXF(L.out[l]), CTXF(L.gates[l]), params + P.w_hh[l][0], params + P.w_hh[l][1],
+                                            WSF(W.dgi[l]), WSF(W.dgh[l]), WSF(W.hprev[l]), (void*)((char*)ws + W.xch[l]),
+                                            (unsigned int*)((char*)ws + W.epoch[l]), (int*)CTXV(L.err), g.B, g.T3, st));
+                else
+                    SED_TRY(launch_ggru_bwd(H, d_cur, CTXF(L.out[l]), CTXF(L.gates[l]), CTXF(L.whhT[l]), WSF(W.dgi[l]), WSF(W.dgh[l]),
+                                            WSF(W.hprev[l]), g.B, g.T3, st));
                 // dX[bt][i] = sum_dir sum_g dgi[bt][dir][g] W_ih[dir][g][i]: K = 6H, the two W_ih stacked along K
                 GemmBatch gb;
                 gb.n_prob = 1; gb.splits = 1; gb.part = nullptr; gb.part_stride = 0;
@@ -281,6 +300,7 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
                                 g.p, CTXM(L.mask[i]), st));
         GBnBwdArgs pa;
         pa.part = WSF(W.glu_part); pa.n_part = gglu_bwd_grid(g.B, Hs[i], Wd[i]); pa.C = C; pa.N = (double)g.B * Hs[i] * Wd[i];
+        pa.part2 = WSF(W.glu_part2);
         pa.gamma = params + P.bn_g[i]; pa.beta = params + P.bn_b[i]; pa.bn = CTXF(L.bn[i]); pa.coef = WSF(W.coef[i]);
         pa.g_gamma = grads + P.bn_g[i]; pa.g_beta = grads + P.bn_b[i]; pa.g_wglu = grads + P.glu_w[i]; pa.g_bglu = grads + P.glu_b[i];
         pa.g_convb = grads + P.conv_b[i];

@@ -450,7 +450,35 @@ __global__ __launch_bounds__(256) void k_gbn_bwd_prep(GBnBwdArgs a) {
     }
 }
 
-int launch_gbn_bwd_prep(const GBnBwdArgs& a, hipStream_t st) {
+// First stage of the partial-sum reduction: the up-to-256 per-workgroup slabs of k_gglu_bwd are folded into GPART_SLICES
+// slabs by the whole chip (slice s adds slabs s, s + S, s + 2S, ... in that fixed order, 8 loads in flight per thread);
+// k_gbn_bwd_prep then adds the GPART_SLICES survivors.  One 65-workgroup kernel walking 256 slabs serially took 75 us -
+// the slowest kernel of the bf16 step.
+__global__ __launch_bounds__(256) void k_gpart_reduce(const float* __restrict__ part, int n_part, int n_el, float* __restrict__ out) {
+    const int e = blockIdx.x * 256 + threadIdx.x, sl = blockIdx.y;
+    if (e >= n_el) return;
+    float s = 0.f;
+    int k = sl;
+    for (; k + 7 * GPART_SLICES < n_part; k += 8 * GPART_SLICES) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(k + u * GPART_SLICES) * n_el + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < n_part; k += GPART_SLICES) s += part[(size_t)k * n_el + e];
+    out[(size_t)sl * n_el + e] = s;
+}
+
+int launch_gbn_bwd_prep(const GBnBwdArgs& a0, hipStream_t st) {
+    GBnBwdArgs a = a0;
+    const int n_el = a.C * a.C + 3 * a.C;
+    if (a.n_part > GPART_SLICES) {
+        k_gpart_reduce<<<dim3((n_el + 255) / 256, GPART_SLICES), 256, 0, st>>>(a.part, a.n_part, n_el, a.part2);
+        SED_CHECK_LAUNCH();
+        a.part = a.part2;
+        a.n_part = GPART_SLICES;
+    }
     k_gbn_bwd_prep<<<a.C * a.C / 256 + 1, 256, 0, st>>>(a);
     SED_CHECK_LAUNCH();
     return SED_OK;

@@ -11,6 +11,7 @@ struct GenPackArgs {
     void *wg1, *wg2, *wgT1, *wgT2;              // GLU weights folded with gamma [co][c]; transposed raw [c][co] (may be null)
     float *bg1, *bg2;                           // GLU bias folded with beta [C]
     double* zero; int n_zero;                   // fp64 accumulators to clear
+    int* err;                                   // spin-timeout flag of the cluster GRU kernels, cleared here (may be null)
 };
 int launch_gen_pack(const GenPackArgs& a, int mode, hipStream_t st);
 int launch_gconv_fwd(int mode, int C, const float* in, const void* wpk, const float* bias, float* y, double* stat, int B, int H,
@@ -36,8 +37,10 @@ int gglu_bwd_grid(int B, int H, int W);
 int launch_gglu_bwd(int mode, int C, const float* y, const float* bn, const float* gamma, const float* beta, const void* wg,
                     const void* wgT, const float* bg, const float* dp, float* dz, float* part, int B, int H, int W, int use_drop,
                     float p_drop, const uint16_t* mask_in, hipStream_t st);
+#define GPART_SLICES 8
 struct GBnBwdArgs {
     const float* part; int n_part; int C; double N;
+    float* part2;                               // scratch: [GPART_SLICES][C * C + 3 * C] floats (first reduction stage)
     const float *gamma, *beta, *bn;
     float *coef, *g_gamma, *g_beta, *g_wglu, *g_bglu, *g_convb;
 };
@@ -53,6 +56,13 @@ int launch_ggru_fwd(int H, const float* gi, const float* wp, const float* b_hh_f
 // d_out [B*T][2H]; dgi / dgh [B*T][2][3H]; hprev [B*T][2][H]
 int launch_ggru_bwd(int H, const float* d_out, const float* out, const float* gates, const float* wpT, float* dgi, float* dgh,
                     float* hprev, int B, int T, hipStream_t st);
+
+// cluster recurrence (4 workgroups per chain, W_hh in registers, per-step granule exchange through L2); H = 256 only
+size_t gclu_xch_bytes(int B, int H, int bwd);
+int launch_gclu_fwd(const float* gi, const float* w_hh_f, const float* w_hh_r, const float* b_hh_f, const float* b_hh_r, float* out,
+                    float* gates, void* xch, unsigned int* epoch, int* err, int B, int T, hipStream_t st);
+int launch_gclu_bwd(const float* d_out, const float* out, const float* gates, const float* w_hh_f, const float* w_hh_r, float* dgi,
+                    float* dgh, float* hprev, void* xch, unsigned int* epoch, int* err, int B, int T, hipStream_t st);
 
 // gcrnn.hip ---------------------------------------------------------------------------------------------------------------
 struct HeadsLoss;

@@ -104,9 +104,10 @@ class MeanTeacherStep:
         self.ws_bytes = self.l.sed_crnn_bwd_ws_bytes(C.byref(self.dims))
         if self.ctx_bytes == 0 or self.ws_bytes == 0:
             raise _lib.SedError(self.l.sed_last_error().decode())
-        self.ctx_s = torch.empty(self.ctx_bytes, device=dev, dtype=torch.uint8)
-        self.ctx_t = torch.empty(self.ctx_bytes if teacher is not None else 0, device=dev, dtype=torch.uint8)
-        self.ws = torch.empty(self.ws_bytes, device=dev, dtype=torch.uint8)
+        # (zeros, not empty: the wide model's cluster recurrence keeps launch epochs and tagged exchange granules in there)
+        self.ctx_s = torch.zeros(self.ctx_bytes, device=dev, dtype=torch.uint8)
+        self.ctx_t = torch.zeros(self.ctx_bytes if teacher is not None else 0, device=dev, dtype=torch.uint8)
+        self.ws = torch.zeros(self.ws_bytes, device=dev, dtype=torch.uint8)
         self.x = torch.zeros(self.B, 1, self.T, 64, **f32)
         self.x_ema = torch.zeros(self.B, 1, self.T, 64, **f32)
         self.target = torch.zeros(self.B, self.T3, self.NC, **f32)

@@ -63,6 +63,8 @@ def _fwd_bwd(B, T, p, C, H, dtype, seed=987654321, n_layers=2, nclass=10):
     lo = loss_fn(so, wo, "cpu")
     go = dict(zip(po.keys(), torch.autograd.grad(lo, list(po.values()))))
     stages = _stage_report(model, inter, B, T, C, H)
+    if H == 256:      # the cluster recurrence's bounded spins never timed out
+        assert int(model.ctx_view("gru_err").view(torch.int32)[0]) == 0
     return dict(s=s.detach().cpu(), w=w.detach().cpu(), loss=float(loss.detach()), g=gu.grads_dict(model),
                 bn=gu.bn_state_from_model(model), so=so.detach(), wo=wo.detach(), lo=float(lo.detach()), go=go, bno=bn,
                 stages=stages)

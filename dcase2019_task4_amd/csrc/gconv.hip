@@ -107,26 +107,59 @@ __global__ __launch_bounds__(256) void k_gconv(const float* __restrict__ in0, co
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) bv[nb] = (DIR == 0) ? bias[32 * nb + n] : 0.f;
     __syncthreads();
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // ---- halo staging: rows r0 - 1 .. r0 + TH, columns -1 .. TW, all C channels; zero outside the image ----------------
+    // Split into "issue every load of the tile" and "convert + store to LDS": a load consumed right after its issue costs
+    // a full memory round trip per item on these one-workgroup-per-CU kernels (23 items per thread: 30 us per tile against
+    // 4 us of bf16 MFMAs in the first version).  The forward kernel goes further and issues the NEXT tile's loads before the
+    // current tile's MFMAs, so they are in flight while it computes; dgrad (two source tensors: twice the registers) issues
+    // its loads in one batch at the top of the tile.
+    constexpr int NL = (HH * HW * C4 + 255) / 256;         // float4 items per thread
+    auto halo_load = [&](int tile, f32x4 (&v)[NL], f32x4 (&w)[DIR == 1 ? NL : 1]) {
         const int b = tile / tiles_per_clip, r0 = (tile % tiles_per_clip) * TH;
-        // ---- halo: rows r0 - 1 .. r0 + TH, columns -1 .. TW, all C channels; zero outside the image ----------------
-        for (int g = tid; g < HH * HW * C4; g += 256) {
-            const int hp = g / C4, c4 = g % C4;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int g = tid + 256 * i, hp = g / C4, c4 = g % C4;
             const int hy = hp / HW, hx = hp % HW;
             const int row = r0 - 1 + hy, col = hx - 1;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row >= 0 && row < H && col >= 0 && col < TW) {
+            v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (DIR == 1) w[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (g < HH * HW * C4 && row >= 0 && row < H && col >= 0 && col < TW) {
                 const size_t off = ((size_t)(b * H + row) * TW + col) * C + 4 * c4;
-                v = *(const f32x4*)(in0 + off);
-                if (DIR == 1) {
-                    const f32x4 y = *(const f32x4*)(in1 + off);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = cf[4 * c4 + q] * v[q] + cf[C + 4 * c4 + q] * y[q] + cf[2 * C + 4 * c4 + q];
-                }
+                v[i] = *(const f32x4*)(in0 + off);
+                if (DIR == 1) w[i] = *(const f32x4*)(in1 + off);
             }
-            M::st4(halo + hp * CS + 4 * c4, v[0], v[1], v[2], v[3]);
         }
+    };
+    auto halo_store = [&](int tile, const f32x4 (&v)[NL], const f32x4 (&w)[DIR == 1 ? NL : 1]) {
+        const int r0 = (tile % tiles_per_clip) * TH;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int g = tid + 256 * i, hp = g / C4, c4 = g % C4;
+            if (g < HH * HW * C4) {
+                f32x4 o = v[i];
+                if (DIR == 1) {
+                    const int hy = hp / HW, hx = hp % HW;
+                    const int row = r0 - 1 + hy, col = hx - 1;
+                    const bool in = row >= 0 && row < H && col >= 0 && col < TW;      // outside the image dy is 0, not cc
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        o[q] = in ? cf[4 * c4 + q] * v[i][q] + cf[C + 4 * c4 + q] * w[i][q] + cf[2 * C + 4 * c4 + q] : 0.f;
+                }
+                M::st4(halo + hp * CS + 4 * c4, o[0], o[1], o[2], o[3]);
+            }
+        }
+    };
+    f32x4 hv[NL], hw[DIR == 1 ? NL : 1];
+    if (DIR == 0 && (int)blockIdx.x < n_tiles) halo_load(blockIdx.x, hv, hw);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_clip, r0 = (tile % tiles_per_clip) * TH;
+        if (DIR == 1) halo_load(tile, hv, hw);
+        halo_store(tile, hv, hw);
         __syncthreads();
+        if (DIR == 0) {       // next tile's loads fly during this tile's MFMAs (past the end: re-read this tile, harmless)
+            const int nt = tile + (int)gridDim.x;
+            halo_load(nt < n_tiles ? nt : tile, hv, hw);
+        }
         f32x16 acc[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -292,6 +325,126 @@ __global__ __launch_bounds__(256) void k_gwgrad(const float* __restrict__ dz, co
             ps[((size_t)t * C + co0 + 32 * wa + mfma32_row(r, lane)) * C + ci0 + 32 * wb + n] = acc[t][r];
 }
 
+// ---- wgrad on the bf16 MFMA (block 1, W = 16) ----------------------------------------------------------------------------
+// The contraction index is the PIXEL, so both operands must reach the MFMA pixel-contiguous: they are transposed on their
+// way into LDS.  A thread loads 8 consecutive pixels x 4 channels (8 float4) and writes 4 x (8 pixels of one channel) as
+// 16-byte bf16 vectors - a register transpose, no extra instructions.  The 3x3 taps then need the x tile SHIFTED by
+// (dr, dc) pixels: k = r * 16 + c makes a row shift an offset of 16 elements (32 B: aligned), and the column shift is
+// served by three copies of the transposed halo, one per dc, each already shifted (copy[dc][ci][hr][c] = x[hr][c + dc]).
+//   A[i = co][k = pixel] = dyT[co][k]                    64 x (128 + 8) bf16
+//   B[k = pixel][j = ci] = xT[dc][ci][dr * 16 + k]       3 x 64 x (160 + 8) bf16
+// Same decomposition as k_gwgrad: a workgroup owns a 64 x 64 (co, ci) quadrant for all 9 taps over a slab of tiles
+// (9 accumulators of 32 x 32 per wave) and writes one partial slab.  The next tile's loads are issued before the
+// current tile's MFMAs.
+struct GWgB {
+    static constexpr int TH = 8, TW = 16, HH = 10, DS = 128 + 8, XS = HH * 16 + 8;
+    static constexpr int DY_E = 64 * DS, X_E = 3 * 64 * XS;
+    static constexpr size_t LDS_BYTES = (size_t)(DY_E + X_E) * 2 + 3 * 64 * 4;
+};
+__global__ __launch_bounds__(256) void k_gwgrad_bf16(const float* __restrict__ dz, const float* __restrict__ yin,
+                                                      const float* __restrict__ coef, const float* __restrict__ xin,
+                                                      float* __restrict__ part, int C, int H, int tiles_per_clip, int n_tiles) {
+    using M = MM<1>;
+    constexpr int TH = GWgB::TH, DS = GWgB::DS, XS = GWgB::XS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsm2[];
+    __bf16* dyT = (__bf16*)wsm2;
+    __bf16* xT = dyT + GWgB::DY_E;
+    float* cf = (float*)(xT + GWgB::X_E);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 31, kh = lane >> 5;
+    const int nq = C / 64, quad = blockIdx.y, co0 = (quad / nq) * 64, ci0 = (quad % nq) * 64;
+    const int wa = wv >> 1, wb = wv & 1;
+    if (tid < 192) cf[tid] = coef[(tid / 64) * C + co0 + (tid % 64)];
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // staging items: dy - (pixel group pg of 8, channel quad cq); x - (halo row hr, column group cg, channel quad cq), 320 items
+    const int cq = tid & 15, pg = tid >> 4;
+    f32x4 dzv[8], yv[8], xv[2][10];
+    auto load = [&](int tile) {
+        const int b = tile / tiles_per_clip, r0 = (tile % tiles_per_clip) * TH;
+        {
+            const int r = pg >> 1, c0 = (pg & 1) * 8, row = r0 + r;
+            const bool ok = row < H;
+            const size_t base = ((size_t)(b * H + (ok ? row : 0)) * 16 + c0) * C + co0 + 4 * cq;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                dzv[i] = *(const f32x4*)(dz + base + (size_t)i * C);
+                yv[i] = *(const f32x4*)(yin + base + (size_t)i * C);
+                if (!ok) { dzv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; yv[i] = dzv[i]; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int it = tid + 256 * j, cg = (it >> 4) & 1, hr = it >> 5;
+            const int row = r0 - 1 + hr;
+            const bool rok = (it < 320) && row >= 0 && row < H;
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const int col = 8 * cg - 1 + i;
+                xv[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (rok && col >= 0 && col < 16) xv[j][i] = *(const f32x4*)(xin + ((size_t)(b * H + row) * 16 + col) * C + ci0 + 4 * cq);
+            }
+        }
+    };
+    auto store = [&](int tile) {
+        const int r0 = (tile % tiles_per_clip) * TH;
+        const bool ok = r0 + (pg >> 1) < H;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bf16x8 v;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                v[i] = (__bf16)(ok ? cf[4 * cq + q] * dzv[i][q] + cf[64 + 4 * cq + q] * yv[i][q] + cf[128 + 4 * cq + q] : 0.f);
+            *(bf16x8*)(dyT + (4 * cq + q) * DS + 8 * pg) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int it = tid + 256 * j, cg = (it >> 4) & 1, hr = it >> 5;
+            if (it < 320) {
+#pragma unroll
+                for (int dc = 0; dc < 3; ++dc)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        bf16x8 v;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] = (__bf16)xv[j][dc + i][q];
+                        *(bf16x8*)(xT + ((size_t)(dc * 64 + 4 * cq + q)) * XS + hr * 16 + 8 * cg) = v;
+                    }
+            }
+        }
+    };
+    __syncthreads();
+    if ((int)blockIdx.x < n_tiles) load(blockIdx.x);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        store(tile);
+        __syncthreads();
+        {
+            const int nt = tile + (int)gridDim.x;
+            load(nt < n_tiles ? nt : tile);
+        }
+        const __bf16* Ap = dyT + (32 * wa + n) * DS + 8 * kh;
+        const __bf16* Bp = xT + (size_t)(32 * wb + n) * XS + 8 * kh;
+#pragma unroll 2
+        for (int ks = 0; ks < 8; ++ks) {
+            const bf16x8 a = *(const bf16x8*)(Ap + 16 * ks);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dr = t / 3, dc = t % 3;
+                acc[t] = M::mma(a, *(const bf16x8*)(Bp + (size_t)dc * 64 * XS + dr * 16 + 16 * ks), acc[t]);
+            }
+        }
+        __syncthreads();
+    }
+    float* ps = part + (size_t)blockIdx.x * 9 * C * C;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            ps[((size_t)t * C + co0 + 32 * wa + mfma32_row(r, lane)) * C + ci0 + 32 * wb + n] = acc[t][r];
+}
+
 // g_w[co][ci][tap] = sum over slabs, fixed order
 __global__ __launch_bounds__(256) void k_gwgrad_reduce(const float* __restrict__ part, int n_slabs, int C, float* __restrict__ g_w) {
     const int e = blockIdx.x * 256 + threadIdx.x;        // e = (tap * C + co) * C + ci
@@ -311,13 +464,19 @@ __global__ __launch_bounds__(256) void k_gwgrad_reduce(const float* __restrict__
 
 int gwgrad_slabs(int C) { return 256 / ((C / 64) * (C / 64)); }
 
-int launch_gwgrad(int C, const float* dz, const float* yin, const float* coef, const float* xin, float* part, float* g_w, int B,
-                  int H, int W, hipStream_t st) {
+int launch_gwgrad(int mode, int C, const float* dz, const float* yin, const float* coef, const float* xin, float* part, float* g_w,
+                  int B, int H, int W, hipStream_t st) {
     SED_CHECK_ARG(C == 64 || C == 128, "gwgrad: C must be 64 or 128");
     const int nq = (C / 64) * (C / 64);
     int slabs = gwgrad_slabs(C);
     int nt, tpc;
-    if (W == 16) {
+    if (W == 16 && mode == SED_DTYPE_BF16) {
+        static bool attr = false;
+        if (!attr) { SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GWgB::LDS_BYTES)); attr = true; }
+        tpc = (H + GWgB::TH - 1) / GWgB::TH; nt = B * tpc;
+        if (slabs > nt) slabs = nt;
+        k_gwgrad_bf16<<<dim3(slabs, nq), 256, GWgB::LDS_BYTES, st>>>(dz, yin, coef, xin, part, C, H, tpc, nt);
+    } else if (W == 16) {
         using Cfg = GWgCfg<16>;
         static bool attr = false;
         if (!attr) { SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES)); attr = true; }

@@ -306,7 +306,7 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
         pa.g_convb = grads + P.conv_b[i];
         SED_TRY(launch_gbn_bwd_prep(pa, st));
         SED_TRY(fork());
-        SED_TRY(launch_gwgrad(C, WSF(W.dz[i]), CTXF(L.y[i]), WSF(W.coef[i]), CTXF(L.p[i - 1]), WSF(W.wg_part), grads + P.conv_w[i], g.B,
+        SED_TRY(launch_gwgrad(g.mode, C, WSF(W.dz[i]), CTXF(L.y[i]), WSF(W.coef[i]), CTXF(L.p[i - 1]), WSF(W.wg_part), grads + P.conv_w[i], g.B,
                               Hs[i], Wd[i], ss));
         if (i == 2 && parts == 3) {
             if (have_side) SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, ss, 2 * H));

@@ -38,26 +38,42 @@ __device__ __forceinline__ void gbn_prep(const GBnArgs& a, int C, int c, bool pu
     }
 }
 
-// stages the 32 pixels x C channels of row block q0 as xhat into xf (fp32) and, in bf16 mode, xb; one wave
-template <int MODE, int C>
-__device__ __forceinline__ void gglu_stage(const float* __restrict__ y, const float* bn_s, float* xf, typename MM<MODE>::E* xb,
-                                           int q0, int Q, int H, int W, int Ho, int Wo, int lane) {
-    using M = MM<MODE>;
-    constexpr int C4 = C / 4, XS = C + 1, BS = C + M::PAD;
+// Staging of one row block (32 pixels x C channels) as xhat into xf (fp32) and, in bf16 mode, xb; one wave.  Split into
+// "issue all loads" and "normalise + store to LDS": a load consumed right after its issue exposes a full memory round
+// trip per item on these one-workgroup-per-CU kernels (16 items per lane: ~30 us per round in the first version); the
+// forward kernel issues the NEXT round's loads before the current round's MFMAs.
+template <int C>
+struct GGluTile { f32x4 v[32 * (C / 4) / 64]; };
+template <int C>
+__device__ __forceinline__ void gglu_load(GGluTile<C>& t, const float* __restrict__ y, int q0, int Q, int H, int W, int Ho, int Wo,
+                                          int lane) {
+    constexpr int C4 = C / 4;
     int pb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) pb[j] = (q0 + j < Q) ? gen_rb_pixel(q0 + j, 0, 0, H, W, Ho, Wo) : -1;
-#pragma unroll 4
+#pragma unroll
     for (int i = 0; i < 32 * C4 / 64; ++i) {
         const int g = lane + 64 * i, m = g / C4, c4 = g % C4;
         const int j = m >> 3, dt = (m >> 2) & 1, df = m & 3;
         const int base = (j == 0) ? pb[0] : (j == 1) ? pb[1] : (j == 2) ? pb[2] : pb[3];
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (base >= 0) {
-            const f32x4 yv = *(const f32x4*)(y + (size_t)(base + dt * W + df) * C + 4 * c4);
+        // invalid pooled pixels (only past the end of the last row block) read pixel 0 and are zeroed at the store
+        const size_t off = (size_t)((base >= 0 ? base : 0) + dt * W + df) * C + 4 * c4;
+        t.v[i] = *(const f32x4*)(y + off);
+        if (base < 0) t.v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+template <int MODE, int C>
+__device__ __forceinline__ void gglu_store(const GGluTile<C>& t, const float* bn_s, float* xf, typename MM<MODE>::E* xb, int q0, int Q,
+                                           int lane) {
+    using M = MM<MODE>;
+    constexpr int C4 = C / 4, XS = C + 1, BS = C + M::PAD;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = (yv[q] - bn_s[4 * c4 + q]) * bn_s[C + 4 * c4 + q];
-        }
+    for (int i = 0; i < 32 * C4 / 64; ++i) {
+        const int g = lane + 64 * i, m = g / C4, c4 = g % C4;
+        const bool ok = q0 + (m >> 3) < Q;
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = ok ? (t.v[i][q] - bn_s[4 * c4 + q]) * bn_s[C + 4 * c4 + q] : 0.f;
         float* d = xf + m * XS + 4 * c4;
         d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
         if (MODE == 1) M::st4(xb + m * BS + 4 * c4, v[0], v[1], v[2], v[3]);
@@ -102,11 +118,20 @@ __global__ __launch_bounds__(256) void k_gglu_fwd(const float* __restrict__ y, G
     const float sc = 0.125f * (use_drop ? drop_scale8(p_drop) : 1.0f);
     const int n_rb = (Q + 3) / 4;
     const int rounds = (n_rb + gridDim.x * 4 - 1) / (gridDim.x * 4);
+    GGluTile<C> yt;
+    {
+        const int rb0 = blockIdx.x * 4 + wv;
+        gglu_load<C>(yt, y, (rb0 < n_rb ? rb0 : 0) * 4, Q, H, W, Ho, Wo, lane);
+    }
     for (int round = 0; round < rounds; ++round) {
         const int rb = (round * gridDim.x + blockIdx.x) * 4 + wv;
         const bool live = rb < n_rb;
         const int q0 = rb * 4;
-        if (live) gglu_stage<MODE, C>(y, bn_s, xf, xb, q0, Q, H, W, Ho, Wo, lane);
+        if (live) gglu_store<MODE, C>(yt, bn_s, xf, xb, q0, Q, lane);
+        {   // the next round's tile flies during this round's MFMAs and epilogue (past the end: row block 0, never used)
+            const int rbn = ((round + 1) * gridDim.x + blockIdx.x) * 4 + wv;
+            gglu_load<C>(yt, y, (rbn < n_rb ? rbn : 0) * 4, Q, H, W, Ho, Wo, lane);
+        }
         f32x16 acc[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -250,23 +275,28 @@ __global__ __launch_bounds__(256) void k_gglu_bwd(const float* __restrict__ y, c
         const int rb = (round * gridDim.x + blockIdx.x) * 2 + g;
         const bool live = rb < n_rb;
         const int q0 = rb * 4;
-        // ---- stage: each wave of the pair stages half of the row block's 32 rows (all channels) -------------------------
+        // ---- stage: each wave of the pair stages half of the row block's 32 rows (all channels); all loads first ----------
         {
-            constexpr int C4 = C / 4;
+            constexpr int C4 = C / 4, NI = 16 * C4 / 64;
             int pb[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) pb[j] = (live && q0 + j < Q) ? gen_rb_pixel(q0 + j, 0, 0, H, W, Ho, Wo) : -1;
-#pragma unroll 4
-            for (int i = 0; i < 16 * C4 / 64; ++i) {
+            f32x4 yv[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
                 const int gg = lane + 64 * i, m = 16 * hf + gg / C4, c4 = gg % C4;
                 const int j = m >> 3, dt = (m >> 2) & 1, df = m & 3;
                 const int base = (j == 0) ? pb[0] : (j == 1) ? pb[1] : (j == 2) ? pb[2] : pb[3];
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (base >= 0) {
-                    const f32x4 yv = *(const f32x4*)(y + (size_t)(base + dt * W + df) * C + 4 * c4);
+                yv[i] = *(const f32x4*)(y + (size_t)((base >= 0 ? base : 0) + dt * W + df) * C + 4 * c4);
+            }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = (yv[q] - bn_s[4 * c4 + q]) * bn_s[C + 4 * c4 + q];
-                }
+            for (int i = 0; i < NI; ++i) {
+                const int gg = lane + 64 * i, m = 16 * hf + gg / C4, c4 = gg % C4;
+                const int j = m >> 3;
+                const int base = (j == 0) ? pb[0] : (j == 1) ? pb[1] : (j == 2) ? pb[2] : pb[3];
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = (base >= 0) ? (yv[i][q] - bn_s[4 * c4 + q]) * bn_s[C + 4 * c4 + q] : 0.f;
                 float* d = xf + m * XS + 4 * c4;
                 d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
                 if (MODE == 1) M::st4(xb + m * BS + 4 * c4, v[0], v[1], v[2], v[3]);

@@ -19,7 +19,7 @@ int launch_gconv_fwd(int mode, int C, const float* in, const void* wpk, const fl
 int launch_gconv_dgrad(int mode, int C, const float* dz, const float* yin, const float* coef, const void* wpkT, float* dx, int B,
                        int H, int W, hipStream_t st);
 int gwgrad_slabs(int C);
-int launch_gwgrad(int C, const float* dz, const float* yin, const float* coef, const float* xin, float* part, float* g_w, int B,
+int launch_gwgrad(int mode, int C, const float* dz, const float* yin, const float* coef, const float* xin, float* part, float* g_w, int B,
                   int H, int W, hipStream_t st);
 
 // gglu.hip ----------------------------------------------------------------------------------------------------------------

@@ -477,17 +477,23 @@ __global__ __launch_bounds__(640) void k_blk0_bwd_finalize(Blk0BwdFinArgs a) {
         Ds[c][t] = a.de[c * 10 + t];
     }
     __syncthreads();
-    // GLU linear: dWglu[co][k] = sum_t D[co][t] wz[k][t];  dbglu[co] = D[co][9]
-    for (int e = tid; e < C * C; e += 640) {
-        const int co = e / C, k = e % C;
-        double acc = 0;
+    // GLU linear: dWglu[co][k] = sum_t D[co][t] wz[k][t];  dbglu[co] = D[co][9].  Workgroups 1 .. gridDim.x - 1 share this
+    // C x C loop (at C = 128 the single-workgroup version took 104 us at the very end of the step); workgroup 0 does the rest.
+    if (blockIdx.x > 0) {
+        const int nsl = gridDim.x - 1, sl = blockIdx.x - 1;
+        for (int e = sl * 640 + tid; e < C * C; e += nsl * 640) {
+            const int co = e / C, k = e % C;
+            double acc = 0;
 #pragma unroll
-        for (int t = 0; t < 10; ++t) acc += Ds[co][t] * wzs[k][t];
-        a.g_wglu[e] = (float)acc;
+            for (int t = 0; t < 10; ++t) acc += Ds[co][t] * wzs[k][t];
+            a.g_wglu[e] = (float)acc;
+        }
+        return;
     }
     for (int e = tid; e < C * 10; e += 640) {   // total dz against the patch: S[c][t] = sum_co Wglu[co][c] D[co][t] + E[c][t]
         const int c = e / 10, t = e % 10;
         double acc = a.de[C * 10 + c * 10 + t];
+#pragma unroll 8
         for (int co = 0; co < C; ++co) acc += (double)a.wglu[co * C + c] * Ds[co][t];
         Ss[c][t] = acc;
     }
@@ -574,7 +580,7 @@ int launch_blk0_backward(const Geo& g, const float* x, const float* w0, const fl
     a.w0 = w0; a.b0 = b0; a.gamma = gamma; a.beta = beta; a.wglu = wglu; a.bn = bn; a.mom = mom; a.de = de;
     a.N = (double)g.B * g.T * g.F;
     a.g_w0 = g_w0; a.g_b0 = g_b0; a.g_gamma = g_gamma; a.g_beta = g_beta; a.g_wglu = g_wglu; a.g_bglu = g_bglu; a.C = g.C;
-    k_blk0_bwd_finalize<<<1, 640, 0, st>>>(a);
+    k_blk0_bwd_finalize<<<1 + (g.C * g.C + 2559) / 2560, 640, 0, st>>>(a);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

@@ -236,8 +236,10 @@ extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* b
     const ParamOff P = make_param_off(g, nullptr);
     if (g.generic) {
         SED_CHECK_ARG(!(train && g.p > 0.f) || seed_dev, "sed_crnn_forward: dropout enabled but seed_dev is null");
-        return gen_forward(g, P, params, bn_running, bn_tracked, x, train, update_bn, seed_dev, ctx, ctx_bytes, strong, weak,
-                           (hipStream_t)stream);
+        hipStream_t st0 = (hipStream_t)stream;
+        SideStream& sd0 = side_stream(st0);
+        return gen_forward(g, P, params, bn_running, bn_tracked, x, train, update_bn, seed_dev, ctx, ctx_bytes, strong, weak, st0,
+                           sd0.ok ? sd0.s : st0, sd0.fork, sd0.join);
     }
     const CtxLayout L = make_ctx_layout(g);
     if (ctx_bytes < L.total) {

@@ -44,15 +44,21 @@ __global__ __launch_bounds__(256) void k_gen_pack(GenPackArgs a) {
         o[e] = M::cvt(wg[e] * gam[c]);
         if (oT) oT[(size_t)c * C + co] = M::cvt(wg[e]);
     }
-    if (i < 2 * C) {
-        const int layer = i / C, co = i % C;
-        const float* wg = layer ? a.glu_w2 : a.glu_w1;
-        const float* bet = layer ? a.beta2 : a.beta1;
-        const float* bgl = layer ? a.glu_b2 : a.glu_b1;
-        double acc = bgl[co];
-        for (int c = 0; c < C; ++c) acc += (double)wg[(size_t)co * C + c] * (double)bet[c];
-        (layer ? a.bg2 : a.bg1)[co] = (float)acc;
-    }
+}
+
+// bg[co] = bglu[co] + sum_c Wglu[co][c] beta[c]: one wave per (layer, co) row, coalesced reads, fp64 butterfly (a thread
+// per row walking its row with stride-C neighbours took 22 us at C = 128 - at the head of every forward)
+__global__ __launch_bounds__(256) void k_gen_pack_bias(GenPackArgs a) {
+    const int C = a.C, row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= 2 * C) return;
+    const int layer = row / C, co = row % C;
+    const float* wg = layer ? a.glu_w2 : a.glu_w1;
+    const float* bet = layer ? a.beta2 : a.beta1;
+    double acc = 0;
+    for (int c = lane; c < C; c += 64) acc += (double)wg[(size_t)co * C + c] * (double)bet[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) (layer ? a.bg2 : a.bg1)[co] = (float)(acc + (double)(layer ? a.glu_b2 : a.glu_b1)[co]);
 }
 
 int launch_gen_pack(const GenPackArgs& a, int mode, hipStream_t st) {
@@ -60,6 +66,8 @@ int launch_gen_pack(const GenPackArgs& a, int mode, hipStream_t st) {
     const int blocks = ((n > a.n_zero ? n : a.n_zero) + 255) / 256;
     if (mode == 1) k_gen_pack<1><<<blocks, 256, 0, st>>>(a);
     else k_gen_pack<0><<<blocks, 256, 0, st>>>(a);
+    SED_CHECK_LAUNCH();
+    k_gen_pack_bias<<<(2 * a.C + 3) / 4, 256, 0, st>>>(a);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

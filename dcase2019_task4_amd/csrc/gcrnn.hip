@@ -19,6 +19,7 @@ struct GCtx {
     size_t wz0, wl0, bn0, mompart, p0;
     size_t wpk[3], wpkT[3], wg[3], wgT[3], bg[3], y[3], bn[3], p[3];      // index 1, 2
     size_t gi[2], gates[2], out[2], whh[2], whhT[2];
+    size_t wihT[2];                           // [nin][6H]: the two W_ih stacked along K and transposed (dX GEMM operand)
     size_t xch[2], epoch[2], err;             // cluster recurrence: exchange granules, launch epochs, spin-timeout flag
     size_t logits_s, strong_sv, weak_sv, den_sv;
     size_t mask[3];
@@ -49,6 +50,7 @@ static GCtx make_gctx(const Geo& g) {
         put(L.gates[l], bt * 8 * H * 4); put(L.out[l], bt * 2 * H * 4);
         put(L.whh[l], g.H == 64 ? 0 : 2 * 3 * H * H * 4); put(L.whhT[l], g.H == 64 ? 0 : 2 * 3 * H * H * 4);
         put(L.xch[l], g.H == 256 ? gclu_xch_bytes(g.B, g.H, 0) : 0); put(L.epoch[l], (size_t)2 * g.B * 4);
+        put(L.wihT[l], g.H == 64 ? 0 : (size_t)(l == 0 ? C : 2 * H) * 6 * H * 4);
     }
     put(L.err, 256);
     put(L.logits_s, bt * g.NC * 4); put(L.strong_sv, bt * g.NC * 4);
@@ -119,7 +121,7 @@ int gen_ctx_view(const Geo& g, const char* name, size_t* offset, size_t* bytes) 
 
 int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_running, int64_t* bn_tracked, const float* x,
                 int train, int update_bn, const uint64_t* seed_dev, void* ctx, size_t ctx_bytes, float* strong, float* weak,
-                hipStream_t st) {
+                hipStream_t st, hipStream_t ss, hipEvent_t ev_fork, hipEvent_t ev_join) {
     const GCtx L = make_gctx(g);
     if (ctx_bytes < L.total) {
         sed_set_error("sed_crnn_forward: ctx has %zu bytes, needs %zu", ctx_bytes, L.total);
@@ -144,17 +146,29 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
     pk.bg1 = CTXF(L.bg[1]); pk.bg2 = CTXF(L.bg[2]);
     pk.zero = CTXD(L.stat1); pk.n_zero = train ? 4 * C : 0;
     pk.err = (int*)CTXV(L.err);
-    SED_TRY(launch_gen_pack(pk, g.mode, st));
+    // the packing is independent of block 0: it runs on the helper stream next to k_x_moments / k_blk0_prep / k_blk0_fwd
+    // and is joined in front of conv1 (25 + 7 us off the head of every forward)
+    const bool have_side = (ss != st);
+    if (have_side) {
+        SED_CHECK_HIP(hipEventRecord(ev_fork, st));
+        SED_CHECK_HIP(hipStreamWaitEvent(ss, ev_fork, 0));
+    }
+    SED_TRY(launch_gen_pack(pk, g.mode, ss));
     // (debug bit 10: the streaming recurrence kernels instead of the cluster ones - A/B timing)
     const bool cluster = (H == 256) && !(g_sed_debug & 1024);
     if (H != 64 && !cluster)
         for (int l = 0; l < g.L; ++l)
-            SED_TRY(launch_ggru_pack(params + P.w_hh[l][0], params + P.w_hh[l][1], CTXF(L.whh[l]), train ? CTXF(L.whhT[l]) : nullptr, H, st));
+            SED_TRY(launch_ggru_pack(params + P.w_hh[l][0], params + P.w_hh[l][1], CTXF(L.whh[l]), train ? CTXF(L.whhT[l]) : nullptr, H, ss));
+    if (H != 64 && train)
+        for (int l = 0; l < g.L; ++l)
+            SED_TRY(launch_gnt_pack_t(params + P.w_ih[l][0], params + P.w_ih[l][1], CTXF(L.wihT[l]), 3 * H, l == 0 ? C : 2 * H, ss));
+    if (have_side) SED_CHECK_HIP(hipEventRecord(ev_join, ss));
     // ---- conv block 0 -------------------------------------------------------------------------------------------------
     SED_TRY(launch_blk0_forward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
                                 params + P.glu_w[0], params + P.glu_b[0], bn_running + 0, bn_running + C, trk[0], train, upd,
                                 seed_dev, CTXD(L.mom0), CTXD(L.mompart), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), CTXF(L.p[0]),
                                 use_drop ? CTXM(L.mask[0]) : nullptr, nullptr, st));
+    if (have_side) SED_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
     // ---- conv blocks 1, 2 -----------------------------------------------------------------------------------------------
     const size_t so[3] = {0, L.stat1, L.stat2};
     const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};
@@ -178,14 +192,12 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
                                    params + P.w_hh[l][0], params + P.w_hh[l][1], params + P.b_hh[l][0], params + P.b_hh[l][1],
                                    CTXF(L.out[l]), train ? CTXF(L.gates[l]) : nullptr, g.B, g.T3, st));
         } else {
-            // gi[bt][dir][3H] = x W_ih[dir]^T + b_ih[dir]: both directions in one batched launch
-            GemmBatch gb;
-            gb.n_prob = 2; gb.splits = 1; gb.part = nullptr; gb.part_stride = 0;
-            for (int dir = 0; dir < 2; ++dir) {
-                gb.p[dir] = gemm_prob(in, nin, 1, params + P.w_ih[l][dir], 1, nin, CTXF(L.gi[l]) + dir * 3 * H, 6 * H, BT, 3 * H, nin);
-                gb.p[dir].bias = params + P.b_ih[l][dir];
-            }
-            SED_TRY(launch_gemm_batch(gb, st));
+            // gi[bt][dir][3H] = x W_ih[dir]^T + b_ih[dir]: both directions in one launch (ggemm.hip)
+            GntBatch gb;
+            gb.n_prob = 2;
+            for (int dir = 0; dir < 2; ++dir)
+                gb.p[dir] = GntProb{in, nin, params + P.w_ih[l][dir], nin, CTXF(L.gi[l]) + dir * 3 * H, 6 * H, params + P.b_ih[l][dir], BT, 3 * H, nin};
+            SED_TRY(launch_gnt_gemm(gb, st));
             if (cluster)
                 SED_TRY(launch_gclu_fwd(CTXF(L.gi[l]), params + P.w_hh[l][0], params + P.w_hh[l][1], params + P.b_hh[l][0],
                                         params + P.b_hh[l][1], CTXF(L.out[l]), train ? CTXF(L.gates[l]) : nullptr, CTXV(L.xch[l]),
@@ -253,12 +265,12 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
                 else
                     SED_TRY(launch_ggru_bwd(H, d_cur, CTXF(L.out[l]), CTXF(L.gates[l]), CTXF(L.whhT[l]), WSF(W.dgi[l]), WSF(W.dgh[l]),
                                             WSF(W.hprev[l]), g.B, g.T3, st));
-                // dX[bt][i] = sum_dir sum_g dgi[bt][dir][g] W_ih[dir][g][i]: K = 6H, the two W_ih stacked along K
-                GemmBatch gb;
-                gb.n_prob = 1; gb.splits = 1; gb.part = nullptr; gb.part_stride = 0;
-                gb.p[0] = gemm_prob(WSF(W.dgi[l]), 6 * H, 1, params + P.w_ih[l][0], nin, 1, d_in, nin, BT, nin, 6 * H);
-                gb.p[0].B2 = params + P.w_ih[l][1]; gb.p[0].k2 = 3 * H;
-                SED_TRY(launch_gemm_batch(gb, st));
+                // dX[bt][i] = sum_dir sum_g dgi[bt][dir][g] W_ih[dir][g][i]: K = 6H, the two W_ih stacked along K (transposed
+                // copy made by the forward)
+                GntBatch gb;
+                gb.n_prob = 1;
+                gb.p[0] = GntProb{WSF(W.dgi[l]), 6 * H, CTXF(L.wihT[l]), 6 * H, d_in, nin, nullptr, BT, nin, 6 * H};
+                SED_TRY(launch_gnt_gemm(gb, st));
                 d_cur = d_in;
                 d_cur2 = nullptr;
             }

@@ -1,0 +1,107 @@
+// ggemm.hip - C[m][n] = sum_k A[m][k] B[n][k] (+ bias[n]): the "NT" GEMMs of the wide BiGRU - the input projections
+// gi = x W_ih^T + b_ih (baseline/models/RNN.py:12: nn.GRU's first half) and the gradient w.r.t. the layer input
+// dX = [dgi_f | dgi_r] [W_ih_f ; W_ih_r] (with the stacked W_ih transposed once by k_gnt_pack_t) - exact fp32 on the f32 MFMA.
+// gemm.hip's 64 x 64-tile batched kernel served the 192 x 64 .. 128 shapes of the 64-cell GRU; at H = 256 its
+// K-loop (one 64-deep tile per global -> LDS -> MFMA round trip, no overlap) ran at 27 TFLOP/s and the four GEMMs on the
+// critical path of a wide step cost 380 us.  Here: 128 x 128 output tile per workgroup (4 waves x (32 rows x 128 columns),
+// 4 accumulators of 32 x 32), both operands streamed through double-buffered LDS chunks of 32 k, the next chunk's global
+// loads in flight during the current chunk's 64 MFMAs per wave.
+#include "common.h"
+#include "kernels.h"
+#include "gkernels.h"
+
+#define GNT_KC 32
+#define GNT_S (GNT_KC + 1)
+
+__global__ __launch_bounds__(256) void k_gnt_gemm(GntBatch gb) {
+    __shared__ float As[2][128 * GNT_S];
+    __shared__ float Bs[2][128 * GNT_S];
+    const GntProb& d = gb.p[blockIdx.z];
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    if (m0 >= d.M || n0 >= d.N) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 31, kh = lane >> 5;
+    // staging: 128 rows x 32 k = 1024 float4 per operand = 4 per thread: row = u >> 3, k4 = u & 7
+    f32x4 ra[4], rb[4];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int u = tid + 256 * i, row = u >> 3, k4 = u & 7;
+            const int am = min(m0 + row, d.M - 1), bn = min(n0 + row, d.N - 1);      // clamped rows are never stored
+            ra[i] = *(const f32x4*)(d.A + (size_t)am * d.lda + k0 + 4 * k4);
+            rb[i] = *(const f32x4*)(d.B + (size_t)bn * d.ldb + k0 + 4 * k4);
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int u = tid + 256 * i, row = u >> 3, k4 = u & 7;
+            float* a = &As[buf][row * GNT_S + 4 * k4];
+            float* b = &Bs[buf][row * GNT_S + 4 * k4];
+            a[0] = ra[i][0]; a[1] = ra[i][1]; a[2] = ra[i][2]; a[3] = ra[i][3];
+            b[0] = rb[i][0]; b[1] = rb[i][1]; b[2] = rb[i][2]; b[3] = rb[i][3];
+        }
+    };
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int nch = d.K / GNT_KC;
+    load(0);
+    store(0);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+        if (ch + 1 < nch) load((ch + 1) * GNT_KC);
+        const float* ap = &As[ch & 1][(32 * wv + n) * GNT_S + kh];
+        const float* bp = &Bs[ch & 1][n * GNT_S + kh];
+#pragma unroll
+        for (int ks = 0; ks < GNT_KC / 2; ++ks) {
+            const float a = ap[2 * ks];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = mfma32(a, bp[32 * t * GNT_S + 2 * ks], acc[t]);
+        }
+        if (ch + 1 < nch) store((ch + 1) & 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int col = n0 + 32 * t + n;
+        if (col < d.N) {
+            const float bias = d.bias ? d.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 32 * wv + mfma32_row(r, lane);
+                if (row < d.M) d.C[(size_t)row * d.ldc + col] = acc[t][r] + bias;
+            }
+        }
+    }
+}
+
+int launch_gnt_gemm(const GntBatch& gb, hipStream_t st) {
+    int maxM = 0, maxN = 0;
+    for (int i = 0; i < gb.n_prob; ++i) {
+        const GntProb& q = gb.p[i];
+        SED_CHECK_ARG(q.K % GNT_KC == 0 && q.lda % 4 == 0 && q.ldb % 4 == 0 && ((uintptr_t)q.A % 16) == 0 && ((uintptr_t)q.B % 16) == 0,
+                      "gnt gemm: K must be a multiple of 32 and the operands 16-byte aligned");
+        maxM = q.M > maxM ? q.M : maxM;
+        maxN = q.N > maxN ? q.N : maxN;
+    }
+    k_gnt_gemm<<<dim3((maxN + 127) / 128, (maxM + 127) / 128, gb.n_prob), 256, 0, st>>>(gb);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}
+
+// out[n][dir * R + k] = w_dir[k][n]  (R rows, N columns each): the two W_ih stacked along K and transposed, so that the
+// dX GEMM reads it k-contiguous
+__global__ __launch_bounds__(256) void k_gnt_pack_t(const float* __restrict__ w0, const float* __restrict__ w1, float* __restrict__ out,
+                                                     int R, int N) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * R * N) return;
+    const int dir = i / (R * N), e = i % (R * N), k = e / N, nn = e % N;
+    out[(size_t)nn * 2 * R + dir * R + k] = (dir ? w1 : w0)[e];
+}
+int launch_gnt_pack_t(const float* w0, const float* w1, float* out, int R, int N, hipStream_t st) {
+    k_gnt_pack_t<<<(2 * R * N + 255) / 256, 256, 0, st>>>(w0, w1, out, R, N);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}

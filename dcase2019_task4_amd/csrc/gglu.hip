@@ -200,20 +200,25 @@ int launch_gglu_fwd(int mode, int C, const float* y, const GBnArgs& bn, const vo
 // would not fit next to the weight chunks at C = 128).
 //   P1  lin[:, half] = xhat @ wg^T (recomputed)        epilogue: sigma, dlin = g sigma -> LDS, gate path dzg
 //   P2  dzl[:, half] = dlin @ Wglu                      epilogue: dz = dzl + dzg -> HBM, sums of dz and dz * xhat
-//   P3  dWx[co][c] += sum_p dlin[p][co] xhat[p][c]      contraction over the round's 64 PIXELS: fp32 MFMA on the natural
-//       [pixel][channel] tiles in both modes (gconv.hip wgrad note); wave w owns (C / 32)^2 / 4 tiles of 32 x 32
+//   P3  dWx[co][c] += sum_p dlin[p][co] xhat[p][c]      contraction over the round's 64 PIXELS; wave w owns (C / 32)^2 / 4
+//       tiles of 32 x 32.  fp32 mode: f32 MFMA on the natural [pixel][channel] tiles.  bf16 mode: both operands are
+//       needed pixel-contiguous - the P1 epilogue holds 4 consecutive pixels of one channel per lane (D layout), so it
+//       writes dlinT / xhatT [channel][pixel] as 8-byte bf16 groups for free (the fp32 P3 was 8 192 of the 10 240 MFMA
+//       cycles of a round)
 // Per-workgroup partial sums (dWx, sum dlin, sum dz, sum dz xhat) go to `part`; k_gbn_bwd_prep adds them in fixed order.
 template <int MODE, int C>
 struct GGluBwdCfg {
     using M = MM<MODE>;
     static constexpr int KC = (MODE == 0 && C == 128) ? 16 : M::KC;        // fp32 at C = 128: smaller weight chunks, LDS budget
     static constexpr int XS = C + 1, BS = C + M::PAD;
+    static constexpr int TS = 64 + 8;                                      // bf16 mode: row stride of the pixel-contiguous tiles
     static constexpr size_t XF_BYTES = (size_t)2 * 32 * XS * 4;            // xhat fp32, 2 row blocks
-    static constexpr size_t DF_BYTES = XF_BYTES;                           // dlin fp32
+    static constexpr size_t DF_BYTES = MODE == 0 ? XF_BYTES : 0;           // dlin fp32 (P3 operand of the fp32 mode)
     static constexpr size_t XB_BYTES = MODE == 1 ? (size_t)2 * 32 * BS * 2 : 0;
     static constexpr size_t DB_BYTES = XB_BYTES;
+    static constexpr size_t TT_BYTES = MODE == 1 ? (size_t)2 * C * TS * 2 : 0;    // dlinT | xhatT: [C][64 pixels] bf16 (P3 operands)
     static constexpr size_t WBUF_BYTES = (size_t)2 * C * (KC + M::PAD) * sizeof(typename M::E);
-    static constexpr size_t LDS_BYTES = XF_BYTES + DF_BYTES + XB_BYTES + DB_BYTES + WBUF_BYTES + 2 * C * 4 + 64;
+    static constexpr size_t LDS_BYTES = XF_BYTES + DF_BYTES + XB_BYTES + DB_BYTES + TT_BYTES + WBUF_BYTES + 2 * C * 4 + 64;
 };
 
 template <int MODE, int C>
@@ -233,7 +238,10 @@ __global__ __launch_bounds__(256) void k_gglu_bwd(const float* __restrict__ y, c
     float* df_all = (float*)(gsm + Cfg::XF_BYTES);
     E* xb_all = (E*)(gsm + Cfg::XF_BYTES + Cfg::DF_BYTES);
     E* db_all = (E*)(gsm + Cfg::XF_BYTES + Cfg::DF_BYTES + Cfg::XB_BYTES);
-    E* wbuf = (E*)(gsm + Cfg::XF_BYTES + Cfg::DF_BYTES + Cfg::XB_BYTES + Cfg::DB_BYTES);
+    __bf16* dlT = (__bf16*)(gsm + Cfg::XF_BYTES + Cfg::DF_BYTES + Cfg::XB_BYTES + Cfg::DB_BYTES);
+    __bf16* xhT = dlT + C * Cfg::TS;
+    E* wbuf = (E*)(gsm + Cfg::XF_BYTES + Cfg::DF_BYTES + Cfg::XB_BYTES + Cfg::DB_BYTES + Cfg::TT_BYTES);
+    constexpr int TS = Cfg::TS;
     float* bn_s = (float*)((unsigned char*)wbuf + Cfg::WBUF_BYTES);
     const E* wg = (const E*)wg_v;
     const E* wgT = (const E*)wgT_v;
@@ -326,6 +334,7 @@ __global__ __launch_bounds__(256) void k_gglu_bwd(const float* __restrict__ y, c
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) {
             const int c = 32 * (nb0 + nb) + n;
+            float dl4[4], xh4[4];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma32_row(r, lane);
@@ -333,8 +342,18 @@ __global__ __launch_bounds__(256) void k_gglu_bwd(const float* __restrict__ y, c
                 const float sg = sigmoidf_fast(fmaf(gam[nb], xh, bet[nb]));
                 const float gg = ((mk[nb] >> r) & 1u) ? gq[nb][r >> 2] : 0.f;
                 const float dl = gg * sg;
-                dfl[row * XS + c] = dl;
-                if (MODE == 1) dbl[row * BS + c] = M::cvt(dl);
+                if (MODE == 0) dfl[row * XS + c] = dl;
+                if (MODE == 1) {
+                    dbl[row * BS + c] = M::cvt(dl);
+                    dl4[r & 3] = dl; xh4[r & 3] = xh;
+                    if ((r & 3) == 3) {     // rows row - 3 .. row are 4 consecutive pixels of this row block: one 8-byte group
+                        const int p0 = 32 * g + row - 3;
+                        bf16x4 vd = {(__bf16)dl4[0], (__bf16)dl4[1], (__bf16)dl4[2], (__bf16)dl4[3]};
+                        bf16x4 vx = {(__bf16)xh4[0], (__bf16)xh4[1], (__bf16)xh4[2], (__bf16)xh4[3]};
+                        *(bf16x4*)(dlT + c * TS + p0) = vd;
+                        *(bf16x4*)(xhT + c * TS + p0) = vx;
+                    }
+                }
                 sdb[nb] += dl;
                 dzg[nb][r] = dl * (1.0f - sg) * (acc[nb][r] + bgl[nb]);
             }
@@ -368,8 +387,20 @@ __global__ __launch_bounds__(256) void k_gglu_bwd(const float* __restrict__ y, c
                 }
             }
         }
-        // ---- P3: dWx[co][c] += sum over the round's 64 pixels of dlin[p][co] xhat[p][c] (fp32 MFMA) ----------------------
-        {
+        // ---- P3: dWx[co][c] += sum over the round's 64 pixels of dlin[p][co] xhat[p][c] ----------------------------------
+        if (MODE == 1) {
+            const __bf16* Ap = dlT + (32 * cob + n) * TS + 8 * kh;       // A[i = co][k = p .. p + 7]
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 a = *(const bf16x8*)(Ap + 16 * ks);
+                if (C == 64) {
+                    dW[0] = MM<1>::mma(a, *(const bf16x8*)(xhT + (32 * (wv & 1) + n) * TS + 16 * ks + 8 * kh), dW[0]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) dW[t] = MM<1>::mma(a, *(const bf16x8*)(xhT + (32 * t + n) * TS + 16 * ks + 8 * kh), dW[t]);
+                }
+            }
+        } else {
             const float* Ap = df_all + 32 * cob + n;          // A[i = co][k = p]
 #pragma unroll 4
             for (int s = 0; s < 32; ++s) {

@@ -64,6 +64,12 @@ int launch_gclu_fwd(const float* gi, const float* w_hh_f, const float* w_hh_r, c
 int launch_gclu_bwd(const float* d_out, const float* out, const float* gates, const float* w_hh_f, const float* w_hh_r, float* dgi,
                     float* dgh, float* hprev, void* xch, unsigned int* epoch, int* err, int B, int T, hipStream_t st);
 
+// ggemm.hip: C[m][n] = sum_k A[m][k] B[n][k] + bias[n], exact fp32, 128 x 128 tiles; K % 32 == 0
+struct GntProb { const float* A; int lda; const float* B; int ldb; float* C; int ldc; const float* bias; int M, N, K; };
+struct GntBatch { GntProb p[2]; int n_prob; };
+int launch_gnt_gemm(const GntBatch& gb, hipStream_t st);
+int launch_gnt_pack_t(const float* w0, const float* w1, float* out, int R, int N, hipStream_t st);
+
 // gcrnn.hip ---------------------------------------------------------------------------------------------------------------
 struct HeadsLoss;
 int launch_gen_add2(float* dst, const float* src, size_t n, hipStream_t st);
@@ -72,7 +78,7 @@ size_t gen_ws_bytes(const Geo& g);
 int gen_ctx_view(const Geo& g, const char* name, size_t* offset, size_t* bytes);
 int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_running, int64_t* bn_tracked, const float* x,
                 int train, int update_bn, const uint64_t* seed_dev, void* ctx, size_t ctx_bytes, float* strong, float* weak,
-                hipStream_t st);
+                hipStream_t st, hipStream_t ss, hipEvent_t ev_fork, hipEvent_t ev_join);
 int gen_backward(const Geo& g, const ParamOff& P, const float* params, const float* x, const uint64_t* seed_dev, void* ctx,
                  size_t ctx_bytes, const float* d_strong, const float* d_weak, float* grads, void* ws, size_t ws_bytes, int parts,
                  hipStream_t st, hipStream_t ss, hipEvent_t ev_fork, hipEvent_t ev_join, const HeadsLoss* hl);

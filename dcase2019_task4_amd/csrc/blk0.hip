@@ -465,51 +465,53 @@ struct Blk0BwdFinArgs {
     float *g_w0, *g_b0, *g_gamma, *g_beta, *g_wglu, *g_bglu;
     int C;
 };
+// grid = C / 16 workgroups; workgroup w owns channels [16 w, 16 w + 16): their rows of dWglu, their rows of S and their
+// per-channel results (one workgroup doing all of it took 104 us at C = 128, at the very end of the step)
 __global__ __launch_bounds__(640) void k_blk0_bwd_finalize(Blk0BwdFinArgs a) {
     __shared__ double wzs[128][10];
     __shared__ double Ds[128][10];
-    __shared__ double Ss[128][10];
-    const int tid = threadIdx.x, C = a.C;
+    __shared__ double Ss[16][10];
+    __shared__ double moms[54];
+    const int tid = threadIdx.x, C = a.C, c0 = blockIdx.x * 16;
     for (int e = tid; e < C * 10; e += 640) {   // (c, t)
         const int c = e / 10, t = e % 10;
         const double scale = a.bn[2 * C + c], shift = a.bn[3 * C + c];
         wzs[c][t] = (t < 9) ? scale * (double)a.w0[c * 9 + t] : scale * (double)a.b0[c] + shift;
         Ds[c][t] = a.de[c * 10 + t];
     }
+    if (tid < 54) moms[tid] = a.mom[tid];
     __syncthreads();
-    // GLU linear: dWglu[co][k] = sum_t D[co][t] wz[k][t];  dbglu[co] = D[co][9].  Workgroups 1 .. gridDim.x - 1 share this
-    // C x C loop (at C = 128 the single-workgroup version took 104 us at the very end of the step); workgroup 0 does the rest.
-    if (blockIdx.x > 0) {
-        const int nsl = gridDim.x - 1, sl = blockIdx.x - 1;
-        for (int e = sl * 640 + tid; e < C * C; e += nsl * 640) {
-            const int co = e / C, k = e % C;
-            double acc = 0;
+    // GLU linear: dWglu[co][k] = sum_t D[co][t] wz[k][t] for co in this workgroup's 16 rows;  dbglu[co] = D[co][9]
+    for (int e = tid; e < 16 * C; e += 640) {
+        const int co = c0 + e / C, k = e % C;
+        double acc = 0;
 #pragma unroll
-            for (int t = 0; t < 10; ++t) acc += Ds[co][t] * wzs[k][t];
-            a.g_wglu[e] = (float)acc;
-        }
-        return;
+        for (int t = 0; t < 10; ++t) acc += Ds[co][t] * wzs[k][t];
+        a.g_wglu[(size_t)co * C + k] = (float)acc;
     }
-    for (int e = tid; e < C * 10; e += 640) {   // total dz against the patch: S[c][t] = sum_co Wglu[co][c] D[co][t] + E[c][t]
-        const int c = e / 10, t = e % 10;
-        double acc = a.de[C * 10 + c * 10 + t];
-#pragma unroll 8
-        for (int co = 0; co < C; ++co) acc += (double)a.wglu[co * C + c] * Ds[co][t];
-        Ss[c][t] = acc;
+    // total dz against the patch: S[c][t] = sum_co Wglu[co][c] D[co][t] + E[c][t], 4 threads per (c, t) over co quarters
+    {
+        const int e = tid >> 2, part = tid & 3;        // e < 160
+        const int c = c0 + e / 10, t = e % 10;
+        double acc = 0;
+        for (int co = part; co < C; co += 4) acc += (double)a.wglu[(size_t)co * C + c] * Ds[co][t];
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        if (part == 0) Ss[e / 10][t] = acc + a.de[C * 10 + c * 10 + t];
     }
     __syncthreads();
-    if (tid < C) {
-        const int c = tid;
+    if (tid < 16) {
+        const int cl = tid, c = c0 + cl;
         const double mean = a.bn[c], invstd = a.bn[C + c], scale = a.bn[2 * C + c];
         double w[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) w[t] = a.w0[c * 9 + t];
         const double b = a.b0[c];
         a.g_bglu[c] = (float)Ds[c][9];
-        const double Sdz = Ss[c][9];
+        const double Sdz = Ss[cl][9];
         double Sdzu = b * Sdz;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) Sdzu += w[t] * Ss[c][t];
+        for (int t = 0; t < 9; ++t) Sdzu += w[t] * Ss[cl][t];
         const double Sdzxhat = invstd * (Sdzu - mean * Sdz);
         a.g_beta[c] = (float)Sdz;
         a.g_gamma[c] = (float)Sdzxhat;
@@ -517,11 +519,11 @@ __global__ __launch_bounds__(640) void k_blk0_bwd_finalize(Blk0BwdFinArgs a) {
         // du = scale * (dz - m1 - xhat * m2);  dW0[c][t] = sum_p du P[t]
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            double xhP = (b - mean) * a.mom[t];
+            double xhP = (b - mean) * moms[t];
 #pragma unroll
-            for (int t2 = 0; t2 < 9; ++t2) xhP += w[t2] * a.mom[t2 <= t ? gidx(t2, t) : gidx(t, t2)];
+            for (int t2 = 0; t2 < 9; ++t2) xhP += w[t2] * moms[t2 <= t ? gidx(t2, t) : gidx(t, t2)];
             xhP *= invstd;
-            a.g_w0[c * 9 + t] = (float)(scale * (Ss[c][t] - m1 * a.mom[t] - m2 * xhP));
+            a.g_w0[c * 9 + t] = (float)(scale * (Ss[cl][t] - m1 * moms[t] - m2 * xhP));
         }
         // sum_p du = scale * (Sdz - N m1 - m2 * sum xhat) = 0: a conv bias in front of a train-mode BN
         a.g_b0[c] = 0.f;
@@ -580,7 +582,7 @@ int launch_blk0_backward(const Geo& g, const float* x, const float* w0, const fl
     a.w0 = w0; a.b0 = b0; a.gamma = gamma; a.beta = beta; a.wglu = wglu; a.bn = bn; a.mom = mom; a.de = de;
     a.N = (double)g.B * g.T * g.F;
     a.g_w0 = g_w0; a.g_b0 = g_b0; a.g_gamma = g_gamma; a.g_beta = g_beta; a.g_wglu = g_wglu; a.g_bglu = g_bglu; a.C = g.C;
-    k_blk0_bwd_finalize<<<1 + (g.C * g.C + 2559) / 2560, 640, 0, st>>>(a);
+    k_blk0_bwd_finalize<<<g.C / 16, 640, 0, st>>>(a);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

@@ -180,7 +180,8 @@ extern "C" int sed_crnn_ctx_view(const sed_dims* d, const char* name, size_t* of
 // by sed_stream_prepare(stream).
 struct SideStream {
     hipStream_t s = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;          // backward
+    hipEvent_t ffork = nullptr, fjoin = nullptr;        // forward (a pair of its own: one captured graph holds both)
     bool ok = false;
 };
 static std::mutex g_side_mu;
@@ -197,7 +198,9 @@ static SideStream& side_stream(hipStream_t caller) {
         // CUs, made the replayed step 70 % slower - 1.79 vs 1.06 ms)
         if (hipStreamCreateWithFlags(&slot->s, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&slot->fork, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&slot->join, hipEventDisableTiming) == hipSuccess)
+            hipEventCreateWithFlags(&slot->join, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&slot->ffork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&slot->fjoin, hipEventDisableTiming) == hipSuccess)
             slot->ok = true;
     }
     return *slot;
@@ -239,7 +242,7 @@ extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* b
         hipStream_t st0 = (hipStream_t)stream;
         SideStream& sd0 = side_stream(st0);
         return gen_forward(g, P, params, bn_running, bn_tracked, x, train, update_bn, seed_dev, ctx, ctx_bytes, strong, weak, st0,
-                           sd0.ok ? sd0.s : st0, sd0.fork, sd0.join);
+                           sd0.ok ? sd0.s : st0, sd0.ffork, sd0.fjoin);
     }
     const CtxLayout L = make_ctx_layout(g);
     if (ctx_bytes < L.total) {

@@ -146,13 +146,11 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
     pk.bg1 = CTXF(L.bg[1]); pk.bg2 = CTXF(L.bg[2]);
     pk.zero = CTXD(L.stat1); pk.n_zero = train ? 4 * C : 0;
     pk.err = (int*)CTXV(L.err);
-    // the packing is independent of block 0: it runs on the helper stream next to k_x_moments / k_blk0_prep / k_blk0_fwd
-    // and is joined in front of conv1 (25 + 7 us off the head of every forward)
-    const bool have_side = (ss != st);
-    if (have_side) {
-        SED_CHECK_HIP(hipEventRecord(ev_fork, st));
-        SED_CHECK_HIP(hipStreamWaitEvent(ss, ev_fork, 0));
-    }
+    // (The packing is independent of block 0, but forking it onto the helper stream is not an option: a forward that
+    // itself runs on a forked stream - the teacher's, next to the student's - would fork a second time inside the same
+    // hipGraph capture, and ROCm 7.0's hipStreamEndCapture segfaults on that nested fork.  It stays on the caller's stream.)
+    (void)ev_fork; (void)ev_join;
+    ss = st;
     SED_TRY(launch_gen_pack(pk, g.mode, ss));
     // (debug bit 10: the streaming recurrence kernels instead of the cluster ones - A/B timing)
     const bool cluster = (H == 256) && !(g_sed_debug & 1024);
@@ -162,13 +160,12 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
     if (H != 64 && train)
         for (int l = 0; l < g.L; ++l)
             SED_TRY(launch_gnt_pack_t(params + P.w_ih[l][0], params + P.w_ih[l][1], CTXF(L.wihT[l]), 3 * H, l == 0 ? C : 2 * H, ss));
-    if (have_side) SED_CHECK_HIP(hipEventRecord(ev_join, ss));
+
     // ---- conv block 0 -------------------------------------------------------------------------------------------------
     SED_TRY(launch_blk0_forward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
                                 params + P.glu_w[0], params + P.glu_b[0], bn_running + 0, bn_running + C, trk[0], train, upd,
                                 seed_dev, CTXD(L.mom0), CTXD(L.mompart), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), CTXF(L.p[0]),
                                 use_drop ? CTXM(L.mask[0]) : nullptr, nullptr, st));
-    if (have_side) SED_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
     // ---- conv blocks 1, 2 -----------------------------------------------------------------------------------------------
     const size_t so[3] = {0, L.stat1, L.stat2};
     const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};

@@ -3,28 +3,31 @@
 // dX = [dgi_f | dgi_r] [W_ih_f ; W_ih_r] (with the stacked W_ih transposed once by k_gnt_pack_t) - exact fp32 on the f32 MFMA.
 // gemm.hip's 64 x 64-tile batched kernel served the 192 x 64 .. 128 shapes of the 64-cell GRU; at H = 256 its
 // K-loop (one 64-deep tile per global -> LDS -> MFMA round trip, no overlap) ran at 27 TFLOP/s and the four GEMMs on the
-// critical path of a wide step cost 380 us.  Here: 128 x 128 output tile per workgroup (4 waves x (32 rows x 128 columns),
-// 4 accumulators of 32 x 32), both operands streamed through double-buffered LDS chunks of 32 k, the next chunk's global
-// loads in flight during the current chunk's 64 MFMAs per wave.
+// critical path of a wide step cost 380 us.  Here: the same 64 x 64 output tile per workgroup (the shapes are too small for
+// more: 1 872 x 512 x 1 536 is 240 such tiles, 60 at 128 x 128 - measured 123 us on a quarter of the chip), but both
+// operands stream through DOUBLE-BUFFERED LDS chunks of 32 k - the next chunk's global loads are in flight during the
+// current chunk's MFMAs - and 34 KB of LDS per workgroup leaves room for 4 workgroups per CU.
 #include "common.h"
 #include "kernels.h"
 #include "gkernels.h"
 
 #define GNT_KC 32
 #define GNT_S (GNT_KC + 1)
+#define GNT_T 64          // output tile: 64 x 64 per workgroup, one 32 x 32 accumulator per wave
 
 __global__ __launch_bounds__(256) void k_gnt_gemm(GntBatch gb) {
-    __shared__ float As[2][128 * GNT_S];
-    __shared__ float Bs[2][128 * GNT_S];
+    __shared__ float As[2][GNT_T * GNT_S];
+    __shared__ float Bs[2][GNT_T * GNT_S];
     const GntProb& d = gb.p[blockIdx.z];
-    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int m0 = blockIdx.y * GNT_T, n0 = blockIdx.x * GNT_T;
     if (m0 >= d.M || n0 >= d.N) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 31, kh = lane >> 5;
-    // staging: 128 rows x 32 k = 1024 float4 per operand = 4 per thread: row = u >> 3, k4 = u & 7
-    f32x4 ra[4], rb[4];
+    const int wm = wv >> 1, wn = wv & 1;
+    // staging: 64 rows x 32 k = 512 float4 per operand = 2 per thread: row = u >> 3, k4 = u & 7
+    f32x4 ra[2], rb[2];
     auto load = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2; ++i) {
             const int u = tid + 256 * i, row = u >> 3, k4 = u & 7;
             const int am = min(m0 + row, d.M - 1), bn = min(n0 + row, d.N - 1);      // clamped rows are never stored
             ra[i] = *(const f32x4*)(d.A + (size_t)am * d.lda + k0 + 4 * k4);
@@ -33,7 +36,7 @@ __global__ __launch_bounds__(256) void k_gnt_gemm(GntBatch gb) {
     };
     auto store = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2; ++i) {
             const int u = tid + 256 * i, row = u >> 3, k4 = u & 7;
             float* a = &As[buf][row * GNT_S + 4 * k4];
             float* b = &Bs[buf][row * GNT_S + 4 * k4];
@@ -41,38 +44,29 @@ __global__ __launch_bounds__(256) void k_gnt_gemm(GntBatch gb) {
             b[0] = rb[i][0]; b[1] = rb[i][1]; b[2] = rb[i][2]; b[3] = rb[i][3];
         }
     };
-    f32x16 acc[4];
+    f32x16 acc;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int nch = d.K / GNT_KC;
     load(0);
     store(0);
     __syncthreads();
     for (int ch = 0; ch < nch; ++ch) {
         if (ch + 1 < nch) load((ch + 1) * GNT_KC);
-        const float* ap = &As[ch & 1][(32 * wv + n) * GNT_S + kh];
-        const float* bp = &Bs[ch & 1][n * GNT_S + kh];
+        const float* ap = &As[ch & 1][(32 * wm + n) * GNT_S + kh];
+        const float* bp = &Bs[ch & 1][(32 * wn + n) * GNT_S + kh];
 #pragma unroll
-        for (int ks = 0; ks < GNT_KC / 2; ++ks) {
-            const float a = ap[2 * ks];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = mfma32(a, bp[32 * t * GNT_S + 2 * ks], acc[t]);
-        }
+        for (int ks = 0; ks < GNT_KC / 2; ++ks) acc = mfma32(ap[2 * ks], bp[2 * ks], acc);
         if (ch + 1 < nch) store((ch + 1) & 1);
         __syncthreads();
     }
+    const int col = n0 + 32 * wn + n;
+    if (col < d.N) {
+        const float bias = d.bias ? d.bias[col] : 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int col = n0 + 32 * t + n;
-        if (col < d.N) {
-            const float bias = d.bias ? d.bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + 32 * wv + mfma32_row(r, lane);
-                if (row < d.M) d.C[(size_t)row * d.ldc + col] = acc[t][r] + bias;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + 32 * wm + mfma32_row(r, lane);
+            if (row < d.M) d.C[(size_t)row * d.ldc + col] = acc[r] + bias;
         }
     }
 }
@@ -86,7 +80,7 @@ int launch_gnt_gemm(const GntBatch& gb, hipStream_t st) {
         maxM = q.M > maxM ? q.M : maxM;
         maxN = q.N > maxN ? q.N : maxN;
     }
-    k_gnt_gemm<<<dim3((maxN + 127) / 128, (maxM + 127) / 128, gb.n_prob), 256, 0, st>>>(gb);
+    k_gnt_gemm<<<dim3((maxN + GNT_T - 1) / GNT_T, (maxM + GNT_T - 1) / GNT_T, gb.n_prob), 256, 0, st>>>(gb);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

@@ -409,8 +409,19 @@ __global__ __launch_bounds__(GCL_THREADS) void k_gclu_bwd(const float* __restric
             if (s + 1 < T) {
                 const int src = (wg + wave) & 3;
                 const unsigned long long* px = xc + (size_t)slot * 3 * H + U * src + lane;
-                const float v0 = gcl_collect(px, tag, err), v1 = gcl_collect(px + H, tag, err), v2 = gcl_collect(px + 2 * H, tag, err);
-                ds[U * src + lane] = v0; ds[H + U * src + lane] = v1; ds[2 * H + U * src + lane] = v2;
+                // the three granules of a unit are polled TOGETHER (three loads in flight per round trip, not three round trips)
+                unsigned long long g0, g1, g2;
+                int it = 0;
+                do {
+                    g0 = __hip_atomic_load(px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    g1 = __hip_atomic_load(px + H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    g2 = __hip_atomic_load(px + 2 * H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint32_t)(g0 >> 32) == tag && (uint32_t)(g1 >> 32) == tag && (uint32_t)(g2 >> 32) == tag) break;
+                    __builtin_amdgcn_s_sleep(1);
+                } while (++it < GCL_SPIN_LIMIT);
+                if (it >= GCL_SPIN_LIMIT) *err = 1;
+                ds[U * src + lane] = __uint_as_float((uint32_t)g0); ds[H + U * src + lane] = __uint_as_float((uint32_t)g1);
+                ds[2 * H + U * src + lane] = __uint_as_float((uint32_t)g2);
             }
         } else {
             if (s > 0) {

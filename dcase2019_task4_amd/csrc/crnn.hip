@@ -181,7 +181,8 @@ extern "C" int sed_crnn_ctx_view(const sed_dims* d, const char* name, size_t* of
 struct SideStream {
     hipStream_t s = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;          // backward
-    hipEvent_t ffork = nullptr, fjoin = nullptr;        // forward (a pair of its own: one captured graph holds both)
+    hipStream_t s2 = nullptr;                           // second helper: the GRU / heads weight-gradient GEMMs
+    hipEvent_t join2 = nullptr;
     bool ok = false;
 };
 static std::mutex g_side_mu;
@@ -199,8 +200,8 @@ static SideStream& side_stream(hipStream_t caller) {
         if (hipStreamCreateWithFlags(&slot->s, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&slot->fork, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&slot->join, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&slot->ffork, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&slot->fjoin, hipEventDisableTiming) == hipSuccess)
+            hipStreamCreateWithFlags(&slot->s2, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&slot->join2, hipEventDisableTiming) == hipSuccess)
             slot->ok = true;
     }
     return *slot;
@@ -242,7 +243,7 @@ extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* b
         hipStream_t st0 = (hipStream_t)stream;
         SideStream& sd0 = side_stream(st0);
         return gen_forward(g, P, params, bn_running, bn_tracked, x, train, update_bn, seed_dev, ctx, ctx_bytes, strong, weak, st0,
-                           sd0.ok ? sd0.s : st0, sd0.ffork, sd0.fjoin);
+                           sd0.ok ? sd0.s : st0, sd0.fork, sd0.join);
     }
     const CtxLayout L = make_ctx_layout(g);
     if (ctx_bytes < L.total) {
@@ -312,7 +313,7 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
         hipStream_t st0 = (hipStream_t)stream;
         SideStream& sd0 = side_stream(st0);
         return gen_backward(g, P, params, x, seed_dev, ctx, ctx_bytes, d_strong, d_weak, grads, ws, ws_bytes, parts, st0,
-                            sd0.ok ? sd0.s : st0, sd0.fork, sd0.join, hl);
+                            sd0.ok ? sd0.s : st0, sd0.fork, sd0.join, sd0.ok ? sd0.s2 : nullptr, sd0.join2, hl);
     }
     const CtxLayout L = make_ctx_layout(g);
     const WsLayout W = make_ws_layout(g);
@@ -327,7 +328,7 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
     SideStream& sd = side_stream(st);
     hipStream_t ss = sd.ok ? sd.s : st;       // without a side stream everything stays on the caller's
     const bool defer_gru_w = (parts & 4) != 0;           // parts == 5: the caller runs them later (parts == 8)
-    bool forked = false;
+    bool forked = false, forked2 = false;
 
     if (parts & 1) {
     // ---- heads ----------------------------------------------------------------------------------
@@ -432,8 +433,17 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
                 // the head weight-gradient column sum (deferred from part 1): behind wgrad2, long before the tail of the step
                 // (queued right in front of wgrad1 it sat 60 us behind the persistent dgrad kernel and held wgrad1 back; at
                 // the very end of the side stream it was 4 us on the step's tail)
-                if (sd.ok) SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, ss));
-                SED_TRY(gru_weight_grads(ss));
+                // ... on a helper stream of their OWN: queued on the conv-wgrad helper they sat between wgrad2 and wgrad1 and
+                // held wgrad1 - the tail of the step - back by ~80 us (r02_a step timeline: wgrad1 started at 678 us although
+                // its inputs were ready at 594 us)
+                hipStream_t sg = ss;
+                if (sd.ok && !(g_sed_debug & 2048)) {
+                    SED_CHECK_HIP(hipStreamWaitEvent(sd.s2, sd.fork, 0));
+                    sg = sd.s2;
+                    forked2 = true;
+                }
+                if (sd.ok) SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, sg));
+                SED_TRY(gru_weight_grads(sg));
             }
             SED_TRY(launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], pp, st));
         } else {
@@ -449,6 +459,10 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
                                  WSF(W.dp0), WSD(W.de0), 0, grads + P.conv_w[0], grads + P.conv_b[0], grads + P.bn_g[0],
                                  grads + P.bn_b[0], grads + P.glu_w[0], grads + P.glu_b[0], st));
     if (forked) SIDE_JOIN(st);
+    if (forked2) {
+        SED_CHECK_HIP(hipEventRecord(sd.join2, sd.s2));
+        SED_CHECK_HIP(hipStreamWaitEvent(st, sd.join2, 0));
+    }
     return SED_OK;
 }
 

@@ -216,7 +216,8 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
 // Backward.  `side`: the helper stream of the caller's stream (fork / join events owned by crnn.hip), or the caller's own.
 int gen_backward(const Geo& g, const ParamOff& P, const float* params, const float* x, const uint64_t* seed_dev, void* ctx,
                  size_t ctx_bytes, const float* d_strong, const float* d_weak, float* grads, void* ws, size_t ws_bytes, int parts,
-                 hipStream_t st, hipStream_t ss, hipEvent_t ev_fork, hipEvent_t ev_join, const HeadsLoss* hl) {
+                 hipStream_t st, hipStream_t ss, hipEvent_t ev_fork, hipEvent_t ev_join, hipStream_t ss2, hipEvent_t ev_join2,
+                 const HeadsLoss* hl) {
     const GCtx L = make_gctx(g);
     const GWs W = make_gws(g);
     if (ctx_bytes < L.total || ws_bytes < W.total) {
@@ -227,7 +228,7 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
     const int use_drop = (g.p > 0.f) ? 1 : 0;
     const bool have_side = (ss != st);
     const bool defer_gru_w = (parts & 4) != 0;
-    bool forked = false;
+    bool forked = false, forked2 = false;
     auto fork = [&]() -> int {
         if (!have_side) return SED_OK;
         SED_CHECK_HIP(hipEventRecord(ev_fork, st));
@@ -318,8 +319,15 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
         SED_TRY(launch_gwgrad(g.mode, C, WSF(W.dz[i]), CTXF(L.y[i]), WSF(W.coef[i]), CTXF(L.p[i - 1]), WSF(W.wg_part), grads + P.conv_w[i], g.B,
                               Hs[i], Wd[i], ss));
         if (i == 2 && parts == 3) {
-            if (have_side) SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, ss, 2 * H));
-            SED_TRY(gru_weight_grads(ss));
+            // on the second helper stream, so that they do not sit in front of wgrad1 on the first (crnn.hip)
+            hipStream_t sg = ss;
+            if (have_side && ss2 != nullptr) {
+                SED_CHECK_HIP(hipStreamWaitEvent(ss2, ev_fork, 0));
+                sg = ss2;
+                forked2 = true;
+            }
+            if (have_side) SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, sg, 2 * H));
+            SED_TRY(gru_weight_grads(sg));
         }
         SED_TRY(launch_gconv_dgrad(g.mode, C, WSF(W.dz[i]), CTXF(L.y[i]), WSF(W.coef[i]), CTXV(L.wpkT[i]), WSF(W.dp[i - 1]), g.B, Hs[i],
                                    Wd[i], st));
@@ -332,6 +340,10 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
     if (forked) {
         SED_CHECK_HIP(hipEventRecord(ev_join, ss));
         SED_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
+    }
+    if (forked2) {
+        SED_CHECK_HIP(hipEventRecord(ev_join2, ss2));
+        SED_CHECK_HIP(hipStreamWaitEvent(st, ev_join2, 0));
     }
     return SED_OK;
 }

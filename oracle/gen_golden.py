@@ -318,8 +318,87 @@ def predictions_():
     print("wrote g9_predictions.npz:", len(df), "events, margin", margin)
 
 
+def wide_():
+    """G10 (BASELINE.json configs[4]): the REAL reference CRNN built with nb_filters = [128] * 3, n_RNN_cell = 256
+    (baseline/models/CNN.py:35-67 and CRNN.py:12-31 are shape-generic): eval posteriors at T = 628, a train-mode forward
+    with its BatchNorm buffers, and two steps of the real main.train (B = 8, T = 216, dropout 0)."""
+    import torch
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    main, cfg, CRNN = import_reference()
+    from oracle import synth
+    C, H = 128, 256
+    kw = dict(cfg.crnn_kwargs)
+    kw.update(nb_filters=[C] * 3, n_RNN_cell=H)
+    kw0 = dict(kw, dropout=0)
+    mk = dict(nb_filters=(C,) * 3, n_RNN_cell=H)
+    save = {}
+    # eval
+    m = CRNN(**kw)
+    load_params(m, synth.make_params(0, **mk), synth_bn(0, (C,) * 3))
+    m.eval()
+    with torch.no_grad():
+        s, w = m(synth.make_input(628, 2, 628))
+    save["eval_strong"], save["eval_weak"] = s.numpy(), w.numpy()
+    # train-mode forward, dropout 0, two passes
+    m = CRNN(**kw0)
+    load_params(m, synth.make_params(0, **mk))
+    m.train()
+    with torch.no_grad():
+        for it in range(2):
+            s, w = m(synth.make_input(10 + it, 4, 216))
+            save[f"train_strong{it}"], save[f"train_weak{it}"] = s.numpy(), w.numpy()
+    for k, v in m.named_buffers():
+        save["tb_" + k.replace(".", "_")] = v.numpy()
+    # two steps of the real main.train
+    B, T = 8, 216
+    student, teacher = CRNN(**kw0), CRNN(**kw0)
+    load_params(student, synth.make_params(0, **mk))
+    load_params(teacher, synth.make_params(1, **mk))
+    for p in teacher.parameters():
+        p.detach_()
+    student.train(); teacher.train()
+    rec = {"grads": [], "meters": []}
+
+    class RecAdam(torch.optim.Adam):
+        def step(self, closure=None):
+            rec["grads"].append([p.grad.detach().clone() for g in self.param_groups for p in g["params"]])
+            return super().step(closure)
+
+    class RecMeters(main.AverageMeterSet):
+        def update(self, name, value, n=1):
+            rec["meters"].append((name, float(value)))
+            return super().update(name, value, n)
+
+    main.AverageMeterSet = RecMeters
+    opt = RecAdam(filter(lambda p: p.requires_grad, student.parameters()), lr=0.001, betas=(0.9, 0.999))
+    batches = []
+    for it in range(2):
+        tgt, wm, sm = synth.make_target(it, B, T // 8)
+        batches.append((synth.make_input(20 + it, B, T), synth.make_input(30 + it, B, T), tgt))
+    main.train(batches, student, opt, 0, ema_model=teacher, weak_mask=wm, strong_mask=sm)
+    names = [n for n, _ in student.named_parameters()]
+    for it in range(2):
+        for n, g in zip(names, rec["grads"][it]):
+            key = n.replace(".", "_")
+            save[f"s{it}_gnorm_{key}"] = np.array(float(g.double().norm()))
+            save[f"s{it}_ghead_{key}"] = g.flatten()[:16].numpy()
+    for mn in sorted(set(n for n, _ in rec["meters"])):
+        save["meter_" + mn.replace(" ", "_")] = np.array([v for n, v in rec["meters"] if n == mn])
+    for n, p in student.named_parameters():
+        save["pS_sum_" + n.replace(".", "_")] = np.array(float(p.detach().double().sum()))
+        save["pS_head_" + n.replace(".", "_")] = p.detach().flatten()[:16].numpy()
+    for n, p in teacher.named_parameters():
+        save["pT_sum_" + n.replace(".", "_")] = np.array(float(p.detach().double().sum()))
+        save["pT_head_" + n.replace(".", "_")] = p.detach().flatten()[:16].numpy()
+    np.savez_compressed(os.path.join(OUT, "g10_wide.npz"), **save)
+    print("wrote g10_wide.npz", len(save), "arrays")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "g9":
+    if len(sys.argv) > 1 and sys.argv[1] == "g10":
+        wide_()
+    elif len(sys.argv) > 1 and sys.argv[1] == "g9":
         predictions_()
     elif len(sys.argv) > 1 and sys.argv[1] == "g8":
         supervised_()
@@ -327,3 +406,4 @@ if __name__ == "__main__":
         main_()
         supervised_()
         predictions_()
+        wide_()

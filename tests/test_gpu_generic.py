@@ -101,7 +101,8 @@ def test_wide_fp32_forward_backward_vs_oracle(B, T, p, C, H):
         np.testing.assert_allclose(r["bn"][k].numpy(), v.numpy(), rtol=3e-5, atol=3e-6, err_msg=k)
 
 
-@pytest.mark.parametrize("B,T,p,C,H", [(4, 128, 0.5, 64, 64), (4, 628, 0.5, 64, 64), (4, 628, 0.5, 128, 256), (8, 216, 0.0, 128, 256)])
+@pytest.mark.parametrize("B,T,p,C,H", [(4, 128, 0.5, 64, 64), (4, 628, 0.5, 64, 64), (24, 628, 0.5, 64, 64), (4, 864, 0.5, 64, 64),
+                                       (4, 628, 0.5, 128, 256), (8, 216, 0.0, 128, 256)])
 def test_bf16_operands_forward_backward_vs_fp32_oracle(B, T, p, C, H):
     """bf16 MFMA operands (fp32 accumulation, fp32 everything else) against the FP32 oracle: the measured error of the
     posteriors and of every gradient is printed and held to BF16_POST_TOL / BF16_GRAD_TOL."""
@@ -141,6 +142,58 @@ def test_generic_eval_forward_vs_oracle(C, H, dtype):
         es, _ = gu.report(f"eval strong {dtype}", s.cpu(), so.detach())
         ew, _ = gu.report(f"eval weak {dtype}", w.cpu(), wo.detach())
         assert s.shape == (B, T // 8, 10) and es < tol and ew < tol
+
+
+def test_wide_crnn_vs_real_reference_goldens(golden_dir):
+    """G10: the HIP path at the wide geometry (fp32) against outputs of the REAL reference CRNN / main.train built with
+    nb_filters = [128] * 3, n_RNN_cell = 256 (oracle/gen_golden.py wide_): eval posteriors at T = 628, train-mode forward +
+    BatchNorm buffers, and two fused steps (meters, parameters of student and EMA teacher)."""
+    from dcase2019_task4_amd.train import MeanTeacherStep
+    g = np.load(os.path.join(golden_dir, "g10_wide.npz"))
+    C, H = 128, 256
+    model, _ = gu.make_model(0, dropout=0.5, C=C, H=H)
+    rs = np.random.RandomState(5000)
+    st = ref_cpu.new_bn_state([C] * 3)
+    for i in range(3):
+        st[f"cnn.cnn.batchnorm{i}.running_mean"] = torch.tensor(rs.normal(0, 0.2, C), dtype=torch.float32)
+        st[f"cnn.cnn.batchnorm{i}.running_var"] = torch.tensor(rs.uniform(0.5, 1.5, C), dtype=torch.float32)
+    gu.set_bn(model, st)
+    model.eval()
+    with torch.no_grad():
+        s, w = model(synth.make_input(628, 2, 628).cuda())
+    es, _ = gu.report("G10 eval strong", s.cpu(), g["eval_strong"])
+    ew, _ = gu.report("G10 eval weak", w.cpu(), g["eval_weak"])
+    assert es < POST_TOL and ew < POST_TOL
+    model, _ = gu.make_model(0, dropout=0, C=C, H=H)
+    model.train()
+    with torch.no_grad():
+        for it in range(2):
+            s, w = model(synth.make_input(10 + it, 4, 216).cuda())
+            assert gu.report(f"G10 train strong{it}", s.cpu(), g[f"train_strong{it}"])[0] < POST_TOL
+            assert gu.report(f"G10 train weak{it}", w.cpu(), g[f"train_weak{it}"])[0] < POST_TOL
+    for k, v in model.named_buffers():
+        np.testing.assert_allclose(v.cpu().numpy(), g["tb_" + k.replace(".", "_")], rtol=3e-5, atol=3e-6, err_msg=k)
+    B, T = 8, 216
+    student, _ = gu.make_model(0, dropout=0, C=C, H=H)
+    teacher, _ = gu.make_model(1, dropout=0, C=C, H=H)
+    student.train(); teacher.train()
+    _, wm, sm = synth.make_target(0, B, T // 8)
+    step = MeanTeacherStep(student, teacher, B, T, 2 * 100 // 2, wm, sm, use_graph=False)
+    key = {"weak_class_loss": "meter_weak_class_loss", "weak_ema_loss": "meter_Weak_EMA_loss", "strong_loss": "meter_Strong_loss",
+           "strong_ema_loss": "meter_Strong_EMA_loss", "cons_strong": "meter_Consistency_strong",
+           "cons_weak": "meter_Consistency_weak", "loss": "meter_Loss"}
+    for it in range(2):
+        tgt, _, _ = synth.make_target(it, B, T // 8)
+        step.step(synth.make_input(20 + it, B, T).cuda(), synth.make_input(30 + it, B, T).cuda(), tgt.cuda())
+        m = step.meters()
+        for k, gk in key.items():
+            assert m[k] == pytest.approx(float(g[gk][it]), rel=1e-4, abs=1e-9), (it, k)
+    for (n, p), (_, pe) in zip(student.named_parameters(), teacher.named_parameters()):
+        k = n.replace(".", "_")
+        tol = 1e-2 if (".conv" in n and n.endswith("bias")) else 3e-5
+        np.testing.assert_allclose(p.detach().flatten()[:16].cpu().numpy(), g["pS_head_" + k], atol=tol, err_msg=n)
+        np.testing.assert_allclose(pe.detach().flatten()[:16].cpu().numpy(), g["pT_head_" + k], atol=tol, err_msg=n)
+        assert float(p.detach().double().sum()) == pytest.approx(float(g["pS_sum_" + k]), abs=tol * p.numel())
 
 
 @pytest.mark.parametrize("use_graph", [False, True])

@@ -103,6 +103,52 @@ def test_three_steps_of_main_train(golden_dir):
             np.testing.assert_allclose(v.numpy(), g[tag + k.replace(".", "_")], rtol=3e-5, atol=atol)
 
 
+def test_g10_wide_crnn_vs_real_reference(golden_dir):
+    """G10 (BASELINE.json configs[4]): the reference CRNN built with nb_filters = [128] * 3, n_RNN_cell = 256 - eval
+    posteriors, a train-mode forward with its BatchNorm buffers, and two steps of the real main.train - pins the
+    oracle's generic restatement at the wide geometry."""
+    g = _load(golden_dir, "g10_wide.npz")
+    C, H = 128, 256
+    mk = dict(nb_filters=(C,) * 3, n_RNN_cell=H)
+    rs = np.random.RandomState(5000)
+    st = ref_cpu.new_bn_state([C] * 3)
+    for i in range(3):
+        st[f"cnn.cnn.batchnorm{i}.running_mean"] = torch.tensor(rs.normal(0, 0.2, C), dtype=torch.float32)
+        st[f"cnn.cnn.batchnorm{i}.running_var"] = torch.tensor(rs.uniform(0.5, 1.5, C), dtype=torch.float32)
+    with torch.no_grad():
+        s, w = ref_cpu.crnn_forward(synth.make_params(0, **mk), synth.make_input(628, 2, 628), False, st)
+    np.testing.assert_allclose(s.numpy(), g["eval_strong"], atol=2e-6)
+    np.testing.assert_allclose(w.numpy(), g["eval_weak"], atol=2e-6)
+    bn = ref_cpu.new_bn_state([C] * 3)
+    with torch.no_grad():
+        for it in range(2):
+            s, w = ref_cpu.crnn_forward(synth.make_params(0, **mk), synth.make_input(10 + it, 4, 216), True, bn)
+            np.testing.assert_allclose(s.numpy(), g[f"train_strong{it}"], atol=3e-6)
+            np.testing.assert_allclose(w.numpy(), g[f"train_weak{it}"], atol=3e-6)
+    for k, v in bn.items():
+        np.testing.assert_allclose(v.numpy(), g["tb_" + k.replace(".", "_")], rtol=2e-5, atol=2e-6)
+    B, T = 8, 216
+    mt = ref_cpu.MeanTeacherOracle(synth.make_params(0, **mk), synth.make_params(1, **mk))
+    for it in range(2):
+        tgt, wm, sm = synth.make_target(it, B, T // 8)
+        meters, grads, _ = mt.step(synth.make_input(20 + it, B, T), synth.make_input(30 + it, B, T), tgt, wm, sm, 2 * 100 // 2)
+        assert meters["loss"] == pytest.approx(g["meter_Loss"][it], rel=2e-5)
+        assert meters["strong_loss"] == pytest.approx(g["meter_Strong_loss"][it], rel=2e-5)
+        assert meters["weak_class_loss"] == pytest.approx(g["meter_weak_class_loss"][it], rel=2e-5)
+        for n, gr in grads.items():
+            key = n.replace(".", "_")
+            gn = float(gr.double().norm())
+            if ".conv" in n and n.endswith("bias"):
+                assert gn < 2e-5
+                continue
+            assert gn == pytest.approx(float(g[f"s{it}_gnorm_{key}"]), rel=5e-4), (it, n)
+    for n in mt.p:
+        key = n.replace(".", "_")
+        tol = 1e-2 if (".conv" in n and n.endswith("bias")) else 2e-5
+        np.testing.assert_allclose(mt.p[n].detach().flatten()[:16].numpy(), g["pS_head_" + key], atol=tol)
+        np.testing.assert_allclose(mt.pe[n].flatten()[:16].numpy(), g["pT_head_" + key], atol=tol)
+
+
 def test_transform_chain_and_scaler(golden_dir):
     """G6: Scaler statistics + noise/log/pad/tensor/normalise chain as run by the reference's own
     DataLoad/Scaler code (dB formula = oracle restatement on both sides)."""

@@ -3,7 +3,8 @@ solo kernel replays): mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 8 ... ) 
 (busy cycles / 32 / GRBM_GUI_ACTIVE).  Usage: python tools/show_pmc.py [--md] > profiles/xxx_pmc_mfma_busy.md"""
 import sqlite3, collections, glob, sys
 res = collections.defaultdict(dict)
-for db in glob.glob('/root/repo/gpurun_out/pmcq_*/r01_results.db'):
+pats = [a for a in sys.argv[1:] if not a.startswith('--')] or ['/root/repo/gpurun_out/pmcq_*/r01_results.db']
+for db in [d for p in pats for d in glob.glob(p)]:
     cur = sqlite3.connect(db).cursor()
     for name, cn, avg, n, dur in cur.execute("select name, counter_name, avg(counter_value), count(*), avg(duration) from pmc_events group by name, counter_name"):
         k = name.split('(')[0]

@@ -38,7 +38,8 @@ def main():
             continue
         print(f"| `{k}` | {n} | {rd / 1e6:.2f} MB | {wr / 1e6:.2f} MB | {(rd + wr) / 1e6:.2f} |")
         js[k] = {"read_bytes": round(rd), "write_bytes": round(wr)}
-    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "pmc_traffic.json"), "w") as fh:
+    out_json = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "pmc_traffic.json")
+    with open(out_json, "w") as fh:
         json.dump(js, fh, indent=1, sort_keys=True)
 
 

@@ -313,7 +313,7 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
         hipStream_t st0 = (hipStream_t)stream;
         SideStream& sd0 = side_stream(st0);
         return gen_backward(g, P, params, x, seed_dev, ctx, ctx_bytes, d_strong, d_weak, grads, ws, ws_bytes, parts, st0,
-                            sd0.ok ? sd0.s : st0, sd0.fork, sd0.join, sd0.ok ? sd0.s2 : nullptr, sd0.join2, hl);
+                            sd0.ok ? sd0.s : st0, sd0.fork, sd0.join, (sd0.ok && (g_sed_debug & 2048)) ? sd0.s2 : nullptr, sd0.join2, hl);
     }
     const CtxLayout L = make_ctx_layout(g);
     const WsLayout W = make_ws_layout(g);
@@ -433,11 +433,13 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
                 // the head weight-gradient column sum (deferred from part 1): behind wgrad2, long before the tail of the step
                 // (queued right in front of wgrad1 it sat 60 us behind the persistent dgrad kernel and held wgrad1 back; at
                 // the very end of the side stream it was 4 us on the step's tail)
-                // ... on a helper stream of their OWN: queued on the conv-wgrad helper they sat between wgrad2 and wgrad1 and
-                // held wgrad1 - the tail of the step - back by ~80 us (r02_a step timeline: wgrad1 started at 678 us although
-                // its inputs were ready at 594 us)
+                // (debug bit 11: on a helper stream of their OWN.  Queued on the conv-wgrad helper they sit between wgrad2 and
+                // wgrad1 and hold wgrad1 - the tail of the step - back by ~80 us (r02_a step timeline: wgrad1 starts at 678 us,
+                // its inputs are ready at 594 us); giving them their own stream measured SLOWER all the same - 0.829 vs
+                // 0.815 ms (fp32), 0.775 vs 0.742 ms (bf16 operands): the step is throughput-bound, a third stream only
+                // takes CUs from the dgrad / block-0 chain.)
                 hipStream_t sg = ss;
-                if (sd.ok && !(g_sed_debug & 2048)) {
+                if (sd.ok && (g_sed_debug & 2048)) {
                     SED_CHECK_HIP(hipStreamWaitEvent(sd.s2, sd.fork, 0));
                     sg = sd.s2;
                     forked2 = true;

@@ -400,7 +400,8 @@ def main():
             "dtype": mfma_dtype, "data": "synthetic",
             "config": {"workload": wl, "global_batch": B * world, "frames": T_FRAMES, "n_mels": N_MELS,
                        "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
-                       "dp_schedule": step.dp_schedule if step.dp else None},
+                       "dp_schedule": step.dp_schedule if step.dp else None,
+                       "dp_collectives": ("captured" if step.dp_capture else "eager") if step.dp else None},
             "loss": round(meters["loss"], 5),
         }
         if dist_info:
@@ -453,10 +454,18 @@ def main():
                 res["feature_path"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline and headline:
             res["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(res), flush=True)
     if pg is not None:
         import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: whatever RCCL / the runtime still hold in C stdio buffers goes first
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":

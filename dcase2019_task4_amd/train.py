@@ -130,13 +130,22 @@ class MeanTeacherStep:
         #   "single": whole backward (parts 3) | ONE all-reduce of the flat gradient buffer | update.  Nothing overlaps.
         #   SED_DP_CAPTURE=1 (RCCL only): the collectives are captured INTO the hipGraph, the whole step is one replay.
         self.dp = process_group is not None and (self.world > 1 or os.environ.get("SED_FORCE_DP") == "1")
-        sched = dp_schedule or os.environ.get("SED_DP_SCHEDULE", "overlap")
-        if sched == "split":
-            sched = "overlap"
-        if sched not in ("overlap", "single"):
-            raise ValueError(f"unknown data-parallel schedule {sched!r}")
-        self.dp_schedule = sched
-        self.dp_capture = self.dp and os.environ.get("SED_DP_CAPTURE") == "1"
+        # Default: the overlap schedule with the collectives CAPTURED into the step's hipGraph when the backend is RCCL and a
+        # trial capture of an all-reduce replays correctly on every rank (one replay per step; measured with a one-rank
+        # RCCL group: 0.836 ms against 0.816 ms without data parallelism, 0.839 ms for "single", and 0.969 ms for the overlap
+        # schedule with EAGER collectives between four graph segments - that one is host-bound: 4 graph launches + 2 async
+        # collectives + stream waits per step).  Otherwise (gloo, or capture not available): "single" with an eager collective.
+        self._cap_stream = torch.cuda.Stream(device=dev)
+        env_cap = os.environ.get("SED_DP_CAPTURE")
+        want = dp_schedule or os.environ.get("SED_DP_SCHEDULE")
+        if want == "split":
+            want = "overlap"
+        if want not in (None, "overlap", "single"):
+            raise ValueError(f"unknown data-parallel schedule {want!r}")
+        self.dp_capture = False
+        if self.dp and use_graph and env_cap != "0" and want != "single":
+            self.dp_capture = (env_cap == "1") or self._collective_capture_works()
+        self.dp_schedule = want or ("overlap" if (self.dp_capture or not self.dp) else "single")
         self._dp_stream = torch.cuda.Stream(device=dev) if self.dp else None
         # train_cnn=False (CRNN.py:18-20, main.py:289-290 filters the optimiser's parameters on requires_grad): the conv
         # blocks' backward is skipped and their gradient stays zero, which makes Adam's update of those entries exactly
@@ -156,7 +165,6 @@ class MeanTeacherStep:
         self._graph_c = None
         self._graph_b = None
         # graphs are captured on a stream of our own whose library helper stream exists BEFORE the capture starts
-        self._cap_stream = torch.cuda.Stream(device=dev)
         for st in (torch.cuda.current_stream(dev), self._cap_stream, self._side, self._dp_stream):
             if st is not None:
                 _lib.check(self.l.sed_stream_prepare(C.c_void_p(st.cuda_stream)), "sed_stream_prepare")
@@ -219,6 +227,34 @@ class MeanTeacherStep:
                                        _lib.stream_ptr()), "sed_adam_ema")
         # (no sed_step_state_advance: the loss / heads-backward kernel of this step already moved the counters on and
         # left the update's own fields derived for this step - sed_mt_loss_backward(advance_state = 1))
+
+    def _collective_capture_works(self):
+        """Trial: capture one all-reduce into a hipGraph, replay it, compare with the eager result; every rank must succeed."""
+        import torch.distributed as dist
+        try:
+            if dist.get_backend(self.pg) != "nccl":
+                return False
+            if self.world == 1:
+                return True          # a one-rank all-reduce is a no-op: nothing to try
+            t = torch.arange(1024, device=self.device, dtype=torch.float32) + self.rank
+            ref = t.clone()
+            dist.all_reduce(ref, group=self.pg)
+            torch.cuda.synchronize(self.device)
+            ok = 1.0
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self._cap_stream):
+                    dist.all_reduce(t, group=self.pg)
+                g.replay()
+                torch.cuda.synchronize(self.device)
+                ok = 1.0 if torch.equal(t, ref) else 0.0
+            except Exception:
+                ok = 0.0
+            flag = torch.tensor([ok], device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+            return bool(flag.item() == 1.0)
+        except Exception:
+            return False
 
     def _folded_seed(self):
         return (self.seed_user + self.rank * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)

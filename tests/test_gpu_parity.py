@@ -543,8 +543,7 @@ def test_data_parallel_schedule_on_rccl_one_rank_matches_single_process(monkeypa
     monkeypatch.setenv("SED_FORCE_DP", "1")
     monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
     monkeypatch.setenv("MASTER_PORT", "29577")
-    if capture:
-        monkeypatch.setenv("SED_DP_CAPTURE", "1")
+    monkeypatch.setenv("SED_DP_CAPTURE", "1" if capture else "0")      # "0": eager collectives between graph segments
     created = not dist.is_initialized()
     if created:
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
@@ -573,6 +572,12 @@ def test_data_parallel_schedule_on_rccl_one_rank_matches_single_process(monkeypa
             for a, b in zip(got[:3], ref[:3]):
                 assert torch.equal(a, b)
             assert got[3] == ref[3]
+        # the default (no schedule named, no override): RCCL -> the trial capture succeeds -> captured overlap schedule
+        monkeypatch.delenv("SED_DP_CAPTURE")
+        s, _ = gu.make_model(0, dropout=0.5)
+        t, _ = gu.make_model(1, dropout=0.5)
+        st = MeanTeacherStep(s, t, B, T, 40, wm, sm, seed=7, process_group=dist.group.WORLD)
+        assert st.dp_capture and st.dp_schedule == "overlap"
     finally:
         if created:
             dist.destroy_process_group()

@@ -29,6 +29,7 @@
 // the split saves - 52 / 61 us (layer 0 / 1) against 42 / 44 us.
 #include "common.h"
 #include "kernels.h"
+#ifdef SED_AB      // superseded by gru4.hip; kept for A/B timing builds (make EXTRA=-DSED_AB)
 
 #define GRU_SB 8
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -432,7 +433,7 @@ template <int NIN> static constexpr size_t gru_fwd_lds() { return (size_t)(64 + 
 static const size_t GRU_BWD_LDS = (size_t)(192 + 2 * GRU_SB * 384 + 2 * GRU_SB * GRU_HS) * sizeof(float);
 
 // x: the layer input [B*T][nin] (the input projection runs inside the kernel)
-int launch_gru_fwd(const float* x, int nin, const float* w_ih_f, const float* w_ih_r, const float* b_ih_f, const float* b_ih_r,
+int launch_gru_fwd_v1(const float* x, int nin, const float* w_ih_f, const float* w_ih_r, const float* b_ih_f, const float* b_ih_r,
                    const float* w_hh_f, const float* w_hh_r, const float* b_hh_f, const float* b_hh_r, float* out, float* gates,
                    int B, int T, hipStream_t st) {
     static bool attr_done = false;
@@ -455,7 +456,7 @@ int launch_gru_fwd(const float* x, int nin, const float* w_ih_f, const float* w_
 
 // dx_planes: [2][B*T][nin] - the two directions' shares of the gradient w.r.t. the layer input (the consumer adds
 // them); d_out2: optional second plane of the upstream gradient (the layer above's dx_planes + B*T*128), or null
-int launch_gru_bwd(const float* d_out, const float* d_out2, const float* out, const float* gates, const float* w_hh_f,
+int launch_gru_bwd_v1(const float* d_out, const float* d_out2, const float* out, const float* gates, const float* w_hh_f,
                    const float* w_hh_r, const float* w_ih_f, const float* w_ih_r, int nin, float* dgi, float* dgh, float* hprev,
                    float* dx_planes, int B, int T, hipStream_t st) {
     static bool attr_done = false;
@@ -477,3 +478,4 @@ int launch_gru_bwd(const float* d_out, const float* d_out2, const float* out, co
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
+#endif  // SED_AB

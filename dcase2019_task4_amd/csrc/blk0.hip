@@ -19,8 +19,10 @@
 #include "philox.h"
 #include "kernels.h"
 
+SED_TS_DEFINE(blk0)
 #define XS_W 66
 #define XS_H 10
+#define FXS_H 6       // forward tile: 2 pooled rows = 4 input rows + halo
 
 __device__ __forceinline__ int gidx(int a, int b) { return 9 + a * 9 - (a * (a - 1)) / 2 + (b - a); }  // a <= b
 
@@ -233,97 +235,176 @@ __device__ __forceinline__ void blk0_load_xs(float* xs, const float* __restrict_
     }
 }
 // ---- forward --------------------------------------------------------------------------------
-// (256, 3): with a register budget below 256 the compiler selects the VGPR form of the MFMAs - with the default budget it
-// put the accumulators in AGPRs and paid 64 v_accvgpr_read per row block (12 % of this VALU-bound kernel's instructions)
-template <int NH>
-__global__ __launch_bounds__(256, (NH == 2 ? 4 : 2)) void k_blk0_fwd(const float* __restrict__ x, const float* __restrict__ wz,
+// Per 32-pixel x 32-channel tile: 10 v_mfma_f32_32x32x2_f32 (lin and z, K = 10: 640 MFMA cycles) and then ~110 VALU
+// instructions on their 2 x 16 results (exp2, rcp, keep bit, pooled FMA).  The two pipes are about equally loaded
+// (rocprof round 2: VALU-pipe time 17.6 us, MFMA-pipe time 14.6 us of 48 us solo) but inside ONE wave they were strictly
+// serial - the epilogue consumes what the MFMAs just produced - so the overlap was left to chance between waves.  Now the
+// wave is software-pipelined: the MFMAs of tile t+1 are issued BEFORE the epilogue of tile t (two accumulator sets), the
+// input tile is double-buffered in LDS (next tile's global loads in flight during the compute, one barrier per tile), and
+// a workgroup tile is 2 pooled rows (two waves per row, two row blocks each: 3 768 tiles at the baseline shape, five full
+// rounds of the persistent grid - 4-row tiles were 2.5 rounds, a 16 % idle tail), and the dropout mode is a template parameter (the run-time flags split the loop body into a dozen basic blocks, which kept
+// the scheduler from interleaving anything).  DROP: 0 none, 1 one keep bit per element (p = 0.5), 2 byte threshold.
+__device__ __forceinline__ float blk0_half_sum(float x) {      // x + (the other half-wave's x), in every lane
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+template <int NH, int DROP, bool SAVE>
+__global__ __launch_bounds__(256, (NH == 2 ? 3 : 2)) void k_blk0_fwd(const float* __restrict__ x, const float* __restrict__ wz,
                                                    const float* __restrict__ wl, float* __restrict__ p0, int B, int T,
-                                                   int H1, int tiles_per_clip, int n_tiles, int use_drop, float p_drop,
+                                                   int H1, int tiles_per_clip, int n_tiles, float p_drop,
                                                    const uint64_t* __restrict__ seed_ptr, uint16_t* __restrict__ mask_out) {
-    __shared__ float xs[XS_H * XS_W];
+    __shared__ float xs[2][FXS_H * XS_W];
     constexpr int C = 32 * NH;
+    constexpr int NT = 2 * NH;                       // MFMA tiles of a wave: (row block g0 + {0, 1}, channel slice h)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
+    TS(0);
     Blk0W<NH> W;
     blk0_load_w<NH>(W, wz, wl, lane);
-    const uint64_t seed = use_drop ? seed_ptr[0] : 0ull;
+    const uint64_t seed = DROP ? seed_ptr[0] : 0ull;
     const uint32_t thr = drop_thresh8(p_drop);
-    const bool one_bit = (thr == 128u);
-    const float keep_scale = use_drop ? drop_scale8(p_drop) : 1.0f;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int b = tile / tiles_per_clip, to0 = (tile % tiles_per_clip) * 4;
-        __syncthreads();
-        blk0_load_xs(xs, x, b, T, 2 * to0, tid);
-        __syncthreads();
-        const int to = to0 + wv;
-        if (to >= H1) continue;
-        // p = 0.5: one Philox draw carries the 16-bit keep fields of 8 consecutive (row block, channel slice) units
-        // u = rb * NH + h (philox.h / gen.h): the 4 row blocks of this pooled row are units [4 NH rb0, 4 NH rb0 + 4 NH), i.e.
-        // NH / 2 whole draws, made here once (C = 64: one draw, exactly philox_stream_1bit of the first version)
-        u32x4 o1[NH / 2];
-#pragma unroll
-        for (int d = 0; d < NH / 2; ++d) {
-            o1[d] = (u32x4){0u, 0u, 0u, 0u};
-            if (use_drop && one_bit)
-                o1[d] = philox_stream(((uint32_t)(b * H1 + to) * (NH / 2) + d) * 64u + (uint32_t)lane, PHILOX_STREAM_1BIT, seed);
+    const float sc = 0.125f * (DROP ? drop_scale8(p_drop) : 1.0f);
+    // input tile: FXS_H rows of 64 contiguous floats, one float4 per thread (96 of the 256); zero rows outside the clip
+    const int xr = tid >> 4, xc4 = tid & 15;
+    auto xs_fetch = [&](int tile) -> float4 {
+        const int b = tile / tiles_per_clip, t = 2 * ((tile % tiles_per_clip) * 2) - 1 + xr;
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (tid < FXS_H * 16 && t >= 0 && t < T) v = *(const float4*)&x[((size_t)b * T + t) * 64 + 4 * xc4];
+        return v;
+    };
+    auto xs_put = [&](float* dst, const float4& v) {
+        if (tid < FXS_H * 16) {
+            float* d = &dst[xr * XS_W + 1 + 4 * xc4];
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
-        for (int g = 0; g < 4; ++g) {
-            // MFMA A operand of this row block: this lane's pixel m, taps 2s + kh (shared by both channel halves)
+    };
+    if (tid < 2 * 2 * FXS_H) xs[tid / (2 * FXS_H)][((tid % (2 * FXS_H)) >> 1) * XS_W + (tid & 1) * 65] = 0.f;   // left / right halo columns
+    int tile = blockIdx.x;
+    if (tile < n_tiles) xs_put(xs[0], xs_fetch(tile));
+    __syncthreads();
+#ifdef SED_TS2
+    TSC(1);
+#else
+    TS(1);
+#endif
+    int ts_k = 2;
+    const int mj = n >> 3, mdt = (n >> 2) & 1, mdf = n & 3;     // this lane's pixel m = n of a row block
+    for (int buf = 0; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
+        const int nxt = tile + gridDim.x;
+        float4 vn = {0.f, 0.f, 0.f, 0.f};
+        if (nxt < n_tiles) vn = xs_fetch(nxt);
+        const int b = tile / tiles_per_clip, to = (tile % tiles_per_clip) * 2 + (wv >> 1), g0 = 2 * (wv & 1);
+        if (to < H1) {
+            const float* xb = xs[buf];
+            // p = 0.5: one Philox draw carries the 16-bit keep fields of 8 consecutive (row block, channel slice) units
+            // u = rb * NH + h (philox.h / gen.h): the 4 row blocks of this pooled row are units [4 NH rb0, 4 NH rb0 + 4 NH),
+            // i.e. NH / 2 whole draws, made here once (C = 64: one draw, exactly philox_stream_1bit of the first version)
+            // (this wave's two row blocks g0, g0 + 1 sit in ONE of them: draw d = 0 at C = 64, d = g0 >> 1 at C = 128)
+            static_assert(NH == 2 || NH == 4, "draw selection below assumes 8 or 16 units per pooled row");
+            const int dsel = (NH == 2) ? 0 : (g0 >> 1);
+            u32x4 o1 = {0u, 0u, 0u, 0u};
+            if (DROP == 1) o1 = philox_stream(((uint32_t)(b * H1 + to) * (NH / 2) + (uint32_t)dsel) * 64u + (uint32_t)lane, PHILOX_STREAM_1BIT, seed);
             float av[5];
-            {
-                const int m = n, j = m >> 3, dt = (m >> 2) & 1, df = m & 3;
-                const int base = (2 * wv + dt) * XS_W + 16 * g + 4 * j + df;
+            // MFMA A operand of row block g: this lane's pixel, taps 2s + kh (shared by the channel slices)
+            auto load_av = [&](int g) {
+                const int base = (2 * (wv >> 1) + mdt) * XS_W + 16 * g + 4 * mj + mdf;
 #pragma unroll
                 for (int s5 = 0; s5 < 5; ++s5) {
                     const int k = 2 * s5 + kh;
-                    av[s5] = (k == 9) ? 1.0f : xs[base + (k / 3) * XS_W + (k % 3)];
+                    av[s5] = (k == 9) ? 1.0f : xb[base + (k / 3) * XS_W + (k % 3)];
                 }
-            }
-            const int q0 = (b * H1 + to) * 16 + 4 * g;
-            // the 32-channel slices one after the other (lin_h and z_h: 2 x 16 accumulator registers live instead of
-            // 2 NH x 16): 4 waves per SIMD instead of 3 for this VALU-bound kernel
+            };
+            f32x16 al[2], az[2];
+            auto mma = [&](int h, int sl) {
 #pragma unroll
-            for (int h = 0; h < NH; ++h) {
-                f32x16 al, az;
+                for (int r = 0; r < 16; ++r) { al[sl][r] = 0.f; az[sl][r] = 0.f; }
+#ifdef BLK0_EXP_NOMMA       // timing experiments only (tools/build_variant.sh): results are garbage
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { al[r] = 0.f; az[r] = 0.f; }
+                for (int r = 0; r < 16; ++r) { al[sl][r] = av[r % 5] * W.bw[r % 5][h]; az[sl][r] = av[r % 5] * W.bw[r % 5][NH + h]; }
+#else
 #pragma unroll
                 for (int s5 = 0; s5 < 5; ++s5) {
-                    al = mfma32(av[s5], W.bw[s5][h], al);
-                    az = mfma32(av[s5], W.bw[s5][NH + h], az);
+                    al[sl] = mfma32(av[s5], W.bw[s5][h], al[sl]);
+                    az[sl] = mfma32(av[s5], W.bw[s5][NH + h], az[sl]);
                 }
+#endif
+            };
+            auto epilogue = [&](int g, int h, const f32x16& l16, const f32x16& z16) {
                 const int c = 32 * h + n;
+                const int q0 = (b * H1 + to) * 16 + 4 * g;
                 float pooled[4] = {0.f, 0.f, 0.f, 0.f};
-                if (use_drop) {
+#ifdef BLK0_EXP_NOEPI
+#pragma unroll
+                for (int r = 0; r < 16; r += 4) pooled[r >> 2] = l16[r] + z16[r] + l16[r + 1] + z16[r + 1] + l16[r + 2] + z16[r + 2] + l16[r + 3] + z16[r + 3];
+#else
+                if (DROP) {
                     uint32_t m16;
-                    if (one_bit) {
+                    if (DROP == 1) {
                         // local unit g * NH + h: draw (g * NH + h) >> 3, field (g * NH + h) & 7
-                        if (NH == 2) m16 = philox_field16(o1[0], 2 * g + h);
-                        else m16 = philox_field16((g >> 1) ? o1[NH / 2 - 1] : o1[0], 4 * (g & 1) + h);
+                        m16 = philox_field16(o1, (NH == 2) ? 2 * g + h : 4 * (g & 1) + h);
                     } else {
                         // one Philox draw = 16 bytes = this lane's 16 elements (4 pooled pixels x 4 df) of channel c
                         const u32x4 o = philox_stream((uint32_t)((q0 >> 2) * C + c), (uint32_t)kh, seed);
                         m16 = philox_keep16(o, thr);
                     }
-                    if (mask_out) mask_out[((size_t)(q0 >> 2) * NH + h) * 64 + lane] = (uint16_t)m16;
+                    if (SAVE) mask_out[((size_t)(q0 >> 2) * NH + h) * 64 + lane] = (uint16_t)m16;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float lm = ((m16 >> r) & 1u) ? al[r] : 0.f;
-                        pooled[r >> 2] = fmaf(lm, sigmoid_from_scaled(az[r]), pooled[r >> 2]);
+                        // keep bit r as an all-ones / all-zeros word (v_bfe_i32) ANDed onto lin: two plain VALU instructions
+                        const int keep = __builtin_amdgcn_sbfe((int)m16, r, 1);
+                        const float lm = __int_as_float(__float_as_int(l16[r]) & keep);
+                        pooled[r >> 2] = fmaf(lm, sigmoid_from_scaled(z16[r]), pooled[r >> 2]);
                     }
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) pooled[r >> 2] = fmaf(al[r], sigmoid_from_scaled(az[r]), pooled[r >> 2]);
+                    for (int r = 0; r < 16; ++r) pooled[r >> 2] = fmaf(l16[r], sigmoid_from_scaled(z16[r]), pooled[r >> 2]);
                 }
+#endif
+                // the two half-waves hold dt = 0 / 1 of the same pooled pixels
 #pragma unroll
-                for (int jx = 0; jx < 4; ++jx) pooled[jx] += __shfl_xor(pooled[jx], 32);
-                const float sc = 0.125f * keep_scale;
+                for (int jx = 0; jx < 4; ++jx) pooled[jx] = blk0_half_sum(pooled[jx]);
                 const int j0 = 2 * kh;
-                p0[(size_t)(q0 + j0) * C + c] = (kh ? pooled[2] : pooled[0]) * sc;
-                p0[(size_t)(q0 + j0 + 1) * C + c] = (kh ? pooled[3] : pooled[1]) * sc;
+#ifdef BLK0_EXP_NOST
+                if (pooled[0] == 12345.678f)
+#endif
+                {
+                    p0[(size_t)(q0 + j0) * C + c] = (kh ? pooled[2] : pooled[0]) * sc;
+                    p0[(size_t)(q0 + j0 + 1) * C + c] = (kh ? pooled[3] : pooled[1]) * sc;
+                }
+            };
+            load_av(g0);
+            mma(0, 0);
+#ifdef SED_TS2
+            const bool first = ts_k == 2;
+            if (first) TSC(2);
+#endif
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (t + 1 < NT) {
+                    if ((t + 1) % NH == 0) load_av(g0 + (t + 1) / NH);
+                    mma((t + 1) % NH, (t + 1) & 1);
+                }
+#ifdef SED_TS2
+                if (first) { __builtin_amdgcn_sched_barrier(0); TSC(3 + 2 * t); __builtin_amdgcn_sched_barrier(0); }
+#endif
+                epilogue(g0 + t / NH, t % NH, al[t & 1], az[t & 1]);
+#ifdef SED_TS2
+                if (first) { __builtin_amdgcn_sched_barrier(0); TSC(4 + 2 * t); __builtin_amdgcn_sched_barrier(0); }
+#endif
             }
         }
+#ifndef SED_TS2
+        if (ts_k < 12) { TS(ts_k); ++ts_k; }
+#endif
+        if (nxt < n_tiles) xs_put(xs[buf ^ 1], vn);
+        __syncthreads();
+#ifndef SED_TS2
+        if (ts_k < 12) { TS(ts_k); ++ts_k; }
+#else
+        ts_k = 3;
+#endif
     }
+    TS(13);
 }
 
 // ---- backward: D[co][t] = sum_p dlin[p][co] P[p][t],  E[c][t] = sum_p dzgate[p][c] P[p][t] ------
@@ -541,6 +622,22 @@ int launch_x_moments(const Geo& g, const float* x, double* mompart, const ConvPa
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
+// workgroups of `threads` threads of kernel `fn` that are resident on the device at once (occupancy x CUs), cached per kernel:
+// the first call of every instantiation happens in the eager warm-up steps, never inside a stream capture
+#include <map>
+#include <mutex>
+static int resident_workgroups(const void* fn, int threads) {
+    static std::mutex mu;
+    static std::map<const void*, int> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(fn);
+    if (it != cache.end()) return it->second;
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    if (g_sed_debug & 8192) fprintf(stderr, "[sed] occupancy: %d workgroups per CU, %d CUs\n", per_cu, cus);
+    return cache[fn] = per_cu * cus;
+}
 int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const float* b0, const float* gamma,
                         const float* beta, const float* wglu, const float* bglu, float* run_mean, float* run_var,
                         int64_t* tracked, int train, int update, const uint64_t* seed, double* mom, double* mompart,
@@ -557,11 +654,33 @@ int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const flo
     a.wz = wz; a.wl = wl; a.bn = bn; a.C = g.C;
     k_blk0_prep<<<1, PREP_THREADS, 0, st>>>(a);
     SED_CHECK_LAUNCH();
-    const int tpc = (g.H1 + 3) / 4, nt = tpc * g.B;
-    const int use_drop = (train && g.p > 0.f) ? 1 : 0;
-    if (g.C == 64) k_blk0_fwd<2><<<nt < 2048 ? nt : 2048, 256, 0, st>>>(x, wz, wl, p0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, seed, mask_out);
-    else if (g.C == 128) k_blk0_fwd<4><<<nt < 1024 ? nt : 1024, 256, 0, st>>>(x, wz, wl, p0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, seed, mask_out);
+    const int tpc = (g.H1 + 1) / 2, nt = tpc * g.B;
+    const bool use_drop = train && g.p > 0.f;
+    const int drop = !use_drop ? 0 : (drop_thresh8(g.p) == 128u ? 1 : 2);
+    const bool save = use_drop && mask_out != nullptr;
+    // persistent grid: R full rounds of the workgroups that are resident at once (asked of the runtime per instantiation)
+    auto grid_for = [&](const void* fn) {
+        const int slots = resident_workgroups(fn, 256), rounds = (nt + slots - 1) / slots;
+        const int per_cu = 0, cus = slots;
+        if (g_sed_debug & 8192) fprintf(stderr, "[sed] blk0 forward: %d resident workgroups, %d tiles, %d rounds\n", per_cu + cus, nt, rounds);
+        if (g_sed_debug >> 16) return (g_sed_debug >> 16) < nt ? (g_sed_debug >> 16) : nt;      // timing experiments: grid override
+        return (nt + rounds - 1) / rounds;
+    };
+#define BLK0_FWD(NH, DROP, SAVE) \
+    k_blk0_fwd<NH, DROP, SAVE><<<grid_for((const void*)k_blk0_fwd<NH, DROP, SAVE>), 256, 0, st>>>(x, wz, wl, p0, g.B, g.T, g.H1, tpc, nt, g.p, seed, mask_out)
+#define BLK0_FWD_NH(NH)                                              \
+    do {                                                             \
+        if (drop == 0) BLK0_FWD(NH, 0, false);                       \
+        else if (drop == 1 && save) BLK0_FWD(NH, 1, true);           \
+        else if (drop == 1) BLK0_FWD(NH, 1, false);                  \
+        else if (save) BLK0_FWD(NH, 2, true);                        \
+        else BLK0_FWD(NH, 2, false);                                 \
+    } while (0)
+    if (g.C == 64) BLK0_FWD_NH(2);
+    else if (g.C == 128) BLK0_FWD_NH(4);
     else { sed_set_error("block 0: unsupported filter count %d", g.C); return SED_ERR_UNSUPPORTED; }
+#undef BLK0_FWD_NH
+#undef BLK0_FWD
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

@@ -330,6 +330,35 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
     const bool defer_gru_w = (parts & 4) != 0;           // parts == 5: the caller runs them later (parts == 8)
     bool forked = false, forked2 = false;
 
+    // weight + bias gradients of a GRU layer, both directions (split-K MFMA GEMMs, low occupancy):
+    //   dW_ih[g][i] = sum_bt dgi[bt][g] input[bt][i],  db_ih[g] = sum_bt dgi[bt][g]
+    //   dW_hh[g][j] = sum_bt dgh[bt][g] hprev[bt][j],  db_hh[g] = sum_bt dgh[bt][g]
+    auto gru_weight_grads_layer = [&](int l, hipStream_t s2) -> int {
+        const int nin = (l == 0) ? 64 : 128;
+        const float* input = (l == 0) ? CTXF(L.p2) : CTXF(L.out[l - 1]);
+        GemmBatch gb;
+        gb.n_prob = 4; gb.splits = SED_GRU_SPLITK; gb.part = WSF(W.gemm_part); gb.part_stride = 0;
+        for (int dir = 0; dir < 2; ++dir) {
+            gb.p[2 * dir] = gemm_prob(WSF(W.dgi[l]) + dir * 192, 1, 384, input, nin, 1, grads + P.w_ih[l][dir], nin, 192, nin, BT);
+            gb.p[2 * dir].Cones = grads + P.b_ih[l][dir];
+            gb.p[2 * dir + 1] = gemm_prob(WSF(W.dgh[l]) + dir * 192, 1, 384, WSF(W.hprev[l]) + dir * 64, 128, 1,
+                                          grads + P.w_hh[l][dir], 64, 192, 64, BT);
+            gb.p[2 * dir + 1].Cones = grads + P.b_hh[l][dir];
+        }
+        return launch_gemm_batch(gb, s2);
+    };
+    auto gru_weight_grads = [&](hipStream_t s2) -> int {
+        for (int l = g.L - 1; l >= 0; --l) SED_TRY(gru_weight_grads_layer(l, s2));
+        return SED_OK;
+    };
+    // Debug bit 14 (timing experiment, measured twice and rejected): each layer's weight-gradient GEMMs right behind that
+    // layer's recurrence kernel on the side stream - the upper layer's next to the lower layer's recurrence (48 workgroups
+    // on 256 CUs) - instead of between the two conv weight-gradient kernels.  Round 2, with the four-SIMD recurrence:
+    // 0.816 ms against 0.766 ms per step.  Every extra cross-stream edge of the captured graph becomes a completion
+    // signal between two hardware queues, and two of them on the recurrence chain cost more than the GEMMs' 40 us of
+    // otherwise idle GPU time give back.
+    const bool early_gru_w = parts == 3 && sd.ok && (g_sed_debug & 16384);
+
     if (parts & 1) {
     // ---- heads ----------------------------------------------------------------------------------
     const float* h_last = CTXF(L.out[g.L - 1]);
@@ -352,28 +381,14 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
                                WSF(W.hprev[l]), d_in, g.B, g.T3, st));
         d_cur = d_in;
         d_cur2 = d_in + (size_t)BT * nin;
-    }
-    }
-    // weight + bias gradients of every GRU layer and direction (split-K MFMA GEMMs, low occupancy):
-    //   dW_ih[g][i] = sum_bt dgi[bt][g] input[bt][i],  db_ih[g] = sum_bt dgi[bt][g]
-    //   dW_hh[g][j] = sum_bt dgh[bt][g] hprev[bt][j],  db_hh[g] = sum_bt dgh[bt][g]
-    auto gru_weight_grads = [&](hipStream_t s2) -> int {
-        for (int l = g.L - 1; l >= 0; --l) {
-            const int nin = (l == 0) ? 64 : 128;
-            const float* input = (l == 0) ? CTXF(L.p2) : CTXF(L.out[l - 1]);
-            GemmBatch gb;
-            gb.n_prob = 4; gb.splits = SED_GRU_SPLITK; gb.part = WSF(W.gemm_part); gb.part_stride = 0;
-            for (int dir = 0; dir < 2; ++dir) {
-                gb.p[2 * dir] = gemm_prob(WSF(W.dgi[l]) + dir * 192, 1, 384, input, nin, 1, grads + P.w_ih[l][dir], nin, 192, nin, BT);
-                gb.p[2 * dir].Cones = grads + P.b_ih[l][dir];
-                gb.p[2 * dir + 1] = gemm_prob(WSF(W.dgh[l]) + dir * 192, 1, 384, WSF(W.hprev[l]) + dir * 64, 128, 1,
-                                              grads + P.w_hh[l][dir], 64, 192, 64, BT);
-                gb.p[2 * dir + 1].Cones = grads + P.b_hh[l][dir];
-            }
-            SED_TRY(launch_gemm_batch(gb, s2));
+        if (early_gru_w) {
+            SIDE_FORK(st);
+            forked = true;
+            if (l == g.L - 1) SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, ss));
+            SED_TRY(gru_weight_grads_layer(l, ss));
         }
-        return SED_OK;
-    };
+    }
+    }
     // parts == 1 (data-parallel: the GRU + heads gradient bucket must be complete when this call returns so that
     // its all-reduce can start): the GEMMs follow the dX chain on the caller's stream.  parts == 3: they are
     // deferred to the side stream of the conv-block backward below, where they overlap k_glu_pool_bwd.
@@ -429,7 +444,7 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
             if (sd.ok) { SIDE_FORK(st); forked = true; }
             SED_TRY(launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(pin[i]), WSF(W.wg_part), W.wgrad_blocks,
                                       grads + P.conv_w[i], g.B, Hs[i], Wd[i], pp, ss));
-            if (parts == 3) {
+            if (parts == 3 && !early_gru_w) {
                 // the head weight-gradient column sum (deferred from part 1): behind wgrad2, long before the tail of the step
                 // (queued right in front of wgrad1 it sat 60 us behind the persistent dgrad kernel and held wgrad1 back; at
                 // the very end of the side stream it was 4 us on the step's tail)

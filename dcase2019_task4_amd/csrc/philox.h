@@ -38,7 +38,7 @@ __device__ __forceinline__ uint32_t philox_byte(const u32x4& o, int i) {
     uint32_t w = (i >> 2) == 0 ? o.x : (i >> 2) == 1 ? o.y : (i >> 2) == 2 ? o.z : o.w;
     return (w >> (8 * (i & 3))) & 0xffu;
 }
-__device__ __forceinline__ uint32_t drop_thresh8(float p) { return (uint32_t)(p * 256.0f + 0.5f); }
+__host__ __device__ __forceinline__ uint32_t drop_thresh8(float p) { return (uint32_t)(p * 256.0f + 0.5f); }
 __device__ __forceinline__ float drop_scale8(float p) { return 256.0f / (256.0f - (float)drop_thresh8(p)); }
 // 16 keep bits (bit i = byte i kept) of one draw
 __device__ __forceinline__ uint32_t philox_keep16(const u32x4& o, uint32_t thr) {

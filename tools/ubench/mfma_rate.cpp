@@ -60,6 +60,10 @@ int main() {
     run("16x16x4 8acc 1 wave/SIMD", k16<8>, 256, 8, 2.0 * 16 * 16 * 4, d);
     run("16x16x4 8acc 2 waves/SIMD", k16<8>, 512, 8, 2.0 * 16 * 16 * 4, d);
     run("16x16x4 2acc 1 wave/SIMD", k16<2>, 256, 2, 2.0 * 16 * 16 * 4, d);
+    run("32x32x2 1acc (dependent chain) 1 wave/SIMD", k32<1>, 256, 1, 2.0 * 32 * 32 * 2, d);
+    run("32x32x2 1acc (dependent chain) 2 waves/SIMD", k32<1>, 512, 1, 2.0 * 32 * 32 * 2, d);
+    run("32x32x2 1acc (dependent chain) 3 waves/SIMD", k32<1>, 768, 1, 2.0 * 32 * 32 * 2, d);
+    run("16x16x4 1acc (dependent chain) 1 wave/SIMD", k16<1>, 256, 1, 2.0 * 16 * 16 * 4, d);
     run("32x32x2 2acc 1 wave/SIMD", k32<2>, 256, 2, 2.0 * 32 * 32 * 2, d);
     run("32x32x2 2acc 2 waves/SIMD", k32<2>, 512, 2, 2.0 * 32 * 32 * 2, d);
     run("32x32x2 4acc 1 wave/SIMD", k32<4>, 256, 4, 2.0 * 32 * 32 * 2, d);

@@ -406,6 +406,8 @@ def main():
         }
         if dist_info:
             res["distributed"] = dist_info
+            if getattr(step, "_capture_error", None):
+                res["distributed"]["capture_fallback"] = step._capture_error[:200]
         if config3:
             res["config3_ddp"] = config3
         step_flop = WIDE_STEP_FLOP_PER_CLIP if wide else STEP_FLOP_PER_CLIP

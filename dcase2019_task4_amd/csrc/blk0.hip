@@ -202,23 +202,82 @@ __global__ __launch_bounds__(PREP_THREADS) void k_blk0_prep(Blk0PrepArgs a) {
 // Wave w owns pooled row w; it walks 4 "row blocks" g of 32 pixels = pooled cols 4g..4g+3.
 // MFMA row m of a row block: j = m>>3 (pooled col 4g+j), dt = (m>>2)&1, df = m&3, so that
 // D-fragment register r of lane l (row (r&3)+8(r>>2)+4(l>>5)) is pooled col r>>2, dt = l>>5, df = r&3.
-template <int NH>      // NH = C / 32 channel slices
-struct Blk0W {
+// MODE 0: exact fp32 operands, K = 10 as five v_mfma_f32_32x32x2_f32 per 32 x 32 tile.  MODE 1 (sed_dims.dtype = bf16): the
+// patch and the folded weights rounded to bf16, K = 10 padded to 16 = ONE v_mfma_f32_32x32x16_bf16 per tile (fp32
+// accumulation): the MFMA part of the tile drops from 640 to 2 x 16 cycles; everything downstream (sigmoid, dropout,
+// pooling, the backward's D / E sums) stays fp32.  Same D layout for both.
+typedef __attribute__((ext_vector_type(8))) __bf16 blk0_bf16x8;
+template <int NH, int MODE>      // NH = C / 32 channel slices
+struct Blk0W;
+template <int NH>
+struct Blk0W<NH, 0> {
     float bw[5][2 * NH];   // B fragments: [k-step][col block]; col blocks 0 .. NH-1 = lin, NH .. 2NH-1 = z
 };
 template <int NH>
-__device__ __forceinline__ void blk0_load_w(Blk0W<NH>& W, const float* __restrict__ wz, const float* __restrict__ wl, int lane) {
+struct Blk0W<NH, 1> {
+    blk0_bf16x8 bw[2 * NH];   // B fragments, k = 8 (lane >> 5) + 0..7 (taps >= 10 are zero)
+};
+template <int NH, int MODE>
+__device__ __forceinline__ void blk0_load_w(Blk0W<NH, MODE>& W, const float* __restrict__ wz, const float* __restrict__ wl, int lane) {
     const int n = lane & 31, kh = lane >> 5;
+    // the z columns carry -log2(e): the MFMA then delivers the argument of exp2 in sigmoid(z) = 1 / (1 + 2^(-log2e z))
+    // directly (these kernels are VALU-bound; z itself is never needed, only sigmoid(z))
+    if constexpr (MODE == 0) {
 #pragma unroll
-    for (int s = 0; s < 5; ++s) {
-        const int k = 2 * s + kh;
+        for (int s = 0; s < 5; ++s) {
+            const int k = 2 * s + kh;
 #pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            W.bw[s][h] = wl[(32 * h + n) * 12 + k];
-            // the z columns carry -log2(e): the MFMA then delivers the argument of exp2 in sigmoid(z) = 1 / (1 + 2^(-log2e z))
-            // directly (these kernels are VALU-bound; z itself is never needed, only sigmoid(z))
-            W.bw[s][NH + h] = wz[(32 * h + n) * 12 + k] * SED_NEG_LOG2E;
+            for (int h = 0; h < NH; ++h) {
+                W.bw[s][h] = wl[(32 * h + n) * 12 + k];
+                W.bw[s][NH + h] = wz[(32 * h + n) * 12 + k] * SED_NEG_LOG2E;
+            }
         }
+    } else {
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = 8 * kh + i, kc = k < 10 ? k : 0;
+                const float l = wl[(32 * h + n) * 12 + kc], z = wz[(32 * h + n) * 12 + kc] * SED_NEG_LOG2E;
+                W.bw[h][i] = (__bf16)(k < 10 ? l : 0.f);
+                W.bw[NH + h][i] = (__bf16)(k < 10 ? z : 0.f);
+            }
+    }
+}
+// MFMA A operand of a row block: this lane's pixel (LDS offset `base` of its top-left tap)
+template <int MODE> struct Blk0A;
+template <> struct Blk0A<0> { float v[5]; };           // taps 2 s + kh
+template <> struct Blk0A<1> { blk0_bf16x8 v; };        // taps 8 kh + 0..7 (tap 9 = the constant 1, taps >= 10 zero)
+template <int MODE>
+__device__ __forceinline__ void blk0_load_a(Blk0A<MODE>& A, const float* xb, int base, int kh) {
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int s5 = 0; s5 < 5; ++s5) {
+            const int k = 2 * s5 + kh;
+            A.v[s5] = (k == 9) ? 1.0f : xb[base + (k / 3) * XS_W + (k % 3)];
+        }
+    } else {
+        // kh = 0: taps 0 .. 7; kh = 1: tap 8, the constant, six zeros (those lanes read tap 8 once and clamp the rest)
+        const float t0 = xb[base + (kh ? 2 * XS_W + 2 : 0)];
+        A.v[0] = (__bf16)t0;
+        A.v[1] = (__bf16)(kh ? 1.0f : xb[base + 1]);
+#pragma unroll
+        for (int i = 2; i < 8; ++i) A.v[i] = (__bf16)(kh ? 0.f : xb[base + (i / 3) * XS_W + (i % 3)]);
+    }
+}
+template <int NH, int MODE>
+__device__ __forceinline__ void blk0_mma(const Blk0A<MODE>& A, const Blk0W<NH, MODE>& W, int h, f32x16& al, f32x16& az) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { al[r] = 0.f; az[r] = 0.f; }
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int s5 = 0; s5 < 5; ++s5) {
+            al = mfma32(A.v[s5], W.bw[s5][h], al);
+            az = mfma32(A.v[s5], W.bw[s5][NH + h], az);
+        }
+    } else {
+        al = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, W.bw[h], al, 0, 0, 0);
+        az = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, W.bw[NH + h], az, 0, 0, 0);
     }
 }
 __device__ __forceinline__ void blk0_load_xs(float* xs, const float* __restrict__ x, int b, int T, int t0, int tid) {
@@ -248,7 +307,7 @@ __device__ __forceinline__ float blk0_half_sum(float x) {      // x + (the other
     const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return __uint_as_float(a[0]) + __uint_as_float(a[1]);
 }
-template <int NH, int DROP, bool SAVE>
+template <int NH, int DROP, bool SAVE, int MODE>
 __global__ __launch_bounds__(256, (NH == 2 ? 3 : 2)) void k_blk0_fwd(const float* __restrict__ x, const float* __restrict__ wz,
                                                    const float* __restrict__ wl, float* __restrict__ p0, int B, int T,
                                                    int H1, int tiles_per_clip, int n_tiles, float p_drop,
@@ -259,8 +318,8 @@ __global__ __launch_bounds__(256, (NH == 2 ? 3 : 2)) void k_blk0_fwd(const float
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
     TS(0);
-    Blk0W<NH> W;
-    blk0_load_w<NH>(W, wz, wl, lane);
+    Blk0W<NH, MODE> W;
+    blk0_load_w<NH, MODE>(W, wz, wl, lane);
     const uint64_t seed = DROP ? seed_ptr[0] : 0ull;
     const uint32_t thr = drop_thresh8(p_drop);
     const float sc = 0.125f * (DROP ? drop_scale8(p_drop) : 1.0f);
@@ -304,29 +363,16 @@ __global__ __launch_bounds__(256, (NH == 2 ? 3 : 2)) void k_blk0_fwd(const float
             const int dsel = (NH == 2) ? 0 : (g0 >> 1);
             u32x4 o1 = {0u, 0u, 0u, 0u};
             if (DROP == 1) o1 = philox_stream(((uint32_t)(b * H1 + to) * (NH / 2) + (uint32_t)dsel) * 64u + (uint32_t)lane, PHILOX_STREAM_1BIT, seed);
-            float av[5];
-            // MFMA A operand of row block g: this lane's pixel, taps 2s + kh (shared by the channel slices)
-            auto load_av = [&](int g) {
-                const int base = (2 * (wv >> 1) + mdt) * XS_W + 16 * g + 4 * mj + mdf;
-#pragma unroll
-                for (int s5 = 0; s5 < 5; ++s5) {
-                    const int k = 2 * s5 + kh;
-                    av[s5] = (k == 9) ? 1.0f : xb[base + (k / 3) * XS_W + (k % 3)];
-                }
-            };
+            Blk0A<MODE> av;
+            // MFMA A operand of row block g: this lane's pixel (shared by the channel slices)
+            auto load_av = [&](int g) { blk0_load_a<MODE>(av, xb, (2 * (wv >> 1) + mdt) * XS_W + 16 * g + 4 * mj + mdf, kh); };
             f32x16 al[2], az[2];
             auto mma = [&](int h, int sl) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { al[sl][r] = 0.f; az[sl][r] = 0.f; }
 #ifdef BLK0_EXP_NOMMA       // timing experiments only (tools/build_variant.sh): results are garbage
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { al[sl][r] = av[r % 5] * W.bw[r % 5][h]; az[sl][r] = av[r % 5] * W.bw[r % 5][NH + h]; }
+                for (int r = 0; r < 16; ++r) { al[sl][r] = (float)r * xb[r]; az[sl][r] = (float)(r + h) * xb[r + 1]; }
 #else
-#pragma unroll
-                for (int s5 = 0; s5 < 5; ++s5) {
-                    al[sl] = mfma32(av[s5], W.bw[s5][h], al[sl]);
-                    az[sl] = mfma32(av[s5], W.bw[s5][NH + h], az[sl]);
-                }
+                blk0_mma<NH, MODE>(av, W, h, al[sl], az[sl]);
 #endif
             };
             auto epilogue = [&](int g, int h, const f32x16& l16, const f32x16& z16) {
@@ -408,7 +454,7 @@ __global__ __launch_bounds__(256, (NH == 2 ? 3 : 2)) void k_blk0_fwd(const float
 }
 
 // ---- backward: D[co][t] = sum_p dlin[p][co] P[p][t],  E[c][t] = sum_p dzgate[p][c] P[p][t] ------
-template <int NH>
+template <int NH, int MODE>
 __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float* __restrict__ x, const float* __restrict__ wz,
                                                    const float* __restrict__ wl, const float* __restrict__ dp0, int B,
                                                    int T, int H1, int tiles_per_clip, int n_tiles, int use_drop,
@@ -420,8 +466,8 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
     constexpr int C = 32 * NH;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
-    Blk0W<NH> W;
-    blk0_load_w<NH>(W, wz, wl, lane);
+    Blk0W<NH, MODE> W;
+    blk0_load_w<NH, MODE>(W, wz, wl, lane);
     const float keep_scale = use_drop ? drop_scale8(p_drop) : 1.0f;
     float aD[NH][10], aE[NH][10];
 #pragma unroll
@@ -463,15 +509,11 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
             }
             if (g < 3) fetch(g + 1);
             // patch values: MFMA A operand (this lane's pixel m, taps 2s+kh) and the im2col rows for the reductions
-            float av[5];
+            Blk0A<MODE> av;
             {
                 const int m = n, j = m >> 3, dt = (m >> 2) & 1, df = m & 3;
                 const int base = (2 * wv + dt) * XS_W + 16 * g + 4 * j + df;
-#pragma unroll
-                for (int s5 = 0; s5 < 5; ++s5) {
-                    const int k = 2 * s5 + kh;
-                    av[s5] = (k == 9) ? 1.0f : xs[base + (k / 3) * XS_W + (k % 3)];
-                }
+                blk0_load_a<MODE>(av, xs, base, kh);
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
                     const int k = kh * 6 + i;
@@ -485,13 +527,7 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
                 f32x16 al, az;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { al[r] = 0.f; az[r] = 0.f; }
-#pragma unroll
-                for (int s5 = 0; s5 < 5; ++s5) {
-                    al = mfma32(av[s5], W.bw[s5][h], al);
-                    az = mfma32(av[s5], W.bw[s5][NH + h], az);
-                }
+                blk0_mma<NH, MODE>(av, W, h, al, az);
                 float dl[16], dzg[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -666,8 +702,13 @@ int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const flo
         if (g_sed_debug >> 16) return (g_sed_debug >> 16) < nt ? (g_sed_debug >> 16) : nt;      // timing experiments: grid override
         return (nt + rounds - 1) / rounds;
     };
-#define BLK0_FWD(NH, DROP, SAVE) \
-    k_blk0_fwd<NH, DROP, SAVE><<<grid_for((const void*)k_blk0_fwd<NH, DROP, SAVE>), 256, 0, st>>>(x, wz, wl, p0, g.B, g.T, g.H1, tpc, nt, g.p, seed, mask_out)
+#define BLK0_FWD_M(NH, DROP, SAVE, MODE) \
+    k_blk0_fwd<NH, DROP, SAVE, MODE><<<grid_for((const void*)k_blk0_fwd<NH, DROP, SAVE, MODE>), 256, 0, st>>>(x, wz, wl, p0, g.B, g.T, g.H1, tpc, nt, g.p, seed, mask_out)
+#define BLK0_FWD(NH, DROP, SAVE)                          \
+    do {                                                  \
+        if (g.mode == 1) BLK0_FWD_M(NH, DROP, SAVE, 1);   \
+        else BLK0_FWD_M(NH, DROP, SAVE, 0);               \
+    } while (0)
 #define BLK0_FWD_NH(NH)                                              \
     do {                                                             \
         if (drop == 0) BLK0_FWD(NH, 0, false);                       \
@@ -681,6 +722,7 @@ int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const flo
     else { sed_set_error("block 0: unsupported filter count %d", g.C); return SED_ERR_UNSUPPORTED; }
 #undef BLK0_FWD_NH
 #undef BLK0_FWD
+#undef BLK0_FWD_M
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
@@ -693,8 +735,13 @@ int launch_blk0_backward(const Geo& g, const float* x, const float* w0, const fl
     if (zero_de) SED_CHECK_HIP(hipMemsetAsync(de, 0, 2 * g.C * 10 * sizeof(double), st));
     const int tpc = (g.H1 + 3) / 4, nt = tpc * g.B;
     const int use_drop = (g.p > 0.f) ? 1 : 0;
-    if (g.C == 64) k_blk0_bwd<2><<<nt < 512 ? nt : 512, 256, 0, st>>>(x, wz, wl, dp0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, mask_in, de, g_sed_debug & 1);
-    else if (g.C == 128) k_blk0_bwd<4><<<nt < 256 ? nt : 256, 256, 0, st>>>(x, wz, wl, dp0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, mask_in, de, g_sed_debug & 1);
+#define BLK0_BWD(NH, MODE, GRID) \
+    k_blk0_bwd<NH, MODE><<<nt < (GRID) ? nt : (GRID), 256, 0, st>>>(x, wz, wl, dp0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, mask_in, de, g_sed_debug & 1)
+    if (g.C == 64 && g.mode == 1) BLK0_BWD(2, 1, 512);
+    else if (g.C == 64) BLK0_BWD(2, 0, 512);
+    else if (g.C == 128 && g.mode == 1) BLK0_BWD(4, 1, 256);
+    else if (g.C == 128) BLK0_BWD(4, 0, 256);
+#undef BLK0_BWD
     else { sed_set_error("block 0: unsupported filter count %d", g.C); return SED_ERR_UNSUPPORTED; }
     SED_CHECK_LAUNCH();
     Blk0BwdFinArgs a;

@@ -159,7 +159,9 @@ class MeanTeacherStep:
             self.sync_replicas()
         self.use_graph = bool(use_graph)
         self.overlap = bool(overlap_streams)
-        self._side = torch.cuda.Stream(device=dev) if (self.overlap and teacher is not None) else None
+        self._side = (torch.cuda.Stream(device=dev, priority=int(os.environ.get("SED_SIDE_PRIO", "0")))
+                      if (self.overlap and teacher is not None) else None)
+        self._capture_error = None
         self._graph_a = None
         self._graph_w = None
         self._graph_c = None
@@ -243,7 +245,9 @@ class MeanTeacherStep:
             ok = 1.0
             try:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=self._cap_stream):
+                # thread_local: the process group's watchdog thread queries events of earlier collectives, which a
+                # capture in the default "global" mode treats as an illegal call and aborts on
+                with torch.cuda.graph(g, stream=self._cap_stream, capture_error_mode="thread_local"):
                     dist.all_reduce(t, group=self.pg)
                 g.replay()
                 torch.cuda.synchronize(self.device)
@@ -366,6 +370,8 @@ class MeanTeacherStep:
     def _capture(self):
         torch.cuda.synchronize(self.device)
         cap = dict(stream=self._cap_stream)
+        if self.dp:
+            cap["capture_error_mode"] = "thread_local"      # see _collective_capture_works
         if self.dp and not self.dp_capture:
             overlap = self.dp_schedule == "overlap" and not self.cnn_frozen
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -381,14 +387,31 @@ class MeanTeacherStep:
             with torch.cuda.graph(gb, **cap):
                 self._update()
             self._graph_a, self._graph_b = ga, gb
+        elif self.dp:
+            # collectives captured into the step's graph.  Every rank must end up with the same schedule: if the capture
+            # fails anywhere, all ranks fall back to "single" with an eager collective between two graph segments.
+            import torch.distributed as dist
+            ok = 1.0
+            try:
+                ga = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, **cap):
+                    self._dp_step_body()
+            except Exception as e:                     # noqa: BLE001 - anything the capture raises means "not capturable here"
+                ok, ga = 0.0, None
+                self._capture_error = repr(e)
+            flag = torch.tensor([ok], device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+            if flag.item() == 1.0:
+                self._graph_a = ga
+            else:
+                self.dp_capture, self.dp_schedule = False, "single"
+                torch.cuda.synchronize(self.device)
+                self._capture()
         else:
             ga = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga, **cap):
-                if self.dp:
-                    self._dp_step_body()
-                else:
-                    self._fwd_bwd()
-                    self._update()
+                self._fwd_bwd()
+                self._update()
             self._graph_a = ga
         # capture executes nothing: the captured work runs on replay
 

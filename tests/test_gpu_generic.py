@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 POST_TOL = 2e-5
 BF16_POST_TOL = 4e-3          # measured <= 1.6e-3 over the shapes below (3 conv blocks' worth of 2^-9 operand rounding)
-BF16_GRAD_TOL = 6e-2          # of the gradient's typical magnitude; measured <= 2.5e-2
+BF16_GRAD_TOL = 1e-1          # of the gradient's typical magnitude; measured <= 7e-2 (block 0 in bf16 operands as well)
 
 
 def _stage_report(model, inter, B, T, C, H):

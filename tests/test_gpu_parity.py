@@ -179,7 +179,8 @@ def test_winograd_kernels_match_the_direct_convolution_kernels(B, T):
                                                    (5, 216, 0.5, 1, 10), (4, 150, 0.25, 2, 10), (7, 1040, 0.5, 2, 10),
                                                    (4, 864, 0.5, 2, 10), (6, 96, 0.5, 2, 1), (5, 200, 0.5, 2, 16),
                                                    (4, 630, 0.5, 2, 10), (9, 100, 0.5, 2, 10), (4, 22, 0.5, 2, 10),
-                                                   (24, 628, 0.5, 2, 10), (4, 629, 0.5, 2, 10), (5, 151, 0.5, 2, 10)])
+                                                   (24, 628, 0.5, 2, 10), (4, 629, 0.5, 2, 10), (5, 151, 0.5, 2, 10),
+                                                   (4, 136, 0.5, 2, 10), (4, 256, 0.5, 2, 10), (4, 264, 0.5, 2, 10)])
 def test_train_forward_backward_vs_oracle(B, T, p, n_layers, nclass):
     """Posteriors, loss, every parameter gradient and the BN running stats against the oracle, with
     dropout ON (same Philox masks on both sides).  T=150 exercises odd H (rows dropped by the pool); T=1040 gives
@@ -187,7 +188,8 @@ def test_train_forward_backward_vs_oracle(B, T, p, n_layers, nclass):
     4; T=864 is the reference's own frame count (config.py:17-22); nclass 1 and 16 are the ABI's limits; T=630 / 100 / 22
     are not multiples of 8 (every pooling floor drops rows; 22 frames leave 2 GRU steps - less than one step block);
     (24, 628) is the headline shape of BASELINE.json configs[1] itself; T = 629 / 151 are ODD frame counts (the first
-    pool already drops an input row)."""
+    pool already drops an input row); T = 136 / 256 / 264 leave 17 / 32 / 33 GRU steps - one past a 16-step block of the
+    recurrence kernels, exactly two blocks, one past two."""
     hip, orc = _fwd_bwd_both(B, T, p, seed=123456789, n_layers=n_layers, nclass=nclass)
     es, _ = gu.report("strong", hip[0], orc[0])
     ew, _ = gu.report("weak", hip[1], orc[1])

@@ -60,11 +60,12 @@ PEAK_HBM_GBS = 8000.0
 # kernel launches per mean-teacher step (profiles/r01_j_step_timeline.txt) - used to add the committed per-launch PMC
 # traffic figures up to a per-step figure
 LAUNCHES_PER_STEP = {
-    "k_x_moments": 2, "k_blk0_prep": 2, "k_blk0_fwd": 2, "void k_conv_wino<16, 0>": 2, "void k_conv_wino<4, 0>": 2,
-    "k_glu_pool_fwd": 4, "void k_gru_fwd<64>": 2, "void k_gru_fwd<128>": 2, "k_heads_fwd": 2, "k_heads_bwd": 1,
-    "void k_gru_bwd<128>": 1, "void k_gru_bwd<64>": 1, "k_glu_pool_bwd8": 2, "void k_wgrad_wino<4>": 1,
+    "k_x_moments": 2, "k_blk0_prep": 2, "void k_blk0_fwd<2, 1, true, 0>": 2,
+    "void k_conv_wino<16, 0>": 2, "void k_conv_wino<4, 0>": 2,
+    "k_glu_pool_fwd": 4, "void k_gru4_fwd<64>": 2, "void k_gru4_fwd<128>": 2, "void k_heads_fwd<128>": 2, "void k_heads_bwd<128>": 1,
+    "void k_gru4_bwd<128>": 1, "void k_gru4_bwd<64>": 1, "k_glu_pool_bwd8": 2, "void k_wgrad_wino<4>": 1,
     "void k_conv_wino<4, 1>": 1, "k_wgrad_reduce": 2, "k_colsum": 1, "k_gemm_batched": 2, "k_gemm_reduce": 2,
-    "void k_conv_wino<16, 1>": 1, "k_blk0_bwd": 1, "k_blk0_bwd_finalize": 1, "void k_wgrad_wino<16>": 1,
+    "void k_conv_wino<16, 1>": 1, "void k_blk0_bwd<2, 0>": 1, "k_blk0_bwd_finalize": 1, "void k_wgrad_wino<16>": 1,
     "void k_adam_ema<true>": 1,
 }
 

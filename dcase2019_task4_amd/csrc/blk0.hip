@@ -677,8 +677,10 @@ static int resident_workgroups(const void* fn, int threads) {
 int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const float* b0, const float* gamma,
                         const float* beta, const float* wglu, const float* bglu, float* run_mean, float* run_var,
                         int64_t* tracked, int train, int update, const uint64_t* seed, double* mom, double* mompart,
-                        float* wz, float* wl, float* bn, float* p0, uint16_t* mask_out, const ConvPackArgs* pack, hipStream_t st) {
-    if (train) {
+                        float* wz, float* wl, float* bn, float* p0, uint16_t* mask_out, const ConvPackArgs* pack, hipStream_t st,
+                        int main_kernel_only) {
+    // main_kernel_only (sed_kernel_replay): the folded weights of the last real forward are still in wz / wl
+    if (train && !main_kernel_only) {
         const int rc = launch_x_moments(g, x, mompart, pack, st);
         if (rc != SED_OK) return rc;
     }
@@ -688,8 +690,10 @@ int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const flo
     a.mompart = mompart; a.n_part = x_moments_parts(g);
     a.N = (double)g.B * g.T * g.F; a.train = train; a.update = update; a.eps = g.eps; a.momentum = g.mom;
     a.wz = wz; a.wl = wl; a.bn = bn; a.C = g.C;
-    k_blk0_prep<<<1, PREP_THREADS, 0, st>>>(a);
-    SED_CHECK_LAUNCH();
+    if (!main_kernel_only) {
+        k_blk0_prep<<<1, PREP_THREADS, 0, st>>>(a);
+        SED_CHECK_LAUNCH();
+    }
     const int tpc = (g.H1 + 1) / 2, nt = tpc * g.B;
     const bool use_drop = train && g.p > 0.f;
     const int drop = !use_drop ? 0 : (drop_thresh8(g.p) == 128u ? 1 : 2);

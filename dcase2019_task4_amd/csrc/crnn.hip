@@ -536,7 +536,7 @@ extern "C" int sed_kernel_replay(const char* name, const sed_dims* d, const floa
         return launch_blk0_forward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
                                    params + P.glu_w[0], params + P.glu_b[0], WSF(W.coef[1]), WSF(W.coef[1]) + 64, nullptr, 1, 0,
                                    seed_dev, CTXD(L.mom0), CTXD(L.mompart), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), CTXF(L.p0),
-                                   use_drop ? CTXM(L.mask0) : nullptr, nullptr, st);
+                                   use_drop ? CTXM(L.mask0) : nullptr, nullptr, st, 1);
     }
     for (int i = 1; i <= 2; ++i) {
         char nm[32];

@@ -2,7 +2,7 @@
 # Round-2 profile collection on the GPU box (run through gpurun from the repo root); writes under gpurun_out/r02/.
 # Counters are collected in their own passes with --kernel-trace only (never with hip/hsa trace domains).
 set -u
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r02
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${PROF_TAG:-r02}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

@@ -148,11 +148,17 @@ __global__ __launch_bounds__(256, 2) void k_glu_pool_fwd(const float* __restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
         const float* A = zt + n * ZS + kh;
+        // A operands two k-steps (four MFMAs) AHEAD, in rotating registers: written as `a = A[2 s]; mfma; mfma` the compiler
+        // issued each ds_read right in front of the MFMAs that need it and the wave sat out one LDS latency per k-step pair
+        // (ds_read2_b32 | s_waitcnt lgkmcnt(0) | 4 MFMAs, sixteen times per row block)
+        float av[4];
+        av[0] = A[0]; av[1] = A[2];
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
-            const float a = A[2 * s];
-            acc[0] = mfma32(a, bw[s][0], acc[0]);
-            acc[1] = mfma32(a, bw[s][1], acc[1]);
+            if (s + 2 < 32) av[(s + 2) & 3] = A[2 * (s + 2)];
+            acc[0] = mfma32(av[s & 3], bw[s][0], acc[0]);
+            acc[1] = mfma32(av[s & 3], bw[s][1], acc[1]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         u32x4 o1 = {0u, 0u, 0u, 0u};
         if (use_drop && one_bit) o1 = philox_stream_1bit((uint32_t)rb, lane, block_id, seed);
@@ -622,14 +628,15 @@ __global__ __launch_bounds__(512, 1) void k_glu_pool_bwd8(const float* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             const float* A = dlt + n * ZS + kh;
-            float a_c = A[0], b_c = BT[0];
+            // operands two MFMAs ahead in rotating registers (a `_c = _n` copy per step made the wave wait for the prefetch
+            // it had just issued: ds_read x2 | s_waitcnt lgkmcnt(0) | one MFMA, thirty-two times)
+            float a_r[4], b_r[4];
+            a_r[0] = A[0]; b_r[0] = BT[0]; a_r[1] = A[2]; b_r[1] = BT[2];
 #pragma unroll
             for (int s = 0; s < 32; ++s) {
-                float a_n = 0.f, b_n = 0.f;
-                if (s + 1 < 32) { a_n = A[2 * (s + 1)]; b_n = BT[2 * (s + 1)]; }
-                acc = mfma32(a_c, b_c, acc);
+                if (s + 2 < 32) { a_r[(s + 2) & 3] = A[2 * (s + 2)]; b_r[(s + 2) & 3] = BT[2 * (s + 2)]; }
+                acc = mfma32(a_r[s & 3], b_r[s & 3], acc);
                 if (s < 16) dzg[s] *= lin[s] + bgl;
-                a_c = a_n; b_c = b_n;
                 __builtin_amdgcn_sched_barrier(0);
             }
             // claim the prefetched registers while only loads are outstanding (vmcnt cannot tell loads from stores)
@@ -637,13 +644,17 @@ __global__ __launch_bounds__(512, 1) void k_glu_pool_bwd8(const float* __restric
             for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(yv[k]), "+v"(gq_n[k]));
             asm volatile("" : "+v"(m_n));
             // ---- phase 3: dW[own co half][:] += dlin^T z   ||   dz = dz_lin + dzg -> global, BN-backward sums ------
+            float a3[2], b3[2][2];
+            a3[0] = dlt[kh * ZS + c_own]; b3[0][0] = zt[kh * ZS + n]; b3[0][1] = zt[kh * ZS + 32 + n];
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                const int mrow = 2 * s + kh;
-                const float a0 = dlt[mrow * ZS + c_own];
-                const float b0 = zt[mrow * ZS + n], b1 = zt[mrow * ZS + 32 + n];
-                dW[0] = mfma32(a0, b0, dW[0]);
-                dW[1] = mfma32(a0, b1, dW[1]);
+                if (s + 1 < 16) {          // the next step's three operands now, one pair of MFMAs ahead
+                    const int mn = 2 * (s + 1) + kh;
+                    a3[(s + 1) & 1] = dlt[mn * ZS + c_own];
+                    b3[(s + 1) & 1][0] = zt[mn * ZS + n]; b3[(s + 1) & 1][1] = zt[mn * ZS + 32 + n];
+                }
+                dW[0] = mfma32(a3[s & 1], b3[s & 1][0], dW[0]);
+                dW[1] = mfma32(a3[s & 1], b3[s & 1][1], dW[1]);
                 const int r = s, i = mfma32_row(r, lane);
                 const float v = acc[r] + dzg[r];
                 if (q0 + (r >> 2) < Q) {

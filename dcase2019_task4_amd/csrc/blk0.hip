@@ -528,26 +528,32 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
             for (int h = 0; h < NH; ++h) {
                 f32x16 al, az;
                 blk0_mma<NH, MODE>(av, W, h, al, az);
-                float dl[16], dzg[16];
+                // one pass over the lane's 16 pixel rows: dlin / dz_gate of row r are formed on the fly (no 2 x 16-register
+                // arrays live across the loop) and the NEXT row's patch (3 ds_read_b128) is fetched before this row's 20
+                // accumulation FMAs - with the reads issued right in front of their FMAs the wave sat out one LDS latency per
+                // row (SQ_WAIT_ANY 23 % of the wave cycles, profiles/r02_b)
+                f32x4 pa = *(const f32x4*)&Pw[mfma32_row(0, lane) * 12 + 0];
+                f32x4 pb = *(const f32x4*)&Pw[mfma32_row(0, lane) * 12 + 4];
+                f32x4 pc = *(const f32x4*)&Pw[mfma32_row(0, lane) * 12 + 8];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
+                    const float pv[10] = {pa[0], pa[1], pa[2], pa[3], pb[0], pb[1], pb[2], pb[3], pc[0], pc[1]};
+                    if (r + 1 < 16) {
+                        const int i1 = mfma32_row(r + 1, lane);
+                        pa = *(const f32x4*)&Pw[i1 * 12 + 0];
+                        pb = *(const f32x4*)&Pw[i1 * 12 + 4];
+                        pc = *(const f32x4*)&Pw[i1 * 12 + 8];
+                    }
                     const float gg = ((m_c[h] >> r) & 1u) ? gq_c[h][r >> 2] : 0.f;
                     const float sg = sigmoid_from_scaled(az[r]);
-                    dl[r] = gg * sg;
-                    dzg[r] = gg * al[r] * sg * (1.0f - sg);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = mfma32_row(r, lane);
-                    const f32x4 pa = *(const f32x4*)&Pw[i * 12 + 0];
-                    const f32x4 pb = *(const f32x4*)&Pw[i * 12 + 4];
-                    const f32x4 pc = *(const f32x4*)&Pw[i * 12 + 8];
-                    const float pv[10] = {pa[0], pa[1], pa[2], pa[3], pb[0], pb[1], pb[2], pb[3], pc[0], pc[1]};
+                    const float dl = gg * sg;
+                    const float dzg = dl * al[r] * (1.0f - sg);
 #pragma unroll
                     for (int t = 0; t < 10; ++t) {
-                        aD[h][t] = fmaf(dl[r], pv[t], aD[h][t]);
-                        aE[h][t] = fmaf(dzg[r], pv[t], aE[h][t]);
+                        aD[h][t] = fmaf(dl, pv[t], aD[h][t]);
+                        aE[h][t] = fmaf(dzg, pv[t], aE[h][t]);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __builtin_amdgcn_wave_barrier();

@@ -370,19 +370,22 @@ def main():
     config3 = None
     if world > 1 and headline and not args.no_extras and args.batch is None:
         # BASELINE.json configs[3]: global batch 512 at N = 8 = 64 clips per GPU ([16|32|16] per rank)
-        s3, t3 = build_models(device, seed=0)
-        x3, xe3, tg3, wm3, sm3 = synthetic_batch(B_CONFIG3, T_FRAMES, 2000 + rank, device)
-        step3 = MeanTeacherStep(s3, t3, B_CONFIG3, T_FRAMES, rampup_length=210 * 100 // 2, weak_mask=wm3, strong_mask=sm3,
-                                seed=4321, use_graph=not args.no_graph, process_group=pg)
-        step3.load_batch(x3, xe3, tg3)
-        for _ in range(5):
-            step3.run()
-        n3 = max(50, args.steps // 4)
-        el3 = time_steps(step3, n3, world, device)
-        config3 = {"workload": "BASELINE.json configs[3]: 64 clips per GPU", "global_batch": B_CONFIG3 * world,
-                   "value": round(B_CONFIG3 * world * n3 / el3, 1), "unit": "clips/s", "ms_per_step": round(el3 / n3 * 1e3, 4),
-                   "steps": n3}
-        del step3
+        try:                                        # the headline line must not depend on this extra leg
+            s3, t3 = build_models(device, seed=0)
+            x3, xe3, tg3, wm3, sm3 = synthetic_batch(B_CONFIG3, T_FRAMES, 2000 + rank, device)
+            step3 = MeanTeacherStep(s3, t3, B_CONFIG3, T_FRAMES, rampup_length=210 * 100 // 2, weak_mask=wm3, strong_mask=sm3,
+                                    seed=4321, use_graph=not args.no_graph, process_group=pg)
+            step3.load_batch(x3, xe3, tg3)
+            for _ in range(5):
+                step3.run()
+            n3 = max(50, args.steps // 4)
+            el3 = time_steps(step3, n3, world, device)
+            config3 = {"workload": "BASELINE.json configs[3]: 64 clips per GPU", "global_batch": B_CONFIG3 * world,
+                       "value": round(B_CONFIG3 * world * n3 / el3, 1), "unit": "clips/s", "ms_per_step": round(el3 / n3 * 1e3, 4),
+                       "steps": n3}
+            del step3
+        except Exception as e:                      # noqa: BLE001
+            config3 = {"error": repr(e)[:300]}
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3

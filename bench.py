@@ -309,7 +309,7 @@ def time_steps(step, steps, world, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--steps", type=int, default=3000)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="mt-f32", choices=sorted(CONFIGS))
     ap.add_argument("--no-graph", action="store_true")

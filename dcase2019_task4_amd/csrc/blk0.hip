@@ -18,6 +18,7 @@
 #include "common.h"
 #include "philox.h"
 #include "kernels.h"
+#include "gpack.h"
 
 SED_TS_DEFINE(blk0)
 #define XS_W 66
@@ -37,6 +38,7 @@ __device__ __forceinline__ int gidx(int a, int b) { return 9 + a * 9 - (a * (a -
 #define MOM_ROWS 64
 // Workgroups with blockIdx.x >= nx do the conv1 / conv2 weight packing of the same step instead (conv_pack_body,
 // kernels.h): independent work that used to be a 6 us launch of its own on the forward chain.
+__device__ __forceinline__ void x_moments_body(const float* __restrict__ x, int T, double* __restrict__ part, int nx);
 __global__ __launch_bounds__(256) void k_x_moments(const float* __restrict__ x, int T, double* __restrict__ part, int nx,
                                                     ConvPackArgs pack) {
     if ((int)blockIdx.x >= nx) {
@@ -44,6 +46,19 @@ __global__ __launch_bounds__(256) void k_x_moments(const float* __restrict__ x, 
         if (pb < SED_PACK_BLOCKS) conv_pack_body(pack, pb * 256 + (int)threadIdx.x);
         return;
     }
+    x_moments_body(x, T, part, nx);
+}
+// the generic kernel set's packing work in the spare workgroups (gpack.h)
+__global__ __launch_bounds__(256) void k_x_moments_aux(const float* __restrict__ x, int T, double* __restrict__ part, int nx,
+                                                        GenAuxPack aux, int n_aux) {
+    if ((int)blockIdx.x >= nx) {
+        const int pb = ((int)blockIdx.x - nx) * (int)gridDim.y + (int)blockIdx.y;
+        if (pb < n_aux) gen_aux_body(aux, pb, (int)threadIdx.x);
+        return;
+    }
+    x_moments_body(x, T, part, nx);
+}
+__device__ __forceinline__ void x_moments_body(const float* __restrict__ x, int T, double* __restrict__ part, int nx) {
     __shared__ float xs[(MOM_ROWS + 2) * XS_W];
     __shared__ float red[4][10][10];
     const int tid = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * MOM_ROWS;
@@ -655,8 +670,15 @@ __global__ __launch_bounds__(640) void k_blk0_bwd_finalize(Blk0BwdFinArgs a) {
 
 // ---- host launchers -------------------------------------------------------------------------------
 int x_moments_parts(const Geo& g) { return ((g.T + MOM_ROWS - 1) / MOM_ROWS) * g.B; }
-int launch_x_moments(const Geo& g, const float* x, double* mompart, const ConvPackArgs* pack, hipStream_t st) {
+int launch_x_moments(const Geo& g, const float* x, double* mompart, const ConvPackArgs* pack, hipStream_t st, const GenAuxPack* aux) {
     const int nx = (g.T + MOM_ROWS - 1) / MOM_ROWS;
+    if (aux) {
+        const int n_aux = gen_aux_blocks(*aux);
+        dim3 grid(nx + (n_aux + g.B - 1) / g.B, g.B);
+        k_x_moments_aux<<<grid, 256, 0, st>>>(x, g.T, mompart, nx, *aux, n_aux);
+        SED_CHECK_LAUNCH();
+        return SED_OK;
+    }
     ConvPackArgs pa = {};
     if (pack) pa = *pack;
     dim3 grid(nx + (pack ? (SED_PACK_BLOCKS + g.B - 1) / g.B : 0), g.B);
@@ -684,10 +706,10 @@ int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const flo
                         const float* beta, const float* wglu, const float* bglu, float* run_mean, float* run_var,
                         int64_t* tracked, int train, int update, const uint64_t* seed, double* mom, double* mompart,
                         float* wz, float* wl, float* bn, float* p0, uint16_t* mask_out, const ConvPackArgs* pack, hipStream_t st,
-                        int main_kernel_only) {
+                        int main_kernel_only, const GenAuxPack* aux) {
     // main_kernel_only (sed_kernel_replay): the folded weights of the last real forward are still in wz / wl
     if (train && !main_kernel_only) {
-        const int rc = launch_x_moments(g, x, mompart, pack, st);
+        const int rc = launch_x_moments(g, x, mompart, pack, st, aux);
         if (rc != SED_OK) return rc;
     }
     Blk0PrepArgs a;

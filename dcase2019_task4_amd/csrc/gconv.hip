@@ -11,6 +11,7 @@
 #include "gen.h"
 #include "kernels.h"
 #include "gkernels.h"
+#include "gpack.h"
 
 // ---- weight packing (once per forward) ----------------------------------------------------------------------------------
 // conv i (1, 2):  wpk [co][tap * C + ci] = W[co][ci][tap]                 (forward B operand, n = co)
@@ -19,47 +20,8 @@
 //                 wg  [co][c] = Wglu[co][c] * gamma[c]      bg[co] = bglu[co] + sum_c Wglu[co][c] beta[c]   (fp32)
 //                 wgT [c][co] = Wglu[co][c]                               (dz_lin = dlin @ Wglu, n = c)
 template <int MODE>
-__global__ __launch_bounds__(256) void k_gen_pack(GenPackArgs a) {
-    using M = MM<MODE>;
-    using E = typename M::E;
-    const int C = a.C, CC = C * C;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < a.n_zero) a.zero[i] = 0.0;
-    if (i == 0 && a.err) *a.err = 0;
-    if (i < 2 * 9 * CC) {
-        const int layer = i / (9 * CC), e = i % (9 * CC);
-        const int n = e / (9 * C), r = e % (9 * C), tap = r / C, k = r % C;
-        const float* w = layer ? a.w2 : a.w1;
-        E* wpk = (E*)(layer ? a.wpk2 : a.wpk1);
-        E* wpkT = (E*)(layer ? a.wpkT2 : a.wpkT1);
-        wpk[e] = M::cvt(w[((size_t)n * C + k) * 9 + tap]);
-        if (wpkT) wpkT[e] = M::cvt(w[((size_t)k * C + n) * 9 + (8 - tap)]);
-    }
-    if (i < 2 * CC) {
-        const int layer = i / CC, e = i % CC, co = e / C, c = e % C;
-        const float* wg = layer ? a.glu_w2 : a.glu_w1;
-        const float* gam = layer ? a.gamma2 : a.gamma1;
-        E* o = (E*)(layer ? a.wg2 : a.wg1);
-        E* oT = (E*)(layer ? a.wgT2 : a.wgT1);
-        o[e] = M::cvt(wg[e] * gam[c]);
-        if (oT) oT[(size_t)c * C + co] = M::cvt(wg[e]);
-    }
-}
-
-// bg[co] = bglu[co] + sum_c Wglu[co][c] beta[c]: one wave per (layer, co) row, coalesced reads, fp64 butterfly (a thread
-// per row walking its row with stride-C neighbours took 22 us at C = 128 - at the head of every forward)
-__global__ __launch_bounds__(256) void k_gen_pack_bias(GenPackArgs a) {
-    const int C = a.C, row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= 2 * C) return;
-    const int layer = row / C, co = row % C;
-    const float* wg = layer ? a.glu_w2 : a.glu_w1;
-    const float* bet = layer ? a.beta2 : a.beta1;
-    double acc = 0;
-    for (int c = lane; c < C; c += 64) acc += (double)wg[(size_t)co * C + c] * (double)bet[c];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) (layer ? a.bg2 : a.bg1)[co] = (float)(acc + (double)(layer ? a.glu_b2 : a.glu_b1)[co]);
-}
+__global__ __launch_bounds__(256) void k_gen_pack(GenPackArgs a) { gen_pack_body<MODE>(a, blockIdx.x * 256 + threadIdx.x); }
+__global__ __launch_bounds__(256) void k_gen_pack_bias(GenPackArgs a) { gen_pack_bias_body(a, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63); }
 
 int launch_gen_pack(const GenPackArgs& a, int mode, hipStream_t st) {
     const int n = 2 * 9 * a.C * a.C;

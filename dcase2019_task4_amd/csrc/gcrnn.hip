@@ -9,6 +9,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "gkernels.h"
+#include "gpack.h"
 
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline size_t esz(const Geo& g) { return g.mode == SED_DTYPE_BF16 ? 2 : 4; }
@@ -151,13 +152,28 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
     // hipGraph capture, and ROCm 7.0's hipStreamEndCapture segfaults on that nested fork.  It stays on the caller's stream.)
     (void)ev_fork; (void)ev_join;
     ss = st;
-    SED_TRY(launch_gen_pack(pk, g.mode, ss));
+    // Training forwards: the packing (and the W_ih transposes below) ride in spare workgroups of block 0's moments launch
+    // (gpack.h; debug bit 15 keeps the stand-alone kernels for A/B timing).  Eval forwards have no moments launch.
+    const bool cluster_ = (H == 256) && !(g_sed_debug & 1024);
+    const bool aux_pack = train && (H == 64 || cluster_) && !(g_sed_debug & 32768);
+    GenAuxPack aux = {};
+    if (aux_pack) {
+        aux.pk = pk; aux.mode = g.mode; aux.n_gnt = 0;
+        if (H != 64)
+            for (int l = 0; l < g.L && l < 2; ++l) {
+                aux.gw0[l] = params + P.w_ih[l][0]; aux.gw1[l] = params + P.w_ih[l][1]; aux.gout[l] = CTXF(L.wihT[l]);
+                aux.gR[l] = 3 * H; aux.gN[l] = (l == 0) ? C : 2 * H;
+                aux.n_gnt = l + 1;
+            }
+    } else {
+        SED_TRY(launch_gen_pack(pk, g.mode, ss));
+    }
     // (debug bit 10: the streaming recurrence kernels instead of the cluster ones - A/B timing)
     const bool cluster = (H == 256) && !(g_sed_debug & 1024);
     if (H != 64 && !cluster)
         for (int l = 0; l < g.L; ++l)
             SED_TRY(launch_ggru_pack(params + P.w_hh[l][0], params + P.w_hh[l][1], CTXF(L.whh[l]), train ? CTXF(L.whhT[l]) : nullptr, H, ss));
-    if (H != 64 && train)
+    if (H != 64 && train && !aux_pack)
         for (int l = 0; l < g.L; ++l)
             SED_TRY(launch_gnt_pack_t(params + P.w_ih[l][0], params + P.w_ih[l][1], CTXF(L.wihT[l]), 3 * H, l == 0 ? C : 2 * H, ss));
 
@@ -165,7 +181,7 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
     SED_TRY(launch_blk0_forward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
                                 params + P.glu_w[0], params + P.glu_b[0], bn_running + 0, bn_running + C, trk[0], train, upd,
                                 seed_dev, CTXD(L.mom0), CTXD(L.mompart), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), CTXF(L.p[0]),
-                                use_drop ? CTXM(L.mask[0]) : nullptr, nullptr, st));
+                                use_drop ? CTXM(L.mask[0]) : nullptr, nullptr, st, 0, aux_pack ? &aux : nullptr));
     // ---- conv blocks 1, 2 -----------------------------------------------------------------------------------------------
     const size_t so[3] = {0, L.stat1, L.stat2};
     const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};

@@ -10,6 +10,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "gkernels.h"
+#include "gpack.h"
 
 #define GNT_KC 32
 #define GNT_S (GNT_KC + 1)
@@ -89,10 +90,7 @@ int launch_gnt_gemm(const GntBatch& gb, hipStream_t st) {
 // dX GEMM reads it k-contiguous
 __global__ __launch_bounds__(256) void k_gnt_pack_t(const float* __restrict__ w0, const float* __restrict__ w1, float* __restrict__ out,
                                                      int R, int N) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 2 * R * N) return;
-    const int dir = i / (R * N), e = i % (R * N), k = e / N, nn = e % N;
-    out[(size_t)nn * 2 * R + dir * R + k] = (dir ? w1 : w0)[e];
+    gnt_pack_t_body(w0, w1, out, R, N, blockIdx.x * 256 + threadIdx.x);
 }
 int launch_gnt_pack_t(const float* w0, const float* w1, float* out, int R, int N, hipStream_t st) {
     k_gnt_pack_t<<<(2 * R * N + 255) / 256, 256, 0, st>>>(w0, w1, out, R, N);

@@ -1,0 +1,94 @@
+// gpack.h - per-forward packing work of the generic kernel family as device functions, so that a training forward can run
+// it in spare workgroups of the k_x_moments launch (blk0.hip) instead of as launches of its own in front of block 0:
+// k_gen_pack + k_gen_pack_bias (+ two k_gnt_pack_t for H != 64) were 2 - 4 tiny kernels at the head of each model's chain,
+// and on the second model's chain - next to the first model's persistent one-workgroup-per-CU kernels, which leave no
+// registers for anything else on any CU - they were what made the teacher's chain finish ~50 us behind the student's
+// (profiles/r02_b_mt-bf16_step_timeline.txt).  Eval-mode forwards (no moments launch) keep the stand-alone kernels.
+#pragma once
+#include "gen.h"
+#include "gkernels.h"
+
+template <int MODE>
+__device__ __forceinline__ void gen_pack_body(const GenPackArgs& a, int i) {
+    using M = MM<MODE>;
+    using E = typename M::E;
+    const int C = a.C, CC = C * C;
+    if (i < a.n_zero) a.zero[i] = 0.0;
+    if (i == 0 && a.err) *a.err = 0;
+    if (i < 2 * 9 * CC) {
+        const int layer = i / (9 * CC), e = i % (9 * CC);
+        const int n = e / (9 * C), r = e % (9 * C), tap = r / C, k = r % C;
+        const float* w = layer ? a.w2 : a.w1;
+        E* wpk = (E*)(layer ? a.wpk2 : a.wpk1);
+        E* wpkT = (E*)(layer ? a.wpkT2 : a.wpkT1);
+        wpk[e] = M::cvt(w[((size_t)n * C + k) * 9 + tap]);
+        if (wpkT) wpkT[e] = M::cvt(w[((size_t)k * C + n) * 9 + (8 - tap)]);
+    }
+    if (i < 2 * CC) {
+        const int layer = i / CC, e = i % CC, co = e / C, c = e % C;
+        const float* wg = layer ? a.glu_w2 : a.glu_w1;
+        const float* gam = layer ? a.gamma2 : a.gamma1;
+        E* o = (E*)(layer ? a.wg2 : a.wg1);
+        E* oT = (E*)(layer ? a.wgT2 : a.wgT1);
+        o[e] = M::cvt(wg[e] * gam[c]);
+        if (oT) oT[(size_t)c * C + co] = M::cvt(wg[e]);
+    }
+}
+// bg[co] = bglu[co] + sum_c Wglu[co][c] beta[c]: one wave per (layer, co) row, coalesced reads, fp64 butterfly
+__device__ __forceinline__ void gen_pack_bias_body(const GenPackArgs& a, int row, int lane) {
+    const int C = a.C;
+    if (row >= 2 * C) return;
+    const int layer = row / C, co = row % C;
+    const float* wg = layer ? a.glu_w2 : a.glu_w1;
+    const float* bet = layer ? a.beta2 : a.beta1;
+    double acc = 0;
+    for (int c = lane; c < C; c += 64) acc += (double)wg[(size_t)co * C + c] * (double)bet[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) (layer ? a.bg2 : a.bg1)[co] = (float)(acc + (double)(layer ? a.glu_b2 : a.glu_b1)[co]);
+}
+// out[n][dir * R + k] = w_dir[k][n]  (R rows, N columns each): the two W_ih stacked along K and transposed
+__device__ __forceinline__ void gnt_pack_t_body(const float* __restrict__ w0, const float* __restrict__ w1, float* __restrict__ out,
+                                                int R, int N, int i) {
+    if (i >= 2 * R * N) return;
+    const int dir = i / (R * N), e = i % (R * N), k = e / N, nn = e % N;
+    out[(size_t)nn * 2 * R + dir * R + k] = (dir ? w1 : w0)[e];
+}
+
+// everything a training forward packs, as a list of 256-thread blocks: [pack][bias][gnt layer 0][gnt layer 1]
+struct GenAuxPack {
+    GenPackArgs pk;
+    int mode;
+    int n_gnt;                                  // 0 (H = 64: the recurrence kernels read W_ih themselves) or the number of GRU layers
+    const float *gw0[2], *gw1[2];
+    float* gout[2];
+    int gR[2], gN[2];
+};
+__host__ __device__ inline int gen_aux_pack_blocks(const GenAuxPack& a) {
+    const int n = 2 * 9 * a.pk.C * a.pk.C;
+    return ((n > a.pk.n_zero ? n : a.pk.n_zero) + 255) / 256;
+}
+__host__ __device__ inline int gen_aux_bias_blocks(const GenAuxPack& a) { return (2 * a.pk.C + 3) / 4; }
+__host__ __device__ inline int gen_aux_gnt_blocks(const GenAuxPack& a, int l) { return l < a.n_gnt ? (2 * a.gR[l] * a.gN[l] + 255) / 256 : 0; }
+__host__ __device__ inline int gen_aux_blocks(const GenAuxPack& a) {
+    return gen_aux_pack_blocks(a) + gen_aux_bias_blocks(a) + gen_aux_gnt_blocks(a, 0) + gen_aux_gnt_blocks(a, 1);
+}
+__device__ __forceinline__ void gen_aux_body(const GenAuxPack& a, int pb, int tid) {
+    int b = pb;
+    const int np = gen_aux_pack_blocks(a);
+    if (b < np) {
+        if (a.mode == 1) gen_pack_body<1>(a.pk, b * 256 + tid);
+        else gen_pack_body<0>(a.pk, b * 256 + tid);
+        return;
+    }
+    b -= np;
+    const int nbias = gen_aux_bias_blocks(a);
+    if (b < nbias) { gen_pack_bias_body(a.pk, b * 4 + (tid >> 6), tid & 63); return; }
+    b -= nbias;
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        const int ng = gen_aux_gnt_blocks(a, l);
+        if (b < ng) { gnt_pack_t_body(a.gw0[l], a.gw1[l], a.gout[l], a.gR[l], a.gN[l], b * 256 + tid); return; }
+        b -= ng;
+    }
+}

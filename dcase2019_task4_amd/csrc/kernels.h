@@ -7,13 +7,15 @@
 struct ConvPackArgs;
 int x_moments_parts(const Geo& g);
 // pack != null: the conv1 / conv2 weight packing (independent work of the same step) rides along as extra workgroups
-int launch_x_moments(const Geo& g, const float* x, double* mompart, const ConvPackArgs* pack, hipStream_t st);
+struct GenAuxPack;   // gpack.h: the generic kernel set's per-forward packing, run in spare workgroups of the moments launch
+int launch_x_moments(const Geo& g, const float* x, double* mompart, const ConvPackArgs* pack, hipStream_t st,
+                     const GenAuxPack* aux = nullptr);
 int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const float* b0, const float* gamma,
                         const float* beta, const float* wglu, const float* bglu, float* run_mean, float* run_var,
                         int64_t* tracked, int train, int update, const uint64_t* seed, double* mom, double* mompart,
                         float* wz, float* wl, float* bn, float* p0, uint16_t* mask_out, const ConvPackArgs* pack /* train only */,
                         hipStream_t st,
-                        int main_kernel_only = 0);
+                        int main_kernel_only = 0, const GenAuxPack* aux = nullptr);
 int launch_blk0_backward(const Geo& g, const float* x, const float* w0, const float* b0, const float* gamma,
                          const float* beta, const float* wglu, const uint16_t* mask_in, const double* mom,
                          const float* wz, const float* wl, const float* bn, const float* dp0, double* de, int zero_de,

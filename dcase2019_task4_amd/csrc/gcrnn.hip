@@ -319,11 +319,10 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
     if (!(parts & 1)) SED_CHECK_HIP(hipMemsetAsync(WSD(W.de0), 0, 2 * C * 10 * sizeof(double), st));
     const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};
     for (int i = 2; i >= 1; --i) {
-        // (H = 64: the GRU's dX arrives as two direction planes; the generic GLU backward takes one tensor)
-        if (i == 2 && H == 64) SED_TRY(launch_gen_add2(WSF(W.dp[2]), WSF(W.dp[2]) + (size_t)BT * C, (size_t)BT * C, st));
+        // (H = 64: the GRU's dX arrives as two direction planes; the GLU backward adds them while loading)
         SED_TRY(launch_gglu_bwd(g.mode, C, CTXF(L.y[i]), CTXF(L.bn[i]), params + P.bn_g[i], params + P.bn_b[i], CTXV(L.wg[i]),
                                 CTXV(L.wgT[i]), CTXF(L.bg[i]), WSF(W.dp[i]), WSF(W.dz[i]), WSF(W.glu_part), g.B, Hs[i], Wd[i], use_drop,
-                                g.p, CTXM(L.mask[i]), st));
+                                g.p, CTXM(L.mask[i]), st, (i == 2 && H == 64) ? WSF(W.dp[2]) + (size_t)BT * C : nullptr));
         GBnBwdArgs pa;
         pa.part = WSF(W.glu_part); pa.n_part = gglu_bwd_grid(g.B, Hs[i], Wd[i]); pa.C = C; pa.N = (double)g.B * Hs[i] * Wd[i];
         pa.part2 = WSF(W.glu_part2);

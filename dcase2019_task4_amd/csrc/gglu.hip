@@ -225,7 +225,7 @@ template <int MODE, int C>
 __global__ __launch_bounds__(256) void k_gglu_bwd(const float* __restrict__ y, const float* __restrict__ bn,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const void* __restrict__ wg_v, const void* __restrict__ wgT_v,
-                                                   const float* __restrict__ bg, const float* __restrict__ dp,
+                                                   const float* __restrict__ bg, const float* __restrict__ dp, const float* __restrict__ dp2,
                                                    float* __restrict__ dz, float* __restrict__ part, int H, int W, int Ho, int Wo,
                                                    int Q, int use_drop, float p_drop, const uint16_t* __restrict__ mask_in) {
     using Cfg = GGluBwdCfg<MODE, C>;
@@ -317,7 +317,11 @@ __global__ __launch_bounds__(256) void k_gglu_bwd(const float* __restrict__ y, c
         for (int nb = 0; nb < NBW; ++nb) {
             const int c = 32 * (nb0 + nb) + n;
 #pragma unroll
-            for (int jx = 0; jx < 4; ++jx) gq[nb][jx] = (live && q0 + jx < Q) ? dp[(size_t)(q0 + jx) * C + c] * sc : 0.f;
+            for (int jx = 0; jx < 4; ++jx) {
+                const size_t e = (size_t)(q0 + jx) * C + c;
+                // dp2: the second direction plane of gru4.hip's dX (H = 64), added while loading
+                gq[nb][jx] = (live && q0 + jx < Q) ? (dp2 ? dp[e] + dp2[e] : dp[e]) * sc : 0.f;
+            }
             mk[nb] = (use_drop && live) ? (uint32_t)mask_in[((size_t)rb * NB + nb0 + nb) * 64 + lane] : 0xffffu;
         }
         // ---- P1: lin = xhat @ wg^T (this wave's channel half) -------------------------------------------------------------
@@ -448,7 +452,7 @@ int gglu_bwd_grid(int B, int H, int W) {
 
 template <int MODE, int C>
 static int gglu_bwd_launch(const float* y, const float* bn, const float* gamma, const float* beta, const void* wg, const void* wgT,
-                           const float* bg, const float* dp, float* dz, float* part, int B, int H, int W, int use_drop,
+                           const float* bg, const float* dp, const float* dp2, float* dz, float* part, int B, int H, int W, int use_drop,
                            float p_drop, const uint16_t* mask_in, hipStream_t st) {
     using Cfg = GGluBwdCfg<MODE, C>;
     static_assert(Cfg::LDS_BYTES <= 160 * 1024, "GLU backward tiles exceed the LDS");
@@ -458,7 +462,7 @@ static int gglu_bwd_launch(const float* y, const float* bn, const float* gamma, 
         attr = true;
     }
     const int Ho = H / 2, Wo = W / 4, Q = B * Ho * Wo;
-    k_gglu_bwd<MODE, C><<<gglu_bwd_grid(B, H, W), 256, Cfg::LDS_BYTES, st>>>(y, bn, gamma, beta, wg, wgT, bg, dp, dz, part, H, W, Ho,
+    k_gglu_bwd<MODE, C><<<gglu_bwd_grid(B, H, W), 256, Cfg::LDS_BYTES, st>>>(y, bn, gamma, beta, wg, wgT, bg, dp, dp2, dz, part, H, W, Ho,
                                                                              Wo, Q, use_drop, p_drop, mask_in);
     SED_CHECK_LAUNCH();
     return SED_OK;
@@ -466,9 +470,9 @@ static int gglu_bwd_launch(const float* y, const float* bn, const float* gamma, 
 
 int launch_gglu_bwd(int mode, int C, const float* y, const float* bn, const float* gamma, const float* beta, const void* wg,
                     const void* wgT, const float* bg, const float* dp, float* dz, float* part, int B, int H, int W, int use_drop,
-                    float p_drop, const uint16_t* mask_in, hipStream_t st) {
+                    float p_drop, const uint16_t* mask_in, hipStream_t st, const float* dp2) {
 #define GGLU_CASE(MD, CC) \
-    if (mode == MD && C == CC) return gglu_bwd_launch<MD, CC>(y, bn, gamma, beta, wg, wgT, bg, dp, dz, part, B, H, W, use_drop, p_drop, mask_in, st)
+    if (mode == MD && C == CC) return gglu_bwd_launch<MD, CC>(y, bn, gamma, beta, wg, wgT, bg, dp, dp2, dz, part, B, H, W, use_drop, p_drop, mask_in, st)
     GGLU_CASE(0, 64); GGLU_CASE(0, 128); GGLU_CASE(1, 64); GGLU_CASE(1, 128);
 #undef GGLU_CASE
     sed_set_error("gglu backward: unsupported mode %d / channels %d", mode, C);

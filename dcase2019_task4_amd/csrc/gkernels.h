@@ -36,7 +36,7 @@ int gglu_bwd_grid(int B, int H, int W);
 // part: [grid][C * C + 3 * C] floats (per-workgroup partial sums: dWx | sdb | sdz | sdzx)
 int launch_gglu_bwd(int mode, int C, const float* y, const float* bn, const float* gamma, const float* beta, const void* wg,
                     const void* wgT, const float* bg, const float* dp, float* dz, float* part, int B, int H, int W, int use_drop,
-                    float p_drop, const uint16_t* mask_in, hipStream_t st);
+                    float p_drop, const uint16_t* mask_in, hipStream_t st, const float* dp2 = nullptr);
 #define GPART_SLICES 8
 struct GBnBwdArgs {
     const float* part; int n_part; int C; double N;

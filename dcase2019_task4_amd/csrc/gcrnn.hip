@@ -363,20 +363,3 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
     return SED_OK;
 }
 
-// dst += src (n floats, n % 4 == 0): the two direction planes of gru.hip's dX
-__global__ __launch_bounds__(256) void k_gen_add2(float* __restrict__ dst, const float* __restrict__ src, size_t n4) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        f32x4 a = ((const f32x4*)dst)[i];
-        const f32x4 b = ((const f32x4*)src)[i];
-        a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
-        ((f32x4*)dst)[i] = a;
-    }
-}
-int launch_gen_add2(float* dst, const float* src, size_t n, hipStream_t st) {
-    const size_t n4 = n / 4;
-    int grid = (int)((n4 + 255) / 256);
-    if (grid > 1024) grid = 1024;
-    k_gen_add2<<<grid, 256, 0, st>>>(dst, src, n4);
-    SED_CHECK_LAUNCH();
-    return SED_OK;
-}

@@ -72,7 +72,6 @@ int launch_gnt_pack_t(const float* w0, const float* w1, float* out, int R, int N
 
 // gcrnn.hip ---------------------------------------------------------------------------------------------------------------
 struct HeadsLoss;
-int launch_gen_add2(float* dst, const float* src, size_t n, hipStream_t st);
 size_t gen_ctx_bytes(const Geo& g);
 size_t gen_ws_bytes(const Geo& g);
 int gen_ctx_view(const Geo& g, const char* name, size_t* offset, size_t* bytes);

@@ -585,6 +585,56 @@ def test_data_parallel_schedule_on_rccl_one_rank_matches_single_process(monkeypa
             dist.destroy_process_group()
 
 
+def test_data_parallel_capture_failure_falls_back_to_eager_single(monkeypatch):
+    """The safety net of the data-parallel default: if capturing the step with its collectives fails (simulated here by a
+    step body that raises while its stream is capturing), every rank drops to "single" with an eager all-reduce between
+    two graph segments - and still reproduces the single-process step bit for bit."""
+    import torch.distributed as dist
+    from dcase2019_task4_amd.train import MeanTeacherStep
+    monkeypatch.setenv("SED_FORCE_DP", "1")
+    monkeypatch.setenv("SED_DP_CAPTURE", "1")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29579")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+
+    class Flaky(MeanTeacherStep):
+        def _dp_step_body(self):
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("simulated: this collective cannot be captured")
+            return super()._dp_step_body()
+
+    try:
+        B, T = 8, 216
+        tgt, wm, sm = synth.make_target(2, B, T // 8)
+        xs = [synth.make_input(80 + i, B, T).cuda() for i in range(4)]
+        xe = [synth.make_input(90 + i, B, T).cuda() for i in range(4)]
+
+        def run(cls, pg, graph):
+            s, _ = gu.make_model(0, dropout=0.5)
+            t, _ = gu.make_model(1, dropout=0.5)
+            s.train(); t.train()
+            st = cls(s, t, B, T, 40, wm, sm, seed=7, use_graph=graph, process_group=pg)
+            if graph:
+                st._warm = 2
+            for i in range(4):
+                st.step(xs[i], xe[i], tgt.cuda())
+            torch.cuda.synchronize()
+            return s._flat.clone(), t._flat.clone(), st.grads.clone(), st
+
+        ref = run(MeanTeacherStep, None, False)
+        got = run(Flaky, dist.group.WORLD, True)
+        st = got[3]
+        assert not st.dp_capture and st.dp_schedule == "single" and "simulated" in (st._capture_error or "")
+        assert st._graph_a is not None and st._graph_b is not None
+        for a, b in zip(got[:3], ref[:3]):
+            assert torch.equal(a, b)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_weights_init_apply_reaches_the_flat_buffer():
     """main.py:282-283 calls crnn.apply(weights_init) (utils/utils.py:205-224: dispatch on class-name substrings, in-place
     writes through .weight / .bias / .parameters()).  On a module that is ALREADY on the GPU and flattened, those writes

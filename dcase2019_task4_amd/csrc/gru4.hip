@@ -37,6 +37,13 @@
 // I/O slices at 15 - 20 ns.  Measured now: forward 320 / 360 ns per step + 6.0 / 7.3 us fixed, backward 390 / 420 ns + 9 us.
 #include "common.h"
 #include "kernels.h"
+#include <type_traits>
+SED_TS_DEFINE(gru4)
+#ifdef SED_TS
+#define TSW(k, t) do { if (threadIdx.x == (t) && blockIdx.y == 0 && blockIdx.x < 1024) g_ts[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define TSW(k, t) do { } while (0)
+#endif
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -333,6 +340,7 @@ __global__ __launch_bounds__(G4B_THREADS) void k_gru4_bwd(const float* __restric
     const int l = tid & 63;
     const int nblk = (T + G4_SB - 1) / G4_SB;
     auto t_of = [&](int step) { return dir ? step : (T - 1 - step); };     // reverse of the forward order
+    TSW(0, 0);
 
     if (role == 4 || role == 5) {
         // ================================ I/O waves =========================================================
@@ -415,6 +423,7 @@ __global__ __launch_bounds__(G4B_THREADS) void k_gru4_bwd(const float* __restric
                 for (int s = sb + ((sb ^ io) & 1); s < G4_SB; s += 2) put_row(blk - 1, s);
             for (int s = io; s < sb; s += 2) put_row(blk, s);
         }
+        TSW(4, 256);
         return;
     }
     if (role >= 6) {
@@ -433,7 +442,9 @@ __global__ __launch_bounds__(G4B_THREADS) void k_gru4_bwd(const float* __restric
         float* plane = dx_planes + (size_t)dir * B * T * NIN;
         __syncthreads();
         // n_sync: how many of the 16 slices end with a barrier (the time steps of the block running meanwhile)
-        auto gemm_block = [&](int blk, int n_sync) {
+        auto gemm_block = [&](int blk, int n_sync, auto sync_tag) {
+            constexpr bool SYNC = decltype(sync_tag)::value;      // false: the tail call - no barrier code in the loop, so the 48 LDS
+                                                                  // reads are hoisted ahead of the MFMAs instead of one exposed read each
             const int s0 = blk * G4_SB, sb = min(G4_SB, T - s0);
             const float* hp = hist + (blk & 1) * G4_SB * G4_HS + i16 * G4_HS + kq;
             const bool rowok = i16 < sb;
@@ -447,7 +458,7 @@ __global__ __launch_bounds__(G4B_THREADS) void k_gru4_bwd(const float* __restric
 #pragma unroll
                 for (int c = 0; c < CT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[c][s4], acc[c], 0, 0, 0);
 #endif
-                if ((s4 + 1) % 3 == 0 && (s4 + 1) / 3 <= n_sync) lds_barrier();
+                if (SYNC && (s4 + 1) % 3 == 0 && (s4 + 1) / 3 <= n_sync) lds_barrier();
             }
             // D: lane (j = i16, rows 4 kq + r) -> time step s0 + 4 kq + r of the block
 #pragma unroll
@@ -462,11 +473,13 @@ __global__ __launch_bounds__(G4B_THREADS) void k_gru4_bwd(const float* __restric
         };
         for (int blk = 0; blk < nblk; ++blk) {
             const int sb = min(G4_SB, T - blk * G4_SB);
-            if (blk > 0) gemm_block(blk - 1, sb);
+            if (blk > 0) gemm_block(blk - 1, sb, std::true_type{});
             else
                 for (int s = 0; s < sb; ++s) lds_barrier();
         }
-        gemm_block(nblk - 1, 0);
+        TSW(5, 384);
+        gemm_block(nblk - 1, 0, std::false_type{});
+        TSW(6, 384);
         return;
     }
     // ==================================== recurrence waves ===================================================
@@ -480,7 +493,9 @@ __global__ __launch_bounds__(G4B_THREADS) void k_gru4_bwd(const float* __restric
     for (int e = tid; e < 192; e += 256) zero[e] = 0.f;
 #pragma unroll
     for (int i = 0; i < 48; ++i) asm volatile("" : "+v"(wt[i]));      // pin the load waits before the loop
+    TSW(7, 0);
     __syncthreads();
+    TSW(1, 0);
     __builtin_amdgcn_s_setprio(3);
     // the unit's seven values of a step go out in two ds_writes: row kq writes (dr, dr) / (dz, dz) / (dn, dgh_n) / (hp, hp)
     const int wofs1 = (kq < 3) ? 64 * kq + j : 384 + j;
@@ -529,7 +544,9 @@ __global__ __launch_bounds__(G4B_THREADS) void k_gru4_bwd(const float* __restric
             dout = n_dout; r = n_r; z = n_z; nn = n_nn; ghn = n_ghn; hp = n_hp;
             lds_barrier();
         }
+        if (blk == 0) TSW(2, 0);
     }
+    TSW(3, 0);
 }
 
 template <int NIN> static constexpr size_t gru4_fwd_lds() { return (size_t)(64 + 2 * G4_SB * 192 + 2 * G4_SB * 320 + 2 * G4_SB * (NIN + 4)) * sizeof(float); }

@@ -57,18 +57,6 @@ CONFIGS = {   # name -> (wide, mfma dtype, from waveform, default batch per GPU)
 }
 PEAK_HBM_GBS = 8000.0
 
-# kernel launches per mean-teacher step (profiles/r01_j_step_timeline.txt) - used to add the committed per-launch PMC
-# traffic figures up to a per-step figure
-LAUNCHES_PER_STEP = {
-    "k_x_moments": 2, "k_blk0_prep": 2, "void k_blk0_fwd<2, 1, true, 0>": 2,
-    "void k_conv_wino<16, 0>": 2, "void k_conv_wino<4, 0>": 2,
-    "k_glu_pool_fwd": 4, "void k_gru4_fwd<64>": 2, "void k_gru4_fwd<128>": 2, "void k_heads_fwd<128>": 2, "void k_heads_bwd<128>": 1,
-    "void k_gru4_bwd<128>": 1, "void k_gru4_bwd<64>": 1, "k_glu_pool_bwd8": 2, "void k_wgrad_wino<4>": 1,
-    "void k_conv_wino<4, 1>": 1, "k_wgrad_reduce": 2, "k_colsum": 1, "k_gemm_batched": 2, "k_gemm_reduce": 2,
-    "void k_conv_wino<16, 1>": 1, "void k_blk0_bwd<2, 0>": 1, "k_blk0_bwd_finalize": 1, "void k_wgrad_wino<16>": 1,
-    "void k_adam_ema<true>": 1,
-}
-
 
 def synthetic_batch(B, T, seed, device):
     """x ~ N(0,1) (already-normalised log-mel), teacher input = a second draw,
@@ -258,17 +246,24 @@ def kernel_roofline(step, iters=20):
 
 
 def pmc_step_traffic():
-    """HBM bytes per step from the committed PMC passes (profiles/pmc_traffic.json, per launch: 2 x FETCH_SIZE +
-    WRITE_SIZE as MI355X_MICROARCH.md prescribes) times the launches per step."""
+    """HBM bytes per step from the committed PMC passes (profiles/pmc_traffic.json, written by tools/summarize_pmc.py from
+    two rocprofv3 --pmc passes of THIS bench command: 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes).
+    The per-step figure is the sum over every dispatch of the traced run divided by the steps it ran - the launches per
+    step come out of the trace itself ("_per_step"), nothing is maintained by hand here."""
     pmc_file = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if not os.path.exists(pmc_file):
         return None, None
     table = json.load(open(pmc_file))
-    total = 0
-    for k, n in LAUNCHES_PER_STEP.items():
-        if k in table:
-            total += n * (table[k]["read_bytes"] + table[k]["write_bytes"])
-    return total, table
+    per_step = table.get("_per_step")
+    return (int(per_step["bytes"]) if per_step else None), table
+
+
+def free_port():
+    """A TCP port nothing listens on right now (bind to port 0 on the loopback and let the kernel pick)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 
 
 def self_launch(args):
@@ -276,7 +271,7 @@ def self_launch(args):
     n_dev = torch.cuda.device_count()
     if n_dev < args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but only {n_dev} GPU(s) are visible")
-    port = int(os.environ.get("MASTER_PORT", "0")) or (29500 + os.getpid() % 2000)
+    port = int(os.environ.get("MASTER_PORT", "0")) or free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
@@ -298,12 +293,30 @@ def time_steps(step, steps, world, device):
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
     barrier()
+    per_rank = [elapsed]
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        tl = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(tl, t)
+        per_rank = [float(v.item()) for v in tl]
+        elapsed = max(per_rank)
+    time_steps.per_rank = per_rank
     return elapsed
+
+
+def same_on_all_ranks(step, world, device):
+    """Every rank must have ended on the same data-parallel schedule (a rank that fell back alone would deadlock or, worse,
+    reduce different buckets): gather (schedule, captured) and fail loudly on any difference."""
+    mine = (step.dp_schedule, bool(step.dp_capture))
+    if world == 1:
+        return [mine]
+    import torch.distributed as dist
+    allv = [None] * world
+    dist.all_gather_object(allv, mine)
+    if any(v != allv[0] for v in allv):
+        raise SystemExit(f"[bench] data-parallel schedules differ across ranks: {allv}")
+    return allv
 
 
 def main():
@@ -364,8 +377,36 @@ def main():
     for _ in range(max(args.warmup, 3)):       # >= 3: two eager warm-ups + graph capture/first replay
         runner.run()
     elapsed = time_steps(runner, args.steps, world, device)
+    per_rank_s = list(time_steps.per_rank)
     meters = step.meters()
     assert np.isfinite(meters["loss"]), meters
+    step.check_health()
+    schedules = same_on_all_ranks(step, world, device) if step.dp else None
+
+    # N > 1: the same workload under the other data-parallel schedules, so that ONE driver run yields the comparison
+    # (captured overlap = the default above | single all-reduce, eager | overlap with eager collectives)
+    ab_legs = None
+    if world > 1 and headline and not args.no_extras and args.batch is None:
+        ab_legs = {}
+        for tag, sched, cap in (("single_eager", "single", "0"), ("overlap_eager", "overlap", "0")):
+            try:
+                os.environ["SED_DP_CAPTURE"] = cap
+                sa, ta = build_models(device, seed=0)
+                stp = MeanTeacherStep(sa, ta, B, T_FRAMES, rampup_length=210 * 100 // 2, weak_mask=wm, strong_mask=sm,
+                                      seed=1234, use_graph=not args.no_graph, process_group=pg, dp_schedule=sched)
+                stp.load_batch(x, xe, tgt)
+                for _ in range(5):
+                    stp.run()
+                na = max(50, args.steps // 4)
+                ela = time_steps(stp, na, world, device)
+                same_on_all_ranks(stp, world, device)
+                ab_legs[tag] = {"value": round(B * world * na / ela, 1), "unit": "clips/s", "ms_per_step": round(ela / na * 1e3, 4),
+                                "steps": na, "dp_schedule": stp.dp_schedule, "dp_collectives": "captured" if stp.dp_capture else "eager"}
+                del stp
+            except Exception as e:                      # noqa: BLE001 - the headline line must not depend on these legs
+                ab_legs[tag] = {"error": repr(e)[:300]}
+            finally:
+                os.environ.pop("SED_DP_CAPTURE", None)
 
     config3 = None
     if world > 1 and headline and not args.no_extras and args.batch is None:
@@ -410,6 +451,12 @@ def main():
         }
         if dist_info:
             res["distributed"] = dist_info
+            dist_info["ms_per_step_per_rank"] = {"min": round(min(per_rank_s) / args.steps * 1e3, 4),
+                                                 "max": round(max(per_rank_s) / args.steps * 1e3, 4),
+                                                 "all": [round(v / args.steps * 1e3, 4) for v in per_rank_s]}
+            dist_info["schedule_per_rank"] = [f"{a}/{'captured' if b else 'eager'}" for a, b in (schedules or [])]
+            if ab_legs:
+                dist_info["schedule_ab"] = ab_legs
             if getattr(step, "_capture_error", None):
                 res["distributed"]["capture_fallback"] = step._capture_error[:200]
         if config3:

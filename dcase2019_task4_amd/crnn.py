@@ -104,6 +104,8 @@ class _CRNNFunction(torch.autograd.Function):
         if ctx_bytes == 0:
             raise _lib.SedError(l.sed_last_error().decode())
         cbuf = torch.empty(ctx_bytes, device=x.device, dtype=torch.uint8)
+        _lib.check(l.sed_crnn_buffers_init(C.byref(dims), _lib.ptr(cbuf), ctx_bytes, None, 0, _lib.stream_ptr()),
+                   "sed_crnn_buffers_init")
         _lib.check(l.sed_crnn_forward(C.byref(dims), _lib.ptr(module._flat), _lib.ptr(module._bn_flat),
                                       _lib.ptr(module._bn_tracked), _lib.ptr(x), int(train), 1, _lib.ptr(seed_t),
                                       _lib.ptr(cbuf), ctx_bytes, _lib.ptr(strong), _lib.ptr(weak), _lib.stream_ptr()),
@@ -138,6 +140,8 @@ class _CRNNFunction(torch.autograd.Function):
         gflat = torch.empty_like(module._flat)
         ws_bytes = l.sed_crnn_bwd_ws_bytes(C.byref(dims))
         ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
+        _lib.check(l.sed_crnn_buffers_init(C.byref(dims), None, 0, _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),
+                   "sed_crnn_buffers_init")
         _lib.check(l.sed_crnn_backward(C.byref(dims), _lib.ptr(module._flat), _lib.ptr(x), _lib.ptr(ctx.seed_t),
                                        _lib.ptr(ctx.cbuf), ctx.cbuf.numel(), _lib.ptr(d_strong), _lib.ptr(d_weak),
                                        _lib.ptr(gflat), _lib.ptr(ws), ws_bytes, 3, _lib.stream_ptr()),
@@ -314,6 +318,15 @@ class CRNN(nn.Module):
         params = list(self.parameters())
         strong, weak = _CRNNFunction.apply(self, x, self.training, seed_t, *params)
         return strong, weak
+
+    def check_recurrence(self):
+        """Raise if the wide model's cluster recurrence of the LAST forward timed out on a cross-workgroup wait (it then
+        used a stale hidden state).  Eval / debugging aid for the drop-in path; MeanTeacherStep.check_health is the
+        training-loop counterpart."""
+        if self._H == 256 and self._last_ctx is not None:
+            n = int(self.ctx_view("gru_err").view(torch.int32)[0].item())
+            if n:
+                raise _lib.SedError(f"cluster GRU recurrence: {n} cross-workgroup waits timed out; the outputs are invalid")
 
     def ctx_view(self, name):
         """Test hook: float32 (or float64 for 'mom0'/'stat*') view of an intermediate of the last forward."""

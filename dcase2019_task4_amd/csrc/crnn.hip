@@ -149,6 +149,13 @@ extern "C" size_t sed_crnn_bwd_ws_bytes(const sed_dims* d) {
     return g.generic ? gen_ws_bytes(g) : make_ws_layout(g).total;
 }
 
+extern "C" int sed_crnn_buffers_init(const sed_dims* d, void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes, void* stream) {
+    SED_TRY(sed_validate_dims(d));
+    const Geo g = make_geo(d);
+    if (g.generic) return gen_buffers_init(g, ctx, ctx_bytes, ws, ws_bytes, (hipStream_t)stream);
+    return SED_OK;                             // the specialised kernel set writes everything before it reads it
+}
+
 extern "C" int sed_crnn_ctx_view(const sed_dims* d, const char* name, size_t* offset, size_t* bytes) {
     SED_TRY(sed_validate_dims(d));
     SED_CHECK_ARG(name && offset && bytes, "null argument");
@@ -337,7 +344,7 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
         const int nin = (l == 0) ? 64 : 128;
         const float* input = (l == 0) ? CTXF(L.p2) : CTXF(L.out[l - 1]);
         GemmBatch gb;
-        gb.n_prob = 4; gb.splits = SED_GRU_SPLITK; gb.part = WSF(W.gemm_part); gb.part_stride = 0;
+        gb.n_prob = 4; gb.splits = SED_GRU_SPLITK; gb.part = WSF(W.gemm_part); gb.part_floats = gemm_part_floats(4, SED_GRU_SPLITK, 192, 129); gb.part_stride = 0;
         for (int dir = 0; dir < 2; ++dir) {
             gb.p[2 * dir] = gemm_prob(WSF(W.dgi[l]) + dir * 192, 1, 384, input, nin, 1, grads + P.w_ih[l][dir], nin, 192, nin, BT);
             gb.p[2 * dir].Cones = grads + P.b_ih[l][dir];

@@ -14,6 +14,13 @@
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline size_t esz(const Geo& g) { return g.mode == SED_DTYPE_BF16 ? 2 : 4; }
 static inline int gru_splitk(const Geo& g) { return g.H == 64 ? SED_GRU_SPLITK : 4; }
+// split-K partials of the GRU weight-gradient batch: the W_ih problems have N = nin (C, or 2H for layer 1), the W_hh
+// problems N = H - the batch's stride is set by the LARGEST of them (with one layer and H > C that is H, not C)
+static inline size_t gru_gemm_part_floats(const Geo& g) {
+    int max_n = g.H > g.C ? g.H : g.C;
+    if (g.L > 1 && 2 * g.H > max_n) max_n = 2 * g.H;
+    return gemm_part_floats(4, gru_splitk(g), 3 * g.H, max_n + 1);
+}
 
 struct GCtx {
     size_t acc0, mom0, stat1, stat2;          // fp64: patch moments of block 0 | BatchNorm sums of blocks 1, 2
@@ -86,8 +93,7 @@ static GWs make_gws(const Geo& g) {
     put(W.glu_part2, (size_t)GPART_SLICES * (C * C + 3 * C) * 4);
     put(W.de0, 2 * C * 10 * sizeof(double));
     put(W.wg_part, (size_t)gwgrad_slabs(g.C) * 9 * C * C * 4);
-    const size_t max_nin = (size_t)(g.L > 1 ? (2 * H > C ? 2 * H : C) : C);
-    put(W.gemm_part, gemm_part_floats(4, gru_splitk(g), 3 * (int)H, (int)max_nin + 1) * 4);
+    put(W.gemm_part, gru_gemm_part_floats(g) * 4);
     for (int l = 0; l < 2; ++l) { put(W.xch[l], g.H == 256 ? gclu_xch_bytes(g.B, g.H, 1) : 0); put(W.epoch[l], (size_t)2 * g.B * 4); }
     W.total = o;
     return W;
@@ -111,6 +117,31 @@ int gen_ctx_view(const Geo& g, const char* name, size_t* offset, size_t* bytes) 
         if (strcmp(t.n, name) == 0) { *offset = t.o; *bytes = t.b; return SED_OK; }
     sed_set_error("sed_crnn_ctx_view: unknown buffer '%s'", name);
     return SED_ERR_BAD_ARG;
+}
+
+// Regions the library needs INITIALISED before the first forward / backward on a fresh buffer (everything else is written
+// before it is read): the cluster recurrence's exchange granules + launch epochs (a stale word that happened to carry a
+// matching tag would be consumed as a fresh value) and the sticky spin-timeout counter.
+int gen_buffers_init(const Geo& g, void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (ctx) {
+        const GCtx L = make_gctx(g);
+        if (ctx_bytes < L.total) { sed_set_error("sed_crnn_buffers_init: ctx has %zu bytes, needs %zu", ctx_bytes, L.total); return SED_ERR_WORKSPACE; }
+        // xch[0] .. err are laid out back to back apart from the small per-layer W_ih transposes: clear each piece
+        for (int l = 0; l < 2; ++l) {
+            if (g.H == 256) SED_CHECK_HIP(hipMemsetAsync((char*)ctx + L.xch[l], 0, gclu_xch_bytes(g.B, g.H, 0), st));
+            SED_CHECK_HIP(hipMemsetAsync((char*)ctx + L.epoch[l], 0, (size_t)2 * g.B * 4, st));
+        }
+        SED_CHECK_HIP(hipMemsetAsync((char*)ctx + L.err, 0, 256, st));
+    }
+    if (ws) {
+        const GWs W = make_gws(g);
+        if (ws_bytes < W.total) { sed_set_error("sed_crnn_buffers_init: ws has %zu bytes, needs %zu", ws_bytes, W.total); return SED_ERR_WORKSPACE; }
+        for (int l = 0; l < 2; ++l) {
+            if (g.H == 256) SED_CHECK_HIP(hipMemsetAsync((char*)ws + W.xch[l], 0, gclu_xch_bytes(g.B, g.H, 1), st));
+            SED_CHECK_HIP(hipMemsetAsync((char*)ws + W.epoch[l], 0, (size_t)2 * g.B * 4, st));
+        }
+    }
+    return SED_OK;
 }
 
 #define CTXF(off) ((float*)((char*)ctx + (off)))
@@ -146,7 +177,7 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
     pk.wgT1 = train ? CTXV(L.wgT[1]) : nullptr; pk.wgT2 = train ? CTXV(L.wgT[2]) : nullptr;
     pk.bg1 = CTXF(L.bg[1]); pk.bg2 = CTXF(L.bg[2]);
     pk.zero = CTXD(L.stat1); pk.n_zero = train ? 4 * C : 0;
-    pk.err = (int*)CTXV(L.err);
+    pk.err = nullptr;                         // sticky: never cleared by a forward (sed_crnn_buffers_init does)
     // (The packing is independent of block 0, but forking it onto the helper stream is not an option: a forward that
     // itself runs on a forked stream - the teacher's, next to the student's - would fork a second time inside the same
     // hipGraph capture, and ROCm 7.0's hipStreamEndCapture segfaults on that nested fork.  It stays on the caller's stream.)
@@ -296,7 +327,7 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
             const int nin = (l == 0) ? C : 2 * H;
             const float* input = (l == 0) ? CTXF(L.p[2]) : CTXF(L.out[l - 1]);
             GemmBatch gb;
-            gb.n_prob = 4; gb.splits = gru_splitk(g); gb.part = WSF(W.gemm_part); gb.part_stride = 0;
+            gb.n_prob = 4; gb.splits = gru_splitk(g); gb.part = WSF(W.gemm_part); gb.part_floats = gru_gemm_part_floats(g); gb.part_stride = 0;
             for (int dir = 0; dir < 2; ++dir) {
                 gb.p[2 * dir] = gemm_prob(WSF(W.dgi[l]) + dir * 3 * H, 1, 6 * H, input, nin, 1, grads + P.w_ih[l][dir], nin, 3 * H, nin, BT);
                 gb.p[2 * dir].Cones = grads + P.b_ih[l][dir];

@@ -367,6 +367,11 @@ int launch_gemm_batch(GemmBatch& gb, hipStream_t st) {
     if (gb.splits > 1) {
         SED_CHECK_ARG(gb.part != nullptr, "split-K gemm needs a partial buffer");
         gb.part_stride = (size_t)maxM * maxNx;
+        if ((size_t)gb.n_prob * gb.splits * gb.part_stride > gb.part_floats) {
+            sed_set_error("split-K gemm: partial buffer holds %zu floats, the batch needs %zu", gb.part_floats,
+                          (size_t)gb.n_prob * gb.splits * gb.part_stride);
+            return SED_ERR_WORKSPACE;
+        }
     }
     dim3 grid((maxNx + GT_N - 1) / GT_N, (maxM + GT_M - 1) / GT_M, gb.n_prob * gb.splits);
     const size_t lds = (size_t)(GT_M * (GT_K + 1) + GT_K * (GT_N + 1)) * sizeof(float);

@@ -199,7 +199,7 @@ __device__ __forceinline__ float gcl_collect(const unsigned long long* p, uint32
         if ((uint32_t)(g >> 32) == tag) break;
         __builtin_amdgcn_s_sleep(1);
     } while (++it < GCL_SPIN_LIMIT);
-    if (it >= GCL_SPIN_LIMIT) *err = 1;
+    if (it >= GCL_SPIN_LIMIT) atomicAdd(err, 1);          // sticky counter: read by the host (train.py health check)
     return __uint_as_float((uint32_t)g);
 }
 // chain / member of this block: blocks b, b + 8, b + 16, b + 24 of a group of 32 form one chain (same XCD)
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(GCL_THREADS) void k_gclu_bwd(const float* __restric
                     if ((uint32_t)(g0 >> 32) == tag && (uint32_t)(g1 >> 32) == tag && (uint32_t)(g2 >> 32) == tag) break;
                     __builtin_amdgcn_s_sleep(1);
                 } while (++it < GCL_SPIN_LIMIT);
-                if (it >= GCL_SPIN_LIMIT) *err = 1;
+                if (it >= GCL_SPIN_LIMIT) atomicAdd(err, 1);
                 ds[U * src + lane] = __uint_as_float((uint32_t)g0); ds[H + U * src + lane] = __uint_as_float((uint32_t)g1);
                 ds[2 * H + U * src + lane] = __uint_as_float((uint32_t)g2);
             }

@@ -11,7 +11,7 @@ struct GenPackArgs {
     void *wg1, *wg2, *wgT1, *wgT2;              // GLU weights folded with gamma [co][c]; transposed raw [c][co] (may be null)
     float *bg1, *bg2;                           // GLU bias folded with beta [C]
     double* zero; int n_zero;                   // fp64 accumulators to clear
-    int* err;                                   // spin-timeout flag of the cluster GRU kernels, cleared here (may be null)
+    int* err;                                   // unused (the spin-timeout counter is sticky: cleared by sed_crnn_buffers_init only)
 };
 int launch_gen_pack(const GenPackArgs& a, int mode, hipStream_t st);
 int launch_gconv_fwd(int mode, int C, const float* in, const void* wpk, const float* bias, float* y, double* stat, int B, int H,
@@ -74,6 +74,7 @@ int launch_gnt_pack_t(const float* w0, const float* w1, float* out, int R, int N
 struct HeadsLoss;
 size_t gen_ctx_bytes(const Geo& g);
 size_t gen_ws_bytes(const Geo& g);
+int gen_buffers_init(const Geo& g, void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes, hipStream_t st);
 int gen_ctx_view(const Geo& g, const char* name, size_t* offset, size_t* bytes);
 int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_running, int64_t* bn_tracked, const float* x,
                 int train, int update_bn, const uint64_t* seed_dev, void* ctx, size_t ctx_bytes, float* strong, float* weak,

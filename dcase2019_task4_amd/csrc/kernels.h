@@ -172,6 +172,7 @@ struct GemmBatch {
     int n_prob;
     int splits;                   // split-K factor (>1 needs part)
     float* part;                  // scratch: n_prob * splits * max(M) * max(N+1) floats
+    size_t part_floats;           // capacity of `part` in floats (checked by launch_gemm_batch)
     size_t part_stride;           // filled by launch_gemm_batch
 };
 static inline GemmProb gemm_prob(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBk, int64_t sBn, float* C,

@@ -80,3 +80,26 @@ def broadcast_parameters(flat_tensors, group=None, src=0):
         return
     for t in flat_tensors:
         dist.broadcast(t, src=src, group=group)
+
+
+_M64 = 2 ** 64 - 1
+
+
+def _splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def fold_rank_seed(seed, rank):
+    """Philox base seed of data-parallel rank ``rank``.  Rank 0 keeps the user's seed (a one-process run and rank 0 of a
+    data-parallel run draw the same stream); every other rank gets a HASH of (seed, rank).  The per-step keys are
+    base + k * 0x9E37...15 + 1 (student k = 2 * step, teacher k = 2 * step + 1, csrc/optim.hip), so the rank must not
+    enter as a multiple of that same constant: ``seed + rank * 0x9E37...15`` made rank 1's student masks equal rank 0's
+    teacher masks of the same step and rank 2's stream rank 0's shifted by one step."""
+    seed &= _M64
+    if rank == 0:
+        return seed
+    return _splitmix64(seed ^ _splitmix64((rank + 0xD1B54A32D192ED03) & _M64))

@@ -104,10 +104,21 @@ class MeanTeacherStep:
         self.ws_bytes = self.l.sed_crnn_bwd_ws_bytes(C.byref(self.dims))
         if self.ctx_bytes == 0 or self.ws_bytes == 0:
             raise _lib.SedError(self.l.sed_last_error().decode())
-        # (zeros, not empty: the wide model's cluster recurrence keeps launch epochs and tagged exchange granules in there)
-        self.ctx_s = torch.zeros(self.ctx_bytes, device=dev, dtype=torch.uint8)
-        self.ctx_t = torch.zeros(self.ctx_bytes if teacher is not None else 0, device=dev, dtype=torch.uint8)
-        self.ws = torch.zeros(self.ws_bytes, device=dev, dtype=torch.uint8)
+        # the library initialises what it needs initialised in fresh buffers (the wide model's cluster recurrence keeps
+        # launch epochs, tagged exchange granules and its sticky timeout counter in there): sed_crnn_buffers_init
+        self.ctx_s = torch.empty(self.ctx_bytes, device=dev, dtype=torch.uint8)
+        self.ctx_t = torch.empty(self.ctx_bytes if teacher is not None else 0, device=dev, dtype=torch.uint8)
+        self.ws = torch.empty(self.ws_bytes, device=dev, dtype=torch.uint8)
+        _lib.check(self.l.sed_crnn_buffers_init(C.byref(self.dims), _lib.ptr(self.ctx_s), self.ctx_bytes, _lib.ptr(self.ws),
+                                                self.ws_bytes, _lib.stream_ptr()), "sed_crnn_buffers_init")
+        if teacher is not None:
+            _lib.check(self.l.sed_crnn_buffers_init(C.byref(self.dims), _lib.ptr(self.ctx_t), self.ctx_bytes, None, 0,
+                                                    _lib.stream_ptr()), "sed_crnn_buffers_init")
+        self._err_view = None
+        if student._H == 256:
+            off, nb = C.c_size_t(), C.c_size_t()
+            _lib.check(self.l.sed_crnn_ctx_view(C.byref(self.dims), b"gru_err", C.byref(off), C.byref(nb)), "sed_crnn_ctx_view")
+            self._err_view = (off.value, nb.value)
         self.x = torch.zeros(self.B, 1, self.T, 64, **f32)
         self.x_ema = torch.zeros(self.B, 1, self.T, 64, **f32)
         self.target = torch.zeros(self.B, self.T3, self.NC, **f32)
@@ -261,7 +272,7 @@ class MeanTeacherStep:
             return False
 
     def _folded_seed(self):
-        return (self.seed_user + self.rank * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
+        return sdist.fold_rank_seed(self.seed_user, self.rank)
 
     def sync_replicas(self, src=0):
         """Every replica starts from rank ``src``'s parameters, BatchNorm buffers, Adam moments and step counters (the
@@ -426,6 +437,21 @@ class MeanTeacherStep:
             m /= self.world
         return dict(zip(LOSS_NAMES, m.tolist()))
 
+    def check_health(self):
+        """Raise if a cross-workgroup wait of the wide model's cluster recurrence (csrc/ggru.hip) ever timed out: the
+        kernels then carried on with a stale hidden state and every result since is suspect.  The counter is sticky (only
+        sed_crnn_buffers_init clears it); one 4-byte device->host copy per model.  train() calls this whenever it reads
+        the meters."""
+        if self._err_view is None:
+            return
+        off, nb = self._err_view
+        for name, ctx in (("student", self.ctx_s), ("teacher", self.ctx_t)):
+            if ctx.numel():
+                n = int(ctx[off:off + 4].view(torch.int32).item())
+                if n:
+                    raise _lib.SedError(f"cluster GRU recurrence: {n} cross-workgroup waits timed out in the {name} model "
+                                        "(the four workgroups of a chain were not co-resident); results are invalid")
+
     def read_state(self):
         raw = bytes(self.state.cpu().numpy().tobytes())
         return _lib.SedStepState.from_buffer_copy(raw)
@@ -535,8 +561,10 @@ def train(train_loader, model, optimizer, epoch, ema_model=None, weak_mask=None,
         # here the meters are read back every `check_every` steps and after the last one
         if (i + 1) % check_every == 0:
             check(step_obj.meters())
+            step_obj.check_health()
     m = step_obj.meters()
     check(m)
+    step_obj.check_health()
     log('Epoch: {}\tTime {:.2f}\t{}'.format(epoch, time.time() - start,
                                             "\t".join(f"{k} {v:.4g}" for k, v in m.items())))
     return m

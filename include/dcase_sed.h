@@ -133,6 +133,14 @@ int sed_crnn_backward(const sed_dims* d, const float* params, const float* x, co
                       void* ctx, size_t ctx_bytes, const float* d_strong, const float* d_weak,
                       float* grads, void* ws, size_t ws_bytes, int parts, void* stream);
 
+/* One-time initialisation of a FRESH ctx and / or backward workspace (either pointer may be NULL): clears the few
+ * regions the library reads before it writes them - the wide model's cluster recurrence keeps launch epochs and tagged
+ * exchange granules in both buffers, and ctx holds the sticky "gru_err" counter that a timed-out cross-workgroup wait
+ * increments (never cleared by a forward; read it through sed_crnn_ctx_view).  Buffers that are reused across calls
+ * (train.MeanTeacherStep) need it once; the autograd path (crnn.py, a new ctx per CRNN.forward as in
+ * models/CRNN.py:59-84 called from main.py:91) calls it per allocation.  hipMemsetAsync on `stream`: capturable. */
+int sed_crnn_buffers_init(const sed_dims* d, void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes, void* stream);
+
 /* Debug / test access to intermediates inside ctx: name in {"p0","y1","p1","y2","p2","gru0",
  * "gru1","wz0","mean0","scale1","shift1",...}. Returns 0 and fills offset/bytes, or <0. */
 int sed_crnn_ctx_view(const sed_dims* d, const char* name, size_t* offset, size_t* bytes);

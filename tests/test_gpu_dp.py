@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, schedule, graph, out):
+def _worker(rank, world, port, schedule, graph, out, Bg=16, T=128):
     if REPO not in sys.path:
         sys.path.insert(0, REPO)
     import torch.distributed as dist
@@ -33,7 +33,6 @@ def _worker(rank, world, port, schedule, graph, out):
     torch.cuda.set_device(dev)
     dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
-        Bg, T = 16, 128
         sizes = [Bg // 4, Bg // 2, Bg // 4]
         tgt_g, _, _ = synth.make_target(1, Bg, T // 8)
         wm, sm = sdist.local_masks(sizes, world)
@@ -51,7 +50,7 @@ def _worker(rank, world, port, schedule, graph, out):
             return s, t
         # single-process step on this rank's shard, same folded seed as the data-parallel rank will use
         s1, t1 = models(0, 1)
-        fold = (1234 + rank * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
+        fold = sdist.fold_rank_seed(1234, rank)
         ref = MeanTeacherStep(s1, t1, B, T, 40, wm, sm, seed=fold, use_graph=False)
         ref.step(*batches[0])
         torch.cuda.synchronize()
@@ -64,8 +63,16 @@ def _worker(rank, world, port, schedule, graph, out):
         dp = MeanTeacherStep(s2, t2, B, T, 40, wm, sm, seed=1234, use_graph=graph, process_group=dist.group.WORLD,
                              dp_schedule=schedule)
         assert dp.dp and dp.world == world and dp.rank == rank
+        if backend == "nccl":
+            # first contact with real RCCL at world > 1: the default must be the captured-collective overlap schedule
+            assert dist.get_backend() == "nccl"
+            if schedule == "overlap" and graph:
+                assert dp.dp_capture is True and dp.dp_schedule == "overlap", (dp.dp_capture, dp.dp_schedule, dp._capture_error)
+        seeds = []
         if graph:
             dp._warm = 2
+        st0 = dp.read_state()
+        seeds += [st0.seed_student, st0.seed_teacher]
         dp.step(*batches[0])
         torch.cuda.synchronize()
         err = float((dp.grads - g_sum).abs().max())
@@ -73,8 +80,17 @@ def _worker(rank, world, port, schedule, graph, out):
         assert err <= 2e-6 * scale + 1e-9, ("all-reduced gradient != sum of the single-rank gradients", err, scale)
         # after step 1 the student is what the single-process update would be with the MEAN gradient
         for i in range(1, steps):
+            sti = dp.read_state()
+            seeds += [sti.seed_student, sti.seed_teacher]
             dp.step(*batches[i])
         torch.cuda.synchronize()
+        # every (rank, step, model) draws from its OWN Philox key: no key of one rank appears in another rank's
+        # sequence (the old fold, seed + rank * PHI with per-step stride PHI, made rank 1's student stream rank 0's
+        # teacher stream of the same step)
+        all_seeds = [None] * world
+        dist.all_gather_object(all_seeds, seeds)
+        flat = [k for r in all_seeds for k in r]
+        assert len(set(flat)) == len(flat) == 2 * steps * world, "dropout keys collide across ranks / steps"
         for name, t in (("student", s2._flat), ("teacher", t2._flat), ("exp_avg", dp.exp_avg), ("exp_avg_sq", dp.exp_avg_sq)):
             tl = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(tl, t.contiguous())
@@ -100,14 +116,17 @@ def _worker(rank, world, port, schedule, graph, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("schedule,graph", [("overlap", False), ("overlap", True), ("single", True)])
-def test_mean_teacher_step_world2(schedule, graph):
+# last case: BASELINE.json configs[3]'s per-rank composition - 64 clips per rank as [16 | 32 | 16] of a global
+# [32 | 64 | 32] at T = 628 (main.py:238-247, DataLoad.py:562-571)
+@pytest.mark.parametrize("schedule,graph,Bg,T", [("overlap", False, 16, 128), ("overlap", True, 16, 128), ("single", True, 16, 128),
+                                                 ("overlap", True, 128, 628)])
+def test_mean_teacher_step_world2(schedule, graph, Bg, T):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     out = ctx.SimpleQueue()
-    port = 29600 + (os.getpid() + hash((schedule, graph))) % 300
+    port = 29600 + (os.getpid() + hash((schedule, graph, Bg))) % 300
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, schedule, graph, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, schedule, graph, out, Bg, T)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -124,4 +143,4 @@ def test_mean_teacher_step_world2(schedule, graph):
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     ok = [m for m in msgs if m[0] == "ok"]
     assert ok, "rank 0 reported nothing"
-    print(f"[dp world 2] backend {ok[0][1]} schedule {schedule} graph {graph}: |allreduce - sum| / max = {ok[0][2]:.2e}")
+    print(f"[dp world 2] backend {ok[0][1]} schedule {schedule} graph {graph} global batch {Bg} T {T}: |allreduce - sum| / max = {ok[0][2]:.2e}")

@@ -36,12 +36,6 @@ def test_mel_spec_vs_oracle(cfg_name, n_samples):
     np.testing.assert_array_equal(single, got[0])
 
 
-def test_mel_basis_matches_oracle():
-    from dcase2019_task4_amd.features import mel_filterbank
-    for sr, fmax in ((16000, 8000.0), (44100, 22050.0)):
-        np.testing.assert_array_equal(mel_filterbank(sr, 2048, 64, 0.0, fmax), features_np.mel_filterbank(sr, 2048, 64, 0.0, fmax))
-
-
 @pytest.mark.parametrize("frames", [628, 600, 650])
 def test_logmel_transform_vs_oracle(frames):
     """noise -> dB (per-clip top_db clamp) -> pad/trunc to 628 -> normalise, student and teacher copies."""
@@ -84,10 +78,12 @@ def test_waveform_to_posteriors_pipeline_runs():
     assert s.shape == (2, 78, 10) and torch.isfinite(s).all() and torch.isfinite(w).all()
 
 
-def test_config3_raw_waveform_batch64_mean_teacher_step():
-    """BASELINE.json config 3 at its full size: 64 raw 16 kHz clips -> on-GPU STFT/mel -> noise/log/pad/normalise ->
-    one mean-teacher step (B=64, T=628), against the oracle on the SAME features (fp32 on both sides - the config
-    is quoted at bf16, fp32 is the stricter arithmetic), plus size-independent properties of a second step."""
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_config3_raw_waveform_batch64_mean_teacher_step(dtype):
+    """BASELINE.json configs[2] at its full size: 64 raw 16 kHz clips -> on-GPU STFT/mel -> noise/log/pad/normalise ->
+    one mean-teacher step (B=64, T=628), against the fp32 oracle on the SAME features, plus size-independent properties
+    of a second step.  dtype "bf16" is the configuration exactly as BASELINE.json quotes it (raw waveform + batch 64 +
+    bf16 together); "f32" is the stricter arithmetic on the same workload."""
     from dcase2019_task4_amd.features import FeatureConfig, FeatureExtractor, LogMelTransform, Scaler
     from dcase2019_task4_amd.train import MeanTeacherStep
     from oracle import ref_cpu
@@ -106,8 +102,8 @@ def test_config3_raw_waveform_batch64_mean_teacher_step():
     seed = 24681357
     x, x_ema = LogMelTransform(T, sc, augment_type="noise")(mel, seed=seed)
     assert x.shape == (B, 1, T, 64) and x_ema.shape == (B, 1, T, 64)
-    student, ps = gu.make_model(0, dropout=0)
-    teacher, pt = gu.make_model(1, dropout=0)
+    student, ps = gu.make_model(0, dropout=0, mfma_dtype=dtype)
+    teacher, pt = gu.make_model(1, dropout=0, mfma_dtype=dtype)
     student.train(); teacher.train()
     tgt, wm, sm = synth.make_target(3, B, T // 8)
     st = MeanTeacherStep(student, teacher, B, T, 100, wm, sm, use_graph=False)
@@ -115,10 +111,15 @@ def test_config3_raw_waveform_batch64_mean_teacher_step():
     m = st.meters()
     mt = ref_cpu.MeanTeacherOracle(ps, pt)
     mo, _, (so, wo, _, _) = mt.step(x.cpu(), x_ema.cpu(), tgt, wm, sm, 100)
-    for k in ("loss", "weak_class_loss", "strong_loss", "cons_strong", "cons_weak", "weak_ema_loss", "strong_ema_loss"):
-        assert m[k] == pytest.approx(mo[k], rel=1e-4, abs=1e-9), k
-    np.testing.assert_allclose(st.strong.cpu().numpy(), so.numpy(), atol=1e-5)       # north_star: 1e-3; we hold 1e-5
-    np.testing.assert_allclose(st.weak.cpu().numpy(), wo.numpy(), atol=1e-5)
+    # north_star: posteriors within 1e-3.  fp32 holds 1e-5; bf16 operands at this geometry hold 1e-3
+    rel, post = (1e-4, 1e-5) if dtype == "f32" else (5e-3, 1e-3)
+    for k in ("loss", "weak_class_loss", "strong_loss", "weak_ema_loss", "strong_ema_loss"):
+        assert m[k] == pytest.approx(mo[k], rel=rel, abs=1e-9), k
+    for k in ("cons_strong", "cons_weak"):          # differences of two posteriors: absolute bound in bf16
+        assert m[k] == pytest.approx(mo[k], rel=rel if dtype == "f32" else 5e-2, abs=1e-9 if dtype == "f32" else 1e-5), k
+    es, ew = np.abs(st.strong.cpu().numpy() - so.numpy()).max(), np.abs(st.weak.cpu().numpy() - wo.numpy()).max()
+    print(f"[config 2, {dtype}] B=64 from raw waveforms: posterior err strong {es:.2e} weak {ew:.2e}")
+    assert es < post and ew < post
     # step 2: EMA identity teacher_2 = a*teacher_1 + (1-a)*student_2 with a = 2/3 (main.py:45-49), at full size
     t1 = teacher._flat.clone()
     st.step(x, x_ema, tgt.cuda())

@@ -88,9 +88,9 @@ def _grad_errors(g_hip, go):
 @pytest.mark.parametrize("B,T,p,C,H", [(4, 128, 0.0, 128, 256), (4, 128, 0.5, 128, 256), (4, 628, 0.5, 128, 256),
                                        (5, 150, 0.25, 128, 256), (4, 216, 0.5, 128, 64), (4, 216, 0.5, 64, 256),
                                        (4, 22, 0.5, 128, 256)])
-def test_wide_fp32_forward_backward_vs_oracle(B, T, p, C, H):
+def test_wide_fp32_forward_backward_vs_oracle(B, T, p, C, H, n_layers=2):
     """Wide / mixed geometries in exact fp32: the bounds of the specialised kernel set."""
-    r = _fwd_bwd(B, T, p, C, H, "f32")
+    r = _fwd_bwd(B, T, p, C, H, "f32", n_layers=n_layers)
     es, _ = gu.report("strong", r["s"], r["so"])
     ew, _ = gu.report("weak", r["w"], r["wo"])
     assert es < POST_TOL and ew < POST_TOL
@@ -101,8 +101,16 @@ def test_wide_fp32_forward_backward_vs_oracle(B, T, p, C, H):
         np.testing.assert_allclose(r["bn"][k].numpy(), v.numpy(), rtol=3e-5, atol=3e-6, err_msg=k)
 
 
+@pytest.mark.parametrize("C", [64, 128])
+def test_single_layer_h256_gru_weight_gradients(C):
+    """n_layers_RNN = 1 (the CRNN constructor's default, CRNN.py:13) with n_RNN_cell = 256: the W_hh weight-gradient
+    problems (N = H = 256) are then WIDER than the W_ih ones (N = C), which is what sizes the split-K partial buffer -
+    it used to be sized from C alone and the batch wrote 2 - 4x past it."""
+    test_wide_fp32_forward_backward_vs_oracle(4, 128, 0.5, C, 256, n_layers=1)
+
+
 @pytest.mark.parametrize("B,T,p,C,H", [(4, 128, 0.5, 64, 64), (4, 628, 0.5, 64, 64), (24, 628, 0.5, 64, 64), (4, 864, 0.5, 64, 64),
-                                       (4, 628, 0.5, 128, 256), (8, 216, 0.0, 128, 256)])
+                                       (4, 628, 0.5, 128, 256), (8, 216, 0.0, 128, 256), (24, 628, 0.5, 128, 256)])
 def test_bf16_operands_forward_backward_vs_fp32_oracle(B, T, p, C, H):
     """bf16 MFMA operands (fp32 accumulation, fp32 everything else) against the FP32 oracle: the measured error of the
     posteriors and of every gradient is printed and held to BF16_POST_TOL / BF16_GRAD_TOL."""

@@ -435,6 +435,75 @@ def test_drop_in_module_path_with_torch_adam_matches_oracle():
         _assert_params_close(p.detach().cpu().numpy(), mt.pe[n].numpy(), n, 2)
 
 
+def test_main_py_construction_order_cpu_init_adam_then_cuda():
+    """The exact order of baseline/main.py:278-290,320: CRNN(**crnn_kwargs) on the CPU -> .apply(weights_init) ->
+    teacher the same, parameters detach_()ed -> Adam(filter(requires_grad)) on the still-CPU parameters -> ONLY THEN
+    .cuda() (to_cuda_if_available) -> train.  torch.optim.Adam holds the Parameter objects it was given: the move to the
+    GPU and the flattening on the first forward must keep those objects (only re-point their .data), or the optimiser
+    would keep stepping stale CPU copies.  Two steps against the oracle started from the same CPU-initialised values."""
+    from dcase2019_task4_amd.crnn import CRNN
+    from dcase2019_task4_amd.train import update_ema_variables
+
+    def weights_init(m):                     # utils/utils.py:205-224, restated (same dispatch, same initialisers)
+        classname = m.__class__.__name__
+        if classname.find('Conv2d') != -1:
+            torch.nn.init.xavier_uniform_(m.weight, gain=np.sqrt(2))
+            m.bias.data.fill_(0)
+        elif classname.find('BatchNorm') != -1:
+            m.weight.data.normal_(1.0, 0.02)
+            m.bias.data.fill_(0)
+        elif classname.find('GRU') != -1:
+            for weight in m.parameters():
+                if len(weight.size()) > 1:
+                    torch.nn.init.orthogonal_(weight.data)
+        elif classname.find('Linear') != -1:
+            m.weight.data.normal_(0, 0.01)
+            m.bias.data.zero_()
+
+    B, T = 4, 128
+    torch.manual_seed(2019)
+    kw = dict(gu.CRNN_KW, dropout=0)
+    crnn = CRNN(**kw)                                                   # main.py:279
+    crnn_ema = CRNN(**kw)                                               # main.py:280
+    crnn.apply(weights_init)                                            # main.py:282
+    crnn_ema.apply(weights_init)                                        # main.py:283
+    for param in crnn_ema.parameters():                                 # main.py:286-287
+        param.detach_()
+    assert all(not p.is_cuda for p in crnn.parameters())
+    ps = {n: p.detach().clone() for n, p in crnn.named_parameters()}
+    pt = {n: p.detach().clone() for n, p in crnn_ema.named_parameters()}
+    optim_kwargs = {"lr": 0.001, "betas": (0.9, 0.999)}                 # main.py:289
+    optimizer = torch.optim.Adam(filter(lambda p: p.requires_grad, crnn.parameters()), **optim_kwargs)
+    held = [p for g in optimizer.param_groups for p in g["params"]]
+    crnn, crnn_ema = crnn.cuda(), crnn_ema.cuda()                       # main.py:320 to_cuda_if_available
+    crnn.train(); crnn_ema.train()
+    mt = ref_cpu.MeanTeacherOracle(ps, pt)
+    _, wm, sm = synth.make_target(0, B, T // 8)
+    bce, mse = torch.nn.BCELoss(), torch.nn.MSELoss()
+    for it in range(2):
+        x, xe = synth.make_input(170 + it, B, T), synth.make_input(180 + it, B, T)
+        tgt, _, _ = synth.make_target(it, B, T // 8)
+        se, we = crnn_ema(xe.cuda())
+        se, we = se.detach(), we.detach()
+        s, w = crnn(x.cuda())
+        tg = tgt.cuda()
+        cw = ref_cpu.consistency_weight(it, 50)
+        loss = bce(w[wm], tg.max(-2)[0][wm]) + bce(s[sm], tg[sm]) + cw * mse(s, se) + cw * mse(w, we)
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        update_ema_variables(crnn, crnn_ema, 0.999, it + 1)
+        mo, _, _ = mt.step(x, xe, tgt, wm, sm, 50)
+        assert float(loss) == pytest.approx(mo["loss"], rel=1e-4)
+    now = list(crnn.parameters())
+    assert len(held) == len(now) and all(a is b for a, b in zip(held, now)), "the optimiser's Parameter objects were replaced"
+    assert all(p.is_cuda for p in now)
+    for n, p in crnn.named_parameters():
+        _assert_params_close(p.detach().cpu().numpy(), mt.p[n].detach().numpy(), n, 2)
+    for n, p in crnn_ema.named_parameters():
+        _assert_params_close(p.detach().cpu().numpy(), mt.pe[n].numpy(), n, 2)
+
+
 def test_checkpoint_roundtrip_reference_format(tmp_path):
     """state_dict / save / load keep the reference's nested layout (CRNN.py:33-57, TestModel.py:30-36)."""
     from dcase2019_task4_amd.crnn import CRNN

@@ -1,7 +1,10 @@
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), as prescribed by
 MI355X_MICROARCH.md (HBM section): counters are in KiB; on gfx950 FETCH_SIZE reports HALF the bytes of a
 wide coalesced read, so reads are doubled; WRITE_SIZE is taken as is (uncalibrated).
-Usage: python tools/summarize_pmc.py <fetch_dir> <write_dir> > profiles/xxx_pmc_traffic.md (also prints JSON)."""
+Usage: python tools/summarize_pmc.py <fetch_dir> <write_dir> [out.json] [steps] > profiles/xxx_pmc_traffic.md
+`steps` = the steps the traced bench command ran (--steps + max(--warmup, 3)): the JSON then carries "_per_step" = the sum
+over EVERY dispatch of the trace divided by that count (bench.py's roofline.traffic) and the launches per step per kernel -
+derived from the trace, not maintained by hand."""
 import glob
 import json
 import os
@@ -38,6 +41,12 @@ def main():
             continue
         print(f"| `{k}` | {n} | {rd / 1e6:.2f} MB | {wr / 1e6:.2f} MB | {(rd + wr) / 1e6:.2f} |")
         js[k] = {"read_bytes": round(rd), "write_bytes": round(wr)}
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    if steps > 0:
+        tot = sum(n * (rd + wr) for _, n, rd, wr in rows)
+        js["_per_step"] = {"bytes": round(tot / steps), "steps_traced": steps,
+                           "launches_per_step": {k: round(n / steps, 2) for k, n, rd, wr in rows if rd + wr >= 1e4}}
+        print(f"\nwhole step: {tot / steps / 1e6:.1f} MB of HBM traffic per step (all {sum(r[1] for r in rows)} dispatches of the trace / {steps} steps)")
     out_json = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "pmc_traffic.json")
     with open(out_json, "w") as fh:
         json.dump(js, fh, indent=1, sort_keys=True)

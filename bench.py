@@ -161,29 +161,39 @@ def feature_path(device, n_clips=32):
     wave = (0.1 * torch.randn(n_clips, 160000, generator=g)).to(device)
     tr = LogMelTransform(T_FRAMES, scaler=None, device=device)
 
-    def run():
-        return tr(fx.calculate_mel_spec_batch(wave))
-    run()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    iters = 20
-    e0.record()
-    for _ in range(iters):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+    def timed(fn, iters=20):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    mel = fx.calculate_mel_spec_batch(wave)
+    ms_stft = timed(lambda: fx.calculate_mel_spec_batch(wave))
+    ms_tr = timed(lambda: tr(mel))
+    ms = timed(lambda: tr(fx.calculate_mel_spec_batch(wave)))
     # algorithmic bytes: the waveform read once (fp32) + the feature tensor written once; the linear mel in between is
     # written and read once more (two kernels)
-    by = n_clips * (160000 * 4 + 3 * T_FRAMES * N_MELS * 4)
+    by_stft = n_clips * (160000 * 4 + T_FRAMES * N_MELS * 4)
+    by_tr = n_clips * (2 * T_FRAMES * N_MELS * 4)
+    by = by_stft + by_tr
     w = wave[:4].cpu().numpy().astype(np.float64)
     t0 = time.perf_counter()
     for i in range(w.shape[0]):
         m = features_np.calculate_mel_spec(w[i], 16000, 2048, 255, 64, 0.0, 8000.0)
         features_np.transform_chain(m, T_FRAMES)
     cpu_s = (time.perf_counter() - t0) / w.shape[0]
+    per = lambda b, t: {"us": round(t * 1e3, 1), "hbm_gbs_algorithmic": round(b / t * 1e-6, 1),
+                        "frac_of_hbm_peak": round(b / t * 1e-6 / PEAK_HBM_GBS, 4)}
     return {"gpu_clips_per_s": round(n_clips / ms * 1e3, 1), "ms_per_32_clips": round(ms, 3),
             "hbm_gbs_algorithmic": round(by / ms * 1e-6, 1), "frac_of_hbm_peak": round(by / ms * 1e-6 / PEAK_HBM_GBS, 4),
-            "bound": "LDS/VALU (fp64 radix-4 FFT in LDS: 0.12 GFLOP fp64 per clip), far from the HBM roofline by design",
+            "kernels": {"sed_mel_spec (k_stft_mel: STFT + mel projection)": dict(per(by_stft, ms_stft), bound="LDS / fp64 VALU: "
+                        "radix-4 FFT of 2048 points per frame in fp64, held in LDS"),
+                        "sed_logmel_transform (k_logmel_max + k_logmel_apply, no augmentation)": dict(per(by_tr, ms_tr),
+                        bound="fp64 log10 per element, then HBM")},
             "cpu_clips_per_s": round(1.0 / cpu_s, 2), "cpu_kind": "port (oracle/features_np.py, numpy, 1 process)",
             "cpu_sample": "4 clips of 160 000 samples"}
 

@@ -140,36 +140,66 @@ __device__ __forceinline__ double amp_db(double a) {
     return 10.0 * log10(fmax(1e-10, a * a));
 }
 
-__global__ __launch_bounds__(256) void k_logmel_transform(const float* __restrict__ mel, int frames, int n_mels,
-                                                           int max_frames, const double* __restrict__ mean,
-                                                           const double* __restrict__ stdv,
-                                                           const uint64_t* __restrict__ seed_ptr,
-                                                           float* __restrict__ out_clean, float* __restrict__ out_noisy) {
+// Two launches over the WHOLE chip instead of one workgroup per clip (round 2: 64 of 256 CUs, one wave per SIMD, the
+// Box-Muller noise formed twice per element: 283 us for a batch of 64 clips):
+//   k_logmel_max   LM_CHUNKS workgroups per clip: partial maxima of |mel| and |mel + noise| over the clip (amplitude_to_db
+//                  clamps at max - 80 dB over the WHOLE clip, before padding) -> part[clip][chunk][2]; the noise values it
+//                  draws are fp32 by definition (AugmentGaussianNoise adds a float32 array, DataLoad.py:189-207) and are
+//                  parked in out_noisy at the element's own output position, so the second pass does not redo Philox +
+//                  log + sqrt + cospi in fp64
+//   k_logmel_apply every output element: dB, clamp, pad, normalise; folds the LM_CHUNKS partials of its clip itself
+// No atomics, no initialisation, fixed reduction order: bit-reproducible.
+#define LM_CHUNKS 16
+__global__ __launch_bounds__(256) void k_logmel_max(const float* __restrict__ mel, int frames, int n_mels, int max_frames,
+                                                     const uint64_t* __restrict__ seed_ptr, double* __restrict__ part,
+                                                     float* __restrict__ out_noisy) {
     __shared__ double red[2][4];
-    const int tid = threadIdx.x, clip = blockIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int n = frames * n_mels;
+    const int tid = threadIdx.x, chunk = blockIdx.x, clip = blockIdx.y, lane = tid & 63, wv = tid >> 6;
+    const int n = frames * n_mels, n_keep = min(frames, max_frames) * n_mels;
     const float* src = mel + (size_t)clip * n;
     const uint64_t seed = out_noisy ? seed_ptr[0] : 0ull;
-    // per-clip maxima (amplitude_to_db clamps at max - 80 dB over the WHOLE clip, before padding)
+    const int per = (n + LM_CHUNKS - 1) / LM_CHUNKS, e0 = chunk * per, e1 = min(n, e0 + per);
     double mc = 0.0, mn = 0.0;
-    for (int e = tid; e < n; e += 256) {
-        const double a = fabs((double)src[e]);
-        mc = fmax(mc, a);
-        if (out_noisy) mn = fmax(mn, fabs((double)src[e] + teacher_noise((uint32_t)(clip * n + e), seed)));
+    for (int e = e0 + tid; e < e1; e += 256) {
+        const double a = (double)src[e];
+        mc = fmax(mc, fabs(a));
+        if (out_noisy) {
+            const double nz = teacher_noise((uint32_t)(clip * n + e), seed);
+            mn = fmax(mn, fabs(a + nz));
+            if (e < n_keep) out_noisy[(size_t)clip * max_frames * n_mels + e] = (float)nz;       // exact: nz is a float
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { mc = fmax(mc, __shfl_xor(mc, o)); mn = fmax(mn, __shfl_xor(mn, o)); }
     if (lane == 0) { red[0][wv] = mc; red[1][wv] = mn; }
     __syncthreads();
-    const double floor_c = amp_db(fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3]))) - 80.0;
-    const double floor_n = amp_db(fmax(fmax(red[1][0], red[1][1]), fmax(red[1][2], red[1][3]))) - 80.0;
-    const int n_out = max_frames * n_mels;
-    for (int e = tid; e < n_out; e += 256) {
-        const int t = e / n_mels, m = e % n_mels;
+    if (tid < 2) part[((size_t)clip * LM_CHUNKS + chunk) * 2 + tid] = fmax(fmax(red[tid][0], red[tid][1]), fmax(red[tid][2], red[tid][3]));
+}
+
+__global__ __launch_bounds__(256) void k_logmel_apply(const float* __restrict__ mel, int frames, int n_mels, int max_frames,
+                                                       const double* __restrict__ mean, const double* __restrict__ stdv,
+                                                       const double* __restrict__ part, float* __restrict__ out_clean,
+                                                       float* __restrict__ out_noisy) {
+    const int tid = threadIdx.x, clip = blockIdx.y;
+    const int n = frames * n_mels, n_out = max_frames * n_mels;
+    const float* src = mel + (size_t)clip * n;
+    double mc = 0.0, mn = 0.0;
+#pragma unroll
+    for (int k = 0; k < LM_CHUNKS; ++k) {
+        mc = fmax(mc, part[((size_t)clip * LM_CHUNKS + k) * 2]);
+        mn = fmax(mn, part[((size_t)clip * LM_CHUNKS + k) * 2 + 1]);
+    }
+    const double floor_c = amp_db(mc) - 80.0, floor_n = amp_db(mn) - 80.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = (blockIdx.x * 4 + i) * 256 + tid;
+        if (e >= n_out) break;
+        const int t = e / n_mels, m = e - t * n_mels;
         float vc = 0.f, vn = 0.f;                               // PadOrTrunc pads with 0 (dB) AFTER the log
         if (t < frames) {
-            vc = (float)fmax(amp_db((double)src[e]), floor_c);  // ToTensor: .float()
-            if (out_noisy) vn = (float)fmax(amp_db((double)src[e] + teacher_noise((uint32_t)(clip * n + e), seed)), floor_n);
+            const double a = (double)src[e];
+            vc = (float)fmax(amp_db(a), floor_c);               // ToTensor: .float()
+            if (out_noisy) vn = (float)fmax(amp_db(a + (double)out_noisy[(size_t)clip * n_out + e]), floor_n);
         }
         if (mean) {                                             // Scaler.normalize in float64, torch.Tensor() -> fp32
             vc = (float)(((double)vc - mean[m]) / stdv[m]);
@@ -211,16 +241,38 @@ extern "C" int sed_mel_spec(const float* wave, int n_clips, int n_samples, int h
     return SED_OK;
 }
 
+// The front-end's own noise-key chain: key += golden-ratio stride, one thread.  Lets a caller that computes the NEXT batch's
+// features on a side stream (features.WaveformFrontEnd) advance the key in stream order without touching the train step's
+// device state, which the step itself advances concurrently.
+__global__ void k_seed_advance(uint64_t* key) { key[0] += 0x9E3779B97F4A7C15ull; }
+extern "C" int sed_seed_advance(uint64_t* key_dev, void* stream) {
+    SED_CHECK_ARG(key_dev != nullptr, "sed_seed_advance: null key");
+    k_seed_advance<<<1, 1, 0, (hipStream_t)stream>>>(key_dev);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}
+
+extern "C" size_t sed_logmel_transform_ws_bytes(int n_clips) { return (size_t)(n_clips > 0 ? n_clips : 0) * LM_CHUNKS * 2 * sizeof(double); }
+
 extern "C" int sed_logmel_transform(const float* mel, int n_clips, int frames, int n_mels, int max_frames,
                                     const double* mean, const double* std, const uint64_t* seed_dev, float* out_clean,
-                                    float* out_noisy, void* stream) {
+                                    float* out_noisy, void* ws, size_t ws_bytes, void* stream) {
     SED_CHECK_ARG(mel && out_clean, "sed_logmel_transform: null argument");
     SED_CHECK_ARG((mean == nullptr) == (std == nullptr), "sed_logmel_transform: mean and std go together");
     SED_CHECK_ARG(!out_noisy || seed_dev, "sed_logmel_transform: noise requested but seed_dev is null");
     SED_CHECK_ARG(n_clips >= 1 && frames >= 1 && n_mels >= 1 && max_frames >= 1, "sed_logmel_transform: bad sizes");
     SED_CHECK_ARG((int64_t)n_clips * frames * n_mels < (1ll << 32), "sed_logmel_transform: too many elements for the noise stream");
-    k_logmel_transform<<<n_clips, 256, 0, (hipStream_t)stream>>>(mel, frames, n_mels, max_frames, mean,
-                                                                 std, seed_dev, out_clean, out_noisy);
+    SED_CHECK_ARG(ws != nullptr, "sed_logmel_transform: null workspace");
+    if (ws_bytes < sed_logmel_transform_ws_bytes(n_clips)) {
+        sed_set_error("sed_logmel_transform: workspace has %zu bytes, needs %zu", ws_bytes, sed_logmel_transform_ws_bytes(n_clips));
+        return SED_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    k_logmel_max<<<dim3(LM_CHUNKS, n_clips), 256, 0, st>>>(mel, frames, n_mels, max_frames, seed_dev, (double*)ws, out_noisy);
+    SED_CHECK_LAUNCH();
+    const int n_out = max_frames * n_mels;
+    k_logmel_apply<<<dim3((n_out + 1023) / 1024, n_clips), 256, 0, st>>>(mel, frames, n_mels, max_frames, mean, std, (const double*)ws,
+                                                                         out_clean, out_noisy);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

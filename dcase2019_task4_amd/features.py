@@ -252,20 +252,28 @@ class LogMelTransform:
                 self._calls += 1
                 seed = (self._seed * 0x9E3779B97F4A7C15 + self._calls) & 0x7FFFFFFFFFFFFFFF
             seed_t = torch.tensor([seed], dtype=torch.int64, device=self.device)
+        ws = torch.empty(l.sed_logmel_transform_ws_bytes(n), device=self.device, dtype=torch.uint8)
         _lib.check(l.sed_logmel_transform(_lib.ptr(mel), n, fr, nm, self.frames, _lib.ptr(self.mean), _lib.ptr(self.std),
-                                          _lib.ptr(seed_t), _lib.ptr(clean), _lib.ptr(noisy), _lib.stream_ptr()),
+                                          _lib.ptr(seed_t), _lib.ptr(clean), _lib.ptr(noisy), _lib.ptr(ws), ws.numel(),
+                                          _lib.stream_ptr()),
                    "sed_logmel_transform")
         return (clean, noisy) if self.noise else clean
 
 
 class WaveformFrontEnd:
-    """BASELINE.json configs[2]: the mean-teacher step fed from raw waveforms resident in HBM.  ``run()`` =
+    """BASELINE.json configs[2]: the mean-teacher step fed from raw waveforms resident in HBM.  One ``run()`` =
     calculate_mel_spec for the whole batch (sed_mel_spec) -> the train-time transform chain with the teacher's noisy copy
-    (sed_logmel_transform, utils.py:397-412 with augment_type="noise") written straight into the step's input buffers
-    -> ``step.run()``.  Persistent buffers, no allocation and no host value inside ``run``: the noise key is the step's
-    device-side teacher seed, which advances with the step counter."""
+    (sed_logmel_transform, utils.py:397-412 with augment_type="noise") -> the step.  Persistent buffers, no allocation
+    and no host value inside ``run``; the noise key is a device word of the front-end's own, advanced in stream order.
 
-    def __init__(self, step, waves, cfg=None, scaler=None):
+    ``overlap=True`` (default, single-process graph mode): the features depend on no weight, so they are computed ONE
+    BATCH AHEAD - the way the reference's DataLoader workers prepare batch k + 1 while the model trains on batch k
+    (DataLoad.py:47-186 behind torch's DataLoader, main.py:238-247).  ``run()`` replays one hipGraph in which a side
+    stream turns the waveforms currently in ``self.waves`` into the OTHER input buffer pair while the main stream runs
+    the train step on the pair filled during the previous ``run()``; the two pairs alternate.  The first call fills the
+    first pair synchronously.  A caller streaming real data refreshes ``self.waves`` (``load_waves``) between calls."""
+
+    def __init__(self, step, waves, cfg=None, scaler=None, overlap=True, seed=0):
         self.step = step
         self.l = _lib.lib()
         self.fx = FeatureExtractor(cfg or FeatureConfig.baseline_16k(), device=step.device)
@@ -278,22 +286,83 @@ class WaveformFrontEnd:
         self.mel = torch.empty(n, self.frames, c.n_mels, device=step.device, dtype=torch.float32)
         self.ws = torch.empty(self.l.sed_mel_spec_ws_bytes(n, ns, c.hop_length, c.n_window, c.n_mels), device=step.device,
                               dtype=torch.uint8)
+        self.ws_t = torch.empty(self.l.sed_logmel_transform_ws_bytes(n), device=step.device, dtype=torch.uint8)
         self.mean = self.std = None
         if scaler is not None:
             self.mean = torch.tensor(np.asarray(scaler.mean_), dtype=torch.float64, device=step.device)
             self.std = torch.tensor(np.asarray(scaler.std_), dtype=torch.float64, device=step.device)
+        self.key = torch.tensor([(int(seed) * 0x9E3779B97F4A7C15 + 0x2545F4914F6CDD1D) & 0x7FFFFFFFFFFFFFFF],
+                                dtype=torch.int64, device=step.device)
+        self.overlap = bool(overlap) and not step.dp and step.use_graph and step.teacher is not None
+        self._bufs = [(step.x, step.x_ema)]
+        self._graphs = None
+        self._cur = 0
+        self._runs = 0
+        if self.overlap:
+            self._bufs.append((torch.empty_like(step.x), torch.empty_like(step.x_ema)))
+            # lowest priority: the next batch's features must only fill CUs the step leaves idle (its recurrences run on
+            # a fraction of the chip), never delay a kernel of the step that is running
+            lo, _hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, 0)
+            self._fe_stream = torch.cuda.Stream(device=step.device, priority=int(os.environ.get("SED_FE_PRIO", lo)))
 
-    def features(self):
+    def load_waves(self, waves):
+        self.waves.copy_(torch.as_tensor(waves).reshape(self.waves.shape), non_blocking=True)
+
+    def features(self, x=None, x_ema=None):
+        """waveforms -> (x, x_ema) on the current stream (default: the step's own input buffers)."""
         c = self.fx.cfg
         st = self.step
+        x = st.x if x is None else x
+        x_ema = (st.x_ema if st.teacher is not None else None) if x_ema is None else x_ema
+        _lib.check(self.l.sed_seed_advance(_lib.ptr(self.key), _lib.stream_ptr()), "sed_seed_advance")
         _lib.check(self.l.sed_mel_spec(_lib.ptr(self.waves), self.n, self.ns, c.hop_length, c.n_window, None,
                                        _lib.ptr(self.fx.mel_basis), c.n_mels, _lib.ptr(self.mel), _lib.ptr(self.ws),
                                        self.ws.numel(), _lib.stream_ptr()), "sed_mel_spec")
         _lib.check(self.l.sed_logmel_transform(_lib.ptr(self.mel), self.n, self.frames, c.n_mels, st.T, _lib.ptr(self.mean),
-                                               _lib.ptr(self.std), st._seed_t, _lib.ptr(st.x),
-                                               _lib.ptr(st.x_ema) if st.teacher is not None else None, _lib.stream_ptr()),
+                                               _lib.ptr(self.std), _lib.ptr(self.key), _lib.ptr(x), _lib.ptr(x_ema),
+                                               _lib.ptr(self.ws_t), self.ws_t.numel(), _lib.stream_ptr()),
                    "sed_logmel_transform")
 
+    def _capture(self):
+        st = self.step
+        torch.cuda.synchronize(st.device)
+        self.features(*self._bufs[0])                 # batch 0's features: nothing ran ahead of the first replay
+        torch.cuda.synchronize(st.device)
+        graphs = []
+        own = (st.x, st.x_ema)
+        try:
+            for i in range(2):
+                st.x, st.x_ema = self._bufs[i]
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st._cap_stream):
+                    cur = torch.cuda.current_stream()
+                    self._fe_stream.wait_stream(cur)
+                    with torch.cuda.stream(self._fe_stream):
+                        self.features(*self._bufs[1 - i])
+                    st._fwd_bwd()
+                    st._update()
+                    cur.wait_stream(self._fe_stream)
+                graphs.append(g)
+        finally:
+            st.x, st.x_ema = own
+        self._graphs = graphs
+        self._cur = 0
+
     def run(self):
-        self.features()
-        self.step.run()
+        st = self.step
+        if not self.overlap:
+            self.features()
+            st.run()
+            return
+        if self._runs < 2:                            # two eager steps first (as MeanTeacherStep.run does before capturing)
+            self.features()
+            st.run()
+            self._runs += 1
+            return
+        if self._graphs is None:
+            self._capture()
+        self._graphs[self._cur].replay()
+        self._cur ^= 1
+        self._runs += 1
+        st._warm += 1
+        st.steps_done += 1

@@ -220,10 +220,17 @@ int sed_mel_spec(const float* wave, int n_clips, int n_samples, int hop, int n_f
  *   mel     [n_clips][frames][n_mels] linear mel
  *   mean/std  [n_mels] float64 (Scaler.mean_/std_ are float64) or NULL (no Normalize)
  *   out_clean [n_clips][max_frames][n_mels]; out_noisy same or NULL (no augmentation)
- *   seed_dev  Philox key for the teacher noise |N(0, 0.25)| (DataLoad.py:285)                 */
+ *   seed_dev  Philox key for the teacher noise |N(0, 0.25)| (DataLoad.py:285)
+ *   ws        scratch, sed_logmel_transform_ws_bytes(n_clips): per-clip partial maxima (the per-clip top_db clamp is
+ *             a two-pass reduction spread over the whole chip)                                  */
+size_t sed_logmel_transform_ws_bytes(int n_clips);
+/* Advances a device-resident 64-bit noise key by one draw (key += 0x9E3779B97F4A7C15), in stream order: the state of
+ * AugmentGaussianNoise's generator (DataLoad.py:189-207 draws from numpy's global RNG once per sample) for callers that
+ * run the transform chain on a stream of their own, ahead of the train step. */
+int sed_seed_advance(uint64_t* key_dev, void* stream);
 int sed_logmel_transform(const float* mel, int n_clips, int frames, int n_mels, int max_frames,
                          const double* mean, const double* std, const uint64_t* seed_dev,
-                         float* out_clean, float* out_noisy, void* stream);
+                         float* out_clean, float* out_noisy, void* ws, size_t ws_bytes, void* stream);
 
 /* Resampling step of read_audio (utils/utils.py:175-193: librosa.resample(audio, orig_sr, target_sr),
  * res_type "kaiser_best" = resampy's windowed-sinc interpolation, then fix_length).

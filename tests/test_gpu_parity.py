@@ -499,8 +499,16 @@ def test_main_py_construction_order_cpu_init_adam_then_cuda():
     assert len(held) == len(now) and all(a is b for a, b in zip(held, now)), "the optimiser's Parameter objects were replaced"
     assert all(p.is_cuda for p in now)
     for n, p in crnn.named_parameters():
+        if n == "dense_softmax.bias":
+            # weights_init leaves the attention layer at bias 0 / weights N(0, .01): its softmax is ~uniform and the bias
+            # gradient cancels to rounding noise (1e-9), which Adam normalises to +-lr on BOTH sides - only bounded
+            assert float((p.detach().cpu() - mt.p[n].detach()).abs().max()) < 3e-3
+            continue
         _assert_params_close(p.detach().cpu().numpy(), mt.p[n].detach().numpy(), n, 2)
     for n, p in crnn_ema.named_parameters():
+        if n == "dense_softmax.bias":
+            assert float((p.detach().cpu() - mt.pe[n]).abs().max()) < 3e-3
+            continue
         _assert_params_close(p.detach().cpu().numpy(), mt.pe[n].numpy(), n, 2)
 
 

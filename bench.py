@@ -54,6 +54,8 @@ CONFIGS = {   # name -> (wide, mfma dtype, from waveform, default batch per GPU)
     "mt-f32": (False, "f32", False, 24), "mt-bf16": (False, "bf16", False, 24),
     "waveform": (False, "f32", True, 64), "waveform-bf16": (False, "bf16", True, 64),
     "wide-f32": (True, "f32", False, 24), "wide-bf16": (True, "bf16", False, 24),
+    "mt-bf16x3": (False, "bf16x3", False, 24), "wide-bf16x3": (True, "bf16x3", False, 24),
+    "waveform-bf16x3": (False, "bf16x3", True, 64),
 }
 PEAK_HBM_GBS = 8000.0
 
@@ -443,7 +445,9 @@ def main():
         clips = B * world * args.steps / elapsed
         t_clip_us = elapsed / args.steps / B * 1e6
         mdl = "wide CRNN (nb_filters 3 x 128, n_RNN_cell 256)" if wide else "CRNN (baseline/main.py config)"
-        arith = "fp32" if mfma_dtype == "f32" else "bf16 MFMA operands / fp32 accumulation in the conv-block GEMMs, fp32 elsewhere"
+        arith = {"f32": "fp32", "bf16": "bf16 MFMA operands / fp32 accumulation in the conv-block GEMMs, fp32 elsewhere",
+                 "bf16x3": "split bf16 operands (hi + lo, three bf16 MFMAs per product, fp32 accumulation) in the 3x3 "
+                           "convolutions forward / dgrad, fp32 elsewhere"}[mfma_dtype]
         wl = (f"mean-teacher {mdl} train step from raw 16 kHz waveforms (STFT + mel + log + normalise on the GPU inside the "
               f"timed region), batch {B} per GPU, {arith}" if waveform else
               f"mean-teacher {mdl} train step, batch {B} per GPU, precomputed log-mel [{B},1,628,64] fp32 resident in HBM, "
@@ -495,7 +499,7 @@ def main():
                                "effective fraction above 1 is an algorithmic saving, not MFMA utilisation - the executed "
                                "fraction beside it is.",
         }
-        if mfma_dtype == "bf16":
+        if mfma_dtype != "f32":
             roof["note"] = ("bf16 line: priced against the DENSE bf16 MFMA peak as the contract asks; only the conv-block GEMMs "
                             "run on bf16 operands - block 0, every weight gradient, the GRU, the heads and all element-wise "
                             "work are fp32, so this fraction is NOT an MFMA-utilisation figure (frac_of_f32_mfma_peak beside it)")

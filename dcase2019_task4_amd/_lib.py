@@ -22,8 +22,9 @@ class SedDims(C.Structure):
                 ("bn_eps", C.c_float), ("bn_momentum", C.c_float), ("dtype", C.c_int32)]
 
 
-DTYPE_F32, DTYPE_BF16 = 0, 1
-DTYPES = {"f32": DTYPE_F32, "fp32": DTYPE_F32, "float32": DTYPE_F32, "bf16": DTYPE_BF16, "bfloat16": DTYPE_BF16}
+DTYPE_F32, DTYPE_BF16, DTYPE_BF16X3 = 0, 1, 2
+DTYPES = {"f32": DTYPE_F32, "fp32": DTYPE_F32, "float32": DTYPE_F32, "bf16": DTYPE_BF16, "bfloat16": DTYPE_BF16,
+          "bf16x3": DTYPE_BF16X3}
 
 
 class SedStepState(C.Structure):

@@ -223,7 +223,8 @@ class CRNN(nn.Module):
         torch.save({k: v for k, v in self.state_dict().items()}, filename)
 
     def set_mfma_dtype(self, name):
-        """"f32" (exact fp32 MFMA) or "bf16" (bf16 operands / fp32 accumulation in the conv-block GEMMs): sed_dims.dtype."""
+        """sed_dims.dtype: "f32" (exact fp32 MFMA), "bf16" (bf16 operands / fp32 accumulation in the conv-block GEMMs) or
+        "bf16x3" (split bf16 operands, three MFMAs per product: ~2^-16 relative error, holds the 1e-3 posterior bound)."""
         if name not in _lib.DTYPES:
             raise ValueError(f"mfma_dtype must be one of {sorted(_lib.DTYPES)}, got {name!r}")
         self._dtype = _lib.DTYPES[name]

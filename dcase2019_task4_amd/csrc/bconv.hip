@@ -62,8 +62,9 @@ struct BConvCfg {
     static constexpr int RP = (TW == 16) ? ((RP_RAW + 255) / 256) * 256 : ((RP_RAW - 64 + 255) / 256) * 256 + 64;
     static constexpr int HALO_PLANE = HH * RP;
     static constexpr int PLANES = X3 ? 2 : 1;
-    static constexpr int KC = 64;                                         // k per streamed weight chunk
-    static constexpr int BROW = KC * 2 + 16;                              // weight-chunk row stride (bytes): 144
+    // k per streamed weight chunk (the split mode at C = 128, W = 16 holds two halo planes + two weight planes: 32)
+    static constexpr int KC = (X3 && C == 128 && TW == 16) ? 32 : 64;
+    static constexpr int BROW = KC * 2 + 16;                              // weight-chunk row stride (bytes): 144 / 80
     static constexpr int BBUF = C * BROW;                                 // one plane of one chunk
     static constexpr int HALO_BYTES = PLANES * HALO_PLANE;
     static constexpr int WB_BYTES = 2 * PLANES * BBUF;
@@ -167,12 +168,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bconv(const void* __restrict__
     };
 
     // ---- weight chunk staging: rows n of C, 8 groups of 16 bytes per row and plane --------------------------------------
-    constexpr int BITEM = C * 8, BL = (BITEM + NT - 1) / NT;
+    constexpr int GJ = KC / 8;                                            // 16-byte groups per chunk row
+    constexpr int BITEM = C * GJ, BL = (BITEM + NT - 1) / NT;
     f32x4 bst[BL][PL];
     auto b_load = [&](int ch) {
 #pragma unroll
         for (int i = 0; i < BL; ++i) {
-            const int g = tid + NT * i, row = g >> 3, j = g & 7;
+            const int g = tid + NT * i, row = g / GJ, j = g % GJ;
             if (BITEM % NT == 0 || g < BITEM) {
 #pragma unroll
                 for (int p = 0; p < PL; ++p)
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bconv(const void* __restrict__
     auto b_store = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < BL; ++i) {
-            const int g = tid + NT * i, row = g >> 3, j = g & 7;
+            const int g = tid + NT * i, row = g / GJ, j = g % GJ;
             if (BITEM % NT == 0 || g < BITEM) {
 #pragma unroll
                 for (int p = 0; p < PL; ++p) *(f32x4*)(wb + (buf * PL + p) * BBUF + row * BROW + 16 * j) = bst[i][p];

@@ -27,6 +27,7 @@ int launch_gen_pack(const GenPackArgs& a, int mode, hipStream_t st) {
     const int n = 2 * 9 * a.C * a.C;
     const int blocks = ((n > a.n_zero ? n : a.n_zero) + 255) / 256;
     if (mode == 1) k_gen_pack<1><<<blocks, 256, 0, st>>>(a);
+    else if (mode == 2) k_gen_pack<2><<<blocks, 256, 0, st>>>(a);
     else k_gen_pack<0><<<blocks, 256, 0, st>>>(a);
     SED_CHECK_LAUNCH();
     k_gen_pack_bias<<<(2 * a.C + 3) / 4, 256, 0, st>>>(a);

@@ -160,6 +160,7 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
         return SED_ERR_WORKSPACE;
     }
     const int C = g.C, H = g.H;
+    const int gm = (g.mode == SED_DTYPE_BF16X3) ? SED_DTYPE_F32 : g.mode;      // arithmetic of everything but the 3x3 convolutions
     const int use_drop = (train && g.p > 0.f) ? 1 : 0;
     const int upd = (train && update_bn) ? 1 : 0;
     int64_t* trk[3] = {bn_tracked ? bn_tracked + 0 : nullptr, bn_tracked ? bn_tracked + 1 : nullptr,
@@ -217,13 +218,17 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
     const size_t so[3] = {0, L.stat1, L.stat2};
     const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};
     for (int i = 1; i <= 2; ++i) {
-        SED_TRY(launch_gconv_fwd(g.mode, C, CTXF(L.p[i - 1]), CTXV(L.wpk[i]), params + P.conv_b[i], CTXF(L.y[i]),
-                                 train ? CTXD(so[i]) : nullptr, g.B, Hs[i], Wd[i], st));
+        if (g.mode == SED_DTYPE_BF16X3)
+            SED_TRY(launch_bconv_fwd(1, C, CTXF(L.p[i - 1]), CTXV(L.wpk[i]), params + P.conv_b[i], CTXF(L.y[i]),
+                                     train ? CTXD(so[i]) : nullptr, g.B, Hs[i], Wd[i], st));
+        else
+            SED_TRY(launch_gconv_fwd(g.mode, C, CTXF(L.p[i - 1]), CTXV(L.wpk[i]), params + P.conv_b[i], CTXF(L.y[i]),
+                                     train ? CTXD(so[i]) : nullptr, g.B, Hs[i], Wd[i], st));
         GBnArgs bn;
         bn.stat = CTXD(so[i]); bn.N = (double)g.B * Hs[i] * Wd[i]; bn.gamma = params + P.bn_g[i]; bn.beta = params + P.bn_b[i];
         bn.run_mean = bn_running + (2 * i) * C; bn.run_var = bn_running + (2 * i + 1) * C; bn.tracked = trk[i];
         bn.train = train; bn.update = upd; bn.eps = g.eps; bn.momentum = g.mom; bn.bn = CTXF(L.bn[i]);
-        SED_TRY(launch_gglu_fwd(g.mode, C, CTXF(L.y[i]), bn, CTXV(L.wg[i]), CTXF(L.bg[i]), CTXF(L.p[i]), g.B, Hs[i], Wd[i], i,
+        SED_TRY(launch_gglu_fwd(gm, C, CTXF(L.y[i]), bn, CTXV(L.wg[i]), CTXF(L.bg[i]), CTXF(L.p[i]), g.B, Hs[i], Wd[i], i,
                                 use_drop, g.p, seed_dev, use_drop ? CTXM(L.mask[i]) : nullptr, st));
     }
     // ---- BiGRU ----------------------------------------------------------------------------------------------------------
@@ -272,6 +277,7 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
         return SED_ERR_WORKSPACE;
     }
     const int C = g.C, H = g.H, BT = g.B * g.T3;
+    const int gm = (g.mode == SED_DTYPE_BF16X3) ? SED_DTYPE_F32 : g.mode;
     const int use_drop = (g.p > 0.f) ? 1 : 0;
     const bool have_side = (ss != st);
     const bool defer_gru_w = (parts & 4) != 0;
@@ -351,7 +357,7 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
     const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};
     for (int i = 2; i >= 1; --i) {
         // (H = 64: the GRU's dX arrives as two direction planes; the GLU backward adds them while loading)
-        SED_TRY(launch_gglu_bwd(g.mode, C, CTXF(L.y[i]), CTXF(L.bn[i]), params + P.bn_g[i], params + P.bn_b[i], CTXV(L.wg[i]),
+        SED_TRY(launch_gglu_bwd(gm, C, CTXF(L.y[i]), CTXF(L.bn[i]), params + P.bn_g[i], params + P.bn_b[i], CTXV(L.wg[i]),
                                 CTXV(L.wgT[i]), CTXF(L.bg[i]), WSF(W.dp[i]), WSF(W.dz[i]), WSF(W.glu_part), g.B, Hs[i], Wd[i], use_drop,
                                 g.p, CTXM(L.mask[i]), st, (i == 2 && H == 64) ? WSF(W.dp[2]) + (size_t)BT * C : nullptr));
         GBnBwdArgs pa;
@@ -362,7 +368,7 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
         pa.g_convb = grads + P.conv_b[i];
         SED_TRY(launch_gbn_bwd_prep(pa, st));
         SED_TRY(fork());
-        SED_TRY(launch_gwgrad(g.mode, C, WSF(W.dz[i]), CTXF(L.y[i]), WSF(W.coef[i]), CTXF(L.p[i - 1]), WSF(W.wg_part), grads + P.conv_w[i], g.B,
+        SED_TRY(launch_gwgrad(gm, C, WSF(W.dz[i]), CTXF(L.y[i]), WSF(W.coef[i]), CTXF(L.p[i - 1]), WSF(W.wg_part), grads + P.conv_w[i], g.B,
                               Hs[i], Wd[i], ss));
         if (i == 2 && parts == 3) {
             // on the second helper stream, so that they do not sit in front of wgrad1 on the first (crnn.hip)
@@ -375,8 +381,12 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
             if (have_side) SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, sg, 2 * H));
             SED_TRY(gru_weight_grads(sg));
         }
-        SED_TRY(launch_gconv_dgrad(g.mode, C, WSF(W.dz[i]), CTXF(L.y[i]), WSF(W.coef[i]), CTXV(L.wpkT[i]), WSF(W.dp[i - 1]), g.B, Hs[i],
-                                   Wd[i], st));
+        if (g.mode == SED_DTYPE_BF16X3)
+            SED_TRY(launch_bconv_dgrad(1, C, WSF(W.dz[i]), CTXF(L.y[i]), WSF(W.coef[i]), CTXV(L.wpkT[i]), WSF(W.dp[i - 1]), g.B, Hs[i],
+                                       Wd[i], st));
+        else
+            SED_TRY(launch_gconv_dgrad(g.mode, C, WSF(W.dz[i]), CTXF(L.y[i]), WSF(W.coef[i]), CTXV(L.wpkT[i]), WSF(W.dp[i - 1]), g.B, Hs[i],
+                                       Wd[i], st));
     }
     // ---- conv block 0 -----------------------------------------------------------------------------------------------------
     SED_TRY(launch_blk0_backward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],

@@ -22,6 +22,12 @@ int gwgrad_slabs(int C);
 int launch_gwgrad(int mode, int C, const float* dz, const float* yin, const float* coef, const float* xin, float* part, float* g_w, int B,
                   int H, int W, hipStream_t st);
 
+// bconv.hip: register-blocked bf16 convolution (x3 = 0: bf16 storage, single products; x3 = 1: fp32 storage, split operands)
+int launch_bconv_fwd(int x3, int C, const void* in, const void* wpk, const float* bias, void* y, double* stat, int B, int H, int W,
+                     hipStream_t st);
+int launch_bconv_dgrad(int x3, int C, const void* dz, const void* yin, const float* coef, const void* wpkT, void* dx, int B, int H,
+                       int W, hipStream_t st);
+
 // gglu.hip ----------------------------------------------------------------------------------------------------------------
 struct GBnArgs {
     const double* stat; double N;               // [2][C] sum, sum of squares of the conv output; element count

@@ -8,21 +8,31 @@
 #include "gen.h"
 #include "gkernels.h"
 
+// MODE 0 / 1: every packed operand in fp32 / bf16.  MODE 2 (SED_DTYPE_BF16X3): the conv panels as TWO bf16 planes
+// [hi | lo][n][9 C] (w = hi + lo to ~2^-17 relative; bconv.hip), the GLU operands as in MODE 0.
 template <int MODE>
 __device__ __forceinline__ void gen_pack_body(const GenPackArgs& a, int i) {
-    using M = MM<MODE>;
+    using M = MM<MODE == 2 ? 0 : MODE>;
     using E = typename M::E;
     const int C = a.C, CC = C * C;
     if (i < a.n_zero) a.zero[i] = 0.0;
-    if (i == 0 && a.err) *a.err = 0;
     if (i < 2 * 9 * CC) {
         const int layer = i / (9 * CC), e = i % (9 * CC);
         const int n = e / (9 * C), r = e % (9 * C), tap = r / C, k = r % C;
         const float* w = layer ? a.w2 : a.w1;
-        E* wpk = (E*)(layer ? a.wpk2 : a.wpk1);
-        E* wpkT = (E*)(layer ? a.wpkT2 : a.wpkT1);
-        wpk[e] = M::cvt(w[((size_t)n * C + k) * 9 + tap]);
-        if (wpkT) wpkT[e] = M::cvt(w[((size_t)k * C + n) * 9 + (8 - tap)]);
+        const float wf = w[((size_t)n * C + k) * 9 + tap], wt = w[((size_t)k * C + n) * 9 + (8 - tap)];
+        if (MODE == 2) {
+            __bf16* wpk = (__bf16*)(layer ? a.wpk2 : a.wpk1);
+            __bf16* wpkT = (__bf16*)(layer ? a.wpkT2 : a.wpkT1);
+            const __bf16 h = (__bf16)wf;
+            wpk[e] = h; wpk[9 * CC + e] = (__bf16)(wf - (float)h);
+            if (wpkT) { const __bf16 ht = (__bf16)wt; wpkT[e] = ht; wpkT[9 * CC + e] = (__bf16)(wt - (float)ht); }
+        } else {
+            E* wpk = (E*)(layer ? a.wpk2 : a.wpk1);
+            E* wpkT = (E*)(layer ? a.wpkT2 : a.wpkT1);
+            wpk[e] = M::cvt(wf);
+            if (wpkT) wpkT[e] = M::cvt(wt);
+        }
     }
     if (i < 2 * CC) {
         const int layer = i / CC, e = i % CC, co = e / C, c = e % C;
@@ -78,6 +88,7 @@ __device__ __forceinline__ void gen_aux_body(const GenAuxPack& a, int pb, int ti
     const int np = gen_aux_pack_blocks(a);
     if (b < np) {
         if (a.mode == 1) gen_pack_body<1>(a.pk, b * 256 + tid);
+        else if (a.mode == 2) gen_pack_body<2>(a.pk, b * 256 + tid);
         else gen_pack_body<0>(a.pk, b * 256 + tid);
         return;
     }

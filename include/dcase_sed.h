@@ -41,12 +41,21 @@ typedef enum {
  *   C in {64, 128}, H in {64, 256}, either dtype: the generic kernel set (gen.h) - BASELINE.json configs[4]'s wide CRNN
  *   (nb_filters 3 x 128, n_RNN_cell 256) and the bf16-operand variants of configs[2] / [4].
  * dtype selects the arithmetic of the GEMM-shaped operators of conv blocks 1 and 2 (3x3 convolutions forward / dgrad,
- * the GLU's Linear forward / backward): SED_DTYPE_F32 = exact fp32 MFMA; SED_DTYPE_BF16 = operands rounded to bf16
- * (round-to-nearest-even) when they are staged on chip, fp32 accumulation.  Everything else - all tensors in HBM, conv
- * block 0, BatchNorm statistics, the gates, every weight gradient, the GRU, the heads, the loss, Adam - is fp32 in both.
- * It is never chosen silently: the caller states it here. */
+ * the GLU's Linear forward / backward):
+ *   SED_DTYPE_F32     exact fp32 MFMA.
+ *   SED_DTYPE_BF16    operands rounded to bf16 (round-to-nearest-even), fp32 accumulation; the fastest mode.  Measured
+ *                     posterior error against the fp32 reference: <= 1.3e-3 (base geometry), 1.6e-3 (wide) - ABOVE the
+ *                     1e-3 the north star names; tests assert the measured bound.
+ *   SED_DTYPE_BF16X3  split operands: every fp32 operand a is carried as a_hi + a_lo (both bf16) and a product is formed
+ *                     as a_hi b_hi + a_hi b_lo + a_lo b_hi on the bf16 MFMA with fp32 accumulation - three MFMAs per
+ *                     K = 16 (96 cycles against 512 for the exact-fp32 MFMA), relative error ~2^-16 per product.  The
+ *                     3x3 convolutions forward / dgrad run this way; everything else is as in SED_DTYPE_F32.  This is the
+ *                     reduced-precision mode that HOLDS the north star's 1e-3 (asserted at 1e-3 on the wide model).
+ * Everything else - conv block 0's statistics, BatchNorm statistics, the gates, the GRU, the heads, the loss, Adam - is
+ * fp32 in all modes.  The mode is never chosen silently: the caller states it here. */
 #define SED_DTYPE_F32 0
 #define SED_DTYPE_BF16 1
+#define SED_DTYPE_BF16X3 2
 typedef struct {
     int32_t B;            /* clips in the batch                                  */
     int32_t T;            /* input frames (628 for BASELINE, 864 for config.py)  */
@@ -58,7 +67,7 @@ typedef struct {
     float   p_drop;       /* dropout probability (config.py:56), 0 disables      */
     float   bn_eps;       /* 1e-3 (models/CNN.py:49)                             */
     float   bn_momentum;  /* 0.99 (models/CNN.py:49)                             */
-    int32_t dtype;        /* SED_DTYPE_F32 / SED_DTYPE_BF16                      */
+    int32_t dtype;        /* SED_DTYPE_F32 / SED_DTYPE_BF16 / SED_DTYPE_BF16X3   */
 } sed_dims;
 
 /* Per-step scalars kept in DEVICE memory so that a captured hipGraph can be replayed while the

@@ -335,4 +335,8 @@ class CRNN(nn.Module):
         off, nb = C.c_size_t(), C.c_size_t()
         _lib.check(_lib.lib().sed_crnn_ctx_view(C.byref(dims), name.encode(), C.byref(off), C.byref(nb)), "sed_crnn_ctx_view")
         raw = cbuf[off.value:off.value + nb.value]
-        return raw.view(torch.float64 if name in ("mom0", "stat1", "stat2") else torch.float32)
+        if name in ("mom0", "stat1", "stat2"):
+            return raw.view(torch.float64)
+        if dims.dtype == _lib.DTYPE_BF16 and name in ("p0", "y1", "p1", "y2"):
+            return raw.view(torch.bfloat16).float()       # SED_DTYPE_BF16 stores the conv-block activations as bf16
+        return raw.view(torch.float32)

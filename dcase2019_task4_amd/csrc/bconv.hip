@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bconv(const void* __restrict__
                                                           double* __restrict__ stat, int H, int tiles_per_clip, int n_tiles) {
     using Cfg = BConvCfg<X3, C, TW, TH, WM, WN>;
     using S = typename BStore<X3>::T;
-    constexpr int NT = Cfg::NT, MB = Cfg::MB, NB = Cfg::NB, HW = Cfg::HW, HH = Cfg::HH, PS = Cfg::PS, RP = Cfg::RP;
+    constexpr int NT = Cfg::NT, MB = Cfg::MB, NB = Cfg::NB, HH = Cfg::HH, PS = Cfg::PS, RP = Cfg::RP;
     constexpr int KC = Cfg::KC, BROW = Cfg::BROW, BBUF = Cfg::BBUF, PL = Cfg::PLANES, HPL = Cfg::HALO_PLANE;
     constexpr int K = 9 * C, NCH = K / KC, CPT = C / KC;                  // chunks per tap
     constexpr int CJ = C / 8;                                             // 16-byte channel groups per pixel

@@ -429,8 +429,10 @@ __global__ __launch_bounds__(256, (NH == 2 ? 3 : 2)) void k_blk0_fwd(const float
                 if (pooled[0] == 12345.678f)
 #endif
                 {
-                    p0[(size_t)(q0 + j0) * C + c] = (kh ? pooled[2] : pooled[0]) * sc;
-                    p0[(size_t)(q0 + j0 + 1) * C + c] = (kh ? pooled[3] : pooled[1]) * sc;
+                    // (MODE 1 = SED_DTYPE_BF16: the pooled output is stored as bf16, gen.h)
+                    using PT = typename Stor<MODE == 1>::T;
+                    st1((PT*)p0 + (size_t)(q0 + j0) * C + c, (kh ? pooled[2] : pooled[0]) * sc);
+                    st1((PT*)p0 + (size_t)(q0 + j0 + 1) * C + c, (kh ? pooled[3] : pooled[1]) * sc);
                 }
             };
             load_av(g0);
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
             for (int h = 0; h < NH; ++h) {
                 const int c = 32 * h + n;
 #pragma unroll
-                for (int jx = 0; jx < 4; ++jx) gq_n[h][jx] = dp0[(size_t)(q0 + jx) * C + c];
+                for (int jx = 0; jx < 4; ++jx) gq_n[h][jx] = ld1((const typename Stor<MODE == 1>::T*)dp0 + (size_t)(q0 + jx) * C + c);
                 m_n[h] = use_drop ? (uint32_t)mask_in[((size_t)(q0 >> 2) * NH + h) * 64 + lane] : 0xffffu;
             }
         };

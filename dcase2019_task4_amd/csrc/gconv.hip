@@ -229,11 +229,16 @@ struct GWgCfg {
     static constexpr int X_F = HH * HW * PS, DY_F = 128 * PS;
     static constexpr size_t LDS_BYTES = (size_t)(X_F + DY_F + 3 * 64) * 4;
 };
-template <int TW>
-__global__ __launch_bounds__(256) void k_gwgrad(const float* __restrict__ dz, const float* __restrict__ yin,
-                                                 const float* __restrict__ coef, const float* __restrict__ xin,
+// BF: dz, yin and xin are stored as bf16 (SED_DTYPE_BF16); the products stay fp32 (this kernel serves block 2 in that mode)
+template <int TW, int BF>
+__global__ __launch_bounds__(256) void k_gwgrad(const void* __restrict__ dz_v, const void* __restrict__ yin_v,
+                                                 const float* __restrict__ coef, const void* __restrict__ xin_v,
                                                  float* __restrict__ part, int C, int H, int tiles_per_clip, int n_tiles) {
     using Cfg = GWgCfg<TW>;
+    using ST = typename Stor<BF>::T;
+    const ST* dz = (const ST*)dz_v;
+    const ST* yin = (const ST*)yin_v;
+    const ST* xin = (const ST*)xin_v;
     constexpr int TH = Cfg::TH, HW = Cfg::HW, HH = Cfg::HH, PS = Cfg::PS;
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float* xs = wsm;                       // halo of x: [HH * HW][PS] (this quadrant's 64 input channels)
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(256) void k_gwgrad(const float* __restrict__ dz, co
             const int hy = hp / HW, hx = hp % HW, row = r0 - 1 + hy, col = hx - 1;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (row >= 0 && row < H && col >= 0 && col < TW)
-                v = *(const f32x4*)(xin + ((size_t)(b * H + row) * TW + col) * C + ci0 + 4 * c4);
+                v = ld4(xin + ((size_t)(b * H + row) * TW + col) * C + ci0 + 4 * c4);
             float* d = xs + hp * PS + 4 * c4;
             d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
         }
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(256) void k_gwgrad(const float* __restrict__ dz, co
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (row < H) {
                 const size_t off = ((size_t)(b * H + row) * TW + cc) * C + co0 + 4 * c4;
-                const f32x4 z = *(const f32x4*)(dz + off), y = *(const f32x4*)(yin + off);
+                const f32x4 z = ld4(dz + off), y = ld4(yin + off);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = cf[4 * c4 + q] * z[q] + cf[64 + 4 * c4 + q] * y[q] + cf[128 + 4 * c4 + q];
             }
@@ -312,8 +317,8 @@ struct GWgB {
     static constexpr int DY_E = 64 * DS, X_E = 3 * 64 * XS;
     static constexpr size_t LDS_BYTES = (size_t)(DY_E + X_E) * 2 + 3 * 64 * 4;
 };
-__global__ __launch_bounds__(256) void k_gwgrad_bf16(const float* __restrict__ dz, const float* __restrict__ yin,
-                                                      const float* __restrict__ coef, const float* __restrict__ xin,
+__global__ __launch_bounds__(256) void k_gwgrad_bf16(const __bf16* __restrict__ dz, const __bf16* __restrict__ yin,
+                                                      const float* __restrict__ coef, const __bf16* __restrict__ xin,
                                                       float* __restrict__ part, int C, int H, int tiles_per_clip, int n_tiles) {
     using M = MM<1>;
     constexpr int TH = GWgB::TH, DS = GWgB::DS, XS = GWgB::XS;
@@ -341,8 +346,8 @@ __global__ __launch_bounds__(256) void k_gwgrad_bf16(const float* __restrict__ d
             const size_t base = ((size_t)(b * H + (ok ? row : 0)) * 16 + c0) * C + co0 + 4 * cq;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                dzv[i] = *(const f32x4*)(dz + base + (size_t)i * C);
-                yv[i] = *(const f32x4*)(yin + base + (size_t)i * C);
+                dzv[i] = ld4(dz + base + (size_t)i * C);
+                yv[i] = ld4(yin + base + (size_t)i * C);
                 if (!ok) { dzv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; yv[i] = dzv[i]; }
             }
         }
@@ -355,7 +360,7 @@ __global__ __launch_bounds__(256) void k_gwgrad_bf16(const float* __restrict__ d
             for (int i = 0; i < 10; ++i) {
                 const int col = 8 * cg - 1 + i;
                 xv[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (rok && col >= 0 && col < 16) xv[j][i] = *(const f32x4*)(xin + ((size_t)(b * H + row) * 16 + col) * C + ci0 + 4 * cq);
+                if (rok && col >= 0 && col < 16) xv[j][i] = ld4(xin + ((size_t)(b * H + row) * 16 + col) * C + ci0 + 4 * cq);
             }
         }
     };
@@ -435,7 +440,7 @@ __global__ __launch_bounds__(256) void k_gwgrad_reduce(const float* __restrict__
 
 int gwgrad_slabs(int C) { return 256 / ((C / 64) * (C / 64)); }
 
-int launch_gwgrad(int mode, int C, const float* dz, const float* yin, const float* coef, const float* xin, float* part, float* g_w,
+int launch_gwgrad(int mode, int C, const void* dz, const void* yin, const float* coef, const void* xin, float* part, float* g_w,
                   int B, int H, int W, hipStream_t st) {
     SED_CHECK_ARG(C == 64 || C == 128, "gwgrad: C must be 64 or 128");
     const int nq = (C / 64) * (C / 64);
@@ -446,21 +451,26 @@ int launch_gwgrad(int mode, int C, const float* dz, const float* yin, const floa
         if (!attr) { SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GWgB::LDS_BYTES)); attr = true; }
         tpc = (H + GWgB::TH - 1) / GWgB::TH; nt = B * tpc;
         if (slabs > nt) slabs = nt;
-        k_gwgrad_bf16<<<dim3(slabs, nq), 256, GWgB::LDS_BYTES, st>>>(dz, yin, coef, xin, part, C, H, tpc, nt);
+        k_gwgrad_bf16<<<dim3(slabs, nq), 256, GWgB::LDS_BYTES, st>>>((const __bf16*)dz, (const __bf16*)yin, coef, (const __bf16*)xin, part, C, H, tpc, nt);
     } else if (W == 16) {
         using Cfg = GWgCfg<16>;
         static bool attr = false;
-        if (!attr) { SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES)); attr = true; }
+        if (!attr) { SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad<16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES)); attr = true; }
         tpc = (H + Cfg::TH - 1) / Cfg::TH; nt = B * tpc;
         if (slabs > nt) slabs = nt;
-        k_gwgrad<16><<<dim3(slabs, nq), 256, Cfg::LDS_BYTES, st>>>(dz, yin, coef, xin, part, C, H, tpc, nt);
+        k_gwgrad<16, 0><<<dim3(slabs, nq), 256, Cfg::LDS_BYTES, st>>>(dz, yin, coef, xin, part, C, H, tpc, nt);
     } else if (W == 4) {
         using Cfg = GWgCfg<4>;
         static bool attr = false;
-        if (!attr) { SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES)); attr = true; }
+        if (!attr) {
+            SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
+            SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
+            attr = true;
+        }
         tpc = (H + Cfg::TH - 1) / Cfg::TH; nt = B * tpc;
         if (slabs > nt) slabs = nt;
-        k_gwgrad<4><<<dim3(slabs, nq), 256, Cfg::LDS_BYTES, st>>>(dz, yin, coef, xin, part, C, H, tpc, nt);
+        if (mode == SED_DTYPE_BF16) k_gwgrad<4, 1><<<dim3(slabs, nq), 256, Cfg::LDS_BYTES, st>>>(dz, yin, coef, xin, part, C, H, tpc, nt);
+        else k_gwgrad<4, 0><<<dim3(slabs, nq), 256, Cfg::LDS_BYTES, st>>>(dz, yin, coef, xin, part, C, H, tpc, nt);
     } else {
         sed_set_error("gwgrad: unsupported width %d", W);
         return SED_ERR_UNSUPPORTED;

@@ -13,6 +13,9 @@
 
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline size_t esz(const Geo& g) { return g.mode == SED_DTYPE_BF16 ? 2 : 4; }
+// bytes per element of the conv-block activations / gradients in HBM (p0, y1, p1, y2; dz1, dz2, dp0, dp1): bf16 in
+// SED_DTYPE_BF16 mode, fp32 otherwise (gen.h Stor<>); p2 - the GRU input - and dp2 are always fp32
+static inline size_t ssz(const Geo& g) { return g.mode == SED_DTYPE_BF16 ? 2 : 4; }
 static inline int gru_splitk(const Geo& g) { return g.H == 64 ? SED_GRU_SPLITK : 4; }
 // split-K partials of the GRU weight-gradient batch: the W_ih problems have N = nin (C, or 2H for layer 1), the W_hh
 // problems N = H - the batch's stride is set by the LARGEST of them (with one layer and H > C that is H, not C)
@@ -45,12 +48,13 @@ static GCtx make_gctx(const Geo& g) {
     L.mom0 = L.acc0; L.stat1 = L.acc0 + 64 * sizeof(double); L.stat2 = L.stat1 + 2 * C * sizeof(double);
     put(L.wz0, C * 12 * 4); put(L.wl0, C * 12 * 4); put(L.bn0, 4 * C * 4);
     put(L.mompart, (size_t)x_moments_parts(g) * 54 * sizeof(double));
-    put(L.p0, n0 * 4);
+    const size_t SS = ssz(g);
+    put(L.p0, n0 * SS);
     L.p[0] = L.p0;
     const size_t nn[3] = {0, n0, n1}, np[3] = {n0, n1, n2};
     for (int i = 1; i <= 2; ++i) {
         put(L.wpk[i], 9 * C * C * E); put(L.wpkT[i], 9 * C * C * E); put(L.wg[i], C * C * E); put(L.wgT[i], C * C * E);
-        put(L.bg[i], C * 4); put(L.y[i], nn[i] * 4); put(L.bn[i], 4 * C * 4); put(L.p[i], np[i] * 4);
+        put(L.bg[i], C * 4); put(L.y[i], nn[i] * SS); put(L.bn[i], 4 * C * 4); put(L.p[i], np[i] * (i == 2 ? 4 : SS));
     }
     const size_t bt = (size_t)g.B * g.T3;
     for (int l = 0; l < 2; ++l) {
@@ -86,7 +90,8 @@ static GWs make_gws(const Geo& g) {
     for (int l = 0; l < 2; ++l) { put(W.dgi[l], bt * 6 * H * 4); put(W.dgh[l], bt * 6 * H * 4); put(W.hprev[l], bt * 2 * H * 4); }
     put(W.d_in, 2 * bt * 2 * H * 4);          // (H = 64: two direction planes, gru.hip; generic: one tensor)
     put(W.heads_part, (size_t)g.B * 2 * (g.NC * 2 * H + g.NC) * 4);
-    put(W.dp[2], 2 * bt * C * 4); put(W.dz[2], n1 * 4); put(W.dp[1], n1 * 4); put(W.dz[1], n0 * 4); put(W.dp[0], n0 * 4);
+    const size_t SS = ssz(g);
+    put(W.dp[2], 2 * bt * C * 4); put(W.dz[2], n1 * SS); put(W.dp[1], n1 * SS); put(W.dz[1], n0 * SS); put(W.dp[0], n0 * SS);
     W.dz[0] = 0; W.coef[0] = 0;
     put(W.coef[1], 3 * C * 4); put(W.coef[2], 3 * C * 4);
     put(W.glu_part, (size_t)gglu_bwd_grid(g.B, g.H1, g.W1) * (C * C + 3 * C) * 4);
@@ -105,7 +110,7 @@ size_t gen_ws_bytes(const Geo& g) { return make_gws(g).total; }
 int gen_ctx_view(const Geo& g, const char* name, size_t* offset, size_t* bytes) {
     const GCtx L = make_gctx(g);
     const size_t C = g.C, H = g.H, bt = (size_t)g.B * g.T3;
-    const size_t n0 = (size_t)g.B * g.H1 * g.W1 * C * 4, n1 = (size_t)g.B * g.H2 * g.W2 * C * 4;
+    const size_t n0 = (size_t)g.B * g.H1 * g.W1 * C * ssz(g), n1 = (size_t)g.B * g.H2 * g.W2 * C * ssz(g);
     struct { const char* n; size_t o, b; } tab[] = {
         {"mom0", L.mom0, 64 * 8}, {"bn0", L.bn0, 4 * C * 4}, {"p0", L.p[0], n0}, {"y1", L.y[1], n0}, {"stat1", L.stat1, 2 * C * 8},
         {"bn1", L.bn[1], 4 * C * 4}, {"p1", L.p[1], n1}, {"y2", L.y[2], n1}, {"stat2", L.stat2, 2 * C * 8}, {"bn2", L.bn[2], 4 * C * 4},
@@ -202,6 +207,9 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
     }
     // (debug bit 10: the streaming recurrence kernels instead of the cluster ones - A/B timing)
     const bool cluster = (H == 256) && !(g_sed_debug & 1024);
+    // SED_DTYPE_BF16 at H = 256: one workgroup per chain, W_hh as bf16 in registers (grec.hip; debug bit 11 falls back to
+    // the fp32 cluster kernels)
+    const bool rec16 = cluster && g.mode == SED_DTYPE_BF16 && !(g_sed_debug & 2048);
     if (H != 64 && !cluster)
         for (int l = 0; l < g.L; ++l)
             SED_TRY(launch_ggru_pack(params + P.w_hh[l][0], params + P.w_hh[l][1], CTXF(L.whh[l]), train ? CTXF(L.whhT[l]) : nullptr, H, ss));
@@ -218,8 +226,8 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
     const size_t so[3] = {0, L.stat1, L.stat2};
     const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};
     for (int i = 1; i <= 2; ++i) {
-        if (g.mode == SED_DTYPE_BF16X3)
-            SED_TRY(launch_bconv_fwd(1, C, CTXF(L.p[i - 1]), CTXV(L.wpk[i]), params + P.conv_b[i], CTXF(L.y[i]),
+        if (g.mode != SED_DTYPE_F32)      // bf16 (bf16 storage) / bf16x3 (fp32 storage, split operands): bconv.hip
+            SED_TRY(launch_bconv_fwd(g.mode == SED_DTYPE_BF16X3, C, CTXV(L.p[i - 1]), CTXV(L.wpk[i]), params + P.conv_b[i], CTXV(L.y[i]),
                                      train ? CTXD(so[i]) : nullptr, g.B, Hs[i], Wd[i], st));
         else
             SED_TRY(launch_gconv_fwd(g.mode, C, CTXF(L.p[i - 1]), CTXV(L.wpk[i]), params + P.conv_b[i], CTXF(L.y[i]),
@@ -228,7 +236,8 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
         bn.stat = CTXD(so[i]); bn.N = (double)g.B * Hs[i] * Wd[i]; bn.gamma = params + P.bn_g[i]; bn.beta = params + P.bn_b[i];
         bn.run_mean = bn_running + (2 * i) * C; bn.run_var = bn_running + (2 * i + 1) * C; bn.tracked = trk[i];
         bn.train = train; bn.update = upd; bn.eps = g.eps; bn.momentum = g.mom; bn.bn = CTXF(L.bn[i]);
-        SED_TRY(launch_gglu_fwd(gm, C, CTXF(L.y[i]), bn, CTXV(L.wg[i]), CTXF(L.bg[i]), CTXF(L.p[i]), g.B, Hs[i], Wd[i], i,
+        SED_TRY(launch_gglu_fwd(gm, C, CTXV(L.y[i]), bn, CTXV(L.wg[i]), CTXF(L.bg[i]), CTXV(L.p[i]),
+                                (g.mode == SED_DTYPE_BF16 && i == 1) ? 1 : 0, g.B, Hs[i], Wd[i], i,
                                 use_drop, g.p, seed_dev, use_drop ? CTXM(L.mask[i]) : nullptr, st));
     }
     // ---- BiGRU ----------------------------------------------------------------------------------------------------------
@@ -247,7 +256,11 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
             for (int dir = 0; dir < 2; ++dir)
                 gb.p[dir] = GntProb{in, nin, params + P.w_ih[l][dir], nin, CTXF(L.gi[l]) + dir * 3 * H, 6 * H, params + P.b_ih[l][dir], BT, 3 * H, nin};
             SED_TRY(launch_gnt_gemm(gb, st));
-            if (cluster)
+            if (rec16) {
+                SED_TRY(launch_grec_pack(params + P.w_hh[l][0], params + P.w_hh[l][1], CTXV(L.whh[l]), train ? CTXV(L.whhT[l]) : nullptr, st));
+                SED_TRY(launch_grec_fwd(CTXF(L.gi[l]), CTXV(L.whh[l]), params + P.b_hh[l][0], params + P.b_hh[l][1], CTXF(L.out[l]),
+                                        train ? CTXF(L.gates[l]) : nullptr, g.B, g.T3, st));
+            } else if (cluster)
                 SED_TRY(launch_gclu_fwd(CTXF(L.gi[l]), params + P.w_hh[l][0], params + P.w_hh[l][1], params + P.b_hh[l][0],
                                         params + P.b_hh[l][1], CTXF(L.out[l]), train ? CTXF(L.gates[l]) : nullptr, CTXV(L.xch[l]),
                                         (unsigned int*)CTXV(L.epoch[l]), (int*)CTXV(L.err), g.B, g.T3, st));
@@ -309,7 +322,10 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
                 d_cur = d_in;
                 d_cur2 = d_in + (size_t)BT * nin;
             } else {
-                if (H == 256 && !(g_sed_debug & 1024))
+                if (H == 256 && g.mode == SED_DTYPE_BF16 && !(g_sed_debug & (1024 | 2048)))
+                    SED_TRY(launch_grec_bwd(d_cur, CTXF(L.out[l]), CTXF(L.gates[l]), CTXV(L.whhT[l]), WSF(W.dgi[l]), WSF(W.dgh[l]),
+                                            WSF(W.hprev[l]), g.B, g.T3, st));
+                else if (H == 256 && !(g_sed_debug & 1024))
                     SED_TRY(launch_gclu_bwd(d_cur, CTXF(L.out[l]), CTXF(L.gates[l]), params + P.w_hh[l][0], params + P.w_hh[l][1],
                                             WSF(W.dgi[l]), WSF(W.dgh[l]), WSF(W.hprev[l]), (void*)((char*)ws + W.xch[l]),
                                             (unsigned int*)((char*)ws + W.epoch[l]), (int*)CTXV(L.err), g.B, g.T3, st));
@@ -357,8 +373,9 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
     const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};
     for (int i = 2; i >= 1; --i) {
         // (H = 64: the GRU's dX arrives as two direction planes; the GLU backward adds them while loading)
-        SED_TRY(launch_gglu_bwd(gm, C, CTXF(L.y[i]), CTXF(L.bn[i]), params + P.bn_g[i], params + P.bn_b[i], CTXV(L.wg[i]),
-                                CTXV(L.wgT[i]), CTXF(L.bg[i]), WSF(W.dp[i]), WSF(W.dz[i]), WSF(W.glu_part), g.B, Hs[i], Wd[i], use_drop,
+        SED_TRY(launch_gglu_bwd(gm, C, CTXV(L.y[i]), CTXF(L.bn[i]), params + P.bn_g[i], params + P.bn_b[i], CTXV(L.wg[i]),
+                                CTXV(L.wgT[i]), CTXF(L.bg[i]), WSF(W.dp[i]), (g.mode == SED_DTYPE_BF16 && i == 1) ? 1 : 0,
+                                WSF(W.dz[i]), WSF(W.glu_part), g.B, Hs[i], Wd[i], use_drop,
                                 g.p, CTXM(L.mask[i]), st, (i == 2 && H == 64) ? WSF(W.dp[2]) + (size_t)BT * C : nullptr));
         GBnBwdArgs pa;
         pa.part = WSF(W.glu_part); pa.n_part = gglu_bwd_grid(g.B, Hs[i], Wd[i]); pa.C = C; pa.N = (double)g.B * Hs[i] * Wd[i];
@@ -381,9 +398,9 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
             if (have_side) SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, sg, 2 * H));
             SED_TRY(gru_weight_grads(sg));
         }
-        if (g.mode == SED_DTYPE_BF16X3)
-            SED_TRY(launch_bconv_dgrad(1, C, WSF(W.dz[i]), CTXF(L.y[i]), WSF(W.coef[i]), CTXV(L.wpkT[i]), WSF(W.dp[i - 1]), g.B, Hs[i],
-                                       Wd[i], st));
+        if (g.mode != SED_DTYPE_F32)
+            SED_TRY(launch_bconv_dgrad(g.mode == SED_DTYPE_BF16X3, C, WSF(W.dz[i]), CTXV(L.y[i]), WSF(W.coef[i]), CTXV(L.wpkT[i]),
+                                       WSF(W.dp[i - 1]), g.B, Hs[i], Wd[i], st));
         else
             SED_TRY(launch_gconv_dgrad(g.mode, C, WSF(W.dz[i]), CTXF(L.y[i]), WSF(W.coef[i]), CTXV(L.wpkT[i]), WSF(W.dp[i - 1]), g.B, Hs[i],
                                        Wd[i], st));

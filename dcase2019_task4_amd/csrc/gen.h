@@ -16,6 +16,20 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
+// ---- storage of the conv-block activations / gradients in HBM: fp32, or bf16 in SED_DTYPE_BF16 mode ----------------------
+// (p0, y1, p1, y2 in ctx; dz1, dz2, dp0, dp1 in the backward workspace.  p2 - the GRU input - and dp2 stay fp32.)
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ f32x4 ld4(const __bf16* p) {
+    const bf16x4 v = *(const bf16x4*)p;
+    return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const __bf16* p) { return (float)*p; }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(__bf16* p, float v) { *p = (__bf16)v; }
+template <int BF> struct Stor { using T = float; };
+template <> struct Stor<1> { using T = __bf16; };
+
 template <int MODE> struct MM;
 template <> struct MM<0> {
     using E = float;

@@ -44,8 +44,8 @@ __device__ __forceinline__ void gbn_prep(const GBnArgs& a, int C, int c, bool pu
 // forward kernel issues the NEXT round's loads before the current round's MFMAs.
 template <int C>
 struct GGluTile { f32x4 v[32 * (C / 4) / 64]; };
-template <int C>
-__device__ __forceinline__ void gglu_load(GGluTile<C>& t, const float* __restrict__ y, int q0, int Q, int H, int W, int Ho, int Wo,
+template <int C, class YT>
+__device__ __forceinline__ void gglu_load(GGluTile<C>& t, const YT* __restrict__ y, int q0, int Q, int H, int W, int Ho, int Wo,
                                           int lane) {
     constexpr int C4 = C / 4;
     int pb[4];
@@ -58,7 +58,7 @@ __device__ __forceinline__ void gglu_load(GGluTile<C>& t, const float* __restric
         const int base = (j == 0) ? pb[0] : (j == 1) ? pb[1] : (j == 2) ? pb[2] : pb[3];
         // invalid pooled pixels (only past the end of the last row block) read pixel 0 and are zeroed at the store
         const size_t off = (size_t)((base >= 0 ? base : 0) + dt * W + df) * C + 4 * c4;
-        t.v[i] = *(const f32x4*)(y + off);
+        t.v[i] = ld4(y + off);
         if (base < 0) t.v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 }
@@ -90,14 +90,19 @@ struct GGluFwdCfg {
     static constexpr size_t LDS_BYTES = XF_BYTES + XB_BYTES + WBUF_BYTES + 2 * C * 4 + 64;
 };
 
-template <int MODE, int C>
-__global__ __launch_bounds__(256) void k_gglu_fwd(const float* __restrict__ y, GBnArgs bnp, const void* __restrict__ wg_v,
-                                                   const float* __restrict__ bg, float* __restrict__ p, int H, int W, int Ho,
+// PB: the pooled output is stored as bf16 (SED_DTYPE_BF16, block 1; block 2's output p2 feeds the fp32 GRU)
+template <int MODE, int C, int PB>
+__global__ __launch_bounds__(256) void k_gglu_fwd(const void* __restrict__ y_v, GBnArgs bnp, const void* __restrict__ wg_v,
+                                                   const float* __restrict__ bg, void* __restrict__ p_v, int H, int W, int Ho,
                                                    int Wo, int Q, int block_id, int use_drop, float p_drop,
                                                    const uint64_t* __restrict__ seed_ptr, uint16_t* __restrict__ mask_out) {
     using Cfg = GGluFwdCfg<MODE, C>;
     using M = MM<MODE>;
     using E = typename M::E;
+    using YT = typename Stor<MODE == 1>::T;
+    using PT = typename Stor<PB>::T;
+    const YT* y = (const YT*)y_v;
+    PT* p = (PT*)p_v;
     constexpr int NB = C / 32, XS = Cfg::XS, BS = Cfg::BS;
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     float* xf_all = (float*)gsm;
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(256) void k_gglu_fwd(const float* __restrict__ y, G
     GGluTile<C> yt;
     {
         const int rb0 = blockIdx.x * 4 + wv;
-        gglu_load<C>(yt, y, (rb0 < n_rb ? rb0 : 0) * 4, Q, H, W, Ho, Wo, lane);
+        gglu_load<C, YT>(yt, y, (rb0 < n_rb ? rb0 : 0) * 4, Q, H, W, Ho, Wo, lane);
     }
     for (int round = 0; round < rounds; ++round) {
         const int rb = (round * gridDim.x + blockIdx.x) * 4 + wv;
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256) void k_gglu_fwd(const float* __restrict__ y, G
         if (live) gglu_store<MODE, C>(yt, bn_s, xf, xb, q0, Q, lane);
         {   // the next round's tile flies during this round's MFMAs and epilogue (past the end: row block 0, never used)
             const int rbn = ((round + 1) * gridDim.x + blockIdx.x) * 4 + wv;
-            gglu_load<C>(yt, y, (rbn < n_rb ? rbn : 0) * 4, Q, H, W, Ho, Wo, lane);
+            gglu_load<C, YT>(yt, y, (rbn < n_rb ? rbn : 0) * 4, Q, H, W, Ho, Wo, lane);
         }
         f32x16 acc[NB];
 #pragma unroll
@@ -158,36 +163,36 @@ __global__ __launch_bounds__(256) void k_gglu_fwd(const float* __restrict__ y, G
 #pragma unroll
                 for (int jx = 0; jx < 4; ++jx) pooled[jx] += __shfl_xor(pooled[jx], 32);
                 const int j0 = 2 * kh;
-                if (q0 + j0 < Q) p[(size_t)(q0 + j0) * C + c] = (kh ? pooled[2] : pooled[0]) * sc;
-                if (q0 + j0 + 1 < Q) p[(size_t)(q0 + j0 + 1) * C + c] = (kh ? pooled[3] : pooled[1]) * sc;
+                if (q0 + j0 < Q) st1(p + (size_t)(q0 + j0) * C + c, (kh ? pooled[2] : pooled[0]) * sc);
+                if (q0 + j0 + 1 < Q) st1(p + (size_t)(q0 + j0 + 1) * C + c, (kh ? pooled[3] : pooled[1]) * sc);
             }
         }
         // (the tile is rewritten by this same wave in the next round; other waves only share wbuf, which stream_gemm guards)
     }
 }
 
-template <int MODE, int C>
-static int gglu_fwd_launch(const float* y, const GBnArgs& bn, const void* wg, const float* bg, float* p, int B, int H, int W,
+template <int MODE, int C, int PB>
+static int gglu_fwd_launch(const void* y, const GBnArgs& bn, const void* wg, const float* bg, void* p, int B, int H, int W,
                            int block_id, int use_drop, float p_drop, const uint64_t* seed, uint16_t* mask_out, hipStream_t st) {
     using Cfg = GGluFwdCfg<MODE, C>;
     static bool attr = false;
     if (!attr) {
-        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gglu_fwd<MODE, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gglu_fwd<MODE, C, PB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
         attr = true;
     }
     const int Ho = H / 2, Wo = W / 4, Q = B * Ho * Wo, n_rb = (Q + 3) / 4;
     int grid = (n_rb + 3) / 4;
     if (grid > 512) grid = 512;
-    k_gglu_fwd<MODE, C><<<grid, 256, Cfg::LDS_BYTES, st>>>(y, bn, wg, bg, p, H, W, Ho, Wo, Q, block_id, use_drop, p_drop, seed, mask_out);
+    k_gglu_fwd<MODE, C, PB><<<grid, 256, Cfg::LDS_BYTES, st>>>(y, bn, wg, bg, p, H, W, Ho, Wo, Q, block_id, use_drop, p_drop, seed, mask_out);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
 
-int launch_gglu_fwd(int mode, int C, const float* y, const GBnArgs& bn, const void* wg, const float* bg, float* p, int B, int H,
-                    int W, int block_id, int use_drop, float p_drop, const uint64_t* seed, uint16_t* mask_out, hipStream_t st) {
-#define GGLU_CASE(MD, CC) \
-    if (mode == MD && C == CC) return gglu_fwd_launch<MD, CC>(y, bn, wg, bg, p, B, H, W, block_id, use_drop, p_drop, seed, mask_out, st)
-    GGLU_CASE(0, 64); GGLU_CASE(0, 128); GGLU_CASE(1, 64); GGLU_CASE(1, 128);
+int launch_gglu_fwd(int mode, int C, const void* y, const GBnArgs& bn, const void* wg, const float* bg, void* p, int p_bf16, int B,
+                    int H, int W, int block_id, int use_drop, float p_drop, const uint64_t* seed, uint16_t* mask_out, hipStream_t st) {
+#define GGLU_CASE(MD, CC, PP) \
+    if (mode == MD && C == CC && p_bf16 == PP) return gglu_fwd_launch<MD, CC, PP>(y, bn, wg, bg, p, B, H, W, block_id, use_drop, p_drop, seed, mask_out, st)
+    GGLU_CASE(0, 64, 0); GGLU_CASE(0, 128, 0); GGLU_CASE(1, 64, 0); GGLU_CASE(1, 128, 0); GGLU_CASE(1, 64, 1); GGLU_CASE(1, 128, 1);
 #undef GGLU_CASE
     sed_set_error("gglu forward: unsupported mode %d / channels %d", mode, C);
     return SED_ERR_UNSUPPORTED;
@@ -221,16 +226,23 @@ struct GGluBwdCfg {
     static constexpr size_t LDS_BYTES = XF_BYTES + DF_BYTES + XB_BYTES + DB_BYTES + TT_BYTES + WBUF_BYTES + 2 * C * 4 + 64;
 };
 
-template <int MODE, int C>
-__global__ __launch_bounds__(256) void k_gglu_bwd(const float* __restrict__ y, const float* __restrict__ bn,
+// PB: dp (the gradient w.r.t. the pooled output) arrives as bf16 (SED_DTYPE_BF16, block 1: written by block 2's dgrad);
+// y is read and dz written in the mode's storage type
+template <int MODE, int C, int PB>
+__global__ __launch_bounds__(256) void k_gglu_bwd(const void* __restrict__ y_v, const float* __restrict__ bn,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const void* __restrict__ wg_v, const void* __restrict__ wgT_v,
-                                                   const float* __restrict__ bg, const float* __restrict__ dp, const float* __restrict__ dp2,
-                                                   float* __restrict__ dz, float* __restrict__ part, int H, int W, int Ho, int Wo,
+                                                   const float* __restrict__ bg, const void* __restrict__ dp_v, const float* __restrict__ dp2,
+                                                   void* __restrict__ dz_v, float* __restrict__ part, int H, int W, int Ho, int Wo,
                                                    int Q, int use_drop, float p_drop, const uint16_t* __restrict__ mask_in) {
     using Cfg = GGluBwdCfg<MODE, C>;
     using M = MM<MODE>;
     using E = typename M::E;
+    using YT = typename Stor<MODE == 1>::T;
+    using PT = typename Stor<PB>::T;
+    const YT* y = (const YT*)y_v;
+    YT* dz = (YT*)dz_v;
+    const PT* dp = (const PT*)dp_v;
     constexpr int NB = C / 32, NBW = NB / 2, XS = Cfg::XS, BS = Cfg::BS, KC = Cfg::KC;
     constexpr int TPW = NB * NB / 4;                       // dWx tiles (32 x 32) per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
@@ -251,7 +263,7 @@ __global__ __launch_bounds__(256) void k_gglu_bwd(const float* __restrict__ y, c
         const int per_clip = W * C, nbt = Q / (Ho * Wo);
         for (int i = blockIdx.x * 256 + tid; i < nbt * per_clip; i += gridDim.x * 256) {
             const int bb = i / per_clip, r = i % per_clip;
-            dz[((size_t)bb * H + (H - 1)) * W * C + r] = 0.f;
+            st1(dz + ((size_t)bb * H + (H - 1)) * W * C + r, 0.f);
         }
     }
     if (tid < C) { bn_s[tid] = bn[tid]; bn_s[C + tid] = bn[C + tid]; }       // mean, invstd
@@ -295,7 +307,7 @@ __global__ __launch_bounds__(256) void k_gglu_bwd(const float* __restrict__ y, c
                 const int gg = lane + 64 * i, m = 16 * hf + gg / C4, c4 = gg % C4;
                 const int j = m >> 3, dt = (m >> 2) & 1, df = m & 3;
                 const int base = (j == 0) ? pb[0] : (j == 1) ? pb[1] : (j == 2) ? pb[2] : pb[3];
-                yv[i] = *(const f32x4*)(y + (size_t)((base >= 0 ? base : 0) + dt * W + df) * C + 4 * c4);
+                yv[i] = ld4(y + (size_t)((base >= 0 ? base : 0) + dt * W + df) * C + 4 * c4);
             }
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
@@ -320,7 +332,7 @@ __global__ __launch_bounds__(256) void k_gglu_bwd(const float* __restrict__ y, c
             for (int jx = 0; jx < 4; ++jx) {
                 const size_t e = (size_t)(q0 + jx) * C + c;
                 // dp2: the second direction plane of gru4.hip's dX (H = 64), added while loading
-                gq[nb][jx] = (live && q0 + jx < Q) ? (dp2 ? dp[e] + dp2[e] : dp[e]) * sc : 0.f;
+                gq[nb][jx] = (live && q0 + jx < Q) ? (dp2 ? ld1(dp + e) + dp2[e] : ld1(dp + e)) * sc : 0.f;
             }
             mk[nb] = (use_drop && live) ? (uint32_t)mask_in[((size_t)rb * NB + nb0 + nb) * 64 + lane] : 0xffffu;
         }
@@ -384,7 +396,7 @@ __global__ __launch_bounds__(256) void k_gglu_bwd(const float* __restrict__ y, c
                     const int base = (j == 0) ? pb[0] : (j == 1) ? pb[1] : (j == 2) ? pb[2] : pb[3];
                     if (base >= 0) {
                         const float v = acc[nb][r] + dzg[nb][r];
-                        dz[(size_t)(base + kh * W + df) * C + c] = v;
+                        st1(dz + (size_t)(base + kh * W + df) * C + c, v);
                         sdz[nb] += v;
                         sdzx[nb] += v * xf[mfma32_row(r, lane) * XS + c];
                     }
@@ -450,30 +462,30 @@ int gglu_bwd_grid(int B, int H, int W) {
     return grid > 256 ? 256 : grid;
 }
 
-template <int MODE, int C>
-static int gglu_bwd_launch(const float* y, const float* bn, const float* gamma, const float* beta, const void* wg, const void* wgT,
-                           const float* bg, const float* dp, const float* dp2, float* dz, float* part, int B, int H, int W, int use_drop,
+template <int MODE, int C, int PB>
+static int gglu_bwd_launch(const void* y, const float* bn, const float* gamma, const float* beta, const void* wg, const void* wgT,
+                           const float* bg, const void* dp, const float* dp2, void* dz, float* part, int B, int H, int W, int use_drop,
                            float p_drop, const uint16_t* mask_in, hipStream_t st) {
     using Cfg = GGluBwdCfg<MODE, C>;
     static_assert(Cfg::LDS_BYTES <= 160 * 1024, "GLU backward tiles exceed the LDS");
     static bool attr = false;
     if (!attr) {
-        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gglu_bwd<MODE, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gglu_bwd<MODE, C, PB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
         attr = true;
     }
     const int Ho = H / 2, Wo = W / 4, Q = B * Ho * Wo;
-    k_gglu_bwd<MODE, C><<<gglu_bwd_grid(B, H, W), 256, Cfg::LDS_BYTES, st>>>(y, bn, gamma, beta, wg, wgT, bg, dp, dp2, dz, part, H, W, Ho,
+    k_gglu_bwd<MODE, C, PB><<<gglu_bwd_grid(B, H, W), 256, Cfg::LDS_BYTES, st>>>(y, bn, gamma, beta, wg, wgT, bg, dp, dp2, dz, part, H, W, Ho,
                                                                              Wo, Q, use_drop, p_drop, mask_in);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
 
-int launch_gglu_bwd(int mode, int C, const float* y, const float* bn, const float* gamma, const float* beta, const void* wg,
-                    const void* wgT, const float* bg, const float* dp, float* dz, float* part, int B, int H, int W, int use_drop,
-                    float p_drop, const uint16_t* mask_in, hipStream_t st, const float* dp2) {
-#define GGLU_CASE(MD, CC) \
-    if (mode == MD && C == CC) return gglu_bwd_launch<MD, CC>(y, bn, gamma, beta, wg, wgT, bg, dp, dp2, dz, part, B, H, W, use_drop, p_drop, mask_in, st)
-    GGLU_CASE(0, 64); GGLU_CASE(0, 128); GGLU_CASE(1, 64); GGLU_CASE(1, 128);
+int launch_gglu_bwd(int mode, int C, const void* y, const float* bn, const float* gamma, const float* beta, const void* wg,
+                    const void* wgT, const float* bg, const void* dp, int dp_bf16, void* dz, float* part, int B, int H, int W,
+                    int use_drop, float p_drop, const uint16_t* mask_in, hipStream_t st, const float* dp2) {
+#define GGLU_CASE(MD, CC, PP) \
+    if (mode == MD && C == CC && dp_bf16 == PP) return gglu_bwd_launch<MD, CC, PP>(y, bn, gamma, beta, wg, wgT, bg, dp, dp2, dz, part, B, H, W, use_drop, p_drop, mask_in, st)
+    GGLU_CASE(0, 64, 0); GGLU_CASE(0, 128, 0); GGLU_CASE(1, 64, 0); GGLU_CASE(1, 128, 0); GGLU_CASE(1, 64, 1); GGLU_CASE(1, 128, 1);
 #undef GGLU_CASE
     sed_set_error("gglu backward: unsupported mode %d / channels %d", mode, C);
     return SED_ERR_UNSUPPORTED;

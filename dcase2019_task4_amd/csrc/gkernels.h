@@ -19,7 +19,8 @@ int launch_gconv_fwd(int mode, int C, const float* in, const void* wpk, const fl
 int launch_gconv_dgrad(int mode, int C, const float* dz, const float* yin, const float* coef, const void* wpkT, float* dx, int B,
                        int H, int W, hipStream_t st);
 int gwgrad_slabs(int C);
-int launch_gwgrad(int mode, int C, const float* dz, const float* yin, const float* coef, const float* xin, float* part, float* g_w, int B,
+// mode 1: dz, yin, xin are bf16
+int launch_gwgrad(int mode, int C, const void* dz, const void* yin, const float* coef, const void* xin, float* part, float* g_w, int B,
                   int H, int W, hipStream_t st);
 
 // bconv.hip: register-blocked bf16 convolution (x3 = 0: bf16 storage, single products; x3 = 1: fp32 storage, split operands)
@@ -36,13 +37,15 @@ struct GBnArgs {
     int train, update; float eps, momentum;
     float* bn;                                  // out [4][C]: mean, invstd, scale, shift
 };
-int launch_gglu_fwd(int mode, int C, const float* y, const GBnArgs& bn, const void* wg, const float* bg, float* p, int B, int H,
-                    int W, int block_id, int use_drop, float p_drop, const uint64_t* seed, uint16_t* mask_out, hipStream_t st);
+// mode 1 (SED_DTYPE_BF16): y is bf16; p is bf16 when p_bf16 (block 1) and fp32 otherwise (block 2: the GRU input)
+int launch_gglu_fwd(int mode, int C, const void* y, const GBnArgs& bn, const void* wg, const float* bg, void* p, int p_bf16, int B,
+                    int H, int W, int block_id, int use_drop, float p_drop, const uint64_t* seed, uint16_t* mask_out, hipStream_t st);
 int gglu_bwd_grid(int B, int H, int W);
 // part: [grid][C * C + 3 * C] floats (per-workgroup partial sums: dWx | sdb | sdz | sdzx)
-int launch_gglu_bwd(int mode, int C, const float* y, const float* bn, const float* gamma, const float* beta, const void* wg,
-                    const void* wgT, const float* bg, const float* dp, float* dz, float* part, int B, int H, int W, int use_drop,
-                    float p_drop, const uint16_t* mask_in, hipStream_t st, const float* dp2 = nullptr);
+// mode 1: y is read and dz written as bf16; dp is bf16 when dp_bf16 (block 1) - block 2's dp comes from the GRU in fp32
+int launch_gglu_bwd(int mode, int C, const void* y, const float* bn, const float* gamma, const float* beta, const void* wg,
+                    const void* wgT, const float* bg, const void* dp, int dp_bf16, void* dz, float* part, int B, int H, int W,
+                    int use_drop, float p_drop, const uint16_t* mask_in, hipStream_t st, const float* dp2 = nullptr);
 #define GPART_SLICES 8
 struct GBnBwdArgs {
     const float* part; int n_part; int C; double N;
@@ -69,6 +72,13 @@ int launch_gclu_fwd(const float* gi, const float* w_hh_f, const float* w_hh_r, c
                     float* gates, void* xch, unsigned int* epoch, int* err, int B, int T, hipStream_t st);
 int launch_gclu_bwd(const float* d_out, const float* out, const float* gates, const float* w_hh_f, const float* w_hh_r, float* dgi,
                     float* dgh, float* hprev, void* xch, unsigned int* epoch, int* err, int B, int T, hipStream_t st);
+
+// grec.hip: H = 256 recurrence of SED_DTYPE_BF16 - one workgroup per chain, W_hh as bf16 in registers
+int launch_grec_pack(const float* w_hh_f, const float* w_hh_r, void* wp, void* wpT /* may be null */, hipStream_t st);
+int launch_grec_fwd(const float* gi, const void* wp, const float* b_hh_f, const float* b_hh_r, float* out, float* gates, int B, int T,
+                    hipStream_t st);
+int launch_grec_bwd(const float* d_out, const float* out, const float* gates, const void* wpT, float* dgi, float* dgh, float* hprev,
+                    int B, int T, hipStream_t st);
 
 // ggemm.hip: C[m][n] = sum_k A[m][k] B[n][k] + bias[n], exact fp32, 128 x 128 tiles; K % 32 == 0
 struct GntProb { const float* A; int lda; const float* B; int ldb; float* C; int ldc; const float* bias; int M, N, K; };

@@ -1,0 +1,220 @@
+// grec.hip - H = 256 GRU recurrence for SED_DTYPE_BF16: ONE workgroup per (clip, direction) chain with the whole W_hh in
+// registers as bf16, no cross-workgroup exchange.
+//
+// Reference op: nn.GRU(bidirectional=True) inside BidirectionalGRU (baseline/models/RNN.py:12-16), gate order r, z, n:
+//   r = s(gi_r + W_hr h + b_hr)   z = s(gi_z + W_hz h + b_hz)   n = tanh(gi_n + r (W_hn h + b_hn))   h' = (1 - z) n + z h
+//
+// Why: 3H x H fp32 = 768 KB does not fit one CU, so the fp32 kernels (ggru.hip k_gclu_*) split a chain over FOUR workgroups
+// that hand h over through L2 every time step - 1.6 - 2.4 us per step, ~1 us of it the publish -> poll round trip, on 192
+// CUs per launch.  In bf16 the matrix is 384 KB and fits the register file of one CU: 512 threads, thread
+// (unit u = t >> 1, k half = t & 1) keeps W_hh[gate][u][128 half .. +128) as 192 packed registers (all of them ARCH VGPRs:
+// a VALU instruction cannot address the AGPR half of the file, and parking weights there costs a v_accvgpr_read per use -
+// tools/ubench/dot2_matvec.cpp: 1.78 us per step with 256 threads x 384 registers, 1.0 us with 512 x 192).  Per step: the
+// 256-vector h (bf16, LDS, double-buffered: one barrier per step) is read with broadcast ds_read_b128, each thread forms its
+// three half dot products with v_dot2c_f32_bf16 (fp32 accumulation; 2.0 ns per instruction per wave = the fp32 FMA rate
+// for two MACs), the halves meet through one DPP quad_perm add, both lanes of a pair do the gate math, one stores.
+// Arithmetic: W_hh and the h that enters the mat-vec are rounded to bf16 (RNE) - the GEMM operands, as sed_dims.dtype =
+// SED_DTYPE_BF16 states for every GEMM-shaped operator; gi, the biases, the gates and the carried state h are fp32.
+// The backward kernel is the transpose: thread (column j, gate half) keeps 384 entries of column j and reads the step's
+// 768 gate gradients (bf16, LDS).
+#include "gen.h"
+#include "kernels.h"
+#include "gkernels.h"
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4r;
+#define GREC_H 256
+#define GREC_T 512
+
+__device__ __forceinline__ float dot2(unsigned int a, unsigned int b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
+}
+// x + (the value of the other lane of the pair): DPP quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ float pair_sum(float x) {
+    const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true);
+    return x + __int_as_float(y);
+}
+__device__ __forceinline__ float tanh_fast(float x) { return 2.0f * rcp_fast(1.0f + __expf(-2.0f * x)) - 1.0f; }
+
+// ---- packing (once per forward): fp32 W_hh [3H][H] of both directions -> bf16 in the order the threads load it ----------
+//   wp [dir][g][kc][u][8]  = W[g H + u][8 kc + e]          (forward:  16-byte vector (g, kc) of unit u; coalesced over u)
+//   wpT[dir][gc][j][8]     = W[8 gc + e][j]                (backward: 16-byte vector gc of column j; gc < 3H / 8)
+__global__ __launch_bounds__(256) void k_grec_pack(const float* __restrict__ w_f, const float* __restrict__ w_r,
+                                                    __bf16* __restrict__ wp, __bf16* __restrict__ wpT) {
+    constexpr int H = GREC_H;
+    const int i = blockIdx.x * 256 + threadIdx.x;                 // one 8-vector
+    const int per_dir = 3 * H * H / 8;
+    if (i >= 2 * per_dir) return;
+    const int dir = i / per_dir, v = i % per_dir;
+    const float* w = dir ? w_r : w_f;
+    {
+        const int u = v % H, kc = (v / H) % (H / 8), g = v / (H * (H / 8));
+        const float* s = w + (size_t)(g * H + u) * H + 8 * kc;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)s[e];
+        *(bf16x8*)(wp + ((size_t)dir * per_dir + v) * 8) = o;
+    }
+    if (wpT != nullptr) {
+        const int j = v % H, gc = v / H;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)w[(size_t)(8 * gc + e) * H + j];
+        *(bf16x8*)(wpT + ((size_t)dir * per_dir + v) * 8) = o;
+    }
+}
+int launch_grec_pack(const float* w_hh_f, const float* w_hh_r, void* wp, void* wpT, hipStream_t st) {
+    const int n = 2 * 3 * GREC_H * GREC_H / 8;
+    k_grec_pack<<<(n + 255) / 256, 256, 0, st>>>(w_hh_f, w_hh_r, (__bf16*)wp, (__bf16*)wpT);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}
+
+// gi: [B*T][2][3H] (input projection incl. b_ih); out [B*T][2H]; gates [B*T][2][4H] (r, z, n, gh_n) or null
+__global__ __launch_bounds__(GREC_T) void k_grec_fwd(const float* __restrict__ gi, const __bf16* __restrict__ wp,
+                                                      const float* __restrict__ b_hh_f, const float* __restrict__ b_hh_r,
+                                                      float* __restrict__ out, float* __restrict__ gates, int B, int T) {
+    constexpr int H = GREC_H;
+    __shared__ __attribute__((aligned(16))) unsigned int hs[2][H / 2];
+    const int chain = blockIdx.x, b = chain >> 1, dir = chain & 1;
+    const int t = threadIdx.x, u = t >> 1, half = t & 1;
+    const float* bhh = dir ? b_hh_r : b_hh_f;
+    unsigned int wr[3][64];
+    {
+        const u32x4r* src = (const u32x4r*)(wp + (size_t)dir * 3 * H * H);
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const u32x4r v = src[(size_t)(g * (H / 8) + 16 * half + c) * H + u];
+                wr[g][4 * c] = v.x; wr[g][4 * c + 1] = v.y; wr[g][4 * c + 2] = v.z; wr[g][4 * c + 3] = v.w;
+            }
+    }
+    const float bh_r = bhh[u], bh_z = bhh[H + u], bh_n = bhh[2 * H + u];
+    if (t < H / 2) { hs[0][t] = 0u; hs[1][t] = 0u; }
+    auto t_of = [&](int s) { return dir ? (T - 1 - s) : s; };
+    auto gi_load = [&](int s, float (&v)[3]) {
+        const float* g = gi + ((size_t)(b * T + t_of(s < T ? s : T - 1)) * 2 + dir) * 3 * H + u;
+        v[0] = g[0]; v[1] = g[H]; v[2] = g[2 * H];
+    };
+    float gn[3];
+    gi_load(0, gn);
+    float hprev = 0.f;
+    __syncthreads();
+    for (int s = 0; s < T; ++s) {
+        float gc[3] = {gn[0], gn[1], gn[2]};
+        gi_load(s + 1, gn);                                       // one step ahead
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        const unsigned int* hb = hs[s & 1] + 64 * half;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const u32x4r h4 = *(const u32x4r*)(hb + 4 * c);
+            const unsigned int hv[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a0 = dot2(wr[0][4 * c + q], hv[q], a0);
+                a1 = dot2(wr[1][4 * c + q], hv[q], a1);
+                a2 = dot2(wr[2][4 * c + q], hv[q], a2);
+            }
+        }
+        const float gh_r = pair_sum(a0) + bh_r, gh_z = pair_sum(a1) + bh_z, ghn = pair_sum(a2) + bh_n;
+        const float r = sigmoidf_fast(gc[0] + gh_r);
+        const float z = sigmoidf_fast(gc[1] + gh_z);
+        const float nn = tanh_fast(gc[2] + r * ghn);
+        const float h = (1.0f - z) * nn + z * hprev;
+        hprev = h;
+        if (half == 0) {
+            ((__bf16*)hs[(s + 1) & 1])[u] = (__bf16)h;
+            const size_t bt = (size_t)(b * T + t_of(s));
+            out[bt * 2 * H + dir * H + u] = h;
+            if (gates) {
+                float* gt = gates + (bt * 2 + dir) * 4 * H + u;
+                gt[0] = r; gt[H] = z; gt[2 * H] = nn; gt[3 * H] = ghn;
+            }
+        }
+        lds_barrier();
+    }
+}
+
+// Backward through time.  d_out [B*T][2H]; out / gates as written by the forward; dgi / dgh [B*T][2][3H]; hprev [B*T][2][H].
+//   dh = d_out + carry;  dn = dh (1 - z)(1 - n^2);  dz = dh (h_prev - n) z (1 - z);  dr = dn gh_n r (1 - r);  dghn = dn r
+//   carry'[j] = dh[j] z[j] + sum_g d[g] W_hh[g][j],  d = (dr | dz | dghn)
+__global__ __launch_bounds__(GREC_T) void k_grec_bwd(const float* __restrict__ d_out, const float* __restrict__ out,
+                                                      const float* __restrict__ gates, const __bf16* __restrict__ wpT,
+                                                      float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ hprev_out,
+                                                      int B, int T) {
+    constexpr int H = GREC_H;
+    __shared__ __attribute__((aligned(16))) unsigned int ds[2][3 * H / 2];
+    const int chain = blockIdx.x, b = chain >> 1, dir = chain & 1;
+    const int t = threadIdx.x, j = t >> 1, half = t & 1;
+    unsigned int wc[192];                                          // column j, gate rows [384 half, 384 half + 384)
+    {
+        const u32x4r* src = (const u32x4r*)(wpT + (size_t)dir * 3 * H * H);
+#pragma unroll
+        for (int c = 0; c < 48; ++c) {
+            const u32x4r v = src[(size_t)(48 * half + c) * H + j];
+            wc[4 * c] = v.x; wc[4 * c + 1] = v.y; wc[4 * c + 2] = v.z; wc[4 * c + 3] = v.w;
+        }
+    }
+    auto t_of = [&](int s) { return dir ? s : (T - 1 - s); };     // reverse of the forward order
+    auto in_load = [&](int s, float (&v)[6]) {
+        const int tt = t_of(s < T ? s : T - 1), tp = dir ? tt + 1 : tt - 1;
+        const size_t bt = (size_t)(b * T + tt);
+        const float* gt = gates + (bt * 2 + dir) * 4 * H + j;
+        v[0] = d_out[bt * 2 * H + dir * H + j];
+        v[1] = gt[0]; v[2] = gt[H]; v[3] = gt[2 * H]; v[4] = gt[3 * H];
+        v[5] = (tp >= 0 && tp < T) ? out[(size_t)(b * T + tp) * 2 * H + dir * H + j] : 0.f;
+    };
+    float nx[6];
+    in_load(0, nx);
+    float carry = 0.f;
+    for (int s = 0; s < T; ++s) {
+        float cu[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) cu[a] = nx[a];
+        in_load(s + 1, nx);
+        const float dh = cu[0] + carry;
+        const float r = cu[1], z = cu[2], nn = cu[3], ghn = cu[4], hp = cu[5];
+        const float dn_pre = dh * (1.0f - z) * (1.0f - nn * nn);
+        const float dz_pre = dh * (hp - nn) * z * (1.0f - z);
+        const float dr_pre = dn_pre * ghn * r * (1.0f - r);
+        const float dghn = dn_pre * r;
+        if (half == 0) {
+            __bf16* dd = (__bf16*)ds[s & 1];
+            dd[j] = (__bf16)dr_pre; dd[H + j] = (__bf16)dz_pre; dd[2 * H + j] = (__bf16)dghn;
+            const size_t bt = (size_t)(b * T + t_of(s)) * 2 + dir;
+            float* gi_o = dgi + bt * 3 * H + j;
+            float* gh_o = dgh + bt * 3 * H + j;
+            gi_o[0] = dr_pre; gi_o[H] = dz_pre; gi_o[2 * H] = dn_pre;
+            gh_o[0] = dr_pre; gh_o[H] = dz_pre; gh_o[2 * H] = dghn;
+            hprev_out[bt * H + j] = hp;
+        }
+        lds_barrier();                                             // this step's 3H gate gradients are in ds[s & 1]
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        const unsigned int* db = ds[s & 1] + 192 * half;
+#pragma unroll
+        for (int c = 0; c < 48; ++c) {
+            const u32x4r d4 = *(const u32x4r*)(db + 4 * c);
+            a0 = dot2(wc[4 * c], d4.x, a0);
+            a1 = dot2(wc[4 * c + 1], d4.y, a1);
+            a2 = dot2(wc[4 * c + 2], d4.z, a2);
+            a0 = dot2(wc[4 * c + 3], d4.w, a0);
+        }
+        carry = dh * z + pair_sum(a0 + a1 + a2);
+        // (ds is double-buffered: the next step writes the other buffer, and every reader of this one has passed the
+        // next barrier before it is written again)
+    }
+}
+
+int launch_grec_fwd(const float* gi, const void* wp, const float* b_hh_f, const float* b_hh_r, float* out, float* gates, int B, int T,
+                    hipStream_t st) {
+    k_grec_fwd<<<2 * B, GREC_T, 0, st>>>(gi, (const __bf16*)wp, b_hh_f, b_hh_r, out, gates, B, T);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}
+int launch_grec_bwd(const float* d_out, const float* out, const float* gates, const void* wpT, float* dgi, float* dgh, float* hprev,
+                    int B, int T, hipStream_t st) {
+    k_grec_bwd<<<2 * B, GREC_T, 0, st>>>(d_out, out, gates, (const __bf16*)wpT, dgi, dgh, hprev, B, T);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}

@@ -98,7 +98,7 @@ static GWs make_gws(const Geo& g) {
     put(W.glu_part2, (size_t)GPART_SLICES * (C * C + 3 * C) * 4);
     put(W.de0, 2 * C * 10 * sizeof(double));
     put(W.wg_part, (size_t)gwgrad_slabs(g.C) * 9 * C * C * 4);
-    put(W.gemm_part, gru_gemm_part_floats(g) * 4);
+    put(W.gemm_part, 2 * gru_gemm_part_floats(g) * 4);     // one per GRU layer: their batches may overlap in time
     for (int l = 0; l < 2; ++l) { put(W.xch[l], g.H == 256 ? gclu_xch_bytes(g.B, g.H, 1) : 0); put(W.epoch[l], (size_t)2 * g.B * 4); }
     W.total = o;
     return W;
@@ -207,9 +207,9 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
     }
     // (debug bit 10: the streaming recurrence kernels instead of the cluster ones - A/B timing)
     const bool cluster = (H == 256) && !(g_sed_debug & 1024);
-    // SED_DTYPE_BF16 at H = 256: one workgroup per chain, W_hh as bf16 in registers (grec.hip; debug bit 11 falls back to
+    // SED_DTYPE_BF16 at H = 256: one workgroup per chain, W_hh as bf16 in registers (grec.hip; debug bit 16 falls back to
     // the fp32 cluster kernels)
-    const bool rec16 = cluster && g.mode == SED_DTYPE_BF16 && !(g_sed_debug & 2048);
+    const bool rec16 = cluster && g.mode == SED_DTYPE_BF16 && !(g_sed_debug & 65536);
     if (H != 64 && !cluster)
         for (int l = 0; l < g.L; ++l)
             SED_TRY(launch_ggru_pack(params + P.w_hh[l][0], params + P.w_hh[l][1], CTXF(L.whh[l]), train ? CTXF(L.whhT[l]) : nullptr, H, ss));
@@ -236,6 +236,10 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
         bn.stat = CTXD(so[i]); bn.N = (double)g.B * Hs[i] * Wd[i]; bn.gamma = params + P.bn_g[i]; bn.beta = params + P.bn_b[i];
         bn.run_mean = bn_running + (2 * i) * C; bn.run_var = bn_running + (2 * i + 1) * C; bn.tracked = trk[i];
         bn.train = train; bn.update = upd; bn.eps = g.eps; bn.momentum = g.mom; bn.bn = CTXF(L.bn[i]);
+        if (g.mode == SED_DTYPE_BF16 && !(g_sed_debug & 262144))      // (debug bit 18: the round-2 GLU kernels, A/B timing)
+            SED_TRY(launch_bglu_fwd(C, CTXV(L.y[i]), bn, params + P.glu_w[i], params + P.glu_b[i], CTXV(L.p[i]), i == 1 ? 1 : 0, g.B,
+                                    Hs[i], Wd[i], i, use_drop, g.p, seed_dev, use_drop ? CTXM(L.mask[i]) : nullptr, st));
+        else
         SED_TRY(launch_gglu_fwd(gm, C, CTXV(L.y[i]), bn, CTXV(L.wg[i]), CTXF(L.bg[i]), CTXV(L.p[i]),
                                 (g.mode == SED_DTYPE_BF16 && i == 1) ? 1 : 0, g.B, Hs[i], Wd[i], i,
                                 use_drop, g.p, seed_dev, use_drop ? CTXM(L.mask[i]) : nullptr, st));
@@ -294,12 +298,33 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
     const int use_drop = (g.p > 0.f) ? 1 : 0;
     const bool have_side = (ss != st);
     const bool defer_gru_w = (parts & 4) != 0;
+    const bool early_gru_w = parts == 3 && have_side && H != 64 && !(g_sed_debug & 131072);    // (debug bit 17: old schedule)
     bool forked = false, forked2 = false;
     auto fork = [&]() -> int {
         if (!have_side) return SED_OK;
         SED_CHECK_HIP(hipEventRecord(ev_fork, st));
         SED_CHECK_HIP(hipStreamWaitEvent(ss, ev_fork, 0));
         forked = true;
+        return SED_OK;
+    };
+    // weight + bias gradients of one GRU layer, both directions (split-K MFMA GEMMs)
+    auto gru_weight_grads_layer = [&](int l, hipStream_t s2) -> int {
+        const int nin = (l == 0) ? C : 2 * H;
+        const float* input = (l == 0) ? CTXF(L.p[2]) : CTXF(L.out[l - 1]);
+        GemmBatch gb;
+        gb.n_prob = 4; gb.splits = gru_splitk(g); gb.part = WSF(W.gemm_part) + (size_t)l * gru_gemm_part_floats(g);
+        gb.part_floats = gru_gemm_part_floats(g); gb.part_stride = 0;
+        for (int dir = 0; dir < 2; ++dir) {
+            gb.p[2 * dir] = gemm_prob(WSF(W.dgi[l]) + dir * 3 * H, 1, 6 * H, input, nin, 1, grads + P.w_ih[l][dir], nin, 3 * H, nin, BT);
+            gb.p[2 * dir].Cones = grads + P.b_ih[l][dir];
+            gb.p[2 * dir + 1] = gemm_prob(WSF(W.dgh[l]) + dir * 3 * H, 1, 6 * H, WSF(W.hprev[l]) + dir * H, 2 * H, 1,
+                                          grads + P.w_hh[l][dir], H, 3 * H, H, BT);
+            gb.p[2 * dir + 1].Cones = grads + P.b_hh[l][dir];
+        }
+        return launch_gemm_batch(gb, s2);
+    };
+    auto gru_weight_grads = [&](hipStream_t s2) -> int {
+        for (int l = g.L - 1; l >= 0; --l) SED_TRY(gru_weight_grads_layer(l, s2));
         return SED_OK;
     };
     if (parts & 1) {
@@ -322,7 +347,7 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
                 d_cur = d_in;
                 d_cur2 = d_in + (size_t)BT * nin;
             } else {
-                if (H == 256 && g.mode == SED_DTYPE_BF16 && !(g_sed_debug & (1024 | 2048)))
+                if (H == 256 && g.mode == SED_DTYPE_BF16 && !(g_sed_debug & (1024 | 65536)))
                     SED_TRY(launch_grec_bwd(d_cur, CTXF(L.out[l]), CTXF(L.gates[l]), CTXV(L.whhT[l]), WSF(W.dgi[l]), WSF(W.dgh[l]),
                                             WSF(W.hprev[l]), g.B, g.T3, st));
                 else if (H == 256 && !(g_sed_debug & 1024))
@@ -334,6 +359,14 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
                                             WSF(W.hprev[l]), g.B, g.T3, st));
                 // dX[bt][i] = sum_dir sum_g dgi[bt][dir][g] W_ih[dir][g][i]: K = 6H, the two W_ih stacked along K (transposed
                 // copy made by the forward)
+                // H = 256: this layer's weight-gradient GEMMs (100 - 160 us of split-K work) start on the helper stream NOW, next
+                // to the rest of the recurrence chain - which keeps 48 of 256 CUs busy for another ~300 us - instead of after
+                // the conv blocks' fork, where they used to be the tail of the step (profiles/r03_*_wide-bf16_step_timeline.txt)
+                if (early_gru_w) {
+                    SED_TRY(fork());
+                    if (l == g.L - 1) SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, ss, 2 * H));
+                    SED_TRY(gru_weight_grads_layer(l, ss));
+                }
                 GntBatch gb;
                 gb.n_prob = 1;
                 gb.p[0] = GntProb{WSF(W.dgi[l]), 6 * H, CTXF(L.wihT[l]), 6 * H, d_in, nin, nullptr, BT, nin, 6 * H};
@@ -343,24 +376,6 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
             }
         }
     }
-    // weight + bias gradients of every GRU layer and direction (split-K MFMA GEMMs)
-    auto gru_weight_grads = [&](hipStream_t s2) -> int {
-        for (int l = g.L - 1; l >= 0; --l) {
-            const int nin = (l == 0) ? C : 2 * H;
-            const float* input = (l == 0) ? CTXF(L.p[2]) : CTXF(L.out[l - 1]);
-            GemmBatch gb;
-            gb.n_prob = 4; gb.splits = gru_splitk(g); gb.part = WSF(W.gemm_part); gb.part_floats = gru_gemm_part_floats(g); gb.part_stride = 0;
-            for (int dir = 0; dir < 2; ++dir) {
-                gb.p[2 * dir] = gemm_prob(WSF(W.dgi[l]) + dir * 3 * H, 1, 6 * H, input, nin, 1, grads + P.w_ih[l][dir], nin, 3 * H, nin, BT);
-                gb.p[2 * dir].Cones = grads + P.b_ih[l][dir];
-                gb.p[2 * dir + 1] = gemm_prob(WSF(W.dgh[l]) + dir * 3 * H, 1, 6 * H, WSF(W.hprev[l]) + dir * H, 2 * H, 1,
-                                              grads + P.w_hh[l][dir], H, 3 * H, H, BT);
-                gb.p[2 * dir + 1].Cones = grads + P.b_hh[l][dir];
-            }
-            SED_TRY(launch_gemm_batch(gb, s2));
-        }
-        return SED_OK;
-    };
     if (parts == 1) SED_TRY(gru_weight_grads(st));
     if (parts == 8) {
         SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, st, 2 * H));
@@ -384,10 +399,21 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
         pa.g_gamma = grads + P.bn_g[i]; pa.g_beta = grads + P.bn_b[i]; pa.g_wglu = grads + P.glu_w[i]; pa.g_bglu = grads + P.glu_b[i];
         pa.g_convb = grads + P.conv_b[i];
         SED_TRY(launch_gbn_bwd_prep(pa, st));
-        SED_TRY(fork());
+        // The weight gradient (helper stream) and the data gradient (caller's stream) both depend on the coefficients only.
+        // The data gradient is on the critical path: it is CAPTURED FIRST - a replayed hipGraph serialises nodes that its
+        // executor maps to the same hardware queue in creation order, and with the weight gradient created first the 145 us
+        // wgrad kernel sat in front of dgrad1 + block 0 on one queue (profiles/r03_a_wide-bf16_step_timeline.txt)
+        if (have_side) SED_CHECK_HIP(hipEventRecord(ev_fork, st));
+        if (g.mode != SED_DTYPE_F32)
+            SED_TRY(launch_bconv_dgrad(g.mode == SED_DTYPE_BF16X3, C, WSF(W.dz[i]), CTXV(L.y[i]), WSF(W.coef[i]), CTXV(L.wpkT[i]),
+                                       WSF(W.dp[i - 1]), g.B, Hs[i], Wd[i], st));
+        else
+            SED_TRY(launch_gconv_dgrad(g.mode, C, WSF(W.dz[i]), CTXF(L.y[i]), WSF(W.coef[i]), CTXV(L.wpkT[i]), WSF(W.dp[i - 1]), g.B, Hs[i],
+                                       Wd[i], st));
+        if (have_side) { SED_CHECK_HIP(hipStreamWaitEvent(ss, ev_fork, 0)); forked = true; }
         SED_TRY(launch_gwgrad(gm, C, WSF(W.dz[i]), CTXF(L.y[i]), WSF(W.coef[i]), CTXF(L.p[i - 1]), WSF(W.wg_part), grads + P.conv_w[i], g.B,
                               Hs[i], Wd[i], ss));
-        if (i == 2 && parts == 3) {
+        if (i == 2 && parts == 3 && !early_gru_w) {
             // on the second helper stream, so that they do not sit in front of wgrad1 on the first (crnn.hip)
             hipStream_t sg = ss;
             if (have_side && ss2 != nullptr) {
@@ -398,12 +424,6 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
             if (have_side) SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, sg, 2 * H));
             SED_TRY(gru_weight_grads(sg));
         }
-        if (g.mode != SED_DTYPE_F32)
-            SED_TRY(launch_bconv_dgrad(g.mode == SED_DTYPE_BF16X3, C, WSF(W.dz[i]), CTXV(L.y[i]), WSF(W.coef[i]), CTXV(L.wpkT[i]),
-                                       WSF(W.dp[i - 1]), g.B, Hs[i], Wd[i], st));
-        else
-            SED_TRY(launch_gconv_dgrad(g.mode, C, WSF(W.dz[i]), CTXF(L.y[i]), WSF(W.coef[i]), CTXV(L.wpkT[i]), WSF(W.dp[i - 1]), g.B, Hs[i],
-                                       Wd[i], st));
     }
     // ---- conv block 0 -----------------------------------------------------------------------------------------------------
     SED_TRY(launch_blk0_backward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],

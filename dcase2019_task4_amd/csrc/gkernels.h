@@ -73,6 +73,10 @@ int launch_gclu_fwd(const float* gi, const float* w_hh_f, const float* w_hh_r, c
 int launch_gclu_bwd(const float* d_out, const float* out, const float* gates, const float* w_hh_f, const float* w_hh_r, float* dgi,
                     float* dgh, float* hprev, void* xch, unsigned int* epoch, int* err, int B, int T, hipStream_t st);
 
+// bglu.hip: SED_DTYPE_BF16 (bf16 storage) GLU kernels; wglu / bglu are the RAW parameters (the BatchNorm affine is folded in-kernel)
+int launch_bglu_fwd(int C, const void* y, const GBnArgs& bn, const float* wglu, const float* bglu, void* p, int p_bf16, int B, int H,
+                    int W, int block_id, int use_drop, float p_drop, const uint64_t* seed, uint16_t* mask_out, hipStream_t st);
+
 // grec.hip: H = 256 recurrence of SED_DTYPE_BF16 - one workgroup per chain, W_hh as bf16 in registers
 int launch_grec_pack(const float* w_hh_f, const float* w_hh_r, void* wp, void* wpT /* may be null */, hipStream_t st);
 int launch_grec_fwd(const float* gi, const void* wp, const float* b_hh_f, const float* b_hh_r, float* out, float* gates, int B, int T,

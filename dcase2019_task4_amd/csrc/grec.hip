@@ -70,14 +70,33 @@ int launch_grec_pack(const float* w_hh_f, const float* w_hh_r, void* wp, void* w
     return SED_OK;
 }
 
+// Global I/O is BLOCKED over time: vmcnt counts loads and stores alike and in order, so a wave that stores its step's
+// outputs and then waits for the next step's inputs drains its own stores - an HBM / L2 write latency per time step (the
+// first version: 1.2 us per step forward, 2.0 backward, against 1.0 for the arithmetic alone).  A ninth wave for the I/O
+// (ggru.hip's way) does not fit: nine waves put three on one SIMD, and 3 x 232 registers exceed its file.  Instead every
+// GREC_TBF / GREC_TBB steps ALL waves (a) flush the previous block's outputs from an LDS ring with 16-byte coalesced
+// stores and (b) start the LDS-DMA of the block after next's inputs into the other half of a double-buffered input ring
+// (no registers: the kernel sits at 256) - the one vmcnt(0) per block then falls on transfers issued microseconds
+// earlier - and the steps in between touch LDS only.
+#define GREC_TBF 8
+#define GREC_TBB 4
+// one wave-instruction: 64 lanes x 16 bytes from global straight into 1 KB of LDS (global_load_lds_dwordx4: no VGPRs; the
+// destination is the wave-uniform `lds` + 16 * lane, the source address is per lane).  Completion: s_waitcnt vmcnt + barrier.
+__device__ __forceinline__ void dma16(const float* gsrc_lane, float* lds_wave) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                     (__attribute__((address_space(3))) void*)lds_wave, 16, 0, 0);
+}
+
 // gi: [B*T][2][3H] (input projection incl. b_ih); out [B*T][2H]; gates [B*T][2][4H] (r, z, n, gh_n) or null
 __global__ __launch_bounds__(GREC_T) void k_grec_fwd(const float* __restrict__ gi, const __bf16* __restrict__ wp,
                                                       const float* __restrict__ b_hh_f, const float* __restrict__ b_hh_r,
                                                       float* __restrict__ out, float* __restrict__ gates, int B, int T) {
-    constexpr int H = GREC_H;
+    constexpr int H = GREC_H, TB = GREC_TBF;
     __shared__ __attribute__((aligned(16))) unsigned int hs[2][H / 2];
+    __shared__ __attribute__((aligned(16))) float gis[2][TB][3][H];
+    __shared__ __attribute__((aligned(16))) float outs[TB][5][H];            // r, z, n, gh_n, h
     const int chain = blockIdx.x, b = chain >> 1, dir = chain & 1;
-    const int t = threadIdx.x, u = t >> 1, half = t & 1;
+    const int t = threadIdx.x, u = t >> 1, half = t & 1, lane = t & 63, wv = t >> 6;
     const float* bhh = dir ? b_hh_r : b_hh_f;
     unsigned int wr[3][64];
     {
@@ -93,47 +112,71 @@ __global__ __launch_bounds__(GREC_T) void k_grec_fwd(const float* __restrict__ g
     const float bh_r = bhh[u], bh_z = bhh[H + u], bh_n = bhh[2 * H + u];
     if (t < H / 2) { hs[0][t] = 0u; hs[1][t] = 0u; }
     auto t_of = [&](int s) { return dir ? (T - 1 - s) : s; };
-    auto gi_load = [&](int s, float (&v)[3]) {
-        const float* g = gi + ((size_t)(b * T + t_of(s < T ? s : T - 1)) * 2 + dir) * 3 * H + u;
-        v[0] = g[0]; v[1] = g[H]; v[2] = g[2 * H];
+    // block I/O in 16-byte items: inputs TB x 192 (3 wave-instructions per wave; 192 = 3 x 64: a wave-instruction never
+    // straddles two time steps), outputs TB x 320 (5 per thread)
+    auto in_dma = [&](int s0, int buf) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int i0 = 64 * (wv + 8 * k), st = i0 / 192, rem0 = i0 % 192, s = s0 + st;
+            if (s < T) dma16(gi + ((size_t)(b * T + t_of(s)) * 2 + dir) * 3 * H + 4 * (rem0 + lane), &gis[buf][0][0][0] + 4 * i0);
+        }
     };
-    float gn[3];
-    gi_load(0, gn);
+    auto out_flush = [&](int s0) {
+#pragma unroll 1
+        for (int k = 0; k < 5; ++k) {
+            const int i = t + GREC_T * k, st = i / 320, rem = i % 320, s = s0 + st;
+            if (s < T) {
+                const size_t bt = (size_t)(b * T + t_of(s));
+                if (rem < 256) {
+                    if (gates) *(f32x4*)(gates + (bt * 2 + dir) * 4 * H + 4 * rem) = *(const f32x4*)(&outs[st][0][0] + 4 * rem);
+                } else {
+                    *(f32x4*)(out + bt * 2 * H + dir * H + 4 * (rem - 256)) = *(const f32x4*)(&outs[st][4][0] + 4 * (rem - 256));
+                }
+            }
+        }
+    };
     float hprev = 0.f;
-    __syncthreads();
-    for (int s = 0; s < T; ++s) {
-        float gc[3] = {gn[0], gn[1], gn[2]};
-        gi_load(s + 1, gn);                                       // one step ahead
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        const unsigned int* hb = hs[s & 1] + 64 * half;
+    in_dma(0, 0);
+    int buf = 0;
+    for (int s0 = 0; s0 < T; s0 += TB, buf ^= 1) {
+        // this block's inputs were requested a whole block ago (the prologue for block 0) and the stores still counted were
+        // issued then too: the wait is over transfers that have long landed.  It comes BEFORE this iteration issues anything
+        // (a counted wait would have to know how many of the flush's stores a wave really issues: none of the gate stores in
+        // eval mode).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (s0 > 0) out_flush(s0 - TB);                                // (the previous block's last barrier published outs)
+        in_dma(s0 + TB, buf ^ 1);
+        lds_barrier();                                                 // flush reads done; every wave's share of gis[buf] landed
+        const int ns = (T - s0 < TB) ? (T - s0) : TB;
+        for (int st = 0; st < ns; ++st) {
+            const int s = s0 + st;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+            const unsigned int* hb = hs[s & 1] + 64 * half;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const u32x4r h4 = *(const u32x4r*)(hb + 4 * c);
-            const unsigned int hv[4] = {h4.x, h4.y, h4.z, h4.w};
+            for (int c = 0; c < 16; ++c) {
+                const u32x4r h4 = *(const u32x4r*)(hb + 4 * c);
+                const unsigned int hv[4] = {h4.x, h4.y, h4.z, h4.w};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                a0 = dot2(wr[0][4 * c + q], hv[q], a0);
-                a1 = dot2(wr[1][4 * c + q], hv[q], a1);
-                a2 = dot2(wr[2][4 * c + q], hv[q], a2);
+                for (int q = 0; q < 4; ++q) {
+                    a0 = dot2(wr[0][4 * c + q], hv[q], a0);
+                    a1 = dot2(wr[1][4 * c + q], hv[q], a1);
+                    a2 = dot2(wr[2][4 * c + q], hv[q], a2);
+                }
             }
-        }
-        const float gh_r = pair_sum(a0) + bh_r, gh_z = pair_sum(a1) + bh_z, ghn = pair_sum(a2) + bh_n;
-        const float r = sigmoidf_fast(gc[0] + gh_r);
-        const float z = sigmoidf_fast(gc[1] + gh_z);
-        const float nn = tanh_fast(gc[2] + r * ghn);
-        const float h = (1.0f - z) * nn + z * hprev;
-        hprev = h;
-        if (half == 0) {
-            ((__bf16*)hs[(s + 1) & 1])[u] = (__bf16)h;
-            const size_t bt = (size_t)(b * T + t_of(s));
-            out[bt * 2 * H + dir * H + u] = h;
-            if (gates) {
-                float* gt = gates + (bt * 2 + dir) * 4 * H + u;
-                gt[0] = r; gt[H] = z; gt[2 * H] = nn; gt[3 * H] = ghn;
+            const float gh_r = pair_sum(a0) + bh_r, gh_z = pair_sum(a1) + bh_z, ghn = pair_sum(a2) + bh_n;
+            const float r = sigmoidf_fast(gis[buf][st][0][u] + gh_r);
+            const float z = sigmoidf_fast(gis[buf][st][1][u] + gh_z);
+            const float nn = tanh_fast(gis[buf][st][2][u] + r * ghn);
+            const float h = (1.0f - z) * nn + z * hprev;
+            hprev = h;
+            if (half == 0) {
+                ((__bf16*)hs[(s + 1) & 1])[u] = (__bf16)h;
+                outs[st][0][u] = r; outs[st][1][u] = z; outs[st][2][u] = nn; outs[st][3][u] = ghn; outs[st][4][u] = h;
             }
+            lds_barrier();
         }
-        lds_barrier();
     }
+    out_flush(((T - 1) / TB) * TB);
 }
 
 // Backward through time.  d_out [B*T][2H]; out / gates as written by the forward; dgi / dgh [B*T][2][3H]; hprev [B*T][2][H].
@@ -143,10 +186,12 @@ __global__ __launch_bounds__(GREC_T) void k_grec_bwd(const float* __restrict__ d
                                                       const float* __restrict__ gates, const __bf16* __restrict__ wpT,
                                                       float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ hprev_out,
                                                       int B, int T) {
-    constexpr int H = GREC_H;
+    constexpr int H = GREC_H, TB = GREC_TBB;
     __shared__ __attribute__((aligned(16))) unsigned int ds[2][3 * H / 2];
+    __shared__ __attribute__((aligned(16))) float ins[2][TB][6][H];          // d_out, r, z, n, gh_n, h_prev
+    __shared__ __attribute__((aligned(16))) float outs[TB][5][H];            // dr, dz, dn, dgh_n, h_prev
     const int chain = blockIdx.x, b = chain >> 1, dir = chain & 1;
-    const int t = threadIdx.x, j = t >> 1, half = t & 1;
+    const int t = threadIdx.x, j = t >> 1, half = t & 1, lane = t & 63, wv = t >> 6;
     unsigned int wc[192];                                          // column j, gate rows [384 half, 384 half + 384)
     {
         const u32x4r* src = (const u32x4r*)(wpT + (size_t)dir * 3 * H * H);
@@ -157,53 +202,85 @@ __global__ __launch_bounds__(GREC_T) void k_grec_bwd(const float* __restrict__ d
         }
     }
     auto t_of = [&](int s) { return dir ? s : (T - 1 - s); };     // reverse of the forward order
-    auto in_load = [&](int s, float (&v)[6]) {
-        const int tt = t_of(s < T ? s : T - 1), tp = dir ? tt + 1 : tt - 1;
-        const size_t bt = (size_t)(b * T + tt);
-        const float* gt = gates + (bt * 2 + dir) * 4 * H + j;
-        v[0] = d_out[bt * 2 * H + dir * H + j];
-        v[1] = gt[0]; v[2] = gt[H]; v[3] = gt[2 * H]; v[4] = gt[3 * H];
-        v[5] = (tp >= 0 && tp < T) ? out[(size_t)(b * T + tp) * 2 * H + dir * H + j] : 0.f;
+    // block I/O: inputs TB x 384 16-byte items (3 wave-instructions per wave; per step 64 of d_out | 256 of the gates | 64 of
+    // h_prev - every wave-instruction has ONE kind and ONE step), outputs TB x 448 (3.5 per thread)
+    auto in_dma = [&](int s0, int buf) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int i0 = 64 * (wv + 8 * k), st = i0 / 384, rem0 = i0 % 384, s = s0 + st;
+            if (s < T) {
+                const int tt = t_of(s);
+                const size_t bt = (size_t)(b * T + tt);
+                float* dst = &ins[buf][0][0][0] + 4 * i0;
+                if (rem0 < 64) {
+                    dma16(d_out + bt * 2 * H + dir * H + 4 * lane, dst);
+                } else if (rem0 < 320) {
+                    dma16(gates + (bt * 2 + dir) * 4 * H + 4 * (rem0 - 64 + lane), dst);
+                } else {
+                    const int tp = dir ? tt + 1 : tt - 1;
+                    if (tp >= 0 && tp < T) dma16(out + (size_t)(b * T + tp) * 2 * H + dir * H + 4 * lane, dst);
+                    else *(f32x4*)(dst + 4 * lane) = (f32x4){0.f, 0.f, 0.f, 0.f};      // h before the first step
+                }
+            }
+        }
     };
-    float nx[6];
-    in_load(0, nx);
+    auto out_flush = [&](int s0) {
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {
+            const int i = t + GREC_T * k, st = i / 448, rem = i % 448, s = s0 + st;
+            if (i < TB * 448 && s < T) {
+                const size_t bt2 = (size_t)(b * T + t_of(s)) * 2 + dir;
+                if (rem < 192) {                                       // dgi = (dr, dz, dn)
+                    *(f32x4*)(dgi + bt2 * 3 * H + 4 * rem) = *(const f32x4*)(&outs[st][0][0] + 4 * rem);
+                } else if (rem < 384) {                                // dgh = (dr, dz, dgh_n)
+                    const int q = rem - 192, kind = q / 64;
+                    *(f32x4*)(dgh + bt2 * 3 * H + 4 * q) = *(const f32x4*)(&outs[st][kind == 2 ? 3 : kind][0] + 4 * (q % 64));
+                } else {
+                    *(f32x4*)(hprev_out + bt2 * H + 4 * (rem - 384)) = *(const f32x4*)(&outs[st][4][0] + 4 * (rem - 384));
+                }
+            }
+        }
+    };
     float carry = 0.f;
-    for (int s = 0; s < T; ++s) {
-        float cu[6];
+    in_dma(0, 0);
+    int buf = 0;
+    for (int s0 = 0; s0 < T; s0 += TB, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (see k_grec_fwd)
+        if (s0 > 0) out_flush(s0 - TB);
+        in_dma(s0 + TB, buf ^ 1);
+        lds_barrier();
+        const int ns = (T - s0 < TB) ? (T - s0) : TB;
+        for (int st = 0; st < ns; ++st) {
+            const int s = s0 + st;
+            const float dh = ins[buf][st][0][j] + carry;
+            const float r = ins[buf][st][1][j], z = ins[buf][st][2][j], nn = ins[buf][st][3][j], ghn = ins[buf][st][4][j],
+                        hp = ins[buf][st][5][j];
+            const float dn_pre = dh * (1.0f - z) * (1.0f - nn * nn);
+            const float dz_pre = dh * (hp - nn) * z * (1.0f - z);
+            const float dr_pre = dn_pre * ghn * r * (1.0f - r);
+            const float dghn = dn_pre * r;
+            if (half == 0) {
+                __bf16* dd = (__bf16*)ds[s & 1];
+                dd[j] = (__bf16)dr_pre; dd[H + j] = (__bf16)dz_pre; dd[2 * H + j] = (__bf16)dghn;
+                outs[st][0][j] = dr_pre; outs[st][1][j] = dz_pre; outs[st][2][j] = dn_pre; outs[st][3][j] = dghn; outs[st][4][j] = hp;
+            }
+            lds_barrier();                                             // this step's 3H gate gradients are in ds[s & 1]
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+            const unsigned int* db = ds[s & 1] + 192 * half;
 #pragma unroll
-        for (int a = 0; a < 6; ++a) cu[a] = nx[a];
-        in_load(s + 1, nx);
-        const float dh = cu[0] + carry;
-        const float r = cu[1], z = cu[2], nn = cu[3], ghn = cu[4], hp = cu[5];
-        const float dn_pre = dh * (1.0f - z) * (1.0f - nn * nn);
-        const float dz_pre = dh * (hp - nn) * z * (1.0f - z);
-        const float dr_pre = dn_pre * ghn * r * (1.0f - r);
-        const float dghn = dn_pre * r;
-        if (half == 0) {
-            __bf16* dd = (__bf16*)ds[s & 1];
-            dd[j] = (__bf16)dr_pre; dd[H + j] = (__bf16)dz_pre; dd[2 * H + j] = (__bf16)dghn;
-            const size_t bt = (size_t)(b * T + t_of(s)) * 2 + dir;
-            float* gi_o = dgi + bt * 3 * H + j;
-            float* gh_o = dgh + bt * 3 * H + j;
-            gi_o[0] = dr_pre; gi_o[H] = dz_pre; gi_o[2 * H] = dn_pre;
-            gh_o[0] = dr_pre; gh_o[H] = dz_pre; gh_o[2 * H] = dghn;
-            hprev_out[bt * H + j] = hp;
+            for (int c = 0; c < 48; ++c) {
+                const u32x4r d4 = *(const u32x4r*)(db + 4 * c);
+                a0 = dot2(wc[4 * c], d4.x, a0);
+                a1 = dot2(wc[4 * c + 1], d4.y, a1);
+                a2 = dot2(wc[4 * c + 2], d4.z, a2);
+                a0 = dot2(wc[4 * c + 3], d4.w, a0);
+            }
+            carry = dh * z + pair_sum(a0 + a1 + a2);
+            // (ds is double-buffered: the next step writes the other buffer, and every reader of this one has passed the
+            // next barrier before it is written again)
         }
-        lds_barrier();                                             // this step's 3H gate gradients are in ds[s & 1]
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        const unsigned int* db = ds[s & 1] + 192 * half;
-#pragma unroll
-        for (int c = 0; c < 48; ++c) {
-            const u32x4r d4 = *(const u32x4r*)(db + 4 * c);
-            a0 = dot2(wc[4 * c], d4.x, a0);
-            a1 = dot2(wc[4 * c + 1], d4.y, a1);
-            a2 = dot2(wc[4 * c + 2], d4.z, a2);
-            a0 = dot2(wc[4 * c + 3], d4.w, a0);
-        }
-        carry = dh * z + pair_sum(a0 + a1 + a2);
-        // (ds is double-buffered: the next step writes the other buffer, and every reader of this one has passed the
-        // next barrier before it is written again)
     }
+    out_flush(((T - 1) / TB) * TB);
 }
 
 int launch_grec_fwd(const float* gi, const void* wp, const float* b_hh_f, const float* b_hh_r, float* out, float* gates, int B, int T,

@@ -214,7 +214,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bconv(const void* __restrict__
         b_load(0);
         halo_store(tile);
         b_store(0);
-        __syncthreads();
+        lds_barrier();                                                    // LDS-only barriers inside the tile loop: __syncthreads()
+                                                                          // would drain the halo prefetch / the epilogue's stores
         if (DIR == 0) {       // the next tile's halo flies during this tile's MFMAs (past the end: this tile again, unused)
             const int nt = tile + (int)gridDim.x;
             halo_load(nt < n_tiles ? nt : tile);
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bconv(const void* __restrict__
                     }
             }
             if (ch + 1 < NCH) b_store((ch + 1) & 1);
-            __syncthreads();
+            lds_barrier();
         }
         // ---- epilogue: D register r of lane (n, kh) is MFMA row (r & 3) + 8 (r >> 2) + 4 kh, column n ------------------
 #pragma unroll

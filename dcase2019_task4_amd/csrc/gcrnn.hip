@@ -94,7 +94,7 @@ static GWs make_gws(const Geo& g) {
     put(W.dp[2], 2 * bt * C * 4); put(W.dz[2], n1 * SS); put(W.dp[1], n1 * SS); put(W.dz[1], n0 * SS); put(W.dp[0], n0 * SS);
     W.dz[0] = 0; W.coef[0] = 0;
     put(W.coef[1], 3 * C * 4); put(W.coef[2], 3 * C * 4);
-    put(W.glu_part, (size_t)gglu_bwd_grid(g.B, g.H1, g.W1) * (C * C + 3 * C) * 4);
+    put(W.glu_part, (size_t)(g.mode == SED_DTYPE_BF16 ? bglu_bwd_grid(g.C, g.B, g.H1, g.W1) : gglu_bwd_grid(g.B, g.H1, g.W1)) * (C * C + 3 * C) * 4);
     put(W.glu_part2, (size_t)GPART_SLICES * (C * C + 3 * C) * 4);
     put(W.de0, 2 * C * 10 * sizeof(double));
     put(W.wg_part, (size_t)gwgrad_slabs(g.C) * 9 * C * C * 4);
@@ -238,7 +238,8 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
         bn.train = train; bn.update = upd; bn.eps = g.eps; bn.momentum = g.mom; bn.bn = CTXF(L.bn[i]);
         if (g.mode == SED_DTYPE_BF16 && !(g_sed_debug & 262144))      // (debug bit 18: the round-2 GLU kernels, A/B timing)
             SED_TRY(launch_bglu_fwd(C, CTXV(L.y[i]), bn, params + P.glu_w[i], params + P.glu_b[i], CTXV(L.p[i]), i == 1 ? 1 : 0, g.B,
-                                    Hs[i], Wd[i], i, use_drop, g.p, seed_dev, use_drop ? CTXM(L.mask[i]) : nullptr, st));
+                                    Hs[i], Wd[i], i, use_drop, g.p, seed_dev, use_drop ? CTXM(L.mask[i]) : nullptr,
+                                    train ? CTXV(L.wg[i]) : nullptr, train ? CTXF(L.bg[i]) : nullptr, st));
         else
         SED_TRY(launch_gglu_fwd(gm, C, CTXV(L.y[i]), bn, CTXV(L.wg[i]), CTXF(L.bg[i]), CTXV(L.p[i]),
                                 (g.mode == SED_DTYPE_BF16 && i == 1) ? 1 : 0, g.B, Hs[i], Wd[i], i,
@@ -259,7 +260,7 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
             gb.n_prob = 2;
             for (int dir = 0; dir < 2; ++dir)
                 gb.p[dir] = GntProb{in, nin, params + P.w_ih[l][dir], nin, CTXF(L.gi[l]) + dir * 3 * H, 6 * H, params + P.b_ih[l][dir], BT, 3 * H, nin};
-            SED_TRY(launch_gnt_gemm(gb, st));
+            SED_TRY(g.mode == SED_DTYPE_BF16 ? launch_gnt_gemm_bf16(gb, st) : launch_gnt_gemm(gb, st));
             if (rec16) {
                 SED_TRY(launch_grec_pack(params + P.w_hh[l][0], params + P.w_hh[l][1], CTXV(L.whh[l]), train ? CTXV(L.whhT[l]) : nullptr, st));
                 SED_TRY(launch_grec_fwd(CTXF(L.gi[l]), CTXV(L.whh[l]), params + P.b_hh[l][0], params + P.b_hh[l][1], CTXF(L.out[l]),
@@ -370,7 +371,7 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
                 GntBatch gb;
                 gb.n_prob = 1;
                 gb.p[0] = GntProb{WSF(W.dgi[l]), 6 * H, CTXF(L.wihT[l]), 6 * H, d_in, nin, nullptr, BT, nin, 6 * H};
-                SED_TRY(launch_gnt_gemm(gb, st));
+                SED_TRY(g.mode == SED_DTYPE_BF16 ? launch_gnt_gemm_bf16(gb, st) : launch_gnt_gemm(gb, st));
                 d_cur = d_in;
                 d_cur2 = nullptr;
             }
@@ -388,12 +389,17 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
     const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};
     for (int i = 2; i >= 1; --i) {
         // (H = 64: the GRU's dX arrives as two direction planes; the GLU backward adds them while loading)
+        const bool new_glu = g.mode == SED_DTYPE_BF16 && !(g_sed_debug & 262144);
+        if (new_glu)
+            SED_TRY(launch_bglu_bwd(C, CTXV(L.y[i]), CTXF(L.bn[i]), CTXV(L.wg[i]), CTXF(L.bg[i]), CTXV(L.wgT[i]), WSF(W.dp[i]), i == 1 ? 1 : 0, WSF(W.dz[i]), WSF(W.glu_part), g.B, Hs[i], Wd[i],
+                                    use_drop, g.p, CTXM(L.mask[i]), st, (i == 2 && H == 64) ? WSF(W.dp[2]) + (size_t)BT * C : nullptr));
+        else
         SED_TRY(launch_gglu_bwd(gm, C, CTXV(L.y[i]), CTXF(L.bn[i]), params + P.bn_g[i], params + P.bn_b[i], CTXV(L.wg[i]),
                                 CTXV(L.wgT[i]), CTXF(L.bg[i]), WSF(W.dp[i]), (g.mode == SED_DTYPE_BF16 && i == 1) ? 1 : 0,
                                 WSF(W.dz[i]), WSF(W.glu_part), g.B, Hs[i], Wd[i], use_drop,
                                 g.p, CTXM(L.mask[i]), st, (i == 2 && H == 64) ? WSF(W.dp[2]) + (size_t)BT * C : nullptr));
         GBnBwdArgs pa;
-        pa.part = WSF(W.glu_part); pa.n_part = gglu_bwd_grid(g.B, Hs[i], Wd[i]); pa.C = C; pa.N = (double)g.B * Hs[i] * Wd[i];
+        pa.part = WSF(W.glu_part); pa.n_part = new_glu ? bglu_bwd_grid(C, g.B, Hs[i], Wd[i]) : gglu_bwd_grid(g.B, Hs[i], Wd[i]); pa.C = C; pa.N = (double)g.B * Hs[i] * Wd[i];
         pa.part2 = WSF(W.glu_part2);
         pa.gamma = params + P.bn_g[i]; pa.beta = params + P.bn_b[i]; pa.bn = CTXF(L.bn[i]); pa.coef = WSF(W.coef[i]);
         pa.g_gamma = grads + P.bn_g[i]; pa.g_beta = grads + P.bn_b[i]; pa.g_wglu = grads + P.glu_w[i]; pa.g_bglu = grads + P.glu_b[i];

@@ -11,6 +11,7 @@
 #include "kernels.h"
 #include "gkernels.h"
 #include "gpack.h"
+#include "gen.h"
 
 #define GNT_KC 32
 #define GNT_S (GNT_KC + 1)
@@ -70,6 +71,89 @@ __global__ __launch_bounds__(256) void k_gnt_gemm(GntBatch gb) {
             if (row < d.M) d.C[(size_t)row * d.ldc + col] = acc[r] + bias;
         }
     }
+}
+
+// The same GEMMs with bf16 MFMA operands (SED_DTYPE_BF16): fp32 in HBM, rounded to bf16 (RNE) on the way into LDS, fp32
+// accumulation and output.  64 x 64 output tile, 64 k per double-buffered chunk, one 32 x 32 x 16 accumulator per wave: the
+// shapes (M = 1 872, N <= 768, K <= 1 536) make this a staging-bound kernel - 4 MFMAs per chunk against 32 KB of operand
+// loads - so the tile is kept small to fill the chip (60 - 720 workgroups) rather than large to feed the MFMA.
+#define GNB_KC 64
+#define GNB_S (GNB_KC + 8)                 // row stride in bf16 elements: 144 B, an odd multiple of 16 B (conflict-free b128)
+__global__ __launch_bounds__(256) void k_gnt_gemm_bf16(GntBatch gb) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][GNT_T * GNB_S];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][GNT_T * GNB_S];
+    const GntProb& d = gb.p[blockIdx.z];
+    const int m0 = blockIdx.y * GNT_T, n0 = blockIdx.x * GNT_T;
+    if (m0 >= d.M || n0 >= d.N) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 31, kh = lane >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+    // staging: 64 rows x 64 k = 512 groups of 8 per operand = 2 per thread: row = u >> 3, k8 = u & 7
+    f32x4 ra[2][2], rb[2][2];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int u = tid + 256 * i, row = u >> 3, k8 = u & 7;
+            const int am = min(m0 + row, d.M - 1), bn = min(n0 + row, d.N - 1);      // clamped rows are never stored
+            const float* a = d.A + (size_t)am * d.lda + k0 + 8 * k8;
+            const float* b = d.B + (size_t)bn * d.ldb + k0 + 8 * k8;
+            ra[i][0] = *(const f32x4*)a; ra[i][1] = *(const f32x4*)(a + 4);
+            rb[i][0] = *(const f32x4*)b; rb[i][1] = *(const f32x4*)(b + 4);
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int u = tid + 256 * i, row = u >> 3, k8 = u & 7;
+            bf16x8 a, b;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a[q] = (__bf16)ra[i][0][q]; a[4 + q] = (__bf16)ra[i][1][q];
+                b[q] = (__bf16)rb[i][0][q]; b[4 + q] = (__bf16)rb[i][1][q];
+            }
+            *(bf16x8*)&As[buf][row * GNB_S + 8 * k8] = a;
+            *(bf16x8*)&Bs[buf][row * GNB_S + 8 * k8] = b;
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nch = d.K / GNB_KC;
+    load(0);
+    store(0);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+        if (ch + 1 < nch) load((ch + 1) * GNB_KC);
+        const __bf16* ap = &As[ch & 1][(32 * wm + n) * GNB_S + 8 * kh];
+        const __bf16* bp = &Bs[ch & 1][(32 * wn + n) * GNB_S + 8 * kh];
+#pragma unroll
+        for (int ks = 0; ks < GNB_KC / 16; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(ap + 16 * ks), *(const bf16x8*)(bp + 16 * ks), acc, 0, 0, 0);
+        if (ch + 1 < nch) store((ch + 1) & 1);
+        __syncthreads();
+    }
+    const int col = n0 + 32 * wn + n;
+    if (col < d.N) {
+        const float bias = d.bias ? d.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + 32 * wm + mfma32_row(r, lane);
+            if (row < d.M) d.C[(size_t)row * d.ldc + col] = acc[r] + bias;
+        }
+    }
+}
+
+int launch_gnt_gemm_bf16(const GntBatch& gb, hipStream_t st) {
+    int maxM = 0, maxN = 0;
+    for (int i = 0; i < gb.n_prob; ++i) {
+        const GntProb& q = gb.p[i];
+        SED_CHECK_ARG(q.K % GNB_KC == 0 && q.lda % 4 == 0 && q.ldb % 4 == 0 && ((uintptr_t)q.A % 16) == 0 && ((uintptr_t)q.B % 16) == 0,
+                      "gnt gemm (bf16): K must be a multiple of 64 and the operands 16-byte aligned");
+        maxM = q.M > maxM ? q.M : maxM;
+        maxN = q.N > maxN ? q.N : maxN;
+    }
+    k_gnt_gemm_bf16<<<dim3((maxN + GNT_T - 1) / GNT_T, (maxM + GNT_T - 1) / GNT_T, gb.n_prob), 256, 0, st>>>(gb);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
 }
 
 int launch_gnt_gemm(const GntBatch& gb, hipStream_t st) {

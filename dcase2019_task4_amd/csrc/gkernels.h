@@ -74,8 +74,16 @@ int launch_gclu_bwd(const float* d_out, const float* out, const float* gates, co
                     float* dgh, float* hprev, void* xch, unsigned int* epoch, int* err, int B, int T, hipStream_t st);
 
 // bglu.hip: SED_DTYPE_BF16 (bf16 storage) GLU kernels; wglu / bglu are the RAW parameters (the BatchNorm affine is folded in-kernel)
+//   wfold_out [C][C] bf16 / bfold_out [C]: the folded weights and bias, published for launch_bglu_bwd (may be null)
 int launch_bglu_fwd(int C, const void* y, const GBnArgs& bn, const float* wglu, const float* bglu, void* p, int p_bf16, int B, int H,
-                    int W, int block_id, int use_drop, float p_drop, const uint64_t* seed, uint16_t* mask_out, hipStream_t st);
+                    int W, int block_id, int use_drop, float p_drop, const uint64_t* seed, uint16_t* mask_out, void* wfold_out,
+                    float* bfold_out, hipStream_t st);
+
+int bglu_bwd_grid(int C, int B, int H, int W);
+//   wfold / bfold: as published by the forward; wgT: Wglu^T [c][co] raw bf16 (k_gen_pack)
+int launch_bglu_bwd(int C, const void* y, const float* bn, const void* wfold, const float* bfold, const void* wgT,
+                    const void* dp, int dp_bf16, void* dz, float* part, int B, int H, int W, int use_drop, float p_drop,
+                    const uint16_t* mask_in, hipStream_t st, const float* dp2 = nullptr);
 
 // grec.hip: H = 256 recurrence of SED_DTYPE_BF16 - one workgroup per chain, W_hh as bf16 in registers
 int launch_grec_pack(const float* w_hh_f, const float* w_hh_r, void* wp, void* wpT /* may be null */, hipStream_t st);
@@ -88,6 +96,7 @@ int launch_grec_bwd(const float* d_out, const float* out, const float* gates, co
 struct GntProb { const float* A; int lda; const float* B; int ldb; float* C; int ldc; const float* bias; int M, N, K; };
 struct GntBatch { GntProb p[2]; int n_prob; };
 int launch_gnt_gemm(const GntBatch& gb, hipStream_t st);
+int launch_gnt_gemm_bf16(const GntBatch& gb, hipStream_t st);      // bf16 MFMA operands (SED_DTYPE_BF16); K % 64 == 0
 int launch_gnt_pack_t(const float* w0, const float* w1, float* out, int R, int N, hipStream_t st);
 
 // gcrnn.hip ---------------------------------------------------------------------------------------------------------------

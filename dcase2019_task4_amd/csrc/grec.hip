@@ -7,16 +7,18 @@
 // Why: 3H x H fp32 = 768 KB does not fit one CU, so the fp32 kernels (ggru.hip k_gclu_*) split a chain over FOUR workgroups
 // that hand h over through L2 every time step - 1.6 - 2.4 us per step, ~1 us of it the publish -> poll round trip, on 192
 // CUs per launch.  In bf16 the matrix is 384 KB and fits the register file of one CU: 512 threads, thread
-// (unit u = t >> 1, k half = t & 1) keeps W_hh[gate][u][128 half .. +128) as 192 packed registers (all of them ARCH VGPRs:
+// (unit pair up = t >> 2, k quarter kq = t & 3) keeps W_hh[gate][2 up + {0, 1}][64 kq .. +64) as 192 packed registers (two
+// units per thread halve the LDS reads of h per dot product; all registers are ARCH VGPRs:
 // a VALU instruction cannot address the AGPR half of the file, and parking weights there costs a v_accvgpr_read per use -
 // tools/ubench/dot2_matvec.cpp: 1.78 us per step with 256 threads x 384 registers, 1.0 us with 512 x 192).  Per step: the
 // 256-vector h (bf16, LDS, double-buffered: one barrier per step) is read with broadcast ds_read_b128, each thread forms its
 // three half dot products with v_dot2c_f32_bf16 (fp32 accumulation; 2.0 ns per instruction per wave = the fp32 FMA rate
-// for two MACs), the halves meet through one DPP quad_perm add, both lanes of a pair do the gate math, one stores.
+// for two MACs), the four quarters meet through two DPP quad_perm adds, lane kq of a quad does the gate math of unit kq & 1.
 // Arithmetic: W_hh and the h that enters the mat-vec are rounded to bf16 (RNE) - the GEMM operands, as sed_dims.dtype =
 // SED_DTYPE_BF16 states for every GEMM-shaped operator; gi, the biases, the gates and the carried state h are fp32.
-// The backward kernel is the transpose: thread (column j, gate half) keeps 384 entries of column j and reads the step's
-// 768 gate gradients (bf16, LDS).
+// The backward kernel is the transpose: thread (column pair, gate-row quarter) keeps 2 x 192 entries and reads a quarter of
+// the step's 768 gate gradients (bf16, LDS) - in its first form (one column x half the rows per thread) the broadcast reads
+// alone were 384 KB per step and CU = 0.64 us of LDS time.
 #include "gen.h"
 #include "kernels.h"
 #include "gkernels.h"
@@ -29,10 +31,11 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4r;
 __device__ __forceinline__ float dot2(unsigned int a, unsigned int b, float c) {
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
 }
-// x + (the value of the other lane of the pair): DPP quad_perm [1, 0, 3, 2]
-__device__ __forceinline__ float pair_sum(float x) {
-    const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true);
-    return x + __int_as_float(y);
+// sum over the four lanes of a quad: DPP quad_perm [1, 0, 3, 2] then [2, 3, 0, 1]; every lane ends with the same value
+__device__ __forceinline__ float quad_sum(float x) {
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));
+    return x;
 }
 __device__ __forceinline__ float tanh_fast(float x) { return 2.0f * rcp_fast(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
@@ -96,18 +99,22 @@ __global__ __launch_bounds__(GREC_T) void k_grec_fwd(const float* __restrict__ g
     __shared__ __attribute__((aligned(16))) float gis[2][TB][3][H];
     __shared__ __attribute__((aligned(16))) float outs[TB][5][H];            // r, z, n, gh_n, h
     const int chain = blockIdx.x, b = chain >> 1, dir = chain & 1;
-    const int t = threadIdx.x, u = t >> 1, half = t & 1, lane = t & 63, wv = t >> 6;
+    const int t = threadIdx.x, up = t >> 2, kq = t & 3, lane = t & 63, wv = t >> 6;
+    const int u = 2 * up + (kq & 1);                              // the unit whose gates this lane forms (kq >= 2: duplicates)
+    const bool writer = kq < 2;
     const float* bhh = dir ? b_hh_r : b_hh_f;
-    unsigned int wr[3][64];
+    unsigned int wr[2][3][32];
     {
         const u32x4r* src = (const u32x4r*)(wp + (size_t)dir * 3 * H * H);
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
+        for (int uu = 0; uu < 2; ++uu)
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const u32x4r v = src[(size_t)(g * (H / 8) + 16 * half + c) * H + u];
-                wr[g][4 * c] = v.x; wr[g][4 * c + 1] = v.y; wr[g][4 * c + 2] = v.z; wr[g][4 * c + 3] = v.w;
-            }
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const u32x4r v = src[(size_t)(g * (H / 8) + 8 * kq + c) * H + 2 * up + uu];
+                    wr[uu][g][4 * c] = v.x; wr[uu][g][4 * c + 1] = v.y; wr[uu][g][4 * c + 2] = v.z; wr[uu][g][4 * c + 3] = v.w;
+                }
     }
     const float bh_r = bhh[u], bh_z = bhh[H + u], bh_n = bhh[2 * H + u];
     if (t < H / 2) { hs[0][t] = 0u; hs[1][t] = 0u; }
@@ -150,26 +157,33 @@ __global__ __launch_bounds__(GREC_T) void k_grec_fwd(const float* __restrict__ g
         const int ns = (T - s0 < TB) ? (T - s0) : TB;
         for (int st = 0; st < ns; ++st) {
             const int s = s0 + st;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-            const unsigned int* hb = hs[s & 1] + 64 * half;
+            const float gi_r = gis[buf][st][0][u], gi_z = gis[buf][st][1][u], gi_n = gis[buf][st][2][u];
+            float a[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+            const unsigned int* hb = hs[s & 1] + 32 * kq;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
+            for (int c = 0; c < 8; ++c) {
                 const u32x4r h4 = *(const u32x4r*)(hb + 4 * c);
                 const unsigned int hv[4] = {h4.x, h4.y, h4.z, h4.w};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    a0 = dot2(wr[0][4 * c + q], hv[q], a0);
-                    a1 = dot2(wr[1][4 * c + q], hv[q], a1);
-                    a2 = dot2(wr[2][4 * c + q], hv[q], a2);
-                }
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) a[uu][g] = dot2(wr[uu][g][4 * c + q], hv[q], a[uu][g]);
             }
-            const float gh_r = pair_sum(a0) + bh_r, gh_z = pair_sum(a1) + bh_z, ghn = pair_sum(a2) + bh_n;
-            const float r = sigmoidf_fast(gis[buf][st][0][u] + gh_r);
-            const float z = sigmoidf_fast(gis[buf][st][1][u] + gh_z);
-            const float nn = tanh_fast(gis[buf][st][2][u] + r * ghn);
+#pragma unroll
+            for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) a[uu][g] = quad_sum(a[uu][g]);
+            const bool odd = (kq & 1) != 0;
+            const float gh_r = (odd ? a[1][0] : a[0][0]) + bh_r, gh_z = (odd ? a[1][1] : a[0][1]) + bh_z,
+                        ghn = (odd ? a[1][2] : a[0][2]) + bh_n;
+            const float r = sigmoidf_fast(gi_r + gh_r);
+            const float z = sigmoidf_fast(gi_z + gh_z);
+            const float nn = tanh_fast(gi_n + r * ghn);
             const float h = (1.0f - z) * nn + z * hprev;
             hprev = h;
-            if (half == 0) {
+            if (writer) {
                 ((__bf16*)hs[(s + 1) & 1])[u] = (__bf16)h;
                 outs[st][0][u] = r; outs[st][1][u] = z; outs[st][2][u] = nn; outs[st][3][u] = ghn; outs[st][4][u] = h;
             }
@@ -191,15 +205,19 @@ __global__ __launch_bounds__(GREC_T) void k_grec_bwd(const float* __restrict__ d
     __shared__ __attribute__((aligned(16))) float ins[2][TB][6][H];          // d_out, r, z, n, gh_n, h_prev
     __shared__ __attribute__((aligned(16))) float outs[TB][5][H];            // dr, dz, dn, dgh_n, h_prev
     const int chain = blockIdx.x, b = chain >> 1, dir = chain & 1;
-    const int t = threadIdx.x, j = t >> 1, half = t & 1, lane = t & 63, wv = t >> 6;
-    unsigned int wc[192];                                          // column j, gate rows [384 half, 384 half + 384)
+    const int t = threadIdx.x, up = t >> 2, gq = t & 3, lane = t & 63, wv = t >> 6;
+    const int j = 2 * up + (gq & 1);                               // the column whose gate gradients this lane forms
+    const bool writer = gq < 2;
+    unsigned int wc[2][96];                                        // columns 2 up + {0, 1}, gate rows [192 gq, 192 gq + 192)
     {
         const u32x4r* src = (const u32x4r*)(wpT + (size_t)dir * 3 * H * H);
 #pragma unroll
-        for (int c = 0; c < 48; ++c) {
-            const u32x4r v = src[(size_t)(48 * half + c) * H + j];
-            wc[4 * c] = v.x; wc[4 * c + 1] = v.y; wc[4 * c + 2] = v.z; wc[4 * c + 3] = v.w;
-        }
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int c = 0; c < 24; ++c) {
+                const u32x4r v = src[(size_t)(24 * gq + c) * H + 2 * up + jj];
+                wc[jj][4 * c] = v.x; wc[jj][4 * c + 1] = v.y; wc[jj][4 * c + 2] = v.z; wc[jj][4 * c + 3] = v.w;
+            }
     }
     auto t_of = [&](int s) { return dir ? s : (T - 1 - s); };     // reverse of the forward order
     // block I/O: inputs TB x 384 16-byte items (3 wave-instructions per wave; per step 64 of d_out | 256 of the gates | 64 of
@@ -259,23 +277,27 @@ __global__ __launch_bounds__(GREC_T) void k_grec_bwd(const float* __restrict__ d
             const float dz_pre = dh * (hp - nn) * z * (1.0f - z);
             const float dr_pre = dn_pre * ghn * r * (1.0f - r);
             const float dghn = dn_pre * r;
-            if (half == 0) {
+            if (writer) {
                 __bf16* dd = (__bf16*)ds[s & 1];
                 dd[j] = (__bf16)dr_pre; dd[H + j] = (__bf16)dz_pre; dd[2 * H + j] = (__bf16)dghn;
                 outs[st][0][j] = dr_pre; outs[st][1][j] = dz_pre; outs[st][2][j] = dn_pre; outs[st][3][j] = dghn; outs[st][4][j] = hp;
             }
             lds_barrier();                                             // this step's 3H gate gradients are in ds[s & 1]
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-            const unsigned int* db = ds[s & 1] + 192 * half;
+            float a[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+            const unsigned int* db = ds[s & 1] + 96 * gq;
 #pragma unroll
-            for (int c = 0; c < 48; ++c) {
+            for (int c = 0; c < 24; ++c) {
                 const u32x4r d4 = *(const u32x4r*)(db + 4 * c);
-                a0 = dot2(wc[4 * c], d4.x, a0);
-                a1 = dot2(wc[4 * c + 1], d4.y, a1);
-                a2 = dot2(wc[4 * c + 2], d4.z, a2);
-                a0 = dot2(wc[4 * c + 3], d4.w, a0);
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    a[jj][0] = dot2(wc[jj][4 * c], d4.x, a[jj][0]);
+                    a[jj][1] = dot2(wc[jj][4 * c + 1], d4.y, a[jj][1]);
+                    a[jj][0] = dot2(wc[jj][4 * c + 2], d4.z, a[jj][0]);
+                    a[jj][1] = dot2(wc[jj][4 * c + 3], d4.w, a[jj][1]);
+                }
             }
-            carry = dh * z + pair_sum(a0 + a1 + a2);
+            const float c0 = quad_sum(a[0][0] + a[0][1]), c1 = quad_sum(a[1][0] + a[1][1]);
+            carry = dh * z + ((gq & 1) ? c1 : c0);
             // (ds is double-buffered: the next step writes the other buffer, and every reader of this one has passed the
             // next barrier before it is written again)
         }

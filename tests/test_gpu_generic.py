@@ -18,8 +18,13 @@ from tests import gpu_util as gu
 pytestmark = pytest.mark.gpu
 
 POST_TOL = 2e-5
-BF16_POST_TOL = 4e-3          # measured <= 1.6e-3 over the shapes below (3 conv blocks' worth of 2^-9 operand rounding)
-BF16_GRAD_TOL = 1e-1          # of the gradient's typical magnitude; measured <= 7e-2 (block 0 in bf16 operands as well)
+# SED_DTYPE_BF16 (bf16 operands AND bf16 storage of the conv-block activations / gradients, bf16 W_hh and GRU projections at
+# H = 256): the asserted bounds are the MEASURED maxima over the shapes below plus ~35 % head-room - posteriors 9.5e-4 (base
+# geometry) / 2.3e-3 (wide), worst gradient element 0.10 of the gradient's typical magnitude.  This mode does NOT hold the north
+# star's 1e-3 on the wide model; SED_DTYPE_BF16X3 (below) does, and is asserted at 1e-3.
+BF16_POST_TOL_BASE = 1.3e-3
+BF16_POST_TOL = 3e-3
+BF16_GRAD_TOL = 1.4e-1
 
 
 def _stage_report(model, inter, B, T, C, H):
@@ -119,7 +124,8 @@ def test_bf16_operands_forward_backward_vs_fp32_oracle(B, T, p, C, H):
     ew, _ = gu.report("weak (bf16 operands)", r["w"], r["wo"])
     worst, name = _grad_errors(r["g"], r["go"])
     print(f"[bf16] C={C} H={H} B={B} T={T}: posterior err strong {es:.2e} weak {ew:.2e}; worst gradient err/typ {worst:.2e} ({name})")
-    assert es < BF16_POST_TOL and ew < BF16_POST_TOL
+    tol = BF16_POST_TOL_BASE if (C, H) == (64, 64) else BF16_POST_TOL
+    assert es < tol and ew < tol
     assert r["loss"] == pytest.approx(r["lo"], rel=5e-3)
     assert worst < BF16_GRAD_TOL, (name, worst)
     # BatchNorm statistics are fp32 sums of the conv outputs, which carry the operand rounding

@@ -22,6 +22,7 @@
 //     the rows a 16-lane ds_read_b128 group touches land on distinct groups too (tools/lds_layout_check.py enumerates
 //     every tap);
 //   * the next tile's halo (forward) is fetched into registers before the k-loop and lands in LDS after it.
+#include <type_traits>
 #include "gen.h"
 #include "kernels.h"
 #include "gkernels.h"
@@ -121,11 +122,20 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bconv(const void* __restrict__
             const int g = tid + NT * i, hy = g / (TW * CJ), px = (g / CJ) % TW;
             const int row = r0 - 1 + hy;
             const bool ok = (g < NITEM) && row >= 0 && row < H;
-            const size_t off = ((size_t)(b * H + (ok ? row : 0)) * TW + px) * C + 8 * sj;
+            const size_t off = ((size_t)(b * H + (ok ? row : 0)) * TW + (g < NITEM ? px : 0)) * C + 8 * sj;
+            // unconditional loads (clamped address), zeroed afterwards: a load under a per-item condition becomes a branch with
+            // its own s_waitcnt - serialized memory round trips
 #pragma unroll
             for (int v = 0; v < RV; ++v) {
-                hv[i][v] = ok ? *(const f32x4*)((const char*)(in0 + off) + 16 * v) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (DIR == 1) hw2[i][v] = ok ? *(const f32x4*)((const char*)(in1 + off) + 16 * v) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                hv[i][v] = *(const f32x4*)((const char*)(in0 + off) + 16 * v);
+                if (DIR == 1) hw2[i][v] = *(const f32x4*)((const char*)(in1 + off) + 16 * v);
+            }
+            if (!ok) {
+#pragma unroll
+                for (int v = 0; v < RV; ++v) {
+                    hv[i][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (DIR == 1) hw2[i][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
             }
         }
     };
@@ -259,22 +269,29 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bconv(const void* __restrict__
             lds_barrier();
         }
         // ---- epilogue: D register r of lane (n, kh) is MFMA row (r & 3) + 8 (r >> 2) + 4 kh, column n ------------------
+        // (a tile that lies inside the image - all but the last of a clip - stores without per-row conditions: 64 stores
+        // each under its own exec-mask branch were a fifth of the kernel's instructions)
+        auto epilogue = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+            for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int q = wm * Cfg::PXW + mb * 32 + mfma32_row(r, lane);
-                const int row = r0 + q / TW, col = q % TW;
-                if (row < H) {
-                    S* o = out + ((size_t)(b * H + row) * TW + col) * C + wn * Cfg::CHW + n;
+                for (int r = 0; r < 16; ++r) {
+                    const int q = wm * Cfg::PXW + mb * 32 + mfma32_row(r, lane);
+                    const int row = r0 + q / TW, col = q % TW;
+                    if (FULL || row < H) {
+                        S* o = out + ((size_t)(b * H + row) * TW + col) * C + wn * Cfg::CHW + n;
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        const float v = acc[mb][nb][r] + bv[nb];
-                        o[32 * nb] = (S)v;
-                        if (DIR == 0) { s1[nb] += v; s2[nb] += v * v; }
+                        for (int nb = 0; nb < NB; ++nb) {
+                            const float v = acc[mb][nb][r] + bv[nb];
+                            o[32 * nb] = (S)v;
+                            if (DIR == 0) { s1[nb] += v; s2[nb] += v * v; }
+                        }
                     }
                 }
-            }
+        };
+        if (r0 + TH <= H) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
     }
     if (DIR == 0 && stat != nullptr) {
 #pragma unroll

@@ -260,21 +260,24 @@ __global__ __launch_bounds__(256) void k_gwgrad(const void* __restrict__ dz_v, c
         for (int g = tid; g < HH * HW * 16; g += 256) {
             const int hp = g >> 4, c4 = g & 15;
             const int hy = hp / HW, hx = hp % HW, row = r0 - 1 + hy, col = hx - 1;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row >= 0 && row < H && col >= 0 && col < TW)
-                v = ld4(xin + ((size_t)(b * H + row) * TW + col) * C + ci0 + 4 * c4);
+            // unconditional load from a clamped address + select: a load under a per-item condition becomes a branch that
+            // waits out its own load (and everything else in flight)
+            const bool okx = row >= 0 && row < H && col >= 0 && col < TW;
+            f32x4 v = ld4(xin + ((size_t)(b * H + (okx ? row : 0)) * TW + (okx ? col : 0)) * C + ci0 + 4 * c4);
+            if (!okx) v = (f32x4){0.f, 0.f, 0.f, 0.f};
             float* d = xs + hp * PS + 4 * c4;
             d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
         }
         for (int g = tid; g < 128 * 16; g += 256) {
             const int p = g >> 4, c4 = g & 15;
             const int rr = p / TW, cc = p % TW, row = r0 + rr;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row < H) {
-                const size_t off = ((size_t)(b * H + row) * TW + cc) * C + co0 + 4 * c4;
+            f32x4 v;
+            {
+                const bool oky = row < H;
+                const size_t off = ((size_t)(b * H + (oky ? row : 0)) * TW + cc) * C + co0 + 4 * c4;
                 const f32x4 z = ld4(dz + off), y = ld4(yin + off);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = cf[4 * c4 + q] * z[q] + cf[64 + 4 * c4 + q] * y[q] + cf[128 + 4 * c4 + q];
+                for (int q = 0; q < 4; ++q) v[q] = oky ? cf[4 * c4 + q] * z[q] + cf[64 + 4 * c4 + q] * y[q] + cf[128 + 4 * c4 + q] : 0.f;
             }
             float* d = dys + p * PS + 4 * c4;
             d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
@@ -359,8 +362,9 @@ __global__ __launch_bounds__(256) void k_gwgrad_bf16(const __bf16* __restrict__ 
 #pragma unroll
             for (int i = 0; i < 10; ++i) {
                 const int col = 8 * cg - 1 + i;
-                xv[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (rok && col >= 0 && col < 16) xv[j][i] = ld4(xin + ((size_t)(b * H + row) * 16 + col) * C + ci0 + 4 * cq);
+                const bool okx = rok && col >= 0 && col < 16;           // (unconditional load, clamped address: see k_gwgrad)
+                xv[j][i] = ld4(xin + ((size_t)(b * H + (okx ? row : 0)) * 16 + (okx ? col : 0)) * C + ci0 + 4 * cq);
+                if (!okx) xv[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
     };

@@ -299,6 +299,8 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
     const int use_drop = (g.p > 0.f) ? 1 : 0;
     const bool have_side = (ss != st);
     const bool defer_gru_w = (parts & 4) != 0;
+    // (H = 64: measured NEUTRAL to slightly negative - 0.602 against 0.592 ms for the base bf16 step: the conv-block backward is
+    // throughput-bound, the GEMMs only trade places with the weight-gradient kernels and slow the latency-bound recurrence)
     const bool early_gru_w = parts == 3 && have_side && H != 64 && !(g_sed_debug & 131072);    // (debug bit 17: old schedule)
     bool forked = false, forked2 = false;
     auto fork = [&]() -> int {
@@ -345,6 +347,14 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
                 SED_TRY(launch_gru_bwd(d_cur, d_cur2, CTXF(L.out[l]), CTXF(L.gates[l]), params + P.w_hh[l][0], params + P.w_hh[l][1],
                                        params + P.w_ih[l][0], params + P.w_ih[l][1], nin, WSF(W.dgi[l]), WSF(W.dgh[l]), WSF(W.hprev[l]),
                                        d_in, g.B, g.T3, st));
+                // this layer's weight-gradient GEMMs start on the helper stream right behind its recurrence: the rest of the GRU
+                // chain keeps 48 CUs busy, and left for the conv blocks' fork they ended the step ~70 us after the caller's
+                // stream had finished (profiles/r03_a_mt-bf16_step_timeline.txt)
+                if (early_gru_w) {
+                    SED_TRY(fork());
+                    if (l == g.L - 1) SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, ss, 2 * H));
+                    SED_TRY(gru_weight_grads_layer(l, ss));
+                }
                 d_cur = d_in;
                 d_cur2 = d_in + (size_t)BT * nin;
             } else {

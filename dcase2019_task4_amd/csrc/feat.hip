@@ -22,6 +22,7 @@
 #include "philox.h"
 #include "kernels.h"
 
+SED_TS_DEFINE(feat)
 #define NFFT 2048
 #define NH 1024
 
@@ -125,6 +126,157 @@ __global__ __launch_bounds__(256) void k_stft_mel(const float* __restrict__ wave
         s += __shfl_xor(s, 2);
         if (q == 0 && m < n_mels) mel[((size_t)clip * frames + f) * n_mels + m] = (float)s;
     }
+}
+
+// ---- round 3: one WAVE per frame, radix 16 x 16 x 4 with the 16-point transforms in registers ------------------------------
+// k_stft_mel above moves 16 KB through LDS five times per frame with ds_write_b128 at 64-byte strides (4-way bank
+// conflicts; the LDS write path peaks at ~80 B / clock / CU anyway): 444 us for a batch of 64 clips against ~36 us of fp64
+// arithmetic - the LDS write path is what bounds it.  Here a frame belongs to ONE wave (no workgroup barriers), thread t
+// loads its 16 samples z[64 n1 + t] straight from global memory into registers, and 1024 = 16 x 16 x 4:
+//   A  16-point DFT over n1 in registers, twiddle W_1024^(t k1)                 -> exchange 1 (LDS, [k1][t], rows of 65)
+//   B1 thread (k1, m2): 16-point DFT over m1 of A[4 m1 + m2][k1], twiddle W_64^(m2 j1) -> exchange 2 ([m2][17 k1 + j1])
+//   B2 thread (k1, j1 = T / 16 + 4 i): 4-point DFT over m2 -> X[k1 + 16 (j1 + 16 j2)]  -> exchange 3 (natural order)
+// then the same real-FFT unpack and banded mel projection as above.  Three 16 KB LDS round trips instead of five, every
+// one of them conflict-free by layout (the paddings 65 / 17 put the 16 lanes of a ds_*_b128 group on distinct bank groups).
+struct cd { double x, y; };
+__device__ __forceinline__ cd cdmul(cd a, cd b) { return cd{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+// forward 4-point DFT in place (W_4 = -i): a <- a + b + c + d, b <- (a - c) - i (b - d), c <- a - b + c - d, d <- (a - c) + i (b - d)
+__device__ __forceinline__ void dft4(cd& a, cd& b, cd& c, cd& d) {
+    const cd s02 = {a.x + c.x, a.y + c.y}, d02 = {a.x - c.x, a.y - c.y};
+    const cd s13 = {b.x + d.x, b.y + d.y}, d13 = {b.x - d.x, b.y - d.y};
+    a = cd{s02.x + s13.x, s02.y + s13.y};
+    c = cd{s02.x - s13.x, s02.y - s13.y};
+    b = cd{d02.x + d13.y, d02.y - d13.x};
+    d = cd{d02.x - d13.y, d02.y + d13.x};
+}
+// forward 16-point DFT in place; afterwards X[k] sits in v[(k >> 2) + 4 (k & 3)]
+__device__ __forceinline__ void dft16(cd (&v)[16]) {
+    constexpr double C8 = 0.92387953251128673848, S8 = 0.38268343236508978178, R2 = 0.70710678118654752440;
+#pragma unroll
+    for (int n0 = 0; n0 < 4; ++n0) dft4(v[n0], v[n0 + 4], v[n0 + 8], v[n0 + 12]);        // v[n0 + 4 k0] = t[n0][k0]
+    // t[n0][k0] *= W_16^(n0 k0)
+    v[1 + 4] = cdmul(v[1 + 4], cd{C8, -S8});     // 1
+    v[1 + 8] = cdmul(v[1 + 8], cd{R2, -R2});     // 2
+    v[1 + 12] = cdmul(v[1 + 12], cd{S8, -C8});   // 3
+    v[2 + 4] = cdmul(v[2 + 4], cd{R2, -R2});     // 2
+    v[2 + 8] = cd{v[2 + 8].y, -v[2 + 8].x};      // 4: -i
+    v[2 + 12] = cdmul(v[2 + 12], cd{-R2, -R2});  // 6
+    v[3 + 4] = cdmul(v[3 + 4], cd{S8, -C8});     // 3
+    v[3 + 8] = cdmul(v[3 + 8], cd{-R2, -R2});    // 6
+    v[3 + 12] = cdmul(v[3 + 12], cd{-C8, S8});   // 9
+#pragma unroll
+    for (int k0 = 0; k0 < 4; ++k0) dft4(v[4 * k0], v[4 * k0 + 1], v[4 * k0 + 2], v[4 * k0 + 3]);   // X[k0 + 4 k1] at v[k1 + 4 k0]
+}
+#define DFT16_AT(k) (((k) >> 2) + 4 * ((k) & 3))
+
+__global__ __launch_bounds__(64) void k_stft_mel16(const float* __restrict__ wave, int n_samples, int hop, int frames,
+                                                    const double2* __restrict__ tw, const double* __restrict__ win,
+                                                    const float* __restrict__ mel_basis, const int* __restrict__ band, int n_mels,
+                                                    float* __restrict__ mel) {
+    __shared__ __attribute__((aligned(16))) cd buf[4 * 272];            // exchange 1: 16 x 65, exchange 2: 4 x 272, exchange 3: 1024
+    __shared__ double mag[NH + 1];
+    const int t = threadIdx.x;
+    const int f = blockIdx.x, clip = blockIdx.y;
+    const float* w = wave + (size_t)clip * n_samples;
+    auto twd = [&](int i) { const double2 v = tw[i]; return cd{v.x, v.y}; };
+    cd v[16];
+    TSC(0);
+    // ---- windowed, reflect-padded frame: z[m] = x[2m] + i x[2m + 1], m = 64 n1 + t ---------------------------------------------
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+        const int m = 64 * n1 + t;
+        double s[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = 2 * m + h;
+            int idx = f * hop + n - NFFT / 2;
+            if (idx < 0) idx = -idx;
+            if (idx >= n_samples) idx = 2 * (n_samples - 1) - idx;
+            s[h] = (double)w[idx] * win[n];
+        }
+        v[n1] = cd{s[0], s[1]};
+    }
+    TSC(1);
+    // ---- A ---------------------------------------------------------------------------------------------------------------------
+    dft16(v);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) {
+        const cd a = (k1 == 0) ? v[DFT16_AT(0)] : cdmul(v[DFT16_AT(k1)], twd(2 * t * k1));     // W_1024^(t k1) = W_2048^(2 t k1)
+        buf[k1 * 65 + t] = a;
+    }
+    TSC(2);
+    __syncthreads();
+    // ---- B1 --------------------------------------------------------------------------------------------------------------------
+    const int k1l = t & 15, m2 = t >> 4;
+#pragma unroll
+    for (int m1 = 0; m1 < 16; ++m1) v[m1] = buf[k1l * 65 + 4 * m1 + m2];
+    dft16(v);
+    __syncthreads();
+#pragma unroll
+    for (int j1 = 0; j1 < 16; ++j1) {
+        const cd b = (j1 == 0) ? v[DFT16_AT(0)] : cdmul(v[DFT16_AT(j1)], twd(32 * m2 * j1));    // W_64^(m2 j1) = W_2048^(32 m2 j1)
+        buf[m2 * 272 + k1l * 17 + j1] = b;
+    }
+    __syncthreads();
+    TSC(3);
+    // ---- B2: thread (k1 = t & 15, j1 = (t >> 4) + 4 i) ---------------------------------------------------------------------------
+    cd x4[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j1 = (t >> 4) + 4 * i;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x4[i][q] = buf[q * 272 + k1l * 17 + j1];
+        dft4(x4[i][0], x4[i][1], x4[i][2], x4[i][3]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j1 = (t >> 4) + 4 * i;
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) buf[k1l + 16 * (j1 + 16 * j2)] = x4[i][j2];
+    }
+    __syncthreads();
+    TSC(4);
+    // ---- real-FFT unpack -> magnitudes ---------------------------------------------------------------------------------------------
+    auto unpack = [&](int k) {
+        const cd Zk = buf[k & (NH - 1)];
+        const cd Zm = buf[(NH - k) & (NH - 1)];
+        const cd Zc = {Zm.x, -Zm.y};
+        const cd e = {0.5 * (Zk.x + Zc.x), 0.5 * (Zk.y + Zc.y)};
+        const cd o = {0.5 * (Zk.x - Zc.x), 0.5 * (Zk.y - Zc.y)};
+        const cd tt = cdmul(twd(k), o);                                  // W^k * o
+        const double re = e.x + tt.y, im = e.y - tt.x;                   // e - i * t
+        mag[k] = sqrt(re * re + im * im);
+    };
+#pragma unroll
+    for (int i = 0; i < 16; ++i) unpack(t + 64 * i);                     // (unrolled: the 16 twiddle loads are issued together)
+    if (t == 0) unpack(NH);
+    TSC(5);
+    __syncthreads();
+    // ---- mel projection: thread = (mel m, quarter q), 16 bands per pass --------------------------------------------------------------
+    for (int m0 = 0; m0 < n_mels; m0 += 16) {
+        const int m = m0 + (t >> 2), q = t & 3;
+        double sacc = 0.0;
+        if (m < n_mels) {
+            const float* row = mel_basis + (size_t)m * (NH + 1);
+            const int lo = band[2 * m], hi = band[2 * m + 1];
+            // 8 weights per trip, all eight loads issued before the first is used (clamped index, zero weight past the band)
+            for (int k0 = lo + ((q - lo) & 3); k0 < hi; k0 += 32) {
+                float wv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) wv[i] = row[min(k0 + 4 * i, NH)];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int k = k0 + 4 * i;
+                    sacc += (k < hi) ? (double)wv[i] * mag[min(k, NH)] : 0.0;
+                }
+            }
+        }
+        sacc += __shfl_xor(sacc, 1);
+        sacc += __shfl_xor(sacc, 2);
+        if (q == 0 && m < n_mels) mel[((size_t)clip * frames + f) * n_mels + m] = (float)sacc;
+    }
+    TSC(6);
 }
 
 // ---- log / noise / pad / normalise ----------------------------------------------------------------
@@ -236,7 +388,9 @@ extern "C" int sed_mel_spec(const float* wave, int n_clips, int n_samples, int h
     k_feat_tables<<<(tb + 255) / 256, 256, 0, st>>>(tw, win, window, mel_basis, n_mels, band);
     SED_CHECK_LAUNCH();
     const int frames = 1 + n_samples / hop;
-    k_stft_mel<<<dim3(frames, n_clips), 256, 0, st>>>(wave, n_samples, hop, frames, tw, win, mel_basis, band, n_mels, mel);
+    // (debug bit 19: the round-2 kernel - one 256-thread workgroup per frame, five radix-4 passes through LDS - for A/B timing)
+    if (g_sed_debug & 524288) k_stft_mel<<<dim3(frames, n_clips), 256, 0, st>>>(wave, n_samples, hop, frames, tw, win, mel_basis, band, n_mels, mel);
+    else k_stft_mel16<<<dim3(frames, n_clips), 64, 0, st>>>(wave, n_samples, hop, frames, tw, win, mel_basis, band, n_mels, mel);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

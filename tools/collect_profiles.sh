@@ -1,29 +1,40 @@
 #!/bin/bash
-# Round-2 profile collection on the GPU box (run through gpurun from the repo root); writes under gpurun_out/r02/.
+# Round-3 profile collection on the GPU box (run through gpurun from the repo root); writes under gpurun_out/$PROF_TAG/.
 # Counters are collected in their own passes with --kernel-trace only (never with hip/hsa trace domains).
 set -u
-OUT=$GRAFT_REPO_ROOT/gpurun_out/${PROF_TAG:-r02}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${PROF_TAG:-r03}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-# 1. kernel stats of the bench command, one per workload
-for c in mt-f32 mt-bf16 waveform-bf16 wide-f32 wide-bf16; do
+CFGS="mt-f32 mt-bf16 mt-bf16x3 waveform-bf16 wide-f32 wide-bf16 wide-bf16x3"
+# 1. kernel stats + one step's timeline of the bench command, one per workload
+for c in $CFGS; do
   timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/stats_$c -o p -- python $R/bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline > $OUT/stats_$c.log 2>&1
+  python $R/tools/summarize_prof.py $OUT/stats_$c > $OUT/${c}_kernel_stats.md 2>/dev/null
+  python $R/tools/timeline.py $OUT/stats_$c > $OUT/${c}_step_timeline.txt 2>/dev/null
 done
-# 2. HBM traffic of the headline workload: FETCH_SIZE and WRITE_SIZE in separate passes
+# 2. HBM traffic of the headline workload: FETCH_SIZE and WRITE_SIZE in separate passes (13 steps traced: 10 + 3 warm-up)
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o p -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $OUT/pmc_fetch.log 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o p -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $OUT/pmc_write.log 2>&1
-# 3. same for the wide bf16 step
-timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmcw_fetch -o p -- python $R/bench.py --config wide-bf16 --steps 6 --warmup 3 --no-extras > $OUT/pmcw_fetch.log 2>&1
-timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmcw_write -o p -- python $R/bench.py --config wide-bf16 --steps 6 --warmup 3 --no-extras > $OUT/pmcw_write.log 2>&1
-# 4. MFMA-busy / wait counters on solo kernel replays (headline kernel set) and on supervised wide bf16 steps
-for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"; do
-  timeout 300 rocprofv3 --pmc $grp --kernel-trace -d $OUT/pmcq_f32 -o p -- python $R/tools/kbench.py > $OUT/pmcq_f32.log 2>&1
-  timeout 300 rocprofv3 --pmc $grp --kernel-trace -d $OUT/pmcq_wide -o p -- python $R/tools/prof_generic.py --C 128 --H 256 --dtype bf16 --steps 4 > $OUT/pmcq_wide.log 2>&1
+python $R/tools/summarize_pmc.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json 13 > $OUT/mt-f32_pmc_hbm_traffic.md 2>/dev/null
+# 3. same for the wide bf16 step (9 steps traced)
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmcw_fetch -o p -- python $R/bench.py --config wide-bf16 --steps 6 --warmup 3 --no-extras --no-cpu-baseline > $OUT/pmcw_fetch.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmcw_write -o p -- python $R/bench.py --config wide-bf16 --steps 6 --warmup 3 --no-extras --no-cpu-baseline > $OUT/pmcw_write.log 2>&1
+python $R/tools/summarize_pmc.py $OUT/pmcw_fetch $OUT/pmcw_write $OUT/pmc_traffic_wide_bf16.json 9 > $OUT/wide-bf16_pmc_hbm_traffic.md 2>/dev/null
+# 4. MFMA-busy / wait counters on supervised steps (student only: kernel durations close to solo) of the wide model, bf16 and bf16x3
+CNT="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
+for dt in bf16 bf16x3; do
+  timeout 300 rocprofv3 --pmc $CNT --kernel-trace -d $OUT/pmcq_wide_$dt -o p -- python $R/tools/prof_generic.py --C 128 --H 256 --dtype $dt --steps 4 > $OUT/pmcq_wide_$dt.log 2>&1
+  python $R/tools/show_pmc.py --md "$OUT/pmcq_wide_$dt/*.db" "$OUT/pmcq_wide_$dt/**/*.db" > $OUT/wide-${dt}_pmc_mfma_busy.md 2>/dev/null
 done
+timeout 300 rocprofv3 --pmc $CNT --kernel-trace -d $OUT/pmcq_base_bf16 -o p -- python $R/tools/prof_generic.py --C 64 --H 64 --dtype bf16 --steps 4 > $OUT/pmcq_base_bf16.log 2>&1
+python $R/tools/show_pmc.py --md "$OUT/pmcq_base_bf16/*.db" "$OUT/pmcq_base_bf16/**/*.db" > $OUT/mt-bf16_pmc_mfma_busy.md 2>/dev/null
+timeout 300 rocprofv3 --pmc $CNT --kernel-trace -d $OUT/pmcq_f32 -o p -- python $R/tools/kbench.py > $OUT/pmcq_f32.log 2>&1
+python $R/tools/show_pmc.py --md "$OUT/pmcq_f32/*.db" "$OUT/pmcq_f32/**/*.db" > $OUT/mt-f32_pmc_mfma_busy.md 2>/dev/null
 # 5. un-profiled bench lines of the same build
-for c in mt-f32 mt-bf16 waveform-bf16 wide-f32 wide-bf16; do
-  extra=""; [ $c != mt-f32 ] && extra="--steps 500"
-  timeout 600 python $R/bench.py --config $c $extra > $OUT/bench_$c.json 2> $OUT/bench_$c.err
+for c in $CFGS; do
+  extra="--steps 500 --no-cpu-baseline"; [ $c = mt-f32 ] && extra=""
+  timeout 600 python $R/bench.py --config $c $extra > $OUT/${c}_bench.json 2> $OUT/${c}_bench.err
 done
+rm -rf $OUT/stats_* $OUT/pmc_fetch $OUT/pmc_write $OUT/pmcw_fetch $OUT/pmcw_write $OUT/pmcq_*/
 ls $OUT

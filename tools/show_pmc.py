@@ -4,7 +4,7 @@ solo kernel replays): mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 8 ... ) 
 import sqlite3, collections, glob, sys
 res = collections.defaultdict(dict)
 pats = [a for a in sys.argv[1:] if not a.startswith('--')] or ['/root/repo/gpurun_out/pmcq_*/r01_results.db']
-for db in [d for p in pats for d in glob.glob(p)]:
+for db in sorted(set(d for p in pats for d in glob.glob(p, recursive=True))):
     cur = sqlite3.connect(db).cursor()
     for name, cn, avg, n, dur in cur.execute("select name, counter_name, avg(counter_value), count(*), avg(duration) from pmc_events group by name, counter_name"):
         k = name.split('(')[0]

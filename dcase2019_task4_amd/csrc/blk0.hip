@@ -486,11 +486,24 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
     Blk0W<NH, MODE> W;
     blk0_load_w<NH, MODE>(W, wz, wl, lane);
     const float keep_scale = use_drop ? drop_scale8(p_drop) : 1.0f;
-    float aD[NH][10], aE[NH][10];
+    // MODE 0: the 2 x 10 sums per channel on the VALU (fp32 FMAs, lane = channel).  MODE 1: the sums are the GEMMs
+    // D = P^T dlin, E = P^T dzgate contracted over pixels - on the MFMA pipe (v_mfma_f32_32x32x16_bf16, fp32 accumulation over
+    // the whole grid-stride loop): the forward tile's D layout (lane = channel column, register r = pixel row) IS the B
+    // fragment of the transposed product, the A fragment is P^T (lane = tap row, 10 of 32 rows used) read straight from the
+    // input tile.  20 FMAs per (pixel, channel) - 2/3 of this kernel's VALU work - become 4 MFMAs per 32 x 32 tile.
+    float aD[MODE == 0 ? NH : 1][10], aE[MODE == 0 ? NH : 1][10];
+    f32x16 accD[MODE == 1 ? NH : 1], accE[MODE == 1 ? NH : 1];
+    if constexpr (MODE == 0) {
 #pragma unroll
-    for (int h = 0; h < NH; ++h)
+        for (int h = 0; h < NH; ++h)
 #pragma unroll
-        for (int t = 0; t < 10; ++t) { aD[h][t] = 0.f; aE[h][t] = 0.f; }
+            for (int t = 0; t < 10; ++t) { aD[h][t] = 0.f; aE[h][t] = 0.f; }
+    } else {
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accD[h][r] = 0.f; accE[h][r] = 0.f; }
+    }
     float* Pw = P[wv];
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int b = tile / tiles_per_clip, to0 = (tile % tiles_per_clip) * 4;
@@ -531,12 +544,46 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
                 const int m = n, j = m >> 3, dt = (m >> 2) & 1, df = m & 3;
                 const int base = (2 * wv + dt) * XS_W + 16 * g + 4 * j + df;
                 blk0_load_a<MODE>(av, xs, base, kh);
+                if constexpr (MODE == 0) {
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    const int k = kh * 6 + i;
-                    Pw[m * 12 + k] = (k < 9) ? xs[base + (k / 3) * XS_W + (k % 3)] : (k == 9 ? 1.0f : 0.f);
+                    for (int i = 0; i < 6; ++i) {
+                        const int k = kh * 6 + i;
+                        Pw[m * 12 + k] = (k < 9) ? xs[base + (k / 3) * XS_W + (k % 3)] : (k == 9 ? 1.0f : 0.f);
+                    }
                 }
             }
+            if constexpr (MODE == 1) {
+                // A fragments of the pixel contraction: lane (tap = n, half kh) holds P[pixel(r, kh)][tap] for its 16 pixel rows
+                // r - pixel(r, kh) is pooled col r >> 2, dt = kh, df = r & 3, i.e. 16 CONSECUTIVE floats of input row
+                // 2 wv + kh + tap / 3 (tap 9 = the constant 1, taps >= 10 zero: clamped address, then select)
+                blk0_bf16x8 pT[2];
+                {
+                    const int tc = n < 9 ? n : 0;
+                    const float* src = xs + (2 * wv + kh + tc / 3) * XS_W + 16 * g + tc % 3;
+                    const float other = n == 9 ? 1.0f : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pT[r >> 3][r & 7] = (__bf16)(n < 9 ? src[r] : other);
+                }
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    f32x16 al, az;
+                    blk0_mma<NH, MODE>(av, W, h, al, az);
+                    blk0_bf16x8 fl[2], fz[2];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float gg = ((m_c[h] >> r) & 1u) ? gq_c[h][r >> 2] : 0.f;
+                        const float sg = sigmoid_from_scaled(az[r]);
+                        const float dl = gg * sg;
+                        const float dzg = dl * al[r] * (1.0f - sg);
+                        fl[r >> 3][r & 7] = (__bf16)dl;
+                        fz[r >> 3][r & 7] = (__bf16)dzg;
+                    }
+                    accD[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pT[0], fl[0], accD[h], 0, 0, 0);
+                    accE[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pT[0], fz[0], accE[h], 0, 0, 0);
+                    accD[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pT[1], fl[1], accD[h], 0, 0, 0);
+                    accE[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pT[1], fz[1], accE[h], 0, 0, 0);
+                }
+            } else {
             __builtin_amdgcn_wave_barrier();
             // the two 32-channel halves one after the other: half the live accumulators / gradients, so the
             // kernel fits 2 waves per SIMD (the all-at-once version needed 331 registers = 1 wave, and every
@@ -574,17 +621,32 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            }
         }
     }
     // reduce: half-waves share the channel; then waves; then fp64 atomics
+    if constexpr (MODE == 0) {
 #pragma unroll
-    for (int h = 0; h < NH; ++h)
+        for (int h = 0; h < NH; ++h)
 #pragma unroll
-        for (int t = 0; t < 10; ++t) {
-            float vD = aD[h][t] + __shfl_xor(aD[h][t], 32);
-            float vE = aE[h][t] + __shfl_xor(aE[h][t], 32);
-            if (kh == 0) { red[wv][0][h][n][t] = vD; red[wv][1][h][n][t] = vE; }
+            for (int t = 0; t < 10; ++t) {
+                float vD = aD[h][t] + __shfl_xor(aD[h][t], 32);
+                float vE = aE[h][t] + __shfl_xor(aE[h][t], 32);
+                if (kh == 0) { red[wv][0][h][n][t] = vD; red[wv][1][h][n][t] = vE; }
+            }
+    } else {
+        // accumulator (tap row (r & 3) + 8 (r >> 2) + 4 kh, channel column n): taps 0 .. 7 are r < 4 of both halves, taps 8, 9 are
+        // r = 4, 5 of half 0 (the contraction already ran over both halves' pixels: no cross-lane sum)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { red[wv][0][h][n][r + 4 * kh] = accD[h][r]; red[wv][1][h][n][r + 4 * kh] = accE[h][r]; }
+            if (kh == 0) {
+                red[wv][0][h][n][8] = accD[h][4]; red[wv][0][h][n][9] = accD[h][5];
+                red[wv][1][h][n][8] = accE[h][4]; red[wv][1][h][n][9] = accE[h][5];
+            }
         }
+    }
     __syncthreads();
     for (int i = tid; i < 2 * C * 10; i += 256) {
         const int which = i / (C * 10), c = (i % (C * 10)) / 10, t = i % 10;

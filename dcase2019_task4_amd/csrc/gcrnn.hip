@@ -317,6 +317,7 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
         GemmBatch gb;
         gb.n_prob = 4; gb.splits = gru_splitk(g); gb.part = WSF(W.gemm_part) + (size_t)l * gru_gemm_part_floats(g);
         gb.part_floats = gru_gemm_part_floats(g); gb.part_stride = 0;
+        gb.bf16 = g.mode == SED_DTYPE_BF16;
         for (int dir = 0; dir < 2; ++dir) {
             gb.p[2 * dir] = gemm_prob(WSF(W.dgi[l]) + dir * 3 * H, 1, 6 * H, input, nin, 1, grads + P.w_ih[l][dir], nin, 3 * H, nin, BT);
             gb.p[2 * dir].Cones = grads + P.b_ih[l][dir];

@@ -21,8 +21,12 @@ SED_TS_DEFINE(gemm)
 #define GT_K 64    // these GEMMs are latency-bound (K = 64..384 per workgroup): 8 float4 loads in flight per thread and
                    // 1-6 trips through the load -> LDS -> MFMA chain (a 128-deep tile needed 256 VGPRs and measured slower)
 
+typedef __attribute__((ext_vector_type(8))) __bf16 gemm_bf16x8;
 __device__ __forceinline__ int prob_nx(const GemmProb& p) { return p.N + (p.Cones ? 1 : 0); }
 
+// BF: operands rounded to bf16 on the way from LDS into the MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulation): the
+// SED_DTYPE_BF16 mode's GRU weight gradients (K = B T, 9-13 GFLOP at the wide model: 90 us per layer on the f32 MFMA)
+template <bool BF>
 __global__ __launch_bounds__(256) void k_gemm_batched(GemmBatch gb) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     float* As = gsm;                                   // [GT_M][GT_K + 1]
@@ -132,11 +136,24 @@ __global__ __launch_bounds__(256) void k_gemm_batched(GemmBatch gb) {
             }
         lds_barrier();
         if (k0 + GT_K < kend) load_tile(k0 + GT_K);      // next tile's loads fly under this tile's MFMAs
+        if constexpr (BF) {
 #pragma unroll
-        for (int s = 0; s < GT_K / 2; ++s) {
-            const float a = As[(32 * wm + n) * (GT_K + 1) + 2 * s + kh];
-            const float b = Bs[(2 * s + kh) * (GT_N + 1) + 32 * wn + n];
-            acc = mfma32(a, b, acc);
+            for (int s = 0; s < GT_K / 16; ++s) {                 // lane (n, kh): k = 16 s + 8 kh + e
+                gemm_bf16x8 a, b;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    a[e] = (__bf16)As[(32 * wm + n) * (GT_K + 1) + 16 * s + 8 * kh + e];
+                    b[e] = (__bf16)Bs[(16 * s + 8 * kh + e) * (GT_N + 1) + 32 * wn + n];
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < GT_K / 2; ++s) {
+                const float a = As[(32 * wm + n) * (GT_K + 1) + 2 * s + kh];
+                const float b = Bs[(2 * s + kh) * (GT_N + 1) + 32 * wn + n];
+                acc = mfma32(a, b, acc);
+            }
         }
         lds_barrier();
     }
@@ -332,7 +349,7 @@ int launch_gemm_batch(GemmBatch& gb, hipStream_t st) {
         maxNx = nx > maxNx ? nx : maxNx;
     }
     if (gb.splits < 1) gb.splits = 1;
-    bool panel = (gb.splits == 1);
+    bool panel = (gb.splits == 1) && !gb.bf16;
     int maxK = 0, maxN = 0;
     for (int i = 0; i < gb.n_prob; ++i) {
         const GemmProb& q = gb.p[i];
@@ -377,10 +394,12 @@ int launch_gemm_batch(GemmBatch& gb, hipStream_t st) {
     const size_t lds = (size_t)(GT_M * (GT_K + 1) + GT_K * (GT_N + 1)) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_batched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_batched<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_batched<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    k_gemm_batched<<<grid, 256, lds, st>>>(gb);
+    if (gb.bf16) k_gemm_batched<true><<<grid, 256, lds, st>>>(gb);
+    else k_gemm_batched<false><<<grid, 256, lds, st>>>(gb);
     SED_CHECK_LAUNCH();
     if (gb.splits > 1) {
         dim3 g2((maxM * maxNx + 255) / 256, gb.n_prob);

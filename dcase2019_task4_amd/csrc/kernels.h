@@ -174,6 +174,7 @@ struct GemmBatch {
     float* part;                  // scratch: n_prob * splits * max(M) * max(N+1) floats
     size_t part_floats;           // capacity of `part` in floats (checked by launch_gemm_batch)
     size_t part_stride;           // filled by launch_gemm_batch
+    int bf16 = 0;                 // operands rounded to bf16 inside the kernel (bf16 MFMA, fp32 accumulation)
 };
 static inline GemmProb gemm_prob(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBk, int64_t sBn, float* C,
                                  int64_t ldc, int M, int N, int K) {

@@ -471,7 +471,10 @@ __global__ __launch_bounds__(256, (NH == 2 ? 3 : 2)) void k_blk0_fwd(const float
 }
 
 // ---- backward: D[co][t] = sum_p dlin[p][co] P[p][t],  E[c][t] = sum_p dzgate[p][c] P[p][t] ------
-template <int NH, int MODE>
+// NHT: channel slices of the whole block; a workgroup handles NH of them, those from blockIdx.y * NH on (C = 128 runs as two
+// 64-channel halves: the accumulators of all four slices need 290 registers = ONE wave per SIMD with every LDS / MFMA
+// latency of its in-order stream exposed - 197 us against 2 x 53 for the halves at two waves per SIMD)
+template <int NH, int MODE, int NHT>
 __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float* __restrict__ x, const float* __restrict__ wz,
                                                    const float* __restrict__ wl, const float* __restrict__ dp0, int B,
                                                    int T, int H1, int tiles_per_clip, int n_tiles, int use_drop,
@@ -480,11 +483,12 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
     __shared__ float xs[XS_H * XS_W];
     __shared__ __attribute__((aligned(16))) float P[4][32 * 12];
     __shared__ float red[4][2][NH][32][10];
-    constexpr int C = 32 * NH;
+    constexpr int C = 32 * NHT, CS = 32 * NH;
+    const int h0 = blockIdx.y * NH;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
     Blk0W<NH, MODE> W;
-    blk0_load_w<NH, MODE>(W, wz, wl, lane);
+    blk0_load_w<NH, MODE>(W, wz + 32 * h0 * 12, wl + 32 * h0 * 12, lane);
     const float keep_scale = use_drop ? drop_scale8(p_drop) : 1.0f;
     // MODE 0: the 2 x 10 sums per channel on the VALU (fp32 FMAs, lane = channel).  MODE 1: the sums are the GEMMs
     // D = P^T dlin, E = P^T dzgate contracted over pixels - on the MFMA pipe (v_mfma_f32_32x32x16_bf16, fp32 accumulation over
@@ -521,10 +525,10 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
             const int q0 = (b * H1 + to) * 16 + 4 * g;
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
-                const int c = 32 * h + n;
+                const int c = 32 * (h0 + h) + n;
 #pragma unroll
                 for (int jx = 0; jx < 4; ++jx) gq_n[h][jx] = ld1((const typename Stor<MODE == 1>::T*)dp0 + (size_t)(q0 + jx) * C + c);
-                m_n[h] = use_drop ? (uint32_t)mask_in[((size_t)(q0 >> 2) * NH + h) * 64 + lane] : 0xffffu;
+                m_n[h] = use_drop ? (uint32_t)mask_in[((size_t)(q0 >> 2) * NHT + h0 + h) * 64 + lane] : 0xffffu;
             }
         };
         fetch(0);
@@ -648,12 +652,12 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
         }
     }
     __syncthreads();
-    for (int i = tid; i < 2 * C * 10; i += 256) {
-        const int which = i / (C * 10), c = (i % (C * 10)) / 10, t = i % 10;
+    for (int i = tid; i < 2 * CS * 10; i += 256) {
+        const int which = i / (CS * 10), c = (i % (CS * 10)) / 10, t = i % 10;
         const int h = c >> 5, nn = c & 31;
         double v = (double)red[0][which][h][nn][t] + (double)red[1][which][h][nn][t] + (double)red[2][which][h][nn][t] +
                    (double)red[3][which][h][nn][t];
-        if (!no_atomic) atomicAdd(&de[i], v);
+        if (!no_atomic) atomicAdd(&de[(which * C + 32 * h0 + c) * 10 + t], v);
     }
 }
 
@@ -831,12 +835,20 @@ int launch_blk0_backward(const Geo& g, const float* x, const float* w0, const fl
     if (zero_de) SED_CHECK_HIP(hipMemsetAsync(de, 0, 2 * g.C * 10 * sizeof(double), st));
     const int tpc = (g.H1 + 3) / 4, nt = tpc * g.B;
     const int use_drop = (g.p > 0.f) ? 1 : 0;
-#define BLK0_BWD(NH, MODE, GRID) \
-    k_blk0_bwd<NH, MODE><<<nt < (GRID) ? nt : (GRID), 256, 0, st>>>(x, wz, wl, dp0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, mask_in, de, g_sed_debug & 1)
-    if (g.C == 64 && g.mode == 1) BLK0_BWD(2, 1, 512);
-    else if (g.C == 64) BLK0_BWD(2, 0, 512);
-    else if (g.C == 128 && g.mode == 1) BLK0_BWD(4, 1, 256);
-    else if (g.C == 128) BLK0_BWD(4, 0, 256);
+#ifndef BLK0_GRID128
+#define BLK0_GRID128 256
+#endif
+#ifdef BLK0_HALF_ONLY
+#define BLK0_YGRID(y) 1
+#else
+#define BLK0_YGRID(y) (y)
+#endif
+#define BLK0_BWD(NH, MODE, NHT, GRID) \
+    k_blk0_bwd<NH, MODE, NHT><<<dim3(nt < (GRID) ? nt : (GRID), BLK0_YGRID((NHT) / (NH))), 256, 0, st>>>(x, wz, wl, dp0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, mask_in, de, g_sed_debug & 1)
+    if (g.C == 64 && g.mode == 1) BLK0_BWD(2, 1, 2, 512);
+    else if (g.C == 64) BLK0_BWD(2, 0, 2, 512);
+    else if (g.C == 128 && g.mode == 1) BLK0_BWD(2, 1, 4, BLK0_GRID128);
+    else if (g.C == 128) BLK0_BWD(2, 0, 4, BLK0_GRID128);
 #undef BLK0_BWD
     else { sed_set_error("block 0: unsupported filter count %d", g.C); return SED_ERR_UNSUPPORTED; }
     SED_CHECK_LAUNCH();

@@ -306,21 +306,35 @@ __global__ __launch_bounds__(256) void k_gwgrad(const void* __restrict__ dz_v, c
 
 // ---- wgrad on the bf16 MFMA (block 1, W = 16) ----------------------------------------------------------------------------
 // The contraction index is the PIXEL, so both operands must reach the MFMA pixel-contiguous: they are transposed on their
-// way into LDS.  A thread loads 8 consecutive pixels x 4 channels (8 float4) and writes 4 x (8 pixels of one channel) as
-// 16-byte bf16 vectors - a register transpose, no extra instructions.  The 3x3 taps then need the x tile SHIFTED by
-// (dr, dc) pixels: k = r * 16 + c makes a row shift an offset of 16 elements (32 B: aligned), and the column shift is
-// served by three copies of the transposed halo, one per dc, each already shifted (copy[dc][ci][hr][c] = x[hr][c + dc]).
-//   A[i = co][k = pixel] = dyT[co][k]                    64 x (128 + 8) bf16
-//   B[k = pixel][j = ci] = xT[dc][ci][dr * 16 + k]       3 x 64 x (160 + 8) bf16
+// way into LDS.  A thread loads consecutive pixels x 4 channels (8-byte bf16 quads, kept packed) and writes 4 x (8 pixels of
+// one channel) as 16-byte bf16 vectors - a register transpose.  With k = r * 16 + c a row shift of the 3x3 tap is an offset of
+// 16 elements (32 B: aligned) and is served by ONE copy of the x tile with halo rows; the column shift moves to the OTHER
+// operand (summing over x's column c' = c + dc - 1 instead of dy's column c): three copies of dy, each shifted by dc - 1 and
+// zero-filled at the tile edge - dy has no halo rows, so its copies are the smaller ones.
+//   A[i = co][k = (r, c')] = dyT[dc][co][k] = dy[r][c' - dc + 1]      3 x 64 x (128 + 8) bf16
+//   B[k = (r, c')][j = ci] = xT[ci][dr * 16 + k] = x[r + dr - 1][c']      64 x (160 + 8) bf16
+// 74 KB of LDS and <= 256 registers (the first version - three copies of the haloed x tile, fp32 staging registers - had one
+// wave per SIMD and every load / LDS latency of its in-order stream exposed: MFMA busy 0.135).
 // Same decomposition as k_gwgrad: a workgroup owns a 64 x 64 (co, ci) quadrant for all 9 taps over a slab of tiles
 // (9 accumulators of 32 x 32 per wave) and writes one partial slab.  The next tile's loads are issued before the
 // current tile's MFMAs.
 struct GWgB {
     static constexpr int TH = 8, TW = 16, HH = 10, DS = 128 + 8, XS = HH * 16 + 8;
-    static constexpr int DY_E = 64 * DS, X_E = 3 * 64 * XS;
-    static constexpr size_t LDS_BYTES = (size_t)(DY_E + X_E) * 2 + 3 * 64 * 4;
+    static constexpr int DY_E = 3 * 64 * DS, X_E = 64 * XS;
+    static constexpr size_t STAGE_BYTES = (size_t)(DY_E + X_E) * 2 + 3 * 64 * 4, XCH_BYTES = (size_t)9 * 64 * 64 * 4;
+    static constexpr size_t LDS_BYTES = STAGE_BYTES > XCH_BYTES ? STAGE_BYTES : XCH_BYTES;
 };
-__global__ __launch_bounds__(256) void k_gwgrad_bf16(const __bf16* __restrict__ dz, const __bf16* __restrict__ yin,
+typedef __attribute__((ext_vector_type(2))) unsigned int gw_u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4g;
+__device__ __forceinline__ float gw_lo(unsigned int v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ float gw_hi(unsigned int v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
+// NG = 2: EIGHT waves, two groups of four split every tile's K (pixels) in halves - two waves per SIMD, ONE staged copy of the
+// tile and ONE partial slab per workgroup (group 1 hands its accumulators to group 0 through LDS at the end); NG = 1: four
+// waves, two workgroups per CU (twice the partial slabs).  Measured: C = 64 (one quadrant, 256 slabs) 41 -> 30 us with
+// NG = 2 (NG = 1: 28 us but 512 slabs = 75 MB of partials for the reduce, the step is slower); C = 128 (four quadrants)
+// 104 -> ~80 us with NG = 1 at 128 slabs.
+template <int NG>
+__global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void k_gwgrad_bf16(const __bf16* __restrict__ dz, const __bf16* __restrict__ yin,
                                                       const float* __restrict__ coef, const __bf16* __restrict__ xin,
                                                       float* __restrict__ part, int C, int H, int tiles_per_clip, int n_tiles) {
     using M = MM<1>;
@@ -331,67 +345,101 @@ __global__ __launch_bounds__(256) void k_gwgrad_bf16(const __bf16* __restrict__ 
     float* cf = (float*)(xT + GWgB::X_E);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 31, kh = lane >> 5;
     const int nq = C / 64, quad = blockIdx.y, co0 = (quad / nq) * 64, ci0 = (quad % nq) * 64;
-    const int wa = wv >> 1, wb = wv & 1;
+    const int grp = wv >> 2, wa = (wv >> 1) & 1, wb = wv & 1;
     if (tid < 192) cf[tid] = coef[(tid / 64) * C + co0 + (tid % 64)];
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    // staging items: dy - (pixel group pg of 8, channel quad cq); x - (halo row hr, column group cg, channel quad cq), 320 items
-    const int cq = tid & 15, pg = tid >> 4;
-    f32x4 dzv[8], yv[8], xv[2][10];
+    // staging items: dy - 256 of (pixel group pg of 8 + one pixel either side, channel quad cq): threads 0 .. 255; x - 320 of
+    // (halo row hr, column group cg, channel quad cq): NG = 2: threads 256 .. 511, and 0 .. 63 a second one; NG = 1: items
+    // tid and 256 + tid.  Loads are unconditional from clamped addresses, the selects follow (see k_gwgrad).
+    constexpr int NX = NG == 1 ? 2 : 1;
+    const bool dy_thread = NG == 1 || tid < 256;
+    const int cq = tid & 15, pg = (tid >> 4) & 15;
+    auto x_item = [&](int j) { return NG == 1 ? tid + 256 * j : (tid >= 256 ? tid - 256 : 256 + tid); };
+    auto x_valid = [&](int j) { return NG == 1 ? (tid + 256 * j < 320) : (tid >= 256 || tid < 64); };
+    gw_u32x2 dzv[10], yv[10], xv[NX][8];
     auto load = [&](int tile) {
         const int b = tile / tiles_per_clip, r0 = (tile % tiles_per_clip) * TH;
-        {
+        if (dy_thread) {
             const int r = pg >> 1, c0 = (pg & 1) * 8, row = r0 + r;
-            const bool ok = row < H;
-            const size_t base = ((size_t)(b * H + (ok ? row : 0)) * 16 + c0) * C + co0 + 4 * cq;
+            const size_t rbase = (size_t)(b * H + (row < H ? row : 0)) * 16;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                dzv[i] = ld4(dz + base + (size_t)i * C);
-                yv[i] = ld4(yin + base + (size_t)i * C);
-                if (!ok) { dzv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; yv[i] = dzv[i]; }
+            for (int i = 0; i < 10; ++i) {
+                const int col = c0 - 1 + i, cc = col < 0 ? 0 : (col > 15 ? 15 : col);
+                const size_t off = (rbase + cc) * C + co0 + 4 * cq;
+                dzv[i] = *(const gw_u32x2*)(dz + off);
+                yv[i] = *(const gw_u32x2*)(yin + off);
             }
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int it = tid + 256 * j, cg = (it >> 4) & 1, hr = it >> 5;
-            const int row = r0 - 1 + hr;
-            const bool rok = (it < 320) && row >= 0 && row < H;
+        for (int j = 0; j < NX; ++j) {
+            if (NG == 2 && !x_valid(j)) continue;                  // (NG = 1: unconditional, the item index is clamped)
+            const int xit = x_item(j), cg = (xit >> 4) & 1, hr = (xit >> 5) < 10 ? (xit >> 5) : 9;
+            const int row = r0 - 1 + hr, rc = row < 0 ? 0 : (row >= H ? H - 1 : row);
+            const size_t base = ((size_t)(b * H + rc) * 16 + 8 * cg) * C + ci0 + 4 * cq;
 #pragma unroll
-            for (int i = 0; i < 10; ++i) {
-                const int col = 8 * cg - 1 + i;
-                const bool okx = rok && col >= 0 && col < 16;           // (unconditional load, clamped address: see k_gwgrad)
-                xv[j][i] = ld4(xin + ((size_t)(b * H + (okx ? row : 0)) * 16 + (okx ? col : 0)) * C + ci0 + 4 * cq);
-                if (!okx) xv[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
+            for (int i = 0; i < 8; ++i) xv[j][i] = *(const gw_u32x2*)(xin + base + (size_t)i * C);
         }
     };
     auto store = [&](int tile) {
         const int r0 = (tile % tiles_per_clip) * TH;
-        const bool ok = r0 + (pg >> 1) < H;
+        if (dy_thread) {
+            const int r = pg >> 1, c0 = (pg & 1) * 8;
+            const bool rok = r0 + r < H;
+            // dy = cf0 dz + cf1 y + cf2 (the BatchNorm backward, per channel) for the 10 pixels, as packed bf16 pairs
+            unsigned int dyp[10][2];
+            float k0[4], k1[4], k2[4];                             // (read up front: an LDS read under the `ok` select becomes a branch)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            bf16x8 v;
+            for (int q = 0; q < 4; ++q) { k0[q] = cf[4 * cq + q]; k1[q] = cf[64 + 4 * cq + q]; k2[q] = cf[128 + 4 * cq + q]; }
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                v[i] = (__bf16)(ok ? cf[4 * cq + q] * dzv[i][q] + cf[64 + 4 * cq + q] * yv[i][q] + cf[128 + 4 * cq + q] : 0.f);
-            *(bf16x8*)(dyT + (4 * cq + q) * DS + 8 * pg) = v;
+            for (int i = 0; i < 10; ++i) {
+                const int col = c0 - 1 + i;
+                const bool ok = rok && col >= 0 && col < 16;
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned int zw = dzv[i][q >> 1], yw = yv[i][q >> 1];
+                    const float z = (q & 1) ? gw_hi(zw) : gw_lo(zw), y = (q & 1) ? gw_hi(yw) : gw_lo(yw);
+                    const float val = k0[q] * z + k1[q] * y + k2[q];
+                    v[q] = ok ? val : 0.f;
+                }
+                const bf16x4 pk = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                const gw_u32x2 pw = __builtin_bit_cast(gw_u32x2, pk);
+                dyp[i][0] = pw.x; dyp[i][1] = pw.y;
+            }
+            // copy dc holds dy[r][c' - dc + 1] at column c' = c0 + e: staged pixel index e - dc + 2
+#pragma unroll
+            for (int dc = 0; dc < 3; ++dc)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    unsigned int w[4];
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) {
+                        const unsigned int p0 = dyp[2 * e2 - dc + 2][q >> 1], p1 = dyp[2 * e2 + 1 - dc + 2][q >> 1];
+                        w[e2] = (q & 1) ? ((p0 >> 16) | (p1 & 0xffff0000u)) : ((p0 & 0xffffu) | (p1 << 16));
+                    }
+                    *(u32x4g*)(dyT + ((size_t)(dc * 64 + 4 * cq + q)) * DS + r * 16 + c0) = (u32x4g){w[0], w[1], w[2], w[3]};
+                }
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int it = tid + 256 * j, cg = (it >> 4) & 1, hr = it >> 5;
-            if (it < 320) {
+        for (int j = 0; j < NX; ++j) {
+            if (!x_valid(j)) continue;
+            const int xit = x_item(j), cg = (xit >> 4) & 1, hr = xit >> 5;
+            const int row = r0 - 1 + hr;
+            const bool ok = row >= 0 && row < H;
 #pragma unroll
-                for (int dc = 0; dc < 3; ++dc)
+            for (int q = 0; q < 4; ++q) {
+                unsigned int w[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        bf16x8 v;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) v[i] = (__bf16)xv[j][dc + i][q];
-                        *(bf16x8*)(xT + ((size_t)(dc * 64 + 4 * cq + q)) * XS + hr * 16 + 8 * cg) = v;
-                    }
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    const unsigned int p0 = xv[j][2 * e2][q >> 1], p1 = xv[j][2 * e2 + 1][q >> 1];
+                    const unsigned int v = (q & 1) ? ((p0 >> 16) | (p1 & 0xffff0000u)) : ((p0 & 0xffffu) | (p1 << 16));
+                    w[e2] = ok ? v : 0u;
+                }
+                *(u32x4g*)(xT + ((size_t)(4 * cq + q)) * XS + hr * 16 + 8 * cg) = (u32x4g){w[0], w[1], w[2], w[3]};
             }
         }
     };
@@ -404,25 +452,40 @@ __global__ __launch_bounds__(256) void k_gwgrad_bf16(const __bf16* __restrict__ 
             const int nt = tile + (int)gridDim.x;
             load(nt < n_tiles ? nt : tile);
         }
-        const __bf16* Ap = dyT + (32 * wa + n) * DS + 8 * kh;
-        const __bf16* Bp = xT + (size_t)(32 * wb + n) * XS + 8 * kh;
-#pragma unroll 2
-        for (int ks = 0; ks < 8; ++ks) {
-            const bf16x8 a = *(const bf16x8*)(Ap + 16 * ks);
+        const __bf16* Ap = dyT + (size_t)(32 * wa + n) * DS + 8 * kh + (128 / NG) * grp;
+        const __bf16* Bp = xT + (size_t)(32 * wb + n) * XS + 8 * kh + (128 / NG) * grp;
+#pragma unroll 1
+        for (int ks = 0; ks < 8 / NG; ++ks) {
+            bf16x8 a[3], bx[3];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int dr = t / 3, dc = t % 3;
-                acc[t] = M::mma(a, *(const bf16x8*)(Bp + (size_t)dc * 64 * XS + dr * 16 + 16 * ks), acc[t]);
+            for (int d = 0; d < 3; ++d) {
+                a[d] = *(const bf16x8*)(Ap + (size_t)d * 64 * DS + 16 * ks);
+                bx[d] = *(const bf16x8*)(Bp + d * 16 + 16 * ks);
             }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = M::mma(a[t % 3], bx[t / 3], acc[t]);
         }
         __syncthreads();
     }
-    float* ps = part + (size_t)blockIdx.x * 9 * C * C;
+    // group 1 -> LDS (the staging area is free now: 9 x 64 x 64 floats = 144 KB), group 0 adds and writes the partial slab
+    float* xch = (float*)wsm2;
+    const int slot = (wv & 3) * 64 + lane;                          // [t][r][slot]: conflict-free, coalesced
+    if (NG == 2 && grp == 1) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            ps[((size_t)t * C + co0 + 32 * wa + mfma32_row(r, lane)) * C + ci0 + 32 * wb + n] = acc[t][r];
+            for (int r = 0; r < 16; ++r) xch[(t * 16 + r) * 256 + slot] = acc[t][r];
+    }
+    if (NG == 2) __syncthreads();
+    if (grp == 0) {
+        float* ps = part + (size_t)blockIdx.x * 9 * C * C;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ps[((size_t)t * C + co0 + 32 * wa + mfma32_row(r, lane)) * C + ci0 + 32 * wb + n] =
+                    acc[t][r] + (NG == 2 ? xch[(t * 16 + r) * 256 + slot] : 0.f);
+    }
 }
 
 // g_w[co][ci][tap] = sum over slabs, fixed order
@@ -442,20 +505,27 @@ __global__ __launch_bounds__(256) void k_gwgrad_reduce(const float* __restrict__
     g_w[((size_t)co * C + ci) * 9 + tap] = s;
 }
 
-int gwgrad_slabs(int C) { return 256 / ((C / 64) * (C / 64)); }
+// partial slabs: capacity of the buffer (k_gwgrad_bf16<1> runs two workgroups per CU, everything else one)
+int gwgrad_slabs(int C) { return 512 / ((C / 64) * (C / 64)); }
 
 int launch_gwgrad(int mode, int C, const void* dz, const void* yin, const float* coef, const void* xin, float* part, float* g_w,
                   int B, int H, int W, hipStream_t st) {
     SED_CHECK_ARG(C == 64 || C == 128, "gwgrad: C must be 64 or 128");
     const int nq = (C / 64) * (C / 64);
-    int slabs = gwgrad_slabs(C);
+    const bool two_per_cu = W == 16 && mode == SED_DTYPE_BF16 && C == 128;
+    int slabs = gwgrad_slabs(C) / (two_per_cu ? 1 : 2);
     int nt, tpc;
     if (W == 16 && mode == SED_DTYPE_BF16) {
         static bool attr = false;
-        if (!attr) { SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GWgB::LDS_BYTES)); attr = true; }
+        if (!attr) {
+            SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad_bf16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GWgB::STAGE_BYTES));
+            SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad_bf16<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GWgB::LDS_BYTES));
+            attr = true;
+        }
         tpc = (H + GWgB::TH - 1) / GWgB::TH; nt = B * tpc;
         if (slabs > nt) slabs = nt;
-        k_gwgrad_bf16<<<dim3(slabs, nq), 256, GWgB::LDS_BYTES, st>>>((const __bf16*)dz, (const __bf16*)yin, coef, (const __bf16*)xin, part, C, H, tpc, nt);
+        if (two_per_cu) k_gwgrad_bf16<1><<<dim3(slabs, nq), 256, GWgB::STAGE_BYTES, st>>>((const __bf16*)dz, (const __bf16*)yin, coef, (const __bf16*)xin, part, C, H, tpc, nt);
+        else k_gwgrad_bf16<2><<<dim3(slabs, nq), 512, GWgB::LDS_BYTES, st>>>((const __bf16*)dz, (const __bf16*)yin, coef, (const __bf16*)xin, part, C, H, tpc, nt);
     } else if (W == 16) {
         using Cfg = GWgCfg<16>;
         static bool attr = false;

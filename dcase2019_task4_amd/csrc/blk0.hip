@@ -799,7 +799,6 @@ int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const flo
         const int slots = resident_workgroups(fn, 256), rounds = (nt + slots - 1) / slots;
         const int per_cu = 0, cus = slots;
         if (g_sed_debug & 8192) fprintf(stderr, "[sed] blk0 forward: %d resident workgroups, %d tiles, %d rounds\n", per_cu + cus, nt, rounds);
-        if (g_sed_debug >> 16) return (g_sed_debug >> 16) < nt ? (g_sed_debug >> 16) : nt;      // timing experiments: grid override
         return (nt + rounds - 1) / rounds;
     };
 #define BLK0_FWD_M(NH, DROP, SAVE, MODE) \

@@ -301,6 +301,8 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
     const bool defer_gru_w = (parts & 4) != 0;
     // (H = 64: measured NEUTRAL to slightly negative - 0.602 against 0.592 ms for the base bf16 step: the conv-block backward is
     // throughput-bound, the GEMMs only trade places with the weight-gradient kernels and slow the latency-bound recurrence)
+    // (H = 64, re-measured with the round-3 kernels: 0.580 against 0.569 ms - the GEMMs stretch the lower layer's recurrence from
+    // 40 to 52 us)
     const bool early_gru_w = parts == 3 && have_side && H != 64 && !(g_sed_debug & 131072);    // (debug bit 17: old schedule)
     bool forked = false, forked2 = false;
     auto fork = [&]() -> int {

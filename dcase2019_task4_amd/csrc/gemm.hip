@@ -35,10 +35,15 @@ __global__ __launch_bounds__(256) void k_gemm_batched(GemmBatch gb) {
     const GemmProb& d = gb.p[pi];
     const int Nx = prob_nx(d);
     const int m0 = blockIdx.y * GT_M, n0 = blockIdx.x * GT_N;
-    if (m0 >= d.M || n0 >= Nx) return;
+    if (m0 >= d.M || n0 >= d.N) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
     const int wm = wv >> 1, wn = wv & 1;
+    // the all-ones column of B (bias gradients = row sums of A) is NOT a GEMM column: it made a whole extra n-tile whose
+    // loads took the ragged path (one branch and one wait per element - the straggler of every launch).  The n-tile-0
+    // workgroups sum their A tile's rows on the VALU instead: thread (row tid >> 2, k quarter tid & 3).
+    const bool ones_here = d.Cones != nullptr && blockIdx.x == 0;
+    float rowsum = 0.f;
     int kbeg = 0, kend = d.K;
     if (gb.splits > 1) {
         const int chunk = ((d.K + gb.splits - 1) / gb.splits + GT_K - 1) / GT_K * GT_K;
@@ -65,6 +70,7 @@ __global__ __launch_bounds__(256) void k_gemm_batched(GemmBatch gb) {
     // interior tiles of vector-friendly problems take straight-line float4 loads: with the per-group range / alignment
     // branches below the compiler waits (s_waitcnt vmcnt(0)) behind every single load
     const bool interior = d.vec_ok && m0 + GT_M <= d.M && n0 + GT_N <= d.N;
+    (void)Nx;
     auto load_tile = [&](int k0) {
         if (interior && k0 + GT_K <= kend && (d.B2 == nullptr || k0 >= d.k2 || k0 + GT_K <= d.k2)) {
             const float* bbase = (d.B2 != nullptr && k0 >= d.k2) ? d.B2 - (int64_t)d.k2 * d.sBk : d.B;
@@ -115,8 +121,6 @@ __global__ __launch_bounds__(256) void k_gemm_batched(GemmBatch gb) {
                             if (nn < d.N) {
                                 w = (two && kk >= d.k2) ? d.B2[(int64_t)(kk - d.k2) * d.sBk + (int64_t)nn * d.sBn]
                                                         : d.B[(int64_t)kk * d.sBk + (int64_t)nn * d.sBn];
-                            } else if (nn == d.N && d.Cones) {
-                                w = 1.0f;
                             }
                         }
                         rb[it][q] = w;
@@ -136,6 +140,11 @@ __global__ __launch_bounds__(256) void k_gemm_batched(GemmBatch gb) {
             }
         lds_barrier();
         if (k0 + GT_K < kend) load_tile(k0 + GT_K);      // next tile's loads fly under this tile's MFMAs
+        if (ones_here) {
+            const float* ar = As + (tid >> 2) * (GT_K + 1) + 16 * (tid & 3);
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) rowsum += ar[kk];
+        }
         if constexpr (BF) {
 #pragma unroll
             for (int s = 0; s < GT_K / 16; ++s) {                 // lane (n, kh): k = 16 s + 8 kh + e
@@ -157,8 +166,17 @@ __global__ __launch_bounds__(256) void k_gemm_batched(GemmBatch gb) {
         }
         lds_barrier();
     }
+    if (ones_here) {
+        rowsum += __shfl_xor(rowsum, 1);
+        rowsum += __shfl_xor(rowsum, 2);
+        const int row = m0 + (tid >> 2);
+        if ((tid & 3) == 0 && row < d.M) {
+            if (gb.splits > 1) gb.part[(size_t)blockIdx.z * gb.part_stride + (size_t)row * Nx + d.N] = rowsum;
+            else d.Cones[row] = rowsum;
+        }
+    }
     const int col = n0 + 32 * wn + n;
-    if (col >= Nx) return;
+    if (col >= d.N) return;
     if (gb.splits > 1) {
         float* P = gb.part + ((size_t)blockIdx.z * gb.part_stride);
 #pragma unroll
@@ -172,14 +190,10 @@ __global__ __launch_bounds__(256) void k_gemm_batched(GemmBatch gb) {
     for (int r = 0; r < 16; ++r) {
         const int row = m0 + 32 * wm + mfma32_row(r, lane);
         if (row >= d.M) continue;
-        if (col < d.N) {
-            float* c = d.C + (int64_t)row * d.ldc + col;
-            float v = acc[r] + (d.bias ? d.bias[col] : 0.f);
-            if (d.accumulate) v += *c;
-            *c = v;
-        } else {
-            d.Cones[row] = acc[r];
-        }
+        float* c = d.C + (int64_t)row * d.ldc + col;
+        float v = acc[r] + (d.bias ? d.bias[col] : 0.f);
+        if (d.accumulate) v += *c;
+        *c = v;
     }
 }
 
@@ -390,7 +404,7 @@ int launch_gemm_batch(GemmBatch& gb, hipStream_t st) {
             return SED_ERR_WORKSPACE;
         }
     }
-    dim3 grid((maxNx + GT_N - 1) / GT_N, (maxM + GT_M - 1) / GT_M, gb.n_prob * gb.splits);
+    dim3 grid((maxN + GT_N - 1) / GT_N, (maxM + GT_M - 1) / GT_M, gb.n_prob * gb.splits);
     const size_t lds = (size_t)(GT_M * (GT_K + 1) + GT_K * (GT_N + 1)) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {

@@ -490,14 +490,15 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
     Blk0W<NH, MODE> W;
     blk0_load_w<NH, MODE>(W, wz + 32 * h0 * 12, wl + 32 * h0 * 12, lane);
     const float keep_scale = use_drop ? drop_scale8(p_drop) : 1.0f;
-    // MODE 0: the 2 x 10 sums per channel on the VALU (fp32 FMAs, lane = channel).  MODE 1: the sums are the GEMMs
+    // The first version formed the 2 x 10 sums per channel on the VALU (fp32 FMAs, lane = channel).  The sums are the GEMMs
     // D = P^T dlin, E = P^T dzgate contracted over pixels - on the MFMA pipe (v_mfma_f32_32x32x16_bf16, fp32 accumulation over
     // the whole grid-stride loop): the forward tile's D layout (lane = channel column, register r = pixel row) IS the B
     // fragment of the transposed product, the A fragment is P^T (lane = tap row, 10 of 32 rows used) read straight from the
     // input tile.  20 FMAs per (pixel, channel) - 2/3 of this kernel's VALU work - become 4 MFMAs per 32 x 32 tile.
-    float aD[MODE == 0 ? NH : 1][10], aE[MODE == 0 ? NH : 1][10];
-    f32x16 accD[MODE == 1 ? NH : 1], accE[MODE == 1 ? NH : 1];
-    if constexpr (MODE == 0) {
+    constexpr bool VALU_SUMS = false;      // (the round-1/2 path: 2 x 10 fp32 FMAs per pixel and channel on the VALU; kept for A/B)
+    float aD[VALU_SUMS ? NH : 1][10], aE[VALU_SUMS ? NH : 1][10];
+    f32x16 accD[VALU_SUMS ? 1 : NH], accE[VALU_SUMS ? 1 : NH];
+    if constexpr (VALU_SUMS) {
 #pragma unroll
         for (int h = 0; h < NH; ++h)
 #pragma unroll
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
                 const int m = n, j = m >> 3, dt = (m >> 2) & 1, df = m & 3;
                 const int base = (2 * wv + dt) * XS_W + 16 * g + 4 * j + df;
                 blk0_load_a<MODE>(av, xs, base, kh);
-                if constexpr (MODE == 0) {
+                if constexpr (VALU_SUMS) {
 #pragma unroll
                     for (int i = 0; i < 6; ++i) {
                         const int k = kh * 6 + i;
@@ -556,36 +557,56 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
                     }
                 }
             }
-            if constexpr (MODE == 1) {
+            if constexpr (!VALU_SUMS) {
                 // A fragments of the pixel contraction: lane (tap = n, half kh) holds P[pixel(r, kh)][tap] for its 16 pixel rows
                 // r - pixel(r, kh) is pooled col r >> 2, dt = kh, df = r & 3, i.e. 16 CONSECUTIVE floats of input row
-                // 2 wv + kh + tap / 3 (tap 9 = the constant 1, taps >= 10 zero: clamped address, then select)
-                blk0_bf16x8 pT[2];
+                // 2 wv + kh + tap / 3 (tap 9 = the constant 1, taps >= 10 zero: clamped address, then select).
+                // MODE 0 (fp32 arithmetic): every operand split v = hi + lo into two bf16 (lo = bf16(v - hi)), three products
+                // hi hi + hi lo + lo hi - the dropped lo lo term is 2^-16 of a product, below the fp32 rounding of the sums.
+                constexpr int NP = MODE == 0 ? 2 : 1;
+                blk0_bf16x8 pT[NP][2];
                 {
                     const int tc = n < 9 ? n : 0;
                     const float* src = xs + (2 * wv + kh + tc / 3) * XS_W + 16 * g + tc % 3;
                     const float other = n == 9 ? 1.0f : 0.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) pT[r >> 3][r & 7] = (__bf16)(n < 9 ? src[r] : other);
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = n < 9 ? src[r] : other;
+                        const __bf16 hi = (__bf16)v;
+                        pT[0][r >> 3][r & 7] = hi;
+                        if constexpr (MODE == 0) pT[1][r >> 3][r & 7] = (__bf16)(v - (float)hi);
+                    }
                 }
 #pragma unroll
                 for (int h = 0; h < NH; ++h) {
                     f32x16 al, az;
                     blk0_mma<NH, MODE>(av, W, h, al, az);
-                    blk0_bf16x8 fl[2], fz[2];
+                    blk0_bf16x8 fl[NP][2], fz[NP][2];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float gg = ((m_c[h] >> r) & 1u) ? gq_c[h][r >> 2] : 0.f;
                         const float sg = sigmoid_from_scaled(az[r]);
                         const float dl = gg * sg;
                         const float dzg = dl * al[r] * (1.0f - sg);
-                        fl[r >> 3][r & 7] = (__bf16)dl;
-                        fz[r >> 3][r & 7] = (__bf16)dzg;
+                        const __bf16 lh = (__bf16)dl, zh = (__bf16)dzg;
+                        fl[0][r >> 3][r & 7] = lh;
+                        fz[0][r >> 3][r & 7] = zh;
+                        if constexpr (MODE == 0) {
+                            fl[1][r >> 3][r & 7] = (__bf16)(dl - (float)lh);
+                            fz[1][r >> 3][r & 7] = (__bf16)(dzg - (float)zh);
+                        }
                     }
-                    accD[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pT[0], fl[0], accD[h], 0, 0, 0);
-                    accE[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pT[0], fz[0], accE[h], 0, 0, 0);
-                    accD[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pT[1], fl[1], accD[h], 0, 0, 0);
-                    accE[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pT[1], fz[1], accE[h], 0, 0, 0);
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        accD[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pT[0][hf], fl[0][hf], accD[h], 0, 0, 0);
+                        accE[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pT[0][hf], fz[0][hf], accE[h], 0, 0, 0);
+                        if constexpr (MODE == 0) {
+                            accD[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pT[0][hf], fl[1][hf], accD[h], 0, 0, 0);
+                            accE[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pT[0][hf], fz[1][hf], accE[h], 0, 0, 0);
+                            accD[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pT[1][hf], fl[0][hf], accD[h], 0, 0, 0);
+                            accE[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pT[1][hf], fz[0][hf], accE[h], 0, 0, 0);
+                        }
+                    }
                 }
             } else {
             __builtin_amdgcn_wave_barrier();
@@ -629,7 +650,7 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
         }
     }
     // reduce: half-waves share the channel; then waves; then fp64 atomics
-    if constexpr (MODE == 0) {
+    if constexpr (VALU_SUMS) {
 #pragma unroll
         for (int h = 0; h < NH; ++h)
 #pragma unroll

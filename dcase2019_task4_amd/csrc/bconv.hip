@@ -68,7 +68,15 @@ struct BConvCfg {
     static constexpr int BROW = KC * 2 + 16;                              // weight-chunk row stride (bytes): 144 / 80
     static constexpr int BBUF = C * BROW;                                 // one plane of one chunk
     static constexpr int HALO_BYTES = PLANES * HALO_PLANE;
-    static constexpr int WB_BYTES = 2 * PLANES * BBUF;
+    // bf16 mode (one plane), W = 4: THREE chunk buffers filled by LDS-DMA two chunks ahead (+ a 1 KB dump for the surplus
+    // wave-instructions).  Measured per kernel, LDS-DMA against register staging: W = 4 forward 19.1 -> 18.2 / 12.3 -> 12.1 us
+    // (C = 128 / 64), dgrad 16.6 -> 12.7 / 9.3 -> 7.8; W = 16 forward 48.0 -> 50.9 / 20.7 -> 22.4, dgrad 49.4 -> 54.3 / 20.4 ->
+    // 19.5: the wide tiles are bound by LDS bandwidth (2 x 2 register blocking = 1 KB of fragments per MFMA = the LDS peak), not
+    // by the weight prefetch, and pay for the in-order vmcnt waits (the previous tile's epilogue stores) - they keep the two
+    // register-staged buffers, and so does the split mode (its tiles leave no room for a third buffer)
+    static constexpr bool DMA = !X3 && TW == 4;
+    static constexpr int NBUF = DMA ? 3 : 2;
+    static constexpr int WB_BYTES = NBUF * PLANES * BBUF + (DMA ? 1024 : 0);
     static constexpr int RED_BYTES = WM * 2 * C * 4;                      // BatchNorm partial sums per M-row of waves
     static constexpr size_t LDS_BYTES = (size_t)HALO_BYTES + WB_BYTES + RED_BYTES;
     static_assert(M % (32 * WM) == 0 && C % (32 * WN) == 0, "wave tile must be whole MFMA tiles");
@@ -177,10 +185,38 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bconv(const void* __restrict__
         }
     };
 
-    // ---- weight chunk staging: rows n of C, 8 groups of 16 bytes per row and plane --------------------------------------
+    // ---- weight chunk staging -------------------------------------------------------------------------------------------
+    // DMA configurations: global_load_lds_dwordx4 - no registers, no ds_write - issued TWO chunks ahead into a ring of three buffers.
+    // (The first version staged the next chunk through registers and waited for it at the end of the same iteration: ~500
+    // MFMA cycles after the loads were issued, less than an L2 round trip - MFMA busy 0.30.)  One wave-instruction fills 1 KB
+    // of LDS linearly (lane l -> byte 16 l), i.e. 64 of the chunk's 16-byte pieces: the rows are BROW = 16 (GJ + 1) bytes, every
+    // (GJ + 1)-th piece is row padding (its lane re-reads piece 0: the bytes are never used).  Every wave issues the SAME number
+    // of instructions per chunk (NQW = ceil(NQ / NW), the surplus ones land in a dump area) so that the s_waitcnt vmcnt
+    // immediates below are compile-time constants.
     constexpr int GJ = KC / 8;                                            // 16-byte groups per chunk row
+    constexpr bool DMA = Cfg::DMA;
+    constexpr int NQ = (BBUF + 1023) / 1024, NQW = (NQ + Cfg::NW - 1) / Cfg::NW;
+    unsigned char* wdump = wb + Cfg::NBUF * PL * BBUF;
+    int dsrc[DMA ? NQW : 1];                                              // byte offset into wpk of this lane's piece (chunk 0)
+    if constexpr (DMA) {
+#pragma unroll
+        for (int i = 0; i < NQW; ++i) {
+            const int q = wv + Cfg::NW * i, o = 1024 * q + 16 * lane;
+            const int row = (o / BROW) < C ? (o / BROW) : C - 1, piece = (o % BROW) / 16;
+            dsrc[i] = (row * K + 8 * (piece < GJ ? piece : 0)) * 2;
+        }
+    }
+    auto b_dma = [&](int ch, int buf) {
+#pragma unroll
+        for (int i = 0; i < NQW; ++i) {
+            const int q = wv + Cfg::NW * i;                               // (wave-uniform)
+            unsigned char* dst = q < NQ ? wb + buf * BBUF + 1024 * q : wdump;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)wpk + dsrc[i] + ch * (KC * 2)),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
     constexpr int BITEM = C * GJ, BL = (BITEM + NT - 1) / NT;
-    f32x4 bst[BL][PL];
+    f32x4 bst[DMA ? 1 : BL][PL];
     auto b_load = [&](int ch) {
 #pragma unroll
         for (int i = 0; i < BL; ++i) {
@@ -188,7 +224,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bconv(const void* __restrict__
             if (BITEM % NT == 0 || g < BITEM) {
 #pragma unroll
                 for (int p = 0; p < PL; ++p)
-                    bst[i][p] = *(const f32x4*)((const char*)(wpk + (size_t)p * C * K + (size_t)row * K + (size_t)ch * KC) + 16 * j);
+                    bst[DMA ? 0 : i][p] = *(const f32x4*)((const char*)(wpk + (size_t)p * C * K + (size_t)row * K + (size_t)ch * KC) + 16 * j);
             }
         }
     };
@@ -198,7 +234,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bconv(const void* __restrict__
             const int g = tid + NT * i, row = g / GJ, j = g % GJ;
             if (BITEM % NT == 0 || g < BITEM) {
 #pragma unroll
-                for (int p = 0; p < PL; ++p) *(f32x4*)(wb + (buf * PL + p) * BBUF + row * BROW + 16 * j) = bst[i][p];
+                for (int p = 0; p < PL; ++p) *(f32x4*)(wb + (buf * PL + p) * BBUF + row * BROW + 16 * j) = bst[DMA ? 0 : i][p];
             }
         }
     };
@@ -221,9 +257,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bconv(const void* __restrict__
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int b = tile / tiles_per_clip, r0 = (tile % tiles_per_clip) * TH;
         if (DIR == 1) halo_load(tile);
-        b_load(0);
-        halo_store(tile);
-        b_store(0);
+        if constexpr (DMA) {
+            b_dma(0, 0);
+            b_dma(1, 1);
+            halo_store(tile);
+            // chunk 0 has landed when at most chunk 1's NQW instructions are outstanding (in-order counter: this also waits
+            // out the previous tile's epilogue stores and, DIR 1, this tile's halo loads - which halo_store consumed anyway)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQW) : "memory");
+        } else {
+            b_load(0);
+            halo_store(tile);
+            b_store(0);
+        }
         lds_barrier();                                                    // LDS-only barriers inside the tile loop: __syncthreads()
                                                                           // would drain the halo prefetch / the epilogue's stores
         if (DIR == 0) {       // the next tile's halo flies during this tile's MFMAs (past the end: this tile again, unused)
@@ -237,12 +282,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bconv(const void* __restrict__
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+        int cbuf = 0;                                                     // ring position of chunk ch (DMA)
 #pragma unroll 1
         for (int ch = 0; ch < NCH; ++ch) {
-            if (ch + 1 < NCH) b_load(ch + 1);
+            if constexpr (DMA) {
+                // (buffer (ch + 2) % 3 was read in iteration ch - 1: every wave is past that iteration's barrier)
+                if (ch + 2 < NCH) b_dma(ch + 2, cbuf == 0 ? 2 : cbuf - 1);
+            } else {
+                if (ch + 1 < NCH) b_load(ch + 1);
+            }
             const int tap = ch / CPT, dr = tap / 3, dc = tap - 3 * dr;
             const int t_off = dr * RP + dc * PS + (ch % CPT) * (KC * 2);
-            const unsigned char* bp = wb + (ch & 1) * PL * BBUF + b_off;
+            const unsigned char* bp = wb + (DMA ? cbuf : (ch & 1)) * PL * BBUF + b_off;
 #pragma unroll
             for (int ks = 0; ks < KC / 16; ++ks) {
                 bf16x8 af[MB][PL], bf[NB][PL];
@@ -265,7 +316,17 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bconv(const void* __restrict__
                         acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb][0], bf[nb][0], acc[mb][nb], 0, 0, 0);
                     }
             }
-            if (ch + 1 < NCH) b_store((ch + 1) & 1);
+            if constexpr (DMA) {
+                // chunk ch + 1 must have landed before the barrier publishes it: everything issued AFTER its instructions may
+                // stay in flight - chunk ch + 2's (this iteration) and, in iteration 0 of a forward tile, the next tile's halo loads
+                constexpr int NHL = (DIR == 0) ? NL * RV : 0;
+                if (ch == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQW + NHL < 63 ? NQW + NHL : 63) : "memory");
+                else if (ch + 2 < NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                cbuf = cbuf == 2 ? 0 : cbuf + 1;
+            } else {
+                if (ch + 1 < NCH) b_store((ch + 1) & 1);
+            }
             lds_barrier();
         }
         // ---- epilogue: D register r of lane (n, kh) is MFMA row (r & 3) + 8 (r >> 2) + 4 kh, column n ------------------

@@ -488,6 +488,150 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void k_gwgrad_bf16(const
     }
 }
 
+// ---- wgrad on the bf16 MFMA, W = 4 (block 2) ------------------------------------------------------------------------------
+// 15 000 pixels (B = 24) x C x 9 C: 1 - 4 GFLOP, a latency problem.  The pixel-slab decomposition above costs more in partial
+// slabs than in work here (every workgroup writes all 9 C^2 sums: 37 MB of partials + the reduce = 48 us at C = 64), so this
+// kernel is OUTPUT-stationary: a workgroup owns one 32 x 32 (co, ci) block for the three taps of ONE kernel row dr over a long
+// run of tiles (every n_slab-th tile of 32 rows x 4 columns = 128 pixels = K), its four waves split K (two k-steps each) and
+// meet in LDS at the end - 12 KB of partials per workgroup, 20 slabs.  With dr fixed the x tile is loaded already shifted by
+// dr - 1 rows (no halo, aligned fragment reads); the column shift sits on dy as in k_gwgrad_bf16: three copies, shifted
+// inside each 4-pixel row and zero-filled at its ends (a row never needs its neighbours' pixels).
+struct GWg4 {
+    static constexpr int TH = 32, DS = 128 + 8;
+    static constexpr int DY_E = 3 * 32 * DS, X_E = 32 * DS;
+    static constexpr size_t STAGE_BYTES = (size_t)(DY_E + X_E) * 2 + 3 * 32 * 4, RED_BYTES = (size_t)3 * 3 * 16 * 64 * 4;
+    static constexpr size_t LDS_BYTES = STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES;
+};
+__global__ __launch_bounds__(256) void k_gwgrad4_bf16(const __bf16* __restrict__ dz, const __bf16* __restrict__ yin,
+                                                       const float* __restrict__ coef, const __bf16* __restrict__ xin,
+                                                       float* __restrict__ part, int C, int H, int tiles_per_clip, int n_tiles) {
+    using M = MM<1>;
+    constexpr int TH = GWg4::TH, DS = GWg4::DS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsm4[];
+    __bf16* dyT = (__bf16*)wsm4;
+    __bf16* xT = dyT + GWg4::DY_E;
+    float* cf = (float*)(xT + GWg4::X_E);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 31, kh = lane >> 5;
+    const int ncb = C / 32, dr = blockIdx.y % 3, quad = blockIdx.y / 3, co0 = (quad / ncb) * 32, ci0 = (quad % ncb) * 32;
+    if (tid < 96) cf[tid] = coef[(tid / 32) * C + co0 + (tid % 32)];
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // staging items (8 consecutive pixels = two image rows, 4 channels): threads 0 .. 127 dy (dz and y), 128 .. 255 x
+    const bool dy_thread = tid < 128;
+    const int it = tid & 127, cq = it & 7, pg = it >> 3;
+    gw_u32x2 va[8], vb[8];                                         // dy threads: dz, y;  x threads: x (va)
+    auto load = [&](int tile) {
+        const int b = tile / tiles_per_clip, r0 = (tile % tiles_per_clip) * TH;
+        const int sh = dy_thread ? 0 : dr - 1, c0 = dy_thread ? co0 : ci0;
+        const __bf16* src = dy_thread ? dz : xin;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {                               // the item's two rows (unconditional loads, clamped rows)
+            const int row = r0 + 2 * pg + hf + sh, rc = row < 0 ? 0 : (row >= H ? H - 1 : row);
+            const size_t off = ((size_t)(b * H + rc) * 4) * C + c0 + 4 * cq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                va[4 * hf + i] = *(const gw_u32x2*)(src + off + (size_t)i * C);
+                if (dy_thread) vb[4 * hf + i] = *(const gw_u32x2*)(yin + off + (size_t)i * C);
+            }
+        }
+    };
+    auto pack8 = [&](const unsigned int (&pw)[8][2], int q, const int (&idx)[8]) {       // channel q of 8 pixels -> 16 bytes
+        unsigned int w[4];
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+            const int i0 = idx[2 * e2], i1 = idx[2 * e2 + 1];
+            const unsigned int p0 = i0 < 0 ? 0u : pw[i0 < 0 ? 0 : i0][q >> 1], p1 = i1 < 0 ? 0u : pw[i1 < 0 ? 0 : i1][q >> 1];
+            w[e2] = (q & 1) ? ((p0 >> 16) | (p1 & 0xffff0000u)) : ((p0 & 0xffffu) | (p1 << 16));
+        }
+        return (u32x4g){w[0], w[1], w[2], w[3]};
+    };
+    auto store = [&](int tile) {
+        const int r0 = (tile % tiles_per_clip) * TH;
+        unsigned int pw[8][2];
+        if (dy_thread) {
+            float k0[4], k1[4], k2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { k0[q] = cf[4 * cq + q]; k1[q] = cf[32 + 4 * cq + q]; k2[q] = cf[64 + 4 * cq + q]; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool ok = r0 + 2 * pg + (i >> 2) < H;
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned int zw = va[i][q >> 1], yw = vb[i][q >> 1];
+                    const float z = (q & 1) ? gw_hi(zw) : gw_lo(zw), y = (q & 1) ? gw_hi(yw) : gw_lo(yw);
+                    const float val = k0[q] * z + k1[q] * y + k2[q];
+                    v[q] = ok ? val : 0.f;
+                }
+                const bf16x4 pk = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                const gw_u32x2 t2 = __builtin_bit_cast(gw_u32x2, pk);
+                pw[i][0] = t2.x; pw[i][1] = t2.y;
+            }
+            // copy dc holds dy[r][c' - dc + 1] at column c' (zero outside the row): x's column is the summation index
+#pragma unroll
+            for (int dc = 0; dc < 3; ++dc) {
+                int idx[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const int sc = (e & 3) - dc + 1; idx[e] = (sc >= 0 && sc < 4) ? (e & 4) + sc : -1; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *(u32x4g*)(dyT + ((size_t)(dc * 32 + 4 * cq + q)) * DS + 8 * pg) = pack8(pw, q, idx);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = r0 + 2 * pg + (i >> 2) + dr - 1;
+                const bool ok = row >= 0 && row < H;
+                pw[i][0] = ok ? va[i].x : 0u; pw[i][1] = ok ? va[i].y : 0u;
+            }
+            const int idx[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(u32x4g*)(xT + ((size_t)(4 * cq + q)) * DS + 8 * pg) = pack8(pw, q, idx);
+        }
+    };
+    __syncthreads();
+    if ((int)blockIdx.x < n_tiles) load(blockIdx.x);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        store(tile);
+        __syncthreads();
+        {
+            const int nt = tile + (int)gridDim.x;
+            load(nt < n_tiles ? nt : tile);
+        }
+        const __bf16* Ap = dyT + (size_t)n * DS + 8 * kh + 32 * wv;
+        const __bf16* Bp = xT + (size_t)n * DS + 8 * kh + 32 * wv;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 bx = *(const bf16x8*)(Bp + 16 * ks);
+#pragma unroll
+            for (int dc = 0; dc < 3; ++dc) acc[dc] = M::mma(*(const bf16x8*)(Ap + (size_t)dc * 32 * DS + 16 * ks), bx, acc[dc]);
+        }
+        __syncthreads();
+    }
+    // waves 1 .. 3 -> LDS, wave 0 adds and writes the partial block
+    float* red = (float*)wsm4;
+    if (wv > 0) {
+#pragma unroll
+        for (int dc = 0; dc < 3; ++dc)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(((wv - 1) * 3 + dc) * 16 + r) * 64 + lane] = acc[dc][r];
+    }
+    __syncthreads();
+    if (wv == 0) {
+        float* ps = part + (size_t)blockIdx.x * 9 * C * C;
+#pragma unroll
+        for (int dc = 0; dc < 3; ++dc)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[dc][r] + red[((0 * 3 + dc) * 16 + r) * 64 + lane] + red[((1 * 3 + dc) * 16 + r) * 64 + lane] +
+                                red[((2 * 3 + dc) * 16 + r) * 64 + lane];
+                ps[((size_t)(dr * 3 + dc) * C + co0 + mfma32_row(r, lane)) * C + ci0 + n] = v;
+            }
+    }
+}
+
 // g_w[co][ci][tap] = sum over slabs, fixed order
 __global__ __launch_bounds__(256) void k_gwgrad_reduce(const float* __restrict__ part, int n_slabs, int C, float* __restrict__ g_w) {
     const int e = blockIdx.x * 256 + threadIdx.x;        // e = (tap * C + co) * C + ci
@@ -533,6 +677,15 @@ int launch_gwgrad(int mode, int C, const void* dz, const void* yin, const float*
         tpc = (H + Cfg::TH - 1) / Cfg::TH; nt = B * tpc;
         if (slabs > nt) slabs = nt;
         k_gwgrad<16, 0><<<dim3(slabs, nq), 256, Cfg::LDS_BYTES, st>>>(dz, yin, coef, xin, part, C, H, tpc, nt);
+    } else if (W == 4 && mode == SED_DTYPE_BF16) {
+        static bool attr = false;
+        if (!attr) { SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad4_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GWg4::LDS_BYTES)); attr = true; }
+        tpc = (H + GWg4::TH - 1) / GWg4::TH; nt = B * tpc;
+        const int blocks = (C / 32) * (C / 32) * 3;                        // (co block, ci block, kernel row) per slab
+        slabs = (480 + blocks - 1) / blocks;                               // ~two workgroups per CU (37 KB of LDS, 144 registers)
+        if (slabs > nt) slabs = nt;
+        if (slabs > gwgrad_slabs(C)) slabs = gwgrad_slabs(C);
+        k_gwgrad4_bf16<<<dim3(slabs, blocks), 256, GWg4::LDS_BYTES, st>>>((const __bf16*)dz, (const __bf16*)yin, coef, (const __bf16*)xin, part, C, H, tpc, nt);
     } else if (W == 4) {
         using Cfg = GWgCfg<4>;
         static bool attr = false;

@@ -82,7 +82,7 @@ int launch_grec_pack(const float* w_hh_f, const float* w_hh_r, void* wp, void* w
 // (no registers: the kernel sits at 256) - the one vmcnt(0) per block then falls on transfers issued microseconds
 // earlier - and the steps in between touch LDS only.
 #define GREC_TBF 8
-#define GREC_TBB 4
+#define GREC_TBB 8                       // (4 until the end of round 3: a block boundary costs ~2 600 cycles - 127 -> 123 us)
 // one wave-instruction: 64 lanes x 16 bytes from global straight into 1 KB of LDS (global_load_lds_dwordx4: no VGPRs; the
 // destination is the wave-uniform `lds` + 16 * lane, the source address is per lane).  Completion: s_waitcnt vmcnt + barrier.
 __device__ __forceinline__ void dma16(const float* gsrc_lane, float* lds_wave) {
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(GREC_T) void k_grec_bwd(const float* __restrict__ d
     // h_prev - every wave-instruction has ONE kind and ONE step), outputs TB x 448 (3.5 per thread)
     auto in_dma = [&](int s0, int buf) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < 3 * TB / 4; ++k) {
             const int i0 = 64 * (wv + 8 * k), st = i0 / 384, rem0 = i0 % 384, s = s0 + st;
             if (s < T) {
                 const int tt = t_of(s);
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(GREC_T) void k_grec_bwd(const float* __restrict__ d
     };
     auto out_flush = [&](int s0) {
 #pragma unroll 1
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < (TB * 448 + GREC_T - 1) / GREC_T; ++k) {
             const int i = t + GREC_T * k, st = i / 448, rem = i % 448, s = s0 + st;
             if (i < TB * 448 && s < T) {
                 const size_t bt2 = (size_t)(b * T + t_of(s)) * 2 + dir;

@@ -639,6 +639,15 @@ __global__ __launch_bounds__(256) void k_gwgrad_reduce(const float* __restrict__
     if (e >= n) return;
     float s = 0.f;
     int k = 0;
+    // 16 slabs per trip, every load issued before the first add (4 per trip left the kernel at one L2 / HBM round trip per 4
+    // slabs: 27 us for 256 slabs of 147 KB); the additions keep the slab order
+    for (; k + 16 <= n_slabs; k += 16) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = part[(size_t)(k + i) * n + e];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += v[i];
+    }
     for (; k + 4 <= n_slabs; k += 4) {
         const float v0 = part[(size_t)k * n + e], v1 = part[(size_t)(k + 1) * n + e], v2 = part[(size_t)(k + 2) * n + e],
                     v3 = part[(size_t)(k + 3) * n + e];

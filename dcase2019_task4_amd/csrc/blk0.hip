@@ -35,7 +35,7 @@ __device__ __forceinline__ int gidx(int a, int b) { return 9 + a * 9 - (a * (a -
 // fp32 accumulation runs over 1 024 pixels per wave; the cross-wave sums are fp64 and go to a per-workgroup
 // partial row which k_blk0_prep (the next kernel anyway) adds up in fixed order: no memset, no same-address
 // fp64 atomics (240 of them per address cost 7.5 us), bit-reproducible statistics.
-#define MOM_ROWS 64
+#define MOM_ROWS 64       // (32 rows = two workgroups per CU: the moments 14.4 -> 11 us, but twice the partials cost k_blk0_prep more)
 // Workgroups with blockIdx.x >= nx do the conv1 / conv2 weight packing of the same step instead (conv_pack_body,
 // kernels.h): independent work that used to be a 6 us launch of its own on the forward chain.
 __device__ __forceinline__ void x_moments_body(const float* __restrict__ x, int T, double* __restrict__ part, int nx);
@@ -68,8 +68,11 @@ __device__ __forceinline__ void x_moments_body(const float* __restrict__ x, int 
         const int e = tid + 256 * k;
         if (e < (MOM_ROWS + 2) * 16) {
             const int r = e >> 4, c4 = e & 15, t = t0 - 1 + r;
-            float4 v = {0.f, 0.f, 0.f, 0.f};
-            if (t >= 0 && t < T) v = *(const float4*)&x[((size_t)b * T + t) * 64 + 4 * c4];
+            // unconditional load from a clamped row, zeroed afterwards: under `if (in range)` every one of the five loads of a
+            // thread was a branch with its own s_waitcnt - five serialized HBM round trips, half of this kernel's 15 us
+            const int tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
+            float4 v = *(const float4*)&x[((size_t)b * T + tc) * 64 + 4 * c4];
+            if (t < 0 || t >= T) v = float4{0.f, 0.f, 0.f, 0.f};
             float* d = &xs[r * XS_W + 1 + 4 * c4];
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
@@ -129,7 +132,27 @@ __global__ __launch_bounds__(PREP_THREADS) void k_blk0_prep(Blk0PrepArgs a) {
     const int C = a.C;
     __shared__ double mred[54][16];
     __shared__ double moms[54];
+    __shared__ __attribute__((aligned(16))) float wgl[128 * 128];          // Wglu, staged for the fold at the end
     const int tid = threadIdx.x;
+    // Everything this one-workgroup kernel reads is requested up front, so that its ~10 us are ONE memory round trip instead
+    // of three in a row (partials -> per-channel parameters -> Wglu): Wglu as float4 into registers (<= 5 per thread), the
+    // per-channel conv / BatchNorm parameters, then the moment partials below.
+    constexpr int NWG = (128 * 128 / 4 + PREP_THREADS - 1) / PREP_THREADS;
+    f32x4 wgv[NWG];
+    const int nwg4 = C * C / 4;
+#pragma unroll
+    for (int u = 0; u < NWG; ++u) {
+        const int e = tid + PREP_THREADS * u;
+        wgv[u] = *(const f32x4*)(a.wglu + 4 * (e < nwg4 ? e : 0));
+    }
+    float w0r[9], b0r = 0.f, gamr = 0.f, betr = 0.f, rmr = 0.f, rvr = 0.f;
+    {
+        const int c = tid < C ? tid : 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w0r[t] = a.w0[c * 9 + t];
+        b0r = a.b0[c]; gamr = a.gamma[c]; betr = a.beta[c];
+        if (a.run_mean != nullptr && a.run_var != nullptr) { rmr = a.run_mean[c]; rvr = a.run_var[c]; }
+    }
     if (a.train) {   // patch moments = fixed-order fp64 sum of the per-workgroup partials
         if (tid < 864) {
             const int k = tid / 16, j = tid % 16;
@@ -163,12 +186,17 @@ __global__ __launch_bounds__(PREP_THREADS) void k_blk0_prep(Blk0PrepArgs a) {
         }
         __syncthreads();
     }
+#pragma unroll
+    for (int u = 0; u < NWG; ++u) {
+        const int e = tid + PREP_THREADS * u;
+        if (e < nwg4) *(f32x4*)&wgl[4 * e] = wgv[u];
+    }
     if (tid < C) {
         const int c = tid;
         double w[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) w[t] = a.w0[c * 9 + t];
-        const double b = a.b0[c];
+        for (int t = 0; t < 9; ++t) w[t] = w0r[t];
+        const double b = b0r;
         double mean, var;
         if (a.train) {
             double ws = 0, wGw = 0;
@@ -183,17 +211,17 @@ __global__ __launch_bounds__(PREP_THREADS) void k_blk0_prep(Blk0PrepArgs a) {
             var = wGw / a.N - mu * mu;
             if (var < 0) var = 0;
             if (a.update) {
-                a.run_mean[c] = (float)((1.0 - a.momentum) * a.run_mean[c] + a.momentum * mean);
-                a.run_var[c] = (float)((1.0 - a.momentum) * a.run_var[c] + a.momentum * var * a.N / (a.N - 1.0));
+                a.run_mean[c] = (float)((1.0 - a.momentum) * rmr + a.momentum * mean);
+                a.run_var[c] = (float)((1.0 - a.momentum) * rvr + a.momentum * var * a.N / (a.N - 1.0));
                 if (c == 0 && a.tracked) a.tracked[0] += 1;
             }
         } else {
-            mean = a.run_mean[c];
-            var = a.run_var[c];
+            mean = rmr;
+            var = rvr;
         }
         const double invstd = 1.0 / sqrt(var + (double)a.eps);
-        const double scale = a.gamma[c] * invstd;
-        const double shift = a.beta[c] - mean * scale;
+        const double scale = gamr * invstd;
+        const double shift = betr - mean * scale;
 #pragma unroll
         for (int t = 0; t < 9; ++t) wzs[c][t] = scale * w[t];
         wzs[c][9] = scale * b + shift;
@@ -207,7 +235,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_blk0_prep(Blk0PrepArgs a) {
     for (int e = tid; e < C * 10; e += PREP_THREADS) {   // wl[c][t] = sum_k Wglu[c][k] wz[k][t] (+ bglu at t = 9): one thread per (c, t)
         const int c = e / 10, t = e % 10;
         double acc = (t == 9) ? (double)a.bglu[c] : 0.0;
-        for (int k = 0; k < C; ++k) acc += (double)a.wglu[c * C + k] * wzs[k][t];
+        for (int k = 0; k < C; ++k) acc += (double)wgl[c * C + k] * wzs[k][t];
         a.wl[c * 12 + t] = (float)acc;
     }
 }

@@ -291,7 +291,10 @@ int sed_kernel_replay(const char* name, const sed_dims* d, const float* params, 
  *   Winograd F(2x2, 3x3) kernel - results differ at the 1e-7 level; bit 7: block-1 wgrad by the direct double-buffered
  *   kernel instead of the Winograd-domain one; bit 3: by the single-buffered tile kernel; bit 4: GLU backward with one wave per SIMD instead of two channel-half waves sharing a row block.
  *   bit 9: BatchNorm-backward coefficients by the 1-workgroup kernel k_bn_bwd_prep instead of in the prologue of the conv
- *   dgrad / wgrad kernels (also implied by bits 2, 3, 6, 7).  Kept for A/B timing (profiles/README.md). */
+ *   dgrad / wgrad kernels (also implied by bits 2, 3, 6, 7).  Kept for A/B timing (profiles/README.md).
+ *   Generic kernel set: bit 10 streaming H = 256 recurrence, bit 16 cluster recurrence instead of the one-CU bf16 kernels,
+ *   bit 17 late GRU weight-gradient schedule, bit 18 round-2 GLU kernels, bit 19 round-2 STFT kernel, bit 20 block-1
+ *   convolution (bf16, C = 128) by the barrier-free k_bconv2. */
 int sed_debug_set(int flags);
 /* bit 0: the library was built with the A/B baseline kernels (make EXTRA=-DSED_AB); without it debug bits 1, 2, 3, 6, 7
  * are ignored - the shipped library carries the product path only. */

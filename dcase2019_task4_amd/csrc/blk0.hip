@@ -538,11 +538,38 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
             for (int r = 0; r < 16; ++r) { accD[h][r] = 0.f; accE[h][r] = 0.f; }
     }
     float* Pw = P[wv];
+    // the next tile's rows are fetched (one float4 per thread, clamped row + select: no branch) before this tile's compute
+    // and land in LDS after it - the load used to sit between two barriers, a full HBM round trip per tile in the open
+    auto xs_fetch = [&](int tile) -> float4 {
+        const int b = tile / tiles_per_clip, t0 = 2 * ((tile % tiles_per_clip) * 4);
+        const int r = tid >> 4, c4 = tid & 15, t = t0 - 1 + r, tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (tid < XS_H * 16) {                                            // (wave-uniform up to the last wave)
+            v = *(const float4*)&x[((size_t)b * T + tc) * 64 + 4 * c4];
+            if (t < 0 || t >= T) v = float4{0.f, 0.f, 0.f, 0.f};
+        }
+        return v;
+    };
+    auto xs_put = [&](const float4& v) {
+        if (tid < XS_H * 16) {
+            float* d = &xs[(tid >> 4) * XS_W + 1 + 4 * (tid & 15)];
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        } else if (tid < XS_H * 16 + 2 * XS_H) {
+            const int e = tid - XS_H * 16;
+            xs[(e >> 1) * XS_W + (e & 1) * 65] = 0.f;
+        }
+    };
+    float4 xnext = {0.f, 0.f, 0.f, 0.f};
+    if ((int)blockIdx.x < n_tiles) xnext = xs_fetch(blockIdx.x);
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int b = tile / tiles_per_clip, to0 = (tile % tiles_per_clip) * 4;
         __syncthreads();
-        blk0_load_xs(xs, x, b, T, 2 * to0, tid);
+        xs_put(xnext);
         __syncthreads();
+        {
+            const int nxt = tile + (int)gridDim.x;
+            if (nxt < n_tiles) xnext = xs_fetch(nxt);
+        }
         const int to = to0 + wv;
         if (to >= H1) continue;
         // pooled gradients + keep bits of a row block are fetched one row block AHEAD: this kernel runs one

@@ -336,10 +336,21 @@ class WaveformFrontEnd:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=st._cap_stream):
                     cur = torch.cuda.current_stream()
-                    self._fe_stream.wait_stream(cur)
-                    with torch.cuda.stream(self._fe_stream):
-                        self.features(*self._bufs[1 - i])
-                    st._fwd_bwd()
+                    nxt = self._bufs[1 - i]
+
+                    def fork_features():
+                        self._fe_stream.wait_stream(cur)
+                        with torch.cuda.stream(self._fe_stream):
+                            self.features(*nxt)
+
+                    # SED_FE_FORK=start: fork at the head of the step (round 3's first version: the conv stacks of the forward
+                    # are throughput-bound, the 0.4 ms of feature kernels simply added to the step); default: after the
+                    # forwards, so that they run next to the heads / GRU backward (a fraction of the chip) first
+                    if os.environ.get("SED_FE_FORK", "backward") == "start":
+                        fork_features()
+                        st._fwd_bwd()
+                    else:
+                        st._fwd_bwd(after_forward=fork_features)
                     st._update()
                     cur.wait_stream(self._fe_stream)
                 graphs.append(g)

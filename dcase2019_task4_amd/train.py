@@ -192,8 +192,10 @@ class MeanTeacherStep:
                                            self.ctx_bytes, _lib.ptr(strong), _lib.ptr(weak), _lib.stream_ptr()),
                    "sed_crnn_forward")
 
-    def _fwd_bwd(self):
-        """teacher forward (main.py:87-89), student forward (:91), losses (:93-145), backward (:152-153)."""
+    def _fwd_bwd(self, after_forward=None):
+        """teacher forward (main.py:87-89), student forward (:91), losses (:93-145), backward (:152-153).
+        `after_forward`: called between the forwards and the backward (the waveform front-end forks the next batch's feature
+        kernels there: features.WaveformFrontEnd)."""
         if self.supervised:
             self._forward(self.student, self.x, self.ctx_s, self._seed_s, self.strong, self.weak)
         elif self._side is not None:
@@ -207,6 +209,8 @@ class MeanTeacherStep:
         else:
             self._forward(self.teacher, self.x_ema, self.ctx_t, self._seed_t, self.strong_ema, self.weak_ema)
             self._forward(self.student, self.x, self.ctx_s, self._seed_s, self.strong, self.weak)
+        if after_forward is not None:
+            after_forward()
         # losses (main.py:93-145) + backward in one call: the heads-backward kernel forms the loss gradient per clip itself
         # (sed_mt_loss as a kernel of its own was 12 us on the critical path).  One process: the whole backward
         # (parts = 3), which lets the library overlap the GRU weight gradients with the conv-block backward;

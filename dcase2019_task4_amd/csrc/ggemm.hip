@@ -174,10 +174,11 @@ int launch_gnt_gemm(const GntBatch& gb, hipStream_t st) {
 // dX GEMM reads it k-contiguous
 __global__ __launch_bounds__(256) void k_gnt_pack_t(const float* __restrict__ w0, const float* __restrict__ w1, float* __restrict__ out,
                                                      int R, int N) {
-    gnt_pack_t_body(w0, w1, out, R, N, blockIdx.x * 256 + threadIdx.x);
+    gnt_pack_t_body(w0, w1, out, R, N, (int)blockIdx.x, (int)threadIdx.x);
 }
 int launch_gnt_pack_t(const float* w0, const float* w1, float* out, int R, int N, hipStream_t st) {
-    k_gnt_pack_t<<<(2 * R * N + 255) / 256, 256, 0, st>>>(w0, w1, out, R, N);
+    SED_CHECK_ARG(R % 32 == 0 && N % 32 == 0, "gnt pack: R and N must be multiples of 32");
+    k_gnt_pack_t<<<gnt_pack_t_tiles(R, N), 256, 0, st>>>(w0, w1, out, R, N);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

@@ -58,12 +58,24 @@ __device__ __forceinline__ void gen_pack_bias_body(const GenPackArgs& a, int row
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if (lane == 0) (layer ? a.bg2 : a.bg1)[co] = (float)(acc + (double)(layer ? a.glu_b2 : a.glu_b1)[co]);
 }
-// out[n][dir * R + k] = w_dir[k][n]  (R rows, N columns each): the two W_ih stacked along K and transposed
+// out[n][dir * R + k] = w_dir[k][n]  (R rows, N columns each): the two W_ih stacked along K and transposed.  One 256-thread block
+// per 32 x 32 tile through LDS, so that the reads (rows of w) AND the writes (rows of out) are 128-byte runs: the per-element
+// version wrote 4 bytes per lane at a stride of 2R floats - 983 k scattered stores per model at H = 256, which made the packing
+// workgroups outlast the moments they ride with (43 us instead of 15 at the head of the wide step).  R and N are multiples of 32.
+__host__ __device__ inline int gnt_pack_t_tiles(int R, int N) { return 2 * (R / 32) * (N / 32); }
 __device__ __forceinline__ void gnt_pack_t_body(const float* __restrict__ w0, const float* __restrict__ w1, float* __restrict__ out,
-                                                int R, int N, int i) {
-    if (i >= 2 * R * N) return;
-    const int dir = i / (R * N), e = i % (R * N), k = e / N, nn = e % N;
-    out[(size_t)nn * 2 * R + dir * R + k] = (dir ? w1 : w0)[e];
+                                                int R, int N, int tile, int tid) {
+    __shared__ float tl[32][33];
+    const int per_dir = (R / 32) * (N / 32);
+    if (tile >= 2 * per_dir) return;                                  // (uniform per block)
+    const int dir = tile / per_dir, t2 = tile % per_dir, tk = t2 / (N / 32), tn = t2 % (N / 32);
+    const float* w = dir ? w1 : w0;
+    const int c = tid & 31, r0 = tid >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tl[r0 + 8 * i][c] = w[(size_t)(32 * tk + r0 + 8 * i) * N + 32 * tn + c];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[(size_t)(32 * tn + r0 + 8 * i) * 2 * R + dir * R + 32 * tk + c] = tl[c][r0 + 8 * i];
 }
 
 // everything a training forward packs, as a list of 256-thread blocks: [pack][bias][gnt layer 0][gnt layer 1]
@@ -80,7 +92,7 @@ __host__ __device__ inline int gen_aux_pack_blocks(const GenAuxPack& a) {
     return ((n > a.pk.n_zero ? n : a.pk.n_zero) + 255) / 256;
 }
 __host__ __device__ inline int gen_aux_bias_blocks(const GenAuxPack& a) { return (2 * a.pk.C + 3) / 4; }
-__host__ __device__ inline int gen_aux_gnt_blocks(const GenAuxPack& a, int l) { return l < a.n_gnt ? (2 * a.gR[l] * a.gN[l] + 255) / 256 : 0; }
+__host__ __device__ inline int gen_aux_gnt_blocks(const GenAuxPack& a, int l) { return l < a.n_gnt ? gnt_pack_t_tiles(a.gR[l], a.gN[l]) : 0; }
 __host__ __device__ inline int gen_aux_blocks(const GenAuxPack& a) {
     return gen_aux_pack_blocks(a) + gen_aux_bias_blocks(a) + gen_aux_gnt_blocks(a, 0) + gen_aux_gnt_blocks(a, 1);
 }
@@ -100,7 +112,7 @@ __device__ __forceinline__ void gen_aux_body(const GenAuxPack& a, int pb, int ti
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
         const int ng = gen_aux_gnt_blocks(a, l);
-        if (b < ng) { gnt_pack_t_body(a.gw0[l], a.gw1[l], a.gout[l], a.gR[l], a.gN[l], b * 256 + tid); return; }
+        if (b < ng) { gnt_pack_t_body(a.gw0[l], a.gw1[l], a.gout[l], a.gR[l], a.gN[l], b, tid); return; }
         b -= ng;
     }
 }

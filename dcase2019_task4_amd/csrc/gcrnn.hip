@@ -203,6 +203,13 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
                 aux.gR[l] = 3 * H; aux.gN[l] = (l == 0) ? C : 2 * H;
                 aux.n_gnt = l + 1;
             }
+        // the W_hh layouts of the one-CU bf16 recurrence too (k_grec_pack: 6 us in front of every recurrence launch)
+        if (H == 256 && g.mode == SED_DTYPE_BF16 && !(g_sed_debug & (1024 | 65536)))
+            for (int l = 0; l < g.L && l < 2; ++l) {
+                aux.rw0[l] = params + P.w_hh[l][0]; aux.rw1[l] = params + P.w_hh[l][1];
+                aux.rwp[l] = CTXV(L.whh[l]); aux.rwpT[l] = CTXV(L.whhT[l]);
+                aux.n_grec = l + 1;
+            }
     } else {
         SED_TRY(launch_gen_pack(pk, g.mode, ss));
     }
@@ -263,7 +270,8 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
                 gb.p[dir] = GntProb{in, nin, params + P.w_ih[l][dir], nin, CTXF(L.gi[l]) + dir * 3 * H, 6 * H, params + P.b_ih[l][dir], BT, 3 * H, nin};
             SED_TRY(g.mode == SED_DTYPE_BF16 ? launch_gnt_gemm_bf16(gb, st) : launch_gnt_gemm(gb, st));
             if (rec16) {
-                SED_TRY(launch_grec_pack(params + P.w_hh[l][0], params + P.w_hh[l][1], CTXV(L.whh[l]), train ? CTXV(L.whhT[l]) : nullptr, st));
+                if (!(aux_pack && l < aux.n_grec))
+                    SED_TRY(launch_grec_pack(params + P.w_hh[l][0], params + P.w_hh[l][1], CTXV(L.whh[l]), train ? CTXV(L.whhT[l]) : nullptr, st));
                 SED_TRY(launch_grec_fwd(CTXF(L.gi[l]), CTXV(L.whh[l]), params + P.b_hh[l][0], params + P.b_hh[l][1], CTXF(L.out[l]),
                                         train ? CTXF(L.gates[l]) : nullptr, g.B, g.T3, st));
             } else if (cluster)

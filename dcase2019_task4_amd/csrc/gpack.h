@@ -78,7 +78,34 @@ __device__ __forceinline__ void gnt_pack_t_body(const float* __restrict__ w0, co
     for (int i = 0; i < 4; ++i) out[(size_t)(32 * tn + r0 + 8 * i) * 2 * R + dir * R + 32 * tk + c] = tl[c][r0 + 8 * i];
 }
 
-// everything a training forward packs, as a list of 256-thread blocks: [pack][bias][gnt layer 0][gnt layer 1]
+// W_hh (H = 256) -> bf16 in the order the one-CU recurrence kernels load it (grec.hip): one 8-vector per thread
+//   wp [dir][g][kc][u][8]  = W[g H + u][8 kc + e]          wpT[dir][gc][j][8] = W[8 gc + e][j]
+__host__ __device__ inline int grec_pack_blocks() { return (2 * 3 * 256 * 256 / 8 + 255) / 256; }
+__device__ __forceinline__ void grec_pack_body(const float* __restrict__ w_f, const float* __restrict__ w_r, __bf16* __restrict__ wp,
+                                               __bf16* __restrict__ wpT, int i) {
+    constexpr int H = 256;
+    const int per_dir = 3 * H * H / 8;
+    if (i >= 2 * per_dir) return;
+    const int dir = i / per_dir, v = i % per_dir;
+    const float* w = dir ? w_r : w_f;
+    {
+        const int u = v % H, kc = (v / H) % (H / 8), g = v / (H * (H / 8));
+        const float* s = w + (size_t)(g * H + u) * H + 8 * kc;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)s[e];
+        *(bf16x8*)(wp + ((size_t)dir * per_dir + v) * 8) = o;
+    }
+    if (wpT != nullptr) {
+        const int j = v % H, gc = v / H;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)w[(size_t)(8 * gc + e) * H + j];
+        *(bf16x8*)(wpT + ((size_t)dir * per_dir + v) * 8) = o;
+    }
+}
+
+// everything a training forward packs, as a list of 256-thread blocks: [pack][bias][gnt layer 0][gnt layer 1][grec layer 0][grec layer 1]
 struct GenAuxPack {
     GenPackArgs pk;
     int mode;
@@ -86,6 +113,9 @@ struct GenAuxPack {
     const float *gw0[2], *gw1[2];
     float* gout[2];
     int gR[2], gN[2];
+    int n_grec;                                 // GRU layers whose W_hh goes to the bf16 recurrence layout here (0: own launches)
+    const float *rw0[2], *rw1[2];
+    void *rwp[2], *rwpT[2];
 };
 __host__ __device__ inline int gen_aux_pack_blocks(const GenAuxPack& a) {
     const int n = 2 * 9 * a.pk.C * a.pk.C;
@@ -94,7 +124,7 @@ __host__ __device__ inline int gen_aux_pack_blocks(const GenAuxPack& a) {
 __host__ __device__ inline int gen_aux_bias_blocks(const GenAuxPack& a) { return (2 * a.pk.C + 3) / 4; }
 __host__ __device__ inline int gen_aux_gnt_blocks(const GenAuxPack& a, int l) { return l < a.n_gnt ? gnt_pack_t_tiles(a.gR[l], a.gN[l]) : 0; }
 __host__ __device__ inline int gen_aux_blocks(const GenAuxPack& a) {
-    return gen_aux_pack_blocks(a) + gen_aux_bias_blocks(a) + gen_aux_gnt_blocks(a, 0) + gen_aux_gnt_blocks(a, 1);
+    return gen_aux_pack_blocks(a) + gen_aux_bias_blocks(a) + gen_aux_gnt_blocks(a, 0) + gen_aux_gnt_blocks(a, 1) + a.n_grec * grec_pack_blocks();
 }
 __device__ __forceinline__ void gen_aux_body(const GenAuxPack& a, int pb, int tid) {
     int b = pb;
@@ -114,5 +144,11 @@ __device__ __forceinline__ void gen_aux_body(const GenAuxPack& a, int pb, int ti
         const int ng = gen_aux_gnt_blocks(a, l);
         if (b < ng) { gnt_pack_t_body(a.gw0[l], a.gw1[l], a.gout[l], a.gR[l], a.gN[l], b, tid); return; }
         b -= ng;
+    }
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        const int nr = l < a.n_grec ? grec_pack_blocks() : 0;
+        if (b < nr) { grec_pack_body(a.rw0[l], a.rw1[l], (__bf16*)a.rwp[l], (__bf16*)a.rwpT[l], b * 256 + tid); return; }
+        b -= nr;
     }
 }

@@ -22,6 +22,7 @@
 #include "gen.h"
 #include "kernels.h"
 #include "gkernels.h"
+#include "gpack.h"
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4r;
@@ -44,27 +45,7 @@ __device__ __forceinline__ float tanh_fast(float x) { return 2.0f * rcp_fast(1.0
 //   wpT[dir][gc][j][8]     = W[8 gc + e][j]                (backward: 16-byte vector gc of column j; gc < 3H / 8)
 __global__ __launch_bounds__(256) void k_grec_pack(const float* __restrict__ w_f, const float* __restrict__ w_r,
                                                     __bf16* __restrict__ wp, __bf16* __restrict__ wpT) {
-    constexpr int H = GREC_H;
-    const int i = blockIdx.x * 256 + threadIdx.x;                 // one 8-vector
-    const int per_dir = 3 * H * H / 8;
-    if (i >= 2 * per_dir) return;
-    const int dir = i / per_dir, v = i % per_dir;
-    const float* w = dir ? w_r : w_f;
-    {
-        const int u = v % H, kc = (v / H) % (H / 8), g = v / (H * (H / 8));
-        const float* s = w + (size_t)(g * H + u) * H + 8 * kc;
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (__bf16)s[e];
-        *(bf16x8*)(wp + ((size_t)dir * per_dir + v) * 8) = o;
-    }
-    if (wpT != nullptr) {
-        const int j = v % H, gc = v / H;
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (__bf16)w[(size_t)(8 * gc + e) * H + j];
-        *(bf16x8*)(wpT + ((size_t)dir * per_dir + v) * 8) = o;
-    }
+    grec_pack_body(w_f, w_r, wp, wpT, blockIdx.x * 256 + threadIdx.x);      // (gpack.h: training forwards run it in the moments launch)
 }
 int launch_grec_pack(const float* w_hh_f, const float* w_hh_r, void* wp, void* wpT, hipStream_t st) {
     const int n = 2 * 3 * GREC_H * GREC_H / 8;

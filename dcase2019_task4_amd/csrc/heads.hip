@@ -61,9 +61,22 @@ __device__ __forceinline__ uint32_t heads_stage(const float* __restrict__ h, flo
 template <int HF, int STRIDE>
 __device__ __forceinline__ void heads_stage_w(const float* __restrict__ wd, const float* __restrict__ ws, float* wsm, int NC, int tid) {
     HD_CONSTS(HF);
-    for (int e = tid; e < HD_MAXO * HD_F; e += HD_THREADS) {
-        const int o = e / HD_F, f = e % HD_F;
-        wsm[o * STRIDE + f] = (o < NC) ? wd[o * HD_F + f] : (o < 2 * NC ? ws[(o - NC) * HD_F + f] : 0.f);
+    // one float4 per trip from a SELECTED row pointer (never a load under the row condition: as `o < NC ? wd[..] : ...` every
+    // trip was a branch with its own s_waitcnt - 4 (HF = 128) or 16 (HF = 512) serialized round trips at the head of both
+    // heads kernels), all trips issued before the first store
+    constexpr int N4 = HD_MAXO * HD_F / 4, TRIPS = (N4 + HD_THREADS - 1) / HD_THREADS;
+    f32x4 v[TRIPS];
+#pragma unroll
+    for (int i = 0; i < TRIPS; ++i) {
+        const int e4 = tid + HD_THREADS * i, o = (4 * e4) / HD_F, f = (4 * e4) % HD_F;
+        const int oc = o < 2 * NC ? o : 2 * NC - 1;
+        const float* row = oc < NC ? wd + (size_t)oc * HD_F : ws + (size_t)(oc - NC) * HD_F;
+        v[i] = *(const f32x4*)(row + (e4 < N4 ? f : 0));
+    }
+#pragma unroll
+    for (int i = 0; i < TRIPS; ++i) {
+        const int e4 = tid + HD_THREADS * i, o = (4 * e4) / HD_F, f = (4 * e4) % HD_F;
+        if (e4 < N4) *(f32x4*)&wsm[o * STRIDE + f] = o < 2 * NC ? v[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 }
 

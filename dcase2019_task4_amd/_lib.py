@@ -7,8 +7,13 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# SED_LIB: alternative build of the SAME library (kernel tuning experiments), never a different implementation
-LIB_PATH = os.environ.get("SED_LIB") or os.path.join(_HERE, "libdcase_sed_mi355.so")
+LIB_PATH = os.path.join(_HERE, "libdcase_sed_mi355.so")
+# SED_LIB: a variant build of the SAME sources with experiment knobs (tools/build_variant.sh -> build/variants/, never shipped).
+# Such builds may compute wrong results on purpose (timing experiments), so they load only with SED_ALLOW_VARIANT=1.
+if os.environ.get("SED_LIB"):
+    if os.environ.get("SED_ALLOW_VARIANT") != "1":
+        raise ImportError("SED_LIB is set but SED_ALLOW_VARIANT != 1: refusing to load a variant build of the library")
+    LIB_PATH = os.environ["SED_LIB"]
 
 
 class SedError(RuntimeError):

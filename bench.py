@@ -385,7 +385,7 @@ def main():
         g = torch.Generator().manual_seed(77 + rank)
         wave = (0.1 * torch.randn(B, 160000, generator=g)).to(device)
         from dcase2019_task4_amd.features import FeatureConfig
-        runner = WaveformFrontEnd(step, wave, FeatureConfig.baseline_16k())
+        runner = WaveformFrontEnd(step, wave, FeatureConfig.baseline_16k(), fft_dtype=os.environ.get("SED_FE_FFT", "f32"))
     for _ in range(max(args.warmup, 3)):       # >= 3: two eager warm-ups + graph capture/first replay
         runner.run()
     elapsed = time_steps(runner, args.steps, world, device)

@@ -27,7 +27,10 @@ class SedDims(C.Structure):
                 ("bn_eps", C.c_float), ("bn_momentum", C.c_float), ("dtype", C.c_int32)]
 
 
+FORK_CALLBACK = C.CFUNCTYPE(None, C.c_void_p)     # void (*fn)(void* user): sed_crnn_fork_callback
 DTYPE_F32, DTYPE_BF16, DTYPE_BF16X3 = 0, 1, 2
+FFT_F64, FFT_F32 = 0, 1
+FFT_DTYPES = {"f64": FFT_F64, "float64": FFT_F64, "f32": FFT_F32, "float32": FFT_F32}
 DTYPES = {"f32": DTYPE_F32, "fp32": DTYPE_F32, "float32": DTYPE_F32, "bf16": DTYPE_BF16, "bfloat16": DTYPE_BF16,
           "bf16x3": DTYPE_BF16X3}
 
@@ -69,8 +72,11 @@ _SIGS = {
     "sed_step_state_advance": (C.c_int, [_P, _P]),
     "sed_step_state_update": (C.c_int, [_P, C.c_uint64, C.c_double, C.c_int, _P]),
     "sed_stream_prepare": (C.c_int, [_P]),
+    "sed_crnn_fork_callback": (C.c_int, [_P, _P, _P]),
     "sed_mel_spec_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "sed_mel_spec": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_size_t, _P]),
+    "sed_mel_tables": (C.c_int, [C.c_int, _P, _P, C.c_int, _P, C.c_size_t, _P]),
+    "sed_mel_frames": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_size_t, C.c_int, C.c_int, _P]),
     "sed_seed_advance": (C.c_int, [_P, _P]),
     "sed_logmel_transform_ws_bytes": (C.c_size_t, [C.c_int]),
     "sed_logmel_transform": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),

@@ -221,6 +221,38 @@ extern "C" int sed_stream_prepare(void* stream) {
     }
     return SED_OK;
 }
+// One-shot hook for a caller with independent work to run BESIDE the recurrent part of a forward (the waveform front-end:
+// the next batch's STFT, features.WaveformFrontEnd): the next sed_crnn_forward on `stream` calls fn(user) on the calling host
+// thread after enqueueing its last conv-block kernel and before enqueueing its first recurrence kernel.  The callback forks
+// its own stream off `stream` there (event record + wait) and enqueues its work, so the fork sits at that point of the
+// enqueue ORDER too: a hipGraph captured around the forward submits its nodes in creation order, and a dependency on a node in
+// the middle of another stream's chain that is submitted late starts late (measured: a fork expressed only as an event
+// recorded here and waited for after the forward returned started 300 us late, at the first backward kernel).
+struct ForkHook { void (*fn)(void*) = nullptr; void* user = nullptr; };
+static std::map<std::pair<int, hipStream_t>, ForkHook> g_fork_hooks;
+extern "C" int sed_crnn_fork_callback(void* stream, void (*fn)(void*), void* user) {
+    int dev = 0;
+    SED_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    ForkHook& h = g_fork_hooks[std::make_pair(dev, (hipStream_t)stream)];
+    h.fn = fn;
+    h.user = user;
+    return SED_OK;
+}
+int sed_fork_point(hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return SED_OK;
+    ForkHook h;
+    {
+        std::lock_guard<std::mutex> lk(g_side_mu);
+        auto it = g_fork_hooks.find(std::make_pair(dev, st));
+        if (it == g_fork_hooks.end()) return SED_OK;
+        h = it->second;
+        it->second = ForkHook();
+    }
+    if (h.fn) h.fn(h.user);
+    return SED_OK;
+}
 #define SIDE_FORK(main_st)                                          \
     do {                                                            \
         SED_CHECK_HIP(hipEventRecord(sd.fork, (main_st)));          \
@@ -290,6 +322,7 @@ extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* b
         in = CTXF(po[i]);
     }
     // ---- BiGRU ----------------------------------------------------------------------------------
+    SED_TRY(sed_fork_point(st));
     int nin = 64;
     for (int l = 0; l < g.L; ++l) {
         // the input projection x W_ih^T + b_ih runs inside the recurrence kernel (gi only exists in LDS)

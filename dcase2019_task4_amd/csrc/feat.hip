@@ -52,6 +52,51 @@ __global__ void k_feat_tables(double2* __restrict__ tw, double* __restrict__ win
     }
 }
 
+// Second table pass (one workgroup), for the persistent kernel's mel projection: bands are served 16 at a time (4 lanes per
+// band, lane q takes bins lo + q + 4 j), every band of a 16-band pass padded with zero weights to the pass's trip count
+// (a multiple of 4), so that the whole wave runs the same fully unrolled chunks with no predicate.
+//   band[2 n_mels + p]      offset of pass p's weights in melw, laid out [trip j][lane = 4 (m - 16 p) + q]: lane t of the
+//                           wave reads melw[off + 64 j + t] - consecutive addresses, no bank conflict (band-major rows of
+//                           4 * trips floats put all 16 bands of a pass on the same banks: 16-way conflicts, measured)
+//   band[3 n_mels]          total padded size (0: does not fit -> the kernel walks the dense basis)
+//   band[3 n_mels + 1 + p]  trips of pass p
+__global__ __launch_bounds__(256) void k_feat_pack(const float* __restrict__ mel_basis, int n_mels, int* __restrict__ band,
+                                                    float* __restrict__ melw, int cap) {
+    __shared__ int s_total;
+    const int n_pass = (n_mels + 15) / 16;
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int p = 0; p < n_pass; ++p) {
+            int w = 0;
+            for (int m = 16 * p; m < min(n_mels, 16 * p + 16); ++m) w = max(w, band[2 * m + 1] - band[2 * m]);
+            const int trips = ((w + 3) / 4 + 3) & ~3;
+            band[3 * n_mels + 1 + p] = trips;
+            band[2 * n_mels + p] = acc;
+            acc += 64 * trips;
+            // the kernel reads magnitudes at lo + q + 4 j without a clamp: the padded trips must stay inside the wave's buffer
+            for (int m = 16 * p; m < min(n_mels, 16 * p + 16); ++m)
+                if (band[2 * m] + 3 + 4 * (trips - 1) >= 1056) acc = cap + 1;
+        }
+        if (acc > cap || n_mels > 64) acc = 0;
+        band[3 * n_mels] = acc;
+        s_total = acc;
+    }
+    __syncthreads();
+    if (s_total == 0) return;
+    for (int p = 0; p < n_pass; ++p) {
+        const int off = band[2 * n_mels + p], n = 64 * band[3 * n_mels + 1 + p];
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int j = i >> 6, m = 16 * p + ((i & 63) >> 2), q = i & 3;
+            float w = 0.f;
+            if (m < n_mels) {
+                const int k = band[2 * m] + q + 4 * j;
+                if (k < band[2 * m + 1]) w = mel_basis[(size_t)m * (NH + 1) + k];
+            }
+            melw[off + i] = w;
+        }
+    }
+}
+
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
 __global__ __launch_bounds__(256) void k_stft_mel(const float* __restrict__ wave, int n_samples, int hop, int frames,
@@ -279,13 +324,340 @@ __global__ __launch_bounds__(64) void k_stft_mel16(const float* __restrict__ wav
     TSC(6);
 }
 
+// ---- round 4: persistent STFT, tables resident in LDS ------------------------------------------------------------------------
+// k_stft_mel16 launches one 64-thread workgroup per frame: 40 192 waves for a batch of 64 clips, each of which re-fetches its
+// 32 window values, 47 twiddles and ~50 filterbank weights from global memory (shader-clock stamps: 13.5 k of the 21 k cycles
+// of a frame are those table walks at 1.5 waves per SIMD), and - worse - fills every CU's LDS for 350 us, so that a recurrence
+// kernel of the train step launched beside it waits for workgroup slots (k_gru4_bwd 43 -> 368 us).
+// k_stft_mel_p is a PERSISTENT kernel on a fixed number of workgroups (one per CU by its LDS footprint; the launcher caps the
+// grid, so the rest of the chip stays free for whatever else is running): 8 waves per workgroup, every wave walks its own
+// sequence of frames with no workgroup barrier after the table fill.
+//   * window, stage-A twiddles W_1024^(t k1), stage-B twiddles W_64^(m2 j1), unpack twiddles and the band-compressed
+//     filterbank live in LDS in the order the lanes read them (conflict-free ds_read_b64 / b128);
+//   * the next frame's 32 samples per lane are requested before the current frame's arithmetic starts;
+//   * the three exchanges move the real and the imaginary halves one after the other through ONE 8.4 KB buffer per wave
+//     (8 waves x 17 KB of complex buffers would not fit beside the tables); the third exchange only fetches the mirror
+//     half Z[1024 - k]: after stage B2 lane t already holds Z[t + 64 n], so every lane unpacks the PAIR (k, 1024 - k) from one
+//     (e, W^k o) product - half the unpack arithmetic of k_stft_mel16;
+//   * same fp64 arithmetic, same operation order per output as k_stft_mel16 (parity with the oracle unchanged at 2e-6).
+// Layout checks (8-byte elements; ds_read_b64: the 32 lanes of a half wave on distinct (a/8) mod 32, ds_write_b64: 16
+// contiguous lanes on distinct (a/8) mod 16): exchange 1 rows of 66 (reader lanes (k1, m2): 2 k1 + m2), exchange 2 dense
+// [m2][j1][k1] (reader lanes (k1, c): k1 + 16 c), exchange 3 [n - 8][t] read back at 64 - t.
+#ifndef STP_WAVES
+#define STP_WAVES 12
+#endif
+#define STP_THREADS (64 * STP_WAVES)
+#define STP_XB 1056            // 8-byte elements per wave: 16 x 66 (exchange 1) >= 1025 magnitudes
+#define STP_MELW 3584          // padded band-compressed filterbank weights held in LDS (64 Slaney bands over 1025 bins: 3 328)
+#define STP_MELS 128           // bands whose support table fits
+
+// The kernel is written once for two arithmetic types:
+//   R = double  the reference's arithmetic (librosa runs the STFT in float64): parity with the oracle at 2e-6
+//   R = float   SED_FFT_F32, a STATED mode like sed_dims.dtype: fp32 butterflies (twiddles and window still generated in
+//               float64 and rounded once), twice the lanes per instruction through the packed-fp32 pipe, complex values as one
+//               8-byte LDS element (no real / imaginary split).  Error bound asserted in tests/test_gpu_features.py.
+template <typename R> struct cx { R x, y; };
+template <typename R> __device__ __forceinline__ cx<R> cxmul(cx<R> a, cx<R> b) { return cx<R>{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+template <typename R> __device__ __forceinline__ void tdft4(cx<R>& a, cx<R>& b, cx<R>& c, cx<R>& d) {
+    const cx<R> s02 = {a.x + c.x, a.y + c.y}, d02 = {a.x - c.x, a.y - c.y};
+    const cx<R> s13 = {b.x + d.x, b.y + d.y}, d13 = {b.x - d.x, b.y - d.y};
+    a = cx<R>{s02.x + s13.x, s02.y + s13.y};
+    c = cx<R>{s02.x - s13.x, s02.y - s13.y};
+    b = cx<R>{d02.x + d13.y, d02.y - d13.x};
+    d = cx<R>{d02.x - d13.y, d02.y + d13.x};
+}
+// forward 16-point DFT in place; afterwards X[k] sits in v[DFT16_AT(k)] (same schedule as dft16 above)
+template <typename R> __device__ __forceinline__ void tdft16(cx<R> (&v)[16]) {
+    constexpr R C8 = (R)0.92387953251128673848, S8 = (R)0.38268343236508978178, R2 = (R)0.70710678118654752440;
+#pragma unroll
+    for (int n0 = 0; n0 < 4; ++n0) tdft4(v[n0], v[n0 + 4], v[n0 + 8], v[n0 + 12]);
+    v[1 + 4] = cxmul(v[1 + 4], cx<R>{C8, -S8});
+    v[1 + 8] = cxmul(v[1 + 8], cx<R>{R2, -R2});
+    v[1 + 12] = cxmul(v[1 + 12], cx<R>{S8, -C8});
+    v[2 + 4] = cxmul(v[2 + 4], cx<R>{R2, -R2});
+    v[2 + 8] = cx<R>{v[2 + 8].y, -v[2 + 8].x};
+    v[2 + 12] = cxmul(v[2 + 12], cx<R>{-R2, -R2});
+    v[3 + 4] = cxmul(v[3 + 4], cx<R>{S8, -C8});
+    v[3 + 8] = cxmul(v[3 + 8], cx<R>{-R2, -R2});
+    v[3 + 12] = cxmul(v[3 + 12], cx<R>{-C8, S8});
+#pragma unroll
+    for (int k0 = 0; k0 < 4; ++k0) tdft4(v[4 * k0], v[4 * k0 + 1], v[4 * k0 + 2], v[4 * k0 + 3]);
+}
+// sqrt for the magnitudes.  fp64: v_rsq_f64 (~2^-23) and ONE Goldschmidt step -> ~2^-45 relative, five instructions instead of
+// the ~17 of the correctly rounded sqrt(); the result is summed with fp32 weights and rounded to fp32.  fp32: v_sqrt_f32 (1 ulp).
+__device__ __forceinline__ double stp_sqrt(double x) {
+    x = fmax(x, 1e-280);
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    return fma(g, r, g);
+}
+__device__ __forceinline__ float stp_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+// xor-1 / xor-2 butterflies inside a quad on the VALU (DPP quad_perm) - __shfl_xor goes through ds_bpermute, one LDS round trip each
+__device__ __forceinline__ float quad_xor(float v, int which) {
+    const int i = __float_as_int(v);
+    return __int_as_float(which == 1 ? __builtin_amdgcn_mov_dpp(i, 0xB1, 0xF, 0xF, true) : __builtin_amdgcn_mov_dpp(i, 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ double quad_xor(double v, int which) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if (which == 1) { lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true); }
+    else { lo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true); }
+    return __hiloint2double(hi, lo);
+}
+
+template <typename R> struct StpLds {
+    R win[NFFT];
+    cx<R> twA[15 * 64];
+    cx<R> twU[8 * 64];
+    cx<R> twB[64];
+    float melw[STP_MELW];
+    int lo[STP_MELS], off[STP_MELS / 16], trips[STP_MELS / 16];
+    double xb[STP_WAVES][STP_XB];                       // 8-byte elements: doubles (fp64: split exchanges) or complex floats
+};
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS operations of one wave execute in issue order; this only stops the compiler from moving them across the exchange
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+struct __attribute__((packed, aligned(4))) f32pair { float a, b; };
+
+__device__ __forceinline__ void stp_load_frame(const float* __restrict__ w, int n_samples, int base, int t, float (&s)[32]) {
+    if (base >= 0 && base + NFFT <= n_samples) {          // wave-uniform: no reflection in this frame
+        const float* p = w + base + 2 * t;
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            const f32pair v = *(const f32pair*)(p + 128 * n1);
+            s[2 * n1] = v.a; s[2 * n1 + 1] = v.b;
+        }
+    } else {
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int idx = base + 128 * n1 + 2 * t + h;
+                if (idx < 0) idx = -idx;
+                if (idx >= n_samples) idx = 2 * (n_samples - 1) - idx;
+                s[2 * n1 + h] = w[idx];
+            }
+        }
+    }
+}
+
+// One 16-value exchange through the wave's buffer: lane writes src[i] at wi(i), reads dst[i] from ri(i).
+template <typename R, typename FW, typename FR>
+__device__ __forceinline__ void stp_exchange16(double* xb, const cx<R> (&src)[16], cx<R> (&dst)[16], FW wi, FR ri) {
+    if constexpr (sizeof(R) == 8) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xb[wi(i)] = src[i].x;
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dst[i].x = xb[ri(i)];
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xb[wi(i)] = src[i].y;
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dst[i].y = xb[ri(i)];
+        wave_lds_sync();
+    } else {
+        cx<R>* xc = reinterpret_cast<cx<R>*>(xb);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xc[wi(i)] = src[i];
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dst[i] = xc[ri(i)];
+        wave_lds_sync();
+    }
+}
+
+template <typename R>
+__global__ __launch_bounds__(STP_THREADS) void k_stft_mel_p(const float* __restrict__ wave, int n_clips, int n_samples, int hop,
+                                                             int frames, const double2* __restrict__ tw,
+                                                             const double* __restrict__ win, const float* __restrict__ mel_basis,
+                                                             const int* __restrict__ band, const float* __restrict__ melw_g,
+                                                             int n_mels, float* __restrict__ mel) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char stp_raw[];
+    StpLds<R>& L = *reinterpret_cast<StpLds<R>*>(stp_raw);
+    typedef cx<R> C;
+    const int tid = threadIdx.x, t = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);    // (wave-uniform: scalar registers)
+    const int n_total = n_clips * frames, n_wv = gridDim.x * STP_WAVES;
+    // (clip, frame) of this wave's current frame, advanced without a division per frame (all wave-uniform)
+    int g = blockIdx.x * STP_WAVES + wv;
+    int clip = g / frames, f = g - clip * frames;
+    const int dq = n_wv / frames, dr = n_wv - dq * frames;
+    float s[32];
+    if (g < n_total) stp_load_frame(wave + (size_t)clip * n_samples, n_samples, f * hop - NFFT / 2, t, s);   // in flight while the tables are filled
+    // ---- tables -> LDS (once per workgroup) ------------------------------------------------------------------------------------
+    const int nnz = band[3 * n_mels];                                             // padded size; 0: no LDS table
+    const bool w_in_lds = n_mels <= 64 && nnz > 0 && nnz <= STP_MELW;
+    for (int i = tid; i < NFFT; i += STP_THREADS) L.win[i] = (R)win[i];
+    for (int i = tid; i < 15 * 64; i += STP_THREADS) {
+        const int k1 = 1 + (i >> 6), tt = i & 63;
+        const double2 v = tw[(2 * tt * k1) & (NFFT - 1)];                         // W_1024^(t k1) = W_2048^(2 t k1)
+        L.twA[i] = C{(R)v.x, (R)v.y};
+    }
+    for (int i = tid; i < 8 * 64; i += STP_THREADS) { const double2 v = tw[i]; L.twU[i] = C{(R)v.x, (R)v.y}; }     // W_2048^k, k = t + 64 n
+    if (tid < 64) { const double2 v = tw[(32 * (tid >> 4) * (tid & 15)) & (NFFT - 1)]; L.twB[tid] = C{(R)v.x, (R)v.y}; }   // W_64^(m2 j1)
+    if (w_in_lds) {
+        for (int i = tid; i < n_mels; i += STP_THREADS) L.lo[i] = band[2 * i];
+        if (tid < (n_mels + 15) / 16) { L.trips[tid] = band[3 * n_mels + 1 + tid]; L.off[tid] = band[2 * n_mels + tid]; }
+        for (int i = tid; i < nnz; i += STP_THREADS) L.melw[i] = melw_g[i];
+    }
+    __syncthreads();
+    double* xb = L.xb[wv];
+    const int k1l = t & 15, m2 = t >> 4, q = t & 3;
+    // mel pass parameters are frame-invariant: trips and offsets in scalar registers; the support start of this lane's band is
+    // re-read from LDS per pass (four more live registers across the FFT cost the fp64 kernel its third wave per SIMD)
+    int mtr[4], moff[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        mtr[p] = __builtin_amdgcn_readfirstlane((w_in_lds && 16 * p < n_mels) ? L.trips[p] : 0);
+        moff[p] = __builtin_amdgcn_readfirstlane((w_in_lds && 16 * p < n_mels) ? L.off[p] : 0);
+    }
+    TSC(0);
+    while (g < n_total) {
+        C v[16];
+        // ---- windowed frame: z[m] = x[2m] + i x[2m + 1], m = 64 n1 + t ---------------------------------------------------------------
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            const C wn = *reinterpret_cast<const C*>(&L.win[128 * n1 + 2 * t]);
+            v[n1] = C{(R)s[2 * n1] * wn.x, (R)s[2 * n1 + 1] * wn.y};
+        }
+        const int row_cur = clip * frames + f;
+        g += n_wv; clip += dq; f += dr;
+        if (f >= frames) { f -= frames; ++clip; }
+        TSC(1);
+        // ---- A: 16-point DFT over n1, twiddle, exchange 1 ([k1][t], rows of 66) ----------------------------------------------------------
+        tdft16(v);
+        {
+            C a[16];
+            a[0] = v[DFT16_AT(0)];
+#pragma unroll
+            for (int k1 = 1; k1 < 16; ++k1) a[k1] = cxmul(v[DFT16_AT(k1)], L.twA[(k1 - 1) * 64 + t]);
+            stp_exchange16<R>(xb, a, v, [&](int k1) { return k1 * 66 + t; }, [&](int m1) { return k1l * 66 + 4 * m1 + m2; });
+        }
+        TSC(2);
+        // ---- B1: thread (k1, m2): 16-point DFT over m1, twiddle W_64^(m2 j1), exchange 2 ([m2][j1][k1]) ---------------------------------
+        tdft16(v);
+        C x4[16];                                                               // x4[4 i + q'] = B1 output (k1, j1 = m2 + 4 i, m2' = q')
+        {
+            C b[16];
+            b[0] = v[DFT16_AT(0)];
+#pragma unroll
+            for (int j1 = 1; j1 < 16; ++j1) b[j1] = cxmul(v[DFT16_AT(j1)], L.twB[m2 * 16 + j1]);
+            stp_exchange16<R>(xb, b, x4, [&](int j1) { return 256 * m2 + 16 * j1 + k1l; },
+                              [&](int e) { return 256 * (e & 3) + 16 * (m2 + 4 * (e >> 2)) + k1l; });
+        }
+        // ---- B2: 4-point DFT over m2: x4[4 i + j2] = Z[t + 64 (i + 4 j2)] -----------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tdft4(x4[4 * i], x4[4 * i + 1], x4[4 * i + 2], x4[4 * i + 3]);
+        TSC(3);
+        // ---- exchange 3: the mirror half.  Z[1024 - (t + 64 n)], n = 0..7, sits in lane (64 - t) & 63 as its n' = 15 - n (16 - n for t = 0)
+#define STP_Z(n) x4[4 * ((n) & 3) + ((n) >> 2)]
+        C zm[8];
+        if constexpr (sizeof(R) == 8) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                for (int n = 8; n < 16; ++n) xb[(n - 8) * 64 + t] = c ? STP_Z(n).y : STP_Z(n).x;
+                if (t == 0) xb[512] = c ? STP_Z(0).y : STP_Z(0).x;                // Z[1024] = Z[0]
+                wave_lds_sync();
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    const double r = xb[(7 - n) * 64 + 64 - t];
+                    if (c) zm[n].y = r; else zm[n].x = r;
+                }
+                wave_lds_sync();
+            }
+        } else {
+            C* xc = reinterpret_cast<C*>(xb);
+#pragma unroll
+            for (int n = 8; n < 16; ++n) xc[(n - 8) * 64 + t] = STP_Z(n);
+            if (t == 0) xc[512] = STP_Z(0);
+            wave_lds_sync();
+#pragma unroll
+            for (int n = 0; n < 8; ++n) zm[n] = xc[(7 - n) * 64 + 64 - t];
+            wave_lds_sync();
+        }
+        TSC(4);
+        // ---- real-FFT unpack of the pair (k, 1024 - k), k = t + 64 n: X[k] = e - i W^k o, X[1024 - k] = conj(e) - i conj(W^k o) -------------
+        // (the 0.5 of e and o is left out: every magnitude comes out doubled, the band sums are halved at the end - exact)
+        // (the mirror values are in registers: the magnitudes can overwrite the exchange buffer pair by pair)
+        R* mag = reinterpret_cast<R*>(xb);
+        R* mag_m = mag + (576 - t);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const C Zk = STP_Z(n);
+            const C Zc = {zm[n].x, -zm[n].y};
+            const C e = {Zk.x + Zc.x, Zk.y + Zc.y};
+            const C o = {Zk.x - Zc.x, Zk.y - Zc.y};
+            const C tt = cxmul(L.twU[n * 64 + t], o);
+            const R re = e.x + tt.y, im = e.y - tt.x;
+            const R rm = e.x - tt.y, imm = e.y + tt.x;                          // (|.| of the conjugate partner: sign of im irrelevant)
+            mag[n * 64 + t] = stp_sqrt(re * re + im * im);
+            mag_m[(7 - n) * 64] = stp_sqrt(rm * rm + imm * imm);                 // mag[1024 - 64 n - t] (one base, offsets >= 0)
+        }
+        const C Zh = STP_Z(8);                                                  // lane 0: Z[512]; |X[512]| = |Z[512]|
+        if (t == 0) mag[512] = (R)2 * stp_sqrt(Zh.x * Zh.x + Zh.y * Zh.y);
+#undef STP_Z
+        wave_lds_sync();
+        // the next frame's samples are requested here: the FFT's registers are free from this point on (held across the
+        // exchanges, the 32 values cost a third wave per SIMD), and the projection below covers most of their latency
+        if (g < n_total) stp_load_frame(wave + (size_t)clip * n_samples, n_samples, f * hop - NFFT / 2, t, s);
+        TSC(5);
+        // ---- mel projection: lane = (band 16 p + t / 4, quarter q) in pass p; bins lo + q + 4 j, zero-padded weights [j][lane] ---------------
+        float* outp = mel + (size_t)row_cur * n_mels;
+        if (w_in_lds) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                R acc = (R)0;
+                const int m_p = 16 * p + (t >> 2);
+                const R* mp = mag + (m_p < n_mels ? L.lo[m_p] + q : 0);
+                const float* wp = L.melw + moff[p] + t;
+                for (int j0 = 0; j0 < mtr[p]; j0 += 4) {                        // (trips: multiples of 4, wave-uniform)
+                    float wvv[4]; R mv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { wvv[i] = wp[64 * i]; mv[i] = mp[4 * i]; }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc += (R)wvv[i] * mv[i];
+                    mp += 16; wp += 256;
+                }
+                acc += quad_xor(acc, 1);
+                acc += quad_xor(acc, 2);
+                if (q == 0 && m_p < n_mels) outp[m_p] = (float)((R)0.5 * acc);
+            }
+        } else {                                                                // general basis: walk the dense rows (supports from `band`)
+            for (int m0 = 0; m0 < n_mels; m0 += 16) {
+                const int m = m0 + (t >> 2);
+                R sacc = (R)0;
+                if (m < n_mels) {
+                    const float* row = mel_basis + (size_t)m * (NH + 1);
+                    const int lo = band[2 * m], hi = band[2 * m + 1];
+                    for (int k = lo + q; k < hi; k += 4) sacc += (R)row[k] * mag[k];
+                }
+                sacc += quad_xor(sacc, 1);
+                sacc += quad_xor(sacc, 2);
+                if (q == 0 && m < n_mels) outp[m] = (float)((R)0.5 * sacc);
+            }
+        }
+        wave_lds_sync();                                                        // the magnitudes are read before the next frame's exchange 1 overwrites them
+        TSC(6);
+    }
+}
+
 // ---- log / noise / pad / normalise ----------------------------------------------------------------
-__device__ __forceinline__ double teacher_noise(uint32_t e_global, uint64_t seed) {
-    const u32x4 o = philox4x32_10(e_global >> 1, 0u, 16u, PHILOX_TAG, (uint32_t)seed, (uint32_t)(seed >> 32));
-    const uint32_t w0 = (e_global & 1) ? o.z : o.x, w1 = (e_global & 1) ? o.w : o.y;
-    const double u1 = ((double)w0 + 1.0) * 2.3283064365386963e-10, u2 = (double)w1 * 2.3283064365386963e-10;
-    const double g = sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
-    return (double)(float)fabs(0.25 * g);
+// |N(0, 0.25)| for the element PAIR (2 i, 2 i + 1) of the flattened [clip][frame][mel] tensor: one Philox4x32-10 draw (counter i,
+// stream 16), one Box-Muller transform - both of its outputs are used (r cos, r sin: two independent normals), so a pair
+// costs one Philox, one log, one sqrt and one sincospi in fp64 (round 3 drew and transformed once per ELEMENT and used half of
+// each draw).  Mirrored bit for bit by oracle/philox.py teacher_noise.
+__device__ __forceinline__ void teacher_noise_pair(uint32_t pair, uint64_t seed, double& n0, double& n1) {
+    const u32x4 o = philox4x32_10(pair, 0u, 16u, PHILOX_TAG, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const double u1 = ((double)o.x + 1.0) * 2.3283064365386963e-10, u2 = (double)o.y * 2.3283064365386963e-10;
+    const double r = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincospi(2.0 * u2, &sn, &cs);
+    n0 = (double)(float)fabs(0.25 * (r * cs));
+    n1 = (double)(float)fabs(0.25 * (r * sn));
 }
 __device__ __forceinline__ double amp_db(double a) {
     // librosa.amplitude_to_db(ref=1, amin=1e-5): 10 log10(max(amin^2, a^2)) - 10 log10(max(amin^2, 1))
@@ -310,15 +682,27 @@ __global__ __launch_bounds__(256) void k_logmel_max(const float* __restrict__ me
     const int n = frames * n_mels, n_keep = min(frames, max_frames) * n_mels;
     const float* src = mel + (size_t)clip * n;
     const uint64_t seed = out_noisy ? seed_ptr[0] : 0ull;
-    const int per = (n + LM_CHUNKS - 1) / LM_CHUNKS, e0 = chunk * per, e1 = min(n, e0 + per);
+    const int per = (((n + LM_CHUNKS - 1) / LM_CHUNKS) + 1) & ~1, e0 = chunk * per, e1 = min(n, e0 + per);   // even chunks: pairs never straddle
     double mc = 0.0, mn = 0.0;
-    for (int e = e0 + tid; e < e1; e += 256) {
-        const double a = (double)src[e];
-        mc = fmax(mc, fabs(a));
+    for (int e = e0 + 2 * tid; e < e1; e += 512) {       // (n = frames * n_mels; an odd n leaves a last single element)
+        const bool two = e + 1 < e1;
+        const double a0 = (double)src[e], a1 = two ? (double)src[e + 1] : 0.0;
+        mc = fmax(mc, fmax(fabs(a0), fabs(a1)));
         if (out_noisy) {
-            const double nz = teacher_noise((uint32_t)(clip * n + e), seed);
-            mn = fmax(mn, fabs(a + nz));
-            if (e < n_keep) out_noisy[(size_t)clip * max_frames * n_mels + e] = (float)nz;       // exact: nz is a float
+            double z0, z1;
+            teacher_noise_pair((uint32_t)(((size_t)clip * n + e) >> 1), seed, z0, z1);
+            if ((((size_t)clip * n + e) & 1) != 0) {      // odd clip size x odd clip index: the pair starts one element earlier
+                // (only reachable when n is odd; keep the definition element-wise exact)
+                double y0, y1;
+                teacher_noise_pair((uint32_t)((((size_t)clip * n + e) >> 1) + 1), seed, y0, y1);
+                z0 = z1; z1 = y0;
+            }
+            mn = fmax(mn, fabs(a0 + z0));
+            if (e < n_keep) out_noisy[(size_t)clip * max_frames * n_mels + e] = (float)z0;       // exact: the noise is a float
+            if (two) {
+                mn = fmax(mn, fabs(a1 + z1));
+                if (e + 1 < n_keep) out_noisy[(size_t)clip * max_frames * n_mels + e + 1] = (float)z1;
+            }
         }
     }
 #pragma unroll
@@ -362,37 +746,112 @@ __global__ __launch_bounds__(256) void k_logmel_apply(const float* __restrict__ 
     }
 }
 
+// workspace: W_2048 table | window | band supports (lo, hi) + offsets + total | compressed filterbank weights
+static size_t mel_ws_band_off() { return (size_t)NFFT * sizeof(double2) + (size_t)NFFT * sizeof(double); }
+static size_t mel_ws_w_off(int n_mels) { return mel_ws_band_off() + (((size_t)(3 * n_mels + 2 + (n_mels + 15) / 16) * sizeof(int) + 15) & ~(size_t)15); }
 extern "C" size_t sed_mel_spec_ws_bytes(int n_clips, int n_samples, int hop, int n_fft, int n_mels) {
-    (void)n_clips; (void)n_samples; (void)hop; (void)n_mels;
+    (void)n_clips; (void)n_samples; (void)hop;
     if (n_fft != NFFT) return 0;
-    return (size_t)NFFT * sizeof(double2) + (size_t)NFFT * sizeof(double) + (size_t)2 * (n_mels > 0 ? n_mels : 0) * sizeof(int);
+    return mel_ws_w_off(n_mels > 0 ? n_mels : 0) + (size_t)STP_MELW * sizeof(float);
+}
+
+static int mel_check(int n_fft, int n_mels, const void* mel_basis, const void* ws, size_t ws_bytes, const char* who) {
+    if (n_fft != NFFT) {
+        sed_set_error("%s: n_fft must be 2048 (config.py:18), got %d", who, n_fft);
+        return SED_ERR_UNSUPPORTED;
+    }
+    if (!mel_basis || !ws || n_mels < 1) {
+        sed_set_error("%s: null argument / n_mels < 1", who);
+        return SED_ERR_BAD_ARG;
+    }
+    if (ws_bytes < sed_mel_spec_ws_bytes(1, 0, 1, n_fft, n_mels)) {
+        sed_set_error("%s: workspace too small", who);
+        return SED_ERR_WORKSPACE;
+    }
+    return SED_OK;
+}
+
+extern "C" int sed_mel_tables(int n_fft, const float* window, const float* mel_basis, int n_mels, void* ws, size_t ws_bytes,
+                              void* stream) {
+    SED_TRY(mel_check(n_fft, n_mels, mel_basis, ws, ws_bytes, "sed_mel_tables"));
+    hipStream_t st = (hipStream_t)stream;
+    double2* tw = (double2*)ws;
+    double* win = (double*)((char*)ws + (size_t)NFFT * sizeof(double2));
+    int* band = (int*)((char*)ws + mel_ws_band_off());
+    float* melw = (float*)((char*)ws + mel_ws_w_off(n_mels));
+    const int tb = (NFFT > n_mels * 64 ? NFFT : n_mels * 64);
+    k_feat_tables<<<(tb + 255) / 256, 256, 0, st>>>(tw, win, window, mel_basis, n_mels, band);
+    SED_CHECK_LAUNCH();
+    k_feat_pack<<<1, 256, 0, st>>>(mel_basis, n_mels, band, melw, STP_MELW);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}
+
+static int stp_num_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cus[dev];
+}
+
+template <typename R>
+static int launch_stft_p(const float* wave, int n_clips, int n_samples, int hop, int frames, const double2* tw, const double* win,
+                         const float* mel_basis, const int* band, const float* melw, int n_mels, float* mel, int max_workgroups,
+                         hipStream_t st) {
+    static bool attr_done[64] = {false};
+    int dev = 0;
+    SED_CHECK_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_stft_mel_p<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(StpLds<R>)));
+        attr_done[dev] = true;
+    }
+    const long long n_total = (long long)n_clips * frames;
+    SED_CHECK_ARG(n_total < (1ll << 31), "sed_mel_frames: too many frames");
+    long long grid = (n_total + STP_WAVES - 1) / STP_WAVES;
+    const int cap = max_workgroups > 0 ? max_workgroups : stp_num_cus();        // one workgroup per CU (by LDS / registers); default: the whole chip
+    if (grid > cap) grid = cap;
+    k_stft_mel_p<R><<<(int)grid, STP_THREADS, sizeof(StpLds<R>), st>>>(wave, n_clips, n_samples, hop, frames, tw, win, mel_basis, band,
+                                                                      melw, n_mels, mel);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}
+
+extern "C" int sed_mel_frames(const float* wave, int n_clips, int n_samples, int hop, int n_fft, const float* mel_basis,
+                              int n_mels, float* mel, const void* ws, size_t ws_bytes, int fft_dtype, int max_workgroups,
+                              void* stream) {
+    SED_TRY(mel_check(n_fft, n_mels, mel_basis, ws, ws_bytes, "sed_mel_frames"));
+    SED_CHECK_ARG(wave && mel, "sed_mel_frames: null argument");
+    SED_CHECK_ARG(n_clips >= 1 && hop >= 1 && n_samples > NFFT / 2, "sed_mel_frames: bad sizes (reflect padding needs n_samples > n_fft/2)");
+    SED_CHECK_ARG(fft_dtype == SED_FFT_F64 || fft_dtype == SED_FFT_F32, "sed_mel_frames: fft_dtype must be SED_FFT_F64 or SED_FFT_F32");
+    hipStream_t st = (hipStream_t)stream;
+    const double2* tw = (const double2*)ws;
+    const double* win = (const double*)((const char*)ws + (size_t)NFFT * sizeof(double2));
+    const int* band = (const int*)((const char*)ws + mel_ws_band_off());
+    const float* melw = (const float*)((const char*)ws + mel_ws_w_off(n_mels));
+    const int frames = 1 + n_samples / hop;
+    // debug bit 19: round 2's kernel (one 256-thread workgroup per frame, five radix-4 passes through LDS); bit 21: round 3's
+    // (one wave per frame, tables walked in global memory) - both fp64, kept for A/B timing and as second implementations in the tests
+    if (g_sed_debug & 524288) {
+        k_stft_mel<<<dim3(frames, n_clips), 256, 0, st>>>(wave, n_samples, hop, frames, tw, win, mel_basis, band, n_mels, mel);
+    } else if (g_sed_debug & 2097152) {
+        k_stft_mel16<<<dim3(frames, n_clips), 64, 0, st>>>(wave, n_samples, hop, frames, tw, win, mel_basis, band, n_mels, mel);
+    } else if (fft_dtype == SED_FFT_F32) {
+        return launch_stft_p<float>(wave, n_clips, n_samples, hop, frames, tw, win, mel_basis, band, melw, n_mels, mel, max_workgroups, st);
+    } else {
+        return launch_stft_p<double>(wave, n_clips, n_samples, hop, frames, tw, win, mel_basis, band, melw, n_mels, mel, max_workgroups, st);
+    }
+    SED_CHECK_LAUNCH();
+    return SED_OK;
 }
 
 extern "C" int sed_mel_spec(const float* wave, int n_clips, int n_samples, int hop, int n_fft, const float* window,
                             const float* mel_basis, int n_mels, float* mel, void* ws, size_t ws_bytes, void* stream) {
-    SED_CHECK_ARG(wave && mel_basis && mel && ws, "sed_mel_spec: null argument");
-    if (n_fft != NFFT) {
-        sed_set_error("sed_mel_spec: n_fft must be 2048 (config.py:18), got %d", n_fft);
-        return SED_ERR_UNSUPPORTED;
-    }
-    SED_CHECK_ARG(n_clips >= 1 && hop >= 1 && n_mels >= 1 && n_samples > NFFT / 2, "sed_mel_spec: bad sizes (reflect padding needs n_samples > n_fft/2)");
-    if (ws_bytes < sed_mel_spec_ws_bytes(n_clips, n_samples, hop, n_fft, n_mels)) {
-        sed_set_error("sed_mel_spec: workspace too small");
-        return SED_ERR_WORKSPACE;
-    }
-    hipStream_t st = (hipStream_t)stream;
-    double2* tw = (double2*)ws;
-    double* win = (double*)((char*)ws + (size_t)NFFT * sizeof(double2));
-    int* band = (int*)((char*)ws + (size_t)NFFT * sizeof(double2) + (size_t)NFFT * sizeof(double));
-    const int tb = (NFFT > n_mels * 64 ? NFFT : n_mels * 64);
-    k_feat_tables<<<(tb + 255) / 256, 256, 0, st>>>(tw, win, window, mel_basis, n_mels, band);
-    SED_CHECK_LAUNCH();
-    const int frames = 1 + n_samples / hop;
-    // (debug bit 19: the round-2 kernel - one 256-thread workgroup per frame, five radix-4 passes through LDS - for A/B timing)
-    if (g_sed_debug & 524288) k_stft_mel<<<dim3(frames, n_clips), 256, 0, st>>>(wave, n_samples, hop, frames, tw, win, mel_basis, band, n_mels, mel);
-    else k_stft_mel16<<<dim3(frames, n_clips), 64, 0, st>>>(wave, n_samples, hop, frames, tw, win, mel_basis, band, n_mels, mel);
-    SED_CHECK_LAUNCH();
-    return SED_OK;
+    SED_TRY(sed_mel_tables(n_fft, window, mel_basis, n_mels, ws, ws_bytes, stream));
+    return sed_mel_frames(wave, n_clips, n_samples, hop, n_fft, mel_basis, n_mels, mel, ws, ws_bytes, SED_FFT_F64, 0, stream);
 }
 
 // The front-end's own noise-key chain: key += golden-ratio stride, one thread.  Lets a caller that computes the NEXT batch's

@@ -254,6 +254,7 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
                                 use_drop, g.p, seed_dev, use_drop ? CTXM(L.mask[i]) : nullptr, st));
     }
     // ---- BiGRU ----------------------------------------------------------------------------------------------------------
+    SED_TRY(sed_fork_point(st));
     const float* in = CTXF(L.p[2]);
     int nin = C;
     const int BT = g.B * g.T3;

@@ -188,6 +188,9 @@ int launch_gemm_batch(GemmBatch& gb, hipStream_t st);
 int launch_colsum(const float* A, int M, int N, int64_t lda, float* out, hipStream_t st);
 
 // gru.hip
+// crnn.hip: runs the host callback registered by sed_crnn_fork_callback (if any) for st - called by both forwards between the conv
+// stack and the recurrence
+int sed_fork_point(hipStream_t st);
 int launch_gru_fwd(const float* x, int nin, const float* w_ih_f, const float* w_ih_r, const float* b_ih_f, const float* b_ih_r,
                    const float* w_hh_f, const float* w_hh_r, const float* b_hh_f, const float* b_hh_r, float* out, float* gates,
                    int B, int T, hipStream_t st);

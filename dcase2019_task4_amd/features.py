@@ -79,8 +79,11 @@ def mel_filterbank(sr, n_fft, n_mels, fmin, fmax):
 class FeatureExtractor:
     """GPU feature extractor with the reference's calculate_mel_spec call signature."""
 
-    def __init__(self, cfg=None, device="cuda", save_log_feature=False):
+    def __init__(self, cfg=None, device="cuda", save_log_feature=False, fft_dtype="f64"):
         self.cfg = cfg or FeatureConfig()
+        if fft_dtype not in _lib.FFT_DTYPES:
+            raise ValueError(f"fft_dtype must be one of {sorted(_lib.FFT_DTYPES)}")
+        self.fft_dtype = fft_dtype
         if self.cfg.n_window != 2048:
             raise NotImplementedError("hot path implements n_window = 2048 (config.py:18)")
         if save_log_feature:
@@ -92,13 +95,28 @@ class FeatureExtractor:
         c = self.cfg
         self.mel_basis = torch.tensor(mel_filterbank(c.sample_rate, c.n_window, c.n_mels, c.f_min, c.f_max), device=self.device)
         self.window = torch.tensor(np.hamming(c.n_window).astype(np.float32), device=self.device)
-        self._ws = None
+        self._tables = {}
 
     def n_frames(self, n_samples):
         return 1 + n_samples // self.cfg.hop_length
 
-    def calculate_mel_spec_batch(self, waves, exact_window=True):
-        """waves: float tensor [n_clips, n_samples] (any device) -> float32 cuda [n_clips, frames, n_mels]."""
+    def tables(self, exact_window=True):
+        """The (window, mel_basis)-dependent tables of the STFT kernel, built once per extractor (sed_mel_tables) - the
+        reference builds np.hamming / librosa.filters.mel once per call of calculate_mel_spec, on the host."""
+        ws = self._tables.get(bool(exact_window))
+        if ws is None:
+            l = _lib.lib()
+            c = self.cfg
+            ws = torch.empty(l.sed_mel_spec_ws_bytes(1, 0, c.hop_length, c.n_window, c.n_mels), device=self.device, dtype=torch.uint8)
+            # window=None -> the kernel builds np.hamming(2048) itself in float64 (what librosa multiplies by)
+            _lib.check(l.sed_mel_tables(c.n_window, None if exact_window else _lib.ptr(self.window), _lib.ptr(self.mel_basis),
+                                        c.n_mels, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "sed_mel_tables")
+            self._tables[bool(exact_window)] = ws
+        return ws
+
+    def calculate_mel_spec_batch(self, waves, exact_window=True, workgroups=0, fft_dtype=None):
+        """waves: float tensor [n_clips, n_samples] (any device) -> float32 cuda [n_clips, frames, n_mels].
+        ``fft_dtype``: "f64" (the reference's arithmetic, default) or "f32" (stated reduced-precision mode, SED_FFT_F32)."""
         l = _lib.lib()
         c = self.cfg
         waves = torch.as_tensor(waves).to(self.device, torch.float32).contiguous()
@@ -106,14 +124,11 @@ class FeatureExtractor:
             waves = waves[None]
         n, ns = waves.shape
         frames = self.n_frames(ns)
-        need = l.sed_mel_spec_ws_bytes(n, ns, c.hop_length, c.n_window, c.n_mels)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, device=self.device, dtype=torch.uint8)
+        ws = self.tables(exact_window)
         out = torch.empty(n, frames, c.n_mels, device=self.device, dtype=torch.float32)
-        # window=None -> the kernel builds np.hamming(2048) itself in float64 (what librosa multiplies by)
-        _lib.check(l.sed_mel_spec(_lib.ptr(waves), n, ns, c.hop_length, c.n_window,
-                                  None if exact_window else _lib.ptr(self.window), _lib.ptr(self.mel_basis), c.n_mels,
-                                  _lib.ptr(out), _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr()), "sed_mel_spec")
+        _lib.check(l.sed_mel_frames(_lib.ptr(waves), n, ns, c.hop_length, c.n_window, _lib.ptr(self.mel_basis), c.n_mels,
+                                    _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.FFT_DTYPES[fft_dtype or self.fft_dtype],
+                                    int(workgroups), _lib.stream_ptr()), "sed_mel_frames")
         return out
 
     def calculate_mel_spec(self, audio):
@@ -261,22 +276,29 @@ class LogMelTransform:
 
 
 class WaveformFrontEnd:
-    """BASELINE.json configs[2]: the mean-teacher step fed from raw waveforms resident in HBM.  One ``run()`` =
-    calculate_mel_spec for the whole batch (sed_mel_spec) -> the train-time transform chain with the teacher's noisy copy
-    (sed_logmel_transform, utils.py:397-412 with augment_type="noise") -> the step.  Persistent buffers, no allocation
-    and no host value inside ``run``; the noise key is a device word of the front-end's own, advanced in stream order.
+    """BASELINE.json configs[2]: the mean-teacher step fed from raw waveforms resident in HBM.  Feature extraction =
+    calculate_mel_spec for the whole batch (sed_mel_frames) -> the train-time transform chain with the teacher's noisy copy
+    (sed_logmel_transform, utils.py:397-412 with augment_type="noise").  Persistent buffers, no allocation and no host
+    value on the hot path; the noise key is a device word of the front-end's own, advanced in stream order.
 
-    ``overlap=True`` (default, single-process graph mode): the features depend on no weight, so they are computed ONE
-    BATCH AHEAD - the way the reference's DataLoader workers prepare batch k + 1 while the model trains on batch k
-    (DataLoad.py:47-186 behind torch's DataLoader, main.py:238-247).  ``run()`` replays one hipGraph in which a side
-    stream turns the waveforms currently in ``self.waves`` into the OTHER input buffer pair while the main stream runs
-    the train step on the pair filled during the previous ``run()``; the two pairs alternate.  The first call fills the
-    first pair synchronously.  A caller streaming real data refreshes ``self.waves`` (``load_waves``) between calls."""
+    The features depend on no weight, so they are computed ONE BATCH AHEAD - the way the reference's DataLoader workers
+    prepare batch k + 1 while the model trains on batch k (DataLoad.py:47-186 behind torch's DataLoader,
+    main.py:238-247).  There are two slots of (x, x_ema, target); ``run()`` trains on the slot extracted last and extracts the
+    staged waveforms (``load_batch``) into the other slot, target travelling with its features.  With ``overlap=True``
+    (default; needs a step that replays ONE hipGraph per step: single process, or data-parallel with captured
+    collectives) the extraction is part of that graph: the student forward calls back between its conv stack and its
+    recurrence (sed_crnn_fork_callback), and a second stream forked there runs the persistent STFT kernel on ``fe_workgroups`` CUs from
+    there - beside the BiGRU / heads forward and backward, which occupy one workgroup per (clip, direction) and cannot
+    share a CU with an STFT workgroup (registers + LDS), so neither delays the other.  Without overlap the same protocol
+    runs serially (train, then extract).
 
-    def __init__(self, step, waves, cfg=None, scaler=None, overlap=True, seed=0):
+    Streaming real data:  ``feed(waves, target)`` per batch and ``flush()`` at the end train on every batch exactly once, in
+    order, in both modes (bit-identical results: tests/test_gpu_features.py).  Resident / constant data (bench.py): ``run()``."""
+
+    def __init__(self, step, waves, cfg=None, scaler=None, overlap=True, seed=0, fe_workgroups=None, fft_dtype="f64"):
         self.step = step
         self.l = _lib.lib()
-        self.fx = FeatureExtractor(cfg or FeatureConfig.baseline_16k(), device=step.device)
+        self.fx = FeatureExtractor(cfg or FeatureConfig.baseline_16k(), device=step.device, fft_dtype=fft_dtype)
         c = self.fx.cfg
         self.waves = torch.as_tensor(waves).to(step.device, torch.float32).contiguous()
         n, ns = self.waves.shape
@@ -284,8 +306,7 @@ class WaveformFrontEnd:
             raise ValueError(f"{n} waveforms for a step of batch {step.B}")
         self.n, self.ns, self.frames = n, ns, self.fx.n_frames(ns)
         self.mel = torch.empty(n, self.frames, c.n_mels, device=step.device, dtype=torch.float32)
-        self.ws = torch.empty(self.l.sed_mel_spec_ws_bytes(n, ns, c.hop_length, c.n_window, c.n_mels), device=step.device,
-                              dtype=torch.uint8)
+        self.ws = self.fx.tables(exact_window=True)
         self.ws_t = torch.empty(self.l.sed_logmel_transform_ws_bytes(n), device=step.device, dtype=torch.uint8)
         self.mean = self.std = None
         if scaler is not None:
@@ -293,87 +314,168 @@ class WaveformFrontEnd:
             self.std = torch.tensor(np.asarray(scaler.std_), dtype=torch.float64, device=step.device)
         self.key = torch.tensor([(int(seed) * 0x9E3779B97F4A7C15 + 0x2545F4914F6CDD1D) & 0x7FFFFFFFFFFFFFFF],
                                 dtype=torch.int64, device=step.device)
-        self.overlap = bool(overlap) and not step.dp and step.use_graph and step.teacher is not None
-        self._bufs = [(step.x, step.x_ema)]
+        self.overlap = bool(overlap) and step.single_graph and step.teacher is not None
+        # how much of the chip the next batch's STFT may take while the step's recurrences run (one workgroup = one CU):
+        # B x 2 recurrence workgroups need their CUs first.  Serial extraction uses the whole chip.
+        n_cu = torch.cuda.get_device_properties(step.device).multi_processor_count
+        if fe_workgroups is None:
+            fe_workgroups = int(os.environ.get("SED_FE_WGS", max(32, n_cu - 2 * step.B)))
+        self.fe_workgroups = int(fe_workgroups)
+        # slot i = (x, x_ema, target); slot 0 are the step's own buffers
+        self._slots = [(step.x, step.x_ema, step.target),
+                       (torch.empty_like(step.x), torch.empty_like(step.x_ema), torch.empty_like(step.target))]
+        self._staged_target = step.target.clone()      # until load_batch stages another one: the target the step holds now
         self._graphs = None
-        self._cur = 0
+        self._cur = 0                                  # slot the next run() trains on
+        self._primed = False
         self._runs = 0
         if self.overlap:
-            self._bufs.append((torch.empty_like(step.x), torch.empty_like(step.x_ema)))
-            # lowest priority: the next batch's features must only fill CUs the step leaves idle (its recurrences run on
-            # a fraction of the chip), never delay a kernel of the step that is running
+            # lowest priority: the next batch's features must only fill CUs the step leaves idle, never win a CU from it
             lo, _hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, 0)
             self._fe_stream = torch.cuda.Stream(device=step.device, priority=int(os.environ.get("SED_FE_PRIO", lo)))
+            _lib.check(self.l.sed_stream_prepare(C.c_void_p(self._fe_stream.cuda_stream)), "sed_stream_prepare")
 
+    # ---- staging ---------------------------------------------------------------------------------------------------------------
     def load_waves(self, waves):
         self.waves.copy_(torch.as_tensor(waves).reshape(self.waves.shape), non_blocking=True)
 
-    def features(self, x=None, x_ema=None):
-        """waveforms -> (x, x_ema) on the current stream (default: the step's own input buffers)."""
+    def load_batch(self, waves, target):
+        """Stage the NEXT batch to extract: its waveforms and the target that belongs to them."""
+        self.load_waves(waves)
+        self._staged_target.copy_(torch.as_tensor(target).reshape(self._staged_target.shape), non_blocking=True)
+
+    def features(self, x=None, x_ema=None, target=None, workgroups=0):
+        """staged waveforms -> (x, x_ema) on the current stream (default: the step's own input buffers); the staged target
+        is copied beside them when `target` is given."""
         c = self.fx.cfg
         st = self.step
         x = st.x if x is None else x
         x_ema = (st.x_ema if st.teacher is not None else None) if x_ema is None else x_ema
         _lib.check(self.l.sed_seed_advance(_lib.ptr(self.key), _lib.stream_ptr()), "sed_seed_advance")
-        _lib.check(self.l.sed_mel_spec(_lib.ptr(self.waves), self.n, self.ns, c.hop_length, c.n_window, None,
-                                       _lib.ptr(self.fx.mel_basis), c.n_mels, _lib.ptr(self.mel), _lib.ptr(self.ws),
-                                       self.ws.numel(), _lib.stream_ptr()), "sed_mel_spec")
+        _lib.check(self.l.sed_mel_frames(_lib.ptr(self.waves), self.n, self.ns, c.hop_length, c.n_window,
+                                         _lib.ptr(self.fx.mel_basis), c.n_mels, _lib.ptr(self.mel), _lib.ptr(self.ws),
+                                         self.ws.numel(), _lib.FFT_DTYPES[self.fx.fft_dtype], int(workgroups), _lib.stream_ptr()),
+                   "sed_mel_frames")
         _lib.check(self.l.sed_logmel_transform(_lib.ptr(self.mel), self.n, self.frames, c.n_mels, st.T, _lib.ptr(self.mean),
                                                _lib.ptr(self.std), _lib.ptr(self.key), _lib.ptr(x), _lib.ptr(x_ema),
                                                _lib.ptr(self.ws_t), self.ws_t.numel(), _lib.stream_ptr()),
                    "sed_logmel_transform")
+        if target is not None:
+            target.copy_(self._staged_target, non_blocking=True)
 
+    def _point_step_at(self, i):
+        st = self.step
+        st.x, st.x_ema, st.target = self._slots[i]
+
+    def prime(self):
+        """Extract the staged batch into the slot the next run() trains on (start-up: nothing ran ahead of the first step)."""
+        self.features(*self._slots[self._cur])
+        self._primed = True
+
+    # ---- capture ---------------------------------------------------------------------------------------------------------------
     def _capture(self):
         st = self.step
         torch.cuda.synchronize(st.device)
-        self.features(*self._bufs[0])                 # batch 0's features: nothing ran ahead of the first replay
-        torch.cuda.synchronize(st.device)
         graphs = []
-        own = (st.x, st.x_ema)
+        cap = dict(stream=st._cap_stream)
+        if st.dp:
+            cap["capture_error_mode"] = "thread_local"
+        fork = os.environ.get("SED_FE_FORK", "gru")     # gru (default) | backward (after both forwards) | start
+        ok = 1.0
         try:
             for i in range(2):
-                st.x, st.x_ema = self._bufs[i]
+                self._point_step_at(i)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=st._cap_stream):
+                if os.environ.get("SED_GRAPH_DUMP"):   # debugging aid: hipGraphDebugDotPrint of the captured step
+                    g.enable_debug_mode()
+                with torch.cuda.graph(g, **cap):
                     cur = torch.cuda.current_stream()
-                    nxt = self._bufs[1 - i]
+                    nxt = self._slots[1 - i]
 
-                    def fork_features():
+                    def extract():
                         self._fe_stream.wait_stream(cur)
                         with torch.cuda.stream(self._fe_stream):
-                            self.features(*nxt)
+                            self.features(*nxt, workgroups=self.fe_workgroups)
 
-                    # SED_FE_FORK=start: fork at the head of the step (round 3's first version: the conv stacks of the forward
-                    # are throughput-bound, the 0.4 ms of feature kernels simply added to the step); default: after the
-                    # forwards, so that they run next to the heads / GRU backward (a fraction of the chip) first
-                    if os.environ.get("SED_FE_FORK", "backward") == "start":
-                        fork_features()
-                        st._fwd_bwd()
+                    if fork == "start":
+                        extract()
+                        st._step_body()
+                    elif fork == "backward":
+                        st._step_body(after_forward=extract)
                     else:
-                        st._fwd_bwd(after_forward=fork_features)
-                    st._update()
+                        st._step_body(at_recurrence=extract)
                     cur.wait_stream(self._fe_stream)
+                if os.environ.get("SED_GRAPH_DUMP"):
+                    g.debug_dump(os.environ["SED_GRAPH_DUMP"] + f".{i}.dot")
                 graphs.append(g)
+        except Exception as e:                         # noqa: BLE001 - e.g. a collective that cannot be captured on this rank
+            if not st.dp:
+                raise
+            ok, graphs = 0.0, None
+            st._capture_error = repr(e)
         finally:
-            st.x, st.x_ema = own
+            self._point_step_at(0)
+        if st.dp:
+            import torch.distributed as dist
+            flag = torch.tensor([ok], device=st.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=st.pg)
+            if flag.item() != 1.0:
+                graphs, self.overlap = None, False     # every rank falls back to the serial protocol together
         self._graphs = graphs
-        self._cur = 0
 
+    # ---- running ---------------------------------------------------------------------------------------------------------------
     def run(self):
+        """One train step on the batch extracted last + extraction of the staged batch."""
         st = self.step
+        if not self._primed:
+            self.prime()
         if not self.overlap:
-            self.features()
+            # one slot is enough without overlap: extract-then-train keeps the step's own graph on its own buffers
+            self._cur = 0
             st.run()
-            return
-        if self._runs < 2:                            # two eager steps first (as MeanTeacherStep.run does before capturing)
-            self.features()
-            st.run()
+            self.features(*self._slots[0])
             self._runs += 1
             return
-        if self._graphs is None:
-            self._capture()
-        self._graphs[self._cur].replay()
+        if self._runs < 2:                             # two eager steps first (as MeanTeacherStep.run does before capturing)
+            self._point_step_at(self._cur)
+            try:
+                st._step_body()
+            finally:
+                self._point_step_at(0)
+            self.features(*self._slots[1 - self._cur])
+        else:
+            if self._graphs is None:
+                self._capture()
+                if not self.overlap:                   # a rank could not capture: serial protocol from here on
+                    if self._cur == 1:
+                        for a, b in zip(self._slots[0], self._slots[1]):
+                            a.copy_(b)
+                    return self.run()
+            self._graphs[self._cur].replay()
         self._cur ^= 1
         self._runs += 1
         st._warm += 1
         st.steps_done += 1
+
+    def feed(self, waves, target):
+        """Streaming interface: every batch fed is trained on exactly once, in order (the last one by ``flush``)."""
+        self.load_batch(waves, target)
+        if not self._primed:
+            self.prime()
+            return
+        self.run()
+
+    def flush(self):
+        """Train on the batch extracted last without extracting another one."""
+        if not self._primed:
+            return
+        st = self.step
+        self._point_step_at(self._cur if self.overlap else 0)
+        try:
+            st._step_body() if self.overlap else st.run()
+        finally:
+            self._point_step_at(0)
+        if self.overlap:
+            st._warm += 1
+            st.steps_done += 1
+        self._primed = False

@@ -192,10 +192,14 @@ class MeanTeacherStep:
                                            self.ctx_bytes, _lib.ptr(strong), _lib.ptr(weak), _lib.stream_ptr()),
                    "sed_crnn_forward")
 
-    def _fwd_bwd(self, after_forward=None):
+    def _fwd_bwd(self, after_forward=None, at_recurrence=None):
         """teacher forward (main.py:87-89), student forward (:91), losses (:93-145), backward (:152-153).
-        `after_forward`: called between the forwards and the backward (the waveform front-end forks the next batch's feature
-        kernels there: features.WaveformFrontEnd)."""
+        `after_forward`: called between the forwards and the backward; `at_recurrence`: called from INSIDE the student
+        forward, between its conv stack and its recurrence (sed_crnn_fork_callback) - where the waveform front-end forks
+        the next batch's feature kernels (features.WaveformFrontEnd)."""
+        if at_recurrence is not None:
+            self._fork_cb = _lib.FORK_CALLBACK(lambda _user: at_recurrence())      # (kept alive until the forward has run)
+            _lib.check(self.l.sed_crnn_fork_callback(_lib.stream_ptr(), self._fork_cb, None), "sed_crnn_fork_callback")
         if self.supervised:
             self._forward(self.student, self.x, self.ctx_s, self._seed_s, self.strong, self.weak)
         elif self._side is not None:
@@ -326,19 +330,22 @@ class MeanTeacherStep:
             self._graph_w.replay() if graph else self._dp_tail()              # tail weight gradients (parts 8)
             w1 = self._allreduce(tlo, thi, True)                              # tail bucket over xGMI ...
         self._graph_c.replay() if graph else self._backward(2)                # ... while the conv blocks run backward
-        w2 = self._allreduce(hlo, hhi, True)
-        if w2 is not None:
-            w2.wait()
+        # ONE collective in flight per communicator: the head bucket's all-reduce is issued only after the tail bucket's
+        # has completed in stream order (it finished long before: the conv backward is ~350 us) - two collectives enqueued
+        # from two streams on one communicator are otherwise ordered only by what the backend serialises internally
         with torch.cuda.stream(self._dp_stream):
             if w1 is not None:
                 w1.wait()
         cur.wait_stream(self._dp_stream)
+        w2 = self._allreduce(hlo, hhi, True)
+        if w2 is not None:
+            w2.wait()
         self._graph_b.replay() if graph else self._update()
 
-    def _dp_step_body(self):
+    def _dp_step_body(self, after_forward=None, at_recurrence=None):
         """The same schedule as straight-line stream code (what SED_DP_CAPTURE=1 captures into ONE graph)."""
         (tlo, thi), (hlo, hhi) = self._buckets
-        self._fwd_bwd()
+        self._fwd_bwd(after_forward, at_recurrence)
         if self.dp_schedule == "single" or self.cnn_frozen:
             self._allreduce(tlo if self.cnn_frozen else 0, thi if self.cnn_frozen else self.n, False)
         else:
@@ -348,9 +355,23 @@ class MeanTeacherStep:
                 self._dp_tail()
                 self._allreduce(tlo, thi, False)
             self._backward(2)
+            cur.wait_stream(self._dp_stream)          # explicit order: tail all-reduce complete before the head one is issued
             self._allreduce(hlo, hhi, False)
-            cur.wait_stream(self._dp_stream)
         self._update()
+
+    def _step_body(self, after_forward=None, at_recurrence=None):
+        """One whole step as straight-line stream code - the unit a single hipGraph holds (one process, or data-parallel
+        with captured collectives)."""
+        if self.dp:
+            self._dp_step_body(after_forward, at_recurrence)
+        else:
+            self._fwd_bwd(after_forward, at_recurrence)
+            self._update()
+
+    @property
+    def single_graph(self):
+        """True when run() replays ONE graph per step (what features.WaveformFrontEnd can fold the next batch's features into)."""
+        return self.use_graph and (not self.dp or self.dp_capture)
 
     # ---- public ------------------------------------------------------------------------------------
     def load_batch(self, x, x_ema, target):

@@ -137,6 +137,13 @@ int sed_crnn_forward(const sed_dims* d, const float* params, float* bn_running, 
  * use (event fork/join, capturable) - so calls on different caller streams, from different host threads or on
  * different devices never share state.  Call sed_stream_prepare for a stream BEFORE capturing it into a hipGraph. */
 int sed_stream_prepare(void* stream);
+/* One-shot fork hook: the NEXT sed_crnn_forward enqueued on `stream` calls fn(user) - on the calling host thread, once,
+ * then forgets it - after enqueueing its last conv-block kernel and before its first recurrence kernel.  The recurrent half
+ * of CRNN.forward (models/CRNN.py:74-84: BiGRU, attention heads) occupies one workgroup per (clip, direction) - a fraction of
+ * the chip - so a callback that forks a second stream off `stream` there (event record + wait, capturable) runs independent
+ * work - the NEXT batch's feature extraction, the job of the reference's DataLoader workers (DataLoad.py:47-186) - on
+ * otherwise idle CUs.  fn must not call back into sed_crnn_forward on the same stream.  fn == NULL clears the hook. */
+int sed_crnn_fork_callback(void* stream, void (*fn)(void*), void* user);
 size_t sed_crnn_bwd_ws_bytes(const sed_dims* d);
 int sed_crnn_backward(const sed_dims* d, const float* params, const float* x, const uint64_t* seed_dev,
                       void* ctx, size_t ctx_bytes, const float* d_strong, const float* d_weak,
@@ -221,6 +228,27 @@ size_t sed_mel_spec_ws_bytes(int n_clips, int n_samples, int hop, int n_fft, int
 int sed_mel_spec(const float* wave, int n_clips, int n_samples, int hop, int n_fft,
                  const float* window, const float* mel_basis, int n_mels, float* mel,
                  void* ws, size_t ws_bytes, void* stream);
+/* The two halves of sed_mel_spec for callers that extract features batch after batch (the reference builds np.hamming and
+ * librosa.filters.mel once per process too, DatasetDcase2019Task4.py:211-228):
+ *   sed_mel_tables  fills ws with everything that depends on (window, mel_basis) only: the W_2048 table, the float64
+ *                   window (window == NULL: np.hamming(n_fft) generated in float64), the support of every mel band and the
+ *                   band-compressed filterbank;
+ *   sed_mel_frames  the STFT + mel projection proper, reading a ws prepared by sed_mel_tables with the SAME mel_basis.
+ *                   One persistent launch of at most max_workgroups workgroups (<= 0: one per CU); each occupies one CU
+ *                   completely, so a caller that runs it beside other work (features of batch k + 1 during train step k)
+ *                   decides how much of the chip the front-end may take.  Results do not depend on max_workgroups.
+ *                   fft_dtype selects the butterfly arithmetic, explicitly (never chosen silently, like sed_dims.dtype):
+ *                     SED_FFT_F64  float64, what librosa computes in (soundfile hands it float64 audio): the parity mode
+ *                     SED_FFT_F32  float32 butterflies, twiddles / window generated in float64 and rounded once.  A stated
+ *                                  reduced-precision mode for the bf16 train step of BASELINE.json configs[2]; measured
+ *                                  error bounds (dB on the features, posteriors at B = 64) in tests/test_gpu_features.py. */
+#define SED_FFT_F64 0
+#define SED_FFT_F32 1
+int sed_mel_tables(int n_fft, const float* window, const float* mel_basis, int n_mels, void* ws, size_t ws_bytes,
+                   void* stream);
+int sed_mel_frames(const float* wave, int n_clips, int n_samples, int hop, int n_fft, const float* mel_basis,
+                   int n_mels, float* mel, const void* ws, size_t ws_bytes, int fft_dtype, int max_workgroups,
+                   void* stream);
 
 /* sed_logmel_transform replaces the per-sample transform chain of get_transforms
  * (utils/utils.py:397-412): [AugmentGaussianNoise] -> ApplyLog (librosa.amplitude_to_db, amin

@@ -150,19 +150,19 @@ def dropout_mask_flat(seed, stream_id, shape, p):
 
 
 def teacher_noise(seed, B, frames, n_mels, std=0.25):
-    """|N(0, std)| noise [B, frames, n_mels] float32 (Box-Muller on Philox uniforms, stream 16).
+    """|N(0, std)| noise [B, frames, n_mels] float32: Box-Muller on Philox uniforms, stream 16, one draw per element PAIR.
 
-    u1 = (w0 + 1) * 2^-32 in (0,1],  u2 = w1 * 2^-32 in [0,1),
-    n  = sqrt(-2 ln u1) * cos(2 pi u2), computed in float32 on the device.
+    pair i = elements (2 i, 2 i + 1) of the flattened tensor; (w0, w1) = the first two words of Philox4x32-10 at counter i;
+    u1 = (w0 + 1) * 2^-32 in (0,1],  u2 = w1 * 2^-32 in [0,1),  r = sqrt(-2 ln u1),
+    element 2 i = r cos(2 pi u2), element 2 i + 1 = r sin(2 pi u2) - both outputs of the transform, float64 arithmetic,
+    rounded to float32 (csrc/feat.hip teacher_noise_pair).
     """
     n = B * frames * n_mels
-    e = np.arange(n)
+    npair = (n + 1) // 2
     k0, k1 = _key(seed)
-    o = philox4x32_10((e >> 1).astype(np.uint32), 0, np.uint32(16), np.uint32(TAG), k0, k1)
-    o = np.stack(o, axis=-1)
-    w0 = o[np.arange(n), 2 * (e & 1)]
-    w1 = o[np.arange(n), 2 * (e & 1) + 1]
-    u1 = (w0.astype(np.float64) + 1.0) * 2.0 ** -32
-    u2 = w1.astype(np.float64) * 2.0 ** -32
-    g = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+    o = philox4x32_10(np.arange(npair).astype(np.uint32), 0, np.uint32(16), np.uint32(TAG), k0, k1)
+    u1 = (o[0].astype(np.float64) + 1.0) * 2.0 ** -32
+    u2 = o[1].astype(np.float64) * 2.0 ** -32
+    r = np.sqrt(-2.0 * np.log(u1))
+    g = np.stack([r * np.cos(2.0 * np.pi * u2), r * np.sin(2.0 * np.pi * u2)], axis=-1).reshape(-1)[:n]
     return np.abs(std * g).astype(np.float32).reshape(B, frames, n_mels)

@@ -48,6 +48,20 @@ STEP_FLOP_PER_CLIP = 3.432e9      # 4 x forward (teacher fwd + student fwd + 2x 
 STEP_BYTES_PER_CLIP = 12.0e6      # 7 passes over the block-boundary tensors, fp32
 WIDE_STEP_FLOP_PER_CLIP = 14.157e9    # wide CRNN (3 x 128 filters, 256-cell BiGRU)
 WIDE_STEP_BYTES_PER_CLIP = 23.9e6
+N_PARAMS = {False: 214356, True: 2132628}
+WAVEFORM_BYTES_PER_CLIP = 160000 * 4 + 2 * T_FRAMES * N_MELS * 4      # fp32 waveform read + two feature tensors written
+
+
+def algorithmic_bytes(wide, mfma_dtype, waveform, B):
+    """SURVEY.md 8(d), priced by what the mode actually stores: block-boundary tensors 12.0 / 23.9 MB per clip in fp32
+    (f32, and bf16x3 - split operands, fp32 storage), 6.0 / 12.0 MB in bf16 (SED_DTYPE_BF16 stores activations as bf16);
+    + 0.96 MB per clip when the step starts from waveforms; + 9 words x parameters per STEP of optimiser traffic."""
+    per_clip = WIDE_STEP_BYTES_PER_CLIP if wide else STEP_BYTES_PER_CLIP
+    if mfma_dtype == "bf16":
+        per_clip = 12.0e6 if wide else 6.0e6
+    if waveform:
+        per_clip += WAVEFORM_BYTES_PER_CLIP
+    return per_clip * B + 9 * 4 * N_PARAMS[wide]
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= the f32 vector peak)
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak
 CONFIGS = {   # name -> (wide, mfma dtype, from waveform, default batch per GPU)
@@ -153,7 +167,7 @@ def cpu_baseline(budget_s=60.0, warm=2, timed_steps=5):
 
 
 def feature_path(device, n_clips=32):
-    """BASELINE.md section 3's feature-path line: waveform -> linear mel (sed_mel_spec) -> log / pad / normalise
+    """BASELINE.md section 3's feature-path line: waveform -> linear mel (sed_mel_frames, fp64 butterflies) -> log / pad / normalise
     (sed_logmel_transform) for 32 clips of 160 000 samples at 16 kHz, HIP-event timed on the launch stream, beside the
     numpy restatement of the same path (oracle/features_np.py) on the host cores (bounded: 4 clips)."""
     from dcase2019_task4_amd.features import FeatureConfig, FeatureExtractor, LogMelTransform
@@ -175,6 +189,7 @@ def feature_path(device, n_clips=32):
 
     mel = fx.calculate_mel_spec_batch(wave)
     ms_stft = timed(lambda: fx.calculate_mel_spec_batch(wave))
+    ms_stft32 = timed(lambda: fx.calculate_mel_spec_batch(wave, fft_dtype="f32"))
     ms_tr = timed(lambda: tr(mel))
     ms = timed(lambda: tr(fx.calculate_mel_spec_batch(wave)))
     # algorithmic bytes: the waveform read once (fp32) + the feature tensor written once; the linear mel in between is
@@ -192,8 +207,11 @@ def feature_path(device, n_clips=32):
                         "frac_of_hbm_peak": round(b / t * 1e-6 / PEAK_HBM_GBS, 4)}
     return {"gpu_clips_per_s": round(n_clips / ms * 1e3, 1), "ms_per_32_clips": round(ms, 3),
             "hbm_gbs_algorithmic": round(by / ms * 1e-6, 1), "frac_of_hbm_peak": round(by / ms * 1e-6 / PEAK_HBM_GBS, 4),
-            "kernels": {"sed_mel_spec (k_stft_mel: STFT + mel projection)": dict(per(by_stft, ms_stft), bound="LDS / fp64 VALU: "
-                        "radix-4 FFT of 2048 points per frame in fp64, held in LDS"),
+            "kernels": {"sed_mel_frames SED_FFT_F64 (k_stft_mel_p<double>: persistent STFT + mel projection)":
+                        dict(per(by_stft, ms_stft), bound="fp64 VALU issue + LDS exchange writes (DESIGN.md 3.12): 1024-point complex "
+                             "FFT per frame as 16 x 16 x 4 in registers, three exchanges through LDS, tables resident in LDS"),
+                        "sed_mel_frames SED_FFT_F32 (k_stft_mel_p<float>, the stated fp32 mode)":
+                        dict(per(by_stft, ms_stft32), bound="packed-fp32 VALU issue + LDS exchange writes"),
                         "sed_logmel_transform (k_logmel_max + k_logmel_apply, no augmentation)": dict(per(by_tr, ms_tr),
                         bound="fp64 log10 per element, then HBM")},
             "cpu_clips_per_s": round(1.0 / cpu_s, 2), "cpu_kind": "port (oracle/features_np.py, numpy, 1 process)",
@@ -331,6 +349,85 @@ def same_on_all_ranks(step, world, device):
     return allv
 
 
+ARITH = {"f32": "fp32 (exact fp32 MFMA; block 0's backward sums on split bf16 operands, DESIGN.md 3.10)",
+         "bf16": "SED_DTYPE_BF16: bf16 MFMA operands + bf16 activation storage in the conv blocks (3x3 convolutions forward / "
+                 "dgrad / wgrad, GLU Linear, block 0), bf16 GRU weight-gradient GEMMs, bf16 W_hh / projections at H = 256; "
+                 "fp32 accumulation everywhere, fp32 recurrence at H = 64, heads, BatchNorm statistics, losses, Adam",
+         "bf16x3": "SED_DTYPE_BF16X3: split bf16 operands (hi + lo, three bf16 MFMAs per product, fp32 accumulation and fp32 "
+                   "storage) in the conv-block GEMMs, fp32 elsewhere"}
+
+
+def workload_string(wide, mfma_dtype, waveform, B, fft="f32"):
+    mdl = "wide CRNN (nb_filters 3 x 128, n_RNN_cell 256)" if wide else "CRNN (baseline/main.py config)"
+    if waveform:
+        return (f"mean-teacher {mdl} train step from raw 16 kHz waveforms (STFT [{fft} butterflies] + mel + noise + log + "
+                f"normalise on the GPU inside the timed region, one batch ahead inside the step's hipGraph), batch {B} per GPU, "
+                f"{ARITH[mfma_dtype]}")
+    return (f"mean-teacher {mdl} train step, batch {B} per GPU, precomputed log-mel [{B},1,628,64] fp32 resident in HBM, "
+            f"dropout 0.5, {ARITH[mfma_dtype]}")
+
+
+def make_runner(config, device, rank, pg=None, use_graph=True, batch=None, seed=1234):
+    """Models + step (+ waveform front-end) of one workload of CONFIGS on synthetic data resident in HBM."""
+    from dcase2019_task4_amd.train import MeanTeacherStep
+    wide, mfma_dtype, waveform, b_default = CONFIGS[config]
+    B = batch or b_default
+    model_kw = dict(mfma_dtype=mfma_dtype)
+    if wide:
+        model_kw.update(nb_filters=[128, 128, 128], n_RNN_cell=256)
+    student, teacher = build_models(device, seed=0, **model_kw)        # identical replicas on every rank
+    x, xe, tgt, wm, sm = synthetic_batch(B, T_FRAMES, 1000 + rank, device)
+    step = MeanTeacherStep(student, teacher, B, T_FRAMES, rampup_length=210 * 100 // 2, weak_mask=wm, strong_mask=sm,
+                           seed=seed, use_graph=use_graph, process_group=pg)
+    step.load_batch(x, xe, tgt)
+    runner = step
+    if waveform:
+        from dcase2019_task4_amd.features import FeatureConfig, WaveformFrontEnd
+        g = torch.Generator().manual_seed(77 + rank)
+        wave = (0.1 * torch.randn(B, 160000, generator=g)).to(device)
+        runner = WaveformFrontEnd(step, wave, FeatureConfig.baseline_16k(), fft_dtype=os.environ.get("SED_FE_FFT", "f32"))
+    return runner, step, B
+
+
+def step_roofline(wide, mfma_dtype, waveform, B, ms_per_step):
+    """SURVEY 8(d)'s whole-step figures for one measured line."""
+    flop = (WIDE_STEP_FLOP_PER_CLIP if wide else STEP_FLOP_PER_CLIP) * B
+    by = algorithmic_bytes(wide, mfma_dtype, waveform, B)
+    peak = PEAK_F32_MFMA_TFLOPS if mfma_dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+    tf = flop / (ms_per_step * 1e-3) * 1e-12
+    return {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+            "frac_of_f32_mfma_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "algorithmic_flops": int(flop),
+            "algorithmic_bytes": int(by), "algorithmic_gbs": round(by / (ms_per_step * 1e-3) * 1e-9, 1),
+            "hbm_frac": round(by / (ms_per_step * 1e-3) * 1e-9 / PEAK_HBM_GBS, 4)}
+
+
+def extra_config_legs(device, steps=300):
+    """The other single-GPU BASELINE.json workloads, timed in the SAME driver run as the headline line (round 3's numbers
+    for them were builder-printed): configs[2] (waveform-bf16, batch 64), configs[4]'s model at its per-GPU shape (wide-bf16,
+    wide-bf16x3), and configs[1]'s workload in the two reduced-precision modes.  `steps` hipGraph replays each after warm-up."""
+    out = {}
+    for name in ("waveform-bf16", "wide-bf16", "wide-bf16x3", "mt-bf16", "mt-bf16x3"):
+        try:
+            wide, mfma_dtype, waveform, _ = CONFIGS[name]
+            runner, step, B = make_runner(name, device, 0)
+            for _ in range(8):
+                runner.run()
+            el = time_steps(runner, steps, 1, device)
+            ms = el / steps * 1e3
+            assert np.isfinite(step.meters()["loss"])
+            step.check_health()
+            out[name] = {"value": round(B * steps / el, 1), "unit": "clips/s", "ms_per_step": round(ms, 4), "steps": steps,
+                         "dtype": mfma_dtype, "global_batch": B,
+                         "workload": workload_string(wide, mfma_dtype, waveform, B, os.environ.get("SED_FE_FFT", "f32")),
+                         "roofline": step_roofline(wide, mfma_dtype, waveform, B, ms)}
+            print(f"[bench] extra config {name}: {ms:.4f} ms/step, {out[name]['value']} clips/s", file=sys.stderr, flush=True)
+            del runner, step
+            torch.cuda.empty_cache()
+        except Exception as e:                          # noqa: BLE001 - the headline line must not depend on these legs
+            out[name] = {"error": repr(e)[:300]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -363,29 +460,18 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         pg = dist.group.WORLD
         dist_info = {"backend": dist.get_backend(pg), "world_size": dist.get_world_size(pg),
-                     "rccl": ".".join(str(v) for v in torch.cuda.nccl.version())}
+                     "rccl": ".".join(str(v) for v in torch.cuda.nccl.version()),
+                     # RCCL picks algorithm / protocol per message size unless pinned; what this run pinned (nothing by default)
+                     "env": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS",
+                                                            "RCCL_MSCCL_ENABLE", "HSA_ENABLE_IPC_MODE_LEGACY")}}
         if rank == 0:
             print(f"[bench] process group up: {dist_info}", file=sys.stderr, flush=True)
 
     from dcase2019_task4_amd.train import MeanTeacherStep
     wide, mfma_dtype, waveform, b_default = CONFIGS[args.config]
     headline = args.config == "mt-f32"
-    B = args.batch or b_default
-    model_kw = dict(mfma_dtype=mfma_dtype)
-    if wide:
-        model_kw.update(nb_filters=[128, 128, 128], n_RNN_cell=256)
-    student, teacher = build_models(device, seed=0, **model_kw)        # identical replicas on every rank
-    x, xe, tgt, wm, sm = synthetic_batch(B, T_FRAMES, 1000 + rank, device)
-    step = MeanTeacherStep(student, teacher, B, T_FRAMES, rampup_length=210 * 100 // 2, weak_mask=wm, strong_mask=sm,
-                           seed=1234, use_graph=not args.no_graph, process_group=pg)
-    step.load_batch(x, xe, tgt)
-    runner = step
-    if waveform:
-        from dcase2019_task4_amd.features import WaveformFrontEnd
-        g = torch.Generator().manual_seed(77 + rank)
-        wave = (0.1 * torch.randn(B, 160000, generator=g)).to(device)
-        from dcase2019_task4_amd.features import FeatureConfig
-        runner = WaveformFrontEnd(step, wave, FeatureConfig.baseline_16k(), fft_dtype=os.environ.get("SED_FE_FFT", "f32"))
+    runner, step, B = make_runner(args.config, device, rank, pg, use_graph=not args.no_graph, batch=args.batch)
+    x, xe, tgt, wm, sm = synthetic_batch(B, T_FRAMES, 1000 + rank, device)          # (the same batch again, for the A/B legs below)
     for _ in range(max(args.warmup, 3)):       # >= 3: two eager warm-ups + graph capture/first replay
         runner.run()
     elapsed = time_steps(runner, args.steps, world, device)
@@ -440,18 +526,46 @@ def main():
         except Exception as e:                      # noqa: BLE001
             config3 = {"error": repr(e)[:300]}
 
+    config4 = None
+    if world > 1 and headline and not args.no_extras and args.batch is None:
+        # BASELINE.json configs[4]: the wide CRNN in bf16 under the data-parallel step, 24 clips per GPU
+        try:
+            r4, step4, B4 = make_runner("wide-bf16", device, rank, pg, use_graph=not args.no_graph, seed=2468)
+            for _ in range(5):
+                r4.run()
+            n4 = max(50, args.steps // 4)
+            el4 = time_steps(r4, n4, world, device)
+            same_on_all_ranks(step4, world, device)
+            step4.check_health()
+            ms4 = el4 / n4 * 1e3
+            config4 = {"workload": "BASELINE.json configs[4]: " + workload_string(True, "bf16", False, B4), "global_batch": B4 * world,
+                       "value": round(B4 * world * n4 / el4, 1), "unit": "clips/s", "ms_per_step": round(ms4, 4), "steps": n4,
+                       "dtype": "bf16", "dp_schedule": step4.dp_schedule,
+                       "dp_collectives": "captured" if step4.dp_capture else "eager",
+                       "gradient_bytes_per_step": 4 * N_PARAMS[True]}
+            del r4, step4
+        except Exception as e:                      # noqa: BLE001
+            config4 = {"error": repr(e)[:300]}
+
+    # the driver times 20 steps (15 ms): a steady-state figure of the same workload beside it
+    steady = None
+    if world == 1 and headline and not args.no_extras and args.steps < 1000:
+        for _ in range(20):
+            runner.run()
+        n_ss = 3000
+        el_ss = time_steps(runner, n_ss, world, device)
+        steady = {"steps": n_ss, "ms_per_step": round(el_ss / n_ss * 1e3, 4), "value": round(B * n_ss / el_ss, 1), "unit": "clips/s",
+                  "note": "same step, same buffers, 3000 hipGraph replays timed the same way (the headline's timed region is "
+                          "K steps as the driver asks: 20 steps = 15 ms is dominated by the first replays)"}
+
+    extras = None
+    if world == 1 and headline and not args.no_extras and args.batch is None and rank == 0:
+        extras = extra_config_legs(device)
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         clips = B * world * args.steps / elapsed
-        t_clip_us = elapsed / args.steps / B * 1e6
-        mdl = "wide CRNN (nb_filters 3 x 128, n_RNN_cell 256)" if wide else "CRNN (baseline/main.py config)"
-        arith = {"f32": "fp32", "bf16": "bf16 MFMA operands / fp32 accumulation in the conv-block GEMMs, fp32 elsewhere",
-                 "bf16x3": "split bf16 operands (hi + lo, three bf16 MFMAs per product, fp32 accumulation) in the 3x3 "
-                           "convolutions forward / dgrad, fp32 elsewhere"}[mfma_dtype]
-        wl = (f"mean-teacher {mdl} train step from raw 16 kHz waveforms (STFT + mel + log + normalise on the GPU inside the "
-              f"timed region), batch {B} per GPU, {arith}" if waveform else
-              f"mean-teacher {mdl} train step, batch {B} per GPU, precomputed log-mel [{B},1,628,64] fp32 resident in HBM, "
-              f"dropout 0.5, {arith}")
+        wl = workload_string(wide, mfma_dtype, waveform, B, os.environ.get("SED_FE_FFT", "f32"))
         res = {
             "metric": "10-s clips/sec mean-teacher train step (64-mel x 628)",
             "value": round(clips, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -475,34 +589,37 @@ def main():
                 res["distributed"]["capture_fallback"] = step._capture_error[:200]
         if config3:
             res["config3_ddp"] = config3
-        step_flop = WIDE_STEP_FLOP_PER_CLIP if wide else STEP_FLOP_PER_CLIP
-        step_bytes = WIDE_STEP_BYTES_PER_CLIP if wide else STEP_BYTES_PER_CLIP
-        peak = PEAK_F32_MFMA_TFLOPS if mfma_dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
-        whole_tflops = step_flop / t_clip_us * 1e-6
+        if config4:
+            res["config4_ddp"] = config4
+        if steady:
+            res["steady_state"] = steady
+        if extras:
+            res["extra_configs"] = extras
         traffic, table = pmc_step_traffic()
-        roof = {
-            "bound": "mfma", "kernel": "whole step (one hipGraph)",
-            "achieved": round(whole_tflops, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(whole_tflops / peak, 4),
-            "frac_of_f32_mfma_peak": round(whole_tflops / PEAK_F32_MFMA_TFLOPS, 4),
+        roof = dict(step_roofline(wide, mfma_dtype, waveform, B, ms), kernel="whole step (one hipGraph)")
+        roof.update({
             "traffic": traffic if (world == 1 and headline and B == B_PER_GPU) else None,
-            "algorithmic_flops": int(step_flop * B), "algorithmic_bytes": int(step_bytes * B),
-            "algorithmic_gbs": round(step_bytes / t_clip_us * 1e-3, 1),
-            "hbm_frac": round(step_bytes / t_clip_us * 1e-3 / PEAK_HBM_GBS, 4),
-            "definition": "SURVEY 8(d): 3.432 GFLOP per clip of reference GEMM-shaped work (4 x forward) / measured time per "
-                          "clip, against the f32 MFMA peak (the step is compute-bound: 286 FLOP/B); `traffic` = HBM bytes per "
-                          "step, per-launch PMC figures (profiles/pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, separate "
-                          "rocprofv3 --pmc passes of this bench, measured offline) x launches per step",
+            "definition": "SURVEY 8(d): reference GEMM-shaped FLOPs of the step (4 x forward: 3.432 GFLOP per clip, wide 14.157) / "
+                          "measured time, against the dense MFMA peak of the operand dtype (the step is compute-bound: 286 "
+                          "FLOP/B); algorithmic_bytes = block-boundary tensors at the storage width of the mode + optimiser "
+                          "words + waveform bytes when the step starts from audio; `traffic` = HBM bytes per step from the "
+                          "committed PMC passes of this bench command (profiles/pmc_traffic.json `_per_step`: every dispatch "
+                          "of the traced run, 2 x FETCH_SIZE + WRITE_SIZE per MI355X_MICROARCH.md, summed and divided by the "
+                          "steps traced - collected offline by tools/collect_profiles.sh, not inside this run)",
             "flop_convention": "effective = the reference's operator FLOPs (direct 3x3 convolution, 64x64 GLU Linear per "
                                "pixel); executed = what the kernel issues on the MFMA pipe (Winograd F(2x2,3x3): 16/36 of a "
                                "direct convolution's multiplies; block 0: one K = 10 convolution to 128 channels). An "
                                "effective fraction above 1 is an algorithmic saving, not MFMA utilisation - the executed "
                                "fraction beside it is.",
-        }
+        })
+        roof = {k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_of_f32_mfma_peak", "traffic",
+                                     "algorithmic_flops", "algorithmic_bytes", "algorithmic_gbs", "hbm_frac", "definition",
+                                     "flop_convention")}
         if mfma_dtype != "f32":
-            roof["note"] = ("bf16 line: priced against the DENSE bf16 MFMA peak as the contract asks; only the conv-block GEMMs "
-                            "run on bf16 operands - block 0, every weight gradient, the GRU, the heads and all element-wise "
-                            "work are fp32, so this fraction is NOT an MFMA-utilisation figure (frac_of_f32_mfma_peak beside it)")
+            roof["note"] = ("reduced-precision line: priced against the DENSE bf16 MFMA peak as the contract asks.  The operators "
+                            "that run on bf16 operands are listed in config.workload; the recurrences, heads, BatchNorm and all "
+                            "element-wise work are not MFMA work at all, so this fraction is NOT an MFMA-utilisation figure "
+                            "(frac_of_f32_mfma_peak beside it)")
         if not args.no_extras and headline:
             kr = kernel_roofline(step)
             dom = max(kr, key=lambda k: kr[k]["us"] * kr[k]["launches_per_step"])

@@ -138,6 +138,10 @@ def _check_grads(g_hip, go):
         # measured <= 2e-4 of the typical magnitude; the bound leaves 5x (+1e-7 absolute: gradients that cancel to ~0 -
         # the softmax bias, whose terms sum to zero over the classes - carry fp32 rounding noise of their O(1e-2) summands)
         np.testing.assert_allclose(g_hip[n].numpy(), g.numpy(), rtol=1e-3, atol=1e-3 * scale + 1e-7, err_msg=n)
+        if n.startswith(("cnn.conv0", "cnn.batchnorm0", "cnn.glu0")):
+            # block 0's backward sums run on split bf16 operands (hi hi + hi lo + lo hi) also in SED_DTYPE_F32 - the one
+            # stated exception to "fp32 MFMA" (include/dcase_sed.h): held 5x tighter than the rest (measured 1 - 3e-5)
+            np.testing.assert_allclose(g_hip[n].numpy(), g.numpy(), rtol=2e-4, atol=2e-4 * scale + 1e-7, err_msg=n)
     return worst
 
 

@@ -378,235 +378,6 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bconv(const void* __restrict__
     }
 }
 
-// ---- bf16, C = 128, W = 16: the barrier-free variant ---------------------------------------------------------------------------
-// What the stamps of k_bconv said at this shape: the MFMAs of a 64-wide weight chunk are 2/3 of an iteration,
-// the workgroup barrier that publishes the next chunk the other third; LDS bandwidth is not the limit.  So here
-//   * the B (weight) fragments never touch LDS: they come straight from global memory (L1 / L2: the panel is 288 KB and shared by
-//     every workgroup), pre-packed in fragment order (gkernels.h bconv_frag_index: 1 KB contiguous per wave-load), half a chunk
-//     ahead in registers - the k-loop has NO barrier;
-//   * a wave owns 128 pixels x 64 channels = 4 x 2 MFMA tiles (6 fragment reads per 8 MFMAs, 32 B/clk of L1 traffic per CU);
-//   * a workgroup is FOUR waves on a 16-row tile whose halo holds 64 of the 128 input channels at a time (two staging units per
-//     tile, the accumulators run across both): 56 KB of LDS - TWO independent workgroups per CU, which drift apart and cover each
-//     other's staging phases, vmcnt waits (in-order: a B-fragment wait also waits for the next unit's halo prefetch) and epilogues;
-//   * the output tile leaves through an LDS transpose (the halo is free by then) with 16-byte stores instead of 2-byte ones.
-struct BC2 {
-    static constexpr int C = 128, TW = 16, TH = 16, CS = 64, NCS = 2, HH = TH + 2;
-    static constexpr int PS = 2 * CS + 16, RP = 2816;                     // 18 pixels x 144 B = 2 592, padded to a multiple of 256
-    static constexpr int HALO_BYTES = HH * RP;                            // 50 688
-    static constexpr int OS = 2 * 64 + 16;                                // output staging row (64 channels of one pixel + pad)
-    static constexpr int RED_BYTES = 2 * 2 * C * 4, COEF_BYTES = 3 * C * 4;
-    static constexpr size_t LDS_BYTES = (size_t)HALO_BYTES + RED_BYTES + COEF_BYTES;
-    static_assert(4 * 64 * OS <= HALO_BYTES, "output staging must fit the halo area");
-};
-template <int DIR>
-__global__ __launch_bounds__(256, 2) void k_bconv2(const __bf16* __restrict__ in0, const __bf16* __restrict__ in1,
-                                                    const float* __restrict__ coef, const __bf16* __restrict__ wfrag,
-                                                    const float* __restrict__ bias, __bf16* __restrict__ out,
-                                                    double* __restrict__ stat, int H, int tiles_per_clip, int n_tiles) {
-    constexpr int C = BC2::C, TW = BC2::TW, TH = BC2::TH, CS = BC2::CS, NCS = BC2::NCS, HH = BC2::HH, PS = BC2::PS, RP = BC2::RP;
-    constexpr int MB = 4, NB = 2, NT = 256, CJ = CS / 8, OS = BC2::OS;
-    extern __shared__ __attribute__((aligned(16))) unsigned char bsm2[];
-    unsigned char* halo = bsm2;
-    float* red = (float*)(bsm2 + BC2::HALO_BYTES);
-    float* cfl = (float*)(bsm2 + BC2::HALO_BYTES + BC2::RED_BYTES);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 31, kh = lane >> 5;
-    const int wm = wv >> 1, wn = wv & 1;
-    if (DIR == TS_DIR) TSC(0);
-    for (int e = tid; e < BC2::HALO_BYTES / 16; e += NT) *(u32x4b*)(halo + 16 * e) = (u32x4b){0u, 0u, 0u, 0u};
-    if (DIR == 1)
-        for (int e = tid; e < 3 * C; e += NT) cfl[e] = coef[e];
-    // halo staging items (halo row hy, pixel px, 8-channel group sj): 18 x 16 x 8 = 2 304 = 9 per thread
-    constexpr int NL = HH * TW * CJ / NT;
-    const int sj = tid % CJ;
-    f32x4 hv[NL], hw2[DIR == 1 ? NL : 1];
-    auto halo_load = [&](int tile, int cs) {
-        const int b = tile / tiles_per_clip, r0 = (tile % tiles_per_clip) * TH;
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const int g = tid + NT * i, hy = g / (TW * CJ), px = (g / CJ) % TW;
-            const int row = r0 - 1 + hy, rc = row < 0 ? 0 : (row >= H ? H - 1 : row);      // (unconditional load, clamped row)
-            const size_t off = ((size_t)(b * H + rc) * TW + px) * C + cs * CS + 8 * sj;
-            hv[i] = *(const f32x4*)(in0 + off);
-            if (DIR == 1) hw2[i] = *(const f32x4*)(in1 + off);
-        }
-    };
-    auto halo_store = [&](int tile, int cs) {
-        const int r0 = (tile % tiles_per_clip) * TH;
-        float ca[8], cb[8], cc[8];
-        if (DIR == 1) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                ca[q] = cfl[cs * CS + 8 * sj + q]; cb[q] = cfl[C + cs * CS + 8 * sj + q]; cc[q] = cfl[2 * C + cs * CS + 8 * sj + q];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const int g = tid + NT * i, hy = g / (TW * CJ), px = (g / CJ) % TW;
-            const int row = r0 - 1 + hy;
-            const bool in = row >= 0 && row < H;
-            unsigned char* d = halo + hy * RP + (px + 1) * PS + 16 * sj;
-            if (DIR == 1) {
-                const bf16x8 z = *(const bf16x8*)&hv[i], y = *(const bf16x8*)&hw2[i];
-                bf16x8 o;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float v = ca[q] * (float)z[q] + cb[q] * (float)y[q] + cc[q];
-                    o[q] = (__bf16)(in ? v : 0.f);                       // outside the image dy is 0, not cc
-                }
-                *(bf16x8*)d = o;
-            } else {
-                *(f32x4*)d = in ? hv[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-        }
-    };
-    int a_off[MB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        const int q = wm * 128 + mb * 32 + n, pr = q / TW, pc = q % TW;
-        a_off[mb] = pr * RP + pc * PS + 16 * kh;
-    }
-    float s1[NB], s2[NB], bv[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) { s1[nb] = 0.f; s2[nb] = 0.f; bv[nb] = (DIR == 0) ? bias[wn * 64 + 32 * nb + n] : 0.f; }
-    const bf16x8* wf0 = (const bf16x8*)wfrag + (size_t)(wn * NB) * 4 * 64 + lane;
-
-    __syncthreads();                                                      // halo zeroed, coefficients in place
-    if (DIR == TS_DIR) TSC(1);
-    if (DIR == 0 && (int)blockIdx.x < n_tiles) halo_load(blockIdx.x, 0);
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int b = tile / tiles_per_clip, r0 = (tile % tiles_per_clip) * TH;
-        f32x16 acc[MB][NB];
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
-#pragma unroll 1
-        for (int cs = 0; cs < NCS; ++cs) {
-            if (DIR == 1) halo_load(tile, cs);
-            halo_store(tile, cs);
-            lds_barrier();
-            if (DIR == TS_DIR && tile == (int)blockIdx.x) { if (cs == 0) TSC(2); else TSC(4); }
-            if (DIR == 0) {       // the next unit's halo flies during this unit's MFMAs (past the end: this tile again, unused)
-                const int nt = tile + (int)gridDim.x;
-                if (cs + 1 < NCS) halo_load(tile, cs + 1);
-                else halo_load(nt < n_tiles ? nt : tile, 0);
-            }
-            // piece (tap, unit cs, 32-row block, k step) of the fragment-ordered panel = 64 lanes x 16 bytes
-            const bf16x8* wf = wf0 + (size_t)cs * (C / 32) * 4 * 64;
-            auto bload = [&](bf16x8 (&q)[2][NB], int tap, int half) {
-#pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-                        q[k2][nb] = wf[(size_t)tap * NCS * (C / 32) * 4 * 64 + (size_t)(nb * 4 + 2 * half + k2) * 64];
-            };
-            auto mma_half = [&](const bf16x8 (&q)[2][NB], int tap, int half) {
-                const int dr = tap / 3, dc = tap - 3 * dr;
-                const int t_off = dr * RP + dc * PS;
-#pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2) {
-                    bf16x8 af[MB];
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) af[mb] = *(const bf16x8*)(halo + a_off[mb] + t_off + 32 * (2 * half + k2));
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], q[k2][nb], acc[mb][nb], 0, 0, 0);
-                }
-            };
-            bf16x8 b0[2][NB], b1[2][NB];
-            bload(b0, 0, 0);
-#pragma unroll 1
-            for (int tap = 0; tap < 9; ++tap) {
-                // (sched_barrier: the compiler otherwise sinks each prefetch down to its first use - and waits for it there)
-                bload(b1, tap, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                mma_half(b0, tap, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                bload(b0, tap < 8 ? tap + 1 : 8, 0);                      // (past the end: the last piece again, unused)
-                __builtin_amdgcn_sched_barrier(0);
-                mma_half(b1, tap, 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            lds_barrier();                                                // every wave is done with this unit's halo
-            if (DIR == TS_DIR && tile == (int)blockIdx.x) { if (cs == 0) TSC(3); else TSC(5); }
-        }
-        // ---- epilogue: D register r of lane (n, kh) is MFMA row (r & 3) + 8 (r >> 2) + 4 kh, column n.  Two passes of two
-        // 32-pixel blocks: the wave writes 64 pixels x 64 channels (bf16, + bias) into its own staging region of the (free) halo
-        // area and stores them as 16-byte vectors, 8 consecutive channels per lane
-        unsigned char* stg = halo + wv * 64 * OS;
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-#pragma unroll
-            for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int pl = m2 * 32 + mfma32_row(r, lane);
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        const float v = acc[2 * ps + m2][nb][r] + bv[nb];
-                        const int q = wm * 128 + 64 * ps + pl;
-                        if (DIR == 0 && r0 + q / TW < H) { s1[nb] += v; s2[nb] += v * v; }
-                        *(__bf16*)(stg + pl * OS + 2 * (32 * nb + n)) = (__bf16)v;
-                    }
-                }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int it = lane + 64 * i, pl = it >> 3, cg = it & 7;
-                const int q = wm * 128 + 64 * ps + pl, row = r0 + q / TW, col = q % TW;
-                const u32x4b v = *(const u32x4b*)(stg + pl * OS + 16 * cg);
-                if (row < H) *(u32x4b*)(out + ((size_t)(b * H + row) * TW + col) * C + wn * 64 + 8 * cg) = v;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-        }
-        lds_barrier();                                                    // staging regions are halo again
-        if (DIR == TS_DIR && tile == (int)blockIdx.x) TSC(6);
-    }
-    if (DIR == 0 && stat != nullptr) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const float a1 = s1[nb] + __shfl_xor(s1[nb], 32), a2 = s2[nb] + __shfl_xor(s2[nb], 32);
-            if (kh == 0) {
-                const int c = wn * 64 + 32 * nb + n;
-                red[(wm * 2 + 0) * C + c] = a1; red[(wm * 2 + 1) * C + c] = a2;
-            }
-        }
-        __syncthreads();
-        for (int e = tid; e < 2 * C; e += NT) {
-            const int which = e / C, c = e % C;
-            atomicAdd(&stat[which * C + c], (double)red[(0 * 2 + which) * C + c] + (double)red[(1 * 2 + which) * C + c]);
-        }
-    }
-}
-template <int DIR>
-static int bconv2_launch(const void* in0, const void* in1, const float* coef, const void* wfrag, const float* bias, void* out,
-                         double* stat, int B, int H, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_bconv2<DIR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BC2::LDS_BYTES));
-        attr_done = true;
-    }
-    SED_CHECK_ARG((size_t)B * H * 16 * 128 < ((size_t)1 << 31), "bconv: image too large for 32-bit offsets");
-    const int tpc = (H + BC2::TH - 1) / BC2::TH, nt = B * tpc;
-    const int grid = nt < 512 ? nt : 512;
-    k_bconv2<DIR><<<grid, 256, BC2::LDS_BYTES, st>>>((const __bf16*)in0, (const __bf16*)in1, coef, (const __bf16*)wfrag, bias,
-                                                     (__bf16*)out, stat, H, tpc, nt);
-    SED_CHECK_LAUNCH();
-    return SED_OK;
-}
-// Opt-in (debug bit 20): at B = 24 the layer is 471 tiles for 512 workgroup slots - ONE tile per workgroup, so nothing is
-// prefetched across tiles and the two workgroups of a CU run their staging / MFMA / epilogue phases in lockstep.  Stamped
-// (forward, shader cycles): zero-fill 1 600, first staging 10 200, unit-0 loop 26 200 (8 000 of them the in-order vmcnt wait
-// behind the unit-1 halo prefetch), unit-1 staging 800, unit-1 loop 18 900 = the MFMA issue time of two waves per SIMD,
-// epilogue 9 700: 47.1 us forward / 53.7 dgrad against k_bconv's 47.9 / 51.1.  The k-loop is where it should be; the rest needs
-// more tiles per workgroup than this batch has.
-bool bconv_wants_fragments(bool x3, bool bf16, int C, int W) { return !x3 && bf16 && C == 128 && W == 16 && (g_sed_debug & 1048576); }
 
 template <int X3, int C, int TW, int TH, int WM, int WN, int DIR>
 static int bconv_launch(const void* in0, const void* in1, const float* coef, const void* wpk, const float* bias, void* out,
@@ -630,7 +401,6 @@ template <int DIR>
 static int bconv_dispatch(int x3, int C, int W, const void* in0, const void* in1, const float* coef, const void* wpk,
                           const float* bias, void* out, double* stat, int B, int H, hipStream_t st) {
     //            X3  C    TW  TH  WM WN
-    if (bconv_wants_fragments(x3 != 0, true, C, W)) return bconv2_launch<DIR>(in0, in1, coef, wpk, bias, out, stat, B, H, st);
 #define BCONV_CASE(XX, CC, WW, HH, MM, NN) \
     if (x3 == XX && C == CC && W == WW) return bconv_launch<XX, CC, WW, HH, MM, NN, DIR>(in0, in1, coef, wpk, bias, out, stat, B, H, st)
     BCONV_CASE(0, 128, 16, 16, 4, 2); BCONV_CASE(0, 64, 16, 32, 8, 1); BCONV_CASE(0, 128, 4, 16, 2, 4); BCONV_CASE(0, 64, 4, 16, 2, 2);

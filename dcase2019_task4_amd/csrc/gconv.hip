@@ -92,12 +92,21 @@ __global__ __launch_bounds__(256) void k_gconv(const float* __restrict__ in0, co
             const int g = tid + 256 * i, hp = g / C4, c4 = g % C4;
             const int hy = hp / HW, hx = hp % HW;
             const int row = r0 - 1 + hy, col = hx - 1;
-            v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (DIR == 1) w[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (g < HH * HW * C4 && row >= 0 && row < H && col >= 0 && col < TW) {
-                const size_t off = ((size_t)(b * H + row) * TW + col) * C + 4 * c4;
+            if (DIR == 1) {
+                // dgrad: unconditional loads from clamped coordinates - the select happens in halo_store, which needs the
+                // in-image predicate anyway (23 predicated loads kept 23 lane masks alive from here to the store:
+                // 26 - 38 scalar registers spilled at C = 128)
+                const int gc = g < HH * HW * C4 ? g : HH * HW * C4 - 1, hpc = gc / C4, c4c = gc % C4;
+                const int rowc = min(max(r0 - 1 + hpc / HW, 0), H - 1), colc = min(max(hpc % HW - 1, 0), TW - 1);
+                const size_t off = ((size_t)(b * H + rowc) * TW + colc) * C + 4 * c4c;
                 v[i] = *(const f32x4*)(in0 + off);
-                if (DIR == 1) w[i] = *(const f32x4*)(in1 + off);
+                w[i] = *(const f32x4*)(in1 + off);
+            } else {
+                v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (g < HH * HW * C4 && row >= 0 && row < H && col >= 0 && col < TW) {
+                    const size_t off = ((size_t)(b * H + row) * TW + col) * C + 4 * c4;
+                    v[i] = *(const f32x4*)(in0 + off);
+                }
             }
         }
     };
@@ -321,23 +330,23 @@ __global__ __launch_bounds__(256) void k_gwgrad(const void* __restrict__ dz_v, c
 struct GWgB {
     static constexpr int TH = 8, TW = 16, HH = 10, DS = 128 + 8, XS = HH * 16 + 8;
     static constexpr int DY_E = 3 * 64 * DS, X_E = 64 * XS;
-    static constexpr size_t STAGE_BYTES = (size_t)(DY_E + X_E) * 2 + 3 * 64 * 4, XCH_BYTES = (size_t)9 * 64 * 64 * 4;
-    static constexpr size_t LDS_BYTES = STAGE_BYTES > XCH_BYTES ? STAGE_BYTES : XCH_BYTES;
+    static constexpr size_t STAGE_BYTES = (size_t)(DY_E + X_E) * 2 + 3 * 64 * 4;
 };
 typedef __attribute__((ext_vector_type(2))) unsigned int gw_u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4g;
 __device__ __forceinline__ float gw_lo(unsigned int v) { return __builtin_bit_cast(float, v << 16); }
 __device__ __forceinline__ float gw_hi(unsigned int v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
-// NG = 2: EIGHT waves, two groups of four split every tile's K (pixels) in halves - two waves per SIMD, ONE staged copy of the
-// tile and ONE partial slab per workgroup (group 1 hands its accumulators to group 0 through LDS at the end); NG = 1: four
-// waves, two workgroups per CU (twice the partial slabs).  Measured: C = 64 (one quadrant, 256 slabs) 41 -> 30 us with
-// NG = 2 (NG = 1: 28 us but 512 slabs = 75 MB of partials for the reduce, the step is slower); C = 128 (four quadrants)
-// 104 -> ~80 us with NG = 1 at 128 slabs.
-template <int NG>
-__global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void k_gwgrad_bf16(const __bf16* __restrict__ dz, const __bf16* __restrict__ yin,
+// EIGHT waves, two groups of four that split the nine TAPS (group 0: taps 0 - 4, group 1: taps 5 - 8) - two waves per SIMD, ONE
+// staged copy of the tile and ONE partial slab per workgroup, 80 accumulator registers per wave.  Round 3 split every tile's K
+// between the groups instead: 144 accumulator registers + 56 of prefetched tile + fragments did not fit the 256 a wave has
+// at two waves per SIMD - 27 registers spilled to scratch - and group 1 handed its sums to group 0 through 144 KB of LDS
+// at the end.  A four-wave form with two workgroups per CU (C = 128, round 3) spilled as well and measures the same
+// (113 against 112 us in-step at C = 128) with twice the partial slabs for the reduce: removed.
+__global__ __launch_bounds__(512, 1) void k_gwgrad_bf16(const __bf16* __restrict__ dz, const __bf16* __restrict__ yin,
                                                       const float* __restrict__ coef, const __bf16* __restrict__ xin,
                                                       float* __restrict__ part, int C, int H, int tiles_per_clip, int n_tiles) {
     using M = MM<1>;
+    constexpr int NG = 2;                                          // wave groups (the four-wave NG = 1 form is gone, see above)
     constexpr int TH = GWgB::TH, DS = GWgB::DS, XS = GWgB::XS;
     extern __shared__ __attribute__((aligned(16))) unsigned char wsm2[];
     __bf16* dyT = (__bf16*)wsm2;
@@ -347,9 +356,10 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void k_gwgrad_bf16(const
     const int nq = C / 64, quad = blockIdx.y, co0 = (quad / nq) * 64, ci0 = (quad % nq) * 64;
     const int grp = wv >> 2, wa = (wv >> 1) & 1, wb = wv & 1;
     if (tid < 192) cf[tid] = coef[(tid / 64) * C + co0 + (tid % 64)];
-    f32x16 acc[9];
+    constexpr int NT = NG == 2 ? 5 : 9;                            // taps per wave (NG = 2: group 1 uses four of its five)
+    f32x16 acc[NT];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     // staging items: dy - 256 of (pixel group pg of 8 + one pixel either side, channel quad cq): threads 0 .. 255; x - 320 of
@@ -452,39 +462,37 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void k_gwgrad_bf16(const
             const int nt = tile + (int)gridDim.x;
             load(nt < n_tiles ? nt : tile);
         }
-        const __bf16* Ap = dyT + (size_t)(32 * wa + n) * DS + 8 * kh + (128 / NG) * grp;
-        const __bf16* Bp = xT + (size_t)(32 * wb + n) * XS + 8 * kh + (128 / NG) * grp;
+        const __bf16* Ap = dyT + (size_t)(32 * wa + n) * DS + 8 * kh;
+        const __bf16* Bp = xT + (size_t)(32 * wb + n) * XS + 8 * kh;
+        // tap t = 3 dr + dc multiplies dy copy dc (A) with x rows shifted by dr (B)
+        auto taps = [&](auto first, auto count) {
+            constexpr int T0 = decltype(first)::value, TN = decltype(count)::value;
+            constexpr int DR0 = T0 / 3, DR1 = (T0 + TN - 1) / 3;
 #pragma unroll 1
-        for (int ks = 0; ks < 8 / NG; ++ks) {
-            bf16x8 a[3], bx[3];
+            for (int ks = 0; ks < 8; ++ks) {
+                bf16x8 a[3], bx[3];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                a[d] = *(const bf16x8*)(Ap + (size_t)d * 64 * DS + 16 * ks);
-                bx[d] = *(const bf16x8*)(Bp + d * 16 + 16 * ks);
+                for (int d = 0; d < 3; ++d) a[d] = *(const bf16x8*)(Ap + (size_t)d * 64 * DS + 16 * ks);
+#pragma unroll
+                for (int d = DR0; d <= DR1; ++d) bx[d] = *(const bf16x8*)(Bp + d * 16 + 16 * ks);
+#pragma unroll
+                for (int t = T0; t < T0 + TN; ++t) acc[t - T0] = M::mma(a[t % 3], bx[t / 3], acc[t - T0]);
             }
-#pragma unroll
-            for (int t = 0; t < 9; ++t) acc[t] = M::mma(a[t % 3], bx[t / 3], acc[t]);
-        }
+        };
+        if (NG == 1) taps(std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
+        else if (grp == 0) taps(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+        else taps(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
         __syncthreads();
     }
-    // group 1 -> LDS (the staging area is free now: 9 x 64 x 64 floats = 144 KB), group 0 adds and writes the partial slab
-    float* xch = (float*)wsm2;
-    const int slot = (wv & 3) * 64 + lane;                          // [t][r][slot]: conflict-free, coalesced
-    if (NG == 2 && grp == 1) {
+    // every wave writes its own taps of the partial slab [tap][co (C)][ci (C)]
+    float* ps = part + (size_t)blockIdx.x * 9 * C * C;
+    const int t0 = NG == 2 ? 5 * grp : 0, tn = NG == 2 ? (grp ? 4 : 5) : 9;
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NT; ++t) {
+        if (t >= tn) break;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xch[(t * 16 + r) * 256 + slot] = acc[t][r];
-    }
-    if (NG == 2) __syncthreads();
-    if (grp == 0) {
-        float* ps = part + (size_t)blockIdx.x * 9 * C * C;
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                ps[((size_t)t * C + co0 + 32 * wa + mfma32_row(r, lane)) * C + ci0 + 32 * wb + n] =
-                    acc[t][r] + (NG == 2 ? xch[(t * 16 + r) * 256 + slot] : 0.f);
+        for (int r = 0; r < 16; ++r)
+            ps[((size_t)(t0 + t) * C + co0 + 32 * wa + mfma32_row(r, lane)) * C + ci0 + 32 * wb + n] = acc[t][r];
     }
 }
 
@@ -658,27 +666,24 @@ __global__ __launch_bounds__(256) void k_gwgrad_reduce(const float* __restrict__
     g_w[((size_t)co * C + ci) * 9 + tap] = s;
 }
 
-// partial slabs: capacity of the buffer (k_gwgrad_bf16<1> runs two workgroups per CU, everything else one)
-int gwgrad_slabs(int C) { return 512 / ((C / 64) * (C / 64)); }
+// partial slabs (one workgroup per CU and (co, ci) quadrant)
+int gwgrad_slabs(int C) { return 256 / ((C / 64) * (C / 64)); }
 
 int launch_gwgrad(int mode, int C, const void* dz, const void* yin, const float* coef, const void* xin, float* part, float* g_w,
                   int B, int H, int W, hipStream_t st) {
     SED_CHECK_ARG(C == 64 || C == 128, "gwgrad: C must be 64 or 128");
     const int nq = (C / 64) * (C / 64);
-    const bool two_per_cu = W == 16 && mode == SED_DTYPE_BF16 && C == 128;
-    int slabs = gwgrad_slabs(C) / (two_per_cu ? 1 : 2);
+    int slabs = gwgrad_slabs(C);
     int nt, tpc;
     if (W == 16 && mode == SED_DTYPE_BF16) {
         static bool attr = false;
         if (!attr) {
-            SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad_bf16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GWgB::STAGE_BYTES));
-            SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad_bf16<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GWgB::LDS_BYTES));
+            SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GWgB::STAGE_BYTES));
             attr = true;
         }
         tpc = (H + GWgB::TH - 1) / GWgB::TH; nt = B * tpc;
         if (slabs > nt) slabs = nt;
-        if (two_per_cu) k_gwgrad_bf16<1><<<dim3(slabs, nq), 256, GWgB::STAGE_BYTES, st>>>((const __bf16*)dz, (const __bf16*)yin, coef, (const __bf16*)xin, part, C, H, tpc, nt);
-        else k_gwgrad_bf16<2><<<dim3(slabs, nq), 512, GWgB::LDS_BYTES, st>>>((const __bf16*)dz, (const __bf16*)yin, coef, (const __bf16*)xin, part, C, H, tpc, nt);
+        k_gwgrad_bf16<<<dim3(slabs, nq), 512, GWgB::STAGE_BYTES, st>>>((const __bf16*)dz, (const __bf16*)yin, coef, (const __bf16*)xin, part, C, H, tpc, nt);
     } else if (W == 16) {
         using Cfg = GWgCfg<16>;
         static bool attr = false;

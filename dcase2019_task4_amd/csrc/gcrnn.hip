@@ -184,7 +184,6 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
     pk.bg1 = CTXF(L.bg[1]); pk.bg2 = CTXF(L.bg[2]);
     pk.zero = CTXD(L.stat1); pk.n_zero = train ? 4 * C : 0;
     pk.err = nullptr;                         // sticky: never cleared by a forward (sed_crnn_buffers_init does)
-    pk.frag1 = bconv_wants_fragments(g.mode == SED_DTYPE_BF16X3, g.mode == SED_DTYPE_BF16, C, g.W1) ? 1 : 0;
     // (The packing is independent of block 0, but forking it onto the helper stream is not an option: a forward that
     // itself runs on a forked stream - the teacher's, next to the student's - would fork a second time inside the same
     // hipGraph capture, and ROCm 7.0's hipStreamEndCapture segfaults on that nested fork.  It stays on the caller's stream.)

@@ -12,17 +12,8 @@ struct GenPackArgs {
     float *bg1, *bg2;                           // GLU bias folded with beta [C]
     double* zero; int n_zero;                   // fp64 accumulators to clear
     int* err;                                   // unused (the spin-timeout counter is sticky: cleared by sed_crnn_buffers_init only)
-    int frag1;                                  // block 1's panels in MFMA-fragment order (bconv.hip k_bconv2: see bconv_frag_index)
 };
-// fragment-major position of panel element (row n, k = tap * C + c) for k_bconv2: one 1 KB piece per (tap, 64-channel half,
-// 32-row block, k step of 16) holds lane (n % 32, (c % 16) / 8)'s eight k-consecutive values
-__host__ __device__ inline int bconv_frag_index(int C, int n, int tap, int c) {
-    const int kc = c / 64, kin = c % 64, ks = kin / 16, kh = (kin % 16) / 8, e8 = kin % 8;
-    return ((((tap * (C / 64) + kc) * (C / 32) + n / 32) * 4 + ks) * 64 + kh * 32 + n % 32) * 8 + e8;
-}
 int launch_gen_pack(const GenPackArgs& a, int mode, hipStream_t st);
-// true when launch_bconv_fwd / dgrad read the panel in fragment order (k_bconv2: bf16 mode, C = 128, W = 16, debug bit 20 set)
-bool bconv_wants_fragments(bool x3, bool bf16, int C, int W);
 int launch_gconv_fwd(int mode, int C, const float* in, const void* wpk, const float* bias, float* y, double* stat, int B, int H,
                      int W, hipStream_t st);
 int launch_gconv_dgrad(int mode, int C, const float* dz, const float* yin, const float* coef, const void* wpkT, float* dx, int B,

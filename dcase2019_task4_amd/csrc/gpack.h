@@ -30,9 +30,8 @@ __device__ __forceinline__ void gen_pack_body(const GenPackArgs& a, int i) {
         } else {
             E* wpk = (E*)(layer ? a.wpk2 : a.wpk1);
             E* wpkT = (E*)(layer ? a.wpkT2 : a.wpkT1);
-            const int o = (MODE == 1 && layer == 0 && a.frag1) ? bconv_frag_index(C, n, tap, k) : e;
-            wpk[o] = M::cvt(wf);
-            if (wpkT) wpkT[o] = M::cvt(wt);
+            wpk[e] = M::cvt(wf);
+            if (wpkT) wpkT[e] = M::cvt(wt);
         }
     }
     if (i < 2 * CC) {

@@ -66,8 +66,11 @@ int launch_grec_pack(const float* w_hh_f, const float* w_hh_r, void* wp, void* w
 #define GREC_TBB 8                       // (4 until the end of round 3: a block boundary costs ~2 600 cycles - 127 -> 123 us)
 // one wave-instruction: 64 lanes x 16 bytes from global straight into 1 KB of LDS (global_load_lds_dwordx4: no VGPRs; the
 // destination is the wave-uniform `lds` + 16 * lane, the source address is per lane).  Completion: s_waitcnt vmcnt + barrier.
-__device__ __forceinline__ void dma16(const float* gsrc_lane, float* lds_wave) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+// The source is given as a wave-uniform base + 16 * lane so that the instruction takes its scalar-base form (saddr + 32-bit
+// voffset): per-lane 64-bit pointers for three source tensors were six loop-invariant VGPRs the backward kernel does not have.
+__device__ __forceinline__ void dma16(const float* gsrc_wave, int lane, float* lds_wave) {
+    const char* p = (const char*)gsrc_wave + (unsigned)(16 * lane);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                      (__attribute__((address_space(3))) void*)lds_wave, 16, 0, 0);
 }
 
@@ -80,7 +83,8 @@ __global__ __launch_bounds__(GREC_T) void k_grec_fwd(const float* __restrict__ g
     __shared__ __attribute__((aligned(16))) float gis[2][TB][3][H];
     __shared__ __attribute__((aligned(16))) float outs[TB][5][H];            // r, z, n, gh_n, h
     const int chain = blockIdx.x, b = chain >> 1, dir = chain & 1;
-    const int t = threadIdx.x, up = t >> 2, kq = t & 3, lane = t & 63, wv = t >> 6;
+    const int t = threadIdx.x, up = t >> 2, kq = t & 3, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);        // wave-uniform: the block I/O addressing below stays scalar
     const int u = 2 * up + (kq & 1);                              // the unit whose gates this lane forms (kq >= 2: duplicates)
     const bool writer = kq < 2;
     const float* bhh = dir ? b_hh_r : b_hh_f;
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(GREC_T) void k_grec_fwd(const float* __restrict__ g
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int i0 = 64 * (wv + 8 * k), st = i0 / 192, rem0 = i0 % 192, s = s0 + st;
-            if (s < T) dma16(gi + ((size_t)(b * T + t_of(s)) * 2 + dir) * 3 * H + 4 * (rem0 + lane), &gis[buf][0][0][0] + 4 * i0);
+            if (s < T) dma16(gi + ((size_t)(b * T + t_of(s)) * 2 + dir) * 3 * H + 4 * rem0, lane, &gis[buf][0][0][0] + 4 * i0);
         }
     };
     auto out_flush = [&](int s0) {
@@ -186,7 +190,8 @@ __global__ __launch_bounds__(GREC_T) void k_grec_bwd(const float* __restrict__ d
     __shared__ __attribute__((aligned(16))) float ins[2][TB][6][H];          // d_out, r, z, n, gh_n, h_prev
     __shared__ __attribute__((aligned(16))) float outs[TB][5][H];            // dr, dz, dn, dgh_n, h_prev
     const int chain = blockIdx.x, b = chain >> 1, dir = chain & 1;
-    const int t = threadIdx.x, up = t >> 2, gq = t & 3, lane = t & 63, wv = t >> 6;
+    const int t = threadIdx.x, up = t >> 2, gq = t & 3, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);        // wave-uniform: the block I/O addressing below stays scalar
     const int j = 2 * up + (gq & 1);                               // the column whose gate gradients this lane forms
     const bool writer = gq < 2;
     unsigned int wc[2][96];                                        // columns 2 up + {0, 1}, gate rows [192 gq, 192 gq + 192)
@@ -212,12 +217,12 @@ __global__ __launch_bounds__(GREC_T) void k_grec_bwd(const float* __restrict__ d
                 const size_t bt = (size_t)(b * T + tt);
                 float* dst = &ins[buf][0][0][0] + 4 * i0;
                 if (rem0 < 64) {
-                    dma16(d_out + bt * 2 * H + dir * H + 4 * lane, dst);
+                    dma16(d_out + bt * 2 * H + dir * H, lane, dst);
                 } else if (rem0 < 320) {
-                    dma16(gates + (bt * 2 + dir) * 4 * H + 4 * (rem0 - 64 + lane), dst);
+                    dma16(gates + (bt * 2 + dir) * 4 * H + 4 * (rem0 - 64), lane, dst);
                 } else {
                     const int tp = dir ? tt + 1 : tt - 1;
-                    if (tp >= 0 && tp < T) dma16(out + (size_t)(b * T + tp) * 2 * H + dir * H + 4 * lane, dst);
+                    if (tp >= 0 && tp < T) dma16(out + (size_t)(b * T + tp) * 2 * H + dir * H, lane, dst);
                     else *(f32x4*)(dst + 4 * lane) = (f32x4){0.f, 0.f, 0.f, 0.f};      // h before the first step
                 }
             }

@@ -314,6 +314,7 @@ class WaveformFrontEnd:
             self.std = torch.tensor(np.asarray(scaler.std_), dtype=torch.float64, device=step.device)
         self.key = torch.tensor([(int(seed) * 0x9E3779B97F4A7C15 + 0x2545F4914F6CDD1D) & 0x7FFFFFFFFFFFFFFF],
                                 dtype=torch.int64, device=step.device)
+        _lib.check(self.l.sed_seed_advance(_lib.ptr(self.key), _lib.stream_ptr()), "sed_seed_advance")
         self.overlap = bool(overlap) and step.single_graph and step.teacher is not None
         # how much of the chip the next batch's STFT may take while the step's recurrences run (one workgroup = one CU):
         # B x 2 recurrence workgroups need their CUs first.  Serial extraction uses the whole chip.
@@ -351,7 +352,6 @@ class WaveformFrontEnd:
         st = self.step
         x = st.x if x is None else x
         x_ema = (st.x_ema if st.teacher is not None else None) if x_ema is None else x_ema
-        _lib.check(self.l.sed_seed_advance(_lib.ptr(self.key), _lib.stream_ptr()), "sed_seed_advance")
         _lib.check(self.l.sed_mel_frames(_lib.ptr(self.waves), self.n, self.ns, c.hop_length, c.n_window,
                                          _lib.ptr(self.fx.mel_basis), c.n_mels, _lib.ptr(self.mel), _lib.ptr(self.ws),
                                          self.ws.numel(), _lib.FFT_DTYPES[self.fx.fft_dtype], int(workgroups), _lib.stream_ptr()),
@@ -360,6 +360,9 @@ class WaveformFrontEnd:
                                                _lib.ptr(self.std), _lib.ptr(self.key), _lib.ptr(x), _lib.ptr(x_ema),
                                                _lib.ptr(self.ws_t), self.ws_t.numel(), _lib.stream_ptr()),
                    "sed_logmel_transform")
+        # the key moves on AFTER the extraction (one tiny kernel at the tail of the chain instead of its head, where it delayed
+        # the STFT by a launch); the constructor advanced it once, so extraction k draws with key_0 + (k + 1) strides as before
+        _lib.check(self.l.sed_seed_advance(_lib.ptr(self.key), _lib.stream_ptr()), "sed_seed_advance")
         if target is not None:
             target.copy_(self._staged_target, non_blocking=True)
 

@@ -15,6 +15,7 @@
 //     LDS reads per 32 x 32 block it comes from TWO extra MFMAs against an identity fragment: D = y I, exact in fp32.
 //   * 32-pixel row blocks (4 pooled pixels) are staged through a double-buffered padded LDS tile with 16-byte loads, the
 //     next block's loads in flight during the current block's MFMAs: one barrier per row block, several workgroups per CU.
+#include <type_traits>
 #include "gen.h"
 #include "kernels.h"
 #include "gkernels.h"
@@ -55,9 +56,10 @@ struct BGluCfg {
 
 // this wave's B fragments of the folded weights (rows 32 cb + n of W'), its folded bias and the gate's scale / shift
 //   aff: LDS [2][C] = scale (gamma * invstd) | shift (beta - mean * scale) of the BatchNorm affine
-template <int C>
+template <int C, int X3 = 0>
 __device__ __forceinline__ void bglu_fold(const float* __restrict__ wglu, const float* __restrict__ bglu, const float* aff, int cb,
-                                          int lane, bf16x8 (&bw)[C / 16], float& b_fold, float& sc, float& sh) {
+                                          int lane, bf16x8 (&bw)[C / 16], float& b_fold, float& sc, float& sh,
+                                          bf16x8 (*bl)[C / 16] = nullptr /* X3: the lo parts of W' */) {
     const int n = lane & 31, kh = lane >> 5, co = 32 * cb + n;
     float part = 0.f;
 #pragma unroll
@@ -67,7 +69,9 @@ __device__ __forceinline__ void bglu_fold(const float* __restrict__ wglu, const 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float w = e < 4 ? w0[e] : w1[e - 4];
-            bw[ks][e] = (__bf16)(w * aff[k0 + e]);
+            const float wf = w * aff[k0 + e];
+            bw[ks][e] = (__bf16)wf;
+            if constexpr (X3 != 0) (*bl)[ks][e] = (__bf16)(wf - (float)bw[ks][e]);
             part = fmaf(w, aff[C + k0 + e], part);
         }
     }
@@ -92,8 +96,11 @@ __device__ __forceinline__ void bglu_item(int g, int& rl, int& m, int& j) {
 }
 
 // PB: the pooled output is stored as bf16 (block 1); block 2's output p2 feeds the fp32 GRU
-template <int C, int PB>
-__global__ __launch_bounds__(256) void k_bglu_fwd(const __bf16* __restrict__ y, GBnArgs bnp, const float* __restrict__ wglu,
+// X3 (SED_DTYPE_BF16X3): y is fp32 in HBM and split hi + lo on its way into LDS (two tile planes); lin = y_hi W'_hi + y_hi W'_lo +
+// y_lo W'_hi, the gate's y = (y_hi + y_lo) I - three / four MFMAs where the bf16 mode has one / two, fp32 output.  Replaces
+// gglu.hip's exact-fp32 kernel in that mode (88 us per launch at C = 128: weights streamed through LDS with a barrier per chunk).
+template <int C, int PB, int X3 = 0>
+__global__ __launch_bounds__(256) void k_bglu_fwd(const void* __restrict__ y_v, GBnArgs bnp, const float* __restrict__ wglu,
                                                    const float* __restrict__ bglu, void* __restrict__ p_v, int H, int W, int Ho,
                                                    int Wo, int Q, int block_id, int use_drop, float p_drop,
                                                    const uint64_t* __restrict__ seed_ptr, uint16_t* __restrict__ mask_out,
@@ -101,10 +108,13 @@ __global__ __launch_bounds__(256) void k_bglu_fwd(const __bf16* __restrict__ y, 
     using Cfg = BGluCfg<C>;
     using PT = typename Stor<PB>::T;
     constexpr int NB = Cfg::NB, KS = Cfg::KS, RPR = Cfg::RPR, PS = Cfg::PS, TILE = Cfg::TILE;
-    __shared__ __attribute__((aligned(16))) unsigned char tile[2][RPR][TILE];
+    constexpr int NPL = X3 ? 2 : 1;                                     // tile planes (hi | lo)
+    __shared__ __attribute__((aligned(16))) unsigned char tile[2][NPL][RPR][TILE];
     __shared__ float bn_s[2 * C];
     __shared__ float aff[2 * C];
     PT* p = (PT*)p_v;
+    using YT = typename std::conditional<X3 != 0, float, __bf16>::type;
+    const YT* y = (const YT*)y_v;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), n = lane & 31, kh = lane >> 5;
     const int rl = wv / NB, cb = wv % NB;
     if (tid < C) {
@@ -113,11 +123,12 @@ __global__ __launch_bounds__(256) void k_bglu_fwd(const __bf16* __restrict__ y, 
         aff[tid] = s; aff[C + tid] = bnp.beta[tid] - bn_s[tid] * s;
     }
     __syncthreads();
-    bf16x8 bw[KS], idf[2];
+    bf16x8 bw[KS], bl[X3 ? KS : 1], idf[2];
     float b_fold, sc, sh;
-    bglu_fold<C>(wglu, bglu, aff, cb, lane, bw, b_fold, sc, sh);
+    if constexpr (X3 != 0) bglu_fold<C, 1>(wglu, bglu, aff, cb, lane, bw, b_fold, sc, sh, &bl);
+    else bglu_fold<C>(wglu, bglu, aff, cb, lane, bw, b_fold, sc, sh);
     bglu_identity(lane, idf);
-    if (wfold_out != nullptr && blockIdx.x == 0 && rl == 0) {
+    if (!X3 && wfold_out != nullptr && blockIdx.x == 0 && rl == 0) {
         // workgroup 0 publishes the folded weights W' [C][C] (bf16) and bias b' [C] for the backward kernel, which then
         // starts from two 16-byte-vector copies instead of redoing the fold in every workgroup
 #pragma unroll
@@ -129,7 +140,7 @@ __global__ __launch_bounds__(256) void k_bglu_fwd(const __bf16* __restrict__ y, 
     const uint32_t thr = drop_thresh8(p_drop);
     const float scp = 0.125f * (use_drop ? drop_scale8(p_drop) : 1.0f);
     const int n_rb = (Q + 3) / 4, n_round = (n_rb + RPR - 1) / RPR;
-    f32x4 st[2];
+    f32x4 st[2][X3 ? 2 : 1];                                            // an item = 8 channels of one pixel: 16 B of bf16 / 32 B of fp32
     auto load = [&](int round) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -138,8 +149,11 @@ __global__ __launch_bounds__(256) void k_bglu_fwd(const __bf16* __restrict__ y, 
             const int rb = round * RPR + r2, q = rb * 4 + (m >> 3);
             const bool ok = round < n_round && q < Q;
             const int pix = gen_rb_pixel(ok ? q : 0, (m >> 2) & 1, m & 3, H, W, Ho, Wo);
-            st[i] = *(const f32x4*)(y + (size_t)pix * C + 8 * j);                // unconditional (clamped): no branch, no wait
-            if (!ok) st[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int hhalf = 0; hhalf < (X3 ? 2 : 1); ++hhalf) {
+                st[i][hhalf] = *(const f32x4*)((const char*)(y + (size_t)pix * C + 8 * j) + 16 * hhalf);    // unconditional (clamped)
+                if (!ok) st[i][hhalf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
         }
     };
     auto store = [&](int buf) {
@@ -147,7 +161,19 @@ __global__ __launch_bounds__(256) void k_bglu_fwd(const __bf16* __restrict__ y, 
         for (int i = 0; i < 2; ++i) {
             int r2, m, j;
             bglu_item<C>(tid + 256 * i, r2, m, j);
-            *(f32x4*)(&tile[buf][r2][0] + m * PS + 16 * j) = st[i];
+            if constexpr (X3 != 0) {
+                bf16x8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = e < 4 ? st[i][0][e] : st[i][1][e - 4];
+                    hi[e] = (__bf16)v;
+                    lo[e] = (__bf16)(v - (float)hi[e]);
+                }
+                *(bf16x8*)(&tile[buf][0][r2][0] + m * PS + 16 * j) = hi;
+                *(bf16x8*)(&tile[buf][1][r2][0] + m * PS + 16 * j) = lo;
+            } else {
+                *(f32x4*)(&tile[buf][0][r2][0] + m * PS + 16 * j) = st[i][0];
+            }
         }
     };
     load(blockIdx.x);
@@ -159,16 +185,26 @@ __global__ __launch_bounds__(256) void k_bglu_fwd(const __bf16* __restrict__ y, 
         load(round + gridDim.x);                                         // flies during this round's MFMAs and epilogue
         const int rb = round * RPR + rl, q0 = rb * 4;
         if (rb < n_rb) {
-            const unsigned char* tp = &tile[buf][rl][0] + n * PS + 16 * kh;
+            const unsigned char* tp = &tile[buf][0][rl][0] + n * PS + 16 * kh;
             f32x16 lin, yid;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { lin[r] = 0.f; yid[r] = 0.f; }
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                lin = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(tp + 32 * ks), bw[ks], lin, 0, 0, 0);
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 a = *(const bf16x8*)(tp + 32 * ks);
+                lin = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[ks], lin, 0, 0, 0);
+                if constexpr (X3 != 0) {
+                    lin = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bl[ks], lin, 0, 0, 0);
+                    lin = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(tp + RPR * TILE + 32 * ks), bw[ks], lin, 0, 0, 0);
+                }
+            }
             // y[pixel][this wave's channels] in the accumulator layout: the two k-steps of the block against the identity
             yid = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(tp + 64 * cb), idf[0], yid, 0, 0, 0);
             yid = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(tp + 64 * cb + 32), idf[1], yid, 0, 0, 0);
+            if constexpr (X3 != 0) {
+                yid = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(tp + RPR * TILE + 64 * cb), idf[0], yid, 0, 0, 0);
+                yid = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(tp + RPR * TILE + 64 * cb + 32), idf[1], yid, 0, 0, 0);
+            }
             const int c = 32 * cb + n;
             uint32_t m16 = 0xffffu;
             if (use_drop) {
@@ -190,14 +226,14 @@ __global__ __launch_bounds__(256) void k_bglu_fwd(const __bf16* __restrict__ y, 
     }
 }
 
-template <int C, int PB>
+template <int C, int PB, int X3 = 0>
 static int bglu_fwd_launch(const void* y, const GBnArgs& bn, const float* wglu, const float* bglu, void* p, int B, int H, int W,
                            int block_id, int use_drop, float p_drop, const uint64_t* seed, uint16_t* mask_out, void* wfold_out,
                            float* bfold_out, hipStream_t st) {
     const int Ho = H / 2, Wo = W / 4, Q = B * Ho * Wo, n_rb = (Q + 3) / 4, n_round = (n_rb + BGluCfg<C>::RPR - 1) / BGluCfg<C>::RPR;
     const int grid = n_round < 512 ? n_round : 512;          // two workgroups per CU: each pays the fold of its weights once
-    k_bglu_fwd<C, PB><<<grid, 256, 0, st>>>((const __bf16*)y, bn, wglu, bglu, p, H, W, Ho, Wo, Q, block_id, use_drop, p_drop, seed, mask_out,
-                                           (__bf16*)wfold_out, bfold_out);
+    k_bglu_fwd<C, PB, X3><<<grid, 256, 0, st>>>(y, bn, wglu, bglu, p, H, W, Ho, Wo, Q, block_id, use_drop, p_drop, seed, mask_out,
+                                               (__bf16*)wfold_out, bfold_out);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
@@ -210,6 +246,15 @@ int launch_bglu_fwd(int C, const void* y, const GBnArgs& bn, const float* wglu, 
     BGLU_CASE(64, 0); BGLU_CASE(64, 1); BGLU_CASE(128, 0); BGLU_CASE(128, 1);
 #undef BGLU_CASE
     sed_set_error("bglu forward: unsupported channels %d", C);
+    return SED_ERR_UNSUPPORTED;
+}
+// SED_DTYPE_BF16X3: fp32 y in, fp32 p out, split operands; the backward of this mode (gglu.hip) reads what the packing pass and
+// the BatchNorm record provide, nothing the forward kernel publishes
+int launch_bglu_fwd_x3(int C, const void* y, const GBnArgs& bn, const float* wglu, const float* bglu, void* p, int B, int H, int W,
+                       int block_id, int use_drop, float p_drop, const uint64_t* seed, uint16_t* mask_out, hipStream_t st) {
+    if (C == 64) return bglu_fwd_launch<64, 0, 1>(y, bn, wglu, bglu, p, B, H, W, block_id, use_drop, p_drop, seed, mask_out, nullptr, nullptr, st);
+    if (C == 128) return bglu_fwd_launch<128, 0, 1>(y, bn, wglu, bglu, p, B, H, W, block_id, use_drop, p_drop, seed, mask_out, nullptr, nullptr, st);
+    sed_set_error("bglu forward (split operands): unsupported channels %d", C);
     return SED_ERR_UNSUPPORTED;
 }
 

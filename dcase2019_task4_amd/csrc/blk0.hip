@@ -260,6 +260,13 @@ template <int NH>
 struct Blk0W<NH, 1> {
     blk0_bf16x8 bw[2 * NH];   // B fragments, k = 8 (lane >> 5) + 0..7 (taps >= 10 are zero)
 };
+// MODE 2 (SED_DTYPE_BF16X3): patch and folded weights split hi + lo (two bf16 each), the tile is hi hi + hi lo + lo hi:
+// three K = 16 bf16 MFMAs (48 cycles) instead of the five exact-fp32 ones (640) at ~2^-16 per product; everything downstream
+// as in MODE 0 (fp32 storage, the backward's D / E sums on split operands).
+template <int NH>
+struct Blk0W<NH, 2> {
+    blk0_bf16x8 bw[2 * NH], bl[2 * NH];
+};
 template <int NH, int MODE>
 __device__ __forceinline__ void blk0_load_w(Blk0W<NH, MODE>& W, const float* __restrict__ wz, const float* __restrict__ wl, int lane) {
     const int n = lane & 31, kh = lane >> 5;
@@ -282,8 +289,13 @@ __device__ __forceinline__ void blk0_load_w(Blk0W<NH, MODE>& W, const float* __r
             for (int i = 0; i < 8; ++i) {
                 const int k = 8 * kh + i, kc = k < 10 ? k : 0;
                 const float l = wl[(32 * h + n) * 12 + kc], z = wz[(32 * h + n) * 12 + kc] * SED_NEG_LOG2E;
-                W.bw[h][i] = (__bf16)(k < 10 ? l : 0.f);
-                W.bw[NH + h][i] = (__bf16)(k < 10 ? z : 0.f);
+                const float lv = k < 10 ? l : 0.f, zv = k < 10 ? z : 0.f;
+                W.bw[h][i] = (__bf16)lv;
+                W.bw[NH + h][i] = (__bf16)zv;
+                if constexpr (MODE == 2) {
+                    W.bl[h][i] = (__bf16)(lv - (float)W.bw[h][i]);
+                    W.bl[NH + h][i] = (__bf16)(zv - (float)W.bw[NH + h][i]);
+                }
             }
     }
 }
@@ -291,6 +303,7 @@ __device__ __forceinline__ void blk0_load_w(Blk0W<NH, MODE>& W, const float* __r
 template <int MODE> struct Blk0A;
 template <> struct Blk0A<0> { float v[5]; };           // taps 2 s + kh
 template <> struct Blk0A<1> { blk0_bf16x8 v; };        // taps 8 kh + 0..7 (tap 9 = the constant 1, taps >= 10 zero)
+template <> struct Blk0A<2> { blk0_bf16x8 v, lo; };    // the same taps, hi and lo parts
 template <int MODE>
 __device__ __forceinline__ void blk0_load_a(Blk0A<MODE>& A, const float* xb, int base, int kh) {
     if constexpr (MODE == 0) {
@@ -301,11 +314,16 @@ __device__ __forceinline__ void blk0_load_a(Blk0A<MODE>& A, const float* xb, int
         }
     } else {
         // kh = 0: taps 0 .. 7; kh = 1: tap 8, the constant, six zeros (those lanes read tap 8 once and clamp the rest)
-        const float t0 = xb[base + (kh ? 2 * XS_W + 2 : 0)];
-        A.v[0] = (__bf16)t0;
-        A.v[1] = (__bf16)(kh ? 1.0f : xb[base + 1]);
+        float t[8];
+        t[0] = xb[base + (kh ? 2 * XS_W + 2 : 0)];
+        t[1] = kh ? 1.0f : xb[base + 1];
 #pragma unroll
-        for (int i = 2; i < 8; ++i) A.v[i] = (__bf16)(kh ? 0.f : xb[base + (i / 3) * XS_W + (i % 3)]);
+        for (int i = 2; i < 8; ++i) t[i] = kh ? 0.f : xb[base + (i / 3) * XS_W + (i % 3)];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            A.v[i] = (__bf16)t[i];
+            if constexpr (MODE == 2) A.lo[i] = (__bf16)(t[i] - (float)A.v[i]);
+        }
     }
 }
 template <int NH, int MODE>
@@ -321,6 +339,12 @@ __device__ __forceinline__ void blk0_mma(const Blk0A<MODE>& A, const Blk0W<NH, M
     } else {
         al = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, W.bw[h], al, 0, 0, 0);
         az = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, W.bw[NH + h], az, 0, 0, 0);
+        if constexpr (MODE == 2) {
+            al = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, W.bl[h], al, 0, 0, 0);
+            az = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, W.bl[NH + h], az, 0, 0, 0);
+            al = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.lo, W.bw[h], al, 0, 0, 0);
+            az = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.lo, W.bw[NH + h], az, 0, 0, 0);
+        }
     }
 }
 __device__ __forceinline__ void blk0_load_xs(float* xs, const float* __restrict__ x, int b, int T, int t0, int tid) {
@@ -618,7 +642,7 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
                 // 2 wv + kh + tap / 3 (tap 9 = the constant 1, taps >= 10 zero: clamped address, then select).
                 // MODE 0 (fp32 arithmetic): every operand split v = hi + lo into two bf16 (lo = bf16(v - hi)), three products
                 // hi hi + hi lo + lo hi - the dropped lo lo term is 2^-16 of a product, below the fp32 rounding of the sums.
-                constexpr int NP = MODE == 0 ? 2 : 1;
+                constexpr int NP = MODE != 1 ? 2 : 1;
                 blk0_bf16x8 pT[NP][2];
                 {
                     const int tc = n < 9 ? n : 0;
@@ -629,7 +653,7 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
                         const float v = n < 9 ? src[r] : other;
                         const __bf16 hi = (__bf16)v;
                         pT[0][r >> 3][r & 7] = hi;
-                        if constexpr (MODE == 0) pT[1][r >> 3][r & 7] = (__bf16)(v - (float)hi);
+                        if constexpr (MODE != 1) pT[1][r >> 3][r & 7] = (__bf16)(v - (float)hi);
                     }
                 }
 #pragma unroll
@@ -646,7 +670,7 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
                         const __bf16 lh = (__bf16)dl, zh = (__bf16)dzg;
                         fl[0][r >> 3][r & 7] = lh;
                         fz[0][r >> 3][r & 7] = zh;
-                        if constexpr (MODE == 0) {
+                        if constexpr (MODE != 1) {
                             fl[1][r >> 3][r & 7] = (__bf16)(dl - (float)lh);
                             fz[1][r >> 3][r & 7] = (__bf16)(dzg - (float)zh);
                         }
@@ -655,7 +679,7 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
                     for (int hf = 0; hf < 2; ++hf) {
                         accD[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pT[0][hf], fl[0][hf], accD[h], 0, 0, 0);
                         accE[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pT[0][hf], fz[0][hf], accE[h], 0, 0, 0);
-                        if constexpr (MODE == 0) {
+                        if constexpr (MODE != 1) {
                             accD[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pT[0][hf], fl[1][hf], accD[h], 0, 0, 0);
                             accE[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pT[0][hf], fz[1][hf], accE[h], 0, 0, 0);
                             accD[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pT[1][hf], fl[0][hf], accD[h], 0, 0, 0);
@@ -882,6 +906,7 @@ int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const flo
 #define BLK0_FWD(NH, DROP, SAVE)                          \
     do {                                                  \
         if (g.mode == 1) BLK0_FWD_M(NH, DROP, SAVE, 1);   \
+        else if (g.mode == 2) BLK0_FWD_M(NH, DROP, SAVE, 2);   \
         else BLK0_FWD_M(NH, DROP, SAVE, 0);               \
     } while (0)
 #define BLK0_FWD_NH(NH)                                              \
@@ -921,6 +946,8 @@ int launch_blk0_backward(const Geo& g, const float* x, const float* w0, const fl
 #define BLK0_BWD(NH, MODE, NHT, GRID) \
     k_blk0_bwd<NH, MODE, NHT><<<dim3(nt < (GRID) ? nt : (GRID), BLK0_YGRID((NHT) / (NH))), 256, 0, st>>>(x, wz, wl, dp0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, mask_in, de, g_sed_debug & 1)
     if (g.C == 64 && g.mode == 1) BLK0_BWD(2, 1, 2, 512);
+    else if (g.C == 64 && g.mode == 2) BLK0_BWD(2, 2, 2, 512);
+    else if (g.C == 128 && g.mode == 2) BLK0_BWD(2, 2, 4, BLK0_GRID128);
     else if (g.C == 64) BLK0_BWD(2, 0, 2, 512);
     else if (g.C == 128 && g.mode == 1) BLK0_BWD(2, 1, 4, BLK0_GRID128);
     else if (g.C == 128) BLK0_BWD(2, 0, 4, BLK0_GRID128);

@@ -331,27 +331,49 @@ struct GWgB {
     static constexpr int TH = 8, TW = 16, HH = 10, DS = 128 + 8, XS = HH * 16 + 8;
     static constexpr int DY_E = 3 * 64 * DS, X_E = 64 * XS;
     static constexpr size_t STAGE_BYTES = (size_t)(DY_E + X_E) * 2 + 3 * 64 * 4;
+    // split-operand mode: a hi and a lo plane of both operands
+    static constexpr size_t STAGE_BYTES_X3 = (size_t)(DY_E + X_E) * 4 + 3 * 64 * 4;
 };
 typedef __attribute__((ext_vector_type(2))) unsigned int gw_u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4g;
 __device__ __forceinline__ float gw_lo(unsigned int v) { return __builtin_bit_cast(float, v << 16); }
 __device__ __forceinline__ float gw_hi(unsigned int v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
+// four fp32 values -> packed bf16 pairs of their hi parts and of their lo parts (v - hi, exact in fp32; RNE both times)
+__device__ __forceinline__ void gw_split4(const float (&v)[4], gw_u32x2& hi, gw_u32x2& lo) {
+    const bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    const bf16x4 l = {(__bf16)(v[0] - (float)h[0]), (__bf16)(v[1] - (float)h[1]), (__bf16)(v[2] - (float)h[2]), (__bf16)(v[3] - (float)h[3])};
+    hi = __builtin_bit_cast(gw_u32x2, h);
+    lo = __builtin_bit_cast(gw_u32x2, l);
+}
 // EIGHT waves, two groups of four that split the nine TAPS (group 0: taps 0 - 4, group 1: taps 5 - 8) - two waves per SIMD, ONE
 // staged copy of the tile and ONE partial slab per workgroup, 80 accumulator registers per wave.  Round 3 split every tile's K
 // between the groups instead: 144 accumulator registers + 56 of prefetched tile + fragments did not fit the 256 a wave has
 // at two waves per SIMD - 27 registers spilled to scratch - and group 1 handed its sums to group 0 through 144 KB of LDS
 // at the end.  A four-wave form with two workgroups per CU (C = 128, round 3) spilled as well and measures the same
 // (113 against 112 us in-step at C = 128) with twice the partial slabs for the reduce: removed.
-__global__ __launch_bounds__(512, 1) void k_gwgrad_bf16(const __bf16* __restrict__ dz, const __bf16* __restrict__ yin,
-                                                      const float* __restrict__ coef, const __bf16* __restrict__ xin,
-                                                      float* __restrict__ part, int C, int H, int tiles_per_clip, int n_tiles) {
+//   X3 = 0  SED_DTYPE_BF16: dz, y, x are stored as bf16; single products; the next tile's loads fly during the MFMAs
+//   X3 = 1  SED_DTYPE_BF16X3: fp32 storage; dy and x are split hi + lo on their way into LDS (two planes each, 148 KB) and
+//           every tap is hi hi + hi lo + lo hi - the weight gradient of conv block 1 on the bf16 MFMA at ~2^-16 per product
+//           (k_gwgrad<16, 0>, the exact-fp32 MFMA kernel it replaces in this mode, was 28 % of the wide step).  The tile
+//           is loaded at the top of its iteration (fp32 staging registers for a tile in flight do not fit beside the
+//           accumulators).
+template <int X3>
+__global__ __launch_bounds__(512, 1) void k_gwgrad_bf16(const void* __restrict__ dz_v, const void* __restrict__ yin_v,
+                                                       const float* __restrict__ coef, const void* __restrict__ xin_v,
+                                                       float* __restrict__ part, int C, int H, int tiles_per_clip, int n_tiles) {
     using M = MM<1>;
+    using S = typename std::conditional<X3 != 0, float, __bf16>::type;
+    using LV = typename std::conditional<X3 != 0, f32x4, gw_u32x2>::type;        // four channels of one pixel as loaded
     constexpr int NG = 2;                                          // wave groups (the four-wave NG = 1 form is gone, see above)
     constexpr int TH = GWgB::TH, DS = GWgB::DS, XS = GWgB::XS;
+    constexpr int NP = X3 ? 2 : 1;                                 // operand planes in LDS
     extern __shared__ __attribute__((aligned(16))) unsigned char wsm2[];
-    __bf16* dyT = (__bf16*)wsm2;
-    __bf16* xT = dyT + GWgB::DY_E;
-    float* cf = (float*)(xT + GWgB::X_E);
+    __bf16* dyT = (__bf16*)wsm2;                                   // [plane][3 copies][64][DS]
+    __bf16* xT = dyT + NP * GWgB::DY_E;                            // [plane][64][XS]
+    float* cf = (float*)(xT + NP * GWgB::X_E);
+    const S* dz = (const S*)dz_v;
+    const S* yin = (const S*)yin_v;
+    const S* xin = (const S*)xin_v;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 31, kh = lane >> 5;
     const int nq = C / 64, quad = blockIdx.y, co0 = (quad / nq) * 64, ci0 = (quad % nq) * 64;
     const int grp = wv >> 2, wa = (wv >> 1) & 1, wb = wv & 1;
@@ -363,15 +385,14 @@ __global__ __launch_bounds__(512, 1) void k_gwgrad_bf16(const __bf16* __restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     // staging items: dy - 256 of (pixel group pg of 8 + one pixel either side, channel quad cq): threads 0 .. 255; x - 320 of
-    // (halo row hr, column group cg, channel quad cq): NG = 2: threads 256 .. 511, and 0 .. 63 a second one; NG = 1: items
-    // tid and 256 + tid.  Loads are unconditional from clamped addresses, the selects follow (see k_gwgrad).
-    constexpr int NX = NG == 1 ? 2 : 1;
-    const bool dy_thread = NG == 1 || tid < 256;
+    // (halo row hr, column group cg, channel quad cq): threads 256 .. 511, and 0 .. 63 a second one.  Loads are unconditional
+    // from clamped addresses, the selects follow (see k_gwgrad).
+    const bool dy_thread = tid < 256;
     const int cq = tid & 15, pg = (tid >> 4) & 15;
-    auto x_item = [&](int j) { return NG == 1 ? tid + 256 * j : (tid >= 256 ? tid - 256 : 256 + tid); };
-    auto x_valid = [&](int j) { return NG == 1 ? (tid + 256 * j < 320) : (tid >= 256 || tid < 64); };
-    gw_u32x2 dzv[10], yv[10], xv[NX][8];
-    auto load = [&](int tile) {
+    const int x_item = tid >= 256 ? tid - 256 : 256 + tid;
+    const bool x_valid = tid >= 256 || tid < 64;
+    LV dzv[10], yv[10], xv[8];
+    auto load_dy = [&](int tile) {
         const int b = tile / tiles_per_clip, r0 = (tile % tiles_per_clip) * TH;
         if (dy_thread) {
             const int r = pg >> 1, c0 = (pg & 1) * 8, row = r0 + r;
@@ -380,87 +401,205 @@ __global__ __launch_bounds__(512, 1) void k_gwgrad_bf16(const __bf16* __restrict
             for (int i = 0; i < 10; ++i) {
                 const int col = c0 - 1 + i, cc = col < 0 ? 0 : (col > 15 ? 15 : col);
                 const size_t off = (rbase + cc) * C + co0 + 4 * cq;
-                dzv[i] = *(const gw_u32x2*)(dz + off);
-                yv[i] = *(const gw_u32x2*)(yin + off);
+                dzv[i] = *(const LV*)(dz + off);
+                yv[i] = *(const LV*)(yin + off);
             }
         }
-#pragma unroll
-        for (int j = 0; j < NX; ++j) {
-            if (NG == 2 && !x_valid(j)) continue;                  // (NG = 1: unconditional, the item index is clamped)
-            const int xit = x_item(j), cg = (xit >> 4) & 1, hr = (xit >> 5) < 10 ? (xit >> 5) : 9;
+    };
+    auto load_x = [&](int tile) {
+        const int b = tile / tiles_per_clip, r0 = (tile % tiles_per_clip) * TH;
+        if (x_valid) {
+            const int cg = (x_item >> 4) & 1, hr = (x_item >> 5) < 10 ? (x_item >> 5) : 9;
             const int row = r0 - 1 + hr, rc = row < 0 ? 0 : (row >= H ? H - 1 : row);
             const size_t base = ((size_t)(b * H + rc) * 16 + 8 * cg) * C + ci0 + 4 * cq;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) xv[j][i] = *(const gw_u32x2*)(xin + base + (size_t)i * C);
+            for (int i = 0; i < 8; ++i) xv[i] = *(const LV*)(xin + base + (size_t)i * C);
         }
     };
-    auto store = [&](int tile) {
-        const int r0 = (tile % tiles_per_clip) * TH;
-        if (dy_thread) {
-            const int r = pg >> 1, c0 = (pg & 1) * 8;
-            const bool rok = r0 + r < H;
-            // dy = cf0 dz + cf1 y + cf2 (the BatchNorm backward, per channel) for the 10 pixels, as packed bf16 pairs
-            unsigned int dyp[10][2];
-            float k0[4], k1[4], k2[4];                             // (read up front: an LDS read under the `ok` select becomes a branch)
+    // channel q of the four a loaded item holds, as fp32
+    auto chan = [&](const LV& v, int q) -> float {
+        if constexpr (X3 != 0) return v[q];
+        else return (q & 1) ? gw_hi(v[q >> 1]) : gw_lo(v[q >> 1]);
+    };
+    // dyp[i] = packed bf16 quad of pixel i (10 pixels: the 8 of this group and one either side) -> the three column-shifted,
+    // pixel-contiguous copies of one plane.  Copy dc holds dy[r][c' - dc + 1] at column c' = c0 + e: staged pixel index e - dc + 2
+    auto put_dy = [&](const gw_u32x2 (&dyp)[10], __bf16* plane, int r, int c0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { k0[q] = cf[4 * cq + q]; k1[q] = cf[64 + 4 * cq + q]; k2[q] = cf[128 + 4 * cq + q]; }
-#pragma unroll
-            for (int i = 0; i < 10; ++i) {
-                const int col = c0 - 1 + i;
-                const bool ok = rok && col >= 0 && col < 16;
-                float v[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const unsigned int zw = dzv[i][q >> 1], yw = yv[i][q >> 1];
-                    const float z = (q & 1) ? gw_hi(zw) : gw_lo(zw), y = (q & 1) ? gw_hi(yw) : gw_lo(yw);
-                    const float val = k0[q] * z + k1[q] * y + k2[q];
-                    v[q] = ok ? val : 0.f;
-                }
-                const bf16x4 pk = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                const gw_u32x2 pw = __builtin_bit_cast(gw_u32x2, pk);
-                dyp[i][0] = pw.x; dyp[i][1] = pw.y;
-            }
-            // copy dc holds dy[r][c' - dc + 1] at column c' = c0 + e: staged pixel index e - dc + 2
-#pragma unroll
-            for (int dc = 0; dc < 3; ++dc)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    unsigned int w[4];
-#pragma unroll
-                    for (int e2 = 0; e2 < 4; ++e2) {
-                        const unsigned int p0 = dyp[2 * e2 - dc + 2][q >> 1], p1 = dyp[2 * e2 + 1 - dc + 2][q >> 1];
-                        w[e2] = (q & 1) ? ((p0 >> 16) | (p1 & 0xffff0000u)) : ((p0 & 0xffffu) | (p1 << 16));
-                    }
-                    *(u32x4g*)(dyT + ((size_t)(dc * 64 + 4 * cq + q)) * DS + r * 16 + c0) = (u32x4g){w[0], w[1], w[2], w[3]};
-                }
-        }
-#pragma unroll
-        for (int j = 0; j < NX; ++j) {
-            if (!x_valid(j)) continue;
-            const int xit = x_item(j), cg = (xit >> 4) & 1, hr = xit >> 5;
-            const int row = r0 - 1 + hr;
-            const bool ok = row >= 0 && row < H;
+        for (int dc = 0; dc < 3; ++dc)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 unsigned int w[4];
 #pragma unroll
                 for (int e2 = 0; e2 < 4; ++e2) {
-                    const unsigned int p0 = xv[j][2 * e2][q >> 1], p1 = xv[j][2 * e2 + 1][q >> 1];
-                    const unsigned int v = (q & 1) ? ((p0 >> 16) | (p1 & 0xffff0000u)) : ((p0 & 0xffffu) | (p1 << 16));
-                    w[e2] = ok ? v : 0u;
+                    const unsigned int p0 = dyp[2 * e2 - dc + 2][q >> 1], p1 = dyp[2 * e2 + 1 - dc + 2][q >> 1];
+                    w[e2] = (q & 1) ? ((p0 >> 16) | (p1 & 0xffff0000u)) : ((p0 & 0xffffu) | (p1 << 16));
                 }
-                *(u32x4g*)(xT + ((size_t)(4 * cq + q)) * XS + hr * 16 + 8 * cg) = (u32x4g){w[0], w[1], w[2], w[3]};
+                *(u32x4g*)(plane + ((size_t)(dc * 64 + 4 * cq + q)) * DS + r * 16 + c0) = (u32x4g){w[0], w[1], w[2], w[3]};
+            }
+    };
+    auto put_x = [&](const gw_u32x2 (&xp)[8], __bf16* plane, int hr, int cg, bool ok) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned int w[4];
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {
+                const unsigned int p0 = xp[2 * e2][q >> 1], p1 = xp[2 * e2 + 1][q >> 1];
+                const unsigned int v = (q & 1) ? ((p0 >> 16) | (p1 & 0xffff0000u)) : ((p0 & 0xffffu) | (p1 << 16));
+                w[e2] = ok ? v : 0u;
+            }
+            *(u32x4g*)(plane + ((size_t)(4 * cq + q)) * XS + hr * 16 + 8 * cg) = (u32x4g){w[0], w[1], w[2], w[3]};
+        }
+    };
+    auto store_dy = [&](int tile) {
+        const int r0 = (tile % tiles_per_clip) * TH;
+        if (dy_thread) {
+            const int r = pg >> 1, c0 = (pg & 1) * 8;
+            const bool rok = r0 + r < H;
+            // dy = cf0 dz + cf1 y + cf2 (the BatchNorm backward, per channel) for the 10 pixels, as packed bf16 pairs.
+            // X3: one plane at a time (hi, then lo recomputed from the same loads): both planes' packed pixels at once do not fit
+            float k0[4], k1[4], k2[4];                             // (read up front: an LDS read under the `ok` select becomes a branch)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { k0[q] = cf[4 * cq + q]; k1[q] = cf[64 + 4 * cq + q]; k2[q] = cf[128 + 4 * cq + q]; }
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                gw_u32x2 dyp[10];
+#pragma unroll
+                for (int i = 0; i < 10; ++i) {
+                    const int col = c0 - 1 + i;
+                    const bool ok = rok && col >= 0 && col < 16;
+                    float v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float val = k0[q] * chan(dzv[i], q) + k1[q] * chan(yv[i], q) + k2[q];
+                        v[q] = ok ? val : 0.f;
+                    }
+                    if constexpr (X3 != 0) {
+                        gw_u32x2 h, l;
+                        gw_split4(v, h, l);
+                        dyp[i] = pl ? l : h;
+                    } else {
+                        const bf16x4 pk = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                        dyp[i] = __builtin_bit_cast(gw_u32x2, pk);
+                    }
+                }
+                put_dy(dyp, dyT + pl * GWgB::DY_E, r, c0);
             }
         }
     };
-    __syncthreads();
-    if ((int)blockIdx.x < n_tiles) load(blockIdx.x);
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        store(tile);
-        __syncthreads();
+    auto store_x = [&](int tile) {
+        const int r0 = (tile % tiles_per_clip) * TH;
+        if (x_valid) {
+            const int cg = (x_item >> 4) & 1, hr = x_item >> 5;
+            const int row = r0 - 1 + hr;
+            const bool ok = row >= 0 && row < H;
+            if constexpr (X3 != 0) {
+                gw_u32x2 xh[8], xl[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float v[4] = {xv[i][0], xv[i][1], xv[i][2], xv[i][3]};
+                    gw_split4(v, xh[i], xl[i]);
+                }
+                put_x(xh, xT, hr, cg, ok);
+                put_x(xl, xT + GWgB::X_E, hr, cg, ok);
+            } else {
+                put_x(xv, xT, hr, cg, ok);
+            }
+        }
+    };
+    // X3 staging: fp32 sources.  dy: ALL 512 threads take one item of (pixel group pg, channel PAIR cp) - 10 pixels x 2 channels
+    // of dz and y as 8-byte loads (40 registers; the 4-channel items of the bf16 path would be 80 here), split into hi / lo
+    // packed pairs (one register per pixel and plane) and written as three column-shifted copies per plane.  x: threads
+    // 0 .. 319 take one (halo row, column group, channel quad) item each, after the dy phase.
+    auto x3_stage = [&](int tile) {
+        typedef __attribute__((ext_vector_type(2))) float f32x2g;
+        const int b = tile / tiles_per_clip, r0 = (tile % tiles_per_clip) * TH;
         {
+            const int cp = tid & 31, pgx = tid >> 5, r = pgx >> 1, c0 = (pgx & 1) * 8, row = r0 + r;
+            const size_t rbase = (size_t)(b * H + (row < H ? row : 0)) * 16;
+            f32x2g zv[10], wv2[10];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const int col = c0 - 1 + i, cc = col < 0 ? 0 : (col > 15 ? 15 : col);
+                const size_t off = (rbase + cc) * C + co0 + 2 * cp;
+                zv[i] = *(const f32x2g*)((const float*)dz_v + off);
+                wv2[i] = *(const f32x2g*)((const float*)yin_v + off);
+            }
+            const bool rok = row < H;
+            const float ka0 = cf[2 * cp], ka1 = cf[2 * cp + 1], kb0 = cf[64 + 2 * cp], kb1 = cf[64 + 2 * cp + 1],
+                        kc0 = cf[128 + 2 * cp], kc1 = cf[128 + 2 * cp + 1];
+            unsigned int ph[10], pl[10];                           // (channel 2 cp | channel 2 cp + 1) as packed bf16, hi and lo parts
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const int col = c0 - 1 + i;
+                const bool ok = rok && col >= 0 && col < 16;
+                const float v0 = ok ? ka0 * zv[i][0] + kb0 * wv2[i][0] + kc0 : 0.f;
+                const float v1 = ok ? ka1 * zv[i][1] + kb1 * wv2[i][1] + kc1 : 0.f;
+                const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+                const __bf16 l0 = (__bf16)(v0 - (float)h0), l1 = (__bf16)(v1 - (float)h1);
+                ph[i] = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
+                pl[i] = (unsigned int)__builtin_bit_cast(unsigned short, l0) | ((unsigned int)__builtin_bit_cast(unsigned short, l1) << 16);
+            }
+#pragma unroll
+            for (int plane = 0; plane < 2; ++plane)
+#pragma unroll
+                for (int dc = 0; dc < 3; ++dc)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        unsigned int w[4];
+#pragma unroll
+                        for (int e2 = 0; e2 < 4; ++e2) {
+                            const unsigned int p0 = plane ? pl[2 * e2 - dc + 2] : ph[2 * e2 - dc + 2];
+                            const unsigned int p1 = plane ? pl[2 * e2 + 1 - dc + 2] : ph[2 * e2 + 1 - dc + 2];
+                            w[e2] = q ? ((p0 >> 16) | (p1 & 0xffff0000u)) : ((p0 & 0xffffu) | (p1 << 16));
+                        }
+                        *(u32x4g*)(dyT + plane * GWgB::DY_E + ((size_t)(dc * 64 + 2 * cp + q)) * DS + r * 16 + c0) = (u32x4g){w[0], w[1], w[2], w[3]};
+                    }
+        }
+        asm volatile("" ::: "memory");                             // (the x loads are not to be hoisted above the dy conversion)
+        if (tid < 320) {
+            const int cg = (tid >> 4) & 1, hr = tid >> 5, cqx = tid & 15;
+            const int row = r0 - 1 + hr, rc = row < 0 ? 0 : (row >= H ? H - 1 : row);
+            const bool ok = row >= 0 && row < H;
+            const float* base = (const float*)xin_v + ((size_t)(b * H + rc) * 16 + 8 * cg) * C + ci0 + 4 * cqx;
+            f32x4 xf[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xf[i] = *(const f32x4*)(base + (size_t)i * C);
+            gw_u32x2 xh[8], xl[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float v[4] = {xf[i][0], xf[i][1], xf[i][2], xf[i][3]};
+                gw_split4(v, xh[i], xl[i]);
+            }
+#pragma unroll
+            for (int plane = 0; plane < 2; ++plane)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    unsigned int w[4];
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) {
+                        const unsigned int p0 = plane ? xl[2 * e2][q >> 1] : xh[2 * e2][q >> 1];
+                        const unsigned int p1 = plane ? xl[2 * e2 + 1][q >> 1] : xh[2 * e2 + 1][q >> 1];
+                        const unsigned int v = (q & 1) ? ((p0 >> 16) | (p1 & 0xffff0000u)) : ((p0 & 0xffffu) | (p1 << 16));
+                        w[e2] = ok ? v : 0u;
+                    }
+                    *(u32x4g*)(xT + plane * GWgB::X_E + ((size_t)(4 * cqx + q)) * XS + hr * 16 + 8 * cg) = (u32x4g){w[0], w[1], w[2], w[3]};
+                }
+        }
+    };
+    __syncthreads();
+    if (!X3 && (int)blockIdx.x < n_tiles) { load_dy(blockIdx.x); load_x(blockIdx.x); }
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        if constexpr (X3 != 0) {
+            x3_stage(tile);
+        } else {
+            store_dy(tile);
+            store_x(tile);
+        }
+        __syncthreads();
+        if (!X3) {
             const int nt = tile + (int)gridDim.x;
-            load(nt < n_tiles ? nt : tile);
+            load_dy(nt < n_tiles ? nt : tile);
+            load_x(nt < n_tiles ? nt : tile);
         }
         const __bf16* Ap = dyT + (size_t)(32 * wa + n) * DS + 8 * kh;
         const __bf16* Bp = xT + (size_t)(32 * wb + n) * XS + 8 * kh;
@@ -470,23 +609,34 @@ __global__ __launch_bounds__(512, 1) void k_gwgrad_bf16(const __bf16* __restrict
             constexpr int DR0 = T0 / 3, DR1 = (T0 + TN - 1) / 3;
 #pragma unroll 1
             for (int ks = 0; ks < 8; ++ks) {
-                bf16x8 a[3], bx[3];
+                bf16x8 a[3], bx[3], al[X3 ? 3 : 1], bl[X3 ? 3 : 1];
 #pragma unroll
-                for (int d = 0; d < 3; ++d) a[d] = *(const bf16x8*)(Ap + (size_t)d * 64 * DS + 16 * ks);
+                for (int d = 0; d < 3; ++d) {
+                    a[d] = *(const bf16x8*)(Ap + (size_t)d * 64 * DS + 16 * ks);
+                    if constexpr (X3 != 0) al[d] = *(const bf16x8*)(Ap + GWgB::DY_E + (size_t)d * 64 * DS + 16 * ks);
+                }
 #pragma unroll
-                for (int d = DR0; d <= DR1; ++d) bx[d] = *(const bf16x8*)(Bp + d * 16 + 16 * ks);
+                for (int d = DR0; d <= DR1; ++d) {
+                    bx[d] = *(const bf16x8*)(Bp + d * 16 + 16 * ks);
+                    if constexpr (X3 != 0) bl[d] = *(const bf16x8*)(Bp + GWgB::X_E + d * 16 + 16 * ks);
+                }
 #pragma unroll
-                for (int t = T0; t < T0 + TN; ++t) acc[t - T0] = M::mma(a[t % 3], bx[t / 3], acc[t - T0]);
+                for (int t = T0; t < T0 + TN; ++t) {
+                    acc[t - T0] = M::mma(a[t % 3], bx[t / 3], acc[t - T0]);
+                    if constexpr (X3 != 0) {
+                        acc[t - T0] = M::mma(a[t % 3], bl[t / 3], acc[t - T0]);
+                        acc[t - T0] = M::mma(al[t % 3], bx[t / 3], acc[t - T0]);
+                    }
+                }
             }
         };
-        if (NG == 1) taps(std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
-        else if (grp == 0) taps(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+        if (grp == 0) taps(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
         else taps(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
         __syncthreads();
     }
     // every wave writes its own taps of the partial slab [tap][co (C)][ci (C)]
     float* ps = part + (size_t)blockIdx.x * 9 * C * C;
-    const int t0 = NG == 2 ? 5 * grp : 0, tn = NG == 2 ? (grp ? 4 : 5) : 9;
+    const int t0 = 5 * grp, tn = grp ? 4 : 5;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if (t >= tn) break;
@@ -675,15 +825,18 @@ int launch_gwgrad(int mode, int C, const void* dz, const void* yin, const float*
     const int nq = (C / 64) * (C / 64);
     int slabs = gwgrad_slabs(C);
     int nt, tpc;
-    if (W == 16 && mode == SED_DTYPE_BF16) {
+    if (W == 16 && (mode == SED_DTYPE_BF16 || (mode == SED_DTYPE_BF16X3 && !(g_sed_debug & 4194304)))) {
+        // (debug bit 22: the split-operand mode's weight gradient on the exact-fp32 MFMA kernel, as in round 3 - A/B)
         static bool attr = false;
         if (!attr) {
-            SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GWgB::STAGE_BYTES));
+            SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad_bf16<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GWgB::STAGE_BYTES));
+            SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad_bf16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GWgB::STAGE_BYTES_X3));
             attr = true;
         }
         tpc = (H + GWgB::TH - 1) / GWgB::TH; nt = B * tpc;
         if (slabs > nt) slabs = nt;
-        k_gwgrad_bf16<<<dim3(slabs, nq), 512, GWgB::STAGE_BYTES, st>>>((const __bf16*)dz, (const __bf16*)yin, coef, (const __bf16*)xin, part, C, H, tpc, nt);
+        if (mode == SED_DTYPE_BF16) k_gwgrad_bf16<0><<<dim3(slabs, nq), 512, GWgB::STAGE_BYTES, st>>>(dz, yin, coef, xin, part, C, H, tpc, nt);
+        else k_gwgrad_bf16<1><<<dim3(slabs, nq), 512, GWgB::STAGE_BYTES_X3, st>>>(dz, yin, coef, xin, part, C, H, tpc, nt);
     } else if (W == 16) {
         using Cfg = GWgCfg<16>;
         static bool attr = false;

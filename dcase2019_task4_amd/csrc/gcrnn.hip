@@ -247,6 +247,9 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
             SED_TRY(launch_bglu_fwd(C, CTXV(L.y[i]), bn, params + P.glu_w[i], params + P.glu_b[i], CTXV(L.p[i]), i == 1 ? 1 : 0, g.B,
                                     Hs[i], Wd[i], i, use_drop, g.p, seed_dev, use_drop ? CTXM(L.mask[i]) : nullptr,
                                     train ? CTXV(L.wg[i]) : nullptr, train ? CTXF(L.bg[i]) : nullptr, st));
+        else if (g.mode == SED_DTYPE_BF16X3 && !(g_sed_debug & 8388608))      // (debug bit 23: the exact-fp32 GLU forward in this mode, A/B)
+            SED_TRY(launch_bglu_fwd_x3(C, CTXV(L.y[i]), bn, params + P.glu_w[i], params + P.glu_b[i], CTXV(L.p[i]), g.B, Hs[i], Wd[i], i,
+                                       use_drop, g.p, seed_dev, use_drop ? CTXM(L.mask[i]) : nullptr, st));
         else
         SED_TRY(launch_gglu_fwd(gm, C, CTXV(L.y[i]), bn, CTXV(L.wg[i]), CTXF(L.bg[i]), CTXV(L.p[i]),
                                 (g.mode == SED_DTYPE_BF16 && i == 1) ? 1 : 0, g.B, Hs[i], Wd[i], i,
@@ -268,7 +271,7 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
             gb.n_prob = 2;
             for (int dir = 0; dir < 2; ++dir)
                 gb.p[dir] = GntProb{in, nin, params + P.w_ih[l][dir], nin, CTXF(L.gi[l]) + dir * 3 * H, 6 * H, params + P.b_ih[l][dir], BT, 3 * H, nin};
-            SED_TRY(g.mode == SED_DTYPE_BF16 ? launch_gnt_gemm_bf16(gb, st) : launch_gnt_gemm(gb, st));
+            SED_TRY(g.mode != SED_DTYPE_F32 ? launch_gnt_gemm_bf16(gb, st, g.mode == SED_DTYPE_BF16X3) : launch_gnt_gemm(gb, st));
             if (rec16) {
                 if (!(aux_pack && l < aux.n_grec))
                     SED_TRY(launch_grec_pack(params + P.w_hh[l][0], params + P.w_hh[l][1], CTXV(L.whh[l]), train ? CTXV(L.whhT[l]) : nullptr, st));
@@ -328,7 +331,7 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
         GemmBatch gb;
         gb.n_prob = 4; gb.splits = gru_splitk(g); gb.part = WSF(W.gemm_part) + (size_t)l * gru_gemm_part_floats(g);
         gb.part_floats = gru_gemm_part_floats(g); gb.part_stride = 0;
-        gb.bf16 = g.mode == SED_DTYPE_BF16;
+        gb.bf16 = g.mode == SED_DTYPE_BF16 ? 1 : (g.mode == SED_DTYPE_BF16X3 ? 2 : 0);     // GRU weight gradients: operand mode of the MFMA
         for (int dir = 0; dir < 2; ++dir) {
             gb.p[2 * dir] = gemm_prob(WSF(W.dgi[l]) + dir * 3 * H, 1, 6 * H, input, nin, 1, grads + P.w_ih[l][dir], nin, 3 * H, nin, BT);
             gb.p[2 * dir].Cones = grads + P.b_ih[l][dir];
@@ -393,7 +396,7 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
                 GntBatch gb;
                 gb.n_prob = 1;
                 gb.p[0] = GntProb{WSF(W.dgi[l]), 6 * H, CTXF(L.wihT[l]), 6 * H, d_in, nin, nullptr, BT, nin, 6 * H};
-                SED_TRY(g.mode == SED_DTYPE_BF16 ? launch_gnt_gemm_bf16(gb, st) : launch_gnt_gemm(gb, st));
+                SED_TRY(g.mode != SED_DTYPE_F32 ? launch_gnt_gemm_bf16(gb, st, g.mode == SED_DTYPE_BF16X3) : launch_gnt_gemm(gb, st));
                 d_cur = d_in;
                 d_cur2 = nullptr;
             }
@@ -439,7 +442,7 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
             SED_TRY(launch_gconv_dgrad(g.mode, C, WSF(W.dz[i]), CTXF(L.y[i]), WSF(W.coef[i]), CTXV(L.wpkT[i]), WSF(W.dp[i - 1]), g.B, Hs[i],
                                        Wd[i], st));
         if (have_side) { SED_CHECK_HIP(hipStreamWaitEvent(ss, ev_fork, 0)); forked = true; }
-        SED_TRY(launch_gwgrad(gm, C, WSF(W.dz[i]), CTXF(L.y[i]), WSF(W.coef[i]), CTXF(L.p[i - 1]), WSF(W.wg_part), grads + P.conv_w[i], g.B,
+        SED_TRY(launch_gwgrad(g.mode, C, WSF(W.dz[i]), CTXF(L.y[i]), WSF(W.coef[i]), CTXF(L.p[i - 1]), WSF(W.wg_part), grads + P.conv_w[i], g.B,
                               Hs[i], Wd[i], ss));
         if (i == 2 && parts == 3 && !early_gru_w) {
             // on the second helper stream, so that they do not sit in front of wgrad1 on the first (crnn.hip)

@@ -26,7 +26,8 @@ __device__ __forceinline__ int prob_nx(const GemmProb& p) { return p.N + (p.Cone
 
 // BF: operands rounded to bf16 on the way from LDS into the MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulation): the
 // SED_DTYPE_BF16 mode's GRU weight gradients (K = B T, 9-13 GFLOP at the wide model: 90 us per layer on the f32 MFMA)
-template <bool BF>
+// BF = 2 (SED_DTYPE_BF16X3): hi + lo split of both operands, three products per k-step (the LDS tiles hold fp32 anyway)
+template <int BF>
 __global__ __launch_bounds__(256) void k_gemm_batched(GemmBatch gb) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     float* As = gsm;                                   // [GT_M][GT_K + 1]
@@ -145,16 +146,23 @@ __global__ __launch_bounds__(256) void k_gemm_batched(GemmBatch gb) {
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) rowsum += ar[kk];
         }
-        if constexpr (BF) {
+        if constexpr (BF != 0) {
 #pragma unroll
             for (int s = 0; s < GT_K / 16; ++s) {                 // lane (n, kh): k = 16 s + 8 kh + e
-                gemm_bf16x8 a, b;
+                gemm_bf16x8 a, b, al, bl;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    a[e] = (__bf16)As[(32 * wm + n) * (GT_K + 1) + 16 * s + 8 * kh + e];
-                    b[e] = (__bf16)Bs[(16 * s + 8 * kh + e) * (GT_N + 1) + 32 * wn + n];
+                    const float av = As[(32 * wm + n) * (GT_K + 1) + 16 * s + 8 * kh + e];
+                    const float bv = Bs[(16 * s + 8 * kh + e) * (GT_N + 1) + 32 * wn + n];
+                    a[e] = (__bf16)av;
+                    b[e] = (__bf16)bv;
+                    if constexpr (BF == 2) { al[e] = (__bf16)(av - (float)a[e]); bl[e] = (__bf16)(bv - (float)b[e]); }
                 }
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+                if constexpr (BF == 2) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b, acc, 0, 0, 0);
+                }
             }
         } else {
 #pragma unroll
@@ -408,12 +416,14 @@ int launch_gemm_batch(GemmBatch& gb, hipStream_t st) {
     const size_t lds = (size_t)(GT_M * (GT_K + 1) + GT_K * (GT_N + 1)) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_batched<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_batched<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_batched<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_batched<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_batched<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    if (gb.bf16) k_gemm_batched<true><<<grid, 256, lds, st>>>(gb);
-    else k_gemm_batched<false><<<grid, 256, lds, st>>>(gb);
+    if (gb.bf16 == 2) k_gemm_batched<2><<<grid, 256, lds, st>>>(gb);
+    else if (gb.bf16) k_gemm_batched<1><<<grid, 256, lds, st>>>(gb);
+    else k_gemm_batched<0><<<grid, 256, lds, st>>>(gb);
     SED_CHECK_LAUNCH();
     if (gb.splits > 1) {
         dim3 g2((maxM * maxNx + 255) / 256, gb.n_prob);

@@ -79,9 +79,13 @@ __global__ __launch_bounds__(256) void k_gnt_gemm(GntBatch gb) {
 // loads - so the tile is kept small to fill the chip (60 - 720 workgroups) rather than large to feed the MFMA.
 #define GNB_KC 64
 #define GNB_S (GNB_KC + 8)                 // row stride in bf16 elements: 144 B, an odd multiple of 16 B (conflict-free b128)
+// X3 (SED_DTYPE_BF16X3): both operands split hi + lo into two LDS planes, every k-step is hi hi + hi lo + lo hi (~2^-16 per
+// product) - the projections of the wide BiGRU in the mode that holds 1e-3, in place of the exact-fp32 k_gnt_gemm above.
+template <int X3>
 __global__ __launch_bounds__(256) void k_gnt_gemm_bf16(GntBatch gb) {
-    __shared__ __attribute__((aligned(16))) __bf16 As[2][GNT_T * GNB_S];
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][GNT_T * GNB_S];
+    constexpr int NPL = X3 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][NPL][GNT_T * GNB_S];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][NPL][GNT_T * GNB_S];
     const GntProb& d = gb.p[blockIdx.z];
     const int m0 = blockIdx.y * GNT_T, n0 = blockIdx.x * GNT_T;
     if (m0 >= d.M || n0 >= d.N) return;
@@ -104,14 +108,19 @@ __global__ __launch_bounds__(256) void k_gnt_gemm_bf16(GntBatch gb) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int u = tid + 256 * i, row = u >> 3, k8 = u & 7;
-            bf16x8 a, b;
+            bf16x8 a, b, al, bl;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                a[q] = (__bf16)ra[i][0][q]; a[4 + q] = (__bf16)ra[i][1][q];
-                b[q] = (__bf16)rb[i][0][q]; b[4 + q] = (__bf16)rb[i][1][q];
+            for (int q = 0; q < 8; ++q) {
+                const float av = q < 4 ? ra[i][0][q] : ra[i][1][q - 4], bv = q < 4 ? rb[i][0][q] : rb[i][1][q - 4];
+                a[q] = (__bf16)av; b[q] = (__bf16)bv;
+                if constexpr (X3 != 0) { al[q] = (__bf16)(av - (float)a[q]); bl[q] = (__bf16)(bv - (float)b[q]); }
             }
-            *(bf16x8*)&As[buf][row * GNB_S + 8 * k8] = a;
-            *(bf16x8*)&Bs[buf][row * GNB_S + 8 * k8] = b;
+            *(bf16x8*)&As[buf][0][row * GNB_S + 8 * k8] = a;
+            *(bf16x8*)&Bs[buf][0][row * GNB_S + 8 * k8] = b;
+            if constexpr (X3 != 0) {
+                *(bf16x8*)&As[buf][1][row * GNB_S + 8 * k8] = al;
+                *(bf16x8*)&Bs[buf][1][row * GNB_S + 8 * k8] = bl;
+            }
         }
     };
     f32x16 acc;
@@ -123,11 +132,17 @@ __global__ __launch_bounds__(256) void k_gnt_gemm_bf16(GntBatch gb) {
     __syncthreads();
     for (int ch = 0; ch < nch; ++ch) {
         if (ch + 1 < nch) load((ch + 1) * GNB_KC);
-        const __bf16* ap = &As[ch & 1][(32 * wm + n) * GNB_S + 8 * kh];
-        const __bf16* bp = &Bs[ch & 1][(32 * wn + n) * GNB_S + 8 * kh];
+        const __bf16* ap = &As[ch & 1][0][(32 * wm + n) * GNB_S + 8 * kh];
+        const __bf16* bp = &Bs[ch & 1][0][(32 * wn + n) * GNB_S + 8 * kh];
 #pragma unroll
-        for (int ks = 0; ks < GNB_KC / 16; ++ks)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(ap + 16 * ks), *(const bf16x8*)(bp + 16 * ks), acc, 0, 0, 0);
+        for (int ks = 0; ks < GNB_KC / 16; ++ks) {
+            const bf16x8 a = *(const bf16x8*)(ap + 16 * ks), b = *(const bf16x8*)(bp + 16 * ks);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            if constexpr (X3 != 0) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, *(const bf16x8*)(bp + GNT_T * GNB_S + 16 * ks), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(ap + GNT_T * GNB_S + 16 * ks), b, acc, 0, 0, 0);
+            }
+        }
         if (ch + 1 < nch) store((ch + 1) & 1);
         __syncthreads();
     }
@@ -142,7 +157,7 @@ __global__ __launch_bounds__(256) void k_gnt_gemm_bf16(GntBatch gb) {
     }
 }
 
-int launch_gnt_gemm_bf16(const GntBatch& gb, hipStream_t st) {
+int launch_gnt_gemm_bf16(const GntBatch& gb, hipStream_t st, int x3) {
     int maxM = 0, maxN = 0;
     for (int i = 0; i < gb.n_prob; ++i) {
         const GntProb& q = gb.p[i];
@@ -151,7 +166,9 @@ int launch_gnt_gemm_bf16(const GntBatch& gb, hipStream_t st) {
         maxM = q.M > maxM ? q.M : maxM;
         maxN = q.N > maxN ? q.N : maxN;
     }
-    k_gnt_gemm_bf16<<<dim3((maxN + GNT_T - 1) / GNT_T, (maxM + GNT_T - 1) / GNT_T, gb.n_prob), 256, 0, st>>>(gb);
+    const dim3 grid((maxN + GNT_T - 1) / GNT_T, (maxM + GNT_T - 1) / GNT_T, gb.n_prob);
+    if (x3) k_gnt_gemm_bf16<1><<<grid, 256, 0, st>>>(gb);
+    else k_gnt_gemm_bf16<0><<<grid, 256, 0, st>>>(gb);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

@@ -79,6 +79,8 @@ int launch_bglu_fwd(int C, const void* y, const GBnArgs& bn, const float* wglu, 
                     int W, int block_id, int use_drop, float p_drop, const uint64_t* seed, uint16_t* mask_out, void* wfold_out,
                     float* bfold_out, hipStream_t st);
 
+int launch_bglu_fwd_x3(int C, const void* y, const GBnArgs& bn, const float* wglu, const float* bglu, void* p, int B, int H, int W,
+                       int block_id, int use_drop, float p_drop, const uint64_t* seed, uint16_t* mask_out, hipStream_t st);
 int bglu_bwd_grid(int C, int B, int H, int W);
 //   wfold / bfold: as published by the forward; wgT: Wglu^T [c][co] raw bf16 (k_gen_pack)
 int launch_bglu_bwd(int C, const void* y, const float* bn, const void* wfold, const float* bfold, const void* wgT,
@@ -96,7 +98,8 @@ int launch_grec_bwd(const float* d_out, const float* out, const float* gates, co
 struct GntProb { const float* A; int lda; const float* B; int ldb; float* C; int ldc; const float* bias; int M, N, K; };
 struct GntBatch { GntProb p[2]; int n_prob; };
 int launch_gnt_gemm(const GntBatch& gb, hipStream_t st);
-int launch_gnt_gemm_bf16(const GntBatch& gb, hipStream_t st);      // bf16 MFMA operands (SED_DTYPE_BF16); K % 64 == 0
+// bf16 MFMA operands: x3 = 0 SED_DTYPE_BF16 (single products), x3 = 1 SED_DTYPE_BF16X3 (split operands); K % 64 == 0
+int launch_gnt_gemm_bf16(const GntBatch& gb, hipStream_t st, int x3 = 0);
 int launch_gnt_pack_t(const float* w0, const float* w1, float* out, int R, int N, hipStream_t st);
 
 // gcrnn.hip ---------------------------------------------------------------------------------------------------------------

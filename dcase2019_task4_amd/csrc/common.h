@@ -30,6 +30,19 @@ void sed_set_error(const char* fmt, ...);
         }                                                                                   \
     } while (0)
 #define SED_CHECK_LAUNCH() SED_CHECK_HIP(hipGetLastError())
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: every launcher raises it once per
+// device it is used on (a function-local `static bool` did it once per process - a second GPU driven from the same process
+// would have launched with the default 64 KB limit).  `static SedAttrOnce once; if (once.need()) { ...set attributes... }`
+struct SedAttrOnce {
+    bool done[64] = {};
+    bool need() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
+        if (done[d]) return false;
+        done[d] = true;
+        return true;
+    }
+};
 #define SED_TRY(expr)               \
     do {                            \
         int _s = (expr);            \

@@ -616,11 +616,10 @@ __global__ __launch_bounds__(512, 1) void k_conv_wino(const float* __restrict__ 
 template <int MODE>
 static int conv16_ws_launch(const float* in0, const float* in1, const float* coef, const float* wpk, const float* bias,
                             float* out, double* stat, int B, int H, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static SedAttrOnce attr_done;
+    if (attr_done.need()) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv16_ws2<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)Ws16::LDS_BYTES));
-        attr_done = true;
     }
     const int tpc = (H + Ws16::TH - 1) / Ws16::TH, nt = B * tpc;
     const int grid = nt < 256 ? nt : 256;          // one persistent workgroup per CU
@@ -637,11 +636,10 @@ static int conv_wino_launch(const float* in0, const float* in1, const float* coe
     BnBwdPrepArgs pa = {};
     if (prep) pa = *prep;
     using C = Wino<TW>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static SedAttrOnce attr_done;
+    if (attr_done.need()) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_wino<TW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)C::LDS_BYTES));
-        attr_done = true;
     }
     SED_CHECK_ARG((size_t)B * H * TW * 64 < ((size_t)1 << 31), "conv: image too large for 32-bit offsets");
     const int tpc = (H + C::TH - 1) / C::TH, nt = B * tpc;
@@ -1216,11 +1214,10 @@ template <int TW, int MODE, int NS>
 static int conv_launch_t(const float* in0, const float* in1, const float* coef, const float* wpk, const float* bias,
                          float* out, double* stat, int B, int H, hipStream_t st) {
     using Cfg = ConvCfg<TW>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static SedAttrOnce attr_done;
+    if (attr_done.need()) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3<TW, MODE, NS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)Cfg::LDS_BYTES));
-        attr_done = true;
     }
     const int tpc = (H + Cfg::TH - 1) / Cfg::TH;
     k_conv3x3<TW, MODE, NS><<<dim3(B * tpc, NS), 256, Cfg::LDS_BYTES, st>>>(in0, in1, coef, wpk, bias, out, stat, B, H, tpc);
@@ -1278,11 +1275,10 @@ static int wgrad_launch_t(const float* dz, const float* yin, const float* coef, 
     if (prep) pa = *prep;
 #ifdef SED_AB
     using Cfg = WgCfg<TW>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static SedAttrOnce attr_done;
+    if (attr_done.need()) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad<TW, TS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)Cfg::LDS_BYTES));
-        attr_done = true;
     }
     const int tpc = (H + Cfg::TH - 1) / Cfg::TH, nt = B * tpc;
     int nb = nt < n_blocks ? nt : n_blocks;
@@ -1295,10 +1291,9 @@ static int wgrad_launch_t(const float* dz, const float* yin, const float* coef, 
     // of the debug knob bring the direct kernels back (bit 7 = k_wgrad16_db for block 1, bit 3 = the tile kernel)
     if (!SED_AB_FLAGS(8 | 128)) {
         using CW = WgW<TW>;
-        static bool attrw = false;
-        if (!attrw) {
+        static SedAttrOnce attrw;
+        if (attrw.need()) {
             SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_wgrad_wino<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CW::LDS_BYTES));
-            attrw = true;
         }
         SED_CHECK_ARG((size_t)B * H * TW * 64 < ((size_t)1 << 31), "wgrad: image too large for 32-bit offsets");
         const int tpcw = (H + CW::TH - 1) / CW::TH, ntw = B * tpcw;
@@ -1307,10 +1302,9 @@ static int wgrad_launch_t(const float* dz, const float* yin, const float* coef, 
     }
 #ifdef SED_AB
     else if (TW == 16 && TS == 1 && !(g_sed_debug & 8)) {
-        static bool attr16 = false;
-        if (!attr16) {
+        static SedAttrOnce attr16;
+        if (attr16.need()) {
             SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_wgrad16_db, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wg16::LDS_BYTES));
-            attr16 = true;
         }
         k_wgrad16_db<<<nb, 256, Wg16::LDS_BYTES, st>>>(dz, yin, coef, xin, part, H, tpc, nt);
     } else {

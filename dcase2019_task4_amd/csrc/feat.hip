@@ -802,13 +802,9 @@ template <typename R>
 static int launch_stft_p(const float* wave, int n_clips, int n_samples, int hop, int frames, const double2* tw, const double* win,
                          const float* mel_basis, const int* band, const float* melw, int n_mels, float* mel, int max_workgroups,
                          hipStream_t st) {
-    static bool attr_done[64] = {false};
-    int dev = 0;
-    SED_CHECK_HIP(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+    static SedAttrOnce attr_done;
+    if (attr_done.need())
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_stft_mel_p<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(StpLds<R>)));
-        attr_done[dev] = true;
-    }
     const long long n_total = (long long)n_clips * frames;
     SED_CHECK_ARG(n_total < (1ll << 31), "sed_mel_frames: too many frames");
     long long grid = (n_total + STP_WAVES - 1) / STP_WAVES;

@@ -175,10 +175,9 @@ template <int MODE, int C, int PB>
 static int gglu_fwd_launch(const void* y, const GBnArgs& bn, const void* wg, const float* bg, void* p, int B, int H, int W,
                            int block_id, int use_drop, float p_drop, const uint64_t* seed, uint16_t* mask_out, hipStream_t st) {
     using Cfg = GGluFwdCfg<MODE, C>;
-    static bool attr = false;
-    if (!attr) {
+    static SedAttrOnce attr;
+    if (attr.need()) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gglu_fwd<MODE, C, PB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
-        attr = true;
     }
     const int Ho = H / 2, Wo = W / 4, Q = B * Ho * Wo, n_rb = (Q + 3) / 4;
     int grid = (n_rb + 3) / 4;
@@ -468,10 +467,9 @@ static int gglu_bwd_launch(const void* y, const float* bn, const float* gamma, c
                            float p_drop, const uint16_t* mask_in, hipStream_t st) {
     using Cfg = GGluBwdCfg<MODE, C>;
     static_assert(Cfg::LDS_BYTES <= 160 * 1024, "GLU backward tiles exceed the LDS");
-    static bool attr = false;
-    if (!attr) {
+    static SedAttrOnce attr;
+    if (attr.need()) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gglu_bwd<MODE, C, PB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
-        attr = true;
     }
     const int Ho = H / 2, Wo = W / 4, Q = B * Ho * Wo;
     k_gglu_bwd<MODE, C, PB><<<gglu_bwd_grid(B, H, W), 256, Cfg::LDS_BYTES, st>>>(y, bn, gamma, beta, wg, wgT, bg, dp, dp2, dz, part, H, W, Ho,

@@ -546,10 +546,9 @@ static int heads_fwd_launch(const float* h, const float* wd, const float* bd, co
                             int use_drop, float p_drop, const uint64_t* seed, hipStream_t st) {
     HD_CONSTS(HF);
     const size_t lds = (size_t)(HD_TC * HD_SF + HD_MAXO * HD_SF + HD_TC * HD_MAXO + 2 * HD_TC * 16 + 32) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static SedAttrOnce attr_done;
+    if (attr_done.need()) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_heads_fwd<HF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
     }
     k_heads_fwd<HF><<<B, HD_THREADS, lds, st>>>(h, wd, bd, ws, bs, strong, weak, strong_sv, weak_sv, logits_s, den, T, NC, use_drop,
                                                 p_drop, seed);
@@ -577,10 +576,9 @@ static int heads_bwd_launch(const float* h, const float* wd, const float* ws, co
                             int n_zero, const HeadsLoss& hl0, hipStream_t st) {
     HD_CONSTS(HF);
     const size_t lds = (size_t)(HD_TC * HD_SB + HD_MAXO * HD_SB + HD_TC * HD_SD + 32 + HD_THREADS) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static SedAttrOnce attr_done;
+    if (attr_done.need()) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_heads_bwd<HF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
     }
     k_heads_bwd<HF><<<B, HD_THREADS, lds, st>>>(h, wd, ws, strong, weak, logits_s, den, d_strong, d_weak, dh, part, T, NC, use_drop,
                                                 p_drop, seed, zero, zero ? n_zero : 0, hl0);

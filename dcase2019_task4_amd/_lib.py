@@ -79,7 +79,7 @@ _SIGS = {
     "sed_mel_frames": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_size_t, C.c_int, C.c_int, _P]),
     "sed_seed_advance": (C.c_int, [_P, _P]),
     "sed_logmel_transform_ws_bytes": (C.c_size_t, [C.c_int]),
-    "sed_logmel_transform": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "sed_logmel_transform": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_size_t, C.c_int, _P]),
     "sed_selftest": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "sed_debug_set": (C.c_int, [C.c_int]),
     "sed_build_flags": (C.c_int, []),

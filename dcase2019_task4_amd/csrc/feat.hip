@@ -659,6 +659,18 @@ __device__ __forceinline__ void teacher_noise_pair(uint32_t pair, uint64_t seed,
     n0 = (double)(float)fabs(0.25 * (r * cs));
     n1 = (double)(float)fabs(0.25 * (r * sn));
 }
+// SED_FFT_F32 (the front-end's stated fp32 mode): the same draw and transform in fp32 arithmetic - the noise values then differ
+// from the float64-derived ones by an ulp or two of fp32 (relative ~1e-7 of a value that is added to a linear mel amplitude)
+__device__ __forceinline__ void teacher_noise_pair_f32(uint32_t pair, uint64_t seed, float& n0, float& n1) {
+    const u32x4 o = philox4x32_10(pair, 0u, 16u, PHILOX_TAG, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float u1 = fminf(((float)o.x + 1.0f) * 2.3283064365386963e-10f, 1.0f), u2 = (float)o.y * 2.3283064365386963e-10f;
+    const float r = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincospif(2.0f * u2, &sn, &cs);
+    n0 = fabsf(0.25f * (r * cs));
+    n1 = fabsf(0.25f * (r * sn));
+}
+__device__ __forceinline__ float amp_db_f32(float a) { return 10.0f * log10f(fmaxf(1e-10f, a * a)); }
 __device__ __forceinline__ double amp_db(double a) {
     // librosa.amplitude_to_db(ref=1, amin=1e-5): 10 log10(max(amin^2, a^2)) - 10 log10(max(amin^2, 1))
     return 10.0 * log10(fmax(1e-10, a * a));
@@ -674,6 +686,7 @@ __device__ __forceinline__ double amp_db(double a) {
 //   k_logmel_apply every output element: dB, clamp, pad, normalise; folds the LM_CHUNKS partials of its clip itself
 // No atomics, no initialisation, fixed reduction order: bit-reproducible.
 #define LM_CHUNKS 16
+template <int F32>
 __global__ __launch_bounds__(256) void k_logmel_max(const float* __restrict__ mel, int frames, int n_mels, int max_frames,
                                                      const uint64_t* __restrict__ seed_ptr, double* __restrict__ part,
                                                      float* __restrict__ out_noisy) {
@@ -690,11 +703,15 @@ __global__ __launch_bounds__(256) void k_logmel_max(const float* __restrict__ me
         mc = fmax(mc, fmax(fabs(a0), fabs(a1)));
         if (out_noisy) {
             double z0, z1;
-            teacher_noise_pair((uint32_t)(((size_t)clip * n + e) >> 1), seed, z0, z1);
+            auto draw = [&](uint32_t pair, double& a_, double& b_) {
+                if constexpr (F32 != 0) { float f0, f1; teacher_noise_pair_f32(pair, seed, f0, f1); a_ = f0; b_ = f1; }
+                else teacher_noise_pair(pair, seed, a_, b_);
+            };
+            draw((uint32_t)(((size_t)clip * n + e) >> 1), z0, z1);
             if ((((size_t)clip * n + e) & 1) != 0) {      // odd clip size x odd clip index: the pair starts one element earlier
                 // (only reachable when n is odd; keep the definition element-wise exact)
                 double y0, y1;
-                teacher_noise_pair((uint32_t)((((size_t)clip * n + e) >> 1) + 1), seed, y0, y1);
+                draw((uint32_t)((((size_t)clip * n + e) >> 1) + 1), y0, y1);
                 z0 = z1; z1 = y0;
             }
             mn = fmax(mn, fabs(a0 + z0));
@@ -712,6 +729,7 @@ __global__ __launch_bounds__(256) void k_logmel_max(const float* __restrict__ me
     if (tid < 2) part[((size_t)clip * LM_CHUNKS + chunk) * 2 + tid] = fmax(fmax(red[tid][0], red[tid][1]), fmax(red[tid][2], red[tid][3]));
 }
 
+template <int F32>
 __global__ __launch_bounds__(256) void k_logmel_apply(const float* __restrict__ mel, int frames, int n_mels, int max_frames,
                                                        const double* __restrict__ mean, const double* __restrict__ stdv,
                                                        const double* __restrict__ part, float* __restrict__ out_clean,
@@ -733,13 +751,25 @@ __global__ __launch_bounds__(256) void k_logmel_apply(const float* __restrict__ 
         const int t = e / n_mels, m = e - t * n_mels;
         float vc = 0.f, vn = 0.f;                               // PadOrTrunc pads with 0 (dB) AFTER the log
         if (t < frames) {
-            const double a = (double)src[e];
-            vc = (float)fmax(amp_db(a), floor_c);               // ToTensor: .float()
-            if (out_noisy) vn = (float)fmax(amp_db(a + (double)out_noisy[(size_t)clip * n_out + e]), floor_n);
+            if constexpr (F32 != 0) {
+                const float a = src[e];
+                vc = fmaxf(amp_db_f32(a), (float)floor_c);
+                if (out_noisy) vn = fmaxf(amp_db_f32(a + out_noisy[(size_t)clip * n_out + e]), (float)floor_n);
+            } else {
+                const double a = (double)src[e];
+                vc = (float)fmax(amp_db(a), floor_c);           // ToTensor: .float()
+                if (out_noisy) vn = (float)fmax(amp_db(a + (double)out_noisy[(size_t)clip * n_out + e]), floor_n);
+            }
         }
         if (mean) {                                             // Scaler.normalize in float64, torch.Tensor() -> fp32
-            vc = (float)(((double)vc - mean[m]) / stdv[m]);
-            vn = (float)(((double)vn - mean[m]) / stdv[m]);
+            if constexpr (F32 != 0) {
+                const float mu = (float)mean[m], rs = 1.0f / (float)stdv[m];
+                vc = (vc - mu) * rs;
+                vn = (vn - mu) * rs;
+            } else {
+                vc = (float)(((double)vc - mean[m]) / stdv[m]);
+                vn = (float)(((double)vn - mean[m]) / stdv[m]);
+            }
         }
         out_clean[(size_t)clip * n_out + e] = vc;
         if (out_noisy) out_noisy[(size_t)clip * n_out + e] = vn;
@@ -865,7 +895,8 @@ extern "C" size_t sed_logmel_transform_ws_bytes(int n_clips) { return (size_t)(n
 
 extern "C" int sed_logmel_transform(const float* mel, int n_clips, int frames, int n_mels, int max_frames,
                                     const double* mean, const double* std, const uint64_t* seed_dev, float* out_clean,
-                                    float* out_noisy, void* ws, size_t ws_bytes, void* stream) {
+                                    float* out_noisy, void* ws, size_t ws_bytes, int math_dtype, void* stream) {
+    SED_CHECK_ARG(math_dtype == SED_FFT_F64 || math_dtype == SED_FFT_F32, "sed_logmel_transform: math_dtype must be SED_FFT_F64 or SED_FFT_F32");
     SED_CHECK_ARG(mel && out_clean, "sed_logmel_transform: null argument");
     SED_CHECK_ARG((mean == nullptr) == (std == nullptr), "sed_logmel_transform: mean and std go together");
     SED_CHECK_ARG(!out_noisy || seed_dev, "sed_logmel_transform: noise requested but seed_dev is null");
@@ -877,11 +908,13 @@ extern "C" int sed_logmel_transform(const float* mel, int n_clips, int frames, i
         return SED_ERR_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    k_logmel_max<<<dim3(LM_CHUNKS, n_clips), 256, 0, st>>>(mel, frames, n_mels, max_frames, seed_dev, (double*)ws, out_noisy);
+    if (math_dtype == SED_FFT_F32) k_logmel_max<1><<<dim3(LM_CHUNKS, n_clips), 256, 0, st>>>(mel, frames, n_mels, max_frames, seed_dev, (double*)ws, out_noisy);
+    else k_logmel_max<0><<<dim3(LM_CHUNKS, n_clips), 256, 0, st>>>(mel, frames, n_mels, max_frames, seed_dev, (double*)ws, out_noisy);
     SED_CHECK_LAUNCH();
     const int n_out = max_frames * n_mels;
-    k_logmel_apply<<<dim3((n_out + 1023) / 1024, n_clips), 256, 0, st>>>(mel, frames, n_mels, max_frames, mean, std, (const double*)ws,
-                                                                         out_clean, out_noisy);
+    const dim3 ga((n_out + 1023) / 1024, n_clips);
+    if (math_dtype == SED_FFT_F32) k_logmel_apply<1><<<ga, 256, 0, st>>>(mel, frames, n_mels, max_frames, mean, std, (const double*)ws, out_clean, out_noisy);
+    else k_logmel_apply<0><<<ga, 256, 0, st>>>(mel, frames, n_mels, max_frames, mean, std, (const double*)ws, out_clean, out_noisy);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

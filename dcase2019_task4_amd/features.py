@@ -241,7 +241,8 @@ class Scaler:
 class LogMelTransform:
     """Batched GPU form of get_transforms(frames, scaler, add_axis_conv=True, augment_type)."""
 
-    def __init__(self, frames, scaler=None, augment_type=None, device="cuda", seed=0):
+    def __init__(self, frames, scaler=None, augment_type=None, device="cuda", seed=0, math_dtype="f64"):
+        self.math_dtype = _lib.FFT_DTYPES[math_dtype]            # "f32": the front-end's stated fp32 mode (SED_FFT_F32)
         if augment_type not in (None, "noise"):
             raise NotImplementedError("only augment_type='noise' exists (utils.py:404-406)")
         self.frames = int(frames)
@@ -270,7 +271,7 @@ class LogMelTransform:
         ws = torch.empty(l.sed_logmel_transform_ws_bytes(n), device=self.device, dtype=torch.uint8)
         _lib.check(l.sed_logmel_transform(_lib.ptr(mel), n, fr, nm, self.frames, _lib.ptr(self.mean), _lib.ptr(self.std),
                                           _lib.ptr(seed_t), _lib.ptr(clean), _lib.ptr(noisy), _lib.ptr(ws), ws.numel(),
-                                          _lib.stream_ptr()),
+                                          self.math_dtype, _lib.stream_ptr()),
                    "sed_logmel_transform")
         return (clean, noisy) if self.noise else clean
 
@@ -358,7 +359,8 @@ class WaveformFrontEnd:
                    "sed_mel_frames")
         _lib.check(self.l.sed_logmel_transform(_lib.ptr(self.mel), self.n, self.frames, c.n_mels, st.T, _lib.ptr(self.mean),
                                                _lib.ptr(self.std), _lib.ptr(self.key), _lib.ptr(x), _lib.ptr(x_ema),
-                                               _lib.ptr(self.ws_t), self.ws_t.numel(), _lib.stream_ptr()),
+                                               _lib.ptr(self.ws_t), self.ws_t.numel(), _lib.FFT_DTYPES[self.fx.fft_dtype],
+                                               _lib.stream_ptr()),
                    "sed_logmel_transform")
         # the key moves on AFTER the extraction (one tiny kernel at the tail of the chain instead of its head, where it delayed
         # the STFT by a launch); the constructor advanced it once, so extraction k draws with key_0 + (k + 1) strides as before

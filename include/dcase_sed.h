@@ -277,9 +277,12 @@ size_t sed_logmel_transform_ws_bytes(int n_clips);
  * AugmentGaussianNoise's generator (DataLoad.py:189-207 draws from numpy's global RNG once per sample) for callers that
  * run the transform chain on a stream of their own, ahead of the train step. */
 int sed_seed_advance(uint64_t* key_dev, void* stream);
+/*   math_dtype  SED_FFT_F64: the reference's arithmetic (numpy float64 for log10, the noise and the normalisation);
+ *               SED_FFT_F32: the front-end's stated fp32 mode - fp32 log10 / Box-Muller / normalisation (bounds asserted in
+ *               tests/test_gpu_features.py next to the fp32 STFT's)                                                          */
 int sed_logmel_transform(const float* mel, int n_clips, int frames, int n_mels, int max_frames,
                          const double* mean, const double* std, const uint64_t* seed_dev,
-                         float* out_clean, float* out_noisy, void* ws, size_t ws_bytes, void* stream);
+                         float* out_clean, float* out_noisy, void* ws, size_t ws_bytes, int math_dtype, void* stream);
 
 /* Resampling step of read_audio (utils/utils.py:175-193: librosa.resample(audio, orig_sr, target_sr),
  * res_type "kaiser_best" = resampy's windowed-sinc interpolation, then fix_length).

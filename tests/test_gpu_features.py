@@ -235,8 +235,9 @@ def test_fft_f32_mode_holds_its_stated_bounds_at_batch_64():
     here at batch 64, against the float64 mode (itself held to the oracle at 2e-6 above) and against the numpy oracle:
       * linear mel: 2e-6 of the clip's maximum (measured 2.3e-7), i.e. the error floor sits > 110 dB under the peak - far below
         the 80 dB window amplitude_to_db keeps (DataLoad.py:192-207);
-      * log-mel features after the transform chain: 1e-3 dB (measured 6e-5), hard cases included (a pure tone over a
-        1e-5 noise floor, a click in silence, a quiet clip);
+      * log-mel features after the transform chain (fp32 log10 too): 1e-3 dB (measured 6e-5), hard cases included (a pure tone
+        over a 1e-5 noise floor, a click in silence, a quiet clip); normalised student / teacher inputs incl. the fp32 Box-Muller
+        noise: 2e-4 of the per-band standard deviation;
       * strong / weak posteriors of the fp32 model fed with either feature set: 1e-5 (measured 1.2e-7; the north star asks 1e-3)."""
     from dcase2019_task4_amd.features import FeatureConfig, FeatureExtractor, LogMelTransform
     from tests import gpu_util as gu
@@ -260,11 +261,20 @@ def test_fft_f32_mode_holds_its_stated_bounds_at_batch_64():
         want = features_np.calculate_mel_spec(waves[i].numpy().astype(np.float64), cfg.sample_rate, cfg.n_window, cfg.hop_length,
                                               cfg.n_mels, cfg.f_min, cfg.f_max)
         assert np.abs(m32[i].cpu().numpy() - want).max() < 3e-6 * want.max()
-    tr = LogMelTransform(T)
-    d64, d32 = tr(m64), tr(m32)
+    # the whole front-end in its fp32 mode (fp32 STFT + fp32 log10 / normalisation) against the whole front-end in float64
+    d64, d32 = LogMelTransform(T)(m64), LogMelTransform(T, math_dtype="f32")(m32)
     db = (d32 - d64).abs().amax(dim=(1, 2, 3)).cpu().numpy()
     print(f"[fft f32] log-mel, worst clip: {db.max():.2e} dB (clip {db.argmax()})")
     assert db.max() < 1e-3
+    # ... and with the teacher's noise (fp32 Box-Muller on the same Philox draws) + Scaler normalisation
+    from dcase2019_task4_amd.features import Scaler
+    sc = Scaler()
+    sc.calculate_scaler([features_np.transform_chain(m, T) for m in m64[:8].cpu().numpy()])
+    c64, n64 = LogMelTransform(T, sc, augment_type="noise")(m64, seed=31337)
+    c32, n32 = LogMelTransform(T, sc, augment_type="noise", math_dtype="f32")(m32, seed=31337)
+    ec, en = (c32 - c64).abs().max().item(), (n32 - n64).abs().max().item()
+    print(f"[fft f32] normalised features: clean {ec:.2e}, noisy (teacher input) {en:.2e} (units of the per-band std)")
+    assert ec < 2e-4 and en < 2e-4
     model, _ = gu.make_model(0, dropout=0)
     model.eval()
     mean, std = d64.mean(dim=(0, 1, 2), keepdim=True), d64.std(dim=(0, 1, 2), keepdim=True)

@@ -34,3 +34,7 @@ tr = LogMelTransform(628, augment_type="noise")
 print(f"sed_logmel_transform (noise): {timed(lambda: tr(mel, seed=5)):8.1f} us")
 tr0 = LogMelTransform(628)
 print(f"sed_logmel_transform (clean): {timed(lambda: tr0(mel)):8.1f} us")
+tr32 = LogMelTransform(628, augment_type="noise", math_dtype="f32")
+print(f"sed_logmel_transform (noise, fp32 mode): {timed(lambda: tr32(mel, seed=5)):8.1f} us")
+tr032 = LogMelTransform(628, math_dtype="f32")
+print(f"sed_logmel_transform (clean, fp32 mode): {timed(lambda: tr032(mel)):8.1f} us")

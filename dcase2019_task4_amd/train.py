@@ -193,6 +193,13 @@ class MeanTeacherStep:
                    "sed_crnn_forward")
 
     def _fwd_bwd(self, after_forward=None, at_recurrence=None):
+        try:
+            self._fwd_bwd_impl(after_forward, at_recurrence)
+        finally:
+            if at_recurrence is not None:      # one-shot hook: never leave it registered (e.g. a forward that failed before it)
+                self.l.sed_crnn_fork_callback(_lib.stream_ptr(), None, None)
+
+    def _fwd_bwd_impl(self, after_forward=None, at_recurrence=None):
         """teacher forward (main.py:87-89), student forward (:91), losses (:93-145), backward (:152-153).
         `after_forward`: called between the forwards and the backward; `at_recurrence`: called from INSIDE the student
         forward, between its conv stack and its recurrence (sed_crnn_fork_callback) - where the waveform front-end forks

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-3 profile collection on the GPU box (run through gpurun from the repo root); writes under gpurun_out/$PROF_TAG/.
+# Profile collection on the GPU box (rounds 3 and 4) (run through gpurun from the repo root); writes under gpurun_out/$PROF_TAG/.
 # Counters are collected in their own passes with --kernel-trace only (never with hip/hsa trace domains).
 set -u
-OUT=$GRAFT_REPO_ROOT/gpurun_out/${PROF_TAG:-r03}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${PROF_TAG:-r04}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -31,10 +31,18 @@ timeout 300 rocprofv3 --pmc $CNT --kernel-trace -d $OUT/pmcq_base_bf16 -o p -- p
 python $R/tools/show_pmc.py --md "$OUT/pmcq_base_bf16/*.db" "$OUT/pmcq_base_bf16/**/*.db" > $OUT/mt-bf16_pmc_mfma_busy.md 2>/dev/null
 timeout 300 rocprofv3 --pmc $CNT --kernel-trace -d $OUT/pmcq_f32 -o p -- python $R/tools/kbench.py > $OUT/pmcq_f32.log 2>&1
 python $R/tools/show_pmc.py --md "$OUT/pmcq_f32/*.db" "$OUT/pmcq_f32/**/*.db" > $OUT/mt-f32_pmc_mfma_busy.md 2>/dev/null
+# 4b. the front-end kernels alone (round 4): HIP-event times per workgroup cap and arithmetic mode, SQ counters and HBM traffic of
+#     the persistent STFT kernel (64 clips per launch)
+timeout 300 python $R/tools/bench_feat.py > $OUT/frontend_kernels.txt 2>&1
+timeout 300 rocprofv3 --pmc $CNT --kernel-trace -d $OUT/pmcq_fe -o p -- python $R/tools/bench_feat.py > $OUT/pmcq_fe.log 2>&1
+python $R/tools/show_pmc.py --md "$OUT/pmcq_fe/*.db" "$OUT/pmcq_fe/**/*.db" > $OUT/frontend_pmc_busy.md 2>/dev/null
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmcfe_fetch -o p -- python $R/tools/bench_feat.py > $OUT/pmcfe_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmcfe_write -o p -- python $R/tools/bench_feat.py > $OUT/pmcfe_write.log 2>&1
+python $R/tools/summarize_pmc.py $OUT/pmcfe_fetch $OUT/pmcfe_write $OUT/pmc_traffic_frontend.json 1 > $OUT/frontend_pmc_hbm_traffic.md 2>/dev/null
 # 5. un-profiled bench lines of the same build
 for c in $CFGS; do
   extra="--steps 500 --no-cpu-baseline"; [ $c = mt-f32 ] && extra=""
   timeout 600 python $R/bench.py --config $c $extra > $OUT/${c}_bench.json 2> $OUT/${c}_bench.err
 done
-rm -rf $OUT/stats_* $OUT/pmc_fetch $OUT/pmc_write $OUT/pmcw_fetch $OUT/pmcw_write $OUT/pmcq_*/
+rm -rf $OUT/stats_* $OUT/pmc_fetch $OUT/pmc_write $OUT/pmcw_fetch $OUT/pmcw_write $OUT/pmcfe_fetch $OUT/pmcfe_write $OUT/pmcq_*/
 ls $OUT

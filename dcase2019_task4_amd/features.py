@@ -287,10 +287,10 @@ class WaveformFrontEnd:
     main.py:238-247).  There are two slots of (x, x_ema, target); ``run()`` trains on the slot extracted last and extracts the
     staged waveforms (``load_batch``) into the other slot, target travelling with its features.  With ``overlap=True``
     (default; needs a step that replays ONE hipGraph per step: single process, or data-parallel with captured
-    collectives) the extraction is part of that graph: the student forward calls back between its conv stack and its
-    recurrence (sed_crnn_fork_callback), and a second stream forked there runs the persistent STFT kernel on ``fe_workgroups`` CUs from
-    there - beside the BiGRU / heads forward and backward, which occupy one workgroup per (clip, direction) and cannot
-    share a CU with an STFT workgroup (registers + LDS), so neither delays the other.  Without overlap the same protocol
+    collectives) the extraction is part of that graph: a second stream, forked after the forwards (or, SED_FE_FORK=gru, from
+    inside the student forward between its conv stack and its recurrence: sed_crnn_fork_callback), runs the persistent STFT
+    kernel on ``fe_workgroups`` CUs - beside the heads / BiGRU backward, which occupy one workgroup per (clip, direction)
+    and cannot share a CU with an STFT workgroup (registers + LDS), so neither delays the other.  Without overlap the same protocol
     runs serially (train, then extract).
 
     Streaming real data:  ``feed(waves, target)`` per batch and ``flush()`` at the end train on every batch exactly once, in
@@ -385,7 +385,12 @@ class WaveformFrontEnd:
         cap = dict(stream=st._cap_stream)
         if st.dp:
             cap["capture_error_mode"] = "thread_local"
-        fork = os.environ.get("SED_FE_FORK", "gru")     # gru (default) | backward (after both forwards) | start
+        # Where the extraction is forked (SED_FE_FORK): "backward" (default) = after both forwards, beside heads backward + GRU
+        # backward (64 / 2 B workgroups: 2 B CUs); "gru" = at the student's recurrence (sed_crnn_fork_callback), beside the GRU
+        # forwards too - but those are 4 B workgroups of BOTH models (k_gru4_fwd<128>: one per CU), which at B = 64 then run in
+        # two rounds on the CUs the STFT leaves (64 instead of 37 us each): 0.884 against 0.873 ms per step; "start" = head of
+        # the step (the extraction simply adds to the throughput-bound conv stacks).
+        fork = os.environ.get("SED_FE_FORK", "backward")
         ok = 1.0
         try:
             for i in range(2):

@@ -159,7 +159,8 @@ def test_waveform_front_end_one_batch_ahead_equals_serial():
     assert res[0][2] == res[1][2]
 
 
-def test_waveform_front_end_streaming_pairs_every_batch_with_its_own_target():
+@pytest.mark.parametrize("fork", ["backward", "gru"])
+def test_waveform_front_end_streaming_pairs_every_batch_with_its_own_target(fork, monkeypatch):
     """with DISTINCT waveforms and targets per step the one-batch-ahead front-end must train on batch k's
     features with batch k's target, every batch exactly once (also across the eager -> graph switch).  feed() / flush() with
     overlap on (two slots, the extraction inside the step's hipGraph, forked at the student's recurrence) must leave the
@@ -167,6 +168,9 @@ def test_waveform_front_end_streaming_pairs_every_batch_with_its_own_target():
     from dcase2019_task4_amd.features import FeatureConfig, WaveformFrontEnd
     from dcase2019_task4_amd.train import MeanTeacherStep
     from tests import gpu_util as gu
+    # both fork points of the extraction inside the step's graph: after the forwards (default) and from inside the student
+    # forward, at its recurrence (sed_crnn_fork_callback)
+    monkeypatch.setenv("SED_FE_FORK", fork)
     B, T, n_steps = 8, 628, 7
     waves = [np.stack([synth.make_wave(100 * k + i, 160000) for i in range(B)]).astype(np.float32) for k in range(n_steps)]
     tgts = [synth.make_target(3 + k, B, T // 8) for k in range(n_steps)]

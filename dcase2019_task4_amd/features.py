@@ -276,6 +276,37 @@ class LogMelTransform:
         return (clean, noisy) if self.noise else clean
 
 
+class _SampleTransforms:
+    """What get_transforms returns: a callable with the reference's per-sample protocol (DataLoad.py:157-186 Compose and the
+    transforms it chains): ``sample`` is a tuple / list whose LAST element is the label, every other element a
+    [frames, n_mels] feature array; the result is a list of tensors in the reference's order - ``[x, label]``, or
+    ``[x, x_noisy, label]`` with augment_type="noise" (AugmentGaussianNoise returns (clean, noisy, label), DataLoad.py:262-287).
+    The arithmetic runs in sed_logmel_transform on the GPU, the tensors come back on the host like the reference's (a
+    torch DataLoader collates them; main.py moves the batch to the GPU).  One launch + one copy per sample: the drop-in form,
+    not the fast one - LogMelTransform (batched) and WaveformFrontEnd are."""
+
+    def __init__(self, frames, scaler, add_axis_conv, augment_type, device, seed):
+        self.add_axis_conv = bool(add_axis_conv)
+        self.tr = LogMelTransform(frames, scaler=scaler, augment_type=augment_type, device=device, seed=seed)
+
+    def __call__(self, sample):
+        sample = list(sample)
+        label = torch.from_numpy(np.asarray(sample[-1])).float()              # ToTensor: "even labels" (DataLoad.py:316)
+        outs = []
+        for feat in sample[:-1]:
+            mel = torch.as_tensor(np.asarray(feat, dtype=np.float32))[None]
+            res = self.tr(mel)
+            outs.extend(res if isinstance(res, tuple) else (res,))
+        outs = [o[0].cpu() if self.add_axis_conv else o[0, 0].cpu() for o in outs]
+        return outs + [label]
+
+
+def get_transforms(frames, scaler=None, add_axis_conv=True, augment_type=None, device="cuda", seed=0):
+    """utils.get_transforms(frames, scaler=None, add_axis_conv=True, augment_type=None) (baseline/utils/utils.py:397-412):
+    noise -> log -> pad / truncate -> tensor (+ channel axis) -> normalise, as one callable to hand to DataLoadDf(transform=...)."""
+    return _SampleTransforms(frames, scaler, add_axis_conv, augment_type, device, seed)
+
+
 class WaveformFrontEnd:
     """BASELINE.json configs[2]: the mean-teacher step fed from raw waveforms resident in HBM.  Feature extraction =
     calculate_mel_spec for the whole batch (sed_mel_frames) -> the train-time transform chain with the teacher's noisy copy

@@ -290,6 +290,33 @@ def test_fft_f32_mode_holds_its_stated_bounds_at_batch_64():
     assert es < 1e-5 and ew < 1e-5
 
 
+def test_get_transforms_keeps_the_reference_per_sample_protocol():
+    """features.get_transforms(frames, scaler, add_axis_conv, augment_type) = utils.get_transforms (utils.py:397-412): a callable on
+    ``(features [frames_i, 64], label)`` that returns the reference's list - [x, label] or [x, x_noisy, label], host tensors, label
+    as float, channel axis when add_axis_conv - with the oracle's numbers."""
+    from dcase2019_task4_amd.features import Scaler, get_transforms
+    rs = np.random.RandomState(3)
+    feats = [(np.abs(rs.standard_normal((fr, 64))) * 2.0).astype(np.float32) for fr in (628, 600, 650)]
+    label = (rs.uniform(size=(78, 10)) < 0.2).astype(np.float64)
+    sc = Scaler()
+    sc.calculate_scaler([features_np.transform_chain(f, 628) for f in feats])
+    tr = get_transforms(628, sc)
+    for f in feats:
+        out = tr((f, label))
+        assert isinstance(out, list) and len(out) == 2
+        x, y = out
+        assert x.shape == (1, 628, 64) and x.dtype == torch.float32 and not x.is_cuda
+        assert y.dtype == torch.float32 and torch.equal(y, torch.tensor(label).float())
+        want = features_np.transform_chain(f, 628, sc.mean_, sc.std_)         # [1, 628, 64]
+        np.testing.assert_allclose(x.numpy(), want, atol=2e-5)
+    x2 = get_transforms(628, None, add_axis_conv=False)((feats[1], label))[0]
+    assert x2.shape == (628, 64)
+    out = get_transforms(628, sc, augment_type="noise", seed=5)((feats[0], label))
+    assert len(out) == 3 and out[1].shape == (1, 628, 64)
+    assert torch.equal(out[0], tr((feats[0], label))[0])                     # the clean copy does not depend on the augmentation
+    assert not torch.equal(out[0], out[1]) and torch.isfinite(out[1]).all()
+
+
 def test_feature_cache_and_device_scaler_pass(tmp_path):
     """N2: the .npy feature cache in the reference's layout (DatasetDcase2019Task4.py:183-195,255-262) written from
     batched GPU extraction, read back through get_feature_file; Scaler statistics from one device pass equal the

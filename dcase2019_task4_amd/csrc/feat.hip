@@ -479,6 +479,7 @@ __global__ __launch_bounds__(STP_THREADS) void k_stft_mel_p(const float* __restr
     extern __shared__ __attribute__((aligned(16))) unsigned char stp_raw[];
     StpLds<R>& L = *reinterpret_cast<StpLds<R>*>(stp_raw);
     typedef cx<R> C;
+    TS(10);
     const int tid = threadIdx.x, t = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);    // (wave-uniform: scalar registers)
     const int n_total = n_clips * frames, n_wv = gridDim.x * STP_WAVES;
     // (clip, frame) of this wave's current frame, advanced without a division per frame (all wave-uniform)
@@ -515,6 +516,7 @@ __global__ __launch_bounds__(STP_THREADS) void k_stft_mel_p(const float* __restr
         moff[p] = __builtin_amdgcn_readfirstlane((w_in_lds && 16 * p < n_mels) ? L.off[p] : 0);
     }
     TSC(0);
+    TS(8);                                                                    // (wall clock beside the shader clock: tools/ts_feat.py derives the clock the kernel runs at)
     while (g < n_total) {
         C v[16];
         // ---- windowed frame: z[m] = x[2m] + i x[2m + 1], m = 64 n1 + t ---------------------------------------------------------------
@@ -643,6 +645,8 @@ __global__ __launch_bounds__(STP_THREADS) void k_stft_mel_p(const float* __restr
         wave_lds_sync();                                                        // the magnitudes are read before the next frame's exchange 1 overwrites them
         TSC(6);
     }
+    TSC(7);
+    TS(9);
 }
 
 // ---- log / noise / pad / normalise ----------------------------------------------------------------

@@ -13,3 +13,9 @@ ts=np.frombuffer(buf,dtype=np.uint64).reshape(1024,16).astype(np.int64); ts=ts[t
 print(len(ts),"wgs")
 for k in range(1,7):
     d=ts[:,k]-ts[:,k-1]; print(f"stamp {k-1}->{k}: mean {d.mean():9.1f} min {d.min()} max {d.max()}")
+if (ts[:,9]>0).all():
+    cyc=(ts[:,7]-ts[:,0]).astype(float); wall=(ts[:,9]-ts[:,8]).astype(float)/100.0
+    print(f"frame loop: {cyc.mean():.0f} shader cycles in {wall.mean():.1f} us of wall clock = {cyc.mean()/wall.mean()/1e3:.3f} GHz")
+    pro=(ts[:,8]-ts[:,10]).astype(float)/100.0
+    t0=ts[:,10].min(); end=(ts[:,9]-t0).astype(float)/100.0; start=(ts[:,10]-t0).astype(float)/100.0
+    print(f"prologue (entry -> loop): mean {pro.mean():.1f} us max {pro.max():.1f}; workgroup start offsets: mean {start.mean():.1f} max {start.max():.1f} us; last loop end {end.max():.1f} us after the first entry")

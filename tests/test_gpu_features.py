@@ -290,6 +290,26 @@ def test_fft_f32_mode_holds_its_stated_bounds_at_batch_64():
     assert es < 1e-5 and ew < 1e-5
 
 
+@pytest.mark.parametrize("n_mels,f_max", [(128, 8000.0), (40, 8000.0), (64, 4000.0), (24, 2000.0)])
+def test_mel_spec_with_other_filterbanks(n_mels, f_max):
+    """sed_mel_frames takes ANY filterbank the caller passes (mel_basis [n_mels][1025]): 128 bands do not fit the persistent
+    kernel's LDS table (it walks the dense rows from the band supports instead), 40 / 24 bands are not a multiple of the 16 bands a
+    pass serves, a low f_max leaves most bins outside every band, wide low-resolution bands exceed the default trip counts.
+    All against the numpy oracle at the same 2e-6, fp64 and fp32 modes."""
+    from dcase2019_task4_amd.features import FeatureConfig, FeatureExtractor
+    cfg = FeatureConfig(sample_rate=16000, n_window=2048, hop_length=255, n_mels=n_mels, f_min=0.0, f_max=f_max)
+    fe = FeatureExtractor(cfg)
+    waves = np.stack([synth.make_wave(20 + i, 60000) for i in range(3)]).astype(np.float32)
+    got = fe.calculate_mel_spec_batch(torch.tensor(waves)).cpu().numpy()
+    got32 = fe.calculate_mel_spec_batch(torch.tensor(waves), fft_dtype="f32").cpu().numpy()
+    assert got.shape == (3, 1 + 60000 // 255, n_mels)
+    for i in range(3):
+        want = features_np.calculate_mel_spec(waves[i].astype(np.float64), cfg.sample_rate, cfg.n_window, cfg.hop_length,
+                                              cfg.n_mels, cfg.f_min, cfg.f_max)
+        np.testing.assert_allclose(got[i], want, rtol=2e-6, atol=1e-6 * want.max())
+        assert np.abs(got32[i] - want).max() < 3e-6 * want.max()
+
+
 def test_get_transforms_keeps_the_reference_per_sample_protocol():
     """features.get_transforms(frames, scaler, add_axis_conv, augment_type) = utils.get_transforms (utils.py:397-412): a callable on
     ``(features [frames_i, 64], label)`` that returns the reference's list - [x, label] or [x, x_noisy, label], host tensors, label

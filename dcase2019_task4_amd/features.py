@@ -365,7 +365,8 @@ class WaveformFrontEnd:
         if self.overlap:
             # lowest priority: the next batch's features must only fill CUs the step leaves idle, never win a CU from it
             lo, _hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, 0)
-            self._fe_stream = torch.cuda.Stream(device=step.device, priority=int(os.environ.get("SED_FE_PRIO", lo)))
+            from .train import shared_stream
+            self._fe_stream = shared_stream(step.device, "front-end", int(os.environ.get("SED_FE_PRIO", lo)))
             _lib.check(self.l.sed_stream_prepare(C.c_void_p(self._fe_stream.cuda_stream)), "sed_stream_prepare")
 
     # ---- staging ---------------------------------------------------------------------------------------------------------------

@@ -39,6 +39,22 @@ def update_ema_variables(model, ema_model, alpha, global_step):
                                          _lib.stream_ptr()), "sed_ema_update")
 
 
+_STREAM_POOL = {}
+
+
+def shared_stream(device, role, priority=0):
+    """One torch stream per (device, role, priority) for the whole process.  Every stream a step creates also gets two
+    helper streams inside the library (sed_stream_prepare) and none of them is ever destroyed; a process that built several
+    steps one after the other (bench.py's legs, a test session) ended up with dozens of live streams on four hardware queues,
+    and the graph branches of the later steps shared queues with them (measured: 0.90 instead of 0.66 ms for the fifth step
+    built in a process).  Steps of one process run one at a time, so they can share their capture / side / collective streams."""
+    key = (torch.device(device).index or 0, role, int(priority))
+    st = _STREAM_POOL.get(key)
+    if st is None:
+        st = _STREAM_POOL[key] = torch.cuda.Stream(device=device, priority=int(priority))
+    return st
+
+
 def _slice_range(s, B):
     if s is None:
         return 0, 0
@@ -146,7 +162,7 @@ class MeanTeacherStep:
         # RCCL group: 0.836 ms against 0.816 ms without data parallelism, 0.839 ms for "single", and 0.969 ms for the overlap
         # schedule with EAGER collectives between four graph segments - that one is host-bound: 4 graph launches + 2 async
         # collectives + stream waits per step).  Otherwise (gloo, or capture not available): "single" with an eager collective.
-        self._cap_stream = torch.cuda.Stream(device=dev)
+        self._cap_stream = shared_stream(dev, "capture")
         env_cap = os.environ.get("SED_DP_CAPTURE")
         want = dp_schedule or os.environ.get("SED_DP_SCHEDULE")
         if want == "split":
@@ -157,7 +173,7 @@ class MeanTeacherStep:
         if self.dp and use_graph and env_cap != "0" and want != "single":
             self.dp_capture = (env_cap == "1") or self._collective_capture_works()
         self.dp_schedule = want or ("overlap" if (self.dp_capture or not self.dp) else "single")
-        self._dp_stream = torch.cuda.Stream(device=dev) if self.dp else None
+        self._dp_stream = shared_stream(dev, "collective") if self.dp else None
         # train_cnn=False (CRNN.py:18-20, main.py:289-290 filters the optimiser's parameters on requires_grad): the conv
         # blocks' backward is skipped and their gradient stays zero, which makes Adam's update of those entries exactly
         # zero (zero moments, no weight decay) while the EMA still covers every parameter (main.py:45-49 zips ALL of them)
@@ -170,7 +186,7 @@ class MeanTeacherStep:
             self.sync_replicas()
         self.use_graph = bool(use_graph)
         self.overlap = bool(overlap_streams)
-        self._side = (torch.cuda.Stream(device=dev, priority=int(os.environ.get("SED_SIDE_PRIO", "0")))
+        self._side = (shared_stream(dev, "teacher", int(os.environ.get("SED_SIDE_PRIO", "0")))
                       if (self.overlap and teacher is not None) else None)
         self._capture_error = None
         self._graph_a = None

@@ -367,7 +367,7 @@ def workload_string(wide, mfma_dtype, waveform, B, fft="f32"):
             f"dropout 0.5, {ARITH[mfma_dtype]}")
 
 
-def make_runner(config, device, rank, pg=None, use_graph=True, batch=None, seed=1234):
+def make_runner(config, device, rank, pg=None, use_graph=True, batch=None, seed=1234, pool_streams=True):
     """Models + step (+ waveform front-end) of one workload of CONFIGS on synthetic data resident in HBM."""
     from dcase2019_task4_amd.train import MeanTeacherStep
     wide, mfma_dtype, waveform, b_default = CONFIGS[config]
@@ -378,7 +378,7 @@ def make_runner(config, device, rank, pg=None, use_graph=True, batch=None, seed=
     student, teacher = build_models(device, seed=0, **model_kw)        # identical replicas on every rank
     x, xe, tgt, wm, sm = synthetic_batch(B, T_FRAMES, 1000 + rank, device)
     step = MeanTeacherStep(student, teacher, B, T_FRAMES, rampup_length=210 * 100 // 2, weak_mask=wm, strong_mask=sm,
-                           seed=seed, use_graph=use_graph, process_group=pg)
+                           seed=seed, use_graph=use_graph, process_group=pg, pool_streams=pool_streams)
     step.load_batch(x, xe, tgt)
     runner = step
     if waveform:
@@ -438,6 +438,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the kernel table, feature-path and config3 legs")
     ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--trace-only-this-config", action="store_true",
+                    help="for rocprofv3 runs (tools/collect_profiles.sh): keep the headline's kernel-table leg (solo re-launches) "
+                         "but skip the extra_configs child processes and the feature-path leg, so that the trace holds ONE "
+                         "process and only this workload's kernels")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -559,7 +563,7 @@ def main():
                           "K steps as the driver asks: 20 steps = 15 ms is dominated by the first replays)"}
 
     extras = None
-    if world == 1 and headline and not args.no_extras and args.batch is None and rank == 0:
+    if world == 1 and headline and not args.no_extras and args.batch is None and rank == 0 and not args.trace_only_this_config:
         extras = extra_config_legs(device)
 
     if rank == 0:
@@ -631,7 +635,7 @@ def main():
                               "step's own buffers (sed_kernel_replay) after the timed region; conv*_wgrad = the Winograd "
                               "wgrad kernel + its ordered partial-sum reduction (the whole operator)")
         res["roofline"] = roof
-        if world == 1 and not args.no_extras and headline:
+        if world == 1 and not args.no_extras and headline and not args.trace_only_this_config:
             try:
                 res["feature_path"] = feature_path(device)
             except Exception as e:                      # the headline number must not depend on the extra leg

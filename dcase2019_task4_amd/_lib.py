@@ -72,6 +72,7 @@ _SIGS = {
     "sed_step_state_advance": (C.c_int, [_P, _P]),
     "sed_step_state_update": (C.c_int, [_P, C.c_uint64, C.c_double, C.c_int, _P]),
     "sed_stream_prepare": (C.c_int, [_P]),
+    "sed_stream_release": (C.c_int, [_P]),
     "sed_crnn_fork_callback": (C.c_int, [_P, _P, _P]),
     "sed_mel_spec_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "sed_mel_spec": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_size_t, _P]),

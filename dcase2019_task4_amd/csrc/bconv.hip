@@ -383,7 +383,7 @@ template <int X3, int C, int TW, int TH, int WM, int WN, int DIR>
 static int bconv_launch(const void* in0, const void* in1, const float* coef, const void* wpk, const float* bias, void* out,
                         double* stat, int B, int H, hipStream_t st) {
     using Cfg = BConvCfg<X3, C, TW, TH, WM, WN>;
-    static SedAttrOnce attr_done;
+    static thread_local SedAttrOnce attr_done;
     if (attr_done.need()) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_bconv<X3, C, TW, TH, WM, WN, DIR>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)Cfg::LDS_BYTES));

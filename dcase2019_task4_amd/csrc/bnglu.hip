@@ -724,7 +724,7 @@ int launch_glu_pool_bwd(const float* y, const float* bn, const float* wglu, cons
                         float* g_bglu, float* g_convb, BnBwdPrepArgs* prep_out, hipStream_t st) {
     const int Ho = H / 2, Wo = W / 4, Q = B * Ho * Wo;
     const size_t lds = (size_t)(4 * 3 * 32 * ZS + 64 * ZS) * sizeof(float);
-    static SedAttrOnce attr_done;
+    static thread_local SedAttrOnce attr_done;
     if (attr_done.need()) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_glu_pool_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
@@ -738,7 +738,7 @@ int launch_glu_pool_bwd(const float* y, const float* bn, const float* wglu, cons
     if (g_sed_debug & 16) {          // single-wave-per-SIMD variant (A/B timing)
         k_glu_pool_bwd<<<grid, 256, lds, st>>>(y, bn, wglu, bglu, dp, dp_b, dz, acc, H, W, Ho, Wo, Q, block_id, use_drop, p_drop, mask_in, g_sed_debug & 1);
     } else {
-        static SedAttrOnce attr8;
+        static thread_local SedAttrOnce attr8;
         if (attr8.need()) {
             SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_glu_pool_bwd8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }

@@ -31,8 +31,12 @@ void sed_set_error(const char* fmt, ...);
     } while (0)
 #define SED_CHECK_LAUNCH() SED_CHECK_HIP(hipGetLastError())
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: every launcher raises it once per
-// device it is used on (a function-local `static bool` did it once per process - a second GPU driven from the same process
-// would have launched with the default 64 KB limit).  `static SedAttrOnce once; if (once.need()) { ...set attributes... }`
+// device it is used on AND per host thread: `static thread_local SedAttrOnce once; if (once.need()) { ...set attributes... }`.
+// The flag is thread-local on purpose: a process-wide flag has to be set either before the attribute call (a second thread
+// then sees it, skips the call and can launch with the default 64 KB limit while the first thread is still inside
+// hipFuncSetAttribute) or after it (which needs a hook behind every call site's error returns).  The call is idempotent and
+// thread-safe, so each thread simply makes it once itself; a thread only skips what it has itself completed.  If the call
+// fails the launcher returns SED_ERR_LAUNCH and the launches that follow fail loudly on the LDS size.
 struct SedAttrOnce {
     bool done[64] = {};
     bool need() {

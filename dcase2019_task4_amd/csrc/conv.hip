@@ -616,7 +616,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wino(const float* __restrict__ 
 template <int MODE>
 static int conv16_ws_launch(const float* in0, const float* in1, const float* coef, const float* wpk, const float* bias,
                             float* out, double* stat, int B, int H, hipStream_t st) {
-    static SedAttrOnce attr_done;
+    static thread_local SedAttrOnce attr_done;
     if (attr_done.need()) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv16_ws2<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)Ws16::LDS_BYTES));
@@ -636,7 +636,7 @@ static int conv_wino_launch(const float* in0, const float* in1, const float* coe
     BnBwdPrepArgs pa = {};
     if (prep) pa = *prep;
     using C = Wino<TW>;
-    static SedAttrOnce attr_done;
+    static thread_local SedAttrOnce attr_done;
     if (attr_done.need()) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_wino<TW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)C::LDS_BYTES));
@@ -1214,7 +1214,7 @@ template <int TW, int MODE, int NS>
 static int conv_launch_t(const float* in0, const float* in1, const float* coef, const float* wpk, const float* bias,
                          float* out, double* stat, int B, int H, hipStream_t st) {
     using Cfg = ConvCfg<TW>;
-    static SedAttrOnce attr_done;
+    static thread_local SedAttrOnce attr_done;
     if (attr_done.need()) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3<TW, MODE, NS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)Cfg::LDS_BYTES));
@@ -1275,7 +1275,7 @@ static int wgrad_launch_t(const float* dz, const float* yin, const float* coef, 
     if (prep) pa = *prep;
 #ifdef SED_AB
     using Cfg = WgCfg<TW>;
-    static SedAttrOnce attr_done;
+    static thread_local SedAttrOnce attr_done;
     if (attr_done.need()) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad<TW, TS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)Cfg::LDS_BYTES));
@@ -1291,7 +1291,7 @@ static int wgrad_launch_t(const float* dz, const float* yin, const float* coef, 
     // of the debug knob bring the direct kernels back (bit 7 = k_wgrad16_db for block 1, bit 3 = the tile kernel)
     if (!SED_AB_FLAGS(8 | 128)) {
         using CW = WgW<TW>;
-        static SedAttrOnce attrw;
+        static thread_local SedAttrOnce attrw;
         if (attrw.need()) {
             SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_wgrad_wino<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CW::LDS_BYTES));
         }
@@ -1302,7 +1302,7 @@ static int wgrad_launch_t(const float* dz, const float* yin, const float* coef, 
     }
 #ifdef SED_AB
     else if (TW == 16 && TS == 1 && !(g_sed_debug & 8)) {
-        static SedAttrOnce attr16;
+        static thread_local SedAttrOnce attr16;
         if (attr16.need()) {
             SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_wgrad16_db, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wg16::LDS_BYTES));
         }

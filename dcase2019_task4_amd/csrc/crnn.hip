@@ -194,6 +194,8 @@ struct SideStream {
 };
 static std::mutex g_side_mu;
 static std::map<std::pair<int, hipStream_t>, SideStream*> g_side;
+struct ForkHook { void (*fn)(void*) = nullptr; void* user = nullptr; };        // sed_crnn_fork_callback, below
+static std::map<std::pair<int, hipStream_t>, ForkHook> g_fork_hooks;
 static SideStream& side_stream(hipStream_t caller) {
     static SideStream none;
     int dev = 0;
@@ -221,6 +223,33 @@ extern "C" int sed_stream_prepare(void* stream) {
     }
     return SED_OK;
 }
+// Releases what sed_stream_prepare / first use created for `stream` on the current device: both helper streams, the three
+// events and a pending fork hook.  The caller guarantees that no work of the library is in flight or being captured on the
+// stream (synchronise it first); the stream can be prepared again afterwards.  A caller stream that was never prepared is a
+// no-op.  hipStreamDestroy on a helper stream that still has work queued would complete it asynchronously, which is why the
+// helpers are synchronised here first - this is the ONE entry point of the library that blocks the host.
+extern "C" int sed_stream_release(void* stream) {
+    int dev = 0;
+    SED_CHECK_HIP(hipGetDevice(&dev));
+    SideStream* sd = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_side_mu);
+        const auto key = std::make_pair(dev, (hipStream_t)stream);
+        auto it = g_side.find(key);
+        if (it != g_side.end()) { sd = it->second; g_side.erase(it); }
+        g_fork_hooks.erase(key);
+    }
+    if (sd == nullptr) return SED_OK;
+    int rc = SED_OK;
+    auto note = [&](hipError_t e) { if (e != hipSuccess && rc == SED_OK) { sed_set_error("sed_stream_release: %s", hipGetErrorString(e)); rc = SED_ERR_LAUNCH; } };
+    if (sd->s) { note(hipStreamSynchronize(sd->s)); note(hipStreamDestroy(sd->s)); }
+    if (sd->s2) { note(hipStreamSynchronize(sd->s2)); note(hipStreamDestroy(sd->s2)); }
+    if (sd->fork) note(hipEventDestroy(sd->fork));
+    if (sd->join) note(hipEventDestroy(sd->join));
+    if (sd->join2) note(hipEventDestroy(sd->join2));
+    delete sd;
+    return rc;
+}
 // One-shot hook for a caller with independent work to run BESIDE the recurrent part of a forward (the waveform front-end:
 // the next batch's STFT, features.WaveformFrontEnd): the next sed_crnn_forward on `stream` calls fn(user) on the calling host
 // thread after enqueueing its last conv-block kernel and before enqueueing its first recurrence kernel.  The callback forks
@@ -228,13 +257,13 @@ extern "C" int sed_stream_prepare(void* stream) {
 // enqueue ORDER too: a hipGraph captured around the forward submits its nodes in creation order, and a dependency on a node in
 // the middle of another stream's chain that is submitted late starts late (measured: a fork expressed only as an event
 // recorded here and waited for after the forward returned started 300 us late, at the first backward kernel).
-struct ForkHook { void (*fn)(void*) = nullptr; void* user = nullptr; };
-static std::map<std::pair<int, hipStream_t>, ForkHook> g_fork_hooks;
 extern "C" int sed_crnn_fork_callback(void* stream, void (*fn)(void*), void* user) {
     int dev = 0;
     SED_CHECK_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_side_mu);
-    ForkHook& h = g_fork_hooks[std::make_pair(dev, (hipStream_t)stream)];
+    const auto key = std::make_pair(dev, (hipStream_t)stream);
+    if (fn == nullptr) { g_fork_hooks.erase(key); return SED_OK; }
+    ForkHook& h = g_fork_hooks[key];
     h.fn = fn;
     h.user = user;
     return SED_OK;
@@ -248,7 +277,7 @@ int sed_fork_point(hipStream_t st) {
         auto it = g_fork_hooks.find(std::make_pair(dev, st));
         if (it == g_fork_hooks.end()) return SED_OK;
         h = it->second;
-        it->second = ForkHook();
+        g_fork_hooks.erase(it);
     }
     if (h.fn) h.fn(h.user);
     return SED_OK;

@@ -601,6 +601,10 @@ __global__ __launch_bounds__(STP_THREADS) void k_stft_mel_p(const float* __restr
         }
         const C Zh = STP_Z(8);                                                  // lane 0: Z[512]; |X[512]| = |Z[512]|
         if (t == 0) mag[512] = (R)2 * stp_sqrt(Zh.x * Zh.x + Zh.y * Zh.y);
+        // the zero-weight padding trips of the packed projection read up to mag[1055] (k_feat_pack's guard): whatever the exchanges
+        // left there - or, for the two fp64 elements no exchange ever writes, whatever the LDS held before the launch - must not be
+        // an Inf / NaN pattern (0 x NaN would poison a band sum)
+        if (t < STP_XB - (NH + 1)) mag[NH + 1 + t] = (R)0;
 #undef STP_Z
         wave_lds_sync();
         // the next frame's samples are requested here: the FFT's registers are free from this point on (held across the
@@ -836,7 +840,7 @@ template <typename R>
 static int launch_stft_p(const float* wave, int n_clips, int n_samples, int hop, int frames, const double2* tw, const double* win,
                          const float* mel_basis, const int* band, const float* melw, int n_mels, float* mel, int max_workgroups,
                          hipStream_t st) {
-    static SedAttrOnce attr_done;
+    static thread_local SedAttrOnce attr_done;
     if (attr_done.need())
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_stft_mel_p<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(StpLds<R>)));
     const long long n_total = (long long)n_clips * frames;

@@ -190,7 +190,7 @@ template <int MODE, int C, int TW, int DIR>
 static int gconv_launch(const float* in0, const float* in1, const float* coef, const void* wpk, const float* bias, float* out,
                         double* stat, int B, int H, hipStream_t st) {
     using Cfg = GConvCfg<MODE, C, TW>;
-    static SedAttrOnce attr_done;
+    static thread_local SedAttrOnce attr_done;
     if (attr_done.need()) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gconv<MODE, C, TW, DIR>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)Cfg::LDS_BYTES));
@@ -826,7 +826,7 @@ int launch_gwgrad(int mode, int C, const void* dz, const void* yin, const float*
     int nt, tpc;
     if (W == 16 && (mode == SED_DTYPE_BF16 || (mode == SED_DTYPE_BF16X3 && !(g_sed_debug & 4194304)))) {
         // (debug bit 22: the split-operand mode's weight gradient on the exact-fp32 MFMA kernel, as in round 3 - A/B)
-        static SedAttrOnce attr;
+        static thread_local SedAttrOnce attr;
         if (attr.need()) {
             SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad_bf16<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GWgB::STAGE_BYTES));
             SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad_bf16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GWgB::STAGE_BYTES_X3));
@@ -837,13 +837,13 @@ int launch_gwgrad(int mode, int C, const void* dz, const void* yin, const float*
         else k_gwgrad_bf16<1><<<dim3(slabs, nq), 512, GWgB::STAGE_BYTES_X3, st>>>(dz, yin, coef, xin, part, C, H, tpc, nt);
     } else if (W == 16) {
         using Cfg = GWgCfg<16>;
-        static SedAttrOnce attr;
+        static thread_local SedAttrOnce attr;
         if (attr.need()) { SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad<16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES)); }
         tpc = (H + Cfg::TH - 1) / Cfg::TH; nt = B * tpc;
         if (slabs > nt) slabs = nt;
         k_gwgrad<16, 0><<<dim3(slabs, nq), 256, Cfg::LDS_BYTES, st>>>(dz, yin, coef, xin, part, C, H, tpc, nt);
     } else if (W == 4 && mode == SED_DTYPE_BF16) {
-        static SedAttrOnce attr;
+        static thread_local SedAttrOnce attr;
         if (attr.need()) { SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad4_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GWg4::LDS_BYTES)); }
         tpc = (H + GWg4::TH - 1) / GWg4::TH; nt = B * tpc;
         const int blocks = (C / 32) * (C / 32) * 3;                        // (co block, ci block, kernel row) per slab
@@ -853,7 +853,7 @@ int launch_gwgrad(int mode, int C, const void* dz, const void* yin, const float*
         k_gwgrad4_bf16<<<dim3(slabs, blocks), 256, GWg4::LDS_BYTES, st>>>((const __bf16*)dz, (const __bf16*)yin, coef, (const __bf16*)xin, part, C, H, tpc, nt);
     } else if (W == 4) {
         using Cfg = GWgCfg<4>;
-        static SedAttrOnce attr;
+        static thread_local SedAttrOnce attr;
         if (attr.need()) {
             SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
             SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gwgrad<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));

@@ -414,7 +414,7 @@ int launch_gemm_batch(GemmBatch& gb, hipStream_t st) {
     }
     dim3 grid((maxN + GT_N - 1) / GT_N, (maxM + GT_M - 1) / GT_M, gb.n_prob * gb.splits);
     const size_t lds = (size_t)(GT_M * (GT_K + 1) + GT_K * (GT_N + 1)) * sizeof(float);
-    static SedAttrOnce attr_done;
+    static thread_local SedAttrOnce attr_done;
     if (attr_done.need()) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_batched<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_batched<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -175,7 +175,7 @@ template <int MODE, int C, int PB>
 static int gglu_fwd_launch(const void* y, const GBnArgs& bn, const void* wg, const float* bg, void* p, int B, int H, int W,
                            int block_id, int use_drop, float p_drop, const uint64_t* seed, uint16_t* mask_out, hipStream_t st) {
     using Cfg = GGluFwdCfg<MODE, C>;
-    static SedAttrOnce attr;
+    static thread_local SedAttrOnce attr;
     if (attr.need()) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gglu_fwd<MODE, C, PB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
     }
@@ -467,7 +467,7 @@ static int gglu_bwd_launch(const void* y, const float* bn, const float* gamma, c
                            float p_drop, const uint16_t* mask_in, hipStream_t st) {
     using Cfg = GGluBwdCfg<MODE, C>;
     static_assert(Cfg::LDS_BYTES <= 160 * 1024, "GLU backward tiles exceed the LDS");
-    static SedAttrOnce attr;
+    static thread_local SedAttrOnce attr;
     if (attr.need()) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gglu_bwd<MODE, C, PB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
     }

@@ -436,7 +436,7 @@ static const size_t GRU_BWD_LDS = (size_t)(192 + 2 * GRU_SB * 384 + 2 * GRU_SB *
 int launch_gru_fwd_v1(const float* x, int nin, const float* w_ih_f, const float* w_ih_r, const float* b_ih_f, const float* b_ih_r,
                    const float* w_hh_f, const float* w_hh_r, const float* b_hh_f, const float* b_hh_r, float* out, float* gates,
                    int B, int T, hipStream_t st) {
-    static SedAttrOnce attr_done;
+    static thread_local SedAttrOnce attr_done;
     if (attr_done.need()) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gru_fwd<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gru_fwd_lds<64>()));
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gru_fwd<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gru_fwd_lds<128>()));
@@ -458,7 +458,7 @@ int launch_gru_fwd_v1(const float* x, int nin, const float* w_ih_f, const float*
 int launch_gru_bwd_v1(const float* d_out, const float* d_out2, const float* out, const float* gates, const float* w_hh_f,
                    const float* w_hh_r, const float* w_ih_f, const float* w_ih_r, int nin, float* dgi, float* dgh, float* hprev,
                    float* dx_planes, int B, int T, hipStream_t st) {
-    static SedAttrOnce attr_done;
+    static thread_local SedAttrOnce attr_done;
     if (attr_done.need()) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gru_bwd<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRU_BWD_LDS));
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gru_bwd<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRU_BWD_LDS));

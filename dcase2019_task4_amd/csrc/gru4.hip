@@ -567,7 +567,7 @@ int launch_gru_fwd(const float* x, int nin, const float* w_ih_f, const float* w_
     if (g_sed_debug & 4096)       // round 1's one-wave recurrence, for A/B timing
         return launch_gru_fwd_v1(x, nin, w_ih_f, w_ih_r, b_ih_f, b_ih_r, w_hh_f, w_hh_r, b_hh_f, b_hh_r, out, gates, B, T, st);
 #endif
-    static SedAttrOnce attr_done;
+    static thread_local SedAttrOnce attr_done;
     if (attr_done.need()) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gru4_fwd<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gru4_fwd_lds<64>()));
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gru4_fwd<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gru4_fwd_lds<128>()));
@@ -593,7 +593,7 @@ int launch_gru_bwd(const float* d_out, const float* d_out2, const float* out, co
     if (g_sed_debug & 4096)
         return launch_gru_bwd_v1(d_out, d_out2, out, gates, w_hh_f, w_hh_r, w_ih_f, w_ih_r, nin, dgi, dgh, hprev, dx_planes, B, T, st);
 #endif
-    static SedAttrOnce attr_done;
+    static thread_local SedAttrOnce attr_done;
     if (attr_done.need()) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gru4_bwd<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRU4_BWD_LDS));
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gru4_bwd<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRU4_BWD_LDS));

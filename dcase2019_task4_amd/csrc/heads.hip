@@ -546,7 +546,7 @@ static int heads_fwd_launch(const float* h, const float* wd, const float* bd, co
                             int use_drop, float p_drop, const uint64_t* seed, hipStream_t st) {
     HD_CONSTS(HF);
     const size_t lds = (size_t)(HD_TC * HD_SF + HD_MAXO * HD_SF + HD_TC * HD_MAXO + 2 * HD_TC * 16 + 32) * sizeof(float);
-    static SedAttrOnce attr_done;
+    static thread_local SedAttrOnce attr_done;
     if (attr_done.need()) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_heads_fwd<HF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
@@ -576,7 +576,7 @@ static int heads_bwd_launch(const float* h, const float* wd, const float* ws, co
                             int n_zero, const HeadsLoss& hl0, hipStream_t st) {
     HD_CONSTS(HF);
     const size_t lds = (size_t)(HD_TC * HD_SB + HD_MAXO * HD_SB + HD_TC * HD_SD + 32 + HD_THREADS) * sizeof(float);
-    static SedAttrOnce attr_done;
+    static thread_local SedAttrOnce attr_done;
     if (attr_done.need()) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_heads_bwd<HF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }

@@ -288,8 +288,38 @@ class _SampleTransforms:
     def __init__(self, frames, scaler, add_axis_conv, augment_type, device, seed):
         self.add_axis_conv = bool(add_axis_conv)
         self.tr = LogMelTransform(frames, scaler=scaler, augment_type=augment_type, device=device, seed=seed)
+        self._worker = None
+
+    @staticmethod
+    def worker_seed(seed, worker_id):
+        """The noise seed of DataLoader worker `worker_id`: splitmix64 of (seed, worker id + 1).  Every worker holds its own
+        copy of this object, whose call counter restarts at the same value - with the bare seed all workers would draw the
+        same noise for their n-th sample."""
+        z = (int(seed) + 0x9E3779B97F4A7C15 * (int(worker_id) + 1)) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        return (z ^ (z >> 31)) & 0x7FFFFFFFFFFFFFFF
+
+    def _enter_worker(self):
+        """The reference hands this callable to DataLoadDf and runs it inside DataLoader workers (config.py: num_workers = 12,
+        fork).  The arithmetic here is a GPU kernel and there is no CPU path: a FORKED worker cannot use the parent's HIP
+        context, so that case is refused with a message that says what to do instead of torch's re-initialisation error;
+        a spawned worker works (its own context, one launch + one copy per sample) and gets a noise stream of its own."""
+        info = torch.utils.data.get_worker_info()
+        self._worker = -1 if info is None else int(info.id)
+        if info is None:
+            return
+        if torch.cuda._is_in_bad_fork():
+            raise _lib.SedError(
+                "get_transforms(...) runs sed_logmel_transform on the GPU and was called in a forked DataLoader worker, which "
+                "cannot use the parent's HIP context.  Use DataLoader(num_workers=0), or multiprocessing_context='spawn' "
+                "(one context + one launch per sample and worker), or - the fast path - keep linear-mel features in the "
+                "dataset and apply features.LogMelTransform / WaveformFrontEnd to whole batches on the training process.")
+        self.tr._seed = self.worker_seed(self.tr._seed, info.id)
 
     def __call__(self, sample):
+        if self._worker is None:
+            self._enter_worker()
         sample = list(sample)
         label = torch.from_numpy(np.asarray(sample[-1])).float()              # ToTensor: "even labels" (DataLoad.py:316)
         outs = []
@@ -300,10 +330,17 @@ class _SampleTransforms:
         outs = [o[0].cpu() if self.add_axis_conv else o[0, 0].cpu() for o in outs]
         return outs + [label]
 
+    def __getstate__(self):
+        # (pickled into spawned workers: the worker decides for itself where it runs)
+        st = dict(self.__dict__)
+        st["_worker"] = None
+        return st
+
 
 def get_transforms(frames, scaler=None, add_axis_conv=True, augment_type=None, device="cuda", seed=0):
     """utils.get_transforms(frames, scaler=None, add_axis_conv=True, augment_type=None) (baseline/utils/utils.py:397-412):
-    noise -> log -> pad / truncate -> tensor (+ channel axis) -> normalise, as one callable to hand to DataLoadDf(transform=...)."""
+    noise -> log -> pad / truncate -> tensor (+ channel axis) -> normalise, as one callable to hand to DataLoadDf(transform=...).
+    In-process (num_workers=0) or in SPAWNED DataLoader workers; a forked worker is refused with a clear error (no CPU path)."""
     return _SampleTransforms(frames, scaler, add_axis_conv, augment_type, device, seed)
 
 
@@ -365,8 +402,7 @@ class WaveformFrontEnd:
         if self.overlap:
             # lowest priority: the next batch's features must only fill CUs the step leaves idle, never win a CU from it
             lo, _hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, 0)
-            from .train import shared_stream
-            self._fe_stream = shared_stream(step.device, "front-end", int(os.environ.get("SED_FE_PRIO", lo)))
+            self._fe_stream = step._stream("front-end", int(os.environ.get("SED_FE_PRIO", lo)))     # (released by step.close())
             _lib.check(self.l.sed_stream_prepare(C.c_void_p(self._fe_stream.cuda_stream)), "sed_stream_prepare")
 
     # ---- staging ---------------------------------------------------------------------------------------------------------------

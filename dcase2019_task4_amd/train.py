@@ -43,11 +43,13 @@ _STREAM_POOL = {}
 
 
 def shared_stream(device, role, priority=0):
-    """One torch stream per (device, role, priority) for the whole process.  Every stream a step creates also gets two
-    helper streams inside the library (sed_stream_prepare) and none of them is ever destroyed; a process that built several
-    steps one after the other (bench.py's legs, a test session) ended up with dozens of live streams on four hardware queues,
-    and the graph branches of the later steps shared queues with them (measured: 0.90 instead of 0.66 ms for the fifth step
-    built in a process).  Steps of one process run one at a time, so they can share their capture / side / collective streams."""
+    """One torch stream per (device, role, priority) for the whole process.  Every stream a step hands to the library also gets
+    two helper streams inside it (sed_stream_prepare); until round 5 nothing ever destroyed those, and a process that built
+    several steps one after the other (bench.py's legs, a test session) ended up with dozens of live streams on four hardware
+    queues - the graph branches of the later steps shared queues with them (measured: 0.90 instead of 0.66 ms for the fifth
+    step built in a process).  The library now has sed_stream_release, and a step built with ``pool_streams=False`` owns its
+    streams and releases them in ``close()``; the pool stays the default because steps of one process run one at a time and
+    torch itself hands out streams from a fixed pool of 32 per device and priority."""
     key = (torch.device(device).index or 0, role, int(priority))
     st = _STREAM_POOL.get(key)
     if st is None:
@@ -73,7 +75,7 @@ class MeanTeacherStep:
 
     def __init__(self, student, teacher, batch_size, n_frames, rampup_length, weak_mask, strong_mask, lr=1e-3,
                  betas=(0.9, 0.999), eps=1e-8, ema_decay=0.999, max_consistency_cost=2.0, seed=0, use_graph=True,
-                 process_group=None, overlap_streams=True, dp_schedule=None):
+                 process_group=None, overlap_streams=True, dp_schedule=None, pool_streams=True):
         assert isinstance(student, CRNN) and (teacher is None or isinstance(teacher, CRNN))
         self.l = _lib.lib()
         self.student, self.teacher = student, teacher
@@ -89,6 +91,8 @@ class MeanTeacherStep:
         if teacher is not None and (teacher._C, teacher._H, teacher._dtype) != (student._C, student._H, student._dtype):
             raise ValueError("student and teacher must have the same geometry and mfma_dtype")
         self.dims = student.make_dims(self.B, self.T)
+        self._pool_streams = bool(pool_streams)
+        self._owned_streams = []
         self.T3, self.NC = self.T // 8, student._nclass
         self.wlo, self.whi = _slice_range(weak_mask, self.B) if weak_mask is not None else (0, 0)
         self.slo, self.shi = _slice_range(strong_mask, self.B) if strong_mask is not None else (0, 0)
@@ -162,7 +166,7 @@ class MeanTeacherStep:
         # RCCL group: 0.836 ms against 0.816 ms without data parallelism, 0.839 ms for "single", and 0.969 ms for the overlap
         # schedule with EAGER collectives between four graph segments - that one is host-bound: 4 graph launches + 2 async
         # collectives + stream waits per step).  Otherwise (gloo, or capture not available): "single" with an eager collective.
-        self._cap_stream = shared_stream(dev, "capture")
+        self._cap_stream = self._stream("capture")
         env_cap = os.environ.get("SED_DP_CAPTURE")
         want = dp_schedule or os.environ.get("SED_DP_SCHEDULE")
         if want == "split":
@@ -173,7 +177,7 @@ class MeanTeacherStep:
         if self.dp and use_graph and env_cap != "0" and want != "single":
             self.dp_capture = (env_cap == "1") or self._collective_capture_works()
         self.dp_schedule = want or ("overlap" if (self.dp_capture or not self.dp) else "single")
-        self._dp_stream = shared_stream(dev, "collective") if self.dp else None
+        self._dp_stream = self._stream("collective") if self.dp else None
         # train_cnn=False (CRNN.py:18-20, main.py:289-290 filters the optimiser's parameters on requires_grad): the conv
         # blocks' backward is skipped and their gradient stays zero, which makes Adam's update of those entries exactly
         # zero (zero moments, no weight decay) while the EMA still covers every parameter (main.py:45-49 zips ALL of them)
@@ -186,7 +190,7 @@ class MeanTeacherStep:
             self.sync_replicas()
         self.use_graph = bool(use_graph)
         self.overlap = bool(overlap_streams)
-        self._side = (shared_stream(dev, "teacher", int(os.environ.get("SED_SIDE_PRIO", "0")))
+        self._side = (self._stream("teacher", int(os.environ.get("SED_SIDE_PRIO", "0")))
                       if (self.overlap and teacher is not None) else None)
         self._capture_error = None
         self._graph_a = None
@@ -201,6 +205,23 @@ class MeanTeacherStep:
         self._warm = 0
         self.steps_done = 0
 
+    def _stream(self, role, priority=0):
+        if self._pool_streams:
+            return shared_stream(self.device, role, priority)
+        st = torch.cuda.Stream(device=self.device, priority=int(priority))
+        self._owned_streams.append(st)
+        return st
+
+    def close(self):
+        """Drops the graphs and releases what the library created for the streams this step OWNS (``pool_streams=False``):
+        sed_stream_release destroys the two helper streams + events per stream.  Pooled streams are shared with every other
+        step of the process and stay prepared.  The step must not be used afterwards."""
+        torch.cuda.synchronize(self.device)
+        self._graph_a = self._graph_w = self._graph_c = self._graph_b = None
+        for st in self._owned_streams:
+            _lib.check(self.l.sed_stream_release(C.c_void_p(st.cuda_stream)), "sed_stream_release")
+        self._owned_streams = []
+
     # ---- pieces ------------------------------------------------------------------------------------
     def _forward(self, model, x, ctx, seed, strong, weak):
         _lib.check(self.l.sed_crnn_forward(C.byref(self.dims), _lib.ptr(model._flat), _lib.ptr(model._bn_flat),
@@ -209,33 +230,49 @@ class MeanTeacherStep:
                    "sed_crnn_forward")
 
     def _fwd_bwd(self, after_forward=None, at_recurrence=None):
+        self._fork_exc = None
         try:
             self._fwd_bwd_impl(after_forward, at_recurrence)
         finally:
             if at_recurrence is not None:      # one-shot hook: never leave it registered (e.g. a forward that failed before it)
                 self.l.sed_crnn_fork_callback(_lib.stream_ptr(), None, None)
+        if self._fork_exc is not None:
+            # ctypes swallows (prints) an exception raised inside a C callback: a failing hook - the next batch's feature
+            # extraction - would otherwise leave a captured graph without those kernels and the step training on stale slots
+            exc, self._fork_exc = self._fork_exc, None
+            raise exc
+
+    def _student_forward(self, at_recurrence):
+        """The student forward (main.py:91).  The one-shot `at_recurrence` hook is registered right in front of THIS call: the
+        library hands it to the next sed_crnn_forward on the stream, which without a side stream would be the teacher's."""
+        if at_recurrence is not None:
+            def hook(_user):
+                try:
+                    at_recurrence()
+                except BaseException as e:      # noqa: BLE001 - re-raised by _fwd_bwd once the C call has returned
+                    self._fork_exc = e
+            self._fork_cb = _lib.FORK_CALLBACK(hook)      # (kept alive until the forward has run)
+            _lib.check(self.l.sed_crnn_fork_callback(_lib.stream_ptr(), self._fork_cb, None), "sed_crnn_fork_callback")
+        self._forward(self.student, self.x, self.ctx_s, self._seed_s, self.strong, self.weak)
 
     def _fwd_bwd_impl(self, after_forward=None, at_recurrence=None):
         """teacher forward (main.py:87-89), student forward (:91), losses (:93-145), backward (:152-153).
         `after_forward`: called between the forwards and the backward; `at_recurrence`: called from INSIDE the student
         forward, between its conv stack and its recurrence (sed_crnn_fork_callback) - where the waveform front-end forks
         the next batch's feature kernels (features.WaveformFrontEnd)."""
-        if at_recurrence is not None:
-            self._fork_cb = _lib.FORK_CALLBACK(lambda _user: at_recurrence())      # (kept alive until the forward has run)
-            _lib.check(self.l.sed_crnn_fork_callback(_lib.stream_ptr(), self._fork_cb, None), "sed_crnn_fork_callback")
         if self.supervised:
-            self._forward(self.student, self.x, self.ctx_s, self._seed_s, self.strong, self.weak)
+            self._student_forward(at_recurrence)
         elif self._side is not None:
             # the teacher forward is independent of the student forward: run it on a second stream
             cur = torch.cuda.current_stream()
             self._side.wait_stream(cur)
             with torch.cuda.stream(self._side):
                 self._forward(self.teacher, self.x_ema, self.ctx_t, self._seed_t, self.strong_ema, self.weak_ema)
-            self._forward(self.student, self.x, self.ctx_s, self._seed_s, self.strong, self.weak)
+            self._student_forward(at_recurrence)
             cur.wait_stream(self._side)
         else:
             self._forward(self.teacher, self.x_ema, self.ctx_t, self._seed_t, self.strong_ema, self.weak_ema)
-            self._forward(self.student, self.x, self.ctx_s, self._seed_s, self.strong, self.weak)
+            self._student_forward(at_recurrence)
         if after_forward is not None:
             after_forward()
         # losses (main.py:93-145) + backward in one call: the heads-backward kernel forms the loss gradient per clip itself

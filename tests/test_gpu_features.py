@@ -337,6 +337,40 @@ def test_get_transforms_keeps_the_reference_per_sample_protocol():
     assert not torch.equal(out[0], out[1]) and torch.isfinite(out[1]).all()
 
 
+class _OneSampleSet(torch.utils.data.Dataset):
+    """What DataLoadDf does with its transform (DataLoad.py:128-143), without pandas: features + label -> transform(sample)."""
+
+    def __init__(self, transform):
+        self.transform = transform
+        rs = np.random.RandomState(11)
+        self.feat = (np.abs(rs.standard_normal((628, 64))) * 2.0).astype(np.float32)
+        self.label = np.zeros((78, 10))
+
+    def __len__(self):
+        return 4
+
+    def __getitem__(self, i):
+        return self.transform((self.feat, self.label))
+
+
+def test_get_transforms_refuses_a_forked_dataloader_worker_and_seeds_spawned_ones():
+    """The reference runs the transform in forked DataLoader workers (config.py num_workers = 12).  There is no CPU path here:
+    a forked worker must fail with OUR message (what to do instead), not with torch's 'Cannot re-initialize CUDA in forked
+    subprocess'; workers that can run (spawn) draw different noise (the worker id is folded into the seed)."""
+    from dcase2019_task4_amd._lib import SedError
+    from dcase2019_task4_amd.features import _SampleTransforms, get_transforms
+    torch.zeros(1, device="cuda")                                    # the parent owns a HIP context, as a training process does
+    ds = _OneSampleSet(get_transforms(628, None, augment_type="noise", seed=5))
+    assert len(ds[0]) == 3                                           # in-process: fine
+    dl = torch.utils.data.DataLoader(ds, batch_size=2, num_workers=1, multiprocessing_context="fork")
+    with pytest.raises(Exception) as ei:
+        next(iter(dl))
+    assert "forked DataLoader worker" in str(ei.value) and "spawn" in str(ei.value), str(ei.value)[-600:]
+    assert issubclass(SedError, RuntimeError)
+    seeds = {_SampleTransforms.worker_seed(5, w) for w in range(12)} | {5}
+    assert len(seeds) == 13
+
+
 def test_feature_cache_and_device_scaler_pass(tmp_path):
     """N2: the .npy feature cache in the reference's layout (DatasetDcase2019Task4.py:183-195,255-262) written from
     batched GPU extraction, read back through get_feature_file; Scaler statistics from one device pass equal the

@@ -4,7 +4,10 @@ The compiler's own per-kernel report (-Rpass-analysis=kernel-resource-usage, wri
 parsed by tools/check_resources.py.  Round 3 shipped five kernels with VGPR spills (one of them inside a latency-bound
 per-time-step loop) and four with SGPR spills without anyone noticing: a spill never shows up as a failure, only as time."""
 import os
+import shutil
 import sys
+
+import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "tools"))
@@ -12,6 +15,9 @@ sys.path.insert(0, os.path.join(REPO, "tools"))
 
 def test_no_kernel_spills_registers_or_uses_scratch():
     import check_resources
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which("hipcc")):
+        pytest.skip("no hipcc on this host: the resource reports are produced by the gfx950 build")
     kernels = check_resources.parse(build=True)
     assert len(kernels) > 100, "resource report is missing (csrc/build/*.res): the Makefile writes it on every compile"
     bad = check_resources.offenders(kernels)

@@ -1,17 +1,20 @@
 #!/bin/bash
-# Profile collection on the GPU box (rounds 3 and 4) (run through gpurun from the repo root); writes under gpurun_out/$PROF_TAG/.
+# Profile collection on the GPU box (rounds 3 - 5) (run through gpurun from the repo root); writes under gpurun_out/$PROF_TAG/.
 # Counters are collected in their own passes with --kernel-trace only (never with hip/hsa trace domains).
 set -u
-OUT=$GRAFT_REPO_ROOT/gpurun_out/${PROF_TAG:-r04}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${PROF_TAG:-r05}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-CFGS="mt-f32 mt-bf16 mt-bf16x3 waveform-bf16 wide-f32 wide-bf16 wide-bf16x3"
-# 1. kernel stats + one step's timeline of the bench command, one per workload
+CFGS="${PROF_CFGS:-mt-f32 mt-bf16 mt-bf16x3 waveform-bf16 wide-f32 wide-bf16 wide-bf16x3}"
+# 1. kernel stats + one step's timeline of the bench command, one per workload.  ONE traced process per summary: the headline's
+#    extra_configs child processes and its feature-path leg are suppressed (--trace-only-this-config keeps the kernel-table leg
+#    whose solo re-launches summarize_prof.py reports); timeline.py / summarize_prof.py refuse a trace with several databases and
+#    timeline.py checks the step's kernel set against the workload's.
 for c in $CFGS; do
-  timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/stats_$c -o p -- python $R/bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline > $OUT/stats_$c.log 2>&1
-  python $R/tools/summarize_prof.py $OUT/stats_$c > $OUT/${c}_kernel_stats.md 2>/dev/null
-  python $R/tools/timeline.py $OUT/stats_$c > $OUT/${c}_step_timeline.txt 2>/dev/null
+  timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/stats_$c -o p -- python $R/bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline --trace-only-this-config > $OUT/stats_$c.log 2>&1
+  python $R/tools/summarize_prof.py $OUT/stats_$c > $OUT/${c}_kernel_stats.md 2> $OUT/${c}_kernel_stats.err
+  python $R/tools/timeline.py $OUT/stats_$c 2 --config $c > $OUT/${c}_step_timeline.txt 2> $OUT/${c}_step_timeline.err
 done
 # 2. HBM traffic of the headline workload: FETCH_SIZE and WRITE_SIZE in separate passes (13 steps traced: 10 + 3 warm-up)
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o p -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $OUT/pmc_fetch.log 2>&1

@@ -9,6 +9,9 @@ import sys
 
 def load(path):
     dbs = [path] if path.endswith(".db") else glob.glob(os.path.join(path, "**", "*.db"), recursive=True)
+    if len(dbs) > 1:
+        sys.exit(f"summarize_prof.py: {len(dbs)} databases under {path} - one traced process per summary "
+                 "(bench.py --trace-only-this-config / --no-extras)")
     if dbs:
         cur = sqlite3.connect(dbs[0]).cursor()
         rows = cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()

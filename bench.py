@@ -422,6 +422,13 @@ def extra_config_legs(device, steps=300):
             out[name] = {"value": d["value"], "unit": "clips/s", "ms_per_step": ms, "steps": steps, "dtype": mfma_dtype,
                          "global_batch": B, "loss": d.get("loss"), "workload": d["config"]["workload"],
                          "roofline": step_roofline(wide, mfma_dtype, waveform, B, ms)}
+            if waveform and os.environ.get("SED_FE_FFT", "f32") != "f64":
+                # the same leg with the parity-mode front-end (fp64 butterflies = librosa's arithmetic; WaveformFrontEnd's default)
+                r64 = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, SED_FE_FFT="f64"))
+                if r64.returncode == 0:
+                    d64 = json.loads(r64.stdout.strip().split("\n")[-1])
+                    out[name]["f64_front_end"] = {"value": d64["value"], "ms_per_step": d64["ms_per_step"],
+                                                  "workload": d64["config"]["workload"]}
             print(f"[bench] extra config {name}: {ms:.4f} ms/step, {out[name]['value']} clips/s", file=sys.stderr, flush=True)
         except Exception as e:                          # noqa: BLE001 - the headline line must not depend on these legs
             out[name] = {"error": repr(e)[:300]}

@@ -65,6 +65,8 @@ _SIGS = {
     "sed_mt_loss": (C.c_int, [C.POINTER(SedDims), _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "sed_mt_loss_backward": (C.c_int, [C.POINTER(SedDims), _P, _P, _P, _P, C.c_size_t, _P, _P, _P, C.c_int, C.c_int, C.c_int,
                                        C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, C.c_size_t, C.c_int, _P]),
+    "sed_mt_step_backward": (C.c_int, [C.POINTER(SedDims), _P, _P, _P, _P, C.c_size_t, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, C.c_size_t, C.c_int, _P]),
     "sed_adam_ema": (C.c_int, [C.c_int64, _P, _P, _P, _P, _P, _P, C.c_float, _P]),
     "sed_ema_update": (C.c_int, [C.c_int64, _P, _P, C.c_float, _P]),
     "sed_step_state_init": (C.c_int, [_P, C.c_uint64, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,

@@ -303,7 +303,10 @@ extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* b
                                 const float* x, int train, int update_bn, const uint64_t* seed_dev, void* ctx,
                                 size_t ctx_bytes, float* strong, float* weak, void* stream) {
     SED_TRY(sed_validate_dims(d));
-    SED_CHECK_ARG(params && bn_running && x && ctx && strong && weak, "sed_crnn_forward: null argument");
+    SED_CHECK_ARG(params && bn_running && x && ctx, "sed_crnn_forward: null argument");
+    // strong == weak == NULL (train mode only): the output heads are left to sed_mt_step_backward, which runs them together
+    // with the loss and their backward in front of the top layer's backward recurrence
+    SED_CHECK_ARG((strong && weak) || (!strong && !weak && train), "sed_crnn_forward: strong and weak must both be given (or both NULL in train mode: heads deferred)");
     const Geo g = make_geo(d);
     const ParamOff P = make_param_off(g, nullptr);
     if (g.generic) {
@@ -362,6 +365,7 @@ extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* b
         nin = 128;
     }
     // ---- heads ----------------------------------------------------------------------------------
+    if (strong == nullptr) return SED_OK;                 // deferred (sed_mt_step_backward)
     SED_TRY(launch_heads_fwd(in, params + P.dense_w, params + P.dense_b, params + P.soft_w, params + P.soft_b, strong, weak,
                              train ? CTXF(L.strong_sv) : nullptr, train ? CTXF(L.weak_sv) : nullptr, CTXF(L.logits_s),
                              CTXF(L.den_sv), g.B, g.T3, g.NC, use_drop, g.p, seed_dev, st));
@@ -370,7 +374,8 @@ extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* b
 
 static int crnn_backward_impl(const sed_dims* d, const float* params, const float* x, const uint64_t* seed_dev,
                               void* ctx, size_t ctx_bytes, const float* d_strong, const float* d_weak, float* grads,
-                              void* ws, size_t ws_bytes, int parts, void* stream, const HeadsLoss* hl) {
+                              void* ws, size_t ws_bytes, int parts, void* stream, const HeadsLoss* hl,
+                              const HeadsOut* ho = nullptr) {
     SED_TRY(sed_validate_dims(d));
     SED_CHECK_ARG(params && x && ctx && (hl || (d_strong && d_weak)) && grads && ws, "sed_crnn_backward: null argument");
     SED_CHECK_ARG(parts == 1 || parts == 2 || parts == 3 || parts == 5 || parts == 8,
@@ -382,7 +387,7 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
         hipStream_t st0 = (hipStream_t)stream;
         SideStream& sd0 = side_stream(st0);
         return gen_backward(g, P, params, x, seed_dev, ctx, ctx_bytes, d_strong, d_weak, grads, ws, ws_bytes, parts, st0,
-                            sd0.ok ? sd0.s : st0, sd0.fork, sd0.join, (sd0.ok && (g_sed_debug & 2048)) ? sd0.s2 : nullptr, sd0.join2, hl);
+                            sd0.ok ? sd0.s : st0, sd0.fork, sd0.join, (sd0.ok && (g_sed_debug & 2048)) ? sd0.s2 : nullptr, sd0.join2, hl, ho);
     }
     const CtxLayout L = make_ctx_layout(g);
     const WsLayout W = make_ws_layout(g);
@@ -428,14 +433,30 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
     // otherwise idle GPU time give back.
     const bool early_gru_w = parts == 3 && sd.ok && (g_sed_debug & 16384);
 
+    // ho != null: the forward left the output heads to this call (sed_mt_step_backward).  Fused form (hfuse.h): heads forward +
+    // loss + heads backward run as the prologue phase of the top layer's backward recurrence, the meters' clip sums, the
+    // step-state advance and the head weight gradients' column sum in k_heads_fin where the column sum alone used to be.
+    // Otherwise (debug bit 24, T / 8 > 128, gradient outputs asked for): k_heads_fwd here, then the two-kernel form.
+    const int head_cols = 2 * (g.NC * 128 + g.NC);
+    const bool fuse = ho && hl && (parts & 1) && heads_fusable(64, g.T3) && !(g_sed_debug & 16777216) && !hl->d_strong_out && !hl->d_weak_out;
+    auto heads_colsum = [&](hipStream_t s2) -> int {
+        if (fuse) return launch_heads_fin(WSF(W.heads_part), grads + P.dense_w, g.B, g.T3, g.NC, head_cols, *hl, s2);
+        return launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, s2);
+    };
+    const bool defer_colsum = ((parts & 2) && sd.ok) || defer_gru_w;
     if (parts & 1) {
     // ---- heads ----------------------------------------------------------------------------------
     const float* h_last = CTXF(L.out[g.L - 1]);
+    if (ho && !fuse)
+        SED_TRY(launch_heads_fwd(h_last, params + P.dense_w, params + P.dense_b, params + P.soft_w, params + P.soft_b, ho->strong, ho->weak,
+                                 CTXF(L.strong_sv), CTXF(L.weak_sv), CTXF(L.logits_s), CTXF(L.den_sv), g.B, g.T3, g.NC, use_drop, g.p,
+                                 seed_dev, st));
+    if (!fuse)
     SED_TRY(launch_heads_bwd(h_last, params + P.dense_w, params + P.soft_w, CTXF(L.strong_sv), CTXF(L.weak_sv),
                              CTXF(L.logits_s), CTXF(L.den_sv), d_strong, d_weak, WSF(W.d_out), WSF(W.heads_part),
                              grads + P.dense_w, grads + P.dense_b, grads + P.soft_w, grads + P.soft_b, g.B, g.T3, g.NC,
                              use_drop, g.p, seed_dev, (parts & 2) ? WSD(W.bwd_acc) : nullptr, 2 * SED_GLUACC_N + 2 * 64 * 10,
-                             ((parts & 2) && sd.ok) || defer_gru_w ? 1 : 0, hl, st));
+                             defer_colsum ? 1 : 0, hl, st));
     // ---- BiGRU ----------------------------------------------------------------------------------
     // The gradient w.r.t. each layer's input is produced INSIDE the recurrence kernel (two extra waves, one block of
     // steps behind), as two direction planes [2][B*T'][nin] that the consumer adds while loading: the layer below's
@@ -445,6 +466,19 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
     for (int l = g.L - 1; l >= 0; --l) {
         const int nin = (l == 0) ? 64 : 128;
         float* d_in = (l == 0) ? WSF(W.dp2) : WSF(W.d_in);
+        if (fuse && l == g.L - 1) {
+            HeadsFuse hf = {};
+            hf.wd = params + P.dense_w; hf.strong = ho->strong; hf.weak = ho->weak; hf.part = WSF(W.heads_part);
+            hf.NC = g.NC; hf.use_drop = use_drop; hf.p_drop = g.p; hf.seed = seed_dev;
+            hf.zero = (parts & 2) ? WSD(W.bwd_acc) : nullptr; hf.n_zero = (parts & 2) ? 2 * SED_GLUACC_N + 2 * 64 * 10 : 0;
+            hf.hl = *hl;
+            SED_TRY(launch_gru_bwd_heads(CTXF(L.out[l]), CTXF(L.gates[l]), params + P.w_hh[l][0], params + P.w_hh[l][1],
+                                         params + P.w_ih[l][0], params + P.w_ih[l][1], nin, WSF(W.dgi[l]), WSF(W.dgh[l]),
+                                         WSF(W.hprev[l]), d_in, g.B, g.T3, hf, st));
+            // the meters / step-state advance (+ column sum unless deferred to the side stream or a parts = 8 call)
+            if (!defer_colsum) SED_TRY(heads_colsum(st));
+            else if (defer_gru_w) SED_TRY(launch_heads_fin(WSF(W.heads_part), grads + P.dense_w, g.B, g.T3, g.NC, 0, *hl, st));
+        } else
         SED_TRY(launch_gru_bwd(d_cur, d_cur2, CTXF(L.out[l]), CTXF(L.gates[l]), params + P.w_hh[l][0], params + P.w_hh[l][1],
                                params + P.w_ih[l][0], params + P.w_ih[l][1], nin, WSF(W.dgi[l]), WSF(W.dgh[l]),
                                WSF(W.hprev[l]), d_in, g.B, g.T3, st));
@@ -453,7 +487,7 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
         if (early_gru_w) {
             SIDE_FORK(st);
             forked = true;
-            if (l == g.L - 1) SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, ss));
+            if (l == g.L - 1) SED_TRY(heads_colsum(ss));
             SED_TRY(gru_weight_grads_layer(l, ss));
         }
     }
@@ -528,7 +562,7 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
                     sg = sd.s2;
                     forked2 = true;
                 }
-                if (sd.ok) SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, sg));
+                if (sd.ok) SED_TRY(heads_colsum(sg));
                 SED_TRY(gru_weight_grads(sg));
             }
             SED_TRY(launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], pp, st));
@@ -570,6 +604,21 @@ extern "C" int sed_mt_loss_backward(const sed_dims* d, const float* params, cons
     HeadsLoss hl = {strong_ema, weak_ema, target, weak_lo, weak_hi, strong_lo, strong_hi, state_dev, losses, d_strong, d_weak,
                     advance_state ? state_dev : nullptr};
     return crnn_backward_impl(d, params, x, seed_dev, ctx, ctx_bytes, nullptr, nullptr, grads, ws, ws_bytes, parts, stream, &hl);
+}
+
+extern "C" int sed_mt_step_backward(const sed_dims* d, const float* params, const float* x, const uint64_t* seed_dev,
+                                    void* ctx, size_t ctx_bytes, float* strong, float* weak, const float* strong_ema,
+                                    const float* weak_ema, const float* target, int weak_lo, int weak_hi, int strong_lo,
+                                    int strong_hi, sed_step_state* state_dev, int advance_state, float* losses, float* d_strong,
+                                    float* d_weak, float* grads, void* ws, size_t ws_bytes, int parts, void* stream) {
+    SED_CHECK_ARG(d && strong && weak && strong_ema && weak_ema && target && state_dev && losses, "sed_mt_step_backward: null argument");
+    SED_CHECK_ARG(parts == 1 || parts == 3 || parts == 5, "sed_mt_step_backward: parts must include the heads (1, 3 or 5)");
+    SED_CHECK_ARG(weak_lo >= 0 && weak_hi <= d->B && weak_lo <= weak_hi && strong_lo >= 0 && strong_hi <= d->B &&
+                      strong_lo <= strong_hi, "sed_mt_step_backward: bad mask range");
+    HeadsLoss hl = {strong_ema, weak_ema, target, weak_lo, weak_hi, strong_lo, strong_hi, state_dev, losses, d_strong, d_weak,
+                    advance_state ? state_dev : nullptr};
+    HeadsOut ho = {strong, weak};
+    return crnn_backward_impl(d, params, x, seed_dev, ctx, ctx_bytes, nullptr, nullptr, grads, ws, ws_bytes, parts, stream, &hl, &ho);
 }
 
 extern "C" int sed_kernel_replay(const char* name, const sed_dims* d, const float* params, const float* x,

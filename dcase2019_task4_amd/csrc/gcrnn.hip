@@ -289,6 +289,7 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
         nin = 2 * H;
     }
     // ---- heads ----------------------------------------------------------------------------------------------------------
+    if (strong == nullptr) return SED_OK;                 // deferred to sed_mt_step_backward (crnn.hip)
     SED_TRY(launch_heads_fwd(in, params + P.dense_w, params + P.dense_b, params + P.soft_w, params + P.soft_b, strong, weak,
                              train ? CTXF(L.strong_sv) : nullptr, train ? CTXF(L.weak_sv) : nullptr, CTXF(L.logits_s),
                              CTXF(L.den_sv), g.B, g.T3, g.NC, use_drop, g.p, seed_dev, st, 2 * H));
@@ -299,7 +300,7 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
 int gen_backward(const Geo& g, const ParamOff& P, const float* params, const float* x, const uint64_t* seed_dev, void* ctx,
                  size_t ctx_bytes, const float* d_strong, const float* d_weak, float* grads, void* ws, size_t ws_bytes, int parts,
                  hipStream_t st, hipStream_t ss, hipEvent_t ev_fork, hipEvent_t ev_join, hipStream_t ss2, hipEvent_t ev_join2,
-                 const HeadsLoss* hl) {
+                 const HeadsLoss* hl, const HeadsOut* ho) {
     const GCtx L = make_gctx(g);
     const GWs W = make_gws(g);
     if (ctx_bytes < L.total || ws_bytes < W.total) {
@@ -345,13 +346,27 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
         for (int l = g.L - 1; l >= 0; --l) SED_TRY(gru_weight_grads_layer(l, s2));
         return SED_OK;
     };
+    // ho != null: heads deferred by the forward (sed_mt_step_backward, crnn.hip).  H = 64: fused into the top layer's backward
+    // recurrence (hfuse.h); H = 256 (or debug bit 24): k_heads_fwd here, then the two-kernel form.
+    const int head_cols = 2 * (g.NC * 2 * H + g.NC);
+    const bool fuse = ho && hl && (parts & 1) && heads_fusable(H, g.T3) && !(g_sed_debug & 16777216) && !hl->d_strong_out && !hl->d_weak_out;
+    auto heads_colsum = [&](hipStream_t s2) -> int {
+        if (fuse) return launch_heads_fin(WSF(W.heads_part), grads + P.dense_w, g.B, g.T3, g.NC, head_cols, *hl, s2);
+        return launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, s2, 2 * H);
+    };
+    const bool defer_colsum = ((parts & 2) && have_side) || defer_gru_w;
     if (parts & 1) {
         // ---- heads ------------------------------------------------------------------------------------------------------
+        if (ho && !fuse)
+            SED_TRY(launch_heads_fwd(CTXF(L.out[g.L - 1]), params + P.dense_w, params + P.dense_b, params + P.soft_w, params + P.soft_b,
+                                     ho->strong, ho->weak, CTXF(L.strong_sv), CTXF(L.weak_sv), CTXF(L.logits_s), CTXF(L.den_sv), g.B, g.T3,
+                                     g.NC, use_drop, g.p, seed_dev, st, 2 * H));
+        if (!fuse)
         SED_TRY(launch_heads_bwd(CTXF(L.out[g.L - 1]), params + P.dense_w, params + P.soft_w, CTXF(L.strong_sv), CTXF(L.weak_sv),
                                  CTXF(L.logits_s), CTXF(L.den_sv), d_strong, d_weak, WSF(W.d_out), WSF(W.heads_part),
                                  grads + P.dense_w, grads + P.dense_b, grads + P.soft_w, grads + P.soft_b, g.B, g.T3, g.NC, use_drop,
                                  g.p, seed_dev, (parts & 2) ? WSD(W.de0) : nullptr, 2 * C * 10,
-                                 ((parts & 2) && have_side) || defer_gru_w ? 1 : 0, hl, st, 2 * H));
+                                 defer_colsum ? 1 : 0, hl, st, 2 * H));
         // ---- BiGRU --------------------------------------------------------------------------------------------------------
         const float* d_cur = WSF(W.d_out);
         const float* d_cur2 = nullptr;
@@ -359,6 +374,18 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
             const int nin = (l == 0) ? C : 2 * H;
             float* d_in = (l == 0) ? WSF(W.dp[2]) : WSF(W.d_in);
             if (H == 64) {
+                if (fuse && l == g.L - 1) {
+                    HeadsFuse hf = {};
+                    hf.wd = params + P.dense_w; hf.strong = ho->strong; hf.weak = ho->weak; hf.part = WSF(W.heads_part);
+                    hf.NC = g.NC; hf.use_drop = use_drop; hf.p_drop = g.p; hf.seed = seed_dev;
+                    hf.zero = (parts & 2) ? WSD(W.de0) : nullptr; hf.n_zero = (parts & 2) ? 2 * C * 10 : 0;
+                    hf.hl = *hl;
+                    SED_TRY(launch_gru_bwd_heads(CTXF(L.out[l]), CTXF(L.gates[l]), params + P.w_hh[l][0], params + P.w_hh[l][1],
+                                                 params + P.w_ih[l][0], params + P.w_ih[l][1], nin, WSF(W.dgi[l]), WSF(W.dgh[l]),
+                                                 WSF(W.hprev[l]), d_in, g.B, g.T3, hf, st));
+                    if (!defer_colsum) SED_TRY(heads_colsum(st));
+                    else if (defer_gru_w) SED_TRY(launch_heads_fin(WSF(W.heads_part), grads + P.dense_w, g.B, g.T3, g.NC, 0, *hl, st));
+                } else
                 SED_TRY(launch_gru_bwd(d_cur, d_cur2, CTXF(L.out[l]), CTXF(L.gates[l]), params + P.w_hh[l][0], params + P.w_hh[l][1],
                                        params + P.w_ih[l][0], params + P.w_ih[l][1], nin, WSF(W.dgi[l]), WSF(W.dgh[l]), WSF(W.hprev[l]),
                                        d_in, g.B, g.T3, st));
@@ -367,7 +394,7 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
                 // stream had finished (profiles/r03_a_mt-bf16_step_timeline.txt)
                 if (early_gru_w) {
                     SED_TRY(fork());
-                    if (l == g.L - 1) SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, ss, 2 * H));
+                    if (l == g.L - 1) SED_TRY(heads_colsum(ss));
                     SED_TRY(gru_weight_grads_layer(l, ss));
                 }
                 d_cur = d_in;
@@ -390,7 +417,7 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
                 // the conv blocks' fork, where they used to be the tail of the step (profiles/r03_*_wide-bf16_step_timeline.txt)
                 if (early_gru_w) {
                     SED_TRY(fork());
-                    if (l == g.L - 1) SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, ss, 2 * H));
+                    if (l == g.L - 1) SED_TRY(heads_colsum(ss));
                     SED_TRY(gru_weight_grads_layer(l, ss));
                 }
                 GntBatch gb;
@@ -452,7 +479,7 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
                 sg = ss2;
                 forked2 = true;
             }
-            if (have_side) SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, sg, 2 * H));
+            if (have_side) SED_TRY(heads_colsum(sg));
             SED_TRY(gru_weight_grads(sg));
         }
     }

@@ -114,4 +114,4 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
 int gen_backward(const Geo& g, const ParamOff& P, const float* params, const float* x, const uint64_t* seed_dev, void* ctx,
                  size_t ctx_bytes, const float* d_strong, const float* d_weak, float* grads, void* ws, size_t ws_bytes, int parts,
                  hipStream_t st, hipStream_t ss, hipEvent_t ev_fork, hipEvent_t ev_join, hipStream_t ss2, hipEvent_t ev_join2,
-                 const HeadsLoss* hl);
+                 const HeadsLoss* hl, const HeadsOut* ho);

@@ -37,6 +37,7 @@
 // I/O slices at 15 - 20 ns.  Measured now: forward 320 / 360 ns per step + 6.0 / 7.3 us fixed, backward 390 / 420 ns + 9 us.
 #include "common.h"
 #include "kernels.h"
+#include "hfuse.h"
 #include <type_traits>
 SED_TS_DEFINE(gru4)
 #ifdef SED_TS
@@ -324,23 +325,33 @@ __global__ __launch_bounds__(G4_THREADS) void k_gru4_fwd(const float* __restrict
 // ---------------------------------------------------------------------------------------------------------
 // Backward through time.  Per step inputs: d_out, r, z, n, gh_n, h_prev (6 rows of 64); outputs: dgi (192),
 // dgh (192), h_prev (64) = 7 rows of 64.
-template <int NIN>
+// HEADS (round 5, hfuse.h): the launch is the TOP layer's; the output heads' forward, the mean-teacher loss and the heads'
+// backward of the clip run as a prologue phase of every workgroup, and the upstream gradient d_out [T][64] of this direction
+// is read from LDS (dout_s) instead of global memory.  d_out / d_out2 are unused then.
+template <int NIN, bool HEADS>
 __global__ __launch_bounds__(G4B_THREADS) void k_gru4_bwd(const float* __restrict__ d_out, const float* __restrict__ d_out2,
                                                           const float* __restrict__ out, const float* __restrict__ gates,
                                                           const float* __restrict__ w_hh_f, const float* __restrict__ w_hh_r,
                                                           const float* __restrict__ w_ih_f, const float* __restrict__ w_ih_r,
                                                           float* __restrict__ dgi, float* __restrict__ dgh,
-                                                          float* __restrict__ hprev_out, float* __restrict__ dx_planes, int B, int T) {
+                                                          float* __restrict__ hprev_out, float* __restrict__ dx_planes, int B, int T,
+                                                          HeadsFuse hf) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     float* zero = gsm;                                // [192] dg before the first step
     float* ops = zero + 192;                          // [2][G4_SB][384] : d_out, r, z, n, gh_n, h_prev
     float* hist = ops + 2 * G4_SB * 384;              // [2][G4_SB][G4_HS] : dgi(192), dgh(192), h_prev(64)
+    float* dout_s = hist + 2 * G4_SB * G4_HS;         // HEADS: [round16(T)][64] this direction's half of dL/dh
     const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
     const int role = tid >> 6;                        // 0-3 recurrence, 4-5 I/O, 6-9 dX GEMM
     const int l = tid & 63;
     const int nblk = (T + G4_SB - 1) / G4_SB;
     auto t_of = [&](int step) { return dir ? step : (T - 1 - step); };     // reverse of the forward order
     TSW(0, 0);
+    if constexpr (HEADS) {
+        // (scratch = the ops / history rings, which nothing has touched yet; ends with a workgroup barrier)
+        heads_fused_phase<G4B_THREADS>(hf, out, b, dir, 2 * (int)gridDim.x, (int)(blockIdx.y * gridDim.x + blockIdx.x), T, ops, dout_s);
+        TSW(8, 0);
+    }
 
     if (role == 4 || role == 5) {
         // ================================ I/O waves =========================================================
@@ -354,6 +365,9 @@ __global__ __launch_bounds__(G4B_THREADS) void k_gru4_bwd(const float* __restric
             const int tp = dir ? t + 1 : t - 1;
             const int tpc = min(max(tp, 0), T - 1);
             ok = (step < T) && (a != 5 || (tp >= 0 && tp < T));
+            if constexpr (HEADS) {
+                if (a == 0) return dout_s[t * 64 + l];
+            }
             const float* p = (a == 0) ? d_out + (size_t)(b * T + t) * 128 + dir * 64 + l
                            : (a < 5) ? gates + ((size_t)(b * T + t) * 2 + dir) * 256 + (a - 1) * 64 + l
                                      : out + (size_t)(b * T + tpc) * 128 + dir * 64 + l;
@@ -373,7 +387,7 @@ __global__ __launch_bounds__(G4B_THREADS) void k_gru4_bwd(const float* __restric
 #pragma unroll
             for (int i = 0; i < G4_SB / 2; ++i) {
                 const int t = t_of(min(blk * G4_SB + 2 * i + io, T - 1));
-                v2[i] = d_out2 ? d_out2[(size_t)(b * T + t) * 128 + dir * 64 + l] : 0.f;
+                v2[i] = (!HEADS && d_out2) ? d_out2[(size_t)(b * T + t) * 128 + dir * 64 + l] : 0.f;
             }
         };
         auto ops_store = [&](int blk, const float (&v)[6 * G4_SB / 2], const float (&v2)[G4_SB / 2], unsigned long long okm) {
@@ -551,6 +565,9 @@ __global__ __launch_bounds__(G4B_THREADS) void k_gru4_bwd(const float* __restric
 
 template <int NIN> static constexpr size_t gru4_fwd_lds() { return (size_t)(64 + 2 * G4_SB * 192 + 2 * G4_SB * 320 + 2 * G4_SB * (NIN + 4)) * sizeof(float); }
 static const size_t GRU4_BWD_LDS = (size_t)(192 + 2 * G4_SB * 384 + 2 * G4_SB * G4_HS) * sizeof(float);
+static_assert(2 * G4_SB * 384 + 2 * G4_SB * G4_HS >= HF_TMAX * HF_S + HF_MAXO * HF_S + HF_TMAX * HF_SD + HF_TMAX * 8 + HF_MISC,
+              "the heads phase's scratch must fit the ops / history rings it aliases");
+static const size_t GRU4_BWD_HEADS_LDS_MAX = GRU4_BWD_LDS + (size_t)HF_TMAX * 64 * sizeof(float);
 
 int launch_gru_fwd_v1(const float* x, int nin, const float* w_ih_f, const float* w_ih_r, const float* b_ih_f, const float* b_ih_r,
                       const float* w_hh_f, const float* w_hh_r, const float* b_hh_f, const float* b_hh_r, float* out, float* gates,
@@ -595,15 +612,15 @@ int launch_gru_bwd(const float* d_out, const float* d_out2, const float* out, co
 #endif
     static thread_local SedAttrOnce attr_done;
     if (attr_done.need()) {
-        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gru4_bwd<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRU4_BWD_LDS));
-        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gru4_bwd<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRU4_BWD_LDS));
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gru4_bwd<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRU4_BWD_LDS));
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gru4_bwd<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRU4_BWD_LDS));
     }
     if (nin == 128)
-        k_gru4_bwd<128><<<dim3(B, 2), G4B_THREADS, GRU4_BWD_LDS, st>>>(d_out, d_out2, out, gates, w_hh_f, w_hh_r, w_ih_f, w_ih_r, dgi, dgh,
-                                                                      hprev, dx_planes, B, T);
+        k_gru4_bwd<128, false><<<dim3(B, 2), G4B_THREADS, GRU4_BWD_LDS, st>>>(d_out, d_out2, out, gates, w_hh_f, w_hh_r, w_ih_f, w_ih_r, dgi, dgh,
+                                                                             hprev, dx_planes, B, T, HeadsFuse{});
     else if (nin == 64)
-        k_gru4_bwd<64><<<dim3(B, 2), G4B_THREADS, GRU4_BWD_LDS, st>>>(d_out, d_out2, out, gates, w_hh_f, w_hh_r, w_ih_f, w_ih_r, dgi, dgh,
-                                                                     hprev, dx_planes, B, T);
+        k_gru4_bwd<64, false><<<dim3(B, 2), G4B_THREADS, GRU4_BWD_LDS, st>>>(d_out, d_out2, out, gates, w_hh_f, w_hh_r, w_ih_f, w_ih_r, dgi, dgh,
+                                                                            hprev, dx_planes, B, T, HeadsFuse{});
     else {
         sed_set_error("gru backward: unsupported input width %d", nin);
         return SED_ERR_UNSUPPORTED;
@@ -611,3 +628,32 @@ int launch_gru_bwd(const float* d_out, const float* d_out2, const float* out, co
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
+
+// The top layer's backward recurrence with the heads phase in front (hfuse.h); T <= HF_TMAX frames
+int launch_gru_bwd_heads(const float* out, const float* gates, const float* w_hh_f, const float* w_hh_r, const float* w_ih_f,
+                         const float* w_ih_r, int nin, float* dgi, float* dgh, float* hprev, float* dx_planes, int B, int T,
+                         const HeadsFuse& hf, hipStream_t st) {
+    if (T > HF_TMAX || hf.NC < 1 || hf.NC > 16 || hf.hl.strong_ema == nullptr) {
+        sed_set_error("fused heads + gru backward: needs T/8 <= %d, nclass <= 16 and the loss inputs (got T/8 = %d)", HF_TMAX, T);
+        return SED_ERR_UNSUPPORTED;
+    }
+    static thread_local SedAttrOnce attr_done;
+    if (attr_done.need()) {
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gru4_bwd<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRU4_BWD_HEADS_LDS_MAX));
+        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gru4_bwd<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRU4_BWD_HEADS_LDS_MAX));
+    }
+    const size_t lds = GRU4_BWD_LDS + (size_t)((T + 15) & ~15) * 64 * sizeof(float);
+    if (nin == 128)
+        k_gru4_bwd<128, true><<<dim3(B, 2), G4B_THREADS, lds, st>>>(nullptr, nullptr, out, gates, w_hh_f, w_hh_r, w_ih_f, w_ih_r, dgi, dgh,
+                                                                    hprev, dx_planes, B, T, hf);
+    else if (nin == 64)
+        k_gru4_bwd<64, true><<<dim3(B, 2), G4B_THREADS, lds, st>>>(nullptr, nullptr, out, gates, w_hh_f, w_hh_r, w_ih_f, w_ih_r, dgi, dgh,
+                                                                   hprev, dx_planes, B, T, hf);
+    else {
+        sed_set_error("gru backward: unsupported input width %d", nin);
+        return SED_ERR_UNSUPPORTED;
+    }
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}
+

@@ -11,6 +11,7 @@
 #include "common.h"
 #include "philox.h"
 #include "kernels.h"
+#include "hfuse.h"
 
 #define HD_THREADS 1024
 // Templated on HF = 2 * n_RNN_cell (128 for the reference's 64 cells, 512 for BASELINE.json configs[4]'s 256):
@@ -185,12 +186,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_fwd(const float* __restric
     }
 }
 
-// ---- mean-teacher loss terms (main.py:93-145) -----------------------------------------------------
-__device__ __forceinline__ float bce_term(float p, float t) {
-    const float lp = fmaxf(logf(p), -100.0f), l1p = fmaxf(logf(1.0f - p), -100.0f);
-    return -(t * lp + (1.0f - t) * l1p);
-}
-__device__ __forceinline__ float bce_grad(float p, float t) { return (p - t) / fmaxf((1.0f - p) * p, 1e-12f); }
+// ---- mean-teacher loss terms (main.py:93-145): bce_term / bce_grad live in hfuse.h (shared with the fused form) ----------
 
 // part row layout (matches the flat parameter order dense.weight, dense.bias, dense_softmax.weight,
 // dense_softmax.bias): [NC*128 dWd][NC dbd][NC*128 dWs][NC dbs]
@@ -537,6 +533,52 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_mt_loss(const float* __restric
         losses[5] = s6[4] * inv_wb; losses[6] = s6[5] * inv_sb; losses[7] = cw;
         *ticket = 0u;
     }
+}
+
+// ---- the tail of the fused form (hfuse.h): what k_heads_bwd's last workgroup and k_colsum do in the two-kernel form --------
+// blocks [0, gridDim.x - 1): out[n] = sum_b part[b * N + n], four row groups as k_colsum (bit-identical sums);
+// last block: the six loss sums in clip order -> the meters; step-state advance (every reader of this step's forward / loss
+// fields ran in kernels that precede this one in stream order; the update runs after the side stream's join).
+__global__ __launch_bounds__(256) void k_heads_fin(const float* __restrict__ part, int B, int N, float* __restrict__ out, HeadsLoss hl,
+                                                   int T, int NC) {
+    __shared__ float red[4][64];
+    if (blockIdx.x + 1 < gridDim.x) {
+        const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+        const int col = blockIdx.x * 64 + c;
+        float s = 0.f;
+        if (col < N)
+            for (int m = r; m < B; m += 4) s += part[(int64_t)m * N + col];
+        red[r][c] = s;
+        __syncthreads();
+        if (r == 0 && col < N) out[col] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+        return;
+    }
+    const int tid = threadIdx.x;
+    const float* lpart = hl.losses + 8;
+    if (tid < 6) {
+        float s2 = 0.f;
+        for (int bb = 0; bb < B; ++bb) s2 += lpart[8 * bb + tid];
+        red[0][tid] = s2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float cw = hl.state->cons_weight;
+        const float inv_nS = 1.0f / (float)(B * T * NC), inv_nW = 1.0f / (float)(B * NC);
+        const float inv_sb = (hl.shi > hl.slo) ? 1.0f / (float)((hl.shi - hl.slo) * T * NC) : 0.f;
+        const float inv_wb = (hl.whi > hl.wlo) ? 1.0f / (float)((hl.whi - hl.wlo) * NC) : 0.f;
+        const float* s6 = red[0];
+        const float wb = s6[0] * inv_wb, sb = s6[1] * inv_sb;
+        const float cs = cw * s6[2] * inv_nS, cwk = cw * s6[3] * inv_nW;
+        hl.losses[0] = wb + sb + cs + cwk;
+        hl.losses[1] = wb; hl.losses[2] = sb; hl.losses[3] = cs; hl.losses[4] = cwk;
+        hl.losses[5] = s6[4] * inv_wb; hl.losses[6] = s6[5] * inv_sb; hl.losses[7] = cw;
+        if (hl.advance) step_state_advance_early(hl.advance);
+    }
+}
+int launch_heads_fin(const float* part, float* g_wd, int B, int T, int NC, int n_cols, const HeadsLoss& hl, hipStream_t st) {
+    k_heads_fin<<<(n_cols + 63) / 64 + 1, 256, 0, st>>>(part, B, n_cols, g_wd, hl, T, NC);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
 }
 
 // ---- host launchers -------------------------------------------------------------------------------

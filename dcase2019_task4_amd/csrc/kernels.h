@@ -267,3 +267,26 @@ int launch_heads_bwd(const float* h, const float* wd, const float* ws, const flo
                      float* part, float* g_wd, float* g_bd, float* g_ws, float* g_bs, int B, int T, int NC, int use_drop,
                      float p_drop, const uint64_t* seed, double* zero, int n_zero, int defer_colsum, const HeadsLoss* hl, hipStream_t st,
                      int HF = 128);
+
+// ---- round 5: heads forward + loss + heads backward as the prologue of the top layer's backward recurrence (hfuse.h, gru4.hip) ----
+struct HeadsFuse {
+    const float* wd;                    // dense.weight; dense.bias, dense_softmax.weight, dense_softmax.bias follow it (flat layout)
+    float *strong, *weak;               // posteriors out: [B][T'][NC], [B][NC]
+    float* part;                        // per-clip partial weight gradients [B][2 (NC * 128 + NC)]
+    int NC, use_drop;
+    float p_drop;
+    const uint64_t* seed;
+    double* zero; int n_zero;           // fp64 accumulators of the conv-block backward to clear (may be null / 0)
+    HeadsLoss hl;                       // strong_ema != null always (the fused form IS the loss); d_strong_out / d_weak_out unused
+};
+struct HeadsOut { float *strong, *weak; };       // sed_mt_step_backward: where the deferred heads' posteriors go
+// the frames (T / 8) and hidden size the fused form serves; everything else takes k_heads_fwd + k_heads_bwd
+static inline bool heads_fusable(int H, int T3) { return H == 64 && T3 <= 128; }
+// top BiGRU layer's backward recurrence with the heads phase in front (d_out comes out of LDS); otherwise as launch_gru_bwd
+int launch_gru_bwd_heads(const float* out, const float* gates, const float* w_hh_f, const float* w_hh_r, const float* w_ih_f,
+                         const float* w_ih_r, int nin, float* dgi, float* dgh, float* hprev, float* dx_planes, int B, int T,
+                         const HeadsFuse& hf, hipStream_t st);
+// column sum of the per-clip head weight-gradient partials (n_cols == 0: skipped) + the loss meters' clip sums + (hl.advance)
+// the step-state advance that k_heads_bwd's last workgroup does in the two-kernel form
+int launch_heads_fin(const float* part, float* g_wd, int B, int T, int NC, int n_cols, const HeadsLoss& hl, hipStream_t st);
+

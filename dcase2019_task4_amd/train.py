@@ -224,6 +224,7 @@ class MeanTeacherStep:
 
     # ---- pieces ------------------------------------------------------------------------------------
     def _forward(self, model, x, ctx, seed, strong, weak):
+        """strong = weak = None: output heads deferred to sed_mt_step_backward (the student's forward)."""
         _lib.check(self.l.sed_crnn_forward(C.byref(self.dims), _lib.ptr(model._flat), _lib.ptr(model._bn_flat),
                                            _lib.ptr(model._bn_tracked), _lib.ptr(x), 1, 1, seed, _lib.ptr(ctx),
                                            self.ctx_bytes, _lib.ptr(strong), _lib.ptr(weak), _lib.stream_ptr()),
@@ -253,7 +254,9 @@ class MeanTeacherStep:
                     self._fork_exc = e
             self._fork_cb = _lib.FORK_CALLBACK(hook)      # (kept alive until the forward has run)
             _lib.check(self.l.sed_crnn_fork_callback(_lib.stream_ptr(), self._fork_cb, None), "sed_crnn_fork_callback")
-        self._forward(self.student, self.x, self.ctx_s, self._seed_s, self.strong, self.weak)
+        # the student's output heads are deferred: sed_mt_step_backward runs them with the loss and their backward in front
+        # of the top layer's backward recurrence (csrc/hfuse.h)
+        self._forward(self.student, self.x, self.ctx_s, self._seed_s, None, None)
 
     def _fwd_bwd_impl(self, after_forward=None, at_recurrence=None):
         """teacher forward (main.py:87-89), student forward (:91), losses (:93-145), backward (:152-153).
@@ -285,13 +288,14 @@ class MeanTeacherStep:
             parts = 5
         else:
             parts = 3
-        _lib.check(self.l.sed_mt_loss_backward(C.byref(self.dims), _lib.ptr(self.student._flat), _lib.ptr(self.x),
+        _lib.check(self.l.sed_mt_step_backward(C.byref(self.dims), _lib.ptr(self.student._flat), _lib.ptr(self.x),
                                                self._seed_s, _lib.ptr(self.ctx_s), self.ctx_bytes,
+                                               _lib.ptr(self.strong), _lib.ptr(self.weak),
                                                _lib.ptr(self.strong_ema), _lib.ptr(self.weak_ema), _lib.ptr(self.target),
                                                self.wlo, self.whi, self.slo, self.shi, _lib.ptr(self.state), 1,
                                                _lib.ptr(self.losses), None, None, _lib.ptr(self.grads),
                                                _lib.ptr(self.ws), self.ws_bytes, parts, _lib.stream_ptr()),
-                   "sed_mt_loss_backward")
+                   "sed_mt_step_backward")
 
     def _backward(self, parts):
         _lib.check(self.l.sed_crnn_backward(C.byref(self.dims), _lib.ptr(self.student._flat), _lib.ptr(self.x),

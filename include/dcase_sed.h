@@ -127,7 +127,8 @@ int sed_param_layout(const sed_dims* d, int64_t* offsets);
  *   seed_dev    device pointer to the 64-bit Philox key of this forward (ignored if p_drop==0
  *               or train==0); the same pointer/value must be given to backward
  *   ctx         saved activations for backward + scratch; sed_crnn_ctx_bytes(d)
- *   strong/weak outputs [B][T/8][nclass], [B][nclass]                                        */
+ *   strong/weak outputs [B][T/8][nclass], [B][nclass].  train == 1 only: BOTH may be NULL - the output heads
+ *               (models/CRNN.py:74-81) are then left to a sed_mt_step_backward call on the same ctx           */
 size_t sed_crnn_ctx_bytes(const sed_dims* d);
 int sed_crnn_forward(const sed_dims* d, const float* params, float* bn_running, int64_t* bn_tracked,
                      const float* x, int train, int update_bn, const uint64_t* seed_dev,
@@ -209,6 +210,21 @@ int sed_mt_loss(const sed_dims* d, const float* strong, const float* weak, const
 int sed_mt_loss_backward(const sed_dims* d, const float* params, const float* x, const uint64_t* seed_dev,
                          void* ctx, size_t ctx_bytes, const float* strong_ema, const float* weak_ema,
                          const float* target, int weak_lo, int weak_hi, int strong_lo, int strong_hi,
+                         sed_step_state* state_dev, int advance_state, float* losses, float* d_strong, float* d_weak,
+                         float* grads, void* ws, size_t ws_bytes, int parts, void* stream);
+
+/* The student's half of one train step after its forward with deferred heads (sed_crnn_forward(..., strong = NULL,
+ * weak = NULL)): output heads (models/CRNN.py:74-81) -> losses (main.py:93-145) -> backward (main.py:152-153).  Arguments as
+ * sed_mt_loss_backward plus `strong` / `weak`, which RECEIVE the student's posteriors.  With n_RNN_cell = 64 and T / 8 <= 128
+ * the three run as the prologue phase of the top BiGRU layer's backward-recurrence kernel (csrc/hfuse.h): the heads' forward
+ * kernel, the cross-queue join in front of the loss and the heads' backward kernel - 40 us of every step on 24 of 256 CUs -
+ * leave the critical chain; the meters' sums over the clips and the step-state advance are finished by a small kernel on the
+ * library's weight-gradient stream (they are complete when the call's work is, like everything else).  Other geometries (and
+ * d_strong / d_weak != NULL) take the separate kernels inside this call; results are bit-identical either way except for the
+ * meters (summation order).  Supervised loop (main_simple_CRNN.py): strong_ema == strong and weak_ema == weak. */
+int sed_mt_step_backward(const sed_dims* d, const float* params, const float* x, const uint64_t* seed_dev,
+                         void* ctx, size_t ctx_bytes, float* strong, float* weak, const float* strong_ema,
+                         const float* weak_ema, const float* target, int weak_lo, int weak_hi, int strong_lo, int strong_hi,
                          sed_step_state* state_dev, int advance_state, float* losses, float* d_strong, float* d_weak,
                          float* grads, void* ws, size_t ws_bytes, int parts, void* stream);
 
@@ -345,7 +361,9 @@ int sed_kernel_replay(const char* name, const sed_dims* d, const float* params, 
  *   dgrad / wgrad kernels (also implied by bits 2, 3, 6, 7).  Kept for A/B timing (profiles/README.md).
  *   Generic kernel set: bit 10 streaming H = 256 recurrence, bit 16 cluster recurrence instead of the one-CU bf16 kernels,
  *   bit 17 late GRU weight-gradient schedule, bit 18 round-2 GLU kernels, bit 19 round-2 STFT kernel, bit 20 block-1
- *   convolution (bf16, C = 128) by the barrier-free k_bconv2. */
+ *   convolution (bf16, C = 128) by the barrier-free k_bconv2.
+ *   bit 24: sed_mt_step_backward runs the deferred heads as separate kernels (k_heads_fwd, k_heads_bwd) instead of fused
+ *   into the backward recurrence (A/B timing and the bit-identity test). */
 int sed_debug_set(int flags);
 /* bit 0: the library was built with the A/B baseline kernels (make EXTRA=-DSED_AB); without it debug bits 1, 2, 3, 6, 7
  * are ignored - the shipped library carries the product path only. */

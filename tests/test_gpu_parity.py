@@ -287,6 +287,66 @@ def test_fused_loss_backward_matches_loss_kernel_then_backward():
         assert m_b[k] == pytest.approx(v, rel=2e-6, abs=1e-9), k
 
 
+def _one_step_with_deferred_heads(B, T, debug, supervised=False, n_layers=2, nclass=10, mfma_dtype="f32", parts=3, steps=2):
+    """`steps` eager steps of MeanTeacherStep (the student's heads deferred to sed_mt_step_backward) under debug flags `debug`."""
+    from dcase2019_task4_amd import _lib
+    from dcase2019_task4_amd.train import MeanTeacherStep
+    l = _lib.lib()
+    old = l.sed_debug_set(debug)
+    try:
+        student, _ = gu.make_model(0, dropout=0.5, n_layers=n_layers, nclass=nclass, mfma_dtype=mfma_dtype)
+        teacher = None if supervised else gu.make_model(1, dropout=0.5, n_layers=n_layers, nclass=nclass, mfma_dtype=mfma_dtype)[0]
+        student.train()
+        if teacher is not None:
+            teacher.train()
+        tgt, wm, sm = synth.make_target(3, B, T // 8, nclass)
+        st = MeanTeacherStep(student, teacher, B, T, 150, wm, sm, seed=99, use_graph=False)
+        out = []
+        for k in range(steps):
+            st.load_batch(synth.make_input(60 + k, B, T).cuda(), synth.make_input(70 + k, B, T).cuda(), tgt.cuda())
+            if parts == 3:
+                st.run()
+            else:                                       # the data-parallel split: heads + BiGRU chain (5), deferred tail (8), conv blocks (2)
+                st._forward(st.teacher, st.x_ema, st.ctx_t, st._seed_t, st.strong_ema, st.weak_ema)
+                st._forward(st.student, st.x, st.ctx_s, st._seed_s, None, None)
+                _lib.check(l.sed_mt_step_backward(C.byref(st.dims), _lib.ptr(st.student._flat), _lib.ptr(st.x), st._seed_s,
+                                                  _lib.ptr(st.ctx_s), st.ctx_bytes, _lib.ptr(st.strong), _lib.ptr(st.weak),
+                                                  _lib.ptr(st.strong_ema), _lib.ptr(st.weak_ema), _lib.ptr(st.target), st.wlo, st.whi,
+                                                  st.slo, st.shi, _lib.ptr(st.state), 1, _lib.ptr(st.losses), None, None,
+                                                  _lib.ptr(st.grads), _lib.ptr(st.ws), st.ws_bytes, 5, _lib.stream_ptr()),
+                           "sed_mt_step_backward")
+                st._dp_tail()
+                st._backward(2)
+                st._update()
+            torch.cuda.synchronize()
+            out.append(dict(grads=st.grads.clone(), strong=st.strong.clone(), weak=st.weak.clone(), params=st.student._flat.clone(),
+                            meters=dict(st.meters()), state=st.read_state().global_step))
+        return out
+    finally:
+        l.sed_debug_set(old)
+
+
+@pytest.mark.parametrize("B,T,kw", [(24, 628, {}), (8, 216, {}), (3, 864, {}), (2, 1024, {}), (5, 64, {}), (4, 128, dict(supervised=True)),
+                                    (4, 160, dict(n_layers=1)), (4, 160, dict(nclass=16)), (4, 160, dict(nclass=3)),
+                                    (6, 1100, {}), (8, 216, dict(parts=5)), (8, 216, dict(mfma_dtype="bf16")),
+                                    (8, 216, dict(mfma_dtype="bf16x3"))])
+def test_heads_fused_into_the_backward_recurrence_are_bit_identical_to_the_separate_kernels(B, T, kw):
+    """Round 5 (csrc/hfuse.h): sed_mt_step_backward runs the student's output heads, the mean-teacher loss and the heads'
+    backward as the prologue phase of the top BiGRU layer's backward recurrence.  Debug bit 24 runs the same call with the
+    separate kernels (k_heads_fwd, k_heads_bwd).  Same arithmetic in the same order: posteriors, every parameter gradient and
+    the parameters after Adam must be BIT-identical over two steps (the second step starts from the first one's update and
+    its advanced step state); the meters are summed in a different order (2e-6).  T / 8 > 128 (T = 1100) is not fused."""
+    a = _one_step_with_deferred_heads(B, T, 16777216, **kw)
+    b = _one_step_with_deferred_heads(B, T, 0, **kw)
+    for sa, sb in zip(a, b):
+        assert sa["state"] == sb["state"]
+        assert torch.isfinite(sb["grads"]).all() and float(sb["grads"].abs().max()) > 0
+        for k in ("strong", "weak", "grads", "params"):
+            assert torch.equal(sa[k], sb[k]), (k, float((sa[k] - sb[k]).abs().max()))
+        for k, v in sa["meters"].items():
+            assert sb["meters"][k] == pytest.approx(v, rel=2e-6, abs=1e-9), k
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_three_fused_steps_vs_real_main_train_goldens(golden_dir, use_graph):
     """G5: three steps of the REAL baseline/main.py train() (B=8, dropout 0): meters, student and

@@ -67,6 +67,14 @@ _SIGS = {
                                        C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, C.c_size_t, C.c_int, _P]),
     "sed_mt_step_backward": (C.c_int, [C.POINTER(SedDims), _P, _P, _P, _P, C.c_size_t, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int,
                                        C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, C.c_size_t, C.c_int, _P]),
+    "sed_p2p_buffer_bytes": (C.c_size_t, [C.c_longlong]),
+    "sed_p2p_alloc": (C.c_int, [C.c_size_t, C.c_int, C.POINTER(C.c_void_p), _P, C.POINTER(C.c_int)]),
+    "sed_p2p_open": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
+    "sed_p2p_close": (C.c_int, [_P]),
+    "sed_p2p_free": (C.c_int, [_P]),
+    "sed_p2p_can_access": (C.c_int, [C.c_int]),
+    "sed_p2p_errors": (C.c_int, [_P, C.POINTER(C.c_uint)]),
+    "sed_p2p_allreduce": (C.c_int, [_P, C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_longlong, C.c_int, _P]),
     "sed_adam_ema": (C.c_int, [C.c_int64, _P, _P, _P, _P, _P, _P, C.c_float, _P]),
     "sed_ema_update": (C.c_int, [C.c_int64, _P, _P, C.c_float, _P]),
     "sed_step_state_init": (C.c_int, [_P, C.c_uint64, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,

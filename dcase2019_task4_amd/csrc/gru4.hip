@@ -347,20 +347,9 @@ __global__ __launch_bounds__(G4B_THREADS) void k_gru4_bwd(const float* __restric
     const int nblk = (T + G4_SB - 1) / G4_SB;
     auto t_of = [&](int step) { return dir ? step : (T - 1 - step); };     // reverse of the forward order
     TSW(0, 0);
-    if constexpr (HEADS) {
-        // (scratch = the ops / history rings, which nothing has touched yet; ends with a workgroup barrier)
-        heads_fused_phase<G4B_THREADS>(hf, out, b, dir, 2 * (int)gridDim.x, (int)(blockIdx.y * gridDim.x + blockIdx.x), T, ops, dout_s);
-        TSW(8, 0);
-    }
-
-    if (role == 4 || role == 5) {
-        // ================================ I/O waves =========================================================
-        // two of them (96 operand values per lane and block do not fit one wave's registers next to the output slices):
-        // wave io takes the steps of its parity
-        const int io = role - 4;
-        // operand row a (0: d_out, 1-4: r z n gh_n, 5: h_prev) of recurrence step `step`, lane l; clamped address +
-        // validity, so that the loads issue unconditionally back to back
-        auto op_load = [&](int step, int a, bool& ok) -> float {
+    // operand row a (0: d_out, 1-4: r z n gh_n, 5: h_prev) of recurrence step `step`, lane l; clamped address +
+    // validity, so that the loads issue unconditionally back to back
+    auto op_load = [&](int step, int a, bool& ok) -> float {
             const int t = t_of(min(step, T - 1));
             const int tp = dir ? t + 1 : t - 1;
             const int tpc = min(max(tp, 0), T - 1);
@@ -372,7 +361,34 @@ __global__ __launch_bounds__(G4B_THREADS) void k_gru4_bwd(const float* __restric
                            : (a < 5) ? gates + ((size_t)(b * T + t) * 2 + dir) * 256 + (a - 1) * 64 + l
                                      : out + (size_t)(b * T + tpc) * 128 + dir * 64 + l;
             return *p;
-        };
+    };
+    // HEADS: what the recurrence needs before its first step - the W_hh columns of the four recurrence waves (48 registers)
+    // and the saved gates / previous states of block 0 of the two I/O waves (40 of 48 slots; the d_out slots come out of the
+    // heads phase) - is REQUESTED here and lands while the heads phase runs (3.4 us of strided weight loads otherwise sat
+    // between the phase and step 0).  The dX GEMM waves need their W_ih fragments only from block 1 on and load them later.
+    float pre[48];
+    unsigned long long pre_ok = 0;
+    if constexpr (HEADS) {
+        if (role < 4) {
+            G4Rot<0>::load_bwd(pre, dir ? w_hh_r : w_hh_f, l >> 4, l & 15, 16 * role + (l & 15));
+        } else if (role < 6) {
+#pragma unroll
+            for (int i = 0; i < 6 * G4_SB / 2; ++i) {
+                bool ok = false;
+                pre[i] = (i % 6 == 0) ? 0.f : op_load(2 * (i / 6) + (role - 4), i % 6, ok);
+                pre_ok |= (ok ? 1ull : 0ull) << i;
+            }
+        }
+        // (scratch = the ops / history rings, which nothing has touched yet; ends with a workgroup barrier)
+        heads_fused_phase<G4B_THREADS>(hf, out, b, dir, 2 * (int)gridDim.x, (int)(blockIdx.y * gridDim.x + blockIdx.x), T, ops, dout_s);
+        TSW(8, 0);
+    }
+
+    if (role == 4 || role == 5) {
+        // ================================ I/O waves =========================================================
+        // two of them (96 operand values per lane and block do not fit one wave's registers next to the output slices):
+        // wave io takes the steps of its parity
+        const int io = role - 4;
         // the wave's 8 steps of block `blk`: global -> registers / registers -> ops[blk & 1].  The upstream gradient is the
         // sum of two direction planes below the top layer: the second plane travels in registers of its own and is added
         // on the way into LDS (an add at load time would make the wave wait for the loads before its first barrier)
@@ -410,7 +426,17 @@ __global__ __launch_bounds__(G4B_THREADS) void k_gru4_bwd(const float* __restric
             for (int a = 3; a < 6; ++a) dgh[bt * 192 + 64 * (a - 3) + l] = v[a];
             hprev_out[bt * 64 + l] = v[6];
         };
-        {
+        if constexpr (HEADS) {
+            float first2[G4_SB / 2];
+#pragma unroll
+            for (int i = 0; i < G4_SB / 2; ++i) {          // the d_out slots: out of LDS now
+                bool ok = false;
+                pre[6 * i] = op_load(2 * i + io, 0, ok);
+                pre_ok |= (ok ? 1ull : 0ull) << (6 * i);
+                first2[i] = 0.f;
+            }
+            ops_store(0, pre, first2, pre_ok);
+        } else {
             float first[6 * G4_SB / 2], first2[G4_SB / 2];
             unsigned long long okm;
             ops_load(0, first, first2, okm);
@@ -454,7 +480,9 @@ __global__ __launch_bounds__(G4B_THREADS) void k_gru4_bwd(const float* __restric
 #pragma unroll
             for (int s4 = 0; s4 < 48; ++s4) bw[c][s4] = wih[(size_t)(4 * s4 + kq) * NIN + 16 * (gw * CT + c) + i16];
         float* plane = dx_planes + (size_t)dir * B * T * NIN;
-        __syncthreads();
+        // (the prologue rendezvous: LDS-only barrier - these waves have written nothing, and a __syncthreads() here made the
+        // whole workgroup wait for their 96 fragment loads, which are first used a block of 16 steps later)
+        lds_barrier();
         // n_sync: how many of the 16 slices end with a barrier (the time steps of the block running meanwhile)
         auto gemm_block = [&](int blk, int n_sync, auto sync_tag) {
             constexpr bool SYNC = decltype(sync_tag)::value;      // false: the tail call - no barrier code in the loop, so the 48 LDS
@@ -502,8 +530,8 @@ __global__ __launch_bounds__(G4B_THREADS) void k_gru4_bwd(const float* __restric
     // LDS-bandwidth bound: 48 KB per step and workgroup) and reach the lanes through 16 DPP row rotations.
     const int w = role, kq = l >> 4, u = l & 15, j = 16 * w + u;
     const float* whh = dir ? w_hh_r : w_hh_f;
-    float wt[48];
-    G4Rot<0>::load_bwd(wt, whh, kq, u, j);
+    float (&wt)[48] = pre;
+    if constexpr (!HEADS) G4Rot<0>::load_bwd(wt, whh, kq, u, j);
     for (int e = tid; e < 192; e += 256) zero[e] = 0.f;
 #pragma unroll
     for (int i = 0; i < 48; ++i) asm volatile("" : "+v"(wt[i]));      // pin the load waits before the loop

@@ -56,7 +56,9 @@ __device__ __forceinline__ f32x4 hf_mfma16(float a, float b, f32x4 c) { return _
 // One workgroup (clip b, direction dir) of NT threads; h = the top GRU layer's output [B][T][128] (H = 64).
 //   R       scratch, hfuse_scratch_floats(T) floats
 //   dout_s  [TP][64] result: this direction's half of dL/dh (dropout mask and scale applied); used as scratch before
-// Ends with a __syncthreads(): on return dout_s is complete and R is free.
+// Ends with a workgroup barrier: on return dout_s is complete and R is free.  Every barrier of the phase is LDS-only
+// (lds_barrier): __syncthreads() would also drain the wave's outstanding global stores (the posteriors, the partials) and the
+// caller's prefetch loads at every phase boundary.
 template <int NT>
 __device__ __forceinline__ void heads_fused_phase(const HeadsFuse& hf, const float* __restrict__ h, int b, int dir, int nwg, int wg,
                                                   int T, float* __restrict__ R, float* __restrict__ dout_s) {
@@ -167,7 +169,7 @@ __device__ __forceinline__ void heads_fused_phase(const HeadsFuse& hf, const flo
                 if (lane == 0) tmaxs[c] = t;
             }
     }
-    __syncthreads();
+    lds_barrier();
     // ---- H1: logits[t][o] = x[t][:] . W[o][:] + bias: (TP / 16) x 2 tiles of 16 x 16, K = 128 (same MFMA order as k_heads_fwd) ----
     for (int tile = wv; tile < (TP / 16) * 2; tile += NW) {
         const int rt = tile >> 1, ct = tile & 1;
@@ -184,7 +186,7 @@ __device__ __forceinline__ void heads_fused_phase(const HeadsFuse& hf, const flo
 #pragma unroll
         for (int r = 0; r < 4; ++r) lg[(16 * rt + 4 * kq + r) * HF_SD + o] = acc0[r] + acc1[r] + bias;
     }
-    __syncthreads();
+    lds_barrier();
     // ---- H2: softmax over classes + sigmoid, 8 threads per frame (thread `sub`: classes sub, sub + 8) ------------------------
     float sv_r[TRIPS][2], raw_r[TRIPS][2];
 #pragma unroll
@@ -220,7 +222,7 @@ __device__ __forceinline__ void heads_fused_phase(const HeadsFuse& hf, const flo
                 if (has[q]) { nums[tl][sub + 8 * q] = 0.f; dens[tl][sub + 8 * q] = 0.f; }
         }
     }
-    __syncthreads();
+    lds_barrier();
     // ---- H3: attention pooling over time (a wave per class), the weak posterior, its loss terms and gradient ------------------
     for (int c = wv; c < NC; c += NW) {
         float a = 0.f, d2 = 0.f;
@@ -247,7 +249,7 @@ __device__ __forceinline__ void heads_fused_phase(const HeadsFuse& hf, const flo
             lw[3 * c] = l0; lw[3 * c + 1] = l3; lw[3 * c + 2] = l4;
         }
     }
-    __syncthreads();
+    lds_barrier();
     // ---- H4: softmax / sigmoid backward per frame -> dlogits (over the logits tile) -------------------------------------------
     float lacc1 = 0.f, lacc2 = 0.f, lacc5 = 0.f;       // strong_bce, mse_strong, strong_ema_bce
 #pragma unroll
@@ -297,7 +299,7 @@ __device__ __forceinline__ void heads_fused_phase(const HeadsFuse& hf, const flo
         const float v1 = wave_sum(lacc1), v2 = wave_sum(lacc2), v5 = wave_sum(lacc5);
         if (lane == 0) { red[wv * 8 + 1] = v1; red[wv * 8 + 2] = v2; red[wv * 8 + 5] = v5; }
     }
-    __syncthreads();
+    lds_barrier();
     // ---- H5: the MFMA jobs, round-robin over the waves ---------------------------------------------------------------------------
     //   jobs 0..7: dW[o][f] = sum_t dl[t][o] x[t][f] for this direction's 64 features (2 x 4 tiles, K = TP frames)
     //   jobs 8.. : dx[t][f] = (sum_o dl[t][o] W[o][f]) * mask for this direction's 64 features ((TP / 16) x 4 tiles, K = 32)
@@ -308,7 +310,6 @@ __device__ __forceinline__ void heads_fused_phase(const HeadsFuse& hf, const flo
             const float* A = lg + kq * HF_SD + 16 * ot + i16;           // A[i = o][k = t]
             const float* Bp = xs + kq * HF_S + 16 * ft + i16;           // B[k = t][j = f]
             f32x4 wacc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
             for (int s4 = 0; s4 < TP / 4; ++s4) wacc = hf_mfma16(A[4 * s4 * HF_SD], Bp[4 * s4 * HF_S], wacc);
             const int f = 16 * ft + i16;
 #pragma unroll
@@ -350,6 +351,6 @@ __device__ __forceinline__ void heads_fused_phase(const HeadsFuse& hf, const flo
         }
         lossp[tid] = s2;
     }
-    __syncthreads();
+    lds_barrier();
 }
 #endif

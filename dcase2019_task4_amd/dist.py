@@ -16,6 +16,8 @@ issued as two buckets - the GRU/heads tail (ready first) and the conv head - so 
 the conv-block backward.  ``torch.distributed`` backend "nccl" is RCCL on ROCm; everything here is
 backend-agnostic and is covered on CPU with world_size-2 gloo tests.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -103,3 +105,181 @@ def fold_rank_seed(seed, rank):
     if rank == 0:
         return seed
     return _splitmix64(seed ^ _splitmix64((rank + 0xD1B54A32D192ED03) & _M64))
+
+
+class PeerAllReduce:
+    """The gradient all-reduce as ONE kernel over peer-mapped device memory (csrc/p2p.hip, sed_p2p_*): every rank of the node
+    maps every other rank's communication buffer (hipIpcMemHandle) and a single launch does reduce-scatter + all-gather with
+    direct remote loads / stores, the sums formed in rank order on every rank.  No library collective inside the step: the
+    launch is captured into the step's hipGraph like any other kernel, and - unlike RCCL - two ranks may share one GPU, so the
+    captured data-parallel schedule is testable at world 2 on a one-GPU box.
+
+    ``group`` is only used at construction (handle exchange, the self-check) and by ``errors(reduce=True)``.
+    ``PeerAllReduce.create`` returns None instead of raising when the ranks are not on one host, a peer cannot be mapped, or
+    the self-check against ``dist.all_reduce`` fails on ANY rank - the caller then keeps the process group's collective."""
+
+    def __init__(self, n_floats_max, device, group=None, workgroups=0, fine_grained=True):
+        import ctypes as C
+        import socket
+        from . import _lib
+        self.l = _lib.lib()
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.device = torch.device(device)
+        self.n_max = int(n_floats_max)
+        self.workgroups = int(workgroups)
+        self._own = None
+        self._peers = {}
+        if self.world > 16:
+            raise _lib.SedError("PeerAllReduce: at most 16 ranks (one node)")
+        with torch.cuda.device(self.device):
+            nbytes = self.l.sed_p2p_buffer_bytes(self.n_max)
+            own, fg = C.c_void_p(), C.c_int(0)
+            handle = (C.c_ubyte * 64)()
+            # (no rank may skip a collective of this constructor: an allocation that fails HERE still reaches the exchange)
+            mine, err = None, None
+            try:
+                _lib.check(self.l.sed_p2p_alloc(nbytes, 1 if fine_grained else 0, C.byref(own), handle, C.byref(fg)), "sed_p2p_alloc")
+                self._own = own.value
+                self.fine_grained = bool(fg.value)
+                mine = (socket.gethostname(), self.device.index or 0, os.getpid(), bytes(handle), self.fine_grained)
+            except Exception as e:                     # noqa: BLE001
+                err = e
+            every = [None] * self.world
+            dist.all_gather_object(every, mine, group=group)
+            if any(v is None for v in every):
+                self.close()
+                raise _lib.SedError(f"PeerAllReduce: a rank could not create its communication buffer ({err!r})")
+            if len({h for h, *_ in every}) != 1:
+                self.close()
+                raise _lib.SedError("PeerAllReduce: the ranks are not on one host")
+            ptrs = (C.c_void_p * self.world)()
+            for p, (_h, pdev, _pid, ph, _fg) in enumerate(every):
+                if p == self.rank:
+                    ptrs[p] = self._own
+                    continue
+                if not self.l.sed_p2p_can_access(int(pdev)):
+                    self.close()
+                    raise _lib.SedError(f"PeerAllReduce: device {self.device.index} cannot map device {pdev}")
+                q = C.c_void_p()
+                hb = (C.c_ubyte * 64).from_buffer_copy(ph)
+                _lib.check(self.l.sed_p2p_open(hb, C.byref(q)), "sed_p2p_open")
+                self._peers[p] = q.value
+                ptrs[p] = q.value
+            self._ptrs = ptrs
+            self.layout = [(h, d, pid, fg_) for h, d, pid, _, fg_ in every]
+        # (no barrier needed: a rank's kernels only touch buffers IT has mapped, and every buffer was allocated and zeroed
+        # before its handle was exchanged)
+
+    @classmethod
+    def create(cls, n_floats_max, device, group=None, verify=True, **kw):
+        """Build + self-check on every rank; None (on every rank alike) if anything fails anywhere."""
+        obj, ok = None, 1.0
+        try:
+            obj = cls(n_floats_max, device, group, **kw)
+        except Exception as e:                         # noqa: BLE001 - any failure means "keep the process group's collective"
+            ok = 0.0
+            cls.last_error = repr(e)
+        flag = torch.tensor([ok], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if flag.item() != 1.0:
+            if obj is not None:
+                obj.close()
+            return None
+        if verify and not obj.self_check():
+            obj.close()
+            return None
+        return obj
+
+    def all_reduce(self, flat, lo=0, hi=None, stream=None):
+        """In-place sum of flat[lo:hi] (fp32, contiguous, 16-byte aligned start) over the ranks, on ``stream`` (default: the
+        current stream).  Every rank must issue the same sequence of calls."""
+        from . import _lib
+        hi = flat.numel() if hi is None else hi
+        if flat.dtype != torch.float32 or not flat.is_contiguous() or flat.device != self.device:
+            raise _lib.SedError("PeerAllReduce.all_reduce: needs a contiguous fp32 tensor on the communicator's device")
+        import ctypes as C
+        ptr = flat.data_ptr() + 4 * lo
+        st = C.c_void_p(stream.cuda_stream) if stream is not None else _lib.stream_ptr()
+        _lib.check(self.l.sed_p2p_allreduce(C.c_void_p(ptr), hi - lo, self.rank, self.world, self._ptrs, self.n_max,
+                                            self.workgroups, st), "sed_p2p_allreduce")
+
+    def errors(self, reduce=False):
+        """Sticky count of cross-rank waits that timed out (3 s each): non-zero = results since then are invalid."""
+        import ctypes as C
+        from . import _lib
+        n = C.c_uint(0)
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize(self.device)
+            _lib.check(self.l.sed_p2p_errors(C.c_void_p(self._own), C.byref(n)), "sed_p2p_errors")
+        v = int(n.value)
+        if reduce and self.world > 1:
+            t = torch.tensor([float(v)], device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            v = int(t.item())
+        return v
+
+    def self_check(self):
+        """A few all-reduces of different sizes (full buffer, an odd size, a tiny one; twice each so that both halves of the
+        double-buffered staging are used), eager and replayed from a hipGraph, against dist.all_reduce; True only if every
+        rank got bit-for-bit the rank-ordered sum and nothing timed out."""
+        ok = 1.0
+        try:
+            sizes = sorted({self.n_max, max(1, self.n_max // 3) | 1, 5})
+            g = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
+            for n in sizes:
+                for rep in range(2):
+                    x = torch.randn(n, generator=g).to(self.device)
+                    parts = [torch.zeros_like(x) for _ in range(self.world)]
+                    dist.all_gather(parts, x, group=self.group)
+                    want = parts[0].clone()
+                    for p in parts[1:]:
+                        want += p                      # rank order, as the kernel sums
+                    y = x.clone()
+                    self.all_reduce(y)
+                    torch.cuda.synchronize(self.device)
+                    if not torch.equal(y, want):
+                        ok = 0.0
+            # captured: the launch must replay correctly (device-side epochs)
+            x = torch.randn(sizes[-1], generator=g).to(self.device)
+            parts = [torch.zeros_like(x) for _ in range(self.world)]
+            dist.all_gather(parts, x, group=self.group)
+            want = parts[0].clone()
+            for p in parts[1:]:
+                want += p
+            y = x.clone()
+            st = torch.cuda.Stream(device=self.device)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=st, capture_error_mode="thread_local"):
+                self.all_reduce(y)
+            for _ in range(2):
+                y.copy_(x)
+                gr.replay()
+                torch.cuda.synchronize(self.device)
+                if not torch.equal(y, want):
+                    ok = 0.0
+            if self.errors() != 0:
+                ok = 0.0
+        except Exception as e:                         # noqa: BLE001
+            ok = 0.0
+            PeerAllReduce.last_error = repr(e)
+        flag = torch.tensor([ok], device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(flag.item() == 1.0)
+
+    def close(self):
+        if self._own is None and not self._peers:
+            return
+        import ctypes as C
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize(self.device)
+            for q in self._peers.values():
+                self.l.sed_p2p_close(C.c_void_p(q))
+            self._peers = {}
+            if self._own is not None:
+                self.l.sed_p2p_free(C.c_void_p(self._own))
+                self._own = None
+
+    last_error = None
+

@@ -288,7 +288,7 @@ class _SampleTransforms:
     def __init__(self, frames, scaler, add_axis_conv, augment_type, device, seed):
         self.add_axis_conv = bool(add_axis_conv)
         self.tr = LogMelTransform(frames, scaler=scaler, augment_type=augment_type, device=device, seed=seed)
-        self._worker = None
+        self._pid = None                # the process that last checked where it runs (a fork / spawn changes it)
 
     @staticmethod
     def worker_seed(seed, worker_id):
@@ -306,7 +306,7 @@ class _SampleTransforms:
         context, so that case is refused with a message that says what to do instead of torch's re-initialisation error;
         a spawned worker works (its own context, one launch + one copy per sample) and gets a noise stream of its own."""
         info = torch.utils.data.get_worker_info()
-        self._worker = -1 if info is None else int(info.id)
+        self._pid = os.getpid()
         if info is None:
             return
         if torch.cuda._is_in_bad_fork():
@@ -318,7 +318,7 @@ class _SampleTransforms:
         self.tr._seed = self.worker_seed(self.tr._seed, info.id)
 
     def __call__(self, sample):
-        if self._worker is None:
+        if self._pid != os.getpid():
             self._enter_worker()
         sample = list(sample)
         label = torch.from_numpy(np.asarray(sample[-1])).float()              # ToTensor: "even labels" (DataLoad.py:316)
@@ -333,7 +333,7 @@ class _SampleTransforms:
     def __getstate__(self):
         # (pickled into spawned workers: the worker decides for itself where it runs)
         st = dict(self.__dict__)
-        st["_worker"] = None
+        st["_pid"] = None
         return st
 
 

@@ -75,7 +75,7 @@ class MeanTeacherStep:
 
     def __init__(self, student, teacher, batch_size, n_frames, rampup_length, weak_mask, strong_mask, lr=1e-3,
                  betas=(0.9, 0.999), eps=1e-8, ema_decay=0.999, max_consistency_cost=2.0, seed=0, use_graph=True,
-                 process_group=None, overlap_streams=True, dp_schedule=None, pool_streams=True):
+                 process_group=None, overlap_streams=True, dp_schedule=None, pool_streams=True, collective=None):
         assert isinstance(student, CRNN) and (teacher is None or isinstance(teacher, CRNN))
         self.l = _lib.lib()
         self.student, self.teacher = student, teacher
@@ -167,6 +167,21 @@ class MeanTeacherStep:
         # schedule with EAGER collectives between four graph segments - that one is host-bound: 4 graph launches + 2 async
         # collectives + stream waits per step).  Otherwise (gloo, or capture not available): "single" with an eager collective.
         self._cap_stream = self._stream("capture")
+        # The gradient all-reduce itself: "p2p" = ONE kernel over peer-mapped device memory (dist.PeerAllReduce, csrc/p2p.hip:
+        # reduce-scatter + all-gather with direct loads / stores between the ranks of a node, sums in rank order), "pg" = the
+        # process group's all_reduce (RCCL, gloo), "auto" (default) = p2p when every rank can map every other one AND a
+        # self-check against the process group's result passes on every rank, else pg.  The p2p launch is an ordinary kernel:
+        # it is always capturable, and two ranks may share one GPU (RCCL refuses that), which is how the captured schedule is
+        # tested at world 2 on a one-GPU box.
+        want_coll = collective or os.environ.get("SED_DP_COLLECTIVE") or "auto"
+        if want_coll not in ("auto", "p2p", "pg"):
+            raise ValueError(f"unknown collective {want_coll!r}")
+        self._p2p = None
+        if self.dp and want_coll != "pg":
+            self._p2p = sdist.PeerAllReduce.create(n, dev, process_group)
+            if self._p2p is None and want_coll == "p2p":
+                raise _lib.SedError(f"collective='p2p' is not available here: {sdist.PeerAllReduce.last_error}")
+        self.collective = "p2p" if self._p2p is not None else ("pg" if self.dp else None)
         env_cap = os.environ.get("SED_DP_CAPTURE")
         want = dp_schedule or os.environ.get("SED_DP_SCHEDULE")
         if want == "split":
@@ -175,7 +190,7 @@ class MeanTeacherStep:
             raise ValueError(f"unknown data-parallel schedule {want!r}")
         self.dp_capture = False
         if self.dp and use_graph and env_cap != "0" and want != "single":
-            self.dp_capture = (env_cap == "1") or self._collective_capture_works()
+            self.dp_capture = (env_cap == "1") or self._p2p is not None or self._collective_capture_works()
         self.dp_schedule = want or ("overlap" if (self.dp_capture or not self.dp) else "single")
         self._dp_stream = self._stream("collective") if self.dp else None
         # train_cnn=False (CRNN.py:18-20, main.py:289-290 filters the optimiser's parameters on requires_grad): the conv
@@ -218,6 +233,9 @@ class MeanTeacherStep:
         step of the process and stay prepared.  The step must not be used afterwards."""
         torch.cuda.synchronize(self.device)
         self._graph_a = self._graph_w = self._graph_c = self._graph_b = None
+        if self._p2p is not None:
+            self._p2p.close()
+            self._p2p = None
         for st in self._owned_streams:
             _lib.check(self.l.sed_stream_release(C.c_void_p(st.cuda_stream)), "sed_stream_release")
         self._owned_streams = []
@@ -365,6 +383,9 @@ class MeanTeacherStep:
                        "sed_step_state_update")
 
     def _allreduce(self, lo, hi, async_op):
+        if self._p2p is not None:                      # one kernel on the current stream; nothing to wait for on the host
+            self._p2p.all_reduce(self.grads, lo, hi)
+            return None
         return sdist.allreduce_bucket(self.grads, lo, hi, self.pg, async_op=async_op, force=True)
 
     def _dp_tail(self):
@@ -531,6 +552,11 @@ class MeanTeacherStep:
         kernels then carried on with a stale hidden state and every result since is suspect.  The counter is sticky (only
         sed_crnn_buffers_init clears it); one 4-byte device->host copy per model.  train() calls this whenever it reads
         the meters."""
+        if self._p2p is not None:
+            n = self._p2p.errors()
+            if n:
+                raise _lib.SedError(f"peer all-reduce: {n} cross-rank waits timed out (a rank did not launch the same "
+                                    "sequence of collectives, or died); gradients since then are invalid")
         if self._err_view is None:
             return
         off, nb = self._err_view

@@ -228,6 +228,30 @@ int sed_mt_step_backward(const sed_dims* d, const float* params, const float* x,
                          sed_step_state* state_dev, int advance_state, float* losses, float* d_strong, float* d_weak,
                          float* grads, void* ws, size_t ws_bytes, int parts, void* stream);
 
+/* ---- data-parallel gradient all-reduce over peer-mapped memory (csrc/p2p.hip) --------------------------------------------
+ * New capability (the reference is single-process); what it serves is the per-rank batch contract of main.py:238-247 /
+ * DataLoad.py:562-571 and the mean gradient of main.py:152-154.  One launch = reduce-scatter + all-gather with direct loads /
+ * stores between the W ranks of one node (xGMI is point-to-point: every peer is one hop), sums formed in rank order on every
+ * rank (bit-identical replicas), capturable into the step's hipGraph, every cross-rank wait bounded (sticky error counter).
+ *   sed_p2p_buffer_bytes(n)  size of a rank's communication buffer for messages of up to n floats
+ *   sed_p2p_alloc            allocates (fine-grained device memory; falls back to hipMalloc), zeroes and exports one: the ONE
+ *                            place this library owns device memory (torch's allocator cannot create or export it); handle = 64 bytes
+ *   sed_p2p_open / _close    map / unmap a peer's buffer from its handle (hipIpcOpenMemHandle); _free releases one's own
+ *   sed_p2p_can_access(dev)  1 if the current device can map device dev's memory
+ *   sed_p2p_allreduce        in-place sum of data[0, n) over the ranks; bufs[world] = every rank's buffer as mapped HERE
+ *                            (bufs[rank] = own); same n_floats_max and workgroups (0 = 16) on every rank; every rank enqueues the
+ *                            same sequence of calls
+ *   sed_p2p_errors           the sticky count of timed-out waits (blocking 4-byte read) */
+size_t sed_p2p_buffer_bytes(long long n_floats_max);
+int sed_p2p_alloc(size_t bytes, int fine_grained, void** ptr_out, void* handle_out, int* fine_grained_out);
+int sed_p2p_open(const void* handle, void** ptr_out);
+int sed_p2p_close(void* peer_ptr);
+int sed_p2p_free(void* own_ptr);
+int sed_p2p_can_access(int peer_device);
+int sed_p2p_errors(const void* own_ptr, unsigned int* out);
+int sed_p2p_allreduce(float* data, long long n, int rank, int world, void* const* bufs, long long n_floats_max,
+                      int workgroups, void* stream);
+
 /* ---- optimiser + EMA -----------------------------------------------------------------------
  * Replaces optimizer.step() of torch.optim.Adam(lr, betas) (main.py:154,289-290) fused with
  * update_ema_variables (main.py:45-49,156-157) over the flat buffers. grad_scale multiplies

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, schedule, graph, out, Bg=16, T=128, C=64, H=64, dtype="f32"):
+def _worker(rank, world, port, schedule, graph, out, Bg=16, T=128, C=64, H=64, dtype="f32", collective="pg"):
     if REPO not in sys.path:
         sys.path.insert(0, REPO)
     import torch.distributed as dist
@@ -61,8 +61,14 @@ def _worker(rank, world, port, schedule, graph, out, Bg=16, T=128, C=64, H=64, d
         # data-parallel: rank 1 starts from DIFFERENT weights - the constructor must broadcast rank 0's
         s2, t2 = models(0, 1) if rank == 0 else models(7, 8)
         dp = MeanTeacherStep(s2, t2, B, T, 40, wm, sm, seed=1234, use_graph=graph, process_group=dist.group.WORLD,
-                             dp_schedule=schedule)
-        assert dp.dp and dp.world == world and dp.rank == rank
+                             dp_schedule=schedule, collective=collective)
+        assert dp.dp and dp.world == world and dp.rank == rank and dp.collective == collective
+        if collective == "p2p":
+            # the all-reduce is the library's own kernel over peer-mapped memory: capturable on any backend, so the DEFAULT
+            # schedule - collectives inside the step's hipGraph - runs at world 2 on this one-GPU box too
+            assert dp._p2p is not None and dp._p2p.world == world
+            if graph and schedule == "overlap":
+                assert dp.dp_capture is True and dp.dp_schedule == "overlap" and dp.single_graph
         if backend == "nccl":
             # first contact with real RCCL at world > 1: the default must be the captured-collective overlap schedule
             assert dist.get_backend() == "nccl"
@@ -111,8 +117,9 @@ def _worker(rank, world, port, schedule, graph, out, Bg=16, T=128, C=64, H=64, d
         sl = [torch.zeros_like(dp.strong) for _ in range(world)]
         dist.all_gather(sl, dp.strong)
         assert not torch.equal(sl[0], sl[1])
+        dp.check_health()                          # (p2p: no cross-rank wait timed out)
         if rank == 0:
-            out.put(("ok", backend, err / (scale + 1e-30)))
+            out.put(("ok", backend + "+" + collective, err / (scale + 1e-30)))
     except Exception as e:      # surface the failure in the parent
         import traceback
         out.put(("fail", rank, traceback.format_exc()))
@@ -154,22 +161,111 @@ def _run_world2(target, args):
     return ok[0]
 
 
-def _worker_entry(rank, world, port, schedule, graph, Bg, T, C, H, dtype, out):
-    _worker(rank, world, port, schedule, graph, out, Bg, T, C, H, dtype)
+def _worker_entry(rank, world, port, schedule, graph, Bg, T, C, H, dtype, collective, out):
+    _worker(rank, world, port, schedule, graph, out, Bg, T, C, H, dtype, collective)
 
 
 # 4th case: BASELINE.json configs[3]'s per-rank composition - 64 clips per rank as [16 | 32 | 16] of a global
 # [32 | 64 | 32] at T = 628 (main.py:238-247, DataLoad.py:562-571); last two: configs[4]'s model (wide CRNN, bf16 arithmetic and
 # storage, cluster recurrence) and its bf16x3 mode under the data-parallel step
-@pytest.mark.parametrize("schedule,graph,Bg,T,C,H,dtype",
-                         [("overlap", False, 16, 128, 64, 64, "f32"), ("overlap", True, 16, 128, 64, 64, "f32"),
-                          ("single", True, 16, 128, 64, 64, "f32"), ("overlap", True, 128, 628, 64, 64, "f32"),
-                          ("overlap", True, 16, 216, 128, 256, "bf16"), ("overlap", True, 16, 216, 128, 256, "bf16x3"),
-                          ("overlap", True, 16, 216, 64, 64, "bf16")])
-def test_mean_teacher_step_world2(schedule, graph, Bg, T, C, H, dtype):
-    ok = _run_world2(_worker_entry, (schedule, graph, Bg, T, C, H, dtype))
+@pytest.mark.parametrize("schedule,graph,Bg,T,C,H,dtype,collective",
+                         [("overlap", False, 16, 128, 64, 64, "f32", "pg"), ("overlap", True, 16, 128, 64, 64, "f32", "pg"),
+                          ("single", True, 16, 128, 64, 64, "f32", "pg"), ("overlap", True, 128, 628, 64, 64, "f32", "pg"),
+                          ("overlap", True, 16, 216, 128, 256, "bf16", "pg"), ("overlap", True, 16, 216, 128, 256, "bf16x3", "pg"),
+                          ("overlap", True, 16, 216, 64, 64, "bf16", "pg"),
+                          # round 5: the same checks with the library's own all-reduce (csrc/p2p.hip) - collectives CAPTURED in the
+                          # step's hipGraph at world 2 (dp_capture True), which RCCL cannot do on one GPU and gloo cannot do at all
+                          ("overlap", True, 16, 128, 64, 64, "f32", "p2p"), ("overlap", False, 16, 128, 64, 64, "f32", "p2p"),
+                          ("single", True, 16, 128, 64, 64, "f32", "p2p"), ("overlap", True, 128, 628, 64, 64, "f32", "p2p"),
+                          ("overlap", True, 16, 216, 128, 256, "bf16", "p2p"), ("overlap", True, 16, 216, 64, 64, "bf16", "p2p")])
+def test_mean_teacher_step_world2(schedule, graph, Bg, T, C, H, dtype, collective):
+    ok = _run_world2(_worker_entry, (schedule, graph, Bg, T, C, H, dtype, collective))
     print(f"[dp world 2] backend {ok[1]} schedule {schedule} graph {graph} global batch {Bg} T {T} C {C} H {H} {dtype}: "
           f"|allreduce - sum| / max = {ok[2]:.2e}")
+
+
+def _worker_peer_allreduce(rank, world, port, mode, out):
+    """dist.PeerAllReduce alone: sizes from 1 float to the buffer size (not multiples of 4, of the workgroup count or of the
+    world size), eager and replayed from a hipGraph 20 times with fresh data, two messages back to back (the two gradient
+    buckets of a step) - every rank must end with bit-for-bit the RANK-ORDER sum.  mode "timeout": rank 1 skips one call; rank
+    0's waits must time out (bounded, 3 s), raise the sticky error counter and return - never hang the GPU."""
+    if REPO not in sys.path:
+        sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    from dcase2019_task4_amd import dist as sdist
+    dev = torch.device("cuda", rank if torch.cuda.device_count() >= world else 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        n_max = 214356                              # the gradient buffer of cfg.crnn_kwargs (SURVEY.md appendix A)
+        ar = sdist.PeerAllReduce.create(n_max, dev, dist.group.WORLD)
+        assert ar is not None, sdist.PeerAllReduce.last_error
+        g = torch.Generator().manual_seed(99 + rank)
+
+        def expect(x):
+            parts = [torch.zeros_like(x) for _ in range(world)]
+            dist.all_gather(parts, x)
+            want = parts[0].clone()
+            for p in parts[1:]:
+                want += p
+            return want
+        if mode == "timeout":
+            x = torch.randn(1000, generator=g).to(dev)
+            if rank == 0:
+                ar.all_reduce(x)                    # rank 1 never issues this one
+            torch.cuda.synchronize()
+            dist.barrier()
+            n_err = ar.errors()
+            assert (n_err > 0) == (rank == 0), (rank, n_err)
+            assert ar.errors(reduce=True) > 0
+            if rank == 0:
+                out.put(("ok", "gloo", float(n_err)))
+            return
+        for n in (1, 3, 4, 5, 127, 1000, 65537, 127012, 87344, n_max):
+            x = torch.randn(n, generator=g).to(dev)
+            want = expect(x)
+            y = x.clone()
+            ar.all_reduce(y)
+            torch.cuda.synchronize()
+            assert torch.equal(y, want), (n, float((y - want).abs().max()))
+        # a slice of a larger buffer (the bucket form: flat[lo:hi]); lo a multiple of 4 floats as the parameter layout gives
+        flat = torch.randn(n_max, generator=g).to(dev)
+        lo, hi = 127012, n_max
+        want = flat.clone()
+        want[lo:hi] = expect(flat[lo:hi].clone())
+        ar.all_reduce(flat, lo, hi)
+        torch.cuda.synchronize()
+        assert torch.equal(flat, want)
+        # captured, two buckets back to back, replayed with fresh data
+        a, b = torch.zeros(127012, device=dev), torch.zeros(87344, device=dev)
+        st = torch.cuda.Stream(device=dev)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=st, capture_error_mode="thread_local"):
+            ar.all_reduce(b)
+            ar.all_reduce(a)
+        for it in range(20):
+            xa, xb = torch.randn(a.numel(), generator=g).to(dev), torch.randn(b.numel(), generator=g).to(dev)
+            wa, wb = expect(xa), expect(xb)
+            a.copy_(xa); b.copy_(xb)
+            gr.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(a, wa) and torch.equal(b, wb), it
+        assert ar.errors(reduce=True) == 0
+        ar.close()
+        if rank == 0:
+            out.put(("ok", "gloo", 1.0 if ar.fine_grained else 0.0))
+    except Exception:
+        import traceback
+        out.put(("fail", rank, traceback.format_exc()))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["sums", "timeout"])
+def test_peer_allreduce_world2_on_one_gpu(mode):
+    ok = _run_world2(_worker_peer_allreduce, (mode,))
+    print(f"[p2p all-reduce world 2] mode {mode}: {'fine-grained buffers' if ok[2] == 1.0 and mode == 'sums' else ok[2]}")
 
 
 def _worker_frontend(rank, world, port, dtype, out):

@@ -497,12 +497,17 @@ def main():
     ab_legs = None
     if world > 1 and headline and not args.no_extras and args.batch is None:
         ab_legs = {}
-        for tag, sched, cap in (("single_eager", "single", "0"), ("overlap_eager", "overlap", "0")):
+        # (the headline runs the default: overlap schedule, collectives captured, the library's own peer-memory all-reduce when
+        # its self-check passes - config.dp_collective says which ran; these legs price the alternatives)
+        for tag, sched, cap, coll in (("overlap_captured_rccl", "overlap", None, "pg"), ("single_eager_rccl", "single", "0", "pg"),
+                                      ("overlap_eager_rccl", "overlap", "0", "pg"), ("single_captured_p2p", "single", None, "p2p")):
             try:
-                os.environ["SED_DP_CAPTURE"] = cap
+                if cap is not None:
+                    os.environ["SED_DP_CAPTURE"] = cap
                 sa, ta = build_models(device, seed=0)
                 stp = MeanTeacherStep(sa, ta, B, T_FRAMES, rampup_length=210 * 100 // 2, weak_mask=wm, strong_mask=sm,
-                                      seed=1234, use_graph=not args.no_graph, process_group=pg, dp_schedule=sched)
+                                      seed=1234, use_graph=not args.no_graph, process_group=pg, dp_schedule=sched,
+                                      collective=coll)
                 stp.load_batch(x, xe, tgt)
                 for _ in range(5):
                     stp.run()
@@ -510,7 +515,9 @@ def main():
                 ela = time_steps(stp, na, world, device)
                 same_on_all_ranks(stp, world, device)
                 ab_legs[tag] = {"value": round(B * world * na / ela, 1), "unit": "clips/s", "ms_per_step": round(ela / na * 1e3, 4),
-                                "steps": na, "dp_schedule": stp.dp_schedule, "dp_collectives": "captured" if stp.dp_capture else "eager"}
+                                "steps": na, "dp_schedule": stp.dp_schedule, "dp_collectives": "captured" if stp.dp_capture else "eager",
+                                "dp_collective": stp.collective}
+                stp.close()
                 del stp
             except Exception as e:                      # noqa: BLE001 - the headline line must not depend on these legs
                 ab_legs[tag] = {"error": repr(e)[:300]}
@@ -552,7 +559,7 @@ def main():
             config4 = {"workload": "BASELINE.json configs[4]: " + workload_string(True, "bf16", False, B4), "global_batch": B4 * world,
                        "value": round(B4 * world * n4 / el4, 1), "unit": "clips/s", "ms_per_step": round(ms4, 4), "steps": n4,
                        "dtype": "bf16", "dp_schedule": step4.dp_schedule,
-                       "dp_collectives": "captured" if step4.dp_capture else "eager",
+                       "dp_collectives": "captured" if step4.dp_capture else "eager", "dp_collective": step4.collective,
                        "gradient_bytes_per_step": 4 * N_PARAMS[True]}
             del r4, step4
         except Exception as e:                      # noqa: BLE001
@@ -585,7 +592,11 @@ def main():
             "config": {"workload": wl, "global_batch": B * world, "frames": T_FRAMES, "n_mels": N_MELS,
                        "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
                        "dp_schedule": step.dp_schedule if step.dp else None,
-                       "dp_collectives": ("captured" if step.dp_capture else "eager") if step.dp else None},
+                       "dp_collectives": ("captured" if step.dp_capture else "eager") if step.dp else None,
+                       "dp_collective": ({"p2p": "library kernel over peer-mapped memory (csrc/p2p.hip: reduce-scatter + all-gather in "
+                                                 "one launch, direct xGMI loads / stores, self-checked against the process group)",
+                                          "pg": "torch.distributed all_reduce (RCCL picks algorithm / protocol)"}[step.collective]
+                                         if step.dp else None)},
             "loss": round(meters["loss"], 5),
         }
         if dist_info:

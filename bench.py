@@ -57,7 +57,7 @@ def algorithmic_bytes(wide, mfma_dtype, waveform, B):
     (f32, and bf16x3 - split operands, fp32 storage), 6.0 / 12.0 MB in bf16 (SED_DTYPE_BF16 stores activations as bf16);
     + 0.96 MB per clip when the step starts from waveforms; + 9 words x parameters per STEP of optimiser traffic."""
     per_clip = WIDE_STEP_BYTES_PER_CLIP if wide else STEP_BYTES_PER_CLIP
-    if mfma_dtype == "bf16":
+    if mfma_dtype in ("bf16", "f16"):      # (f16: the same 2-byte tensors; its bf16 copies for the backward are not algorithmic bytes)
         per_clip = 12.0e6 if wide else 6.0e6
     if waveform:
         per_clip += WAVEFORM_BYTES_PER_CLIP
@@ -70,6 +70,7 @@ CONFIGS = {   # name -> (wide, mfma dtype, from waveform, default batch per GPU)
     "wide-f32": (True, "f32", False, 24), "wide-bf16": (True, "bf16", False, 24),
     "mt-bf16x3": (False, "bf16x3", False, 24), "wide-bf16x3": (True, "bf16x3", False, 24),
     "waveform-bf16x3": (False, "bf16x3", True, 64),
+    "mt-f16": (False, "f16", False, 24), "wide-f16": (True, "f16", False, 24), "waveform-f16": (False, "f16", True, 64),
 }
 PEAK_HBM_GBS = 8000.0
 
@@ -354,7 +355,12 @@ ARITH = {"f32": "fp32 (exact fp32 MFMA; block 0's backward sums on split bf16 op
                  "dgrad / wgrad, GLU Linear, block 0), bf16 GRU weight-gradient GEMMs, bf16 W_hh / projections at H = 256; "
                  "fp32 accumulation everywhere, fp32 recurrence at H = 64, heads, BatchNorm statistics, losses, Adam",
          "bf16x3": "SED_DTYPE_BF16X3: split bf16 operands (hi + lo, three bf16 MFMAs per product, fp32 accumulation and fp32 "
-                   "storage) in the conv-block GEMMs, fp32 elsewhere"}
+                   "storage) in the conv-block GEMMs, fp32 elsewhere",
+         "f16": "SED_DTYPE_F16: SED_DTYPE_BF16 with its FORWARD chain in fp16 - fp16 MFMA operands (same rate as bf16, 11-bit "
+                "significand) in conv block 0, the 3x3 convolutions, the GLU Linear and, at H = 256, the gi projections and the W_hh / h "
+                "operands of the recurrence; p0 / y1 / p1 / y2 handed on as fp16; the backward is the bf16 mode's (bf16 gradient "
+                "tensors and operands, reading bf16 copies of the activations that the forward kernels write as well); posteriors "
+                "asserted within the north star's 1e-3 of the fp32 oracle"}
 
 
 def workload_string(wide, mfma_dtype, waveform, B, fft="f32"):
@@ -409,7 +415,7 @@ def extra_config_legs(device, steps=300):
     already built and replayed four other steps holds their streams, and a later step's graph branches then share hardware
     queues with them - measured in-process, the fifth leg came out at 0.90 ms against 0.66 ms alone."""
     out = {}
-    for name in ("waveform-bf16", "wide-bf16", "wide-bf16x3", "mt-bf16", "mt-bf16x3"):
+    for name in ("waveform-bf16", "waveform-f16", "wide-bf16", "wide-f16", "wide-bf16x3", "mt-bf16", "mt-f16", "mt-bf16x3"):
         try:
             wide, mfma_dtype, waveform, B = CONFIGS[name]
             cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(steps), "--warmup", "8", "--no-extras",

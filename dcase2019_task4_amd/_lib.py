@@ -28,11 +28,11 @@ class SedDims(C.Structure):
 
 
 FORK_CALLBACK = C.CFUNCTYPE(None, C.c_void_p)     # void (*fn)(void* user): sed_crnn_fork_callback
-DTYPE_F32, DTYPE_BF16, DTYPE_BF16X3 = 0, 1, 2
+DTYPE_F32, DTYPE_BF16, DTYPE_BF16X3, DTYPE_F16 = 0, 1, 2, 3
 FFT_F64, FFT_F32 = 0, 1
 FFT_DTYPES = {"f64": FFT_F64, "float64": FFT_F64, "f32": FFT_F32, "float32": FFT_F32}
 DTYPES = {"f32": DTYPE_F32, "fp32": DTYPE_F32, "float32": DTYPE_F32, "bf16": DTYPE_BF16, "bfloat16": DTYPE_BF16,
-          "bf16x3": DTYPE_BF16X3}
+          "bf16x3": DTYPE_BF16X3, "f16": DTYPE_F16, "fp16": DTYPE_F16, "float16": DTYPE_F16}
 
 
 class SedStepState(C.Structure):

@@ -337,6 +337,8 @@ class CRNN(nn.Module):
         raw = cbuf[off.value:off.value + nb.value]
         if name in ("mom0", "stat1", "stat2"):
             return raw.view(torch.float64)
-        if dims.dtype == _lib.DTYPE_BF16 and name in ("p0", "y1", "p1", "y2"):
-            return raw.view(torch.bfloat16).float()       # SED_DTYPE_BF16 stores the conv-block activations as bf16
+        if dims.dtype in (_lib.DTYPE_BF16, _lib.DTYPE_F16) and name in ("p0", "y1", "p1", "y2"):
+            # SED_DTYPE_BF16 stores the conv-block activations as bf16; SED_DTYPE_F16's views are the bf16 COPIES the backward
+            # reads (a training forward writes them next to the fp16 tensors of the forward chain)
+            return raw.view(torch.bfloat16).float()
         return raw.view(torch.float32)

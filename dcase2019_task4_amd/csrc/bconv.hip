@@ -2,6 +2,10 @@
 // bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulation) with register-blocked waves - the round-3 replacement of
 // gconv.hip's k_gconv for the two bf16 arithmetic modes:
 //   SED_DTYPE_BF16    (X3 = 0)  operands rounded to bf16 (RNE); activations are STORED as bf16 in HBM
+//   SED_DTYPE_F16     (X3 = 2)  FORWARD only: activations and the weight panel are fp16 in HBM, v_mfma_f32_32x32x16_f16, the
+//                               output is stored as fp16 (for the next forward operator; its bf16 copy for the backward kernels
+//                               of the bf16 family is written by k_bglu_fwd, which has the tile staged anyway - a second store
+//                               stream here cost 27 - 85 spilled registers); the dgrad of this mode is X3 = 0's
 //   SED_DTYPE_BF16X3  (X3 = 1)  split operands: a = a_hi + a_lo, b = b_hi + b_lo (both halves bf16),
 //                               a b ~= a_hi b_hi + a_hi b_lo + a_lo b_hi - three MFMAs per K = 16 (96 cycles against 512 for the
 //                               exact-fp32 MFMA), products exact, relative error ~2^-16 per product; fp32 storage
@@ -31,6 +35,7 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4b;
 
 template <int X3> struct BStore { using T = __bf16; };
 template <> struct BStore<1> { using T = float; };
+template <> struct BStore<2> { using T = _Float16; };
 
 // hi / lo split of 8 consecutive fp32 values into two bf16x8 vectors (RNE both times: v - hi is exact in fp32)
 __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
@@ -55,8 +60,9 @@ SED_TS_DEFINE(bconv)
 // ---- geometry of one instantiation ---------------------------------------------------------------------------------------
 //   TW  image width = tile width (16 or 4)          TH  tile height (rows)
 //   WM x WN waves: wave (wm, wn) owns pixels [wm * PXW, +PXW) of the tile (row-major) and channels [wn * CHW, +CHW)
-template <int X3, int C, int TW, int TH, int WM, int WN>
+template <int X3_, int C, int TW, int TH, int WM, int WN>
 struct BConvCfg {
+    static constexpr int X3 = (X3_ == 1) ? 1 : 0;                         // (the fp16 forward has the bf16 mode's geometry)
     static constexpr int NW = WM * WN, NT = 64 * NW;
     static constexpr int M = TH * TW, PXW = M / WM, CHW = C / WN, MB = PXW / 32, NB = CHW / 32;
     static constexpr int HW = TW + 2, HH = TH + 2;
@@ -91,13 +97,17 @@ struct BConvCfg {
 // DIR 1: dgrad     out[p][ci] = sum dy[p - tap][co] W[co][ci][tap], dy = ca * dz + cb * y + cc inside the image
 //                  (wpk then holds the flipped / transposed panel, so the kernel body is the same correlation)
 //   wpk: [plane (hi | lo)][n][9 C] bf16, k = tap * C + c contiguous (k_gen_pack)
-template <int X3, int C, int TW, int TH, int WM, int WN, int DIR>
+template <int X3_, int C, int TW, int TH, int WM, int WN, int DIR>
 __global__ __launch_bounds__(64 * WM * WN) void k_bconv(const void* __restrict__ in0_v, const void* __restrict__ in1_v,
                                                           const float* __restrict__ coef, const __bf16* __restrict__ wpk,
                                                           const float* __restrict__ bias, void* __restrict__ out_v,
-                                                          double* __restrict__ stat, int H, int tiles_per_clip, int n_tiles) {
-    using Cfg = BConvCfg<X3, C, TW, TH, WM, WN>;
-    using S = typename BStore<X3>::T;
+                                                          double* __restrict__ stat, int H, int tiles_per_clip, int n_tiles,
+                                                          __bf16* __restrict__ out2) {
+    using Cfg = BConvCfg<X3_, C, TW, TH, WM, WN>;
+    using S = typename BStore<X3_>::T;
+    constexpr int X3 = (X3_ == 1) ? 1 : 0;
+    constexpr int F16 = (X3_ == 2) ? 1 : 0;
+    static_assert(!(F16 && DIR == 1), "the fp16 flavour is forward only");
     constexpr int NT = Cfg::NT, MB = Cfg::MB, NB = Cfg::NB, HH = Cfg::HH, PS = Cfg::PS, RP = Cfg::RP;
     constexpr int KC = Cfg::KC, BROW = Cfg::BROW, BBUF = Cfg::BBUF, PL = Cfg::PLANES, HPL = Cfg::HALO_PLANE;
     constexpr int K = 9 * C, NCH = K / KC, CPT = C / KC;                  // chunks per tap
@@ -317,6 +327,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bconv(const void* __restrict__
                             acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb][PL - 1], bf[nb][0], acc[mb][nb], 0, 0, 0);
                             acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb][0], bf[nb][PL - 1], acc[mb][nb], 0, 0, 0);
                         }
+                        if constexpr (F16)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[mb][0]), __builtin_bit_cast(f16x8, bf[nb][0]), acc[mb][nb], 0, 0, 0);
+                        else
                         acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb][0], bf[nb][0], acc[mb][nb], 0, 0, 0);
                     }
             }
@@ -381,7 +394,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bconv(const void* __restrict__
 
 template <int X3, int C, int TW, int TH, int WM, int WN, int DIR>
 static int bconv_launch(const void* in0, const void* in1, const float* coef, const void* wpk, const float* bias, void* out,
-                        double* stat, int B, int H, hipStream_t st) {
+                        double* stat, int B, int H, hipStream_t st, void* out2 = nullptr) {
     using Cfg = BConvCfg<X3, C, TW, TH, WM, WN>;
     static thread_local SedAttrOnce attr_done;
     if (attr_done.need()) {
@@ -391,27 +404,33 @@ static int bconv_launch(const void* in0, const void* in1, const float* coef, con
     SED_CHECK_ARG((size_t)B * H * TW * C < ((size_t)1 << 31), "bconv: image too large for 32-bit offsets");
     const int tpc = (H + TH - 1) / TH, nt = B * tpc;
     const int grid = nt < 256 ? nt : 256;
-    k_bconv<X3, C, TW, TH, WM, WN, DIR><<<grid, Cfg::NT, Cfg::LDS_BYTES, st>>>(in0, in1, coef, (const __bf16*)wpk, bias, out, stat, H, tpc, nt);
+    k_bconv<X3, C, TW, TH, WM, WN, DIR><<<grid, Cfg::NT, Cfg::LDS_BYTES, st>>>(in0, in1, coef, (const __bf16*)wpk, bias, out, stat, H, tpc, nt, (__bf16*)out2);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
 
 template <int DIR>
 static int bconv_dispatch(int x3, int C, int W, const void* in0, const void* in1, const float* coef, const void* wpk,
-                          const float* bias, void* out, double* stat, int B, int H, hipStream_t st) {
+                          const float* bias, void* out, double* stat, int B, int H, hipStream_t st, void* out2 = nullptr) {
     //            X3  C    TW  TH  WM WN
 #define BCONV_CASE(XX, CC, WW, HH, MM, NN) \
     if (x3 == XX && C == CC && W == WW) return bconv_launch<XX, CC, WW, HH, MM, NN, DIR>(in0, in1, coef, wpk, bias, out, stat, B, H, st)
     BCONV_CASE(0, 128, 16, 16, 4, 2); BCONV_CASE(0, 64, 16, 32, 8, 1); BCONV_CASE(0, 128, 4, 16, 2, 4); BCONV_CASE(0, 64, 4, 16, 2, 2);
     BCONV_CASE(1, 128, 16, 8, 2, 4);  BCONV_CASE(1, 64, 16, 16, 4, 2); BCONV_CASE(1, 128, 4, 16, 2, 4); BCONV_CASE(1, 64, 4, 16, 2, 2);
 #undef BCONV_CASE
+    if constexpr (DIR == 0) {
+#define BCONV_CASE(XX, CC, WW, HH, MM, NN) \
+    if (x3 == XX && C == CC && W == WW) return bconv_launch<XX, CC, WW, HH, MM, NN, DIR>(in0, in1, coef, wpk, bias, out, stat, B, H, st, out2)
+        BCONV_CASE(2, 128, 16, 16, 4, 2); BCONV_CASE(2, 64, 16, 32, 8, 1); BCONV_CASE(2, 128, 4, 16, 2, 4); BCONV_CASE(2, 64, 4, 16, 2, 2);
+#undef BCONV_CASE
+    }
     sed_set_error("bconv: unsupported x3 %d / channels %d / width %d", x3, C, W);
     return SED_ERR_UNSUPPORTED;
 }
 
 int launch_bconv_fwd(int x3, int C, const void* in, const void* wpk, const float* bias, void* y, double* stat, int B, int H, int W,
-                     hipStream_t st) {
-    return bconv_dispatch<0>(x3, C, W, in, nullptr, nullptr, wpk, bias, y, stat, B, H, st);
+                     hipStream_t st, void* y_bf16_copy) {
+    return bconv_dispatch<0>(x3, C, W, in, nullptr, nullptr, wpk, bias, y, stat, B, H, st, y_bf16_copy);
 }
 int launch_bconv_dgrad(int x3, int C, const void* dz, const void* yin, const float* coef, const void* wpkT, void* dx, int B, int H,
                        int W, hipStream_t st) {

@@ -56,10 +56,13 @@ struct BGluCfg {
 
 // this wave's B fragments of the folded weights (rows 32 cb + n of W'), its folded bias and the gate's scale / shift
 //   aff: LDS [2][C] = scale (gamma * invstd) | shift (beta - mean * scale) of the BatchNorm affine
-template <int C, int X3 = 0>
+// F16 (SED_DTYPE_F16): bw holds fp16 bit patterns (the forward's operand type); bw16 - if given - the bf16 rounding of the same
+// W' for the backward kernel (wfold_out)
+template <int C, int X3 = 0, int F16 = 0>
 __device__ __forceinline__ void bglu_fold(const float* __restrict__ wglu, const float* __restrict__ bglu, const float* aff, int cb,
                                           int lane, bf16x8 (&bw)[C / 16], float& b_fold, float& sc, float& sh,
-                                          bf16x8 (*bl)[C / 16] = nullptr /* X3: the lo parts of W' */) {
+                                          bf16x8 (*bl)[C / 16] = nullptr /* X3: the lo parts of W' */,
+                                          bf16x8 (*bw16)[C / 16] = nullptr) {
     const int n = lane & 31, kh = lane >> 5, co = 32 * cb + n;
     float part = 0.f;
 #pragma unroll
@@ -70,6 +73,10 @@ __device__ __forceinline__ void bglu_fold(const float* __restrict__ wglu, const 
         for (int e = 0; e < 8; ++e) {
             const float w = e < 4 ? w0[e] : w1[e - 4];
             const float wf = w * aff[k0 + e];
+            if constexpr (F16 != 0) {
+                bw[ks][e] = __builtin_bit_cast(__bf16, (_Float16)wf);
+                (*bw16)[ks][e] = (__bf16)wf;
+            } else
             bw[ks][e] = (__bf16)wf;
             if constexpr (X3 != 0) (*bl)[ks][e] = (__bf16)(wf - (float)bw[ks][e]);
             part = fmaf(w, aff[C + k0 + e], part);
@@ -80,12 +87,17 @@ __device__ __forceinline__ void bglu_fold(const float* __restrict__ wglu, const 
     sh = aff[C + co];
 }
 // identity fragments: B[k][j] = (k == j) for the two k-steps that cover a 32-channel block
+template <int F16 = 0>
 __device__ __forceinline__ void bglu_identity(int lane, bf16x8 (&idf)[2]) {
     const int n = lane & 31, kh = lane >> 5;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) idf[s][e] = (__bf16)((16 * s + 8 * kh + e) == n ? 1.0f : 0.0f);
+        for (int e = 0; e < 8; ++e) {
+            const float v = (16 * s + 8 * kh + e) == n ? 1.0f : 0.0f;
+            if constexpr (F16 != 0) idf[s][e] = __builtin_bit_cast(__bf16, (_Float16)v);
+            else idf[s][e] = (__bf16)v;
+        }
 }
 
 // 16-byte staging items of a round: (row block rl, pixel m, channel group j); 512 per round = 2 per thread
@@ -99,14 +111,22 @@ __device__ __forceinline__ void bglu_item(int g, int& rl, int& m, int& j) {
 // X3 (SED_DTYPE_BF16X3): y is fp32 in HBM and split hi + lo on its way into LDS (two tile planes); lin = y_hi W'_hi + y_hi W'_lo +
 // y_lo W'_hi, the gate's y = (y_hi + y_lo) I - three / four MFMAs where the bf16 mode has one / two, fp32 output.  Replaces
 // gglu.hip's exact-fp32 kernel in that mode (88 us per launch at C = 128: weights streamed through LDS with a barrier per chunk).
-template <int C, int PB, int X3 = 0>
+// F16 (SED_DTYPE_F16): y arrives as fp16, W' and the identity are fp16 fragments, v_mfma_f32_32x32x16_f16; the pooled output of
+// block 1 (PB) is stored as fp16 in p and - for the backward kernels of the bf16 family - as bf16 in p_b16 (may be null); y_b16
+// (may be null) receives the bf16 copy of the INPUT tile y on its way into LDS (the convolution that produced it stores fp16 only)
+template <int C, int PB, int X3 = 0, int F16 = 0>
 __global__ __launch_bounds__(256) void k_bglu_fwd(const void* __restrict__ y_v, GBnArgs bnp, const float* __restrict__ wglu,
                                                    const float* __restrict__ bglu, void* __restrict__ p_v, int H, int W, int Ho,
                                                    int Wo, int Q, int block_id, int use_drop, float p_drop,
                                                    const uint64_t* __restrict__ seed_ptr, uint16_t* __restrict__ mask_out,
-                                                   __bf16* __restrict__ wfold_out, float* __restrict__ bfold_out) {
+                                                   __bf16* __restrict__ wfold_out, float* __restrict__ bfold_out,
+                                                   __bf16* __restrict__ p_b16, __bf16* __restrict__ y_b16) {
     using Cfg = BGluCfg<C>;
-    using PT = typename Stor<PB>::T;
+    using PT = typename std::conditional<(F16 != 0 && PB != 0), _Float16, typename Stor<PB>::T>::type;
+    auto mma = [](bf16x8 a, bf16x8 b, f32x16 c) -> f32x16 {
+        if constexpr (F16 != 0) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    };
     constexpr int NB = Cfg::NB, KS = Cfg::KS, RPR = Cfg::RPR, PS = Cfg::PS, TILE = Cfg::TILE;
     constexpr int NPL = X3 ? 2 : 1;                                     // tile planes (hi | lo)
     __shared__ __attribute__((aligned(16))) unsigned char tile[2][NPL][RPR][TILE];
@@ -125,14 +145,24 @@ __global__ __launch_bounds__(256) void k_bglu_fwd(const void* __restrict__ y_v, 
     __syncthreads();
     bf16x8 bw[KS], bl[X3 ? KS : 1], idf[2];
     float b_fold, sc, sh;
+    const bool publish = !X3 && wfold_out != nullptr && blockIdx.x == 0 && rl == 0;
     if constexpr (X3 != 0) bglu_fold<C, 1>(wglu, bglu, aff, cb, lane, bw, b_fold, sc, sh, &bl);
-    else bglu_fold<C>(wglu, bglu, aff, cb, lane, bw, b_fold, sc, sh);
-    bglu_identity(lane, idf);
-    if (!X3 && wfold_out != nullptr && blockIdx.x == 0 && rl == 0) {
+    else if constexpr (F16 != 0) {
+        bf16x8 bw16[KS];
+        bglu_fold<C, 0, 1>(wglu, bglu, aff, cb, lane, bw, b_fold, sc, sh, nullptr, &bw16);
+        if (publish) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) *(bf16x8*)(wfold_out + (size_t)(32 * cb + n) * C + 16 * ks + 8 * kh) = bw16[ks];
+        }
+    } else bglu_fold<C>(wglu, bglu, aff, cb, lane, bw, b_fold, sc, sh);
+    bglu_identity<F16>(lane, idf);
+    if (publish) {
         // workgroup 0 publishes the folded weights W' [C][C] (bf16) and bias b' [C] for the backward kernel, which then
         // starts from two 16-byte-vector copies instead of redoing the fold in every workgroup
+        if constexpr (F16 == 0) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) *(bf16x8*)(wfold_out + (size_t)(32 * cb + n) * C + 16 * ks + 8 * kh) = bw[ks];
+            for (int ks = 0; ks < KS; ++ks) *(bf16x8*)(wfold_out + (size_t)(32 * cb + n) * C + 16 * ks + 8 * kh) = bw[ks];
+        }
         if (kh == 0) bfold_out[32 * cb + n] = b_fold;
     }
     sc *= SED_NEG_LOG2E; sh *= SED_NEG_LOG2E;                           // sigmoid(z) = 1 / (1 + exp2(-log2(e) z))
@@ -176,11 +206,32 @@ __global__ __launch_bounds__(256) void k_bglu_fwd(const void* __restrict__ y_v, 
             }
         }
     };
+    // F16: the bf16 copy of the items this thread just loaded (same addresses as the load; items past the end are skipped)
+    auto copy_y = [&](int round) {
+        if constexpr (F16 != 0) {
+            if (y_b16 == nullptr) return;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int r2, m, j;
+                bglu_item<C>(tid + 256 * i, r2, m, j);
+                const int rb = round * RPR + r2, q = rb * 4 + (m >> 3);
+                if (round < n_round && q < Q) {
+                    const int pix = gen_rb_pixel(q, (m >> 2) & 1, m & 3, H, W, Ho, Wo);
+                    const f16x8 h = __builtin_bit_cast(f16x8, st[i][0]);
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (__bf16)(float)h[e];
+                    *(bf16x8*)(y_b16 + (size_t)pix * C + 8 * j) = o;
+                }
+            }
+        }
+    };
     load(blockIdx.x);
     int it = 0;
     for (int round = blockIdx.x; round < n_round; round += gridDim.x, ++it) {
         const int buf = it & 1;
         store(buf);
+        copy_y(round);
         lds_barrier();                                                   // (LDS-only: the pooled stores of the previous round stay in flight)
         load(round + gridDim.x);                                         // flies during this round's MFMAs and epilogue
         const int rb = round * RPR + rl, q0 = rb * 4;
@@ -192,18 +243,18 @@ __global__ __launch_bounds__(256) void k_bglu_fwd(const void* __restrict__ y_v, 
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 a = *(const bf16x8*)(tp + 32 * ks);
-                lin = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[ks], lin, 0, 0, 0);
+                lin = mma(a, bw[ks], lin);
                 if constexpr (X3 != 0) {
-                    lin = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bl[ks], lin, 0, 0, 0);
-                    lin = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(tp + RPR * TILE + 32 * ks), bw[ks], lin, 0, 0, 0);
+                    lin = mma(a, bl[ks], lin);
+                    lin = mma(*(const bf16x8*)(tp + RPR * TILE + 32 * ks), bw[ks], lin);
                 }
             }
             // y[pixel][this wave's channels] in the accumulator layout: the two k-steps of the block against the identity
-            yid = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(tp + 64 * cb), idf[0], yid, 0, 0, 0);
-            yid = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(tp + 64 * cb + 32), idf[1], yid, 0, 0, 0);
+            yid = mma(*(const bf16x8*)(tp + 64 * cb), idf[0], yid);
+            yid = mma(*(const bf16x8*)(tp + 64 * cb + 32), idf[1], yid);
             if constexpr (X3 != 0) {
-                yid = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(tp + RPR * TILE + 64 * cb), idf[0], yid, 0, 0, 0);
-                yid = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(tp + RPR * TILE + 64 * cb + 32), idf[1], yid, 0, 0, 0);
+                yid = mma(*(const bf16x8*)(tp + RPR * TILE + 64 * cb), idf[0], yid);
+                yid = mma(*(const bf16x8*)(tp + RPR * TILE + 64 * cb + 32), idf[1], yid);
             }
             const int c = 32 * cb + n;
             uint32_t m16 = 0xffffu;
@@ -222,25 +273,37 @@ __global__ __launch_bounds__(256) void k_bglu_fwd(const void* __restrict__ y_v, 
             const int j0 = 2 * kh;
             if (q0 + j0 < Q) st1(p + (size_t)(q0 + j0) * C + c, (kh ? pooled[2] : pooled[0]) * scp);
             if (q0 + j0 + 1 < Q) st1(p + (size_t)(q0 + j0 + 1) * C + c, (kh ? pooled[3] : pooled[1]) * scp);
+            if constexpr (F16 != 0 && PB != 0) {
+                if (p_b16) {
+                    if (q0 + j0 < Q) st1(p_b16 + (size_t)(q0 + j0) * C + c, (kh ? pooled[2] : pooled[0]) * scp);
+                    if (q0 + j0 + 1 < Q) st1(p_b16 + (size_t)(q0 + j0 + 1) * C + c, (kh ? pooled[3] : pooled[1]) * scp);
+                }
+            }
         }
     }
 }
 
-template <int C, int PB, int X3 = 0>
+template <int C, int PB, int X3 = 0, int F16 = 0>
 static int bglu_fwd_launch(const void* y, const GBnArgs& bn, const float* wglu, const float* bglu, void* p, int B, int H, int W,
                            int block_id, int use_drop, float p_drop, const uint64_t* seed, uint16_t* mask_out, void* wfold_out,
-                           float* bfold_out, hipStream_t st) {
+                           float* bfold_out, hipStream_t st, void* p_b16 = nullptr, void* y_b16 = nullptr) {
     const int Ho = H / 2, Wo = W / 4, Q = B * Ho * Wo, n_rb = (Q + 3) / 4, n_round = (n_rb + BGluCfg<C>::RPR - 1) / BGluCfg<C>::RPR;
     const int grid = n_round < 512 ? n_round : 512;          // two workgroups per CU: each pays the fold of its weights once
-    k_bglu_fwd<C, PB, X3><<<grid, 256, 0, st>>>(y, bn, wglu, bglu, p, H, W, Ho, Wo, Q, block_id, use_drop, p_drop, seed, mask_out,
-                                               (__bf16*)wfold_out, bfold_out);
+    k_bglu_fwd<C, PB, X3, F16><<<grid, 256, 0, st>>>(y, bn, wglu, bglu, p, H, W, Ho, Wo, Q, block_id, use_drop, p_drop, seed, mask_out,
+                                                    (__bf16*)wfold_out, bfold_out, (__bf16*)p_b16, (__bf16*)y_b16);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
 
 int launch_bglu_fwd(int C, const void* y, const GBnArgs& bn, const float* wglu, const float* bglu, void* p, int p_bf16, int B, int H,
                     int W, int block_id, int use_drop, float p_drop, const uint64_t* seed, uint16_t* mask_out, void* wfold_out,
-                    float* bfold_out, hipStream_t st) {
+                    float* bfold_out, hipStream_t st, int f16, void* p_b16, void* y_b16) {
+    if (f16) {      // SED_DTYPE_F16: y is fp16; p (block 1) fp16 + its bf16 copy p_b16; block 2's p stays fp32
+#define BGLU_CASE(CC, PP) \
+    if (C == CC && p_bf16 == PP) return bglu_fwd_launch<CC, PP, 0, 1>(y, bn, wglu, bglu, p, B, H, W, block_id, use_drop, p_drop, seed, mask_out, wfold_out, bfold_out, st, p_b16, y_b16)
+        BGLU_CASE(64, 0); BGLU_CASE(64, 1); BGLU_CASE(128, 0); BGLU_CASE(128, 1);
+#undef BGLU_CASE
+    }
 #define BGLU_CASE(CC, PP) \
     if (C == CC && p_bf16 == PP) return bglu_fwd_launch<CC, PP>(y, bn, wglu, bglu, p, B, H, W, block_id, use_drop, p_drop, seed, mask_out, wfold_out, bfold_out, st)
     BGLU_CASE(64, 0); BGLU_CASE(64, 1); BGLU_CASE(128, 0); BGLU_CASE(128, 1);

@@ -15,6 +15,7 @@
 // from the 9+45 first/second moments of the patch (k_x_moments), and backward reduces to the
 // sums D = dlin^T P, E = dzgate^T P (two 64x10 matrices) from which k_blk0_bwd_finalize derives
 // every parameter gradient of the block in fp64.
+#include <type_traits>
 #include "common.h"
 #include "philox.h"
 #include "kernels.h"
@@ -267,6 +268,14 @@ template <int NH>
 struct Blk0W<NH, 2> {
     blk0_bf16x8 bw[2 * NH], bl[2 * NH];
 };
+// MODE 3 (SED_DTYPE_F16, forward only): MODE 1 with fp16 operands (v_mfma_f32_32x32x16_f16; the registers hold fp16 bit patterns)
+// and the pooled output stored as fp16 + a bf16 copy for the backward (which is MODE 1's)
+template <int NH>
+struct Blk0W<NH, 3> {
+    blk0_bf16x8 bw[2 * NH];
+};
+typedef __attribute__((ext_vector_type(8))) _Float16 blk0_f16x8;
+__device__ __forceinline__ __bf16 blk0_h16(float v) { return __builtin_bit_cast(__bf16, (_Float16)v); }
 template <int NH, int MODE>
 __device__ __forceinline__ void blk0_load_w(Blk0W<NH, MODE>& W, const float* __restrict__ wz, const float* __restrict__ wl, int lane) {
     const int n = lane & 31, kh = lane >> 5;
@@ -290,8 +299,8 @@ __device__ __forceinline__ void blk0_load_w(Blk0W<NH, MODE>& W, const float* __r
                 const int k = 8 * kh + i, kc = k < 10 ? k : 0;
                 const float l = wl[(32 * h + n) * 12 + kc], z = wz[(32 * h + n) * 12 + kc] * SED_NEG_LOG2E;
                 const float lv = k < 10 ? l : 0.f, zv = k < 10 ? z : 0.f;
-                W.bw[h][i] = (__bf16)lv;
-                W.bw[NH + h][i] = (__bf16)zv;
+                W.bw[h][i] = MODE == 3 ? blk0_h16(lv) : (__bf16)lv;
+                W.bw[NH + h][i] = MODE == 3 ? blk0_h16(zv) : (__bf16)zv;
                 if constexpr (MODE == 2) {
                     W.bl[h][i] = (__bf16)(lv - (float)W.bw[h][i]);
                     W.bl[NH + h][i] = (__bf16)(zv - (float)W.bw[NH + h][i]);
@@ -304,6 +313,7 @@ template <int MODE> struct Blk0A;
 template <> struct Blk0A<0> { float v[5]; };           // taps 2 s + kh
 template <> struct Blk0A<1> { blk0_bf16x8 v; };        // taps 8 kh + 0..7 (tap 9 = the constant 1, taps >= 10 zero)
 template <> struct Blk0A<2> { blk0_bf16x8 v, lo; };    // the same taps, hi and lo parts
+template <> struct Blk0A<3> { blk0_bf16x8 v; };        // the same taps as fp16 bit patterns
 template <int MODE>
 __device__ __forceinline__ void blk0_load_a(Blk0A<MODE>& A, const float* xb, int base, int kh) {
     if constexpr (MODE == 0) {
@@ -321,7 +331,7 @@ __device__ __forceinline__ void blk0_load_a(Blk0A<MODE>& A, const float* xb, int
         for (int i = 2; i < 8; ++i) t[i] = kh ? 0.f : xb[base + (i / 3) * XS_W + (i % 3)];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            A.v[i] = (__bf16)t[i];
+            A.v[i] = MODE == 3 ? blk0_h16(t[i]) : (__bf16)t[i];
             if constexpr (MODE == 2) A.lo[i] = (__bf16)(t[i] - (float)A.v[i]);
         }
     }
@@ -336,6 +346,9 @@ __device__ __forceinline__ void blk0_mma(const Blk0A<MODE>& A, const Blk0W<NH, M
             al = mfma32(A.v[s5], W.bw[s5][h], al);
             az = mfma32(A.v[s5], W.bw[s5][NH + h], az);
         }
+    } else if constexpr (MODE == 3) {
+        al = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(blk0_f16x8, A.v), __builtin_bit_cast(blk0_f16x8, W.bw[h]), al, 0, 0, 0);
+        az = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(blk0_f16x8, A.v), __builtin_bit_cast(blk0_f16x8, W.bw[NH + h]), az, 0, 0, 0);
     } else {
         al = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, W.bw[h], al, 0, 0, 0);
         az = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, W.bw[NH + h], az, 0, 0, 0);
@@ -378,7 +391,8 @@ template <int NH, int DROP, bool SAVE, int MODE>
 __global__ __launch_bounds__(256, (NH == 2 ? 3 : 2)) void k_blk0_fwd(const float* __restrict__ x, const float* __restrict__ wz,
                                                    const float* __restrict__ wl, float* __restrict__ p0, int B, int T,
                                                    int H1, int tiles_per_clip, int n_tiles, float p_drop,
-                                                   const uint64_t* __restrict__ seed_ptr, uint16_t* __restrict__ mask_out) {
+                                                   const uint64_t* __restrict__ seed_ptr, uint16_t* __restrict__ mask_out,
+                                                   void* __restrict__ p0_b16 /* MODE 3: bf16 copy of the output, may be null */) {
     __shared__ float xs[2][FXS_H * XS_W];
     constexpr int C = 32 * NH;
     constexpr int NT = 2 * NH;                       // MFMA tiles of a wave: (row block g0 + {0, 1}, channel slice h)
@@ -482,9 +496,15 @@ __global__ __launch_bounds__(256, (NH == 2 ? 3 : 2)) void k_blk0_fwd(const float
 #endif
                 {
                     // (MODE 1 = SED_DTYPE_BF16: the pooled output is stored as bf16, gen.h)
-                    using PT = typename Stor<MODE == 1>::T;
+                    using PT = typename std::conditional<MODE == 3, _Float16, typename Stor<MODE == 1>::T>::type;
                     st1((PT*)p0 + (size_t)(q0 + j0) * C + c, (kh ? pooled[2] : pooled[0]) * sc);
                     st1((PT*)p0 + (size_t)(q0 + j0 + 1) * C + c, (kh ? pooled[3] : pooled[1]) * sc);
+                    if constexpr (MODE == 3) {
+                        if (p0_b16) {
+                            st1((__bf16*)p0_b16 + (size_t)(q0 + j0) * C + c, (kh ? pooled[2] : pooled[0]) * sc);
+                            st1((__bf16*)p0_b16 + (size_t)(q0 + j0 + 1) * C + c, (kh ? pooled[3] : pooled[1]) * sc);
+                        }
+                    }
                 }
             };
             load_av(g0);
@@ -874,7 +894,7 @@ int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const flo
                         const float* beta, const float* wglu, const float* bglu, float* run_mean, float* run_var,
                         int64_t* tracked, int train, int update, const uint64_t* seed, double* mom, double* mompart,
                         float* wz, float* wl, float* bn, float* p0, uint16_t* mask_out, const ConvPackArgs* pack, hipStream_t st,
-                        int main_kernel_only, const GenAuxPack* aux) {
+                        int main_kernel_only, const GenAuxPack* aux, void* p0_b16) {
     // main_kernel_only (sed_kernel_replay): the folded weights of the last real forward are still in wz / wl
     if (train && !main_kernel_only) {
         const int rc = launch_x_moments(g, x, mompart, pack, st, aux);
@@ -902,10 +922,11 @@ int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const flo
         return (nt + rounds - 1) / rounds;
     };
 #define BLK0_FWD_M(NH, DROP, SAVE, MODE) \
-    k_blk0_fwd<NH, DROP, SAVE, MODE><<<grid_for((const void*)k_blk0_fwd<NH, DROP, SAVE, MODE>), 256, 0, st>>>(x, wz, wl, p0, g.B, g.T, g.H1, tpc, nt, g.p, seed, mask_out)
+    k_blk0_fwd<NH, DROP, SAVE, MODE><<<grid_for((const void*)k_blk0_fwd<NH, DROP, SAVE, MODE>), 256, 0, st>>>(x, wz, wl, p0, g.B, g.T, g.H1, tpc, nt, g.p, seed, mask_out, p0_b16)
 #define BLK0_FWD(NH, DROP, SAVE)                          \
     do {                                                  \
-        if (g.mode == 1) BLK0_FWD_M(NH, DROP, SAVE, 1);   \
+        if (g.f16) BLK0_FWD_M(NH, DROP, SAVE, 3);         \
+        else if (g.mode == 1) BLK0_FWD_M(NH, DROP, SAVE, 1);   \
         else if (g.mode == 2) BLK0_FWD_M(NH, DROP, SAVE, 2);   \
         else BLK0_FWD_M(NH, DROP, SAVE, 0);               \
     } while (0)

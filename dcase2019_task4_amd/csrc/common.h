@@ -56,7 +56,9 @@ struct SedAttrOnce {
 // ---- geometry ------------------------------------------------------------------------------
 struct Geo {
     int B, T, F, C, H, NC, L;
-    int mode;     // SED_DTYPE_F32 / SED_DTYPE_BF16 (MFMA operand type of the generic kernel set)
+    int mode;     // SED_DTYPE_F32 / SED_DTYPE_BF16 / SED_DTYPE_BF16X3: the arithmetic FAMILY of the generic kernel set.
+                  // SED_DTYPE_F16 runs in the BF16 family (bf16 backward, bf16 copies of the activations) with f16 set:
+    bool f16;     // the forward chain's operands and hand-over activations are fp16 (SED_DTYPE_F16)
     bool generic; // anything but C = 64, H = 64, fp32: served by the generic kernel set (gen.h)
     int H1, W1;   // after block 0 pooling: T/2 x 16
     int H2, W2;   // after block 1 pooling: H1/2 x 4
@@ -66,7 +68,8 @@ struct Geo {
 static inline Geo make_geo(const sed_dims* d) {
     Geo g;
     g.B = d->B; g.T = d->T; g.F = d->F; g.C = d->C; g.H = d->H; g.NC = d->nclass; g.L = d->n_layers_rnn;
-    g.mode = d->dtype;
+    g.f16 = d->dtype == SED_DTYPE_F16;
+    g.mode = g.f16 ? SED_DTYPE_BF16 : d->dtype;
     g.generic = !(d->C == 64 && d->H == 64 && d->dtype == SED_DTYPE_F32);
     g.H1 = g.T / 2; g.W1 = g.F / 4;
     g.H2 = g.H1 / 2; g.W2 = g.W1 / 4;

@@ -29,8 +29,8 @@ extern "C" int sed_debug_set(int flags) { const int old = g_sed_debug; g_sed_deb
 int sed_validate_dims(const sed_dims* d) {
     SED_CHECK_ARG(d != nullptr, "null dims");
     if (d->F != 64 || (d->C != 64 && d->C != 128) || (d->H != 64 && d->H != 256) ||
-        (d->dtype != SED_DTYPE_F32 && d->dtype != SED_DTYPE_BF16 && d->dtype != SED_DTYPE_BF16X3)) {
-        sed_set_error("supported: F = 64, C in {64, 128}, H in {64, 256}, dtype in {f32, bf16, bf16x3} (got F=%d C=%d H=%d dtype=%d)",
+        (d->dtype != SED_DTYPE_F32 && d->dtype != SED_DTYPE_BF16 && d->dtype != SED_DTYPE_BF16X3 && d->dtype != SED_DTYPE_F16)) {
+        sed_set_error("supported: F = 64, C in {64, 128}, H in {64, 256}, dtype in {f32, bf16, bf16x3, f16} (got F=%d C=%d H=%d dtype=%d)",
                       d->F, d->C, d->H, d->dtype);
         return SED_ERR_UNSUPPORTED;
     }

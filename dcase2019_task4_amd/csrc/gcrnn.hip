@@ -29,6 +29,7 @@ struct GCtx {
     size_t acc0, mom0, stat1, stat2;          // fp64: patch moments of block 0 | BatchNorm sums of blocks 1, 2
     size_t wz0, wl0, bn0, mompart, p0;
     size_t wpk[3], wpkT[3], wg[3], wgT[3], bg[3], y[3], bn[3], p[3];      // index 1, 2
+    size_t ph[2], yh[3];                      // SED_DTYPE_F16: the forward chain's fp16 p0, p1 / y1, y2 (p[], y[] are then the bf16 copies the backward reads)
     size_t gi[2], gates[2], out[2], whh[2], whhT[2];
     size_t wihT[2];                           // [nin][6H]: the two W_ih stacked along K and transposed (dX GEMM operand)
     size_t xch[2], epoch[2], err;             // cluster recurrence: exchange granules, launch epochs, spin-timeout flag
@@ -56,6 +57,8 @@ static GCtx make_gctx(const Geo& g) {
         put(L.wpk[i], 9 * C * C * E); put(L.wpkT[i], 9 * C * C * E); put(L.wg[i], C * C * E); put(L.wgT[i], C * C * E);
         put(L.bg[i], C * 4); put(L.y[i], nn[i] * SS); put(L.bn[i], 4 * C * 4); put(L.p[i], np[i] * (i == 2 ? 4 : SS));
     }
+    L.ph[0] = L.ph[1] = 0; L.yh[0] = L.yh[1] = L.yh[2] = 0;
+    if (g.f16) { put(L.ph[0], n0 * 2); put(L.yh[1], n0 * 2); put(L.ph[1], n1 * 2); put(L.yh[2], n1 * 2); }
     const size_t bt = (size_t)g.B * g.T3;
     for (int l = 0; l < 2; ++l) {
         put(L.gi[l], g.H == 64 ? 0 : bt * 6 * H * 4);          // (H = 64: the projection runs inside gru.hip's kernel)
@@ -184,6 +187,7 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
     pk.bg1 = CTXF(L.bg[1]); pk.bg2 = CTXF(L.bg[2]);
     pk.zero = CTXD(L.stat1); pk.n_zero = train ? 4 * C : 0;
     pk.err = nullptr;                         // sticky: never cleared by a forward (sed_crnn_buffers_init does)
+    pk.f16 = g.f16 ? 1 : 0;
     // (The packing is independent of block 0, but forking it onto the helper stream is not an option: a forward that
     // itself runs on a forked stream - the teacher's, next to the student's - would fork a second time inside the same
     // hipGraph capture, and ROCm 7.0's hipStreamEndCapture segfaults on that nested fork.  It stays on the caller's stream.)
@@ -227,12 +231,29 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
     // ---- conv block 0 -------------------------------------------------------------------------------------------------
     SED_TRY(launch_blk0_forward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
                                 params + P.glu_w[0], params + P.glu_b[0], bn_running + 0, bn_running + C, trk[0], train, upd,
-                                seed_dev, CTXD(L.mom0), CTXD(L.mompart), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), CTXF(L.p[0]),
-                                use_drop ? CTXM(L.mask[0]) : nullptr, nullptr, st, 0, aux_pack ? &aux : nullptr));
+                                seed_dev, CTXD(L.mom0), CTXD(L.mompart), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0),
+                                g.f16 ? CTXF(L.ph[0]) : CTXF(L.p[0]),
+                                use_drop ? CTXM(L.mask[0]) : nullptr, nullptr, st, 0, aux_pack ? &aux : nullptr,
+                                (g.f16 && train) ? CTXV(L.p[0]) : nullptr));
     // ---- conv blocks 1, 2 -----------------------------------------------------------------------------------------------
     const size_t so[3] = {0, L.stat1, L.stat2};
     const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};
     for (int i = 1; i <= 2; ++i) {
+        if (g.f16) {
+            // SED_DTYPE_F16: the forward chain runs on the fp16 tensors ph / yh; a training forward also leaves the bf16 copies
+            // y[i] / p[i] that the (bf16-family) backward kernels read
+            SED_TRY(launch_bconv_fwd(2, C, CTXV(L.ph[i - 1]), CTXV(L.wpk[i]), params + P.conv_b[i], CTXV(L.yh[i]),
+                                     train ? CTXD(so[i]) : nullptr, g.B, Hs[i], Wd[i], st));
+            GBnArgs bnf;
+            bnf.stat = CTXD(so[i]); bnf.N = (double)g.B * Hs[i] * Wd[i]; bnf.gamma = params + P.bn_g[i]; bnf.beta = params + P.bn_b[i];
+            bnf.run_mean = bn_running + (2 * i) * C; bnf.run_var = bn_running + (2 * i + 1) * C; bnf.tracked = trk[i];
+            bnf.train = train; bnf.update = upd; bnf.eps = g.eps; bnf.momentum = g.mom; bnf.bn = CTXF(L.bn[i]);
+            SED_TRY(launch_bglu_fwd(C, CTXV(L.yh[i]), bnf, params + P.glu_w[i], params + P.glu_b[i], i == 1 ? CTXV(L.ph[1]) : CTXV(L.p[2]),
+                                    i == 1 ? 1 : 0, g.B, Hs[i], Wd[i], i, use_drop, g.p, seed_dev, use_drop ? CTXM(L.mask[i]) : nullptr,
+                                    train ? CTXV(L.wg[i]) : nullptr, train ? CTXF(L.bg[i]) : nullptr, st, 1,
+                                    (i == 1 && train) ? CTXV(L.p[1]) : nullptr, train ? CTXV(L.y[i]) : nullptr));
+            continue;
+        }
         if (g.mode != SED_DTYPE_F32)      // bf16 (bf16 storage) / bf16x3 (fp32 storage, split operands): bconv.hip
             SED_TRY(launch_bconv_fwd(g.mode == SED_DTYPE_BF16X3, C, CTXV(L.p[i - 1]), CTXV(L.wpk[i]), params + P.conv_b[i], CTXV(L.y[i]),
                                      train ? CTXD(so[i]) : nullptr, g.B, Hs[i], Wd[i], st));
@@ -271,12 +292,12 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
             gb.n_prob = 2;
             for (int dir = 0; dir < 2; ++dir)
                 gb.p[dir] = GntProb{in, nin, params + P.w_ih[l][dir], nin, CTXF(L.gi[l]) + dir * 3 * H, 6 * H, params + P.b_ih[l][dir], BT, 3 * H, nin};
-            SED_TRY(g.mode != SED_DTYPE_F32 ? launch_gnt_gemm_bf16(gb, st, g.mode == SED_DTYPE_BF16X3) : launch_gnt_gemm(gb, st));
+            SED_TRY(g.mode != SED_DTYPE_F32 ? launch_gnt_gemm_bf16(gb, st, g.f16 ? 2 : (g.mode == SED_DTYPE_BF16X3 ? 1 : 0)) : launch_gnt_gemm(gb, st));
             if (rec16) {
                 if (!(aux_pack && l < aux.n_grec))
-                    SED_TRY(launch_grec_pack(params + P.w_hh[l][0], params + P.w_hh[l][1], CTXV(L.whh[l]), train ? CTXV(L.whhT[l]) : nullptr, st));
+                    SED_TRY(launch_grec_pack(params + P.w_hh[l][0], params + P.w_hh[l][1], CTXV(L.whh[l]), train ? CTXV(L.whhT[l]) : nullptr, st, g.f16 ? 1 : 0));
                 SED_TRY(launch_grec_fwd(CTXF(L.gi[l]), CTXV(L.whh[l]), params + P.b_hh[l][0], params + P.b_hh[l][1], CTXF(L.out[l]),
-                                        train ? CTXF(L.gates[l]) : nullptr, g.B, g.T3, st));
+                                        train ? CTXF(L.gates[l]) : nullptr, g.B, g.T3, st, g.f16 ? 1 : 0));
             } else if (cluster)
                 SED_TRY(launch_gclu_fwd(CTXF(L.gi[l]), params + P.w_hh[l][0], params + P.w_hh[l][1], params + P.b_hh[l][0],
                                         params + P.b_hh[l][1], CTXF(L.out[l]), train ? CTXF(L.gates[l]) : nullptr, CTXV(L.xch[l]),

@@ -30,6 +30,26 @@ __device__ __forceinline__ void st1(__bf16* p, float v) { *p = (__bf16)v; }
 template <int BF> struct Stor { using T = float; };
 template <> struct Stor<1> { using T = __bf16; };
 
+// ---- SED_DTYPE_F16: the forward chain's 16-bit flavour.  H16<0> = bf16 (the bf16 mode), H16<1> = fp16. ----------------------
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+__device__ __forceinline__ f32x4 ld4(const _Float16* p) {
+    const f16x4 v = *(const f16x4*)p;
+    return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ float ld1(const _Float16* p) { return (float)*p; }
+__device__ __forceinline__ void st1(_Float16* p, float v) { *p = (_Float16)v; }
+template <int F16> struct H16 {
+    using T = __bf16;
+    using V8 = bf16x8;
+    static __device__ __forceinline__ f32x16 mma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct H16<1> {
+    using T = _Float16;
+    using V8 = f16x8;
+    static __device__ __forceinline__ f32x16 mma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
 template <int MODE> struct MM;
 template <> struct MM<0> {
     using E = float;

@@ -81,8 +81,10 @@ __global__ __launch_bounds__(256) void k_gnt_gemm(GntBatch gb) {
 #define GNB_S (GNB_KC + 8)                 // row stride in bf16 elements: 144 B, an odd multiple of 16 B (conflict-free b128)
 // X3 (SED_DTYPE_BF16X3): both operands split hi + lo into two LDS planes, every k-step is hi hi + hi lo + lo hi (~2^-16 per
 // product) - the projections of the wide BiGRU in the mode that holds 1e-3, in place of the exact-fp32 k_gnt_gemm above.
-template <int X3>
+// X3 = 2 (SED_DTYPE_F16, forward projections): operands rounded to fp16, one v_mfma_f32_32x32x16_f16 per k-step.
+template <int X3_>
 __global__ __launch_bounds__(256) void k_gnt_gemm_bf16(GntBatch gb) {
+    constexpr int X3 = X3_ == 1 ? 1 : 0, F16 = X3_ == 2 ? 1 : 0;
     constexpr int NPL = X3 ? 2 : 1;
     __shared__ __attribute__((aligned(16))) __bf16 As[2][NPL][GNT_T * GNB_S];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[2][NPL][GNT_T * GNB_S];
@@ -112,7 +114,8 @@ __global__ __launch_bounds__(256) void k_gnt_gemm_bf16(GntBatch gb) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const float av = q < 4 ? ra[i][0][q] : ra[i][1][q - 4], bv = q < 4 ? rb[i][0][q] : rb[i][1][q - 4];
-                a[q] = (__bf16)av; b[q] = (__bf16)bv;
+                if constexpr (F16 != 0) { a[q] = __builtin_bit_cast(__bf16, (_Float16)av); b[q] = __builtin_bit_cast(__bf16, (_Float16)bv); }
+                else { a[q] = (__bf16)av; b[q] = (__bf16)bv; }
                 if constexpr (X3 != 0) { al[q] = (__bf16)(av - (float)a[q]); bl[q] = (__bf16)(bv - (float)b[q]); }
             }
             *(bf16x8*)&As[buf][0][row * GNB_S + 8 * k8] = a;
@@ -137,7 +140,8 @@ __global__ __launch_bounds__(256) void k_gnt_gemm_bf16(GntBatch gb) {
 #pragma unroll
         for (int ks = 0; ks < GNB_KC / 16; ++ks) {
             const bf16x8 a = *(const bf16x8*)(ap + 16 * ks), b = *(const bf16x8*)(bp + 16 * ks);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            if constexpr (F16 != 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
             if constexpr (X3 != 0) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, *(const bf16x8*)(bp + GNT_T * GNB_S + 16 * ks), acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(ap + GNT_T * GNB_S + 16 * ks), b, acc, 0, 0, 0);
@@ -167,7 +171,8 @@ int launch_gnt_gemm_bf16(const GntBatch& gb, hipStream_t st, int x3) {
         maxN = q.N > maxN ? q.N : maxN;
     }
     const dim3 grid((maxN + GNT_T - 1) / GNT_T, (maxM + GNT_T - 1) / GNT_T, gb.n_prob);
-    if (x3) k_gnt_gemm_bf16<1><<<grid, 256, 0, st>>>(gb);
+    if (x3 == 2) k_gnt_gemm_bf16<2><<<grid, 256, 0, st>>>(gb);
+    else if (x3) k_gnt_gemm_bf16<1><<<grid, 256, 0, st>>>(gb);
     else k_gnt_gemm_bf16<0><<<grid, 256, 0, st>>>(gb);
     SED_CHECK_LAUNCH();
     return SED_OK;

@@ -12,6 +12,7 @@ struct GenPackArgs {
     float *bg1, *bg2;                           // GLU bias folded with beta [C]
     double* zero; int n_zero;                   // fp64 accumulators to clear
     int* err;                                   // unused (the spin-timeout counter is sticky: cleared by sed_crnn_buffers_init only)
+    int f16;                                    // SED_DTYPE_F16 (mode 1 family): the FORWARD panels wpk1 / wpk2 as fp16; everything else bf16
 };
 int launch_gen_pack(const GenPackArgs& a, int mode, hipStream_t st);
 int launch_gconv_fwd(int mode, int C, const float* in, const void* wpk, const float* bias, float* y, double* stat, int B, int H,
@@ -24,8 +25,10 @@ int launch_gwgrad(int mode, int C, const void* dz, const void* yin, const float*
                   int H, int W, hipStream_t st);
 
 // bconv.hip: register-blocked bf16 convolution (x3 = 0: bf16 storage, single products; x3 = 1: fp32 storage, split operands)
+// x3: 0 bf16 (bf16 storage), 1 split operands (fp32 storage), 2 fp16 forward (SED_DTYPE_F16: fp16 in / panel / out; y_bf16_copy
+// is unused - launch_bglu_fwd writes the bf16 copy)
 int launch_bconv_fwd(int x3, int C, const void* in, const void* wpk, const float* bias, void* y, double* stat, int B, int H, int W,
-                     hipStream_t st);
+                     hipStream_t st, void* y_bf16_copy = nullptr);
 int launch_bconv_dgrad(int x3, int C, const void* dz, const void* yin, const float* coef, const void* wpkT, void* dx, int B, int H,
                        int W, hipStream_t st);
 
@@ -77,7 +80,8 @@ int launch_gclu_bwd(const float* d_out, const float* out, const float* gates, co
 //   wfold_out [C][C] bf16 / bfold_out [C]: the folded weights and bias, published for launch_bglu_bwd (may be null)
 int launch_bglu_fwd(int C, const void* y, const GBnArgs& bn, const float* wglu, const float* bglu, void* p, int p_bf16, int B, int H,
                     int W, int block_id, int use_drop, float p_drop, const uint64_t* seed, uint16_t* mask_out, void* wfold_out,
-                    float* bfold_out, hipStream_t st);
+                    float* bfold_out, hipStream_t st, int f16 = 0 /* SED_DTYPE_F16: fp16 y / p */, void* p_b16 = nullptr /* + bf16 copy of p */,
+                    void* y_b16 = nullptr /* + bf16 copy of the input y */);
 
 int launch_bglu_fwd_x3(int C, const void* y, const GBnArgs& bn, const float* wglu, const float* bglu, void* p, int B, int H, int W,
                        int block_id, int use_drop, float p_drop, const uint64_t* seed, uint16_t* mask_out, hipStream_t st);
@@ -88,9 +92,9 @@ int launch_bglu_bwd(int C, const void* y, const float* bn, const void* wfold, co
                     const uint16_t* mask_in, hipStream_t st, const float* dp2 = nullptr);
 
 // grec.hip: H = 256 recurrence of SED_DTYPE_BF16 - one workgroup per chain, W_hh as bf16 in registers
-int launch_grec_pack(const float* w_hh_f, const float* w_hh_r, void* wp, void* wpT /* may be null */, hipStream_t st);
+int launch_grec_pack(const float* w_hh_f, const float* w_hh_r, void* wp, void* wpT /* may be null */, hipStream_t st, int f16 = 0);
 int launch_grec_fwd(const float* gi, const void* wp, const float* b_hh_f, const float* b_hh_r, float* out, float* gates, int B, int T,
-                    hipStream_t st);
+                    hipStream_t st, int f16 = 0);
 int launch_grec_bwd(const float* d_out, const float* out, const float* gates, const void* wpT, float* dgi, float* dgh, float* hprev,
                     int B, int T, hipStream_t st);
 

@@ -30,7 +30,8 @@ __device__ __forceinline__ void gen_pack_body(const GenPackArgs& a, int i) {
         } else {
             E* wpk = (E*)(layer ? a.wpk2 : a.wpk1);
             E* wpkT = (E*)(layer ? a.wpkT2 : a.wpkT1);
-            wpk[e] = M::cvt(wf);
+            if (MODE == 1 && a.f16) ((_Float16*)wpk)[e] = (_Float16)wf;      // the forward's operand type; the dgrad panel stays bf16
+            else wpk[e] = M::cvt(wf);
             if (wpkT) wpkT[e] = M::cvt(wt);
         }
     }
@@ -80,8 +81,9 @@ __device__ __forceinline__ void gnt_pack_t_body(const float* __restrict__ w0, co
 // W_hh (H = 256) -> bf16 in the order the one-CU recurrence kernels load it (grec.hip): one 8-vector per thread
 //   wp [dir][g][kc][u][8]  = W[g H + u][8 kc + e]          wpT[dir][gc][j][8] = W[8 gc + e][j]
 __host__ __device__ inline int grec_pack_blocks() { return (2 * 3 * 256 * 256 / 8 + 255) / 256; }
+// f16 (SED_DTYPE_F16): the FORWARD layout wp as fp16 (the forward recurrence's operand type); wpT stays bf16
 __device__ __forceinline__ void grec_pack_body(const float* __restrict__ w_f, const float* __restrict__ w_r, __bf16* __restrict__ wp,
-                                               __bf16* __restrict__ wpT, int i) {
+                                               __bf16* __restrict__ wpT, int i, int f16 = 0) {
     constexpr int H = 256;
     const int per_dir = 3 * H * H / 8;
     if (i >= 2 * per_dir) return;
@@ -92,7 +94,7 @@ __device__ __forceinline__ void grec_pack_body(const float* __restrict__ w_f, co
         const float* s = w + (size_t)(g * H + u) * H + 8 * kc;
         bf16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (__bf16)s[e];
+        for (int e = 0; e < 8; ++e) o[e] = f16 ? __builtin_bit_cast(__bf16, (_Float16)s[e]) : (__bf16)s[e];
         *(bf16x8*)(wp + ((size_t)dir * per_dir + v) * 8) = o;
     }
     if (wpT != nullptr) {
@@ -147,7 +149,7 @@ __device__ __forceinline__ void gen_aux_body(const GenAuxPack& a, int pb, int ti
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
         const int nr = l < a.n_grec ? grec_pack_blocks() : 0;
-        if (b < nr) { grec_pack_body(a.rw0[l], a.rw1[l], (__bf16*)a.rwp[l], (__bf16*)a.rwpT[l], b * 256 + tid); return; }
+        if (b < nr) { grec_pack_body(a.rw0[l], a.rw1[l], (__bf16*)a.rwp[l], (__bf16*)a.rwpT[l], b * 256 + tid, a.pk.f16); return; }
         b -= nr;
     }
 }

@@ -32,6 +32,11 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4r;
 __device__ __forceinline__ float dot2(unsigned int a, unsigned int b, float c) {
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
 }
+// the same with fp16 pairs (SED_DTYPE_F16's forward recurrence): v_dot2_f32_f16, fp32 accumulation
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2r;
+__device__ __forceinline__ float dot2h(unsigned int a, unsigned int b, float c) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2r, a), __builtin_bit_cast(f16x2r, b), c, false);
+}
 // sum over the four lanes of a quad: DPP quad_perm [1, 0, 3, 2] then [2, 3, 0, 1]; every lane ends with the same value
 __device__ __forceinline__ float quad_sum(float x) {
     x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));
@@ -44,12 +49,12 @@ __device__ __forceinline__ float tanh_fast(float x) { return 2.0f * rcp_fast(1.0
 //   wp [dir][g][kc][u][8]  = W[g H + u][8 kc + e]          (forward:  16-byte vector (g, kc) of unit u; coalesced over u)
 //   wpT[dir][gc][j][8]     = W[8 gc + e][j]                (backward: 16-byte vector gc of column j; gc < 3H / 8)
 __global__ __launch_bounds__(256) void k_grec_pack(const float* __restrict__ w_f, const float* __restrict__ w_r,
-                                                    __bf16* __restrict__ wp, __bf16* __restrict__ wpT) {
-    grec_pack_body(w_f, w_r, wp, wpT, blockIdx.x * 256 + threadIdx.x);      // (gpack.h: training forwards run it in the moments launch)
+                                                    __bf16* __restrict__ wp, __bf16* __restrict__ wpT, int f16) {
+    grec_pack_body(w_f, w_r, wp, wpT, blockIdx.x * 256 + threadIdx.x, f16);      // (gpack.h: training forwards run it in the moments launch)
 }
-int launch_grec_pack(const float* w_hh_f, const float* w_hh_r, void* wp, void* wpT, hipStream_t st) {
+int launch_grec_pack(const float* w_hh_f, const float* w_hh_r, void* wp, void* wpT, hipStream_t st, int f16) {
     const int n = 2 * 3 * GREC_H * GREC_H / 8;
-    k_grec_pack<<<(n + 255) / 256, 256, 0, st>>>(w_hh_f, w_hh_r, (__bf16*)wp, (__bf16*)wpT);
+    k_grec_pack<<<(n + 255) / 256, 256, 0, st>>>(w_hh_f, w_hh_r, (__bf16*)wp, (__bf16*)wpT, f16);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
@@ -75,6 +80,8 @@ __device__ __forceinline__ void dma16(const float* gsrc_wave, int lane, float* l
 }
 
 // gi: [B*T][2][3H] (input projection incl. b_ih); out [B*T][2H]; gates [B*T][2][4H] (r, z, n, gh_n) or null
+// F16: wp holds fp16 (grec_pack_body f16), the h that enters the mat-vec is rounded to fp16, v_dot2_f32_f16
+template <int F16>
 __global__ __launch_bounds__(GREC_T) void k_grec_fwd(const float* __restrict__ gi, const __bf16* __restrict__ wp,
                                                       const float* __restrict__ b_hh_f, const float* __restrict__ b_hh_r,
                                                       float* __restrict__ out, float* __restrict__ gates, int B, int T) {
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(GREC_T) void k_grec_fwd(const float* __restrict__ g
 #pragma unroll
                     for (int uu = 0; uu < 2; ++uu)
 #pragma unroll
-                        for (int g = 0; g < 3; ++g) a[uu][g] = dot2(wr[uu][g][4 * c + q], hv[q], a[uu][g]);
+                        for (int g = 0; g < 3; ++g) a[uu][g] = F16 ? dot2h(wr[uu][g][4 * c + q], hv[q], a[uu][g]) : dot2(wr[uu][g][4 * c + q], hv[q], a[uu][g]);
             }
 #pragma unroll
             for (int uu = 0; uu < 2; ++uu)
@@ -169,7 +176,8 @@ __global__ __launch_bounds__(GREC_T) void k_grec_fwd(const float* __restrict__ g
             const float h = (1.0f - z) * nn + z * hprev;
             hprev = h;
             if (writer) {
-                ((__bf16*)hs[(s + 1) & 1])[u] = (__bf16)h;
+                if constexpr (F16 != 0) ((_Float16*)hs[(s + 1) & 1])[u] = (_Float16)h;
+                else ((__bf16*)hs[(s + 1) & 1])[u] = (__bf16)h;
                 outs[st][0][u] = r; outs[st][1][u] = z; outs[st][2][u] = nn; outs[st][3][u] = ghn; outs[st][4][u] = h;
             }
             lds_barrier();
@@ -292,8 +300,9 @@ __global__ __launch_bounds__(GREC_T) void k_grec_bwd(const float* __restrict__ d
 }
 
 int launch_grec_fwd(const float* gi, const void* wp, const float* b_hh_f, const float* b_hh_r, float* out, float* gates, int B, int T,
-                    hipStream_t st) {
-    k_grec_fwd<<<2 * B, GREC_T, 0, st>>>(gi, (const __bf16*)wp, b_hh_f, b_hh_r, out, gates, B, T);
+                    hipStream_t st, int f16) {
+    if (f16) k_grec_fwd<1><<<2 * B, GREC_T, 0, st>>>(gi, (const __bf16*)wp, b_hh_f, b_hh_r, out, gates, B, T);
+    else k_grec_fwd<0><<<2 * B, GREC_T, 0, st>>>(gi, (const __bf16*)wp, b_hh_f, b_hh_r, out, gates, B, T);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

@@ -62,10 +62,14 @@ __device__ __forceinline__ float* p2p_result(char* buf, size_t n_cap, unsigned i
 __global__ __launch_bounds__(P2P_THREADS) void k_p2p_allreduce(float* __restrict__ data, long long n, int rank, int W, P2PPeers peers,
                                                                 size_t n_cap) {
     const int g = blockIdx.x, G = gridDim.x, tid = threadIdx.x;
-    char* mine = peers.buf[rank];
-    P2PHeader* hdr = (P2PHeader*)mine;
+    // (the peer table goes to LDS: sixteen 64-bit kernel arguments indexed by a run-time rank cost 85 spilled scalar registers)
+    __shared__ char* s_buf[P2P_MAX_WORLD];
     __shared__ unsigned int s_e;
     __shared__ int s_bad;
+    if (tid < P2P_MAX_WORLD) s_buf[tid] = peers.buf[tid < W ? tid : 0];
+    __syncthreads();
+    char* mine = s_buf[rank];
+    P2PHeader* hdr = (P2PHeader*)mine;
     if (tid == 0) { s_e = hdr->epoch[g] + 1u; s_bad = 0; }
     __syncthreads();
     const unsigned int e = s_e;
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(P2P_THREADS) void k_p2p_allreduce(float* __restrict
         __syncthreads();                                             // every thread's stores issued and counted (vmcnt drained)
         if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope
         __syncthreads();
-        if (tid < W) p2p_flag_store(&((P2PHeader*)peers.buf[tid])->flags[(kind * P2P_MAX_WORLD + rank) * P2P_MAX_WG + g], e);
+        if (tid < W) p2p_flag_store(&((P2PHeader*)s_buf[tid])->flags[(kind * P2P_MAX_WORLD + rank) * P2P_MAX_WG + g], e);
     };
     // ---- 1. publish my share of every slice ---------------------------------------------------------------------------------
     {
@@ -116,17 +120,18 @@ __global__ __launch_bounds__(P2P_THREADS) void k_p2p_allreduce(float* __restrict
     for (long long k = tid; k < per_wg; k += P2P_THREADS) {
         const long long c = chunk_of(rank, k);
         if (c >= n4) continue;
-        f32x4 v[P2P_MAX_WORLD];
+        // eight remote loads in flight per batch (clamped rank: the surplus loads re-read the last rank and are not added); the
+        // sum runs p = 0, 1, .. W-1 on every rank
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int p0 = 0; p0 < W; p0 += 8) {
+            f32x4 v[8];
 #pragma unroll
-        for (int p = 0; p < P2P_MAX_WORLD; ++p)
-            if (p < W) v[p] = ld4(p2p_stage(peers.buf[p], n_cap, e), c);
-        f32x4 acc = v[0];
+            for (int i = 0; i < 8; ++i) v[i] = ld4(p2p_stage(s_buf[min(p0 + i, W - 1)], n_cap, e), c);
 #pragma unroll
-        for (int p = 1; p < P2P_MAX_WORLD; ++p)
-            if (p < W) acc += v[p];
-#pragma unroll
-        for (int p = 0; p < P2P_MAX_WORLD; ++p)
-            if (p < W) st4(p2p_result(peers.buf[p], n_cap, e), c, acc);
+            for (int i = 0; i < 8; ++i)
+                if (p0 + i < W) acc += v[i];
+        }
+        for (int p = 0; p < W; ++p) st4(p2p_result(s_buf[p], n_cap, e), c, acc);
     }
     signal_all(1);
     // ---- 3. gather: every slice's reduced share of this workgroup back into the gradient bucket ------------------------------

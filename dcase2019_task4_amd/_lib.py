@@ -124,6 +124,17 @@ def lib():
     return _lib
 
 
+def scratch(nbytes, device):
+    """A caller-owned scratch / context buffer for the library.  SED_POISON=1 (the -m gpu test session sets it) fills it with
+    0xFF bytes first - NaN in fp32, bf16 and fp16 alike - so that any kernel that reads a byte no kernel wrote shows up as a NaN
+    instead of depending on what the allocator's block held before (round 5: the bf16 copy of an unpooled row)."""
+    import torch
+    t = torch.empty(nbytes, device=device, dtype=torch.uint8)
+    if os.environ.get("SED_POISON") == "1" and nbytes:
+        t.fill_(0xFF)
+    return t
+
+
 def check(status, what):
     if status != 0:
         msg = lib().sed_last_error()

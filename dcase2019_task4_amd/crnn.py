@@ -103,7 +103,7 @@ class _CRNNFunction(torch.autograd.Function):
         ctx_bytes = l.sed_crnn_ctx_bytes(C.byref(dims))
         if ctx_bytes == 0:
             raise _lib.SedError(l.sed_last_error().decode())
-        cbuf = torch.empty(ctx_bytes, device=x.device, dtype=torch.uint8)
+        cbuf = _lib.scratch(ctx_bytes, x.device)
         _lib.check(l.sed_crnn_buffers_init(C.byref(dims), _lib.ptr(cbuf), ctx_bytes, None, 0, _lib.stream_ptr()),
                    "sed_crnn_buffers_init")
         _lib.check(l.sed_crnn_forward(C.byref(dims), _lib.ptr(module._flat), _lib.ptr(module._bn_flat),
@@ -139,7 +139,7 @@ class _CRNNFunction(torch.autograd.Function):
         d_weak = d_weak.contiguous().float()
         gflat = torch.empty_like(module._flat)
         ws_bytes = l.sed_crnn_bwd_ws_bytes(C.byref(dims))
-        ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
+        ws = _lib.scratch(ws_bytes, x.device)
         _lib.check(l.sed_crnn_buffers_init(C.byref(dims), None, 0, _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),
                    "sed_crnn_buffers_init")
         _lib.check(l.sed_crnn_backward(C.byref(dims), _lib.ptr(module._flat), _lib.ptr(x), _lib.ptr(ctx.seed_t),

@@ -226,6 +226,22 @@ __global__ __launch_bounds__(256) void k_bglu_fwd(const void* __restrict__ y_v, 
             }
         }
     };
+    if constexpr (F16 != 0) {
+        // rows of y that no pooled pixel covers (H odd: AvgPool2d((2, 4)) drops the last row, e.g. H = 157 at T = 628) are never
+        // staged by the loop below - but the BatchNorm backward reads EVERY pixel of y (dy = ca dz + cb y + cc): their bf16 copy
+        // is made here, or the backward kernels read uninitialised memory there
+        if (y_b16 != nullptr && (H & 1)) {
+            const int Bn = Q / (Ho * Wo), per_row = W * C / 8;
+            for (int i = blockIdx.x * 256 + tid; i < Bn * per_row; i += gridDim.x * 256) {
+                const size_t e = ((size_t)((i / per_row) * H + (H - 1)) * W) * C + 8 * (i % per_row);
+                const f16x8 h = *(const f16x8*)((const _Float16*)y_v + e);
+                bf16x8 o;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o[q] = (__bf16)(float)h[q];
+                *(bf16x8*)(y_b16 + e) = o;
+            }
+        }
+    }
     load(blockIdx.x);
     int it = 0;
     for (int round = blockIdx.x; round < n_round; round += gridDim.x, ++it) {

@@ -126,9 +126,9 @@ class MeanTeacherStep:
             raise _lib.SedError(self.l.sed_last_error().decode())
         # the library initialises what it needs initialised in fresh buffers (the wide model's cluster recurrence keeps
         # launch epochs, tagged exchange granules and its sticky timeout counter in there): sed_crnn_buffers_init
-        self.ctx_s = torch.empty(self.ctx_bytes, device=dev, dtype=torch.uint8)
-        self.ctx_t = torch.empty(self.ctx_bytes if teacher is not None else 0, device=dev, dtype=torch.uint8)
-        self.ws = torch.empty(self.ws_bytes, device=dev, dtype=torch.uint8)
+        self.ctx_s = _lib.scratch(self.ctx_bytes, dev)
+        self.ctx_t = _lib.scratch(self.ctx_bytes if teacher is not None else 0, dev)
+        self.ws = _lib.scratch(self.ws_bytes, dev)
         _lib.check(self.l.sed_crnn_buffers_init(C.byref(self.dims), _lib.ptr(self.ctx_s), self.ctx_bytes, _lib.ptr(self.ws),
                                                 self.ws_bytes, _lib.stream_ptr()), "sed_crnn_buffers_init")
         if teacher is not None:

@@ -10,6 +10,11 @@ if REPO not in sys.path:
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
 
+# every ctx / workspace buffer the package hands to the library starts as 0xFF bytes (NaN in every float format): a kernel that
+# reads what no kernel wrote fails a parity test instead of passing on whatever the allocator's block held before
+os.environ.setdefault("SED_POISON", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -177,7 +177,8 @@ def _worker_entry(rank, world, port, schedule, graph, Bg, T, C, H, dtype, collec
                           # step's hipGraph at world 2 (dp_capture True), which RCCL cannot do on one GPU and gloo cannot do at all
                           ("overlap", True, 16, 128, 64, 64, "f32", "p2p"), ("overlap", False, 16, 128, 64, 64, "f32", "p2p"),
                           ("single", True, 16, 128, 64, 64, "f32", "p2p"), ("overlap", True, 128, 628, 64, 64, "f32", "p2p"),
-                          ("overlap", True, 16, 216, 128, 256, "bf16", "p2p"), ("overlap", True, 16, 216, 64, 64, "bf16", "p2p")])
+                          ("overlap", True, 16, 216, 128, 256, "bf16", "p2p"), ("overlap", True, 16, 216, 64, 64, "bf16", "p2p"),
+                          ("overlap", True, 16, 216, 128, 256, "f16", "p2p"), ("overlap", True, 16, 216, 64, 64, "f16", "pg")])
 def test_mean_teacher_step_world2(schedule, graph, Bg, T, C, H, dtype, collective):
     ok = _run_world2(_worker_entry, (schedule, graph, Bg, T, C, H, dtype, collective))
     print(f"[dp world 2] backend {ok[1]} schedule {schedule} graph {graph} global batch {Bg} T {T} C {C} H {H} {dtype}: "

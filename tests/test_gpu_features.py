@@ -80,7 +80,7 @@ def test_waveform_to_posteriors_pipeline_runs():
     assert s.shape == (2, 78, 10) and torch.isfinite(s).all() and torch.isfinite(w).all()
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16x3", "f16"])
 def test_config3_raw_waveform_batch64_mean_teacher_step(dtype):
     """BASELINE.json configs[2] at its full size: 64 raw 16 kHz clips -> on-GPU STFT/mel -> noise/log/pad/normalise ->
     one mean-teacher step (B=64, T=628), against the fp32 oracle on the SAME features, plus size-independent properties
@@ -115,11 +115,12 @@ def test_config3_raw_waveform_batch64_mean_teacher_step(dtype):
     mo, _, (so, wo, _, _) = mt.step(x.cpu(), x_ema.cpu(), tgt, wm, sm, 100)
     # north_star: posteriors within 1e-3.  fp32 holds 1e-5; bf16 operands at this geometry hold 1e-3
     # bf16x3 (split operands) is the reduced-precision mode asserted AT the north star's 1e-3
-    rel, post = {"f32": (1e-4, 1e-5), "bf16": (5e-3, BF16_POST_TOL), "bf16x3": (1e-4, 1e-3)}[dtype]
+    # f16 (round 5: fp16 forward chain, the bf16 mode's backward) is the mode that holds 1e-3 at bf16 speed - asserted AT 1e-3
+    rel, post = {"f32": (1e-4, 1e-5), "bf16": (5e-3, BF16_POST_TOL), "bf16x3": (1e-4, 1e-3), "f16": (2e-3, 1e-3)}[dtype]
     for k in ("loss", "weak_class_loss", "strong_loss", "weak_ema_loss", "strong_ema_loss"):
         assert m[k] == pytest.approx(mo[k], rel=rel, abs=1e-9), k
     for k in ("cons_strong", "cons_weak"):          # differences of two posteriors: absolute bound in bf16
-        assert m[k] == pytest.approx(mo[k], rel=rel if dtype != "bf16" else 5e-2, abs=1e-9 if dtype != "bf16" else 1e-5), k
+        assert m[k] == pytest.approx(mo[k], rel=rel if dtype not in ("bf16", "f16") else 5e-2, abs=1e-9 if dtype not in ("bf16", "f16") else 1e-5), k
     es, ew = np.abs(st.strong.cpu().numpy() - so.numpy()).max(), np.abs(st.weak.cpu().numpy() - wo.numpy()).max()
     print(f"[config 2, {dtype}] B=64 from raw waveforms: posterior err strong {es:.2e} weak {ew:.2e}")
     assert es < post and ew < post
@@ -128,7 +129,7 @@ def test_config3_raw_waveform_batch64_mean_teacher_step(dtype):
     st.step(x, x_ema, tgt.cuda())
     a = 1.0 - 1.0 / 3.0
     np.testing.assert_allclose(teacher._flat.cpu().numpy(), (a * t1 + (1 - a) * student._flat).cpu().numpy(), atol=1e-6)
-    assert all(np.isfinite(v) for v in st.meters().values())
+    assert all(np.isfinite(v) for v in st.meters().values()), st.meters()
 
 
 def test_waveform_front_end_one_batch_ahead_equals_serial():

@@ -338,8 +338,8 @@ _TRAJ = {}
 TRAJ_STEPS, TRAJ_B, TRAJ_T = 50, 8, 216
 # loss of step k relative to the fp32 oracle's loss of step k, maximum over the 50 steps, and the strong posteriors after step 50.
 # Measured (round 4): f32 3.5e-6 / 1.2e-5, bf16x3 3.7e-6 / 1.3e-5, bf16 4.9e-4 / 3.5e-3; asserted with head-room.
-TRAJ_TOL = {"f32": 5e-5, "bf16x3": 5e-5, "bf16": 2e-3}
-TRAJ_POST_TOL = {"f32": 1e-4, "bf16x3": 1e-4, "bf16": 7e-3}
+TRAJ_TOL = {"f32": 5e-5, "bf16x3": 5e-5, "bf16": 2e-3, "f16": 2e-3}      # (f16: the bf16 mode's backward steers the trajectory)
+TRAJ_POST_TOL = {"f32": 1e-4, "bf16x3": 1e-4, "bf16": 7e-3, "f16": 7e-3}
 
 
 def _hip_trajectory(dtype):
@@ -378,7 +378,7 @@ def _oracle_trajectory(hip):
     return _TRAJ["oracle"]
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16x3", "bf16", "f16"])
 def test_fifty_step_loss_trajectory_tracks_the_fp32_oracle(dtype):
     """50 mean-teacher steps (B = 8, T = 216, dropout 0.5, the same Philox masks on both sides, Adam + EMA + consistency ramp)
     on the device in each arithmetic mode against the fp32 CPU oracle: the loss of EVERY step within a stated relative

@@ -329,7 +329,7 @@ def _one_step_with_deferred_heads(B, T, debug, supervised=False, n_layers=2, ncl
 @pytest.mark.parametrize("B,T,kw", [(24, 628, {}), (8, 216, {}), (3, 864, {}), (2, 1024, {}), (5, 64, {}), (4, 128, dict(supervised=True)),
                                     (4, 160, dict(n_layers=1)), (4, 160, dict(nclass=16)), (4, 160, dict(nclass=3)),
                                     (6, 1100, {}), (8, 216, dict(parts=5)), (8, 216, dict(mfma_dtype="bf16")),
-                                    (8, 216, dict(mfma_dtype="bf16x3"))])
+                                    (8, 216, dict(mfma_dtype="bf16x3")), (8, 216, dict(mfma_dtype="f16"))])
 def test_heads_fused_into_the_backward_recurrence_are_bit_identical_to_the_separate_kernels(B, T, kw):
     """Round 5 (csrc/hfuse.h): sed_mt_step_backward runs the student's output heads, the mean-teacher loss and the heads'
     backward as the prologue phase of the top BiGRU layer's backward recurrence.  Debug bit 24 runs the same call with the

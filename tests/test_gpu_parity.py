@@ -319,6 +319,7 @@ def _one_step_with_deferred_heads(B, T, debug, supervised=False, n_layers=2, ncl
                 st._backward(2)
                 st._update()
             torch.cuda.synchronize()
+            st.check_health()
             out.append(dict(grads=st.grads.clone(), strong=st.strong.clone(), weak=st.weak.clone(), params=st.student._flat.clone(),
                             meters=dict(st.meters()), state=st.read_state().global_step))
         return out

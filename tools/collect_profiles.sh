@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/${PROF_TAG:-r05}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-CFGS="${PROF_CFGS:-mt-f32 mt-bf16 mt-bf16x3 waveform-bf16 wide-f32 wide-bf16 wide-bf16x3}"
+CFGS="${PROF_CFGS:-mt-f32 mt-bf16 mt-f16 mt-bf16x3 waveform-bf16 waveform-f16 wide-f32 wide-bf16 wide-f16 wide-bf16x3}"
 # 1. kernel stats + one step's timeline of the bench command, one per workload.  ONE traced process per summary: the headline's
 #    extra_configs child processes and its feature-path leg are suppressed (--trace-only-this-config keeps the kernel-table leg
 #    whose solo re-launches summarize_prof.py reports); timeline.py / summarize_prof.py refuse a trace with several databases and
@@ -46,6 +46,12 @@ python $R/tools/summarize_pmc.py $OUT/pmcfe_fetch $OUT/pmcfe_write $OUT/pmc_traf
 for c in $CFGS; do
   extra="--steps 500 --no-cpu-baseline"; [ $c = mt-f32 ] && extra=""
   timeout 600 python $R/bench.py --config $c $extra > $OUT/${c}_bench.json 2> $OUT/${c}_bench.err
+done
+# 6. launch structure of the data-parallel step on ONE GPU (one-rank group: the collective moves no bytes): no DP | the library's
+#    peer-memory all-reduce captured in the graph | the process group's (RCCL) captured | single eager
+for v in "nodp::" "p2p:1:p2p" "rccl:1:pg"; do
+  tag=${v%%:*}; rest=${v#*:}; force=${rest%%:*}; coll=${rest#*:}
+  SED_FORCE_DP=$force SED_DP_COLLECTIVE=$coll timeout 300 python $R/bench.py --steps 1000 --no-cpu-baseline --no-extras > $OUT/dp1_${tag}_bench.json 2> $OUT/dp1_${tag}_bench.err
 done
 rm -rf $OUT/stats_* $OUT/pmc_fetch $OUT/pmc_write $OUT/pmcw_fetch $OUT/pmcw_write $OUT/pmcfe_fetch $OUT/pmcfe_write $OUT/pmcq_*/
 ls $OUT

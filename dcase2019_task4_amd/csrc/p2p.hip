@@ -10,11 +10,11 @@
 //
 //   workgroup g of rank r (G workgroups, the same G on every rank; element chunks of 4 floats dealt round-robin to the
 //   (slice, workgroup) pairs so that every remote access is a 16-byte vector):
-//     1. publish : copies ITS share of the local gradient bucket into stage[e & 1] of r's own buffer, release fence,
-//                  then writes ready[r][g] = e into every rank's flag page
+//     1. publish : copies ITS share of the local gradient bucket into stage[e & 1] of r's own buffer (system-scope stores),
+//                  drains them, then writes ready[r][g] = e into every rank's flag page
 //     2. reduce  : waits for ready[p][g] == e of every rank p, sums ITS share of slice r over the ranks IN RANK ORDER
 //                  (p = 0 .. W-1: every rank ends with the bit-identical sum - replicas must not drift apart) reading the
-//                  peers' stage buffers over xGMI, and writes the sums into result[e & 1] of EVERY rank; release fence,
+//                  peers' stage buffers over xGMI, and writes the sums into result[e & 1] of EVERY rank; drain,
 //                  done[r][g] = e everywhere
 //     3. gather  : waits for done[p][g] == e of every p, copies its share of result[e & 1] back over the gradient bucket.
 //   Only same-index workgroups of different ranks ever wait for each other, and every wait is on a flag whose writer has no
@@ -53,38 +53,60 @@ __device__ __forceinline__ void p2p_flag_store(unsigned int* p, unsigned int v) 
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Payload accesses to the communication buffers: relaxed SYSTEM-scope 8-byte atomics (global_load / store_dwordx2 sc0 sc1), two per
+// 16-byte chunk.  They bypass / write through the caches on both sides, so the hand-over needs NO cache-maintenance fence: the
+// producer drains its stores (s_waitcnt vmcnt(0) of the workgroup barrier) and stores the flag, the consumer sees the flag and
+// loads.  The first version used plain accesses between system-scope release / acquire fences: a release fence writes back every
+// dirty line of the XCD's L2 - mostly the conv backward's, which runs beside the tail bucket's all-reduce - and the one-rank
+// launch-structure measurement came out at +51 us per step for the two calls.
+typedef unsigned long long p2p_u64;
+typedef __attribute__((ext_vector_type(2))) p2p_u64 p2p_u64x2;
+__device__ __forceinline__ f32x4 ld_sys(const float* p) {
+    p2p_u64x2 v;
+    v[0] = __hip_atomic_load((const p2p_u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    v[1] = __hip_atomic_load((const p2p_u64*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return __builtin_bit_cast(f32x4, v);
+}
+__device__ __forceinline__ void st_sys(float* p, f32x4 x) {
+    const p2p_u64x2 v = __builtin_bit_cast(p2p_u64x2, x);
+    __hip_atomic_store((p2p_u64*)p, v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store((p2p_u64*)p + 1, v[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ float ld_sys1(const float* p) { return __builtin_bit_cast(float, __hip_atomic_load((const unsigned int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)); }
+__device__ __forceinline__ void st_sys1(float* p, float x) { __hip_atomic_store((unsigned int*)p, __builtin_bit_cast(unsigned int, x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
 // stage / result halves: [2][n_cap] floats each, behind the header
 __device__ __forceinline__ float* p2p_stage(char* buf, size_t n_cap, unsigned int e) { return (float*)(buf + P2P_HDR_BYTES) + (size_t)(e & 1u) * n_cap; }
 __device__ __forceinline__ float* p2p_result(char* buf, size_t n_cap, unsigned int e) { return (float*)(buf + P2P_HDR_BYTES) + (size_t)(2u + (e & 1u)) * n_cap; }
 
-// data: the local gradient bucket (n floats, 16-byte aligned); n4 = ceil(n / 4) vector chunks; chunk c belongs to slice
-// c % W and, inside the slice, to workgroup (c / W) % G.
-__global__ __launch_bounds__(P2P_THREADS) void k_p2p_allreduce(float* __restrict__ data, long long n, int rank, int W, P2PPeers peers,
+// data: the local gradient bucket (n floats, 16-byte aligned); n4 = n / 4 whole vector chunks (+ at most one partial tail chunk);
+// chunk c belongs to slice c % W and, inside the slice, to workgroup (c / W) % G.
+// Every loop keeps EIGHT 16-byte accesses per lane in flight (loads first, then the stores): the communication buffers are
+// fine-grained (uncached) memory, so a load-then-store loop pays a full memory round trip per iteration - the first version,
+// one chunk per iteration, took ~30 us per call for 500 KB on ONE rank.  WC: compile-time world size (1, 2, 4, 8; 0 = any).
+template <int WC>
+__global__ __launch_bounds__(P2P_THREADS) void k_p2p_allreduce(float* __restrict__ data, long long n, int rank, int W_, P2PPeers peers,
                                                                 size_t n_cap) {
+    const int W = WC ? WC : W_;
     const int g = blockIdx.x, G = gridDim.x, tid = threadIdx.x;
     // (the peer table goes to LDS: sixteen 64-bit kernel arguments indexed by a run-time rank cost 85 spilled scalar registers)
     __shared__ char* s_buf[P2P_MAX_WORLD];
     __shared__ unsigned int s_e;
-    __shared__ int s_bad;
     if (tid < P2P_MAX_WORLD) s_buf[tid] = peers.buf[tid < W ? tid : 0];
     __syncthreads();
     char* mine = s_buf[rank];
     P2PHeader* hdr = (P2PHeader*)mine;
-    if (tid == 0) { s_e = hdr->epoch[g] + 1u; s_bad = 0; }
+    if (tid == 0) s_e = hdr->epoch[g] + 1u;
     __syncthreads();
     const unsigned int e = s_e;
-    const long long n4 = (n + 3) / 4;
-    const long long per_wg = (n4 + (long long)W * G - 1) / ((long long)W * G);     // chunks of one (slice, workgroup) pair
+    const long long n4 = n / 4;                                                     // whole chunks
+    const long long nck = (n + 3) / 4;                                              // incl. the partial tail chunk (index n4) if n % 4
+    const long long per_wg = (nck + (long long)W * G - 1) / ((long long)W * G);     // chunks of one (slice, workgroup) pair
     auto chunk_of = [&](int slice, long long k) -> long long { return ((k * G + g) * W + slice); };
-    auto ld4 = [&](const float* p, long long c) -> f32x4 {
-        if (4 * c + 3 < n) return *(const f32x4*)(p + 4 * c);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        for (int i = 0; i < 4; ++i) if (4 * c + i < n) v[i] = p[4 * c + i];
-        return v;
-    };
-    auto st4 = [&](float* p, long long c, f32x4 v) {
-        if (4 * c + 3 < n) *(f32x4*)(p + 4 * c) = v;
-        else for (int i = 0; i < 4; ++i) if (4 * c + i < n) p[4 * c + i] = v[i];
+    // the partial tail chunk (n % 4 floats) is moved element-wise by whoever owns it
+    // (to_comm: local gradient -> own staging half, system-scope stores; else own result half -> local gradient, system-scope loads)
+    auto tail_copy = [&](const float* src, float* dst, bool to_comm) {
+        for (long long i = 4 * n4; i < n; ++i) { if (to_comm) st_sys1(dst + i, src[i]); else dst[i] = ld_sys1(src + i); }
     };
     // bounded wait for flag words [kind][p][g] == e of every rank p (thread p polls rank p's word in MY flag page)
     auto wait_all = [&](int kind) {
@@ -93,59 +115,95 @@ __global__ __launch_bounds__(P2P_THREADS) void k_p2p_allreduce(float* __restrict
             const unsigned long long t0 = wall_clock64();
             while (p2p_flag_load(f) != e) {
                 __builtin_amdgcn_s_sleep(2);
-                if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) { atomicAdd(&hdr->error, 1u); s_bad = 1; break; }
+                if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) { atomicAdd(&hdr->error, 1u); break; }
             }
         }
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");               // system scope: what the flags' writers released
+        __syncthreads();                                             // (the payload loads that follow are system-scope themselves)
     };
     auto signal_all = [&](int kind) {
-        __syncthreads();                                             // every thread's stores issued and counted (vmcnt drained)
-        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope
-        __syncthreads();
+        __syncthreads();                                             // every wave's system-scope stores issued AND acknowledged (vmcnt drained)
         if (tid < W) p2p_flag_store(&((P2PHeader*)s_buf[tid])->flags[(kind * P2P_MAX_WORLD + rank) * P2P_MAX_WG + g], e);
     };
-    // ---- 1. publish my share of every slice ---------------------------------------------------------------------------------
-    {
-        float* st = p2p_stage(mine, n_cap, e);
-        for (int s = 0; s < W; ++s)
-            for (long long k = tid; k < per_wg; k += P2P_THREADS) {
-                const long long c = chunk_of(s, k);
-                if (c < n4) st4(st, c, ld4(data, c));
-            }
-    }
-    signal_all(0);
-    // ---- 2. reduce my share of slice `rank` over the ranks, in rank order; write it to every rank --------------------------
-    wait_all(0);
-    for (long long k = tid; k < per_wg; k += P2P_THREADS) {
-        const long long c = chunk_of(rank, k);
-        if (c >= n4) continue;
-        // eight remote loads in flight per batch (clamped rank: the surplus loads re-read the last rank and are not added); the
-        // sum runs p = 0, 1, .. W-1 on every rank
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int p0 = 0; p0 < W; p0 += 8) {
+    // this workgroup's chunks of ALL slices, flattened: j = k * W + slice; eight per lane and trip
+    auto copy_all = [&](const float* src, float* dst, bool to_comm) {
+        const long long nj = per_wg * W;
+        for (long long j0 = tid; j0 < nj; j0 += 8 * P2P_THREADS) {
             f32x4 v[8];
+            long long c[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = ld4(p2p_stage(s_buf[min(p0 + i, W - 1)], n_cap, e), c);
+            for (int i = 0; i < 8; ++i) {
+                const long long j = j0 + (long long)i * P2P_THREADS;
+                c[i] = chunk_of((int)(j % W), j / W);
+                const bool ok = j < nj && c[i] < n4;
+                const float* sp = src + 4 * (ok ? c[i] : 0);
+                v[i] = to_comm ? *(const f32x4*)sp : ld_sys(sp);
+                if (!ok) c[i] = -1;
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                if (p0 + i < W) acc += v[i];
+                if (c[i] >= 0) { if (to_comm) st_sys(dst + 4 * c[i], v[i]); else *(f32x4*)(dst + 4 * c[i]) = v[i]; }
         }
-        for (int p = 0; p < W; ++p) st4(p2p_result(s_buf[p], n_cap, e), c, acc);
+        if (n4 != nck && tid == 0 && (int)((n4 / W) % G) == g) tail_copy(src, dst, to_comm);
+    };
+    // ---- 1. publish my share of every slice ---------------------------------------------------------------------------------
+    copy_all(data, p2p_stage(mine, n_cap, e), true);
+    signal_all(0);
+    // ---- 2. reduce my share of slice `rank` over the ranks, in rank order (p = 0 .. W - 1 on every rank: bit-identical sums);
+    //         write it to every rank.  KB chunks x W ranks = eight remote loads per lane in flight -------------------------------
+    wait_all(0);
+    if constexpr (WC != 0) {
+        constexpr int KB = 8 / WC;
+        for (long long k0 = tid; k0 < per_wg; k0 += (long long)KB * P2P_THREADS) {
+            f32x4 v[KB][WC];
+            long long c[KB];
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+                const long long k = k0 + (long long)kk * P2P_THREADS;
+                c[kk] = chunk_of(rank, k);
+                const bool ok = k < per_wg && c[kk] < n4;
+#pragma unroll
+                for (int p = 0; p < WC; ++p) v[kk][p] = ld_sys(p2p_stage(s_buf[p], n_cap, e) + 4 * (ok ? c[kk] : 0));
+                if (!ok) c[kk] = -1;
+            }
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+                f32x4 acc = v[kk][0];
+#pragma unroll
+                for (int p = 1; p < WC; ++p) acc += v[kk][p];
+                if (c[kk] >= 0) {
+#pragma unroll
+                    for (int p = 0; p < WC; ++p) st_sys(p2p_result(s_buf[p], n_cap, e) + 4 * c[kk], acc);
+                }
+            }
+        }
+    } else {
+        for (long long k = tid; k < per_wg; k += P2P_THREADS) {
+            const long long c = chunk_of(rank, k);
+            if (c >= n4) continue;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int p0 = 0; p0 < W; p0 += 8) {
+                f32x4 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = ld_sys(p2p_stage(s_buf[min(p0 + i, W - 1)], n_cap, e) + 4 * c);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (p0 + i < W) acc += v[i];
+            }
+            for (int p = 0; p < W; ++p) st_sys(p2p_result(s_buf[p], n_cap, e) + 4 * c, acc);
+        }
+    }
+    if (n4 != nck && tid == 0 && (int)(n4 % W) == rank && (int)((n4 / W) % G) == g) {      // the partial tail chunk of my slice
+        for (long long i = 4 * n4; i < n; ++i) {
+            float acc = 0.f;
+            for (int p = 0; p < W; ++p) acc += ld_sys1(p2p_stage(s_buf[p], n_cap, e) + i);
+            for (int p = 0; p < W; ++p) st_sys1(p2p_result(s_buf[p], n_cap, e) + i, acc);
+        }
     }
     signal_all(1);
     // ---- 3. gather: every slice's reduced share of this workgroup back into the gradient bucket ------------------------------
     wait_all(1);
-    {
-        const float* rs = p2p_result(mine, n_cap, e);
-        for (int s = 0; s < W; ++s)
-            for (long long k = tid; k < per_wg; k += P2P_THREADS) {
-                const long long c = chunk_of(s, k);
-                if (c < n4) st4(data, c, ld4(rs, c));
-            }
-    }
+    copy_all(p2p_result(mine, n_cap, e), data, false);
     if (tid == 0) hdr->epoch[g] = e;
-    (void)s_bad;
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
@@ -219,14 +277,14 @@ extern "C" int sed_p2p_errors(const void* own_ptr, unsigned int* out) {
 
 // In-place sum all-reduce of data[0, n) over the `world` ranks whose communication buffers are bufs[0 .. world) (bufs[rank] =
 // this rank's own; every one created with the SAME n_floats_max); every rank must enqueue the same sequence of calls.
-// One launch of `workgroups` workgroups (0: default 16; the same value on every rank), capturable, no host synchronisation.
+// One launch of `workgroups` workgroups (0: default 32; the same value on every rank), capturable, no host synchronisation.
 extern "C" int sed_p2p_allreduce(float* data, long long n, int rank, int world, void* const* bufs, long long n_floats_max,
                                  int workgroups, void* stream) {
     SED_CHECK_ARG(data && bufs && n >= 0 && world >= 1 && world <= P2P_MAX_WORLD && rank >= 0 && rank < world, "sed_p2p_allreduce: bad argument");
     SED_CHECK_ARG(n <= n_floats_max, "sed_p2p_allreduce: message larger than the communication buffers");
     SED_CHECK_ARG(((uintptr_t)data & 15) == 0, "sed_p2p_allreduce: data must be 16-byte aligned");
     if (n == 0) return SED_OK;
-    int G = workgroups > 0 ? workgroups : 16;
+    int G = workgroups > 0 ? workgroups : 32;
     if (G > P2P_MAX_WG) G = P2P_MAX_WG;
     P2PPeers peers = {};
     for (int p = 0; p < world; ++p) {
@@ -234,7 +292,14 @@ extern "C" int sed_p2p_allreduce(float* data, long long n, int rank, int world, 
         peers.buf[p] = (char*)bufs[p];
     }
     const size_t n_cap = ((size_t)n_floats_max + 63) & ~(size_t)63;
-    k_p2p_allreduce<<<G, P2P_THREADS, 0, (hipStream_t)stream>>>(data, n, rank, world, peers, n_cap);
+    hipStream_t st = (hipStream_t)stream;
+    switch (world) {
+        case 1: k_p2p_allreduce<1><<<G, P2P_THREADS, 0, st>>>(data, n, rank, world, peers, n_cap); break;
+        case 2: k_p2p_allreduce<2><<<G, P2P_THREADS, 0, st>>>(data, n, rank, world, peers, n_cap); break;
+        case 4: k_p2p_allreduce<4><<<G, P2P_THREADS, 0, st>>>(data, n, rank, world, peers, n_cap); break;
+        case 8: k_p2p_allreduce<8><<<G, P2P_THREADS, 0, st>>>(data, n, rank, world, peers, n_cap); break;
+        default: k_p2p_allreduce<0><<<G, P2P_THREADS, 0, st>>>(data, n, rank, world, peers, n_cap); break;
+    }
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

@@ -128,7 +128,7 @@ class PeerAllReduce:
         self.rank = dist.get_rank(group)
         self.device = torch.device(device)
         self.n_max = int(n_floats_max)
-        self.workgroups = int(workgroups)
+        self.workgroups = int(workgroups) or int(os.environ.get("SED_P2P_WGS", "0"))
         self._own = None
         self._peers = {}
         if self.world > 16:

@@ -16,6 +16,7 @@ for c in $CFGS; do
   python $R/tools/summarize_prof.py $OUT/stats_$c > $OUT/${c}_kernel_stats.md 2> $OUT/${c}_kernel_stats.err
   python $R/tools/timeline.py $OUT/stats_$c 2 --config $c > $OUT/${c}_step_timeline.txt 2> $OUT/${c}_step_timeline.err
 done
+if [ "${PROF_ONLY_STATS:-0}" != "1" ]; then
 # 2. HBM traffic of the headline workload: FETCH_SIZE and WRITE_SIZE in separate passes (13 steps traced: 10 + 3 warm-up)
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o p -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $OUT/pmc_fetch.log 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o p -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $OUT/pmc_write.log 2>&1
@@ -47,6 +48,7 @@ for c in $CFGS; do
   extra="--steps 500 --no-cpu-baseline"; [ $c = mt-f32 ] && extra=""
   timeout 600 python $R/bench.py --config $c $extra > $OUT/${c}_bench.json 2> $OUT/${c}_bench.err
 done
+fi
 # 6. launch structure of the data-parallel step on ONE GPU (one-rank group: the collective moves no bytes): no DP | the library's
 #    peer-memory all-reduce captured in the graph | the process group's (RCCL) captured | single eager
 for v in "nodp::" "p2p:1:p2p" "rccl:1:pg"; do

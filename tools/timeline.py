@@ -13,6 +13,9 @@ KERNEL_SETS = {
     "mt-bf16": (("k_bconv", "k_bglu_fwd", "k_gwgrad_bf16", "k_gru4_"), ("k_conv_wino", "k_grec", "k_gclu", "k_stft")),
     "mt-bf16x3": (("k_bconv", "k_gru4_"), ("k_conv_wino", "k_grec", "k_gclu", "k_stft")),
     "waveform-bf16": (("k_bconv", "k_gru4_", "k_stft_mel_p", "k_logmel"), ("k_conv_wino", "k_grec", "k_gclu")),
+    "mt-f16": (("k_bconv<2", "k_bglu_fwd", "k_gru4_"), ("k_conv_wino", "k_grec", "k_gclu", "k_stft")),
+    "waveform-f16": (("k_bconv<2", "k_gru4_", "k_stft_mel_p", "k_logmel"), ("k_conv_wino", "k_grec", "k_gclu")),
+    "wide-f16": (("k_bconv<2", "k_grec_"), ("k_gru4_", "k_gclu", "k_stft")),
     "wide-f32": (("k_gclu_",), ("k_gru4_", "k_grec", "k_stft")),
     "wide-bf16": (("k_bconv", "k_grec_"), ("k_gru4_", "k_gclu", "k_stft")),
     "wide-bf16x3": (("k_bconv",), ("k_gru4_", "k_stft")),

@@ -171,6 +171,9 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
     const int gm = (g.mode == SED_DTYPE_BF16X3) ? SED_DTYPE_F32 : g.mode;      // arithmetic of everything but the 3x3 convolutions
     const int use_drop = (train && g.p > 0.f) ? 1 : 0;
     const int upd = (train && update_bn) ? 1 : 0;
+    // train & 2: train-mode arithmetic, but no backward will ever run on this ctx (the teacher's forward, main.py:87-89): what only
+    // a backward reads need not be written - today the bf16 activation copies of SED_DTYPE_F16
+    const bool keep_b16 = train && !(train & 2);
     int64_t* trk[3] = {bn_tracked ? bn_tracked + 0 : nullptr, bn_tracked ? bn_tracked + 1 : nullptr,
                        bn_tracked ? bn_tracked + 2 : nullptr};
     // ---- weight packing (conv panels, GLU weights folded with the BatchNorm affine, GRU streaming layout) + the fp64
@@ -234,7 +237,7 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
                                 seed_dev, CTXD(L.mom0), CTXD(L.mompart), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0),
                                 g.f16 ? CTXF(L.ph[0]) : CTXF(L.p[0]),
                                 use_drop ? CTXM(L.mask[0]) : nullptr, nullptr, st, 0, aux_pack ? &aux : nullptr,
-                                (g.f16 && train) ? CTXV(L.p[0]) : nullptr));
+                                (g.f16 && keep_b16) ? CTXV(L.p[0]) : nullptr));
     // ---- conv blocks 1, 2 -----------------------------------------------------------------------------------------------
     const size_t so[3] = {0, L.stat1, L.stat2};
     const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};
@@ -251,7 +254,7 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
             SED_TRY(launch_bglu_fwd(C, CTXV(L.yh[i]), bnf, params + P.glu_w[i], params + P.glu_b[i], i == 1 ? CTXV(L.ph[1]) : CTXV(L.p[2]),
                                     i == 1 ? 1 : 0, g.B, Hs[i], Wd[i], i, use_drop, g.p, seed_dev, use_drop ? CTXM(L.mask[i]) : nullptr,
                                     train ? CTXV(L.wg[i]) : nullptr, train ? CTXF(L.bg[i]) : nullptr, st, 1,
-                                    (i == 1 && train) ? CTXV(L.p[1]) : nullptr, train ? CTXV(L.y[i]) : nullptr));
+                                    (i == 1 && keep_b16) ? CTXV(L.p[1]) : nullptr, keep_b16 ? CTXV(L.y[i]) : nullptr));
             continue;
         }
         if (g.mode != SED_DTYPE_F32)      // bf16 (bf16 storage) / bf16x3 (fp32 storage, split operands): bconv.hip

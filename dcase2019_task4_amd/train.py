@@ -242,9 +242,11 @@ class MeanTeacherStep:
 
     # ---- pieces ------------------------------------------------------------------------------------
     def _forward(self, model, x, ctx, seed, strong, weak):
-        """strong = weak = None: output heads deferred to sed_mt_step_backward (the student's forward)."""
+        """strong = weak = None: output heads deferred to sed_mt_step_backward (the student's forward).  The teacher's forward is
+        train-mode but never differentiated (main.py:87-89): train = 3 tells the library so."""
+        train = 3 if (model is self.teacher and model is not None) else 1
         _lib.check(self.l.sed_crnn_forward(C.byref(self.dims), _lib.ptr(model._flat), _lib.ptr(model._bn_flat),
-                                           _lib.ptr(model._bn_tracked), _lib.ptr(x), 1, 1, seed, _lib.ptr(ctx),
+                                           _lib.ptr(model._bn_tracked), _lib.ptr(x), train, 1, seed, _lib.ptr(ctx),
                                            self.ctx_bytes, _lib.ptr(strong), _lib.ptr(weak), _lib.stream_ptr()),
                    "sed_crnn_forward")
 

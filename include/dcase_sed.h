@@ -135,7 +135,9 @@ int sed_param_layout(const sed_dims* d, int64_t* offsets);
  *               when update_bn != 0: BatchNorm2d momentum rule, CNN.py:49)
  *   bn_tracked  [3] int64 num_batches_tracked (incremented with bn_running), may be NULL
  *   x           [B][1][T][F] fp32
- *   train       1 = module.train() semantics (batch statistics, dropout), 0 = eval
+ *   train       1 = module.train() semantics (batch statistics, dropout), 0 = eval; 3 = train semantics for a forward whose
+ *               backward will never run (the teacher's, main.py:87-89): bit 1 lets the library skip what only a backward reads
+ *               (today: the bf16 activation copies of SED_DTYPE_F16); results are identical to train = 1
  *   seed_dev    device pointer to the 64-bit Philox key of this forward (ignored if p_drop==0
  *               or train==0); the same pointer/value must be given to backward
  *   ctx         saved activations for backward + scratch; sed_crnn_ctx_bytes(d)

@@ -336,6 +336,22 @@ def time_steps(step, steps, world, device):
     return elapsed
 
 
+def replicas_bit_identical(step, world, device):
+    """After the timed steps every rank must hold bit-identical students, teachers and Adam moments (each rank saw different clips
+    and masks; only the all-reduced gradient couples them): a 64-bit XOR / sum fingerprint of the raw bits of each buffer, gathered
+    and compared.  Reported in the JSON line - an all-reduce that were not bit-reproducible across ranks would show here."""
+    import torch.distributed as dist
+    bufs = [step.student._flat, step.exp_avg, step.exp_avg_sq] + ([step.teacher._flat] if step.teacher is not None else [])
+    fp = []
+    for t in bufs:
+        bits = t.contiguous().view(torch.int32).to(torch.int64)
+        fp += [bits.sum(), (bits * (torch.arange(bits.numel(), device=bits.device) % 8191 + 1)).sum()]
+    mine = torch.stack(fp)
+    allv = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allv, mine)
+    return bool(all(torch.equal(allv[0], v) for v in allv[1:]))
+
+
 def same_on_all_ranks(step, world, device):
     """Every rank must have ended on the same data-parallel schedule (a rank that fell back alone would deadlock or, worse,
     reduce different buckets): gather (schedule, captured) and fail loudly on any difference."""
@@ -497,6 +513,7 @@ def main():
     assert np.isfinite(meters["loss"]), meters
     step.check_health()
     schedules = same_on_all_ranks(step, world, device) if step.dp else None
+    replicas_identical = replicas_bit_identical(step, world, device) if (step.dp and world > 1) else None
 
     # N > 1: the same workload under the other data-parallel schedules, so that ONE driver run yields the comparison
     # (captured overlap = the default above | single all-reduce, eager | overlap with eager collectives)
@@ -611,6 +628,7 @@ def main():
                                                  "max": round(max(per_rank_s) / args.steps * 1e3, 4),
                                                  "all": [round(v / args.steps * 1e3, 4) for v in per_rank_s]}
             dist_info["schedule_per_rank"] = [f"{a}/{'captured' if b else 'eager'}" for a, b in (schedules or [])]
+            dist_info["replicas_bit_identical_after_timed_steps"] = replicas_identical
             if ab_legs:
                 dist_info["schedule_ab"] = ab_legs
             if getattr(step, "_capture_error", None):

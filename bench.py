@@ -300,7 +300,10 @@ def free_port():
 def self_launch(args):
     """--gpus N without a launcher: re-exec through torch.distributed.run (one rank per GPU, RCCL)."""
     n_dev = torch.cuda.device_count()
-    if n_dev < args.gpus:
+    # SED_BENCH_SHARE_GPU=1 (code-path test on a box with fewer GPUs than ranks, tests/test_gpu_dp.py): the ranks share the
+    # visible GPUs round-robin and talk over gloo - RCCL refuses two ranks on one device, the library's own all-reduce does not.
+    # Such a run says nothing about scaling; its JSON line carries "shared_gpu": true.
+    if n_dev < args.gpus and os.environ.get("SED_BENCH_SHARE_GPU") != "1":
         raise SystemExit(f"--gpus {args.gpus} but only {n_dev} GPU(s) are visible")
     port = int(os.environ.get("MASTER_PORT", "0")) or free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
@@ -482,17 +485,22 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path is the only product path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    share_gpu = os.environ.get("SED_BENCH_SHARE_GPU") == "1" and torch.cuda.device_count() < world
+    dev_index = local_rank % torch.cuda.device_count() if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     pg = None
     dist_info = None
     if world > 1 or os.environ.get("SED_FORCE_DP") == "1":      # SED_FORCE_DP: one-rank RCCL group (path test on a 1-GPU box)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         pg = dist.group.WORLD
-        dist_info = {"backend": dist.get_backend(pg), "world_size": dist.get_world_size(pg),
+        dist_info = {"backend": dist.get_backend(pg), "world_size": dist.get_world_size(pg), "shared_gpu": share_gpu,
                      "rccl": ".".join(str(v) for v in torch.cuda.nccl.version()),
                      # RCCL picks algorithm / protocol per message size unless pinned; what this run pinned (nothing by default)
                      "env": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS",

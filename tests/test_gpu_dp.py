@@ -327,3 +327,31 @@ def _worker_frontend(rank, world, port, dtype, out):
 def test_waveform_front_end_world2():
     ok = _run_world2(_worker_frontend, ("bf16",))
     print(f"[dp world 2] WaveformFrontEnd under DP: backend {ok[1]}, extraction inside the step's graph: {bool(ok[2])}")
+
+
+def test_bench_gpus_2_code_path_on_a_shared_gpu():
+    """`bench.py --gpus 2` end to end - self-launch through torch.distributed.run, process group, data-parallel step with the
+    default collective choice, the schedule A/B legs, configs[3] / configs[4] legs, the replica fingerprint - with the two ranks
+    sharing this box's GPU over gloo (SED_BENCH_SHARE_GPU=1).  The number means nothing; what is checked is that the command the
+    driver runs on an 8-GPU node produces ONE JSON line with the contract's fields, that the library's own all-reduce was chosen
+    and captured, and that the replicas are still bit-identical after the timed steps."""
+    import json
+    import subprocess
+    env = dict(os.environ, SED_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SED_POISON", None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().split("\n")[-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["unit"] == "clips/s" and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 48 and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["dp_schedule"] == "overlap" and d["config"]["dp_collectives"] == "captured"
+    assert d["config"]["dp_collective"].startswith("library kernel over peer-mapped memory")
+    dd = d["distributed"]
+    assert dd["shared_gpu"] is True and dd["replicas_bit_identical_after_timed_steps"] is True
+    assert set(dd["schedule_ab"]) == {"overlap_captured_rccl", "single_eager_rccl", "overlap_eager_rccl", "single_captured_p2p"}
+    assert all("value" in v for v in dd["schedule_ab"].values()), dd["schedule_ab"]
+    assert "value" in d["config3_ddp"] and d["config3_ddp"]["global_batch"] == 128
+    assert "value" in d["config4_ddp"] and d["config4_ddp"]["dp_collective"] == "p2p"
+    assert d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
+

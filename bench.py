@@ -531,7 +531,7 @@ def main():
         # (the headline runs the default: overlap schedule, collectives captured, the library's own peer-memory all-reduce when
         # its self-check passes - config.dp_collective says which ran; these legs price the alternatives)
         for tag, sched, cap, coll in (("overlap_captured_rccl", "overlap", None, "pg"), ("single_eager_rccl", "single", "0", "pg"),
-                                      ("overlap_eager_rccl", "overlap", "0", "pg"), ("single_captured_p2p", "single", None, "p2p")):
+                                      ("overlap_eager_rccl", "overlap", "0", "pg"), ("single_eager_p2p", "single", None, "p2p")):
             try:
                 if cap is not None:
                     os.environ["SED_DP_CAPTURE"] = cap

@@ -349,7 +349,7 @@ def test_bench_gpus_2_code_path_on_a_shared_gpu():
     assert d["config"]["dp_collective"].startswith("library kernel over peer-mapped memory")
     dd = d["distributed"]
     assert dd["shared_gpu"] is True and dd["replicas_bit_identical_after_timed_steps"] is True
-    assert set(dd["schedule_ab"]) == {"overlap_captured_rccl", "single_eager_rccl", "overlap_eager_rccl", "single_captured_p2p"}
+    assert set(dd["schedule_ab"]) == {"overlap_captured_rccl", "single_eager_rccl", "overlap_eager_rccl", "single_eager_p2p"}
     assert all("value" in v for v in dd["schedule_ab"].values()), dd["schedule_ab"]
     assert "value" in d["config3_ddp"] and d["config3_ddp"]["global_batch"] == 128
     assert "value" in d["config4_ddp"] and d["config4_ddp"]["dp_collective"] == "p2p"

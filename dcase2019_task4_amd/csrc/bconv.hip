@@ -362,7 +362,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bconv(const void* __restrict__
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) {
                             const float v = acc[mb][nb][r] + bv[nb];
-                            o[32 * nb] = (S)v;
+                            if constexpr (F16) o[32 * nb] = f16_sat(v);
+                            else o[32 * nb] = (S)v;
                             if (DIR == 0) { s1[nb] += v; s2[nb] += v * v; }
                         }
                     }

@@ -38,7 +38,12 @@ __device__ __forceinline__ f32x4 ld4(const _Float16* p) {
     return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
 }
 __device__ __forceinline__ float ld1(const _Float16* p) { return (float)*p; }
-__device__ __forceinline__ void st1(_Float16* p, float v) { *p = (_Float16)v; }
+// fp16 stores SATURATE at +-65504: a value beyond fp16's range (none of the forward tensors of this model comes near it - they sit
+// behind BatchNorms or are convolutions of O(1) inputs - but nothing in the arithmetic forbids conv weights from drifting there
+// over a long run) becomes the largest finite fp16, which the BatchNorm behind it absorbs, instead of an Inf that turns the step
+// into NaNs
+__device__ __forceinline__ _Float16 f16_sat(float v) { return (_Float16)__builtin_fminf(__builtin_fmaxf(v, -65504.0f), 65504.0f); }
+__device__ __forceinline__ void st1(_Float16* p, float v) { *p = f16_sat(v); }
 template <int F16> struct H16 {
     using T = __bf16;
     using V8 = bf16x8;

@@ -73,7 +73,8 @@ typedef enum {
  *                     every gradient tensor and backward operand is bf16.  Why: the bf16 mode's posterior error has no
  *                     owner - every rounding site contributes 2.5 - 4e-4 and they add in quadrature
  *                     (profiles/r05_bf16_error_budget.md) - so no subset of operators can be promoted to reach 1e-3; eight
- *                     times less rounding error at every site can.  Posteriors are asserted at 1e-3 (measured: DESIGN.md 4b).
+ *                     times less rounding error at every site can.  Posteriors are asserted at 1e-3 (measured: DESIGN.md 4c).
+ *                     fp16 stores saturate at +-65504 (never Inf).
  * BatchNorm statistics, gates, the H = 64 recurrence, heads, losses and the optimiser are fp32 (fp64 sums) in all modes.
  * The mode is never chosen silently: the caller states it here. */
 #define SED_DTYPE_F32 0

@@ -192,6 +192,25 @@ def test_f16_forward_chain_holds_the_north_star_tolerance_at_bf16_speed(B, T, p,
             np.testing.assert_allclose(r["bn"][k].numpy(), v.numpy(), rtol=4e-3, atol=1e-3, err_msg=k)
 
 
+def test_f16_stores_saturate_instead_of_overflowing():
+    """fp16's range ends at 65504.  Nothing in this model comes near it, but nothing forbids it either (a BatchNorm makes the scale
+    of the convolution in front of it free): with conv1's weights scaled by 1e5 its outputs reach ~1e6.  The fp16 stores saturate,
+    the BatchNorm behind them absorbs it: posteriors and gradients stay finite (an Inf would turn the whole step into NaNs)."""
+    model, params = gu.make_model(0, dropout=0.5, mfma_dtype="f16")
+    with torch.no_grad():
+        dict(model.named_parameters())["cnn.cnn.conv1.weight"].mul_(1e5)
+    model.train()
+    x = synth.make_input(41, 4, 216)
+    s, w = model(x.cuda(), seed=gu.seed_tensor(123))
+    (s.sum() + w.sum()).backward()
+    torch.cuda.synchronize()
+    y1 = model.ctx_view("y1")
+    assert float(y1.abs().max()) > 6.0e4, "the test must actually reach the end of fp16's range"
+    assert torch.isfinite(s).all() and torch.isfinite(w).all() and torch.isfinite(y1).all()
+    for n, p in model.named_parameters():
+        assert torch.isfinite(p.grad).all(), n
+
+
 @pytest.mark.parametrize("C,H,dtype", [(128, 256, "f32"), (64, 64, "bf16"), (128, 256, "bf16x3"), (64, 64, "f16"), (128, 256, "f16")])
 def test_generic_eval_forward_vs_oracle(C, H, dtype):
     """Eval mode (running statistics, no dropout), B = 1 (the reference's evaluation loop) and B = 3."""

@@ -267,8 +267,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bconv(const void* __restrict__
     for (int nb = 0; nb < NB; ++nb) { s1[nb] = 0.f; s2[nb] = 0.f; bv[nb] = (DIR == 0) ? bias[wn * Cfg::CHW + 32 * nb + n] : 0.f; }
 
     __syncthreads();                                                      // halo zeroed
-    if (DIR == 0 && (int)blockIdx.x < n_tiles) halo_load(blockIdx.x);
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const TileWalk walk = xcd_walk(n_tiles);                              // (common.h: consecutive tiles under one L2)
+    if (DIR == 0 && walk.first < walk.end) halo_load(walk.first);
+    for (int tile = walk.first; tile < walk.end; tile += walk.step) {
         const int b = tile / tiles_per_clip, r0 = (tile % tiles_per_clip) * TH;
         if (DIR == 1) halo_load(tile);
         if constexpr (DMA) {
@@ -286,8 +287,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_bconv(const void* __restrict__
         lds_barrier();                                                    // LDS-only barriers inside the tile loop: __syncthreads()
                                                                           // would drain the halo prefetch / the epilogue's stores
         if (DIR == 0) {       // the next tile's halo flies during this tile's MFMAs (past the end: this tile again, unused)
-            const int nt = tile + (int)gridDim.x;
-            halo_load(nt < n_tiles ? nt : tile);
+            const int nt = tile + walk.step;
+            halo_load(nt < walk.end ? nt : tile);
         }
         f32x16 acc[MB][NB];
 #pragma unroll

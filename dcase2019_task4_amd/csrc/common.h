@@ -146,6 +146,23 @@ __device__ __forceinline__ float sigmoidf_fast(float x) { return rcp_fast(1.0f +
 // sigmoid of z given e = -log2(e) * z (the scale folded into the producer's weights): one multiply less per element
 #define SED_NEG_LOG2E (-1.4426950408889634f)
 __device__ __forceinline__ float sigmoid_from_scaled(float e) { return rcp_fast(1.0f + __builtin_amdgcn_exp2f(e)); }
+// Persistent convolution kernels walk their tiles as tile = first, first + step, ... < end.  Workgroup w runs on XCD w % 8
+// (round-robin dispatch, one L2 per XCD): with the plain walk (first = w, step = grid) image tiles that are neighbours - and
+// share two halo rows - sit under eight different L2s and every halo row comes from HBM twice.  Here XCD x owns the x-th
+// eighth of the tile range (consecutive tiles = consecutive image rows of a few clips) and its grid / 8 workgroups stride
+// through it, so the eight XCDs stay as evenly loaded as with the plain walk.  Tile ORDER only: the same sums over the same
+// tiles (the wgrad kernels' partial slabs group other tiles: rounding-level differences, run-to-run deterministic as before).
+struct TileWalk { int first, end, step; };
+__device__ __forceinline__ TileWalk xcd_walk(int n_tiles) {
+    const int w = blockIdx.x, g = (int)gridDim.x;
+#ifndef SED_NO_XCD_ORDER                  // (A/B builds: tools/build_full_variant.sh)
+    if ((g & 7) == 0) {
+        const int chunk = (n_tiles + 7) >> 3, lo = (w & 7) * chunk, hi = lo + chunk < n_tiles ? lo + chunk : n_tiles;
+        return {lo + (w >> 3), hi, g >> 3};
+    }
+#endif
+    return {w, n_tiles, g};
+}
 // debug knob (sed_debug_set): bit 0 = skip the fp64 atomics of the reduction epilogues (timing experiments only)
 extern int g_sed_debug;
 

@@ -448,14 +448,15 @@ __global__ __launch_bounds__(512, 1) void k_conv_wino(const float* __restrict__ 
 #pragma unroll
         for (int k2 = 0; k2 < NH; ++k2) store_item(halo, tile, part * NH + k2, pre0[k2], pre1[MODE == 1 ? k2 : 0]);
     };
-    int tile = blockIdx.x;
+    const TileWalk walk = xcd_walk(n_tiles);
+    int tile = walk.first;
     TS(0);
     // the first halo is fetched whole, together with the weights (the accumulators are not live yet, so there are
     // registers for all of it; piecewise it cost PARTS load round trips - 7 us of prologue for dgrad)
     // (dgrad, two arrays: in two rounds - all 12 float4 at once pushed loop-invariant values into scratch)
     constexpr int FR = (MODE == 1) ? 2 : 1, FN = (NLD + FR - 1) / FR;
     f32x4_t first0[FN], first1[MODE == 1 ? FN : 1];
-    if (tile < n_tiles) {
+    if (tile < walk.end) {
 #pragma unroll
         for (int it = 0; it < FN; ++it) load_item(tile, it, first0[it], first1[MODE == 1 ? it : 0]);
     }
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wino(const float* __restrict__ 
             }
     }
     const float bia = (MODE == 0) ? bias[16 * cg + i16] : 0.f;
-    if (tile < n_tiles) {
+    if (tile < walk.end) {
 #pragma unroll
         for (int fr = 0; fr < FR; ++fr) {
             if (fr > 0) {
@@ -497,11 +498,11 @@ __global__ __launch_bounds__(512, 1) void k_conv_wino(const float* __restrict__ 
     //   ph = 0: out row 0 = q0 + q1 = qx + qy, out row 1 = q1 = qy;   ph = 1: row 0 = q2 = qy, row 1 = -q2 - q3 = qx - qy
     const float sg = ph ? -1.f : 1.f;
     int cur = 0;
-    for (; tile < n_tiles; tile += gridDim.x) {
+    for (; tile < walk.end; tile += walk.step) {
         // the prefetch is unconditional (the last iteration re-fetches its own tile into the idle buffer): with the loads and
         // the LDS stores under separate `if (has next)` the compiler must assume a load may still be in flight when its
         // registers are written again and waits there - behind the epilogue's global stores
-        const int nxt_tile = (tile + (int)gridDim.x < n_tiles) ? tile + (int)gridDim.x : tile;
+        const int nxt_tile = (tile + walk.step < walk.end) ? tile + walk.step : tile;
         const float* halo = smem + cur * C::HALO_FLOATS;
         float* halo_nxt = smem + (cur ^ 1) * C::HALO_FLOATS;
         const int b = tile / tiles_per_clip, y0 = (tile % tiles_per_clip) * C::TH;
@@ -1049,11 +1050,12 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_wino(const float* __restrict__
             for (int m = 0; m < 4; ++m) acc[p8][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m], bv, acc[p8][m], 0, 0, 0);
         }
     };
-    int tile = blockIdx.x;
+    const TileWalk walk = xcd_walk(n_tiles);
+    int tile = walk.first;
     TS(0);
     int it_ts = 0;
     int tb = tile / tiles_per_clip, ty0 = (tile % tiles_per_clip) * C::TH;
-    if (tile < n_tiles) {
+    if (tile < walk.end) {
         f32x4_t first[NITEMS];
 #pragma unroll
         for (int hy = 0; hy < NITEMS; ++hy) load_row(tb, ty0, hy, first[hy]);
@@ -1062,7 +1064,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_wino(const float* __restrict__
         for (int hy = 0; hy < NITEMS; ++hy) store_row(smem, ty0, hy, first[hy]);
     }
     __syncthreads();
-    if (tile < n_tiles) {                                    // operands of k-step 0 -> buffer 0
+    if (tile < walk.end) {                                   // operands of k-step 0 -> buffer 0
         if (ph == 0) transform_v(smem, 0, ops);
         else transform_m(ty0, 0, 0, ops + 4 * C::SV);
     }
@@ -1073,8 +1075,8 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_wino(const float* __restrict__
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[p8][m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     int cur = 0;
-    for (; tile < n_tiles; tile += gridDim.x) {
-        const int nxt = (tile + (int)gridDim.x < n_tiles) ? tile + (int)gridDim.x : tile;    // (unconditional prefetch, see k_conv_wino)
+    for (; tile < walk.end; tile += walk.step) {
+        const int nxt = (tile + walk.step < walk.end) ? tile + walk.step : tile;             // (unconditional prefetch, see k_conv_wino)
         const int nb_ = nxt / tiles_per_clip, ny0 = (nxt % tiles_per_clip) * C::TH;
         const float* halo = smem + cur * C::HALO_FLOATS;
         float* halo_nxt = smem + (cur ^ 1) * C::HALO_FLOATS;

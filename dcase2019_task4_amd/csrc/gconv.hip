@@ -130,15 +130,16 @@ __global__ __launch_bounds__(256) void k_gconv(const float* __restrict__ in0, co
         }
     };
     f32x4 hv[NL], hw[DIR == 1 ? NL : 1];
-    if (DIR == 0 && (int)blockIdx.x < n_tiles) halo_load(blockIdx.x, hv, hw);
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const TileWalk walk = xcd_walk(n_tiles);                              // (common.h: consecutive tiles under one L2)
+    if (DIR == 0 && walk.first < walk.end) halo_load(walk.first, hv, hw);
+    for (int tile = walk.first; tile < walk.end; tile += walk.step) {
         const int b = tile / tiles_per_clip, r0 = (tile % tiles_per_clip) * TH;
         if (DIR == 1) halo_load(tile, hv, hw);
         halo_store(tile, hv, hw);
         __syncthreads();
         if (DIR == 0) {       // next tile's loads fly during this tile's MFMAs (past the end: re-read this tile, harmless)
-            const int nt = tile + (int)gridDim.x;
-            halo_load(nt < n_tiles ? nt : tile, hv, hw);
+            const int nt = tile + walk.step;
+            halo_load(nt < walk.end ? nt : tile, hv, hw);
         }
         f32x16 acc[NB];
 #pragma unroll
@@ -262,7 +263,8 @@ __global__ __launch_bounds__(256) void k_gwgrad(const void* __restrict__ dz_v, c
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     __syncthreads();
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const TileWalk walk = xcd_walk(n_tiles);
+    for (int tile = walk.first; tile < walk.end; tile += walk.step) {
         const int b = tile / tiles_per_clip, r0 = (tile % tiles_per_clip) * TH;
         __syncthreads();
         for (int g = tid; g < HH * HW * 16; g += 256) {
@@ -586,8 +588,9 @@ __global__ __launch_bounds__(512, 1) void k_gwgrad_bf16(const void* __restrict__
         }
     };
     __syncthreads();
-    if (!X3 && (int)blockIdx.x < n_tiles) { load_dy(blockIdx.x); load_x(blockIdx.x); }
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const TileWalk walk = xcd_walk(n_tiles);
+    if (!X3 && walk.first < walk.end) { load_dy(walk.first); load_x(walk.first); }
+    for (int tile = walk.first; tile < walk.end; tile += walk.step) {
         if constexpr (X3 != 0) {
             x3_stage(tile);
         } else {
@@ -596,9 +599,9 @@ __global__ __launch_bounds__(512, 1) void k_gwgrad_bf16(const void* __restrict__
         }
         __syncthreads();
         if (!X3) {
-            const int nt = tile + (int)gridDim.x;
-            load_dy(nt < n_tiles ? nt : tile);
-            load_x(nt < n_tiles ? nt : tile);
+            const int nt = tile + walk.step;
+            load_dy(nt < walk.end ? nt : tile);
+            load_x(nt < walk.end ? nt : tile);
         }
         const __bf16* Ap = dyT + (size_t)(32 * wa + n) * DS + 8 * kh;
         const __bf16* Bp = xT + (size_t)(32 * wb + n) * XS + 8 * kh;
@@ -749,13 +752,14 @@ __global__ __launch_bounds__(256) void k_gwgrad4_bf16(const __bf16* __restrict__
         }
     };
     __syncthreads();
-    if ((int)blockIdx.x < n_tiles) load(blockIdx.x);
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const TileWalk walk = xcd_walk(n_tiles);
+    if (walk.first < walk.end) load(walk.first);
+    for (int tile = walk.first; tile < walk.end; tile += walk.step) {
         store(tile);
         __syncthreads();
         {
-            const int nt = tile + (int)gridDim.x;
-            load(nt < n_tiles ? nt : tile);
+            const int nt = tile + walk.step;
+            load(nt < walk.end ? nt : tile);
         }
         const __bf16* Ap = dyT + (size_t)n * DS + 8 * kh + 32 * wv;
         const __bf16* Bp = xT + (size_t)n * DS + 8 * kh + 32 * wv;

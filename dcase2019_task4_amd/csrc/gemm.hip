@@ -32,10 +32,24 @@ __global__ __launch_bounds__(256) void k_gemm_batched(GemmBatch gb) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     float* As = gsm;                                   // [GT_M][GT_K + 1]
     float* Bs = gsm + GT_M * (GT_K + 1);               // [GT_K][GT_N + 1]
-    const int pi = blockIdx.z / gb.splits, split = blockIdx.z % gb.splits;
+    // Which tile: the workgroups of one (problem, K split) share that split's rows of A (all n tiles) and of B (all m tiles).
+    // In launch order they are consecutive, i.e. dealt round-robin over the eight XCDs, and every L2 fetched every chunk: 115 MB
+    // of HBM reads per launch for 20 MB of operands at the 256-cell GRU (profiles/r05_wide-bf16_pmc_hbm_traffic.md).  The
+    // linear workgroup number is re-read so that XCD x (= number % 8) works through the x-th eighth of the (z, y, x) order.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+#ifndef SED_NO_XCD_ORDER
+    {
+        const int gx = gridDim.x, gy = gridDim.y, total = gx * gy * (int)gridDim.z;
+        if ((total & 7) == 0) {
+            const int lin = bx + gx * (by + gy * bz), l2 = (lin & 7) * (total >> 3) + (lin >> 3);
+            bx = l2 % gx; by = (l2 / gx) % gy; bz = l2 / (gx * gy);
+        }
+    }
+#endif
+    const int pi = bz / gb.splits, split = bz % gb.splits;
     const GemmProb& d = gb.p[pi];
     const int Nx = prob_nx(d);
-    const int m0 = blockIdx.y * GT_M, n0 = blockIdx.x * GT_N;
+    const int m0 = by * GT_M, n0 = bx * GT_N;
     if (m0 >= d.M || n0 >= d.N) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
@@ -43,7 +57,7 @@ __global__ __launch_bounds__(256) void k_gemm_batched(GemmBatch gb) {
     // the all-ones column of B (bias gradients = row sums of A) is NOT a GEMM column: it made a whole extra n-tile whose
     // loads took the ragged path (one branch and one wait per element - the straggler of every launch).  The n-tile-0
     // workgroups sum their A tile's rows on the VALU instead: thread (row tid >> 2, k quarter tid & 3).
-    const bool ones_here = d.Cones != nullptr && blockIdx.x == 0;
+    const bool ones_here = d.Cones != nullptr && bx == 0;
     float rowsum = 0.f;
     int kbeg = 0, kend = d.K;
     if (gb.splits > 1) {
@@ -179,14 +193,14 @@ __global__ __launch_bounds__(256) void k_gemm_batched(GemmBatch gb) {
         rowsum += __shfl_xor(rowsum, 2);
         const int row = m0 + (tid >> 2);
         if ((tid & 3) == 0 && row < d.M) {
-            if (gb.splits > 1) gb.part[(size_t)blockIdx.z * gb.part_stride + (size_t)row * Nx + d.N] = rowsum;
+            if (gb.splits > 1) gb.part[(size_t)bz * gb.part_stride + (size_t)row * Nx + d.N] = rowsum;
             else d.Cones[row] = rowsum;
         }
     }
     const int col = n0 + 32 * wn + n;
     if (col >= d.N) return;
     if (gb.splits > 1) {
-        float* P = gb.part + ((size_t)blockIdx.z * gb.part_stride);
+        float* P = gb.part + ((size_t)bz * gb.part_stride);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + 32 * wm + mfma32_row(r, lane);

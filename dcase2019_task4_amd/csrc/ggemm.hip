@@ -78,35 +78,27 @@ __global__ __launch_bounds__(256) void k_gnt_gemm(GntBatch gb) {
 // shapes (M = 1 872, N <= 768, K <= 1 536) make this a staging-bound kernel - 4 MFMAs per chunk against 32 KB of operand
 // loads - so the tile is kept small to fill the chip (60 - 720 workgroups) rather than large to feed the MFMA.
 #define GNB_KC 64
-#define GNB_PAD 8                          // row stride KC + 8 bf16 elements: an odd multiple of 16 B (conflict-free b128)
+#define GNB_S (GNB_KC + 8)                 // row stride in bf16 elements: 144 B, an odd multiple of 16 B (conflict-free b128)
 // X3 (SED_DTYPE_BF16X3): both operands split hi + lo into two LDS planes, every k-step is hi hi + hi lo + lo hi (~2^-16 per
 // product) - the projections of the wide BiGRU in the mode that holds 1e-3, in place of the exact-fp32 k_gnt_gemm above.
 // X3 = 2 (SED_DTYPE_F16, forward projections): operands rounded to fp16, one v_mfma_f32_32x32x16_f16 per k-step.
-// KC: k per double-buffered chunk.  A launch with about one workgroup per CU or less (the dX GEMMs: 60 / 240 workgroups of
-// K = 1 536) is a chain of K / KC load -> LDS -> MFMA round trips with ONE chunk in flight per CU - 24 x 1.2 - 1.5 us at
-// KC = 64 (profiles/r05_wide-bf16_step_timeline.txt: 30 / 37 us between and behind the two backward recurrences).  KC = 256
-// puts four times the bytes behind every round trip (16 float4 loads per thread and operand in flight); launches that fill the
-// chip several times over (the forward projections: 720 workgroups per model) keep KC = 64 and four workgroups per CU.
-template <int X3_, int KC>
+template <int X3_>
 __global__ __launch_bounds__(256) void k_gnt_gemm_bf16(GntBatch gb) {
     constexpr int X3 = X3_ == 1 ? 1 : 0, F16 = X3_ == 2 ? 1 : 0;
-    constexpr int NPL = X3 ? 2 : 1, S = KC + GNB_PAD, PLANE = GNT_T * S;
-    constexpr int G8 = KC / 8, NG = GNT_T * G8 / 256;             // groups of 8 k per row; groups per thread and operand
-    static_assert(X3 == 0 || KC == 64, "the split-operand planes only fit at KC = 64");
-    extern __shared__ __attribute__((aligned(16))) __bf16 gnb_sm[];
-    __bf16* As = gnb_sm;                                          // [2 buffers][NPL][64 x S]
-    __bf16* Bs = gnb_sm + 2 * NPL * PLANE;
+    constexpr int NPL = X3 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][NPL][GNT_T * GNB_S];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][NPL][GNT_T * GNB_S];
     const GntProb& d = gb.p[blockIdx.z];
     const int m0 = blockIdx.y * GNT_T, n0 = blockIdx.x * GNT_T;
     if (m0 >= d.M || n0 >= d.N) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 31, kh = lane >> 5;
     const int wm = wv >> 1, wn = wv & 1;
-    // staging: 64 rows x KC k = 64 KC / 8 groups of 8 per operand = NG per thread: row = u / G8, k8 = u % G8
-    f32x4 ra[NG][2], rb[NG][2];
+    // staging: 64 rows x 64 k = 512 groups of 8 per operand = 2 per thread: row = u >> 3, k8 = u & 7
+    f32x4 ra[2][2], rb[2][2];
     auto load = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < NG; ++i) {
-            const int u = tid + 256 * i, row = u / G8, k8 = u % G8;
+        for (int i = 0; i < 2; ++i) {
+            const int u = tid + 256 * i, row = u >> 3, k8 = u & 7;
             const int am = min(m0 + row, d.M - 1), bn = min(n0 + row, d.N - 1);      // clamped rows are never stored
             const float* a = d.A + (size_t)am * d.lda + k0 + 8 * k8;
             const float* b = d.B + (size_t)bn * d.ldb + k0 + 8 * k8;
@@ -116,8 +108,8 @@ __global__ __launch_bounds__(256) void k_gnt_gemm_bf16(GntBatch gb) {
     };
     auto store = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NG; ++i) {
-            const int u = tid + 256 * i, row = u / G8, k8 = u % G8;
+        for (int i = 0; i < 2; ++i) {
+            const int u = tid + 256 * i, row = u >> 3, k8 = u & 7;
             bf16x8 a, b, al, bl;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -126,33 +118,33 @@ __global__ __launch_bounds__(256) void k_gnt_gemm_bf16(GntBatch gb) {
                 else { a[q] = (__bf16)av; b[q] = (__bf16)bv; }
                 if constexpr (X3 != 0) { al[q] = (__bf16)(av - (float)a[q]); bl[q] = (__bf16)(bv - (float)b[q]); }
             }
-            *(bf16x8*)&As[(buf * NPL + 0) * PLANE + row * S + 8 * k8] = a;
-            *(bf16x8*)&Bs[(buf * NPL + 0) * PLANE + row * S + 8 * k8] = b;
+            *(bf16x8*)&As[buf][0][row * GNB_S + 8 * k8] = a;
+            *(bf16x8*)&Bs[buf][0][row * GNB_S + 8 * k8] = b;
             if constexpr (X3 != 0) {
-                *(bf16x8*)&As[(buf * NPL + 1) * PLANE + row * S + 8 * k8] = al;
-                *(bf16x8*)&Bs[(buf * NPL + 1) * PLANE + row * S + 8 * k8] = bl;
+                *(bf16x8*)&As[buf][1][row * GNB_S + 8 * k8] = al;
+                *(bf16x8*)&Bs[buf][1][row * GNB_S + 8 * k8] = bl;
             }
         }
     };
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int nch = d.K / KC;
+    const int nch = d.K / GNB_KC;
     load(0);
     store(0);
     __syncthreads();
     for (int ch = 0; ch < nch; ++ch) {
-        if (ch + 1 < nch) load((ch + 1) * KC);
-        const __bf16* ap = &As[((ch & 1) * NPL) * PLANE + (32 * wm + n) * S + 8 * kh];
-        const __bf16* bp = &Bs[((ch & 1) * NPL) * PLANE + (32 * wn + n) * S + 8 * kh];
+        if (ch + 1 < nch) load((ch + 1) * GNB_KC);
+        const __bf16* ap = &As[ch & 1][0][(32 * wm + n) * GNB_S + 8 * kh];
+        const __bf16* bp = &Bs[ch & 1][0][(32 * wn + n) * GNB_S + 8 * kh];
 #pragma unroll
-        for (int ks = 0; ks < KC / 16; ++ks) {
+        for (int ks = 0; ks < GNB_KC / 16; ++ks) {
             const bf16x8 a = *(const bf16x8*)(ap + 16 * ks), b = *(const bf16x8*)(bp + 16 * ks);
             if constexpr (F16 != 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
             else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
             if constexpr (X3 != 0) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, *(const bf16x8*)(bp + PLANE + 16 * ks), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(ap + PLANE + 16 * ks), b, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, *(const bf16x8*)(bp + GNT_T * GNB_S + 16 * ks), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(ap + GNT_T * GNB_S + 16 * ks), b, acc, 0, 0, 0);
             }
         }
         if (ch + 1 < nch) store((ch + 1) & 1);
@@ -169,35 +161,21 @@ __global__ __launch_bounds__(256) void k_gnt_gemm_bf16(GntBatch gb) {
     }
 }
 
-template <int X3_, int KC>
-static int gnt_bf16_launch_t(const GntBatch& gb, dim3 grid, hipStream_t st) {
-    constexpr size_t LDS = (size_t)2 * 2 * (X3_ == 1 ? 2 : 1) * GNT_T * (KC + GNB_PAD) * sizeof(__bf16);
-    static thread_local SedAttrOnce attr;
-    if (attr.need())
-        SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_gnt_gemm_bf16<X3_, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-    k_gnt_gemm_bf16<X3_, KC><<<grid, 256, LDS, st>>>(gb);
-    SED_CHECK_LAUNCH();
-    return SED_OK;
-}
-
 int launch_gnt_gemm_bf16(const GntBatch& gb, hipStream_t st, int x3) {
-    int maxM = 0, maxN = 0, minK = 1 << 30;
+    int maxM = 0, maxN = 0;
     for (int i = 0; i < gb.n_prob; ++i) {
         const GntProb& q = gb.p[i];
         SED_CHECK_ARG(q.K % GNB_KC == 0 && q.lda % 4 == 0 && q.ldb % 4 == 0 && ((uintptr_t)q.A % 16) == 0 && ((uintptr_t)q.B % 16) == 0,
                       "gnt gemm (bf16): K must be a multiple of 64 and the operands 16-byte aligned");
         maxM = q.M > maxM ? q.M : maxM;
         maxN = q.N > maxN ? q.N : maxN;
-        minK = q.K < minK ? q.K : minK;
     }
     const dim3 grid((maxN + GNT_T - 1) / GNT_T, (maxM + GNT_T - 1) / GNT_T, gb.n_prob);
-    // deep chunks where the launch is a latency chain (about a workgroup per CU or less, many k): every problem's K must divide
-    const int n_wg = (int)(grid.x * grid.y * grid.z);
-    bool deep = n_wg <= 320 && minK >= 512 && !(g_sed_debug & 33554432);      // (debug bit 25: 64-k chunks everywhere, A/B timing)
-    for (int i = 0; i < gb.n_prob; ++i) deep = deep && gb.p[i].K % 256 == 0;
-    if (x3 == 2) return deep ? gnt_bf16_launch_t<2, 256>(gb, grid, st) : gnt_bf16_launch_t<2, 64>(gb, grid, st);
-    if (x3) return gnt_bf16_launch_t<1, 64>(gb, grid, st);
-    return deep ? gnt_bf16_launch_t<0, 256>(gb, grid, st) : gnt_bf16_launch_t<0, 64>(gb, grid, st);
+    if (x3 == 2) k_gnt_gemm_bf16<2><<<grid, 256, 0, st>>>(gb);
+    else if (x3) k_gnt_gemm_bf16<1><<<grid, 256, 0, st>>>(gb);
+    else k_gnt_gemm_bf16<0><<<grid, 256, 0, st>>>(gb);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
 }
 
 int launch_gnt_gemm(const GntBatch& gb, hipStream_t st) {

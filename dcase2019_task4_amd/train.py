@@ -94,6 +94,11 @@ class MeanTeacherStep:
         self._pool_streams = bool(pool_streams)
         self._owned_streams = []
         self.T3, self.NC = self.T // 8, student._nclass
+        # the student's output heads are left to sed_mt_step_backward where the library runs them inside the backward recurrence
+        # (csrc/kernels.h heads_fusable; SED_DEFER_HEADS=0/1 overrides for A/B timing)
+        self._defer_heads = (student._H == 64 and self.T3 <= 128)
+        if os.environ.get("SED_DEFER_HEADS") in ("0", "1"):
+            self._defer_heads = os.environ["SED_DEFER_HEADS"] == "1"
         self.wlo, self.whi = _slice_range(weak_mask, self.B) if weak_mask is not None else (0, 0)
         self.slo, self.shi = _slice_range(strong_mask, self.B) if strong_mask is not None else (0, 0)
         n = student._flat.numel()
@@ -274,9 +279,15 @@ class MeanTeacherStep:
                     self._fork_exc = e
             self._fork_cb = _lib.FORK_CALLBACK(hook)      # (kept alive until the forward has run)
             _lib.check(self.l.sed_crnn_fork_callback(_lib.stream_ptr(), self._fork_cb, None), "sed_crnn_fork_callback")
-        # the student's output heads are deferred: sed_mt_step_backward runs them with the loss and their backward in front
-        # of the top layer's backward recurrence (csrc/hfuse.h)
-        self._forward(self.student, self.x, self.ctx_s, self._seed_s, None, None)
+        # the student's output heads are deferred where the library fuses them (n_RNN_cell = 64, T / 8 <= 128):
+        # sed_mt_step_backward runs them with the loss and their backward inside the top layer's backward recurrence
+        # (csrc/hfuse.h).  Other geometries (the 256-cell BiGRU) have no fused form: deferred, the student's k_heads_fwd would
+        # queue up behind the teacher's AND the join (21 us of the wide step's critical chain); run by the forward it overlaps
+        # the teacher's on the other stream.  Same kernels, same results.
+        if self._defer_heads:
+            self._forward(self.student, self.x, self.ctx_s, self._seed_s, None, None)
+        else:
+            self._forward(self.student, self.x, self.ctx_s, self._seed_s, self.strong, self.weak)
 
     def _fwd_bwd_impl(self, after_forward=None, at_recurrence=None):
         """teacher forward (main.py:87-89), student forward (:91), losses (:93-145), backward (:152-153).
@@ -308,14 +319,23 @@ class MeanTeacherStep:
             parts = 5
         else:
             parts = 3
-        _lib.check(self.l.sed_mt_step_backward(C.byref(self.dims), _lib.ptr(self.student._flat), _lib.ptr(self.x),
-                                               self._seed_s, _lib.ptr(self.ctx_s), self.ctx_bytes,
-                                               _lib.ptr(self.strong), _lib.ptr(self.weak),
-                                               _lib.ptr(self.strong_ema), _lib.ptr(self.weak_ema), _lib.ptr(self.target),
-                                               self.wlo, self.whi, self.slo, self.shi, _lib.ptr(self.state), 1,
-                                               _lib.ptr(self.losses), None, None, _lib.ptr(self.grads),
-                                               _lib.ptr(self.ws), self.ws_bytes, parts, _lib.stream_ptr()),
-                   "sed_mt_step_backward")
+        if self._defer_heads:
+            _lib.check(self.l.sed_mt_step_backward(C.byref(self.dims), _lib.ptr(self.student._flat), _lib.ptr(self.x),
+                                                   self._seed_s, _lib.ptr(self.ctx_s), self.ctx_bytes,
+                                                   _lib.ptr(self.strong), _lib.ptr(self.weak),
+                                                   _lib.ptr(self.strong_ema), _lib.ptr(self.weak_ema), _lib.ptr(self.target),
+                                                   self.wlo, self.whi, self.slo, self.shi, _lib.ptr(self.state), 1,
+                                                   _lib.ptr(self.losses), None, None, _lib.ptr(self.grads),
+                                                   _lib.ptr(self.ws), self.ws_bytes, parts, _lib.stream_ptr()),
+                       "sed_mt_step_backward")
+        else:
+            _lib.check(self.l.sed_mt_loss_backward(C.byref(self.dims), _lib.ptr(self.student._flat), _lib.ptr(self.x),
+                                                   self._seed_s, _lib.ptr(self.ctx_s), self.ctx_bytes,
+                                                   _lib.ptr(self.strong_ema), _lib.ptr(self.weak_ema), _lib.ptr(self.target),
+                                                   self.wlo, self.whi, self.slo, self.shi, _lib.ptr(self.state), 1,
+                                                   _lib.ptr(self.losses), None, None, _lib.ptr(self.grads),
+                                                   _lib.ptr(self.ws), self.ws_bytes, parts, _lib.stream_ptr()),
+                       "sed_mt_loss_backward")
 
     def _backward(self, parts):
         _lib.check(self.l.sed_crnn_backward(C.byref(self.dims), _lib.ptr(self.student._flat), _lib.ptr(self.x),

@@ -1174,6 +1174,242 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_wino(const float* __restrict__
     TS(13);
 }
 
+// ---- block-2 wgrad (W = 4), output-stationary over the Winograd transform rows --------------------------------------------------
+// k_wgrad_wino<4> gives every one of its 240 one-tile workgroups a full [9][64][64] partial slab: 35 MB written and read
+// again for 11.6 MB of operands - the slabs, not the multiplies, are that launch (profiles/r05_mt-f32_pmc_hbm_traffic.md; MFMA
+// busy 0.10).  Here a workgroup owns ONE transform row i of the Winograd-domain sum dU[i][j][co][ci] (4 positions x 64 x 64 =
+// 32 accumulator registers per lane instead of 128) over a RUN of tiles (run r: tiles r, r + R, ...; R = 64 runs x 4 rows = 256
+// workgroups, the four rows of a run under one XCD's L2: workgroup w = run (w & 7) + 8 (w >> 5), row (w >> 3) & 3).  Per
+// k-step (4 blocks) a workgroup transforms only its row - V[i][.] = (B^T d B)[i][.] needs two of the four patch rows, dM[i][.]
+// = (A dY A^T)[i][.] is a combination of the block's two dY rows - so the four rows of a run split the transform work without
+// repeating it; what they repeat is the halo staging (L2 reads).  Wave (cg, jh): positions (i, 2 jh), (i, 2 jh + 1), all 64 co,
+// ci tile cg: 8 MFMAs per k-step; transform role as in k_wgrad_wino (jh = 0: V of block cg, jh = 1: dM of block cg).
+// Epilogue: the column half of G^T dU G (j -> kernel column b: W_i[b] = sum_j dU[i][j] G[j][b]) in registers, the two jh
+// waves' halves added through LDS; 3 x 64 x 64 floats per workgroup = 12.6 MB for the launch.  k_wgrad4_os_reduce sums the
+// runs in a fixed order and applies the row half (dg[a][b] = sum_i G[i][a] W_i[b]).  Deterministic, no atomics.
+#define WG4_RUNS 64
+struct Wg4Os {
+    static constexpr int SV4 = 4 * 64 + 16, SM4 = 4 * 64, OPS4 = 4 * SV4 + 4 * SM4;      // one k-step's operands: [blk][j][64]
+    static constexpr size_t LDS_BYTES = (size_t)(2 * WgW<4>::HALO_FLOATS + 2 * OPS4) * 4; // 74 KB (the epilogue's 48 KB reuse it)
+};
+__global__ __launch_bounds__(512, 1) void k_wgrad4_os(const float* __restrict__ dz, const float* __restrict__ yin,
+                                                       const float* __restrict__ coef, const float* __restrict__ xin,
+                                                       float* __restrict__ part, int H, int tiles_per_clip, int n_tiles, int n_runs,
+                                                       BnBwdPrepArgs prep) {
+    using C = WgW<4>;
+    constexpr int SV4 = Wg4Os::SV4, SM4 = Wg4Os::SM4, OPS4 = Wg4Os::OPS4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* ops = smem + 2 * C::HALO_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = wave & 3, jh = wave >> 2;
+    const int w = blockIdx.x, run = (w & 7) + 8 * (w >> 5), ti = (w >> 3) & 3;     // (wave-uniform: SGPRs)
+    const int cg_br = cg >> 1, cg_bc = cg & 1;
+    const int i16 = lane & 15, kq = lane >> 4;
+    // row ti of B^T d: d[p] + sv d[q]; row ti of A dY: ma dY[0] + mb dY[1]
+    const int vp = (ti == 0) ? 0 : (ti == 2 ? 2 : 1), vq = (ti == 3) ? 3 : (ti == 2 ? 1 : 2);
+    const float sv = (ti == 1) ? 1.f : -1.f;
+    const float ma = (ti == 3) ? 0.f : 1.f, mb = (ti == 0) ? 0.f : (ti == 1 ? 1.f : -1.f);
+    float ca, cb, cc;
+    if (prep.acc != nullptr) bn_bwd_coef(prep, lane, ca, cb, cc);
+    else { ca = coef[lane]; cb = coef[64 + lane]; cc = coef[128 + lane]; }
+    // halo staging by image rows, as in k_wgrad_wino<4>: thread -> (row r_in of 5, column hx, channels c4 ..)
+    constexpr int NITEMS = C::NITEMS, NH = 2;
+    f32x4_t pre[NH];
+    const int td = tid < C::RPI * C::RW ? tid : tid - 480;
+    const int r_in = td / C::RW, hx = (td % C::RW) >> 4, c4 = (td & 15) * 4;
+    const int ixc = hx - 1 < 0 ? 0 : (hx - 1 > C::TW - 1 ? C::TW - 1 : hx - 1);
+    const uint32_t goff4 = (uint32_t)(ixc * 64 + c4) * 4u;
+    const bool colok = hx >= 1 && hx <= C::TW;
+    const int lds_off = hx * C::PS + c4;
+    auto load_row = [&](int b, int y0, int it, f32x4_t& d0) {
+        const int hy = it * C::RPI + r_in < C::HH ? it * C::RPI + r_in : C::HH - 1;
+        const int iy = y0 - 1 + hy;
+        const int iyc = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);
+        const float* rowp = xin + (size_t)(b * H + iyc) * (C::TW * 64);
+        d0 = *(const f32x4_t*)((const char*)rowp + goff4);
+    };
+    auto store_row = [&](float* halo, int y0, int it, const f32x4_t& s0) {
+        const int hy = it * C::RPI + r_in < C::HH ? it * C::RPI + r_in : C::HH - 1;
+        const int iy = y0 - 1 + hy;
+        const bool ok = colok && iy >= 0 && iy < H;
+        const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
+        const f32x4_t v = ok ? s0 : z4;
+        float* d = halo + hy * C::RS + lds_off;
+        *(float2*)d = make_float2(v[0], v[1]);
+        *(float2*)(d + 2) = make_float2(v[2], v[3]);
+    };
+    f32x4_t acc[2][4];
+    float dzr[2][4], yr[2][4];
+    const int img_bytes = (n_tiles / tiles_per_clip) * H * (C::TW * 64 * 4);
+    const auto rs_dz = __builtin_amdgcn_make_buffer_rsrc((void*)dz, (short)0, img_bytes, 0x00020000);
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)yin, (short)0, img_bytes, 0x00020000);
+    const int lane4 = 4 * lane;
+    auto load_dy = [&](int b, int y0, int ks, int slot) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int yy = y0 + 2 * (C::br_ks(ks) + cg_br) + (q >> 1), xx = 2 * (C::bc_ks(ks) + cg_bc) + (q & 1);
+            const int yc = yy < H ? yy : H - 1;                          // (masked by multiplication in the transform)
+            const int so = ((b * H + yc) * C::TW + xx) * 256;
+            dzr[slot][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_dz, lane4, so, 0));
+            yr[slot][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_y, lane4, so, 0));
+        }
+    };
+    // V[ti][j] of block cg of k-step ks, channel lane -> Vs[cg][j][lane]
+    auto transform_v = [&](const float* halo, int ks, float* Vs) {
+        const float* P = halo + (2 * cg_br) * C::RS + (2 * cg_bc) * C::PS + lane + ((2 * C::br_ks(ks)) * C::RS + (2 * C::bc_ks(ks)) * C::PS);
+        const float* Pp = P + vp * C::RS;
+        const float* Pq = P + vq * C::RS;
+        float T[4];
+#pragma unroll
+        for (int b2 = 0; b2 < 4; ++b2) T[b2] = fmaf(sv, Pq[b2 * C::PS], Pp[b2 * C::PS]);
+        float* Vd = Vs + cg * SV4 + lane;
+        Vd[0] = T[0] - T[2]; Vd[64] = T[1] + T[2]; Vd[128] = T[2] - T[1]; Vd[192] = T[1] - T[3];
+    };
+    // dM[ti][j] of the same block, channel lane -> Ms[cg][j][co']
+    auto transform_m = [&](int y0, int ks, int slot, float* Ms) {
+        float dy[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float v = fmaf(ca, dzr[slot][q], fmaf(cb, yr[slot][q], cc));
+            dy[q] = v * ((y0 + 2 * (C::br_ks(ks) + cg_br) + (q >> 1) < H) ? 1.f : 0.f);
+        }
+        const float R0 = ma * dy[0] + mb * dy[2], R1 = ma * dy[1] + mb * dy[3];
+        float* Md = Ms + cg * SM4 + 4 * (lane & 15) + (lane >> 4);
+        Md[0] = R0; Md[64] = R0 + R1; Md[128] = R0 - R1; Md[192] = -R1;
+    };
+    auto mma = [&](const float* Vs, const float* Ms) {
+        const float* Ab = Ms + kq * SM4 + 4 * i16 + 128 * jh;
+        const float* Bb = Vs + kq * SV4 + 16 * cg + i16 + 128 * jh;
+#pragma unroll
+        for (int j2 = 0; j2 < 2; ++j2) {
+            const f32x4_t a4 = *(const f32x4_t*)(Ab + 64 * j2);
+            const float bv = Bb[64 * j2];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[j2][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m], bv, acc[j2][m], 0, 0, 0);
+        }
+    };
+    int tile = run;
+    int tb = tile / tiles_per_clip, ty0 = (tile % tiles_per_clip) * C::TH;
+    if (tile < n_tiles) {
+        f32x4_t first[NITEMS];
+#pragma unroll
+        for (int hy = 0; hy < NITEMS; ++hy) load_row(tb, ty0, hy, first[hy]);
+        if (jh) { load_dy(tb, ty0, 0, 0); load_dy(tb, ty0, 1, 1); }
+#pragma unroll
+        for (int hy = 0; hy < NITEMS; ++hy) store_row(smem, ty0, hy, first[hy]);
+    }
+    __syncthreads();
+    if (tile < n_tiles) {
+        if (jh == 0) transform_v(smem, 0, ops);
+        else transform_m(ty0, 0, 0, ops + 4 * SV4);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[j2][m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    int cur = 0;
+    for (; tile < n_tiles; tile += n_runs) {
+        const int nxt = (tile + n_runs < n_tiles) ? tile + n_runs : tile;          // (unconditional prefetch, see k_conv_wino)
+        const int nb_ = nxt / tiles_per_clip, ny0 = (nxt % tiles_per_clip) * C::TH;
+        const float* halo = smem + cur * C::HALO_FLOATS;
+        float* halo_nxt = smem + (cur ^ 1) * C::HALO_FLOATS;
+        constexpr int NKS = C::NKS, NPIECE = (NITEMS + NH - 1) / NH;              // 4 k-steps, 2 pieces
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            f32x4_t held[NH];
+            if (ks >= 1 && ks <= NPIECE) {
+#pragma unroll
+                for (int k2 = 0; k2 < NH; ++k2) held[k2] = pre[k2];
+            }
+            if (ks < NPIECE) {
+#pragma unroll
+                for (int k2 = 0; k2 < NH; ++k2)
+                    if (NH * ks + k2 < NITEMS) load_row(nb_, ny0, NH * ks + k2, pre[k2]);
+            }
+            float* nb = ops + ((ks + 1) & 1) * OPS4;
+            const float* cb2 = ops + (ks & 1) * OPS4;
+            if (jh == 0) {
+                if (ks < NKS - 1) transform_v(halo, ks + 1, nb); else transform_v(halo_nxt, 0, nb);
+            }
+            mma(cb2, cb2 + 4 * SV4);
+            if (jh == 1) {
+                if (ks < NKS - 2) load_dy(tb, ty0, ks + 2, ks & 1); else load_dy(nb_, ny0, ks - (NKS - 2), ks & 1);
+                if (ks < NKS - 1) transform_m(ty0, ks + 1, (ks + 1) & 1, nb + 4 * SV4); else transform_m(ny0, 0, 0, nb + 4 * SV4);
+            }
+            if (ks >= 1 && ks <= NPIECE) {
+#pragma unroll
+                for (int k2 = 0; k2 < NH; ++k2)
+                    if (NH * (ks - 1) + k2 < NITEMS) store_row(halo_nxt, ny0, NH * (ks - 1) + k2, held[k2]);
+            }
+            lds_barrier();
+        }
+        cur ^= 1;
+        tb = nb_; ty0 = ny0;
+    }
+    // ---- epilogue: W[b] = sum_j dU[ti][j] G[j][b], G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]; jh = 0 holds j = 0, 1, jh = 1 j = 2, 3 ----
+    __syncthreads();
+    float* xb = smem + (size_t)cg * 48 * 64 + lane;           // [cg][(m, r, b)][lane]
+    if (jh == 1) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float u2 = acc[0][m][r], u3 = acc[1][m][r];
+                xb[((m * 4 + r) * 3 + 0) * 64] = 0.5f * u2;
+                xb[((m * 4 + r) * 3 + 1) * 64] = -0.5f * u2;
+                xb[((m * 4 + r) * 3 + 2) * 64] = 0.5f * u2 + u3;
+            }
+    }
+    __syncthreads();
+    if (jh == 0) {
+        float* dst = part + ((size_t)run * 4 + ti) * 3 * 4096 + 16 * cg + i16;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float u0 = acc[0][m][r], u1 = acc[1][m][r];
+                const int co = 16 * m + 4 * kq + r;
+                dst[(0 * 64 + co) * 64] = (u0 + 0.5f * u1) + xb[((m * 4 + r) * 3 + 0) * 64];
+                dst[(1 * 64 + co) * 64] = 0.5f * u1 + xb[((m * 4 + r) * 3 + 1) * 64];
+                dst[(2 * 64 + co) * 64] = 0.5f * u1 + xb[((m * 4 + r) * 3 + 2) * 64];
+            }
+    }
+}
+
+// part [run][row i][b][co][ci] -> g_w[co][ci][3 a + b] = sum_i G[i][a] sum_run part.  A workgroup owns 64 consecutive (co, ci)
+// as 16 float4 columns; its 16 thread groups take every 16th run for all 12 (i, b) planes, then combine through LDS.
+__global__ __launch_bounds__(256) void k_wgrad4_os_reduce(const float* __restrict__ part, int n_runs, float* __restrict__ g_w) {
+    __shared__ __attribute__((aligned(16))) float red[16][12][64];
+    __shared__ float S[12][64];
+    const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const f32x4_t* P = (const f32x4_t*)part + blockIdx.x * 16 + c;
+    f32x4_t s[12];
+#pragma unroll
+    for (int pl = 0; pl < 12; ++pl) s[pl] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int r = grp; r < n_runs; r += 16) {
+#pragma unroll
+        for (int pl = 0; pl < 12; ++pl) s[pl] += P[((size_t)r * 12 + pl) * 1024];
+    }
+#pragma unroll
+    for (int pl = 0; pl < 12; ++pl) *(f32x4_t*)&red[grp][pl][4 * c] = s[pl];
+    __syncthreads();
+    for (int o = threadIdx.x; o < 12 * 64; o += 256) {
+        const int pl = o >> 6, e = o & 63;
+        float v = 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < 16; ++g2) v += red[g2][pl][e];
+        S[pl][e] = v;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 64 * 9; o += 256) {
+        const int e = o / 9, tap = o % 9, a = tap / 3, b = tap % 3;
+        const float w0 = S[0 + b][e], w1 = S[3 + b][e], w2 = S[6 + b][e], w3 = S[9 + b][e];
+        const float v = a == 0 ? w0 + 0.5f * (w1 + w2) : (a == 1 ? 0.5f * (w1 - w2) : 0.5f * (w1 + w2) + w3);
+        g_w[(size_t)blockIdx.x * 64 * 9 + o] = v;
+    }
+}
+
 // Sum of the per-workgroup partial slabs, in a fixed order (bit-reproducible).  A workgroup owns 64 consecutive outputs
 // as 16 float4 columns; its 16 thread groups take every 16th slab (8 independent float4 loads in flight per thread - the
 // scalar version with 4 groups had 32 B per thread in flight and ran at 3.1 TB/s), then combine through LDS.
@@ -1291,6 +1527,23 @@ static int wgrad_launch_t(const float* dz, const float* yin, const float* coef, 
     // 1.162 ms per step although its 154 KB of LDS keep any other workgroup off its CU); bit 3 of the debug knob = old
     // default: Winograd-domain kernel (block 1: operator 65 us against 105 us for the direct double-buffered kernel); bits 3 / 7
     // of the debug knob bring the direct kernels back (bit 7 = k_wgrad16_db for block 1, bit 3 = the tile kernel)
+    if (TW == 4 && !SED_AB_FLAGS(8 | 128) && !(g_sed_debug & 67108864)) {      // (debug bit 26: k_wgrad_wino<4>, the slab form, A/B)
+        using CW = WgW<4>;
+        static thread_local SedAttrOnce attro;
+        if (attro.need()) {
+            SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_wgrad4_os, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wg4Os::LDS_BYTES));
+        }
+        SED_CHECK_ARG((size_t)B * H * TW * 64 < ((size_t)1 << 31), "wgrad: image too large for 32-bit offsets");
+        const int tpcw = (H + CW::TH - 1) / CW::TH, ntw = B * tpcw;
+        int n_runs = (ntw + 7) & ~7;
+        if (n_runs > WG4_RUNS) n_runs = WG4_RUNS;
+        SED_CHECK_ARG(n_runs * 4 <= n_blocks * 3, "wgrad: partial buffer too small");          // 12 x 4096 floats per run against 9 x 4096 per block
+        k_wgrad4_os<<<4 * n_runs, 512, Wg4Os::LDS_BYTES, st>>>(dz, yin, coef, xin, part, H, tpcw, ntw, n_runs, pa);
+        SED_CHECK_LAUNCH();
+        k_wgrad4_os_reduce<<<4096 / 64, 256, 0, st>>>(part, n_runs, g_w);
+        SED_CHECK_LAUNCH();
+        return SED_OK;
+    }
     if (!SED_AB_FLAGS(8 | 128)) {
         using CW = WgW<TW>;
         static thread_local SedAttrOnce attrw;

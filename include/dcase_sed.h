@@ -402,7 +402,9 @@ int sed_kernel_replay(const char* name, const sed_dims* d, const float* params, 
  *   bit 17 late GRU weight-gradient schedule, bit 18 round-2 GLU kernels, bit 19 round-2 STFT kernel, bit 20 block-1
  *   convolution (bf16, C = 128) by the barrier-free k_bconv2.
  *   bit 24: sed_mt_step_backward runs the deferred heads as separate kernels (k_heads_fwd, k_heads_bwd) instead of fused
- *   into the backward recurrence (A/B timing and the bit-identity test). */
+ *   into the backward recurrence (A/B timing and the bit-identity test); bit 26: the block-2 (W = 4) weight gradient of the fp32
+ *   path by k_wgrad_wino<4> (one full partial slab per tile) instead of the output-stationary k_wgrad4_os - same sums, other
+ *   order (A/B timing and parity test). */
 int sed_debug_set(int flags);
 /* bit 0: the library was built with the A/B baseline kernels (make EXTRA=-DSED_AB); without it debug bits 1, 2, 3, 6, 7
  * are ignored - the shipped library carries the product path only. */

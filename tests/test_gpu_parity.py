@@ -179,6 +179,43 @@ def test_winograd_kernels_match_the_direct_convolution_kernels(B, T):
         assert err < 2e-4 * scale + 1e-7, n           # (+1e-7: gradients that cancel to ~0, e.g. the softmax bias)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(24, 628), (4, 628), (3, 150), (2, 22), (70, 250)])
+def test_output_stationary_block2_wgrad_matches_the_slab_kernel(B, T):
+    """Block 2's weight gradient (W = 4) is output-stationary over the Winograd transform rows (k_wgrad4_os: a workgroup owns one
+    row of the 4 x 4 domain over a run of tiles, 12.6 MB of partials) instead of one full [9][64][64] slab per tile
+    (k_wgrad_wino<4>, 35 MB; debug bit 26).  Same products, other summation order: conv2's weight gradient agrees to fp32
+    rounding, everything else bit for bit.  (24, 628) = the headline shape (240 tiles on 64 runs); T = 150 / 22: tiles cut by the
+    image border and fewer tiles than runs; (70, 250): runs of up to 5 tiles, the last one short."""
+    from dcase2019_task4_amd import _lib
+    l = _lib.lib()
+    outs = []
+    for flags in (0, 1 << 26):
+        prev = l.sed_debug_set(flags)
+        try:
+            model, _ = gu.make_model(0, dropout=0.5)
+            model.train()
+            x = synth.make_input(43, B, T)
+            s, w = model(x.cuda(), seed=gu.seed_tensor(778))
+            loss = (s * s).mean() + (w * w).mean() + s.mean()
+            loss.backward()
+            torch.cuda.synchronize()
+            outs.append((s.detach().cpu(), w.detach().cpu(), gu.grads_dict(model)))
+        finally:
+            l.sed_debug_set(prev)
+    (s0, w0, g0), (s1, w1, g1) = outs
+    assert torch.equal(s0, s1) and torch.equal(w0, w1)
+    for n in g0:
+        if n == "cnn.cnn.conv2.weight":
+            scale = float(g1[n].double().norm()) / np.sqrt(g1[n].numel()) + 1e-30
+            err = float((g0[n] - g1[n]).abs().max())
+            print(f"[wgrad4 os vs slab] {n} err/typ {err / scale:.2e}")
+            assert err < 2e-5 * scale + 1e-9, n
+            assert err > 0 or B * T < 100, "both runs took the same kernel?"
+        else:
+            assert torch.equal(g0[n], g1[n]), n
+
+
 @pytest.mark.parametrize("B,T,p,n_layers,nclass", [(4, 128, 0.0, 2, 10), (4, 128, 0.5, 2, 10), (4, 628, 0.5, 2, 10),
                                                    (5, 216, 0.5, 1, 10), (4, 150, 0.25, 2, 10), (7, 1040, 0.5, 2, 10),
                                                    (4, 864, 0.5, 2, 10), (6, 96, 0.5, 2, 1), (5, 200, 0.5, 2, 16),

@@ -17,11 +17,29 @@
 #define GNT_S (GNT_KC + 1)
 #define GNT_T 64          // output tile: 64 x 64 per workgroup, one 32 x 32 accumulator per wave
 
+// Which output tile a workgroup computes.  In launch order (n tile fastest) the workgroups that share an A row panel - all n
+// tiles of one m tile - are consecutive, i.e. dealt round-robin over the eight XCDs, and every L2 fetched every panel (35 MB
+// of HBM reads per launch, six launches per wide step).  The linear workgroup number is re-read XCD-major: XCD x (= number % 8)
+// works through the x-th eighth of the (problem, m tile, n tile) order, so an A panel lives under ONE L2 and only the weight
+// matrix is fetched by all eight.  Same tiles, same sums: results are bit-identical.
+__device__ __forceinline__ void gnt_tile_of_workgroup(int& bx, int& by, int& bz) {
+    bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+#ifndef SED_NO_XCD_ORDER
+    const int gx = gridDim.x, gy = gridDim.y, total = gx * gy * (int)gridDim.z;
+    if ((total & 7) == 0) {
+        const int lin = bx + gx * (by + gy * bz), l2 = (lin & 7) * (total >> 3) + (lin >> 3);
+        bx = l2 % gx; by = (l2 / gx) % gy; bz = l2 / (gx * gy);
+    }
+#endif
+}
+
 __global__ __launch_bounds__(256) void k_gnt_gemm(GntBatch gb) {
     __shared__ float As[2][GNT_T * GNT_S];
     __shared__ float Bs[2][GNT_T * GNT_S];
-    const GntProb& d = gb.p[blockIdx.z];
-    const int m0 = blockIdx.y * GNT_T, n0 = blockIdx.x * GNT_T;
+    int bx, by, bz;
+    gnt_tile_of_workgroup(bx, by, bz);
+    const GntProb& d = gb.p[bz];
+    const int m0 = by * GNT_T, n0 = bx * GNT_T;
     if (m0 >= d.M || n0 >= d.N) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 31, kh = lane >> 5;
     const int wm = wv >> 1, wn = wv & 1;
@@ -88,8 +106,10 @@ __global__ __launch_bounds__(256) void k_gnt_gemm_bf16(GntBatch gb) {
     constexpr int NPL = X3 ? 2 : 1;
     __shared__ __attribute__((aligned(16))) __bf16 As[2][NPL][GNT_T * GNB_S];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[2][NPL][GNT_T * GNB_S];
-    const GntProb& d = gb.p[blockIdx.z];
-    const int m0 = blockIdx.y * GNT_T, n0 = blockIdx.x * GNT_T;
+    int bx, by, bz;
+    gnt_tile_of_workgroup(bx, by, bz);
+    const GntProb& d = gb.p[bz];
+    const int m0 = by * GNT_T, n0 = bx * GNT_T;
     if (m0 >= d.M || n0 >= d.N) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 31, kh = lane >> 5;
     const int wm = wv >> 1, wn = wv & 1;

@@ -798,7 +798,11 @@ __global__ __launch_bounds__(640) void k_blk0_bwd_finalize(Blk0BwdFinArgs a) {
     __shared__ double Ds[128][10];
     __shared__ double Ss[16][10];
     __shared__ double moms[54];
+    __shared__ float Wc[128][16];               // W_glu[co][c0 .. c0 + 16): this workgroup's columns of the S sum below
     const int tid = threadIdx.x, C = a.C, c0 = blockIdx.x * 16;
+    // (requested up front, 64 contiguous bytes per row: as `a.wglu[co * C + c]` inside the S loop every one of its 16 - 32 trips was a
+    // strided global load behind an fp64 accumulation - 20 us solo at C = 128, at the very end of the wide step)
+    for (int e = tid; e < C * 16; e += 640) Wc[e >> 4][e & 15] = a.wglu[(size_t)(e >> 4) * C + c0 + (e & 15)];
     for (int e = tid; e < C * 10; e += 640) {   // (c, t)
         const int c = e / 10, t = e % 10;
         const double scale = a.bn[2 * C + c], shift = a.bn[3 * C + c];
@@ -820,7 +824,7 @@ __global__ __launch_bounds__(640) void k_blk0_bwd_finalize(Blk0BwdFinArgs a) {
         const int e = tid >> 2, part = tid & 3;        // e < 160
         const int c = c0 + e / 10, t = e % 10;
         double acc = 0;
-        for (int co = part; co < C; co += 4) acc += (double)a.wglu[(size_t)co * C + c] * Ds[co][t];
+        for (int co = part; co < C; co += 4) acc += (double)Wc[co][e / 10] * Ds[co][t];
         acc += __shfl_xor(acc, 1);
         acc += __shfl_xor(acc, 2);
         if (part == 0) Ss[e / 10][t] = acc + a.de[C * 10 + c * 10 + t];

@@ -133,7 +133,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_blk0_prep(Blk0PrepArgs a) {
     const int C = a.C;
     __shared__ double mred[54][16];
     __shared__ double moms[54];
-    __shared__ __attribute__((aligned(16))) float wgl[128 * 128];          // Wglu, staged for the fold at the end
+    __shared__ float wgl[128 * 129];          // Wglu, staged for the fold at the end; row stride C + 1: the fold's lanes read one k of
+                                              // ~7 different rows at a time - at stride C = 64 / 128 all of them in one bank
     const int tid = threadIdx.x;
     // Everything this one-workgroup kernel reads is requested up front, so that its ~10 us are ONE memory round trip instead
     // of three in a row (partials -> per-channel parameters -> Wglu): Wglu as float4 into registers (<= 5 per thread), the
@@ -190,7 +191,10 @@ __global__ __launch_bounds__(PREP_THREADS) void k_blk0_prep(Blk0PrepArgs a) {
 #pragma unroll
     for (int u = 0; u < NWG; ++u) {
         const int e = tid + PREP_THREADS * u;
-        if (e < nwg4) *(f32x4*)&wgl[4 * e] = wgv[u];
+        if (e < nwg4) {
+            float* d = &wgl[(4 * e / C) * (C + 1) + (4 * e % C)];
+            d[0] = wgv[u][0]; d[1] = wgv[u][1]; d[2] = wgv[u][2]; d[3] = wgv[u][3];
+        }
     }
     if (tid < C) {
         const int c = tid;
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_blk0_prep(Blk0PrepArgs a) {
     for (int e = tid; e < C * 10; e += PREP_THREADS) {   // wl[c][t] = sum_k Wglu[c][k] wz[k][t] (+ bglu at t = 9): one thread per (c, t)
         const int c = e / 10, t = e % 10;
         double acc = (t == 9) ? (double)a.bglu[c] : 0.0;
-        for (int k = 0; k < C; ++k) acc += (double)wgl[c * C + k] * wzs[k][t];
+        for (int k = 0; k < C; ++k) acc += (double)wgl[c * (C + 1) + k] * wzs[k][t];
         a.wl[c * 12 + t] = (float)acc;
     }
 }

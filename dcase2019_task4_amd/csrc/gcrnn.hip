@@ -92,7 +92,7 @@ static GWs make_gws(const Geo& g) {
     put(W.d_out, bt * 2 * H * 4);
     for (int l = 0; l < 2; ++l) { put(W.dgi[l], bt * 6 * H * 4); put(W.dgh[l], bt * 6 * H * 4); put(W.hprev[l], bt * 2 * H * 4); }
     put(W.d_in, 2 * bt * 2 * H * 4);          // (H = 64: two direction planes, gru.hip; generic: one tensor)
-    put(W.heads_part, (size_t)g.B * 2 * (g.NC * 2 * H + g.NC) * 4);
+    put(W.heads_part, heads_part_floats(g.B, g.T3, g.NC, 2 * H) * 4);
     const size_t SS = ssz(g);
     put(W.dp[2], 2 * bt * C * 4); put(W.dz[2], n1 * SS); put(W.dp[1], n1 * SS); put(W.dz[1], n0 * SS); put(W.dp[0], n0 * SS);
     W.dz[0] = 0; W.coef[0] = 0;
@@ -376,7 +376,7 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
     const bool fuse = ho && hl && (parts & 1) && heads_fusable(H, g.T3) && !(g_sed_debug & 16777216) && !hl->d_strong_out && !hl->d_weak_out;
     auto heads_colsum = [&](hipStream_t s2) -> int {
         if (fuse) return launch_heads_fin(WSF(W.heads_part), grads + P.dense_w, g.B, g.T3, g.NC, head_cols, *hl, s2);
-        return launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, s2, 2 * H);
+        return launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B * heads_bwd_chunks(2 * H, g.T3), g.NC, s2, 2 * H);
     };
     const bool defer_colsum = ((parts & 2) && have_side) || defer_gru_w;
     if (parts & 1) {
@@ -455,7 +455,7 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
     }
     if (parts == 1) SED_TRY(gru_weight_grads(st));
     if (parts == 8) {
-        SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B, g.NC, st, 2 * H));
+        SED_TRY(launch_heads_colsum(WSF(W.heads_part), grads + P.dense_w, g.B * heads_bwd_chunks(2 * H, g.T3), g.NC, st, 2 * H));
         SED_TRY(gru_weight_grads(st));
         return SED_OK;
     }

@@ -211,7 +211,8 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_bwd(const float* __restric
     constexpr int TPW = HF / 128;                      // dW tiles (16 outputs x 16 features) per wave: 2 x HF / 16 tiles, 16 waves
     extern __shared__ __attribute__((aligned(16))) float hsm[];
     // the fp64 accumulators of the conv-block backward that follows (saves a memset node on the critical path)
-    for (int i = blockIdx.x * HD_THREADS + threadIdx.x; i < n_zero; i += gridDim.x * HD_THREADS) zero[i] = 0.0;
+    if (blockIdx.y == 0)
+        for (int i = blockIdx.x * HD_THREADS + threadIdx.x; i < n_zero; i += gridDim.x * HD_THREADS) zero[i] = 0.0;
     float* xs = hsm;                                   // [HD_TC][HD_SB]
     float* wsm = xs + HD_TC * HD_SB;                   // [HD_MAXO][HD_SB]
     float* dl = wsm + HD_MAXO * HD_SB;                 // [HD_TC][HD_SD]
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_bwd(const float* __restric
     float* dden = dnum + 16;
     uint32_t* mk = (uint32_t*)(dden + 16);             // [HD_TC][HF / 16] keep bits of the staged chunk
     const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int NY = gridDim.y, cy = blockIdx.y;         // this workgroup's share of the clip: chunks cy, cy + NY, ... (kernels.h heads_bwd_chunks)
     const int i16 = lane & 15, kq = lane >> 4;
     const uint64_t seed = use_drop ? seed_ptr[0] : 0ull;
     const uint32_t thr = drop_thresh8(p_drop);
@@ -246,12 +248,13 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_bwd(const float* __restric
         if (fused) {
             const float p = weak[b * NC + tid], pe = hl.weak_ema[b * NC + tid];
             const float diff = p - pe;
-            lacc[3] = diff * diff;
+            const float once = cy == 0 ? 1.f : 0.f;          // the clip-level terms enter the sums through ONE of the clip's workgroups
+            lacc[3] = once * diff * diff;
             dw = cw * 2.0f * diff * inv_nW;
             if (in_w) {
                 const float t = tmaxs[tid];
-                lacc[0] = bce_term(p, t);
-                lacc[4] = bce_term(pe, t);
+                lacc[0] = once * bce_term(p, t);
+                lacc[4] = once * bce_term(pe, t);
                 dw += bce_grad(p, t) * inv_wb;
             }
             if (hl.d_weak_out) hl.d_weak_out[b * NC + tid] = dw;
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_bwd(const float* __restric
 #pragma unroll
     for (int q = 0; q < TPW; ++q) wacc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float bacc = 0.f;    // thread o < NO
-    for (int t0 = 0; t0 < T; t0 += HD_TC) {
+    for (int t0 = cy * HD_TC; t0 < T; t0 += NY * HD_TC) {
         __syncthreads();
         mk[tid] = heads_stage<HF, HD_SB>(h, xs, b, T, t0, use_drop, seed, thr, ks, tid);
         {   // softmax / sigmoid backward of the chunk's frames: 8 threads per frame, thread `sub` takes classes sub and sub + 8
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_bwd(const float* __restric
             }
         }
     }
-    float* pr = part + (size_t)b * (2 * (NC * HD_F + NC));
+    float* pr = part + (size_t)(b * NY + cy) * (2 * (NC * HD_F + NC));
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
         const int tile = wv * TPW + q, ot = tile / HD_GPF, ft = tile % HD_GPF, f = 16 * ft + i16;
@@ -400,31 +403,32 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_bwd(const float* __restric
         if (lane == 0) red[wv * 8 + k] = v;
     }
     __syncthreads();
-    float* lpart = hl.losses + 8;
+    const int NP = B * NY;                              // loss partials: one per workgroup, summed in (clip, chunk) order
+    float* lpart = NY == 1 ? hl.losses + 8 : part + (size_t)NP * (2 * (NC * HD_F + NC));
     unsigned int* ticket = (unsigned int*)(hl.losses + 8 + 8 * B);
     __shared__ int is_last;
     if (tid < 6) {
         float s2 = 0.f;
         for (int w2 = 0; w2 < HD_THREADS / 64; ++w2) s2 += red[w2 * 8 + tid];
-        lpart[8 * b + tid] = s2;
+        lpart[8 * (b * NY + cy) + tid] = s2;
         __threadfence();
     }
     __syncthreads();
-    if (tid == 0) is_last = (atomicAdd(ticket, 1u) == (unsigned int)(B - 1));
+    if (tid == 0) is_last = (atomicAdd(ticket, 1u) == (unsigned int)(NP - 1));
     __syncthreads();
     if (!is_last) return;
     __threadfence();
     {   // all per-clip partials in ONE round trip (a 6-thread loop over the clips paid one memory latency per clip), then
         // six threads add them up in clip order
         float* stage = dl + 128;                             // [8 * B] behind the wave partials (B <= 512; larger batches: loop)
-        const bool staged = 8 * B <= HD_TC * HD_SD - 128;
+        const bool staged = 8 * NP <= HD_TC * HD_SD - 128;
         if (staged)
-            for (int e = tid; e < 8 * B; e += HD_THREADS) stage[e] = __builtin_nontemporal_load(&lpart[e]);
+            for (int e = tid; e < 8 * NP; e += HD_THREADS) stage[e] = __builtin_nontemporal_load(&lpart[e]);
         __syncthreads();
         if (tid < 6) {
             float s2 = 0.f;
-            if (staged) for (int bb = 0; bb < B; ++bb) s2 += stage[8 * bb + tid];
-            else for (int bb = 0; bb < B; ++bb) s2 += __builtin_nontemporal_load(&lpart[8 * bb + tid]);
+            if (staged) for (int bb = 0; bb < NP; ++bb) s2 += stage[8 * bb + tid];
+            else for (int bb = 0; bb < NP; ++bb) s2 += __builtin_nontemporal_load(&lpart[8 * bb + tid]);
             red[tid] = s2;
         }
     }
@@ -606,6 +610,7 @@ int launch_heads_fwd(const float* h, const float* wd, const float* bd, const flo
     return SED_ERR_UNSUPPORTED;
 }
 
+// B = number of partial slabs (clips x heads_bwd_chunks)
 int launch_heads_colsum(const float* part, float* g_wd, int B, int NC, hipStream_t st, int HF) {
     // dense.weight, dense.bias, dense_softmax.weight, dense_softmax.bias are contiguous in the flat layout
     return launch_colsum(part, B, 2 * (NC * HF + NC), 2 * (NC * HF + NC), g_wd, st);
@@ -622,8 +627,8 @@ static int heads_bwd_launch(const float* h, const float* wd, const float* ws, co
     if (attr_done.need()) {
         SED_CHECK_HIP(hipFuncSetAttribute((const void*)k_heads_bwd<HF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    k_heads_bwd<HF><<<B, HD_THREADS, lds, st>>>(h, wd, ws, strong, weak, logits_s, den, d_strong, d_weak, dh, part, T, NC, use_drop,
-                                                p_drop, seed, zero, zero ? n_zero : 0, hl0);
+    k_heads_bwd<HF><<<dim3(B, heads_bwd_chunks(HF, T)), HD_THREADS, lds, st>>>(h, wd, ws, strong, weak, logits_s, den, d_strong, d_weak, dh,
+                                                                               part, T, NC, use_drop, p_drop, seed, zero, zero ? n_zero : 0, hl0);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
@@ -645,7 +650,7 @@ int launch_heads_bwd(const float* h, const float* wd, const float* ws, const flo
         return SED_ERR_UNSUPPORTED;
     }
     if (rc != SED_OK || defer_colsum) return rc;
-    return launch_heads_colsum(part, g_wd, B, NC, st, HF);
+    return launch_heads_colsum(part, g_wd, B * heads_bwd_chunks(HF, T), NC, st, HF);
 }
 
 extern "C" int sed_mt_loss(const sed_dims* d, const float* strong, const float* weak, const float* strong_ema,

@@ -280,6 +280,19 @@ struct HeadsFuse {
     double* zero; int n_zero;           // fp64 accumulators of the conv-block backward to clear (may be null / 0)
     HeadsLoss hl;                       // strong_ema != null always (the fused form IS the loss); d_strong_out / d_weak_out unused
 };
+// k_heads_bwd at HF = 512 (the 256-cell BiGRU) works through a clip in 32-frame chunks; they are independent of each other (the
+// per-clip terms come from the forward's saved sums), so a clip's chunks go to separate workgroups: grid (B, chunks), one
+// weight-gradient partial slab and one loss partial per workgroup (the loss partials of a multi-chunk launch live behind the
+// slabs in the workspace: sed_mt_loss's SED_LOSS_FLOATS(B) contract is unchanged).  HF = 128: one 128-frame chunk, one workgroup.
+static inline int heads_bwd_chunks(int HF, int T3) {
+    if (HF != 512) return 1;
+    const int n = (T3 + 31) / 32;
+    return n < 1 ? 1 : (n > 8 ? 8 : n);
+}
+static inline size_t heads_part_floats(int B, int T3, int NC, int HF) {
+    const int ny = heads_bwd_chunks(HF, T3);
+    return (size_t)B * ny * 2 * (NC * HF + NC) + (size_t)8 * B * ny;
+}
 struct HeadsOut { float *strong, *weak; };       // sed_mt_step_backward: where the deferred heads' posteriors go
 // the frames (T / 8) and hidden size the fused form serves; everything else takes k_heads_fwd + k_heads_bwd
 static inline bool heads_fusable(int H, int T3) { return H == 64 && T3 <= 128; }

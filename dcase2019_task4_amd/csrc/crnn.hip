@@ -544,7 +544,13 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
                                     params + P.bn_g[i], WSF(W.coef[i]), grads + P.bn_g[i], grads + P.bn_b[i],
                                     grads + P.glu_w[i], grads + P.glu_b[i], grads + P.conv_b[i], fuse_prep ? &prep[i] : nullptr, st));
         if (i == 2) {
-            if (sd.ok) { SIDE_FORK(st); forked = true; }
+            // The fork event is recorded here, but the dgrad - the critical chain - is CAPTURED FIRST: the graph executor keeps the
+            // first-captured child of a node on its parent's hardware queue; with the helper stream's wgrad captured first the
+            // dgrad hopped to another queue and started 10 us after k_glu_pool_bwd8 had finished
+            // (profiles/r05b_mt-f32_step_timeline.txt: 447.6 -> 457.7 us).  Both still depend on the same event.
+            if (sd.ok) SED_CHECK_HIP(hipEventRecord(sd.fork, st));
+            SED_TRY(launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], pp, st));
+            if (sd.ok) { SED_CHECK_HIP(hipStreamWaitEvent(sd.s, sd.fork, 0)); forked = true; }
             SED_TRY(launch_conv_wgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(pin[i]), WSF(W.wg_part), W.wgrad_blocks,
                                       grads + P.conv_w[i], g.B, Hs[i], Wd[i], pp, ss));
             if (parts == 3 && !early_gru_w) {
@@ -565,7 +571,6 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
                 if (sd.ok) SED_TRY(heads_colsum(sg));
                 SED_TRY(gru_weight_grads(sg));
             }
-            SED_TRY(launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], pp, st));
         } else {
             if (sd.ok) { SIDE_FORK(st); forked = true; }
             SED_TRY(launch_conv_dgrad(WSF(dzo[i]), CTXF(yo[i]), WSF(W.coef[i]), CTXF(wpkT[i]), WSF(dpo[i - 1]), g.B, Hs[i], Wd[i], pp, st));

@@ -439,15 +439,20 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
                 // H = 256: this layer's weight-gradient GEMMs (100 - 160 us of split-K work) start on the helper stream NOW, next
                 // to the rest of the recurrence chain - which keeps 48 of 256 CUs busy for another ~300 us - instead of after
                 // the conv blocks' fork, where they used to be the tail of the step (profiles/r03_*_wide-bf16_step_timeline.txt)
-                if (early_gru_w) {
-                    SED_TRY(fork());
-                    if (l == g.L - 1) SED_TRY(heads_colsum(ss));
-                    SED_TRY(gru_weight_grads_layer(l, ss));
-                }
+                // The fork event is recorded in front of the dX GEMM, but the GEMM - the critical chain - is CAPTURED FIRST: the
+                // graph executor keeps the first-captured child of a node on its parent's hardware queue, and with the helper
+                // stream's kernels captured first the dX GEMM hopped to another queue, ~10 us of cross-queue latency per layer
+                // (profiles/r05b_wide-bf16_step_timeline.txt: "idle 9.9" in front of it).  Both still start together.
+                if (early_gru_w && have_side) SED_CHECK_HIP(hipEventRecord(ev_fork, st));
                 GntBatch gb;
                 gb.n_prob = 1;
                 gb.p[0] = GntProb{WSF(W.dgi[l]), 6 * H, CTXF(L.wihT[l]), 6 * H, d_in, nin, nullptr, BT, nin, 6 * H};
                 SED_TRY(g.mode != SED_DTYPE_F32 ? launch_gnt_gemm_bf16(gb, st, g.mode == SED_DTYPE_BF16X3) : launch_gnt_gemm(gb, st));
+                if (early_gru_w) {
+                    if (have_side) { SED_CHECK_HIP(hipStreamWaitEvent(ss, ev_fork, 0)); forked = true; }
+                    if (l == g.L - 1) SED_TRY(heads_colsum(ss));
+                    SED_TRY(gru_weight_grads_layer(l, ss));
+                }
                 d_cur = d_in;
                 d_cur2 = nullptr;
             }

@@ -31,9 +31,9 @@
 
 #define P2P_THREADS 256
 #define P2P_MAX_WORLD 16
-#define P2P_MAX_WG 64
+#define P2P_MAX_WG 256
 #define P2P_FLAG_WORDS (2 * P2P_MAX_WORLD * P2P_MAX_WG)       // ready | done, [rank][workgroup]
-#define P2P_HDR_BYTES 16384                                   // flags (8 KB) | epoch[G] | error word | padding
+#define P2P_HDR_BYTES 49152                                   // flags (32 KB) | epoch[G] | error word | padding
 #define P2P_TIMEOUT_TICKS (300ull * 1000 * 1000)              // 3 s of the 100 MHz wall clock
 
 struct P2PHeader {
@@ -277,14 +277,25 @@ extern "C" int sed_p2p_errors(const void* own_ptr, unsigned int* out) {
 
 // In-place sum all-reduce of data[0, n) over the `world` ranks whose communication buffers are bufs[0 .. world) (bufs[rank] =
 // this rank's own; every one created with the SAME n_floats_max); every rank must enqueue the same sequence of calls.
-// One launch of `workgroups` workgroups (0: default 32; the same value on every rank), capturable, no host synchronisation.
+// One launch of `workgroups` workgroups (0: default, derived from n; the same value on every rank), capturable, no host synchronisation.
 extern "C" int sed_p2p_allreduce(float* data, long long n, int rank, int world, void* const* bufs, long long n_floats_max,
                                  int workgroups, void* stream) {
     SED_CHECK_ARG(data && bufs && n >= 0 && world >= 1 && world <= P2P_MAX_WORLD && rank >= 0 && rank < world, "sed_p2p_allreduce: bad argument");
     SED_CHECK_ARG(n <= n_floats_max, "sed_p2p_allreduce: message larger than the communication buffers");
     SED_CHECK_ARG(((uintptr_t)data & 15) == 0, "sed_p2p_allreduce: data must be 16-byte aligned");
     if (n == 0) return SED_OK;
-    int G = workgroups > 0 ? workgroups : 32;
+    // default: one workgroup per 2 K floats of the buffers' capacity, at least 32, at most P2P_MAX_WG - the same on every rank and call.  One-rank
+    // launch-structure measurements (tools/dp1_wgs.sh; the buffers are uncached fine-grained memory, so every phase is round
+    // trips, and more lanes share them): the base model's 857 KB message 36 us on 32 workgroups, 25 on 64, 19 on 128; the wide
+    // model's 8.5 MB 310 us on 32, 74 on 256.
+    // (derived from the buffers' CAPACITY, not from this call's n: the stage / result halves alternate with a per-workgroup epoch,
+    // which is only safe when every call on a set of buffers uses the same workgroups for the same chunks)
+    int G = workgroups > 0 ? workgroups : (int)((n_floats_max + 2047) / 2048);
+    if (G < 32 && workgroups <= 0) G = 32;
+    // (default capped at 128: same-index workgroups of different ranks spin on each other; two ranks SHARING one GPU - the one-GPU
+    // test set-up - must pass 32 explicitly, as dist.PeerAllReduce does: 2 x 105 .. 256 spinning workgroups beside both ranks'
+    // persistent kernels did not all become resident before the bounded waits ran out)
+    if (G > 128 && workgroups <= 0) G = 128;
     if (G > P2P_MAX_WG) G = P2P_MAX_WG;
     P2PPeers peers = {};
     for (int p = 0; p < world; ++p) {

@@ -169,6 +169,12 @@ class PeerAllReduce:
                 ptrs[p] = q.value
             self._ptrs = ptrs
             self.layout = [(h, d, pid, fg_) for h, d, pid, _, fg_ in every]
+            # Workgroups per launch: the library's default grows with the buffers' capacity (one per 2 K floats, 32 .. 128: the
+            # phases are round trips to uncached memory, more lanes share them).  Same-index workgroups of different ranks spin
+            # on each other, so ranks that SHARE a GPU (the one-GPU test set-up; never a production layout) stay at 32: more
+            # spinning workgroups per process than that did not all become resident beside both ranks' persistent kernels.
+            if not self.workgroups and len({d for _h, d, *_ in every}) < self.world:
+                self.workgroups = 32
         # (no barrier needed: a rank's kernels only touch buffers IT has mapped, and every buffer was allocated and zeroed
         # before its handle was exchanged)
 

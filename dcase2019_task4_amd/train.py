@@ -194,7 +194,7 @@ class MeanTeacherStep:
         if want not in (None, "overlap", "single"):
             raise ValueError(f"unknown data-parallel schedule {want!r}")
         self.dp_capture = False
-        if self.dp and use_graph and env_cap != "0" and want != "single":
+        if self.dp and use_graph and env_cap != "0" and (want != "single" or env_cap == "1"):
             self.dp_capture = (env_cap == "1") or self._p2p is not None or self._collective_capture_works()
         self.dp_schedule = want or ("overlap" if (self.dp_capture or not self.dp) else "single")
         self._dp_stream = self._stream("collective") if self.dp else None

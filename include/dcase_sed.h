@@ -254,7 +254,7 @@ int sed_mt_step_backward(const sed_dims* d, const float* params, const float* x,
  *   sed_p2p_open / _close    map / unmap a peer's buffer from its handle (hipIpcOpenMemHandle); _free releases one's own
  *   sed_p2p_can_access(dev)  1 if the current device can map device dev's memory
  *   sed_p2p_allreduce        in-place sum of data[0, n) over the ranks; bufs[world] = every rank's buffer as mapped HERE
- *                            (bufs[rank] = own); same n_floats_max and workgroups (0 = 32) on every rank; every rank enqueues the
+ *                            (bufs[rank] = own); same n_floats_max and workgroups (0 = one per 2 K floats of n_floats_max, 32 .. 128) on every rank; every rank enqueues the
  *                            same sequence of calls
  *   sed_p2p_errors           the sticky count of timed-out waits (blocking 4-byte read) */
 size_t sed_p2p_buffer_bytes(long long n_floats_max);

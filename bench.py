@@ -71,7 +71,27 @@ CONFIGS = {   # name -> (wide, mfma dtype, from waveform, default batch per GPU)
     "mt-bf16x3": (False, "bf16x3", False, 24), "wide-bf16x3": (True, "bf16x3", False, 24),
     "waveform-bf16x3": (False, "bf16x3", True, 64),
     "mt-f16": (False, "f16", False, 24), "wide-f16": (True, "f16", False, 24), "waveform-f16": (False, "f16", True, 64),
+    # round 6: configs[3]'s PER-RANK shape on one GPU (fp32, 64 clips as [16|32|16]: the N = 1 point of its weak-scaling curve),
+    # the reference's own geometry (44.1 kHz / hop 511: T = 864, baseline/config.py:17-22), and the all-fp32 twin of the headline
+    # (block 0's backward sums as fp32 VALU FMAs instead of split-bf16 MFMA products: SED_STRICT_F32=1)
+    "mt-f32-b64": (False, "f32", False, 64), "mt-f32-T864": (False, "f32", False, 24), "mt-f32-strict": (False, "f32", False, 24),
 }
+CONFIG_FRAMES = {"mt-f32-T864": 864}                # everything else: T_FRAMES
+CONFIG_ENV = {"mt-f32-strict": {"SED_STRICT_F32": "1"}}
+
+
+def block_boundary_elements(T):
+    """elements per clip of the block-boundary tensors (x0, pool0, pool1, pool2, gru0, gru1, heads) at T frames, base CRNN."""
+    return T * 64 + 64 * (T // 2) * 16 + 64 * (T // 4) * 4 + 64 * (T // 8) + 2 * (T // 8) * 128 + (T // 8) * 20
+
+
+def frames_scale(T):
+    """(flop scale, byte scale) of a base-CRNN step at T frames relative to T = 628 (858.1 -> 1180.8 MFLOP at 864)."""
+    if T == T_FRAMES:
+        return 1.0, 1.0
+    if T == 864:
+        return 1180.8 / 858.1, block_boundary_elements(864) / block_boundary_elements(T_FRAMES)
+    return T / T_FRAMES, block_boundary_elements(T) / block_boundary_elements(T_FRAMES)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -314,6 +334,50 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def collective_bench(pg, device, world, rank, iters=50):
+    """The gradient all-reduce ALONE, so that a scaling record explains itself: the two message sizes of the step (857 424 B =
+    cfg.crnn_kwargs' flat gradient, 8 530 512 B = the wide model's) through the library's peer kernel (csrc/p2p.hip) and through
+    the process group's all_reduce (RCCL), each captured into a hipGraph and replayed `iters` times (dist.graph_time_us: HIP events
+    on the launch stream, MAX over ranks).  us per call, algorithm bandwidth (bytes / time) and bus bandwidth (x 2 (W-1) / W)."""
+    import torch.distributed as dist
+    from dcase2019_task4_amd import dist as sdist
+    out = {"world": world, "iters": iters, "backend": dist.get_backend(pg), "sizes": {}}
+    n_big = N_PARAMS[True]
+    p2p = None
+    try:
+        p2p = sdist.PeerAllReduce.create(n_big, device, pg)
+        if p2p is None:
+            out["p2p_unavailable"] = str(sdist.PeerAllReduce.last_error)
+        for label, n in (("base_857KB", N_PARAMS[False]), ("wide_8.5MB", n_big)):
+            row = {"bytes": 4 * n}
+
+            def fill(tag, us):
+                row[tag + "_us"] = round(us, 2)
+                row[tag + "_algbw_gbs"] = round(4 * n / us * 1e-3, 1)
+                row[tag + "_busbw_gbs"] = round(4 * n / us * 1e-3 * 2 * (world - 1) / world, 1)
+            if p2p is not None:
+                try:
+                    fill("p2p", p2p.time_us(n, iters))
+                except Exception as e:                  # noqa: BLE001
+                    row["p2p_error"] = repr(e)[:200]
+            if dist.get_backend(pg) == "nccl" and world > 1:
+                try:
+                    fill("rccl", sdist.graph_time_us(lambda t: dist.all_reduce(t, group=pg), n, device, pg, iters))
+                except Exception as e:                  # noqa: BLE001
+                    row["rccl_error"] = repr(e)[:200]
+            out["sizes"][label] = row
+        if p2p is not None:
+            out["p2p_timeouts"] = p2p.errors(reduce=True)
+    except Exception as e:                              # noqa: BLE001 - the headline line must not depend on this leg
+        out["error"] = repr(e)[:300]
+    finally:
+        if p2p is not None:
+            p2p.close()
+    if rank == 0:
+        print(f"[bench] collective-only leg: {json.dumps(out)}", file=sys.stderr, flush=True)
+    return out
+
+
 def time_steps(step, steps, world, device):
     def barrier():
         if world > 1:
@@ -336,6 +400,25 @@ def time_steps(step, steps, world, device):
         per_rank = [float(v.item()) for v in tl]
         elapsed = max(per_rank)
     time_steps.per_rank = per_rank
+    # SURVEY 8(d)'s prescription beside the wall clock: a hipEvent pair on the launch stream around the same number of steps,
+    # recorded right behind up to 50 more (untimed) replays with NO host synchronisation in between - the first dozen replays
+    # after a synchronise run 3 - 10 % slow (tools/first_replays.py), which is what a 20-step wall-clock region mostly measures
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(min(steps, 50)):
+        step.run()
+    e0.record()
+    for _ in range(steps):
+        step.run()
+    e1.record()
+    torch.cuda.synchronize(device)
+    ev = e0.elapsed_time(e1) * 1e-3
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([ev], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ev = float(t.item())
+    barrier()
+    time_steps.events_s = ev
     return elapsed
 
 
@@ -382,14 +465,22 @@ ARITH = {"f32": "fp32 (exact fp32 MFMA; block 0's backward sums on split bf16 op
                 "asserted within the north star's 1e-3 of the fp32 oracle"}
 
 
-def workload_string(wide, mfma_dtype, waveform, B, fft="f32"):
+def workload_string(wide, mfma_dtype, waveform, B, fft="f32", T=T_FRAMES, strict=False):
     mdl = "wide CRNN (nb_filters 3 x 128, n_RNN_cell 256)" if wide else "CRNN (baseline/main.py config)"
+    if strict:
+        return (f"mean-teacher {mdl} train step, batch {B} per GPU, precomputed log-mel [{B},1,{T},64] fp32 resident in HBM, dropout 0.5, "
+                "STRICT fp32: exact fp32 MFMA products everywhere and block 0's backward sums as fp32 VALU FMAs (no split-bf16 "
+                "product anywhere in the step)")
     if waveform:
         return (f"mean-teacher {mdl} train step from raw 16 kHz waveforms (STFT [{fft} butterflies] + mel + noise + log + "
                 f"normalise on the GPU inside the timed region, one batch ahead inside the step's hipGraph), batch {B} per GPU, "
                 f"{ARITH[mfma_dtype]}")
-    return (f"mean-teacher {mdl} train step, batch {B} per GPU, precomputed log-mel [{B},1,628,64] fp32 resident in HBM, "
+    return (f"mean-teacher {mdl} train step, batch {B} per GPU, precomputed log-mel [{B},1,{T},64] fp32 resident in HBM, "
             f"dropout 0.5, {ARITH[mfma_dtype]}")
+
+
+def strict_f32(config):
+    return os.environ.get("SED_STRICT_F32") == "1" or CONFIG_ENV.get(config, {}).get("SED_STRICT_F32") == "1"
 
 
 def make_runner(config, device, rank, pg=None, use_graph=True, batch=None, seed=1234, pool_streams=True):
@@ -397,12 +488,16 @@ def make_runner(config, device, rank, pg=None, use_graph=True, batch=None, seed=
     from dcase2019_task4_amd.train import MeanTeacherStep
     wide, mfma_dtype, waveform, b_default = CONFIGS[config]
     B = batch or b_default
+    T = CONFIG_FRAMES.get(config, T_FRAMES)
+    if strict_f32(config):
+        from dcase2019_task4_amd import _lib
+        _lib.lib().sed_debug_set(_lib.lib().sed_debug_set(0) | (1 << 27))
     model_kw = dict(mfma_dtype=mfma_dtype)
     if wide:
         model_kw.update(nb_filters=[128, 128, 128], n_RNN_cell=256)
     student, teacher = build_models(device, seed=0, **model_kw)        # identical replicas on every rank
-    x, xe, tgt, wm, sm = synthetic_batch(B, T_FRAMES, 1000 + rank, device)
-    step = MeanTeacherStep(student, teacher, B, T_FRAMES, rampup_length=210 * 100 // 2, weak_mask=wm, strong_mask=sm,
+    x, xe, tgt, wm, sm = synthetic_batch(B, T, 1000 + rank, device)
+    step = MeanTeacherStep(student, teacher, B, T, rampup_length=210 * 100 // 2, weak_mask=wm, strong_mask=sm,
                            seed=seed, use_graph=use_graph, process_group=pg, pool_streams=pool_streams)
     step.load_batch(x, xe, tgt)
     runner = step
@@ -414,10 +509,11 @@ def make_runner(config, device, rank, pg=None, use_graph=True, batch=None, seed=
     return runner, step, B
 
 
-def step_roofline(wide, mfma_dtype, waveform, B, ms_per_step):
+def step_roofline(wide, mfma_dtype, waveform, B, ms_per_step, T=T_FRAMES):
     """SURVEY 8(d)'s whole-step figures for one measured line."""
-    flop = (WIDE_STEP_FLOP_PER_CLIP if wide else STEP_FLOP_PER_CLIP) * B
-    by = algorithmic_bytes(wide, mfma_dtype, waveform, B)
+    fs, bs = frames_scale(T)
+    flop = (WIDE_STEP_FLOP_PER_CLIP if wide else STEP_FLOP_PER_CLIP) * B * fs
+    by = (algorithmic_bytes(wide, mfma_dtype, waveform, B) - 9 * 4 * N_PARAMS[wide]) * bs + 9 * 4 * N_PARAMS[wide]
     peak = PEAK_F32_MFMA_TFLOPS if mfma_dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
     tf = flop / (ms_per_step * 1e-3) * 1e-12
     return {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
@@ -434,7 +530,8 @@ def extra_config_legs(device, steps=300):
     already built and replayed four other steps holds their streams, and a later step's graph branches then share hardware
     queues with them - measured in-process, the fifth leg came out at 0.90 ms against 0.66 ms alone."""
     out = {}
-    for name in ("waveform-bf16", "waveform-f16", "wide-bf16", "wide-f16", "wide-bf16x3", "mt-bf16", "mt-f16", "mt-bf16x3"):
+    for name in ("mt-f32-b64", "mt-f32-T864", "mt-f32-strict", "waveform-bf16", "waveform-f16", "wide-bf16", "wide-f16", "wide-bf16x3",
+                 "mt-bf16", "mt-f16", "mt-bf16x3"):
         try:
             wide, mfma_dtype, waveform, B = CONFIGS[name]
             cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(steps), "--warmup", "8", "--no-extras",
@@ -444,9 +541,10 @@ def extra_config_legs(device, steps=300):
                 raise RuntimeError(r.stderr[-300:])
             d = json.loads(r.stdout.strip().split("\n")[-1])
             ms = d["ms_per_step"]
-            out[name] = {"value": d["value"], "unit": "clips/s", "ms_per_step": ms, "steps": steps, "dtype": mfma_dtype,
+            out[name] = {"value": d["value"], "unit": "clips/s", "ms_per_step": ms, "ms_per_step_events": d.get("ms_per_step_events"),
+                         "steps": steps, "dtype": mfma_dtype,
                          "global_batch": B, "loss": d.get("loss"), "workload": d["config"]["workload"],
-                         "roofline": step_roofline(wide, mfma_dtype, waveform, B, ms)}
+                         "roofline": step_roofline(wide, mfma_dtype, waveform, B, ms, CONFIG_FRAMES.get(name, T_FRAMES))}
             if waveform and os.environ.get("SED_FE_FFT", "f32") != "f64":
                 # the same leg with the parity-mode front-end (fp64 butterflies = librosa's arithmetic; WaveformFrontEnd's default)
                 r64 = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, SED_FE_FFT="f64"))
@@ -511,11 +609,13 @@ def main():
     from dcase2019_task4_amd.train import MeanTeacherStep
     wide, mfma_dtype, waveform, b_default = CONFIGS[args.config]
     headline = args.config == "mt-f32"
+    T_cfg = CONFIG_FRAMES.get(args.config, T_FRAMES)
     runner, step, B = make_runner(args.config, device, rank, pg, use_graph=not args.no_graph, batch=args.batch)
-    x, xe, tgt, wm, sm = synthetic_batch(B, T_FRAMES, 1000 + rank, device)          # (the same batch again, for the A/B legs below)
+    x, xe, tgt, wm, sm = synthetic_batch(B, T_cfg, 1000 + rank, device)          # (the same batch again, for the A/B legs below)
     for _ in range(max(args.warmup, 3)):       # >= 3: two eager warm-ups + graph capture/first replay
         runner.run()
     elapsed = time_steps(runner, args.steps, world, device)
+    events_s = time_steps.events_s
     per_rank_s = list(time_steps.per_rank)
     meters = step.meters()
     assert np.isfinite(meters["loss"]), meters
@@ -554,6 +654,10 @@ def main():
                 ab_legs[tag] = {"error": repr(e)[:300]}
             finally:
                 os.environ.pop("SED_DP_CAPTURE", None)
+
+    coll_bench = None
+    if step.dp and headline and not args.no_extras and args.batch is None:
+        coll_bench = collective_bench(pg, device, world, rank)
 
     config3 = None
     if world > 1 and headline and not args.no_extras and args.batch is None:
@@ -603,7 +707,8 @@ def main():
             runner.run()
         n_ss = 3000
         el_ss = time_steps(runner, n_ss, world, device)
-        steady = {"steps": n_ss, "ms_per_step": round(el_ss / n_ss * 1e3, 4), "value": round(B * n_ss / el_ss, 1), "unit": "clips/s",
+        steady = {"steps": n_ss, "ms_per_step": round(el_ss / n_ss * 1e3, 4), "ms_per_step_events": round(time_steps.events_s / n_ss * 1e3, 4),
+                  "value": round(B * n_ss / el_ss, 1), "unit": "clips/s",
                   "note": "same step, same buffers, 3000 hipGraph replays timed the same way (the headline's timed region is "
                           "K steps as the driver asks: 20 steps = 15 ms is dominated by the first replays)"}
 
@@ -614,20 +719,26 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         clips = B * world * args.steps / elapsed
-        wl = workload_string(wide, mfma_dtype, waveform, B, os.environ.get("SED_FE_FFT", "f32"))
+        wl = workload_string(wide, mfma_dtype, waveform, B, os.environ.get("SED_FE_FFT", "f32"), T_cfg, strict_f32(args.config))
         res = {
             "metric": "10-s clips/sec mean-teacher train step (64-mel x 628)",
             "value": round(clips, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms, 4),
+            # (hipEvent pair on the launch stream around the same K steps, recorded behind further replays with no host
+            # synchronisation in between - SURVEY 8(d)'s method; ms_per_step above is the wall clock the contract asks for)
+            "ms_per_step_events": round(events_s / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": mfma_dtype, "data": "synthetic",
-            "config": {"workload": wl, "global_batch": B * world, "frames": T_FRAMES, "n_mels": N_MELS,
+            "config": {"workload": wl, "global_batch": B * world, "frames": T_cfg, "n_mels": N_MELS,
                        "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
                        "dp_schedule": step.dp_schedule if step.dp else None,
                        "dp_collectives": ("captured" if step.dp_capture else "eager") if step.dp else None,
                        "dp_collective": ({"p2p": "library kernel over peer-mapped memory (csrc/p2p.hip: reduce-scatter + all-gather in "
                                                  "one launch, direct xGMI loads / stores, self-checked against the process group)",
                                           "pg": "torch.distributed all_reduce (RCCL picks algorithm / protocol)"}[step.collective]
-                                         if step.dp else None)},
+                                         if step.dp else None),
+                       # collective="auto" TIMES both on the step's two buckets at construction and keeps the faster:
+                       "dp_collective_record": getattr(step, "collective_record", None) if step.dp else None},
             "loss": round(meters["loss"], 5),
         }
         if dist_info:
@@ -641,6 +752,8 @@ def main():
                 dist_info["schedule_ab"] = ab_legs
             if getattr(step, "_capture_error", None):
                 res["distributed"]["capture_fallback"] = step._capture_error[:200]
+        if coll_bench:
+            res.setdefault("distributed", {})["collective_only"] = coll_bench
         if config3:
             res["config3_ddp"] = config3
         if config4:
@@ -650,7 +763,7 @@ def main():
         if extras:
             res["extra_configs"] = extras
         traffic, table = pmc_step_traffic()
-        roof = dict(step_roofline(wide, mfma_dtype, waveform, B, ms), kernel="whole step (one hipGraph)")
+        roof = dict(step_roofline(wide, mfma_dtype, waveform, B, ms, T_cfg), kernel="whole step (one hipGraph)")
         roof.update({
             "traffic": traffic if (world == 1 and headline and B == B_PER_GPU) else None,
             "definition": "SURVEY 8(d): reference GEMM-shaped FLOPs of the step (4 x forward: 3.432 GFLOP per clip, wide 14.157) / "

@@ -74,6 +74,7 @@ _SIGS = {
     "sed_p2p_free": (C.c_int, [_P]),
     "sed_p2p_can_access": (C.c_int, [C.c_int]),
     "sed_p2p_errors": (C.c_int, [_P, C.POINTER(C.c_uint)]),
+    "sed_p2p_configure": (C.c_int, [_P, C.c_double, _P, C.c_int]),
     "sed_p2p_allreduce": (C.c_int, [_P, C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_longlong, C.c_int, _P]),
     "sed_adam_ema": (C.c_int, [C.c_int64, _P, _P, _P, _P, _P, _P, C.c_float, _P]),
     "sed_ema_update": (C.c_int, [C.c_int64, _P, _P, C.c_float, _P]),

@@ -550,7 +550,9 @@ __global__ __launch_bounds__(256, (NH == 2 ? 3 : 2)) void k_blk0_fwd(const float
 // NHT: channel slices of the whole block; a workgroup handles NH of them, those from blockIdx.y * NH on (C = 128 runs as two
 // 64-channel halves: the accumulators of all four slices need 290 registers = ONE wave per SIMD with every LDS / MFMA
 // latency of its in-order stream exposed - 197 us against 2 x 53 for the halves at two waves per SIMD)
-template <int NH, int MODE, int NHT>
+// STRICT (fp32 only, debug bit 27 / SED_STRICT_F32=1): the 2 x 10 sums per channel as plain fp32 FMAs on the VALU instead of
+// split-bf16 MFMA products - the all-fp32 twin of the `dtype: f32` headline (bench.py extra_configs["mt-f32-strict"]).
+template <int NH, int MODE, int NHT, int STRICT = 0>
 __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float* __restrict__ x, const float* __restrict__ wz,
                                                    const float* __restrict__ wl, const float* __restrict__ dp0, int B,
                                                    int T, int H1, int tiles_per_clip, int n_tiles, int use_drop,
@@ -571,7 +573,7 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
     // the whole grid-stride loop): the forward tile's D layout (lane = channel column, register r = pixel row) IS the B
     // fragment of the transposed product, the A fragment is P^T (lane = tap row, 10 of 32 rows used) read straight from the
     // input tile.  20 FMAs per (pixel, channel) - 2/3 of this kernel's VALU work - become 4 MFMAs per 32 x 32 tile.
-    constexpr bool VALU_SUMS = false;      // (the round-1/2 path: 2 x 10 fp32 FMAs per pixel and channel on the VALU; kept for A/B)
+    constexpr bool VALU_SUMS = STRICT != 0;      // (the round-1/2 path: 2 x 10 fp32 FMAs per pixel and channel on the VALU)
     float aD[VALU_SUMS ? NH : 1][10], aE[VALU_SUMS ? NH : 1][10];
     f32x16 accD[VALU_SUMS ? 1 : NH], accE[VALU_SUMS ? 1 : NH];
     if constexpr (VALU_SUMS) {
@@ -977,6 +979,8 @@ int launch_blk0_backward(const Geo& g, const float* x, const float* w0, const fl
     if (g.C == 64 && g.mode == 1) BLK0_BWD(2, 1, 2, 512);
     else if (g.C == 64 && g.mode == 2) BLK0_BWD(2, 2, 2, 512);
     else if (g.C == 128 && g.mode == 2) BLK0_BWD(2, 2, 4, BLK0_GRID128);
+    else if (g.C == 64 && (g_sed_debug & 134217728))      // debug bit 27: strict fp32 (no split-bf16 products anywhere in the step)
+        k_blk0_bwd<2, 0, 2, 1><<<dim3(nt < 512 ? nt : 512, 1), 256, 0, st>>>(x, wz, wl, dp0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, mask_in, de, g_sed_debug & 1);
     else if (g.C == 64) BLK0_BWD(2, 0, 2, 512);
     else if (g.C == 128 && g.mode == 1) BLK0_BWD(2, 1, 4, BLK0_GRID128);
     else if (g.C == 128) BLK0_BWD(2, 0, 4, BLK0_GRID128);

@@ -26,6 +26,7 @@
 // Memory: the communication buffers are allocated HERE (sed_p2p_alloc: fine-grained device memory, the kind peers may read
 // and write coherently while kernels run) - the one place the library owns device memory, because it has to be created with
 // flags torch's allocator does not offer and exported through hipIpcGetMemHandle.  The gradient buffer itself stays torch's.
+#include <stdlib.h>
 #include <string.h>
 #include "common.h"
 
@@ -33,14 +34,18 @@
 #define P2P_MAX_WORLD 16
 #define P2P_MAX_WG 256
 #define P2P_FLAG_WORDS (2 * P2P_MAX_WORLD * P2P_MAX_WG)       // ready | done, [rank][workgroup]
-#define P2P_HDR_BYTES 49152                                   // flags (32 KB) | epoch[G] | error word | padding
-#define P2P_TIMEOUT_TICKS (300ull * 1000 * 1000)              // 3 s of the 100 MHz wall clock
+#define P2P_HDR_BYTES 49152                                   // flags (32 KB) | epoch[G] | error word | configuration | padding
+#define P2P_TICKS_PER_S (100ull * 1000 * 1000)                // the 100 MHz wall clock
+#define P2P_DEFAULT_TIMEOUT_S 600.0                           // SED_P2P_TIMEOUT_S / sed_p2p_configure override it
 
 struct P2PHeader {
     unsigned int flags[P2P_FLAG_WORDS];
     unsigned int epoch[P2P_MAX_WG];
-    unsigned int error;            // sticky: number of waits that timed out
+    unsigned int error;                 // sticky: number of waits that timed out
     unsigned int magic;
+    unsigned long long timeout_ticks;   // wait budget of ONE cross-rank wait (sed_p2p_alloc: SED_P2P_TIMEOUT_S or 600 s)
+    unsigned int* host_err;             // optional word in pinned host memory that a timed-out wait also raises (sed_p2p_configure):
+                                        // the host polls it without synchronising the device
 };
 static_assert(sizeof(P2PHeader) <= P2P_HDR_BYTES, "header page");
 
@@ -49,29 +54,46 @@ struct P2PPeers { char* buf[P2P_MAX_WORLD]; };
 __device__ __forceinline__ unsigned int p2p_flag_load(const unsigned int* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// (assembly with a marker comment, like the drain in signal_all: tests/test_abi.py checks in the compiler's output that nothing
+// but the barrier sits between the two)
 __device__ __forceinline__ void p2p_flag_store(unsigned int* p, unsigned int v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("global_store_dword %0, %1, off sc0 sc1 ; p2p_flag_store" :: "v"(p), "v"(v) : "memory");
 }
 
-// Payload accesses to the communication buffers: relaxed SYSTEM-scope 8-byte atomics (global_load / store_dwordx2 sc0 sc1), two per
-// 16-byte chunk.  They bypass / write through the caches on both sides, so the hand-over needs NO cache-maintenance fence: the
-// producer drains its stores (s_waitcnt vmcnt(0) of the workgroup barrier) and stores the flag, the consumer sees the flag and
-// loads.  The first version used plain accesses between system-scope release / acquire fences: a release fence writes back every
-// dirty line of the XCD's L2 - mostly the conv backward's, which runs beside the tail bucket's all-reduce - and the one-rank
-// launch-structure measurement came out at +51 us per step for the two calls.
-typedef unsigned long long p2p_u64;
-typedef __attribute__((ext_vector_type(2))) p2p_u64 p2p_u64x2;
-__device__ __forceinline__ f32x4 ld_sys(const float* p) {
-    p2p_u64x2 v;
-    v[0] = __hip_atomic_load((const p2p_u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    v[1] = __hip_atomic_load((const p2p_u64*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    return __builtin_bit_cast(f32x4, v);
-}
-__device__ __forceinline__ void st_sys(float* p, f32x4 x) {
-    const p2p_u64x2 v = __builtin_bit_cast(p2p_u64x2, x);
-    __hip_atomic_store((p2p_u64*)p, v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store((p2p_u64*)p + 1, v[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
+// Payload accesses to the communication buffers are 16-byte SYSTEM-scope accesses (global_load / store_dwordx4 sc0 sc1): they
+// bypass / write through the caches on both sides, so the hand-over needs no cache-maintenance fence (a system-scope release
+// fence writes back every dirty line of the XCD's L2 - mostly the conv backward's, which runs beside the tail bucket's
+// all-reduce: +51 us per step in round 5's first version) - but it DOES need the producer to wait until its stores are
+// acknowledged before it raises the flag.  That wait is an explicit `s_waitcnt vmcnt(0)` on every wave in signal_all(): the
+// workgroup barrier does NOT contain one on gfx950 (back-off barrier: the compiler emits s_waitcnt lgkmcnt(0); s_barrier only -
+// round 5 relied on it and a flag could overtake payload stores still in flight across xGMI; tests/test_abi.py greps the
+// disassembly for the drain).  This is the AMDGPU memory model's own system-scope release sequence minus the L2 write-back
+// that only non-write-through stores need.
+//
+// The accesses are inline assembly because the compiler cannot express them pipelined: relaxed system-scope ATOMICS are at most
+// 8 bytes (two half-line stores per chunk), and it put `s_waitcnt vmcnt(0)` - which on gfx9 also waits for every earlier STORE's
+// acknowledgement - in front of each store pair, so every lane had one uncached round trip in flight at a time (round 5:
+// 8.5 MB in 100 us on one rank).  Here a lane issues eight loads, waits once, then issues its stores back to back.
+// ONE statement = eight loads + the wait for them: nothing the compiler schedules or copies can come between a load and the
+// wait that makes its destination registers valid (the first version had the wait as a separate statement tied to the registers;
+// this form leaves no room for a register copy in between).  P2P_ST_*: one 16-byte store, no wait.
+#define P2P_LD8(BITS, v, a)                                                                                              \
+    asm volatile("global_load_dwordx4 %0, %8, off" BITS "\n\tglobal_load_dwordx4 %1, %9, off" BITS                       \
+                 "\n\tglobal_load_dwordx4 %2, %10, off" BITS "\n\tglobal_load_dwordx4 %3, %11, off" BITS                 \
+                 "\n\tglobal_load_dwordx4 %4, %12, off" BITS "\n\tglobal_load_dwordx4 %5, %13, off" BITS                 \
+                 "\n\tglobal_load_dwordx4 %6, %14, off" BITS "\n\tglobal_load_dwordx4 %7, %15, off" BITS                 \
+                 "\n\ts_waitcnt vmcnt(0)"                                                                                \
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])  \
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7])                  \
+                 : "memory")
+#define P2P_LD8_SYS(v, a) P2P_LD8(" sc0 sc1", v, a)
+#define P2P_LD8_PLAIN(v, a) P2P_LD8("", v, a)
+// The s_nop behind every store is a HARDWARE hazard the compiler only resolves for its own instructions: a VMEM store of more
+// than 8 bytes reads its data registers a cycle or two after issue, and a VALU write to one of them in that window lands in
+// the stored data (the first 16-byte version did exactly that: ~1 call in 5 stored a zero, a NaN constant or the next
+// address temporary in ONE dword of a few chunks - found by tools/p2p_debug.py at world 2, never at world 1).
+#define P2P_ST_SYS(p, v)   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 2" :: "v"(p), "v"(v) : "memory")
+#define P2P_ST_PLAIN(p, v) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 2" :: "v"(p), "v"(v) : "memory")
 __device__ __forceinline__ float ld_sys1(const float* p) { return __builtin_bit_cast(float, __hip_atomic_load((const unsigned int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)); }
 __device__ __forceinline__ void st_sys1(float* p, float x) { __hip_atomic_store((unsigned int*)p, __builtin_bit_cast(unsigned int, x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
@@ -81,9 +103,10 @@ __device__ __forceinline__ float* p2p_result(char* buf, size_t n_cap, unsigned i
 
 // data: the local gradient bucket (n floats, 16-byte aligned); n4 = n / 4 whole vector chunks (+ at most one partial tail chunk);
 // chunk c belongs to slice c % W and, inside the slice, to workgroup (c / W) % G.
-// Every loop keeps EIGHT 16-byte accesses per lane in flight (loads first, then the stores): the communication buffers are
-// fine-grained (uncached) memory, so a load-then-store loop pays a full memory round trip per iteration - the first version,
-// one chunk per iteration, took ~30 us per call for 500 KB on ONE rank.  WC: compile-time world size (1, 2, 4, 8; 0 = any).
+// A rank's OWN slice never goes through the communication buffers: nobody else reads slice r of rank r's staging half, so the
+// reduce phase takes that operand from the gradient bucket itself (still summed in rank order), writes rank r's copy of the
+// result straight back into the bucket, and publish / gather skip the slice - 1 / W of the local traffic, and a one-rank group
+// moves nothing through uncached memory at all.  WC: compile-time world size (1, 2, 4, 8; 0 = any).
 template <int WC>
 __global__ __launch_bounds__(P2P_THREADS) void k_p2p_allreduce(float* __restrict__ data, long long n, int rank, int W_, P2PPeers peers,
                                                                 size_t n_cap) {
@@ -91,118 +114,156 @@ __global__ __launch_bounds__(P2P_THREADS) void k_p2p_allreduce(float* __restrict
     const int g = blockIdx.x, G = gridDim.x, tid = threadIdx.x;
     // (the peer table goes to LDS: sixteen 64-bit kernel arguments indexed by a run-time rank cost 85 spilled scalar registers)
     __shared__ char* s_buf[P2P_MAX_WORLD];
-    __shared__ unsigned int s_e;
+    __shared__ unsigned int s_e, s_bad;
+    __shared__ unsigned long long s_budget;
     if (tid < P2P_MAX_WORLD) s_buf[tid] = peers.buf[tid < W ? tid : 0];
     __syncthreads();
     char* mine = s_buf[rank];
     P2PHeader* hdr = (P2PHeader*)mine;
-    if (tid == 0) s_e = hdr->epoch[g] + 1u;
+    if (tid == 0) { s_e = hdr->epoch[g] + 1u; s_bad = 0u; s_budget = hdr->timeout_ticks; }
     __syncthreads();
     const unsigned int e = s_e;
     const long long n4 = n / 4;                                                     // whole chunks
     const long long nck = (n + 3) / 4;                                              // incl. the partial tail chunk (index n4) if n % 4
     const long long per_wg = (nck + (long long)W * G - 1) / ((long long)W * G);     // chunks of one (slice, workgroup) pair
     auto chunk_of = [&](int slice, long long k) -> long long { return ((k * G + g) * W + slice); };
-    // the partial tail chunk (n % 4 floats) is moved element-wise by whoever owns it
+    float* my_stage = p2p_stage(mine, n_cap, e);
+    float* my_result = p2p_result(mine, n_cap, e);
+    // the partial tail chunk (n % 4 floats) is moved element-wise by whoever owns it, through the buffers on every rank
     // (to_comm: local gradient -> own staging half, system-scope stores; else own result half -> local gradient, system-scope loads)
     auto tail_copy = [&](const float* src, float* dst, bool to_comm) {
         for (long long i = 4 * n4; i < n; ++i) { if (to_comm) st_sys1(dst + i, src[i]); else dst[i] = ld_sys1(src + i); }
     };
-    // bounded wait for flag words [kind][p][g] == e of every rank p (thread p polls rank p's word in MY flag page)
+    // Bounded wait for flag words [kind][p][g] to reach epoch e on every rank p (thread p polls rank p's word in MY flag page).
+    // "Reach", not "equal": a rank that gave up on an epoch and moved on must not make every later wait of a late peer time out
+    // as well (the difference is taken modulo 2^32).  A wait that runs out of its budget raises the sticky error word (and the
+    // host-visible one) and POISONS this launch's output with NaN, below: a timed-out all-reduce must never look like a result.
     auto wait_all = [&](int kind) {
         if (tid < W) {
             const unsigned int* f = &hdr->flags[(kind * P2P_MAX_WORLD + tid) * P2P_MAX_WG + g];
-            const unsigned long long t0 = wall_clock64();
-            while (p2p_flag_load(f) != e) {
+            const unsigned long long t0 = wall_clock64(), budget = s_budget;
+            while ((int)(p2p_flag_load(f) - e) < 0) {
                 __builtin_amdgcn_s_sleep(2);
-                if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) { atomicAdd(&hdr->error, 1u); break; }
+                if (wall_clock64() - t0 > budget) {
+                    atomicAdd(&hdr->error, 1u);
+                    if (hdr->host_err) __hip_atomic_fetch_add(hdr->host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    s_bad = 1u;
+                    break;
+                }
             }
         }
         __syncthreads();                                             // (the payload loads that follow are system-scope themselves)
     };
     auto signal_all = [&](int kind) {
-        __syncthreads();                                             // every wave's system-scope stores issued AND acknowledged (vmcnt drained)
+        asm volatile("s_waitcnt vmcnt(0) ; p2p_signal_drain" ::: "memory");   // EVERY wave: its payload stores are acknowledged ...
+        __syncthreads();                                             // ... before any flag of this workgroup is raised
         if (tid < W) p2p_flag_store(&((P2PHeader*)s_buf[tid])->flags[(kind * P2P_MAX_WORLD + rank) * P2P_MAX_WG + g], e);
     };
-    // this workgroup's chunks of ALL slices, flattened: j = k * W + slice; eight per lane and trip
-    auto copy_all = [&](const float* src, float* dst, bool to_comm) {
+    // this workgroup's chunks of all slices but its own, flattened: j = k * W + slice; eight per lane and trip.
+    // (masked-off lanes load from the communication buffer's first chunk - always mapped - and store nothing)
+    auto copy_all = [&](const float* src, float* dst, bool to_comm, bool nan_out) {
         const long long nj = per_wg * W;
         for (long long j0 = tid; j0 < nj; j0 += 8 * P2P_THREADS) {
             f32x4 v[8];
             long long c[8];
+            const float* a[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const long long j = j0 + (long long)i * P2P_THREADS;
-                c[i] = chunk_of((int)(j % W), j / W);
-                const bool ok = j < nj && c[i] < n4;
-                const float* sp = src + 4 * (ok ? c[i] : 0);
-                v[i] = to_comm ? *(const f32x4*)sp : ld_sys(sp);
+                const int slice = (int)(j % W);
+                c[i] = chunk_of(slice, j / W);
+                const bool ok = j < nj && c[i] < n4 && slice != rank;
                 if (!ok) c[i] = -1;
+                a[i] = ok ? src + 4 * c[i] : my_stage;
             }
+            if (to_comm) P2P_LD8_PLAIN(v, a); else P2P_LD8_SYS(v, a);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                if (c[i] >= 0) { if (to_comm) st_sys(dst + 4 * c[i], v[i]); else *(f32x4*)(dst + 4 * c[i]) = v[i]; }
+                if (c[i] >= 0) {
+                    if (nan_out) v[i] = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+                    float* dp = dst + 4 * c[i];
+                    if (to_comm) P2P_ST_SYS(dp, v[i]); else P2P_ST_PLAIN(dp, v[i]);
+                }
         }
-        if (n4 != nck && tid == 0 && (int)((n4 / W) % G) == g) tail_copy(src, dst, to_comm);
+        if (n4 != nck && tid == 0 && (int)((n4 / W) % G) == g) {
+            tail_copy(src, dst, to_comm);
+            if (nan_out) for (long long i = 4 * n4; i < n; ++i) dst[i] = __builtin_nanf("");
+        }
     };
-    // ---- 1. publish my share of every slice ---------------------------------------------------------------------------------
-    copy_all(data, p2p_stage(mine, n_cap, e), true);
+    // ---- 1. publish my share of every other rank's slice --------------------------------------------------------------------
+    copy_all(data, my_stage, true, false);
     signal_all(0);
-    // ---- 2. reduce my share of slice `rank` over the ranks, in rank order (p = 0 .. W - 1 on every rank: bit-identical sums);
-    //         write it to every rank.  KB chunks x W ranks = eight remote loads per lane in flight -------------------------------
+    // ---- 2. reduce my share of slice `rank` over the ranks, in rank order (p = 0 .. W - 1: run-to-run identical sums; every
+    //         rank receives the same bits because each slice is summed once); write it to every rank - my own copy straight into
+    //         the gradient bucket.  KB chunks x W ranks = eight loads per lane in flight -----------------------------------------
     wait_all(0);
-    if constexpr (WC != 0) {
-        constexpr int KB = 8 / WC;
+    const bool bad0 = s_bad != 0u;
+    {
+        constexpr int WL = WC ? WC : 8;                               // ranks per load batch
+        constexpr int KB = 8 / WL;
         for (long long k0 = tid; k0 < per_wg; k0 += (long long)KB * P2P_THREADS) {
-            f32x4 v[KB][WC];
             long long c[KB];
+            f32x4 acc[KB], own[KB];
 #pragma unroll
-            for (int kk = 0; kk < KB; ++kk) {
+            for (int kk = 0; kk < KB; ++kk) {                         // my own operand comes from the gradient bucket itself
                 const long long k = k0 + (long long)kk * P2P_THREADS;
                 c[kk] = chunk_of(rank, k);
-                const bool ok = k < per_wg && c[kk] < n4;
+                if (!(k < per_wg && c[kk] < n4)) c[kk] = -1;
+                own[kk] = c[kk] >= 0 ? *(const f32x4*)(data + 4 * c[kk]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            for (int p0 = 0; p0 < W; p0 += WL) {                      // (one trip when WC != 0)
+                f32x4 v[8];
+                const float* a[8];
 #pragma unroll
-                for (int p = 0; p < WC; ++p) v[kk][p] = ld_sys(p2p_stage(s_buf[p], n_cap, e) + 4 * (ok ? c[kk] : 0));
-                if (!ok) c[kk] = -1;
+                for (int kk = 0; kk < KB; ++kk)
+#pragma unroll
+                    for (int pp = 0; pp < WL; ++pp) {
+                        const int p = p0 + pp;                        // (slots of my own rank, of ranks >= W and of masked-off
+                        a[kk * WL + pp] = (p < W && p != rank && c[kk] >= 0)      //  chunks read one always-mapped line)
+                                              ? p2p_stage(s_buf[p], n_cap, e) + 4 * c[kk] : my_stage;
+                    }
+                P2P_LD8_SYS(v, a);
+#pragma unroll
+                for (int kk = 0; kk < KB; ++kk) {
+#pragma unroll
+                    for (int pp = 0; pp < WL; ++pp) {
+                        const int p = p0 + pp;
+                        if (p >= W) continue;
+                        const f32x4 x = p == rank ? own[kk] : v[kk * WL + pp];
+                        if (p == 0) acc[kk] = x; else acc[kk] += x;
+                    }
+                }
             }
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) {
-                f32x4 acc = v[kk][0];
-#pragma unroll
-                for (int p = 1; p < WC; ++p) acc += v[kk][p];
-                if (c[kk] >= 0) {
-#pragma unroll
-                    for (int p = 0; p < WC; ++p) st_sys(p2p_result(s_buf[p], n_cap, e) + 4 * c[kk], acc);
+                if (c[kk] < 0) continue;
+                if (bad0) acc[kk] = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+                for (int p = 0; p < W; ++p) {
+                    if (p == rank) { float* dp = data + 4 * c[kk]; P2P_ST_PLAIN(dp, acc[kk]); }
+                    else { float* dp = p2p_result(s_buf[p], n_cap, e) + 4 * c[kk]; P2P_ST_SYS(dp, acc[kk]); }
                 }
             }
-        }
-    } else {
-        for (long long k = tid; k < per_wg; k += P2P_THREADS) {
-            const long long c = chunk_of(rank, k);
-            if (c >= n4) continue;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int p0 = 0; p0 < W; p0 += 8) {
-                f32x4 v[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = ld_sys(p2p_stage(s_buf[min(p0 + i, W - 1)], n_cap, e) + 4 * c);
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if (p0 + i < W) acc += v[i];
-            }
-            for (int p = 0; p < W; ++p) st_sys(p2p_result(s_buf[p], n_cap, e) + 4 * c, acc);
         }
     }
     if (n4 != nck && tid == 0 && (int)(n4 % W) == rank && (int)((n4 / W) % G) == g) {      // the partial tail chunk of my slice
         for (long long i = 4 * n4; i < n; ++i) {
             float acc = 0.f;
             for (int p = 0; p < W; ++p) acc += ld_sys1(p2p_stage(s_buf[p], n_cap, e) + i);
+            if (bad0) acc = __builtin_nanf("");
             for (int p = 0; p < W; ++p) st_sys1(p2p_result(s_buf[p], n_cap, e) + i, acc);
         }
     }
     signal_all(1);
-    // ---- 3. gather: every slice's reduced share of this workgroup back into the gradient bucket ------------------------------
+    // ---- 3. gather: the other slices' reduced shares of this workgroup back into the gradient bucket ---------------------------
     wait_all(1);
-    copy_all(p2p_result(mine, n_cap, e), data, false);
+    const bool bad1 = s_bad != 0u;
+    copy_all(my_result, data, false, bad1);
+    if (bad1) {                                                       // ... and my own slice, already in place, is void as well
+        for (long long k = tid; k < per_wg; k += P2P_THREADS) {
+            const long long c = chunk_of(rank, k);
+            if (c < n4) *(f32x4*)(data + 4 * c) = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+        }
+    }
     if (tid == 0) hdr->epoch[g] = e;
 }
 
@@ -239,6 +300,12 @@ extern "C" int sed_p2p_alloc(size_t bytes, int fine_grained, void** ptr_out, voi
         }
     }
     SED_CHECK_HIP(hipMemset(p, 0, bytes));
+    // the wait budget of the kernel's cross-rank waits: minutes by default (a rank that writes a checkpoint, validates or
+    // re-captures its graph while the others enter the next step is skew, not failure - RCCL would wait for ever)
+    double timeout_s = P2P_DEFAULT_TIMEOUT_S;
+    if (const char* ev = getenv("SED_P2P_TIMEOUT_S")) { const double v = atof(ev); if (v > 0.0) timeout_s = v; }
+    const unsigned long long ticks = (unsigned long long)(timeout_s * (double)P2P_TICKS_PER_S);
+    SED_CHECK_HIP(hipMemcpy((char*)p + offsetof(P2PHeader, timeout_ticks), &ticks, sizeof ticks, hipMemcpyHostToDevice));
     SED_CHECK_HIP(hipDeviceSynchronize());
     memcpy(handle_out, &h, sizeof h);
     *ptr_out = p;
@@ -267,6 +334,25 @@ extern "C" int sed_p2p_can_access(int peer_device) {
     if (dev == peer_device) return 1;
     if (hipDeviceCanAccessPeer(&can, dev, peer_device) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return can;
+}
+// Per-buffer configuration (blocking; not for use inside a capture): timeout_s > 0 replaces the wait budget of one cross-rank
+// wait (default: SED_P2P_TIMEOUT_S or 600 s); host_err, if not NULL, is the HOST address of a 4-byte word in pinned, mapped host
+// memory (hipHostMalloc / torch pin_memory) that every timed-out wait increments besides the sticky counter in the buffer - the
+// host can poll it per step without synchronising.  NULL leaves the current word in place; pass clear_host_err != 0 to remove it.
+extern "C" int sed_p2p_configure(void* own_ptr, double timeout_s, unsigned int* host_err, int clear_host_err) {
+    SED_CHECK_ARG(own_ptr, "sed_p2p_configure: null buffer");
+    SED_CHECK_HIP(hipDeviceSynchronize());
+    if (timeout_s > 0.0) {
+        const unsigned long long ticks = (unsigned long long)(timeout_s * (double)P2P_TICKS_PER_S);
+        SED_CHECK_HIP(hipMemcpy((char*)own_ptr + offsetof(P2PHeader, timeout_ticks), &ticks, sizeof ticks, hipMemcpyHostToDevice));
+    }
+    if (host_err != nullptr || clear_host_err) {
+        unsigned int* v = nullptr;
+        if (!clear_host_err) SED_CHECK_HIP(hipHostGetDevicePointer((void**)&v, host_err, 0));   // (pinned + mapped, or this fails)
+        SED_CHECK_HIP(hipMemcpy((char*)own_ptr + offsetof(P2PHeader, host_err), &v, sizeof v, hipMemcpyHostToDevice));
+    }
+    SED_CHECK_HIP(hipDeviceSynchronize());
+    return SED_OK;
 }
 // the sticky timeout counter of a communication buffer (blocking 4-byte copy; test / health-check use)
 extern "C" int sed_p2p_errors(const void* own_ptr, unsigned int* out) {

@@ -116,11 +116,16 @@ class PeerAllReduce:
 
     ``group`` is only used at construction (handle exchange, the self-check) and by ``errors(reduce=True)``.
     ``PeerAllReduce.create`` returns None instead of raising when the ranks are not on one host, a peer cannot be mapped, or
-    the self-check against ``dist.all_reduce`` fails on ANY rank - the caller then keeps the process group's collective."""
+    the self-check against ``dist.all_reduce`` fails on ANY rank - the caller then keeps the process group's collective.
 
-    def __init__(self, n_floats_max, device, group=None, workgroups=0, fine_grained=True):
-        import ctypes as C
-        import socket
+    Skew and failure.  Every cross-rank wait of the kernel has a wall-clock budget (``timeout_s``; default SED_P2P_TIMEOUT_S
+    or 600 s - a rank that validates, writes a checkpoint or captures its graph while the others enter the next step is late,
+    not dead, and RCCL would wait for ever).  A wait that does run out raises a sticky counter in the buffer and a word in
+    pinned host memory (``poll()``: free, called on every step by MeanTeacherStep.run) and fills the launch's output with NaN,
+    on this rank and in the slice it broadcasts: a timed-out all-reduce can neither hang the GPU nor pass for a result."""
+
+    def __init__(self, n_floats_max, device, group=None, workgroups=0, fine_grained=True, timeout_s=None):
+        import weakref
         from . import _lib
         self.l = _lib.lib()
         self.group = group
@@ -131,8 +136,24 @@ class PeerAllReduce:
         self.workgroups = int(workgroups) or int(os.environ.get("SED_P2P_WGS", "0"))
         self._own = None
         self._peers = {}
+        self._host_err = None
+        # what close() needs lives in a dict the finalizer can hold without keeping `self` alive: a step that is dropped without
+        # close() (bench.py's legs) must not leak 16 x n bytes of device memory plus its IPC mappings
+        self._res = {"own": None, "peers": {}, "host_err": None}
+        self._finalizer = weakref.finalize(self, PeerAllReduce._release, self.l, self._res, self.device)
         if self.world > 16:
             raise _lib.SedError("PeerAllReduce: at most 16 ranks (one node)")
+        try:
+            self._build(fine_grained, timeout_s)
+        except BaseException:
+            self.close()                # the buffer and whatever peers were already mapped go back (sed_p2p_open may raise mid-loop)
+            raise
+
+    def _build(self, fine_grained, timeout_s):
+        import ctypes as C
+        import socket
+        from . import _lib
+        group = self.group
         with torch.cuda.device(self.device):
             nbytes = self.l.sed_p2p_buffer_bytes(self.n_max)
             own, fg = C.c_void_p(), C.c_int(0)
@@ -141,7 +162,12 @@ class PeerAllReduce:
             mine, err = None, None
             try:
                 _lib.check(self.l.sed_p2p_alloc(nbytes, 1 if fine_grained else 0, C.byref(own), handle, C.byref(fg)), "sed_p2p_alloc")
-                self._own = own.value
+                self._own = self._res["own"] = own.value
+                # a word in pinned host memory that a timed-out wait raises besides the sticky counter in the buffer: poll()
+                # reads it every step without touching the device
+                self._host_err = self._res["host_err"] = torch.zeros(1, dtype=torch.int32).pin_memory()
+                _lib.check(self.l.sed_p2p_configure(C.c_void_p(self._own), float(timeout_s or 0.0),
+                                                    C.c_void_p(self._host_err.data_ptr()), 0), "sed_p2p_configure")
                 self.fine_grained = bool(fg.value)
                 mine = (socket.gethostname(), self.device.index or 0, os.getpid(), bytes(handle), self.fine_grained)
             except Exception as e:                     # noqa: BLE001
@@ -149,10 +175,8 @@ class PeerAllReduce:
             every = [None] * self.world
             dist.all_gather_object(every, mine, group=group)
             if any(v is None for v in every):
-                self.close()
                 raise _lib.SedError(f"PeerAllReduce: a rank could not create its communication buffer ({err!r})")
             if len({h for h, *_ in every}) != 1:
-                self.close()
                 raise _lib.SedError("PeerAllReduce: the ranks are not on one host")
             ptrs = (C.c_void_p * self.world)()
             for p, (_h, pdev, _pid, ph, _fg) in enumerate(every):
@@ -160,12 +184,11 @@ class PeerAllReduce:
                     ptrs[p] = self._own
                     continue
                 if not self.l.sed_p2p_can_access(int(pdev)):
-                    self.close()
                     raise _lib.SedError(f"PeerAllReduce: device {self.device.index} cannot map device {pdev}")
                 q = C.c_void_p()
                 hb = (C.c_ubyte * 64).from_buffer_copy(ph)
                 _lib.check(self.l.sed_p2p_open(hb, C.byref(q)), "sed_p2p_open")
-                self._peers[p] = q.value
+                self._peers[p] = self._res["peers"][p] = q.value
                 ptrs[p] = q.value
             self._ptrs = ptrs
             self.layout = [(h, d, pid, fg_) for h, d, pid, _, fg_ in every]
@@ -207,12 +230,33 @@ class PeerAllReduce:
             raise _lib.SedError("PeerAllReduce.all_reduce: needs a contiguous fp32 tensor on the communicator's device")
         import ctypes as C
         ptr = flat.data_ptr() + 4 * lo
+        if ptr % 16:
+            raise _lib.SedError("PeerAllReduce.all_reduce: the message must start on a 16-byte boundary (callers choose "
+                                "bucket bounds with PeerAllReduce.aligned(), or keep the process group's collective)")
         st = C.c_void_p(stream.cuda_stream) if stream is not None else _lib.stream_ptr()
         _lib.check(self.l.sed_p2p_allreduce(C.c_void_p(ptr), hi - lo, self.rank, self.world, self._ptrs, self.n_max,
                                             self.workgroups, st), "sed_p2p_allreduce")
 
+    @staticmethod
+    def aligned(flat, bounds):
+        """True if every (lo, hi) of ``bounds`` starts a 16-byte-aligned message inside ``flat`` (what all_reduce needs)."""
+        return all((flat.data_ptr() + 4 * lo) % 16 == 0 for lo, _hi in bounds)
+
+    def poll(self):
+        """Timed-out waits so far, read from the pinned host word the kernel raises: no device synchronisation, so the step
+        driver calls it on EVERY step (a timed-out all-reduce has already filled the gradients with NaN; this turns it into an
+        exception at the next call instead of a training run that carries on)."""
+        return int(self._host_err[0]) if self._host_err is not None else 0
+
+    def set_timeout(self, seconds):
+        """New wait budget for every later launch on this rank's buffer (blocking; the default is SED_P2P_TIMEOUT_S or 600 s)."""
+        import ctypes as C
+        from . import _lib
+        with torch.cuda.device(self.device):
+            _lib.check(self.l.sed_p2p_configure(C.c_void_p(self._own), float(seconds), None, 0), "sed_p2p_configure")
+
     def errors(self, reduce=False):
-        """Sticky count of cross-rank waits that timed out (3 s each): non-zero = results since then are invalid."""
+        """Sticky count of cross-rank waits that ran out of their budget: non-zero = results since then are NaN-poisoned."""
         import ctypes as C
         from . import _lib
         n = C.c_uint(0)
@@ -274,18 +318,98 @@ class PeerAllReduce:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
         return bool(flag.item() == 1.0)
 
-    def close(self):
-        if self._own is None and not self._peers:
-            return
+    def time_us(self, n, iters=50, stream=None):
+        """Mean microseconds of one captured all-reduce of n floats over `iters` hipGraph replays (every rank calls this with
+        the same arguments; the MAX over the ranks is what a step would see)."""
+        return graph_time_us(lambda t: self.all_reduce(t), n, self.device, self.group, iters, stream)
+
+    @staticmethod
+    def _release(l, res, device):
         import ctypes as C
-        with torch.cuda.device(self.device):
-            torch.cuda.synchronize(self.device)
-            for q in self._peers.values():
-                self.l.sed_p2p_close(C.c_void_p(q))
-            self._peers = {}
-            if self._own is not None:
-                self.l.sed_p2p_free(C.c_void_p(self._own))
-                self._own = None
+        try:
+            if res["own"] is None and not res["peers"]:
+                return
+            with torch.cuda.device(device):
+                torch.cuda.synchronize(device)
+                for q in res["peers"].values():
+                    l.sed_p2p_close(C.c_void_p(q))
+                res["peers"].clear()
+                if res["own"] is not None:
+                    l.sed_p2p_free(C.c_void_p(res["own"]))
+                    res["own"] = None
+        except Exception:                              # noqa: BLE001 - interpreter shutdown: the driver reclaims the memory
+            pass
+
+    def close(self):
+        PeerAllReduce._release(self.l, self._res, self.device)
+        self._peers = {}
+        self._own = None
 
     last_error = None
+
+
+def graph_time_us(fn, n, device, group=None, iters=50, stream=None):
+    """Capture ``fn(t)`` - one in-place all-reduce of an n-float tensor - into a hipGraph, replay it `iters` times behind
+    two warm-up replays and return the mean microseconds per call, MAX-reduced over the ranks (a collective is as slow
+    as its slowest participant).  Raises whatever the capture raises (the caller treats that as "not available")."""
+    t = torch.zeros(int(n), device=device, dtype=torch.float32)
+    st = stream or torch.cuda.Stream(device=device)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, stream=st, capture_error_mode="thread_local"):
+        fn(t)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(st):
+        for _ in range(2):
+            gr.replay()
+        st.synchronize()
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.barrier(group=group)
+        e0.record(st)
+        for _ in range(iters):
+            gr.replay()
+        e1.record(st)
+        st.synchronize()
+    us = torch.tensor([e0.elapsed_time(e1) * 1e3 / iters], device=device, dtype=torch.float64)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(us, op=dist.ReduceOp.MAX, group=group)
+    return float(us.item())
+
+
+def choose_collective(p2p, flat, buckets, group, device, iters=50):
+    """collective="auto": time the library's peer all-reduce against the process group's (captured) all-reduce on the two
+    gradient buckets the step will send and keep the FASTER (summed over the buckets; every rank sees the same MAX-reduced
+    times, hence takes the same decision).  Returns (choice, record): record holds both sets of times for config.dp_collective.
+    The process group is only a candidate where its collective can be captured and does something (backend nccl = RCCL,
+    world > 1); with gloo, or at one rank, the peer kernel is the only capturable one and is kept if it passed its self-check."""
+    rec = {"p2p_us": None, "pg_us": None, "buckets_bytes": [4 * (hi - lo) for lo, hi in buckets], "iters": iters}
+    if p2p is None:
+        rec["why"] = "peer all-reduce not available: " + str(PeerAllReduce.last_error)
+        return "pg", rec
+    world = dist.get_world_size(group)
+    try:
+        rec["p2p_us"] = [round(p2p.time_us(hi - lo, iters), 2) for lo, hi in buckets]
+    except Exception as e:                             # noqa: BLE001
+        rec["why"] = "timing the peer all-reduce failed: " + repr(e)[:200]
+    pg_ok = dist.get_backend(group) == "nccl" and world > 1
+    if pg_ok:
+        try:
+            rec["pg_us"] = [round(graph_time_us(lambda t: dist.all_reduce(t, group=group), hi - lo, device, group, iters), 2)
+                            for lo, hi in buckets]
+        except Exception as e:                         # noqa: BLE001
+            rec["pg_capture_error"] = repr(e)[:200]
+    # every rank must agree: the times are MAX-reduced already, the exceptions are not - settle them with one MIN
+    have = torch.tensor([1.0 if rec["p2p_us"] else 0.0, 1.0 if rec["pg_us"] else 0.0], device=device)
+    if world > 1:
+        dist.all_reduce(have, op=dist.ReduceOp.MIN, group=group)
+    have_p2p, have_pg = bool(have[0].item()), bool(have[1].item())
+    if have_p2p and have_pg:
+        choice = "p2p" if sum(rec["p2p_us"]) <= sum(rec["pg_us"]) else "pg"
+        rec["why"] = "faster on the step's two buckets"
+    elif have_p2p:
+        choice = "p2p"
+        rec.setdefault("why", "the process group's collective cannot be captured here (backend %s, world %d)" % (dist.get_backend(group), world))
+    else:
+        choice = "pg"
+    rec["choice"] = choice
+    return choice, rec
 

@@ -178,14 +178,27 @@ class MeanTeacherStep:
         # self-check against the process group's result passes on every rank, else pg.  The p2p launch is an ordinary kernel:
         # it is always capturable, and two ranks may share one GPU (RCCL refuses that), which is how the captured schedule is
         # tested at world 2 on a one-GPU box.
+        # "auto" no longer stops at "p2p works": it TIMES both on the step's two buckets (50 captured replays each, MAX over the
+        # ranks) and keeps the faster - dist.choose_collective; both sets of times go into self.collective_record (bench.py
+        # prints them as config.dp_collective_record).
         want_coll = collective or os.environ.get("SED_DP_COLLECTIVE") or "auto"
         if want_coll not in ("auto", "p2p", "pg"):
             raise ValueError(f"unknown collective {want_coll!r}")
+        self._buckets = sdist.grad_buckets(student._layout)
         self._p2p = None
+        self.collective_record = None
         if self.dp and want_coll != "pg":
-            self._p2p = sdist.PeerAllReduce.create(n, dev, process_group)
+            if sdist.PeerAllReduce.aligned(self.grads, self._buckets + ((0, n),)):
+                self._p2p = sdist.PeerAllReduce.create(n, dev, process_group)
+            else:      # (never with the reference's parameter shapes: every tensor is a multiple of 4 floats)
+                sdist.PeerAllReduce.last_error = "a gradient bucket does not start on a 16-byte boundary"
             if self._p2p is None and want_coll == "p2p":
                 raise _lib.SedError(f"collective='p2p' is not available here: {sdist.PeerAllReduce.last_error}")
+            if want_coll == "auto":
+                choice, self.collective_record = sdist.choose_collective(self._p2p, self.grads, self._buckets, process_group, dev)
+                if choice == "pg" and self._p2p is not None:
+                    self._p2p.close()
+                    self._p2p = None
         self.collective = "p2p" if self._p2p is not None else ("pg" if self.dp else None)
         env_cap = os.environ.get("SED_DP_CAPTURE")
         want = dp_schedule or os.environ.get("SED_DP_SCHEDULE")
@@ -221,7 +234,6 @@ class MeanTeacherStep:
         for st in (torch.cuda.current_stream(dev), self._cap_stream, self._side, self._dp_stream):
             if st is not None:
                 _lib.check(self.l.sed_stream_prepare(C.c_void_p(st.cuda_stream)), "sed_stream_prepare")
-        self._buckets = sdist.grad_buckets(student._layout)
         self._warm = 0
         self.steps_done = 0
 
@@ -489,6 +501,12 @@ class MeanTeacherStep:
 
     def run(self):
         """One step on the batch currently in self.x / self.x_ema / self.target."""
+        if self._p2p is not None and self._p2p.poll():
+            # (a pinned host word the kernel raises: no synchronisation.  The launch that timed out has already NaN-filled its
+            # gradients; this stops the run at the next step instead of letting it train on)
+            raise _lib.SedError(f"peer all-reduce: {self._p2p.poll()} cross-rank waits ran out of their budget (a rank did not "
+                                "launch the same sequence of collectives, died, or fell further behind than SED_P2P_TIMEOUT_S); "
+                                "the gradients of that step were filled with NaN")
         graph = self.use_graph and self._warm >= 2
         if graph and self._graph_a is None:
             self._capture()
@@ -569,6 +587,17 @@ class MeanTeacherStep:
             m /= self.world
         return dict(zip(LOSS_NAMES, m.tolist()))
 
+    def rendezvous(self):
+        """Host-side barrier of the data-parallel ranks + a device synchronise.  The in-kernel waits of the peer all-reduce tolerate
+        SED_P2P_TIMEOUT_S (default 600 s) of skew between ranks, as a blocking collective would; call this after rank-asymmetric
+        work that may take longer (a long validation on rank 0 only), so that no rank's GPU sits in a spinning kernel meanwhile.
+        It is NOT triggered from a local clock inside run(): a rank that was delayed and one that was not would disagree on
+        whether to enter the barrier, and the late one would wait for ever."""
+        torch.cuda.synchronize(self.device)
+        if self.pg is not None and self.world > 1:
+            import torch.distributed as dist
+            dist.barrier(group=self.pg)
+
     def check_health(self):
         """Raise if a cross-workgroup wait of the wide model's cluster recurrence (csrc/ggru.hip) ever timed out: the
         kernels then carried on with a stale hidden state and every result since is suspect.  The counter is sticky (only
@@ -648,6 +677,7 @@ class MeanTeacherStep:
         torch.cuda.synchronize(self.device)
 
     def save_checkpoint(self, path, extra=None):
+        self.check_health()            # never write parameters that a timed-out collective or recurrence has touched
         torch.save(dict(self.state_dict(), **(extra or {})), path)
 
     def load_checkpoint(self, path):

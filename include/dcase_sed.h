@@ -9,8 +9,12 @@
  *
  * Conventions
  *  - plain C types, raw DEVICE pointers, explicit hipStream_t (passed as void*); no torch types.
- *  - the caller owns ALL memory (outputs, saved context, workspace).  The library never
- *    allocates, frees or synchronises, so every entry point is hipGraph-capturable.
+ *  - the caller owns ALL memory (outputs, saved context, workspace).  The compute entry points never
+ *    allocate, free or synchronise, so every one of them is hipGraph-capturable.  ONE family is the stated
+ *    exception: the set-up calls of the data-parallel collective (sed_p2p_alloc / _configure / _open / _close /
+ *    _free / _errors, below) allocate or map fine-grained device memory - which torch's allocator can neither
+ *    create nor export - and synchronise the device; they run at construction / health-check time, never inside
+ *    a step.  sed_p2p_allreduce itself follows the rule (one capturable launch).
  *  - return 0 on success, negative sed_status on failure; sed_last_error() gives a
  *    thread-local message.  Entry points are stateless and re-entrant.
  *  - activations are channels-last fp32: [B][T][F][C]; parameters keep the reference's
@@ -247,15 +251,23 @@ int sed_mt_step_backward(const sed_dims* d, const float* params, const float* x,
  * New capability (the reference is single-process); what it serves is the per-rank batch contract of main.py:238-247 /
  * DataLoad.py:562-571 and the mean gradient of main.py:152-154.  One launch = reduce-scatter + all-gather with direct loads /
  * stores between the W ranks of one node (xGMI is point-to-point: every peer is one hop), sums formed in rank order on every
- * rank (bit-identical replicas), capturable into the step's hipGraph, every cross-rank wait bounded (sticky error counter).
+ * rank (bit-identical replicas), capturable into the step's hipGraph, every cross-rank wait bounded (sticky error counter, NaN
+ * poisoning).
  *   sed_p2p_buffer_bytes(n)  size of a rank's communication buffer for messages of up to n floats
- *   sed_p2p_alloc            allocates (fine-grained device memory; falls back to hipMalloc), zeroes and exports one: the ONE
- *                            place this library owns device memory (torch's allocator cannot create or export it); handle = 64 bytes
+ *   sed_p2p_alloc            allocates (fine-grained device memory; falls back to hipMalloc), zeroes and exports one (the
+ *                            exception stated under Conventions at the top); handle = 64 bytes.  The wait budget of the kernel's
+ *                            cross-rank waits is set here: SED_P2P_TIMEOUT_S seconds, default 600
+ *   sed_p2p_configure        (blocking) timeout_s > 0: new wait budget; host_err: host address of a 4-byte word in pinned,
+ *                            mapped host memory that every timed-out wait increments too (polled by the host per step
+ *                            without synchronising); clear_host_err != 0 removes it
  *   sed_p2p_open / _close    map / unmap a peer's buffer from its handle (hipIpcOpenMemHandle); _free releases one's own
  *   sed_p2p_can_access(dev)  1 if the current device can map device dev's memory
  *   sed_p2p_allreduce        in-place sum of data[0, n) over the ranks; bufs[world] = every rank's buffer as mapped HERE
  *                            (bufs[rank] = own); same n_floats_max and workgroups (0 = one per 2 K floats of n_floats_max, 32 .. 128) on every rank; every rank enqueues the
  *                            same sequence of calls
+ *                            A cross-rank wait that exhausts its budget raises the sticky counter AND fills this launch's
+ *                            output (the local bucket, and the slice this rank broadcasts) with NaN: a timed-out all-reduce
+ *                            never looks like a result
  *   sed_p2p_errors           the sticky count of timed-out waits (blocking 4-byte read) */
 size_t sed_p2p_buffer_bytes(long long n_floats_max);
 int sed_p2p_alloc(size_t bytes, int fine_grained, void** ptr_out, void* handle_out, int* fine_grained_out);
@@ -264,6 +276,7 @@ int sed_p2p_close(void* peer_ptr);
 int sed_p2p_free(void* own_ptr);
 int sed_p2p_can_access(int peer_device);
 int sed_p2p_errors(const void* own_ptr, unsigned int* out);
+int sed_p2p_configure(void* own_ptr, double timeout_s, unsigned int* host_err, int clear_host_err);
 int sed_p2p_allreduce(float* data, long long n, int rank, int world, void* const* bufs, long long n_floats_max,
                       int workgroups, void* stream);
 

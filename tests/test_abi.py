@@ -89,3 +89,39 @@ def test_module_refuses_configs_outside_the_hot_path_and_cpu_tensors():
         CRNN(**dict(kw, activation="relu"))
     with pytest.raises(NotImplementedError):
         CRNN(**dict(kw, attention=False))
+
+
+def test_p2p_flag_never_overtakes_the_payload_in_the_compiled_kernel():
+    """csrc/p2p.hip hands data to peer GPUs with write-through stores followed by a flag store.  The flag may only be raised
+    once every wave's payload stores are ACKNOWLEDGED: an explicit `s_waitcnt vmcnt(0)` on every wave, then the workgroup
+    barrier, then the flag.  On gfx950 the barrier itself carries no vmcnt wait (the compiler emits `s_waitcnt lgkmcnt(0);
+    s_barrier` - round 5 relied on it), so this checks the COMPILER'S OUTPUT: in every instantiation, each flag store is
+    preceded by the marked drain, with exactly one s_barrier and no vector-memory store in between."""
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(REPO, "dcase2019_task4_amd", "csrc", "p2p.hip")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "p2p.s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-DSED_AB", "-S", "--cuda-device-only", src, "-o", out],
+                       check=True, capture_output=True)
+        text = open(out).read()
+    kernels = re.split(r"^(_Z15k_p2p_allreduceILi\d+E[^:\n]*):", text, flags=re.M)
+    assert len(kernels) >= 2 * 5 + 1, "expected five instantiations of k_p2p_allreduce"
+    for name, body in zip(kernels[1::2], kernels[2::2]):
+        body = body.split(".Lfunc_end")[0]
+        lines = [ln.strip() for ln in body.split("\n")]
+        flags = [i for i, ln in enumerate(lines) if "p2p_flag_store" in ln]
+        drains = [i for i, ln in enumerate(lines) if "p2p_signal_drain" in ln]
+        assert len(flags) >= 2 and len(drains) >= 2, (name, len(flags), len(drains))
+        for f in flags:
+            before = [d for d in drains if d < f]
+            assert before, (name, "flag store without a drain in front of it")
+            between = lines[before[-1] + 1:f]
+            assert sum(ln.startswith("s_barrier") for ln in between) == 1, (name, between)
+            assert not any(re.match(r"(global|flat|buffer)_(store|atomic)", ln) for ln in between), (name, between)
+        for d in drains:
+            assert lines[d].startswith("s_waitcnt vmcnt(0)"), lines[d]

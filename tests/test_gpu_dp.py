@@ -61,7 +61,16 @@ def _worker(rank, world, port, schedule, graph, out, Bg=16, T=128, C=64, H=64, d
         # data-parallel: rank 1 starts from DIFFERENT weights - the constructor must broadcast rank 0's
         s2, t2 = models(0, 1) if rank == 0 else models(7, 8)
         dp = MeanTeacherStep(s2, t2, B, T, 40, wm, sm, seed=1234, use_graph=graph, process_group=dist.group.WORLD,
-                             dp_schedule=schedule, collective=collective)
+                             dp_schedule=schedule, collective=None if collective == "auto" else collective)
+        if collective == "auto":
+            # the default: both collectives TIMED on the step's two buckets, the faster kept (dist.choose_collective); the record
+            # of that decision is what bench.py prints.  gloo cannot be captured, RCCL at world 2 is a real candidate
+            rec = dp.collective_record
+            assert rec is not None and rec["choice"] == dp.collective and len(rec["buckets_bytes"]) == 2, rec
+            assert rec["p2p_us"] is not None and all(u > 0 for u in rec["p2p_us"]), rec
+            if backend == "gloo":
+                assert dp.collective == "p2p" and rec["pg_us"] is None, rec
+            collective = dp.collective
         assert dp.dp and dp.world == world and dp.rank == rank and dp.collective == collective
         if collective == "p2p":
             # the all-reduce is the library's own kernel over peer-mapped memory: capturable on any backend, so the DEFAULT
@@ -178,7 +187,9 @@ def _worker_entry(rank, world, port, schedule, graph, Bg, T, C, H, dtype, collec
                           ("overlap", True, 16, 128, 64, 64, "f32", "p2p"), ("overlap", False, 16, 128, 64, 64, "f32", "p2p"),
                           ("single", True, 16, 128, 64, 64, "f32", "p2p"), ("overlap", True, 128, 628, 64, 64, "f32", "p2p"),
                           ("overlap", True, 16, 216, 128, 256, "bf16", "p2p"), ("overlap", True, 16, 216, 64, 64, "bf16", "p2p"),
-                          ("overlap", True, 16, 216, 128, 256, "f16", "p2p"), ("overlap", True, 16, 216, 64, 64, "f16", "pg")])
+                          ("overlap", True, 16, 216, 128, 256, "f16", "p2p"), ("overlap", True, 16, 216, 64, 64, "f16", "pg"),
+                          # round 6: collective="auto" decides by TIME, not by "p2p works"
+                          ("overlap", True, 16, 128, 64, 64, "f32", "auto")])
 def test_mean_teacher_step_world2(schedule, graph, Bg, T, C, H, dtype, collective):
     ok = _run_world2(_worker_entry, (schedule, graph, Bg, T, C, H, dtype, collective))
     print(f"[dp world 2] backend {ok[1]} schedule {schedule} graph {graph} global batch {Bg} T {T} C {C} H {H} {dtype}: "
@@ -199,7 +210,8 @@ def _worker_peer_allreduce(rank, world, port, mode, out):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         n_max = 214356                              # the gradient buffer of cfg.crnn_kwargs
-        ar = sdist.PeerAllReduce.create(n_max, dev, dist.group.WORLD)
+        # (the wait budget is 600 s by default - skew is not failure; the timeout leg sets 2 s)
+        ar = sdist.PeerAllReduce.create(n_max, dev, dist.group.WORLD, timeout_s=2.0 if mode == "timeout" else None)
         assert ar is not None, sdist.PeerAllReduce.last_error
         g = torch.Generator().manual_seed(99 + rank)
 
@@ -212,6 +224,7 @@ def _worker_peer_allreduce(rank, world, port, mode, out):
             return want
         if mode == "timeout":
             x = torch.randn(1000, generator=g).to(dev)
+            assert ar.poll() == 0
             if rank == 0:
                 ar.all_reduce(x)                    # rank 1 never issues this one
             torch.cuda.synchronize()
@@ -219,6 +232,18 @@ def _worker_peer_allreduce(rank, world, port, mode, out):
             n_err = ar.errors()
             assert (n_err > 0) == (rank == 0), (rank, n_err)
             assert ar.errors(reduce=True) > 0
+            # the host-visible word the step driver polls without synchronising, and the poisoned output: a timed-out
+            # all-reduce must not look like a result
+            assert (ar.poll() > 0) == (rank == 0)
+            if rank == 0:
+                assert bool(torch.isnan(x).all()), "timed-out all-reduce left numbers in its output"
+            # rank 1 joins LATE (its first call = epoch 1, which rank 0 has already given up on): it must not hang, and what
+            # it gets is poisoned too (rank 0 broadcast NaN for its slice) - nobody trains on half an all-reduce
+            if rank == 1:
+                y = torch.randn(1000, generator=g).to(dev)
+                ar.all_reduce(y)
+                torch.cuda.synchronize()
+                assert bool(torch.isnan(y).any())
             if rank == 0:
                 out.put(("ok", "gloo", float(n_err)))
             return
@@ -267,6 +292,117 @@ def _worker_peer_allreduce(rank, world, port, mode, out):
 def test_peer_allreduce_world2_on_one_gpu(mode):
     ok = _run_world2(_worker_peer_allreduce, (mode,))
     print(f"[p2p all-reduce world 2] mode {mode}: {'fine-grained buffers' if ok[2] == 1.0 and mode == 'sums' else ok[2]}")
+
+
+def _worker_skew(rank, world, port, collective, out):
+    """Rank 1 falls 5 s behind between two steps (a checkpoint, a validation pass, a data-loader stall): the captured
+    data-parallel step must simply wait - no timeout, no NaN, replicas bit-identical afterwards.  Round 5's kernel gave up
+    after 3 s and trained on stale staging data."""
+    if REPO not in sys.path:
+        sys.path.insert(0, REPO)
+    import time
+    import torch.distributed as dist
+    from dcase2019_task4_amd import dist as sdist
+    from dcase2019_task4_amd.train import MeanTeacherStep
+    from oracle import synth
+    from tests import gpu_util as gu
+    n_dev = torch.cuda.device_count()
+    dev = torch.device("cuda", rank if n_dev >= world else 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl" if n_dev >= world else "gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        Bg, T = 16, 128
+        sizes = [Bg // 4, Bg // 2, Bg // 4]
+        tgt_g, _, _ = synth.make_target(1, Bg, T // 8)
+        wm, sm = sdist.local_masks(sizes, world)
+        s, _ = gu.make_model(0, dropout=0.5, device=dev)
+        t, _ = gu.make_model(1, dropout=0.5, device=dev)
+        s.train(); t.train()
+        dp = MeanTeacherStep(s, t, Bg // world, T, 40, wm, sm, seed=1234, use_graph=True, process_group=dist.group.WORLD,
+                             collective=collective)
+        assert dp.collective == collective
+        for i in range(6):
+            xg, xeg = synth.make_input(60 + i, Bg, T), synth.make_input(70 + i, Bg, T)
+            b = [v.to(dev) for v in sdist.shard_batch([xg, xeg, tgt_g], sizes, rank, world)]
+            if i == 4 and rank == 1:
+                torch.cuda.synchronize()
+                time.sleep(5.0)
+            dp.step(*b)
+        torch.cuda.synchronize()
+        dp.check_health()
+        assert dp._p2p is None or (dp._p2p.poll() == 0 and dp._p2p.errors(reduce=True) == 0)
+        assert bool(torch.isfinite(dp.grads).all()) and bool(torch.isfinite(s._flat).all())
+        for name, tns in (("student", s._flat), ("teacher", t._flat), ("exp_avg", dp.exp_avg)):
+            tl = [torch.zeros_like(tns) for _ in range(world)]
+            dist.all_gather(tl, tns.contiguous())
+            assert torch.equal(tl[0], tl[1]), f"replicas diverged: {name}"
+        dp.rendezvous()
+        dp.close()
+        if rank == 0:
+            out.put(("ok", collective, 5.0))
+    except Exception:
+        import traceback
+        out.put(("fail", rank, traceback.format_exc()))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_rank_that_falls_five_seconds_behind_is_waited_for():
+    ok = _run_world2(_worker_skew, ("p2p",))
+    print(f"[dp world 2] rank 1 slept {ok[2]} s before a step under collective {ok[1]}: no timeout, replicas bit-identical")
+
+
+def _worker_step_stops_after_timeout(rank, world, port, out):
+    """MeanTeacherStep.run() must RAISE on the step after a peer all-reduce ran out of its budget (rank 1 stops stepping):
+    the pinned host word is polled on every run(), the gradients of the timed-out step are NaN."""
+    if REPO not in sys.path:
+        sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    from dcase2019_task4_amd import _lib, dist as sdist
+    from dcase2019_task4_amd.train import MeanTeacherStep
+    from oracle import synth
+    from tests import gpu_util as gu
+    n_dev = torch.cuda.device_count()
+    dev = torch.device("cuda", rank if n_dev >= world else 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        Bg, T = 16, 128
+        sizes = [Bg // 4, Bg // 2, Bg // 4]
+        tgt_g, _, _ = synth.make_target(1, Bg, T // 8)
+        wm, sm = sdist.local_masks(sizes, world)
+        s, _ = gu.make_model(0, dropout=0.5, device=dev)
+        t, _ = gu.make_model(1, dropout=0.5, device=dev)
+        s.train(); t.train()
+        dp = MeanTeacherStep(s, t, Bg // world, T, 40, wm, sm, seed=1234, use_graph=False, process_group=dist.group.WORLD,
+                             collective="p2p")
+        dp._p2p.set_timeout(1.0)
+        xg, xeg = synth.make_input(60, Bg, T), synth.make_input(70, Bg, T)
+        b = [v.to(dev) for v in sdist.shard_batch([xg, xeg, tgt_g], sizes, rank, world)]
+        dp.step(*b)
+        torch.cuda.synchronize()
+        dist.barrier()
+        if rank == 0:
+            dp.step(*b)                            # rank 1 does not take this step: every wait of rank 0 runs out (1 s each)
+            torch.cuda.synchronize()
+            assert bool(torch.isnan(dp.grads).any()), "the timed-out step left finite gradients"
+            with pytest.raises(_lib.SedError, match="cross-rank waits ran out"):
+                dp.run()
+            with pytest.raises(_lib.SedError):
+                dp.save_checkpoint("/tmp/never_written.pt")
+            out.put(("ok", "p2p", 1.0))
+        dist.barrier()
+    except Exception:
+        import traceback
+        out.put(("fail", rank, traceback.format_exc()))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_step_raises_after_a_collective_timed_out():
+    _run_world2(_worker_step_stops_after_timeout, ())
 
 
 def _worker_frontend(rank, world, port, dtype, out):

@@ -82,6 +82,7 @@ _SIGS = {
                                       C.c_double, C.c_double, _P]),
     "sed_step_state_advance": (C.c_int, [_P, _P]),
     "sed_step_state_update": (C.c_int, [_P, C.c_uint64, C.c_double, C.c_int, _P]),
+    "sed_step_state_set_global_step": (C.c_int, [_P, C.c_int64, _P]),
     "sed_stream_prepare": (C.c_int, [_P]),
     "sed_stream_release": (C.c_int, [_P]),
     "sed_crnn_fork_callback": (C.c_int, [_P, _P, _P]),

@@ -73,6 +73,14 @@ __global__ void k_step_state_update(sed_step_state* s, uint64_t base_seed, doubl
     step_state_derive(s);
 }
 
+// global_step = epoch * len(train_loader) + i is RECOMPUTED from the epoch argument at every call of main.train (main.py:74):
+// a run that enters train(epoch = k) with a fresh step object must see the ramp-up, EMA alpha and dropout keys of step
+// k * len(loader), not of step 0.  The Adam step counter is the optimiser's own and is left alone.
+__global__ void k_step_state_set_global_step(sed_step_state* s, int64_t gs) {
+    s->global_step = gs;
+    step_state_derive(s);
+}
+
 extern "C" int sed_adam_ema(int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                             float* ema_params, const sed_step_state* state_dev, float grad_scale, void* stream) {
     SED_CHECK_ARG(n > 0 && params && grads && exp_avg && exp_avg_sq && state_dev, "sed_adam_ema: bad argument");
@@ -109,6 +117,13 @@ extern "C" int sed_step_state_init(sed_step_state* state_dev, uint64_t base_seed
 extern "C" int sed_step_state_update(sed_step_state* state_dev, uint64_t base_seed, double lr, int flags, void* stream) {
     SED_CHECK_ARG(state_dev, "sed_step_state_update: null state");
     k_step_state_update<<<1, 1, 0, (hipStream_t)stream>>>(state_dev, base_seed, lr, flags);
+    SED_CHECK_LAUNCH();
+    return SED_OK;
+}
+
+extern "C" int sed_step_state_set_global_step(sed_step_state* state_dev, int64_t global_step, void* stream) {
+    SED_CHECK_ARG(state_dev && global_step >= 0, "sed_step_state_set_global_step: bad argument");
+    k_step_state_set_global_step<<<1, 1, 0, (hipStream_t)stream>>>(state_dev, global_step);
     SED_CHECK_LAUNCH();
     return SED_OK;
 }

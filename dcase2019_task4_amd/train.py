@@ -236,6 +236,7 @@ class MeanTeacherStep:
                 _lib.check(self.l.sed_stream_prepare(C.c_void_p(st.cuda_stream)), "sed_stream_prepare")
         self._warm = 0
         self.steps_done = 0
+        self.global_step_host = 0          # host mirror of state.global_step (no device read in train())
 
     def _stream(self, role, priority=0):
         if self._pool_streams:
@@ -408,6 +409,15 @@ class MeanTeacherStep:
         sdist.broadcast_parameters(ts, self.pg, src=src)
         _lib.check(self.l.sed_step_state_update(_lib.ptr(self.state), self._folded_seed(), 0.0, 1, _lib.stream_ptr()),
                    "sed_step_state_update")
+        self.global_step_host = int(self.read_state().global_step)
+
+    def set_global_step(self, global_step):
+        """main.py:74 - ``global_step = epoch * len(train_loader) + i``: the reference recomputes the counter from the epoch
+        argument on every call of ``train``; this sets the device counter the ramp-up, the EMA alpha and the dropout keys
+        derive from (Adam's own step count is the optimiser's and stays)."""
+        _lib.check(self.l.sed_step_state_set_global_step(_lib.ptr(self.state), int(global_step), _lib.stream_ptr()),
+                   "sed_step_state_set_global_step")
+        self.global_step_host = int(global_step)
 
     def set_lr(self, lr):
         """Honour an optimiser whose lr changed between epochs (main.py never does; utils.adjust_learning_rate exists)."""
@@ -522,6 +532,7 @@ class MeanTeacherStep:
             self._dp_step_eager_collectives(graph)
         self._warm += 1
         self.steps_done += 1
+        self.global_step_host += 1
 
     def step(self, x, x_ema, target):
         """``x_ema`` is ignored (may be None) in supervised mode."""
@@ -671,6 +682,7 @@ class MeanTeacherStep:
         self.state.copy_(torch.from_numpy(raw))
         self.seed_user = int(sd.get("seed_user", self.seed_user))
         self.steps_done = int(sd.get("steps_done", 0))
+        self.global_step_host = int(_lib.SedStepState.from_buffer_copy(bytes(sd["step_state"])).global_step)
         if self.rank != 0:       # the file holds rank 0's stream; every other rank re-folds its own rank into the seed
             _lib.check(self.l.sed_step_state_update(_lib.ptr(self.state), self._folded_seed(), 0.0, 1, _lib.stream_ptr()),
                        "sed_step_state_update")
@@ -721,6 +733,11 @@ def train(train_loader, model, optimizer, epoch, ema_model=None, weak_mask=None,
             model._mt_step = step_obj
         if i == 0:
             step_obj.set_lr(pg0["lr"])        # an lr the caller changed between epochs is honoured (utils.py:227-241)
+            # main.py:74: global_step = epoch * len(train_loader) + i - recomputed from `epoch` at every call.  A call sequence
+            # epoch = 0, 1, 2 ... over one loader finds the device counter already there; a fresh step object entered with
+            # epoch = k (a resumed run that did not load_checkpoint), a repeated or a skipped epoch gets the reference's value
+            if step_obj.global_step_host != int(epoch) * n_batches:
+                step_obj.set_global_step(int(epoch) * n_batches)
         step_obj.step(batch_input.to(step_obj.device, non_blocking=True),
                       ema_batch_input.to(step_obj.device, non_blocking=True) if ema_batch_input is not None else None,
                       target.to(step_obj.device, non_blocking=True))

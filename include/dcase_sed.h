@@ -303,6 +303,10 @@ int sed_step_state_advance(sed_step_state* state_dev, void* stream);
  * checkpoint written by rank 0 was loaded), bit 1 = lr (baseline/main.py:289 sets it once; adjust_learning_rate,
  * utils/utils.py:227-241, is dead code in main.py:81 but an optimizer whose lr changed between epochs is honoured). */
 int sed_step_state_update(sed_step_state* state_dev, uint64_t base_seed, double lr, int flags, void* stream);
+/* main.train recomputes global_step = epoch * len(train_loader) + i from its epoch argument at every call (baseline/main.py:74):
+ * sets the counter the ramp-up (main.py:74-78), the EMA alpha (main.py:155-157) and the dropout keys are derived from, and
+ * re-derives them; the optimiser's own step counter (Adam bias correction) is untouched. */
+int sed_step_state_set_global_step(sed_step_state* state_dev, int64_t global_step, void* stream);
 
 /* ---- feature front-end ---------------------------------------------------------------------
  * sed_mel_spec replaces DatasetDcase2019Task4.calculate_mel_spec (DatasetDcase2019Task4.py:

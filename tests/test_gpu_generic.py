@@ -75,7 +75,13 @@ def _fwd_bwd(B, T, p, C, H, dtype, seed=987654321, n_layers=2, nclass=10):
                 stages=stages)
 
 
-def _grad_errors(g_hip, go):
+def _grad_class(name):
+    return "cnn" if name.startswith("cnn") else ("rnn" if name.startswith("rnn") else "heads")
+
+
+def _grad_errors(g_hip, go, per_class=None):
+    """Worst gradient element per parameter, relative to the gradient's typical magnitude (rms); prints the per-layer table.
+    ``per_class``: a dict that receives the maximum per layer class (cnn / rnn / heads)."""
     worst, worst_name = 0.0, None
     for n, g in go.items():
         if ".conv" in n and n.endswith("bias"):
@@ -85,6 +91,8 @@ def _grad_errors(g_hip, go):
         err = float((g_hip[n] - g).abs().max())
         rel = (err - 1e-7) / scale
         print(f"[grad] {n:40s} |g|/sqrt(n) {scale:.3e}  max|err| {err:.3e}  err/typ {err / scale:.3e}")
+        if per_class is not None:
+            per_class[_grad_class(n)] = max(per_class.get(_grad_class(n), 0.0), rel)
         if rel > worst:
             worst, worst_name = rel, n
     return worst, worst_name
@@ -161,7 +169,15 @@ def test_bf16x3_split_operands_hold_the_north_star_tolerance(B, T, p, C, H):
 
 
 F16_POST_TOL = 1e-3          # the north star's bound; measured 1 - 3e-4 (tests/bf16_budget.py predicts 1.1e-4 base / 3.1e-4 wide)
-F16_GRAD_TOL = BF16_GRAD_TOL   # the backward IS the bf16 mode's
+# SED_DTYPE_F16's OWN gradient bounds (round 6; until then the bf16 mode's 1.4e-1 was re-used): the measured maximum over the
+# twelve geometries below per layer class (profiles/r06_f16_gradient_errors.md: worst element / rms of the gradient), + 35 %.
+#   conv blocks   6.7e-2  (batchnorm0.bias / glu0.linear.bias at (24, 628): 64-element vectors, each a sum over 965 k pixels with
+#                          cancellation; every other conv-block tensor <= 5.1e-2) - the conv-block BACKWARD is the bf16 mode's:
+#                          bf16 gradient tensors and operands (8-bit significands; fp16's range does not cover 1e-9 .. 1e-4)
+#   recurrences   2.6e-2 at H = 64 (fp32 recurrence; the error is what arrives from p2), 4.2e-2 at H = 256 (bf16 dgate operands)
+#   heads         5.7e-3 (fp32 kernels on an fp16-accurate forward)
+# The bf16 mode on the same shapes: 1.0e-1 / 8.1e-2 / 4.0e-2.
+F16_GRAD_TOL = {"cnn": 9.0e-2, "rnn64": 3.6e-2, "rnn256": 5.7e-2, "heads": 7.8e-3}
 
 
 @pytest.mark.parametrize("B,T,p,C,H", [(4, 128, 0.5, 64, 64), (4, 628, 0.5, 64, 64), (24, 628, 0.5, 64, 64), (4, 864, 0.5, 64, 64),
@@ -173,21 +189,19 @@ def test_f16_forward_chain_holds_the_north_star_tolerance_at_bf16_speed(B, T, p,
     GEMM-shaped operator and the activations the forward hands on (11-bit significand, same MFMA rate and bytes as bf16) - and
     the bf16 mode's backward unchanged (it reads bf16 copies the forward kernels write).  Against the FP32 oracle on identical
     inputs and Philox masks: posteriors within the north star's 1e-3, asserted AT 1e-3 on the base and the wide model incl.
-    BASELINE configs[4]'s per-GPU shape (24, 628); gradients at the bf16 mode's bound."""
+    BASELINE configs[4]'s per-GPU shape (24, 628); gradients at the mode's OWN measured bounds per layer class (F16_GRAD_TOL)."""
     r = _fwd_bwd(B, T, p, C, H, "f16")
     es, _ = gu.report("strong (f16 forward)", r["s"], r["so"])
     ew, _ = gu.report("weak (f16 forward)", r["w"], r["wo"])
-    worst, name = _grad_errors(r["g"], r["go"])
-    print(f"[f16] C={C} H={H} B={B} T={T}: posterior err strong {es:.2e} weak {ew:.2e}; worst gradient err/typ {worst:.2e} ({name})")
+    cls = {}
+    worst, name = _grad_errors(r["g"], r["go"], cls)
+    print(f"[f16] C={C} H={H} B={B} T={T}: posterior err strong {es:.2e} weak {ew:.2e}; worst gradient err/typ {worst:.2e} ({name}); "
+          f"per class cnn {cls['cnn']:.2e} rnn {cls['rnn']:.2e} heads {cls['heads']:.2e}")
     assert es < F16_POST_TOL and ew < F16_POST_TOL
     assert r["loss"] == pytest.approx(r["lo"], rel=1e-3)
-    if worst >= F16_GRAD_TOL:
-        # a shape outside the bf16 test's list (small batch, 8-bit dropout draws): the backward is the bf16 mode's, so the bound is
-        # what the bf16 mode itself does on this shape
-        rb = _fwd_bwd(B, T, p, C, H, "bf16")
-        worst_b, name_b = _grad_errors(rb["g"], rb["go"])
-        print(f"[f16] gradient bound from the bf16 mode on this shape: {worst_b:.2e} ({name_b})")
-        assert worst < 1.3 * worst_b, (name, worst, worst_b)
+    assert cls["cnn"] < F16_GRAD_TOL["cnn"], (name, cls)
+    assert cls["rnn"] < F16_GRAD_TOL["rnn%d" % H], (name, cls)
+    assert cls["heads"] < F16_GRAD_TOL["heads"], (name, cls)
     for k, v in r["bno"].items():
         if not k.endswith("num_batches_tracked"):
             np.testing.assert_allclose(r["bn"][k].numpy(), v.numpy(), rtol=4e-3, atol=1e-3, err_msg=k)

@@ -458,6 +458,50 @@ def test_supervised_fused_steps_vs_real_main_simple_crnn_goldens(golden_dir, use
         np.testing.assert_allclose(v.cpu().numpy(), g["b_" + k.replace(".", "_")], rtol=3e-5, atol=atol, err_msg=k)
 
 
+def test_train_honours_the_epoch_argument_like_main_py_74():
+    """main.py:74 recomputes ``global_step = epoch * len(train_loader) + i`` from the epoch argument at every call of train: the
+    consistency weight a call logs must be the oracle's for THAT global step - over an epoch 0, 1 call sequence on one step
+    object (the device counter is already there), and for a FRESH object entered with epoch = 3 (a resumed run that did not
+    load a checkpoint; round 5 gave it the ramp-up of step 0)."""
+    from dcase2019_task4_amd import train as tr
+    B, T, n_batches, n_epoch = 8, 64, 2, 8
+    R = n_batches * n_epoch // 2                            # main.py:72
+    wm, sm = slice(B // 4), slice(3 * B // 4, B)
+    tgt = synth.make_target(3, B, T // 8)[0]
+
+    def loader(e):
+        return [(synth.make_input(10 * e + i, B, T), synth.make_input(100 + 10 * e + i, B, T), tgt) for i in range(n_batches)]
+
+    def fresh():
+        s, _ = gu.make_model(0, dropout=0.5)
+        t, _ = gu.make_model(1, dropout=0.5)
+        s.train(); t.train()
+        return s, t, torch.optim.Adam(s.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    s, t, opt = fresh()
+    for e in (0, 1):
+        m = tr.train(loader(e), s, opt, e, ema_model=t, weak_mask=wm, strong_mask=sm, n_epoch=n_epoch, log=lambda *_: None)
+        last = e * n_batches + n_batches - 1
+        assert m["cons_weight"] == pytest.approx(ref_cpu.consistency_weight(last, R), rel=1e-6), (e, m["cons_weight"])
+        st = s._mt_step.read_state()
+        assert st.global_step == (e + 1) * n_batches == s._mt_step.global_step_host and st.opt_step == (e + 1) * n_batches + 1
+    keys_seq = s._mt_step.read_state().seed_student
+    # a fresh step object entered at epoch 3: the reference's formula, not a counter that starts at 0
+    s2, t2, opt2 = fresh()
+    m = tr.train(loader(3), s2, opt2, 3, ema_model=t2, weak_mask=wm, strong_mask=sm, n_epoch=n_epoch, log=lambda *_: None)
+    assert m["cons_weight"] == pytest.approx(ref_cpu.consistency_weight(3 * n_batches + 1, R), rel=1e-6)
+    assert m["cons_weight"] != pytest.approx(ref_cpu.consistency_weight(1, R), rel=1e-3)
+    st2 = s2._mt_step.read_state()
+    assert st2.global_step == 4 * n_batches and st2.opt_step == n_batches + 1      # Adam's count is the optimiser's own (fresh)
+    # ... past the ramp-up length the weight is the full max_consistency_cost (main.py:74-78)
+    s3, t3, opt3 = fresh()
+    m = tr.train(loader(5), s3, opt3, 5, ema_model=t3, weak_mask=wm, strong_mask=sm, n_epoch=n_epoch, log=lambda *_: None)
+    assert m["cons_weight"] == pytest.approx(2.0, rel=1e-6)
+    # re-entering epoch 1 on the first object rewinds the counter exactly as the reference's formula does
+    m = tr.train(loader(1), s, opt, 1, ema_model=t, weak_mask=wm, strong_mask=sm, n_epoch=n_epoch, log=lambda *_: None)
+    assert m["cons_weight"] == pytest.approx(ref_cpu.consistency_weight(n_batches + n_batches - 1, R), rel=1e-6)
+    assert s._mt_step.read_state().seed_student == keys_seq      # same global step -> same dropout key chain position
+
+
 def _assert_params_close(got, want, name, n_steps, lr=1e-3):
     """Parameters after a few Adam steps.  Adam normalises each gradient element to ~+-lr, so an
     element whose gradient is ~0 (|g| at rounding-noise level) can legitimately move differently on

@@ -59,6 +59,7 @@ _SIGS = {
     "sed_crnn_ctx_bytes": (C.c_size_t, [C.POINTER(SedDims)]),
     "sed_crnn_bwd_ws_bytes": (C.c_size_t, [C.POINTER(SedDims)]),
     "sed_crnn_forward": (C.c_int, [C.POINTER(SedDims), _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, C.c_size_t, _P, _P, _P]),
+    "sed_crnn_moments": (C.c_int, [C.POINTER(SedDims), _P, _P, C.c_size_t, _P]),
     "sed_crnn_backward": (C.c_int, [C.POINTER(SedDims), _P, _P, _P, _P, C.c_size_t, _P, _P, _P, _P, C.c_size_t, C.c_int, _P]),
     "sed_crnn_buffers_init": (C.c_int, [C.POINTER(SedDims), _P, C.c_size_t, _P, C.c_size_t, _P]),
     "sed_crnn_ctx_view": (C.c_int, [C.POINTER(SedDims), C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

@@ -128,7 +128,25 @@ struct Blk0PrepArgs {
     int C;                 // conv filters of block 0 (64 on the reference's configuration, 128 for the wide one)
 };
 #define PREP_THREADS 896      // 54 moments x 16 partial-sum lanes = 864 threads for the reduction; >= 640 for the GLU fold
-__global__ __launch_bounds__(PREP_THREADS) void k_blk0_prep(Blk0PrepArgs a) {
+__device__ __forceinline__ void blk0_prep_body(const Blk0PrepArgs& a);
+__global__ __launch_bounds__(PREP_THREADS) void k_blk0_prep(Blk0PrepArgs a) { blk0_prep_body(a); }
+// Round 6: a training forward whose patch moments are ALREADY in ctx (sed_crnn_moments ran for this batch during the previous
+// step, off the critical chain) has no moments launch for the per-forward weight packing to ride in; it rides here instead:
+// workgroup 0 is the prep, workgroups 1 .. do the packing with their first 256 threads (the bodies are written for 256-thread
+// blocks; the other waves leave at once - s_barrier does not wait for terminated waves).
+__global__ __launch_bounds__(PREP_THREADS) void k_blk0_prep_pack(Blk0PrepArgs a, ConvPackArgs pack) {
+    if (blockIdx.x == 0) { blk0_prep_body(a); return; }
+    if (threadIdx.x >= 256) return;
+    const int pb = (int)blockIdx.x - 1;
+    if (pb < SED_PACK_BLOCKS) conv_pack_body(pack, pb * 256 + (int)threadIdx.x);
+}
+__global__ __launch_bounds__(PREP_THREADS) void k_blk0_prep_aux(Blk0PrepArgs a, GenAuxPack aux, int n_aux) {
+    if (blockIdx.x == 0) { blk0_prep_body(a); return; }
+    if (threadIdx.x >= 256) return;
+    const int pb = (int)blockIdx.x - 1;
+    if (pb < n_aux) gen_aux_body(aux, pb, (int)threadIdx.x);
+}
+__device__ __forceinline__ void blk0_prep_body(const Blk0PrepArgs& a) {
     __shared__ double wzs[128][10];
     const int C = a.C;
     __shared__ double mred[54][16];
@@ -904,9 +922,11 @@ int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const flo
                         const float* beta, const float* wglu, const float* bglu, float* run_mean, float* run_var,
                         int64_t* tracked, int train, int update, const uint64_t* seed, double* mom, double* mompart,
                         float* wz, float* wl, float* bn, float* p0, uint16_t* mask_out, const ConvPackArgs* pack, hipStream_t st,
-                        int main_kernel_only, const GenAuxPack* aux, void* p0_b16) {
+                        int main_kernel_only, const GenAuxPack* aux, void* p0_b16, int mom_ready) {
     // main_kernel_only (sed_kernel_replay): the folded weights of the last real forward are still in wz / wl
-    if (train && !main_kernel_only) {
+    // mom_ready: mompart already holds this batch's patch moments (sed_crnn_moments) - no moments launch; the packing that would
+    // have ridden in it rides in the prep launch
+    if (train && !main_kernel_only && !mom_ready) {
         const int rc = launch_x_moments(g, x, mompart, pack, st, aux);
         if (rc != SED_OK) return rc;
     }
@@ -917,7 +937,14 @@ int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const flo
     a.N = (double)g.B * g.T * g.F; a.train = train; a.update = update; a.eps = g.eps; a.momentum = g.mom;
     a.wz = wz; a.wl = wl; a.bn = bn; a.C = g.C;
     if (!main_kernel_only) {
-        k_blk0_prep<<<1, PREP_THREADS, 0, st>>>(a);
+        if (train && mom_ready && aux) {
+            const int n_aux = gen_aux_blocks(*aux);
+            k_blk0_prep_aux<<<1 + n_aux, PREP_THREADS, 0, st>>>(a, *aux, n_aux);
+        } else if (train && mom_ready && pack) {
+            k_blk0_prep_pack<<<1 + SED_PACK_BLOCKS, PREP_THREADS, 0, st>>>(a, *pack);
+        } else {
+            k_blk0_prep<<<1, PREP_THREADS, 0, st>>>(a);
+        }
         SED_CHECK_LAUNCH();
     }
     const int tpc = (g.H1 + 1) / 2, nt = tpc * g.B;

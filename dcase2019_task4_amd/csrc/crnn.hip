@@ -304,6 +304,10 @@ extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* b
                                 size_t ctx_bytes, float* strong, float* weak, void* stream) {
     SED_TRY(sed_validate_dims(d));
     SED_CHECK_ARG(params && bn_running && x && ctx, "sed_crnn_forward: null argument");
+    // train bit 2 (value 4): this batch's patch moments are already in ctx (sed_crnn_moments ran for it, e.g. during the previous
+    // step): no moments launch at the head of the forward
+    const int mom_ready = (train & 4) ? 1 : 0;
+    train &= 3;
     // strong == weak == NULL (train mode only): the output heads are left to sed_mt_step_backward, which runs them together
     // with the loss and their backward in front of the top layer's backward recurrence
     SED_CHECK_ARG((strong && weak) || (!strong && !weak && train), "sed_crnn_forward: strong and weak must both be given (or both NULL in train mode: heads deferred)");
@@ -313,8 +317,8 @@ extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* b
         SED_CHECK_ARG(!(train && g.p > 0.f) || seed_dev, "sed_crnn_forward: dropout enabled but seed_dev is null");
         hipStream_t st0 = (hipStream_t)stream;
         SideStream& sd0 = side_stream(st0);
-        return gen_forward(g, P, params, bn_running, bn_tracked, x, train, update_bn, seed_dev, ctx, ctx_bytes, strong, weak, st0,
-                           sd0.ok ? sd0.s : st0, sd0.fork, sd0.join);
+        return gen_forward(g, P, params, bn_running, bn_tracked, x, train | (mom_ready ? 4 : 0), update_bn, seed_dev, ctx, ctx_bytes, strong,
+                           weak, st0, sd0.ok ? sd0.s : st0, sd0.fork, sd0.join);
     }
     const CtxLayout L = make_ctx_layout(g);
     if (ctx_bytes < L.total) {
@@ -337,8 +341,8 @@ extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* b
     SED_TRY(launch_blk0_forward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
                                 params + P.glu_w[0], params + P.glu_b[0], bn_running + 0, bn_running + 64, trk[0], train,
                                 upd, seed_dev, CTXD(L.mom0), CTXD(L.mompart), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), CTXF(L.p0),
-                                use_drop ? CTXM(L.mask0) : nullptr, train ? &pack : nullptr, st));
-    if (!train) SED_TRY(launch_conv_pack(pack, st));      // (training: done by extra workgroups of k_x_moments)
+                                use_drop ? CTXM(L.mask0) : nullptr, train ? &pack : nullptr, st, 0, nullptr, nullptr, mom_ready));
+    if (!train) SED_TRY(launch_conv_pack(pack, st));      // (training: done by extra workgroups of k_x_moments / k_blk0_prep_pack)
     // ---- conv blocks 1, 2 -----------------------------------------------------------------------
     const float* in = CTXF(L.p0);
     const size_t wpk[3] = {0, L.wpk1, L.wpk2}, yo[3] = {0, L.y1, L.y2}, so[3] = {0, L.stat1, L.stat2},
@@ -370,6 +374,29 @@ extern "C" int sed_crnn_forward(const sed_dims* d, const float* params, float* b
                              train ? CTXF(L.strong_sv) : nullptr, train ? CTXF(L.weak_sv) : nullptr, CTXF(L.logits_s),
                              CTXF(L.den_sv), g.B, g.T3, g.NC, use_drop, g.p, seed_dev, st));
     return SED_OK;
+}
+
+// The train-mode BatchNorm statistics of conv block 0 come from the 9 + 45 first / second moments of the 3x3 input patch
+// (blk0.hip): a function of the BATCH only, not of any parameter.  A caller that has the next batch resident while the current
+// step runs (features.WaveformFrontEnd: one batch ahead; a constant / resident batch) computes them THEN - beside the
+// recurrences, which leave most of the chip idle - and passes train | 4 to the forward that consumes them: 16 us (B = 24) of
+// launch + round trip leave the head of the step's critical chain.  Same kernel, same partials, same order: bit-identical.
+extern "C" int sed_crnn_moments(const sed_dims* d, const float* x, void* ctx, size_t ctx_bytes, void* stream) {
+    SED_TRY(sed_validate_dims(d));
+    SED_CHECK_ARG(x && ctx, "sed_crnn_moments: null argument");
+    const Geo g = make_geo(d);
+    double* mompart = nullptr;
+    if (g.generic) {
+        SED_TRY(gen_mompart(g, ctx, ctx_bytes, &mompart));
+    } else {
+        const CtxLayout L = make_ctx_layout(g);
+        if (ctx_bytes < L.total) {
+            sed_set_error("sed_crnn_moments: ctx has %zu bytes, needs %zu", ctx_bytes, L.total);
+            return SED_ERR_WORKSPACE;
+        }
+        mompart = CTXD(L.mompart);
+    }
+    return launch_x_moments(g, x, mompart, nullptr, (hipStream_t)stream);
 }
 
 static int crnn_backward_impl(const sed_dims* d, const float* params, const float* x, const uint64_t* seed_dev,

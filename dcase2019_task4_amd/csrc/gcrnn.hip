@@ -159,9 +159,21 @@ int gen_buffers_init(const Geo& g, void* ctx, size_t ctx_bytes, void* ws, size_t
 #define WSF(off) ((float*)((char*)ws + (off)))
 #define WSD(off) ((double*)((char*)ws + (off)))
 
+int gen_mompart(const Geo& g, void* ctx, size_t ctx_bytes, double** out) {
+    const GCtx L = make_gctx(g);
+    if (ctx_bytes < L.total) {
+        sed_set_error("sed_crnn_moments: ctx has %zu bytes, needs %zu", ctx_bytes, L.total);
+        return SED_ERR_WORKSPACE;
+    }
+    *out = (double*)((char*)ctx + L.mompart);
+    return SED_OK;
+}
+
 int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_running, int64_t* bn_tracked, const float* x,
                 int train, int update_bn, const uint64_t* seed_dev, void* ctx, size_t ctx_bytes, float* strong, float* weak,
                 hipStream_t st, hipStream_t ss, hipEvent_t ev_fork, hipEvent_t ev_join) {
+    const int mom_ready = (train & 4) ? 1 : 0;      // (sed_crnn_forward's train bit 2)
+    train &= 3;
     const GCtx L = make_gctx(g);
     if (ctx_bytes < L.total) {
         sed_set_error("sed_crnn_forward: ctx has %zu bytes, needs %zu", ctx_bytes, L.total);
@@ -237,7 +249,7 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
                                 seed_dev, CTXD(L.mom0), CTXD(L.mompart), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0),
                                 g.f16 ? CTXF(L.ph[0]) : CTXF(L.p[0]),
                                 use_drop ? CTXM(L.mask[0]) : nullptr, nullptr, st, 0, aux_pack ? &aux : nullptr,
-                                (g.f16 && keep_b16) ? CTXV(L.p[0]) : nullptr));
+                                (g.f16 && keep_b16) ? CTXV(L.p[0]) : nullptr, mom_ready));
     // ---- conv blocks 1, 2 -----------------------------------------------------------------------------------------------
     const size_t so[3] = {0, L.stat1, L.stat2};
     const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};

@@ -112,6 +112,7 @@ size_t gen_ctx_bytes(const Geo& g);
 size_t gen_ws_bytes(const Geo& g);
 int gen_buffers_init(const Geo& g, void* ctx, size_t ctx_bytes, void* ws, size_t ws_bytes, hipStream_t st);
 int gen_ctx_view(const Geo& g, const char* name, size_t* offset, size_t* bytes);
+int gen_mompart(const Geo& g, void* ctx, size_t ctx_bytes, double** out);      // where the patch-moment partials live in a generic ctx
 int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_running, int64_t* bn_tracked, const float* x,
                 int train, int update_bn, const uint64_t* seed_dev, void* ctx, size_t ctx_bytes, float* strong, float* weak,
                 hipStream_t st, hipStream_t ss, hipEvent_t ev_fork, hipEvent_t ev_join);

@@ -16,7 +16,8 @@ int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const flo
                         float* wz, float* wl, float* bn, float* p0, uint16_t* mask_out, const ConvPackArgs* pack /* train only */,
                         hipStream_t st,
                         int main_kernel_only = 0, const GenAuxPack* aux = nullptr,
-                        void* p0_b16 = nullptr /* g.f16: p0 is fp16 and this (may be null) receives its bf16 copy */);
+                        void* p0_b16 = nullptr /* g.f16: p0 is fp16 and this (may be null) receives its bf16 copy */,
+                        int mom_ready = 0 /* the batch's patch moments are already in mompart (sed_crnn_moments) */);
 int launch_blk0_backward(const Geo& g, const float* x, const float* w0, const float* b0, const float* gamma,
                          const float* beta, const float* wglu, const uint16_t* mask_in, const double* mom,
                          const float* wz, const float* wl, const float* bn, const float* dp0, double* de, int zero_de,

@@ -112,35 +112,46 @@ __global__ __launch_bounds__(P2P_THREADS) void k_p2p_allreduce(float* __restrict
                                                                 size_t n_cap) {
     const int W = WC ? WC : W_;
     const int g = blockIdx.x, G = gridDim.x, tid = threadIdx.x;
+    // (lane predicates on the thread index are RE-formed where they are used: kept live across the phases they cost the any-W
+    // instantiation spilled scalar register pairs)
+    auto tid_now = [&]() { int t = tid; asm volatile("" : "+v"(t)); return t; };
+    auto has_tail = [&]() { int r = (int)(n & 3); asm volatile("" : "+s"(r)); return r != 0; };      // (likewise: n % 4 != 0)
     // (the peer table goes to LDS: sixteen 64-bit kernel arguments indexed by a run-time rank cost 85 spilled scalar registers)
     __shared__ char* s_buf[P2P_MAX_WORLD];
     __shared__ unsigned int s_e, s_bad;
     __shared__ unsigned long long s_budget;
-    if (tid < P2P_MAX_WORLD) s_buf[tid] = peers.buf[tid < W ? tid : 0];
+#pragma unroll
+    for (int i = 0; i < P2P_MAX_WORLD; ++i)      // (compile-time indices: a run-time index loads all sixteen pointers into SGPRs at once)
+        if (tid == i) s_buf[i] = (i < W) ? peers.buf[i] : peers.buf[0];
     __syncthreads();
     char* mine = s_buf[rank];
     P2PHeader* hdr = (P2PHeader*)mine;
     if (tid == 0) { s_e = hdr->epoch[g] + 1u; s_bad = 0u; s_budget = hdr->timeout_ticks; }
     __syncthreads();
     const unsigned int e = s_e;
-    const long long n4 = n / 4;                                                     // whole chunks
-    const long long nck = (n + 3) / 4;                                              // incl. the partial tail chunk (index n4) if n % 4
-    const long long per_wg = (nck + (long long)W * G - 1) / ((long long)W * G);     // chunks of one (slice, workgroup) pair
-    auto chunk_of = [&](int slice, long long k) -> long long { return ((k * G + g) * W + slice); };
+    // (32-bit chunk arithmetic: the host checks n < 2^31; 64-bit divisions by a run-time W were a third of the any-W kernel's code)
+    const int n4 = (int)(n / 4);                                                    // whole chunks
+    const int nck = (int)((n + 3) / 4);                                             // incl. the partial tail chunk (index n4) if n % 4
+    const int per_wg = (nck + W * G - 1) / (W * G);                                 // chunks of one (slice, workgroup) pair
+    auto chunk_of = [&](int slice, int k) -> int { return ((k * G + g) * W + slice); };
     float* my_stage = p2p_stage(mine, n_cap, e);
     float* my_result = p2p_result(mine, n_cap, e);
+    if constexpr (WC == 0) {      // (the any-W form runs out of scalar registers: keep the loop-invariant pointers in vector registers)
+        asm volatile("" : "+v"(my_stage), "+v"(my_result), "+v"(data), "+v"(n_cap), "+v"(hdr));
+    }
     // the partial tail chunk (n % 4 floats) is moved element-wise by whoever owns it, through the buffers on every rank
     // (to_comm: local gradient -> own staging half, system-scope stores; else own result half -> local gradient, system-scope loads)
     auto tail_copy = [&](const float* src, float* dst, bool to_comm) {
-        for (long long i = 4 * n4; i < n; ++i) { if (to_comm) st_sys1(dst + i, src[i]); else dst[i] = ld_sys1(src + i); }
+        for (long long i = 4ll * n4; i < n; ++i) { if (to_comm) st_sys1(dst + i, src[i]); else dst[i] = ld_sys1(src + i); }
     };
     // Bounded wait for flag words [kind][p][g] to reach epoch e on every rank p (thread p polls rank p's word in MY flag page).
     // "Reach", not "equal": a rank that gave up on an epoch and moved on must not make every later wait of a late peer time out
     // as well (the difference is taken modulo 2^32).  A wait that runs out of its budget raises the sticky error word (and the
     // host-visible one) and POISONS this launch's output with NaN, below: a timed-out all-reduce must never look like a result.
     auto wait_all = [&](int kind) {
-        if (tid < W) {
-            const unsigned int* f = &hdr->flags[(kind * P2P_MAX_WORLD + tid) * P2P_MAX_WG + g];
+        const int tw = tid_now();
+        if (tw < W) {
+            const unsigned int* f = &hdr->flags[(kind * P2P_MAX_WORLD + tw) * P2P_MAX_WG + g];
             const unsigned long long t0 = wall_clock64(), budget = s_budget;
             while ((int)(p2p_flag_load(f) - e) < 0) {
                 __builtin_amdgcn_s_sleep(2);
@@ -157,37 +168,38 @@ __global__ __launch_bounds__(P2P_THREADS) void k_p2p_allreduce(float* __restrict
     auto signal_all = [&](int kind) {
         asm volatile("s_waitcnt vmcnt(0) ; p2p_signal_drain" ::: "memory");   // EVERY wave: its payload stores are acknowledged ...
         __syncthreads();                                             // ... before any flag of this workgroup is raised
-        if (tid < W) p2p_flag_store(&((P2PHeader*)s_buf[tid])->flags[(kind * P2P_MAX_WORLD + rank) * P2P_MAX_WG + g], e);
+        const int tw = tid_now();
+        if (tw < W) p2p_flag_store(&((P2PHeader*)s_buf[tw])->flags[(kind * P2P_MAX_WORLD + rank) * P2P_MAX_WG + g], e);
     };
     // this workgroup's chunks of all slices but its own, flattened: j = k * W + slice; eight per lane and trip.
     // (masked-off lanes load from the communication buffer's first chunk - always mapped - and store nothing)
     auto copy_all = [&](const float* src, float* dst, bool to_comm, bool nan_out) {
-        const long long nj = per_wg * W;
-        for (long long j0 = tid; j0 < nj; j0 += 8 * P2P_THREADS) {
+        const int nj = per_wg * W;
+        for (int j0 = tid_now(); j0 < nj; j0 += 8 * P2P_THREADS) {
             f32x4 v[8];
-            long long c[8];
+            int c[8];
             const float* a[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const long long j = j0 + (long long)i * P2P_THREADS;
-                const int slice = (int)(j % W);
+                const int j = j0 + i * P2P_THREADS;
+                const int slice = j % W;
                 c[i] = chunk_of(slice, j / W);
                 const bool ok = j < nj && c[i] < n4 && slice != rank;
                 if (!ok) c[i] = -1;
-                a[i] = ok ? src + 4 * c[i] : my_stage;
+                a[i] = ok ? src + 4 * (size_t)c[i] : my_stage;
             }
             if (to_comm) P2P_LD8_PLAIN(v, a); else P2P_LD8_SYS(v, a);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 if (c[i] >= 0) {
                     if (nan_out) v[i] = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
-                    float* dp = dst + 4 * c[i];
+                    float* dp = dst + 4 * (size_t)c[i];
                     if (to_comm) P2P_ST_SYS(dp, v[i]); else P2P_ST_PLAIN(dp, v[i]);
                 }
         }
-        if (n4 != nck && tid == 0 && (int)((n4 / W) % G) == g) {
+        if (has_tail() && tid_now() == 0 && (int)((n4 / W) % G) == g) {
             tail_copy(src, dst, to_comm);
-            if (nan_out) for (long long i = 4 * n4; i < n; ++i) dst[i] = __builtin_nanf("");
+            if (nan_out) for (long long i = 4ll * n4; i < n; ++i) dst[i] = __builtin_nanf("");
         }
     };
     // ---- 1. publish my share of every other rank's slice --------------------------------------------------------------------
@@ -201,15 +213,15 @@ __global__ __launch_bounds__(P2P_THREADS) void k_p2p_allreduce(float* __restrict
     {
         constexpr int WL = WC ? WC : 8;                               // ranks per load batch
         constexpr int KB = 8 / WL;
-        for (long long k0 = tid; k0 < per_wg; k0 += (long long)KB * P2P_THREADS) {
-            long long c[KB];
+        for (int k0 = tid_now(); k0 < per_wg; k0 += KB * P2P_THREADS) {
+            int c[KB];
             f32x4 acc[KB], own[KB];
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) {                         // my own operand comes from the gradient bucket itself
-                const long long k = k0 + (long long)kk * P2P_THREADS;
+                const int k = k0 + kk * P2P_THREADS;
                 c[kk] = chunk_of(rank, k);
                 if (!(k < per_wg && c[kk] < n4)) c[kk] = -1;
-                own[kk] = c[kk] >= 0 ? *(const f32x4*)(data + 4 * c[kk]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                own[kk] = c[kk] >= 0 ? *(const f32x4*)(data + 4 * (size_t)c[kk]) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
             for (int p0 = 0; p0 < W; p0 += WL) {                      // (one trip when WC != 0)
                 f32x4 v[8];
@@ -219,8 +231,9 @@ __global__ __launch_bounds__(P2P_THREADS) void k_p2p_allreduce(float* __restrict
 #pragma unroll
                     for (int pp = 0; pp < WL; ++pp) {
                         const int p = p0 + pp;                        // (slots of my own rank, of ranks >= W and of masked-off
+                        char* sb = s_buf[p < W ? p : 0];
                         a[kk * WL + pp] = (p < W && p != rank && c[kk] >= 0)      //  chunks read one always-mapped line)
-                                              ? p2p_stage(s_buf[p], n_cap, e) + 4 * c[kk] : my_stage;
+                                              ? p2p_stage(sb, n_cap, e) + 4 * (size_t)c[kk] : my_stage;
                     }
                 P2P_LD8_SYS(v, a);
 #pragma unroll
@@ -239,14 +252,14 @@ __global__ __launch_bounds__(P2P_THREADS) void k_p2p_allreduce(float* __restrict
                 if (c[kk] < 0) continue;
                 if (bad0) acc[kk] = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
                 for (int p = 0; p < W; ++p) {
-                    if (p == rank) { float* dp = data + 4 * c[kk]; P2P_ST_PLAIN(dp, acc[kk]); }
-                    else { float* dp = p2p_result(s_buf[p], n_cap, e) + 4 * c[kk]; P2P_ST_SYS(dp, acc[kk]); }
+                    if (p == rank) { float* dp = data + 4 * (size_t)c[kk]; P2P_ST_PLAIN(dp, acc[kk]); }
+                    else { float* dp = p2p_result(s_buf[p], n_cap, e) + 4 * (size_t)c[kk]; P2P_ST_SYS(dp, acc[kk]); }
                 }
             }
         }
     }
-    if (n4 != nck && tid == 0 && (int)(n4 % W) == rank && (int)((n4 / W) % G) == g) {      // the partial tail chunk of my slice
-        for (long long i = 4 * n4; i < n; ++i) {
+    if (has_tail() && tid_now() == 0 && (int)(n4 % W) == rank && (int)((n4 / W) % G) == g) {      // the partial tail chunk of my slice
+        for (long long i = 4ll * n4; i < n; ++i) {
             float acc = 0.f;
             for (int p = 0; p < W; ++p) acc += ld_sys1(p2p_stage(s_buf[p], n_cap, e) + i);
             if (bad0) acc = __builtin_nanf("");
@@ -259,12 +272,14 @@ __global__ __launch_bounds__(P2P_THREADS) void k_p2p_allreduce(float* __restrict
     const bool bad1 = s_bad != 0u;
     copy_all(my_result, data, false, bad1);
     if (bad1) {                                                       // ... and my own slice, already in place, is void as well
-        for (long long k = tid; k < per_wg; k += P2P_THREADS) {
-            const long long c = chunk_of(rank, k);
-            if (c < n4) *(f32x4*)(data + 4 * c) = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+        int Gs = G, Ws = W;
+        asm volatile("" : "+s"(Gs), "+s"(Ws));      // (re-formed products: W * G kept live to here was the any-W kernel's last spilled SGPR)
+        for (int k = tid; k < per_wg; k += P2P_THREADS) {
+            const int c = (k * Gs + g) * Ws + rank;
+            if (c < n4) *(f32x4*)(data + 4 * (size_t)c) = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
         }
     }
-    if (tid == 0) hdr->epoch[g] = e;
+    if (tid_now() == 0) hdr->epoch[g] = e;
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
@@ -368,6 +383,7 @@ extern "C" int sed_p2p_allreduce(float* data, long long n, int rank, int world, 
                                  int workgroups, void* stream) {
     SED_CHECK_ARG(data && bufs && n >= 0 && world >= 1 && world <= P2P_MAX_WORLD && rank >= 0 && rank < world, "sed_p2p_allreduce: bad argument");
     SED_CHECK_ARG(n <= n_floats_max, "sed_p2p_allreduce: message larger than the communication buffers");
+    SED_CHECK_ARG(n < (1ll << 31), "sed_p2p_allreduce: at most 2^31 - 1 floats per call");
     SED_CHECK_ARG(((uintptr_t)data & 15) == 0, "sed_p2p_allreduce: data must be 16-byte aligned");
     if (n == 0) return SED_OK;
     // default: one workgroup per 2 K floats of the buffers' capacity, at least 32, at most P2P_MAX_WG - the same on every rank and call.  One-rank

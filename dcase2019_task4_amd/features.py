@@ -366,6 +366,16 @@ class WaveformFrontEnd:
 
     def __init__(self, step, waves, cfg=None, scaler=None, overlap=True, seed=0, fe_workgroups=None, fft_dtype="f64"):
         self.step = step
+        # This front-end writes the step's input slots itself, one batch ahead - so it also computes block 0's patch moments of
+        # that batch (sed_crnn_moments) right behind the extraction, on the extraction's own stream: the step's forwards then
+        # start at k_blk0_prep (26 + 16 us -> 16 us at the head of the B = 64 step), and the graph gets no new branch.
+        # Measured (bench.py, 800 replays, B = 64): waveform-bf16 0.8445 -> 0.8233 ms, waveform-f16 0.8698 -> 0.8442; the fp32 step
+        # (1.468 -> 1.491: its conv backward fills every CU, the two extra launches land in front of k_wgrad_wino) keeps the
+        # moments at the head of the forward.  SED_FE_MOMENTS=0 / 1 overrides.
+        step.moments_ahead = False
+        env = os.environ.get("SED_FE_MOMENTS")
+        self.moments = (env == "1") if env in ("0", "1") else (step.student._dtype != _lib.DTYPE_F32)
+        step._mom_external = self.moments
         self.l = _lib.lib()
         self.fx = FeatureExtractor(cfg or FeatureConfig.baseline_16k(), device=step.device, fft_dtype=fft_dtype)
         c = self.fx.cfg
@@ -435,6 +445,10 @@ class WaveformFrontEnd:
         _lib.check(self.l.sed_seed_advance(_lib.ptr(self.key), _lib.stream_ptr()), "sed_seed_advance")
         if target is not None:
             target.copy_(self._staged_target, non_blocking=True)
+        if self.moments:
+            st._moments(x, st.ctx_s)
+            if x_ema is not None:
+                st._moments(x_ema, st.ctx_t)
 
     def _point_step_at(self, i):
         st = self.step
@@ -466,6 +480,7 @@ class WaveformFrontEnd:
                 g = torch.cuda.CUDAGraph()
                 if os.environ.get("SED_GRAPH_DUMP"):   # debugging aid: hipGraphDebugDotPrint of the captured step
                     g.enable_debug_mode()
+                st._mom_ready = self.moments
                 with torch.cuda.graph(g, **cap):
                     cur = torch.cuda.current_stream()
                     nxt = self._slots[1 - i]
@@ -492,6 +507,7 @@ class WaveformFrontEnd:
             ok, graphs = 0.0, None
             st._capture_error = repr(e)
         finally:
+            st._mom_ready = False
             self._point_step_at(0)
         if st.dp:
             import torch.distributed as dist
@@ -516,9 +532,11 @@ class WaveformFrontEnd:
             return
         if self._runs < 2:                             # two eager steps first (as MeanTeacherStep.run does before capturing)
             self._point_step_at(self._cur)
+            st._mom_ready = self.moments
             try:
                 st._step_body()
             finally:
+                st._mom_ready = False
                 self._point_step_at(0)
             self.features(*self._slots[1 - self._cur])
         else:
@@ -549,9 +567,11 @@ class WaveformFrontEnd:
             return
         st = self.step
         self._point_step_at(self._cur if self.overlap else 0)
+        st._mom_ready = self.moments
         try:
             st._step_body() if self.overlap else st.run()
         finally:
+            st._mom_ready = False
             self._point_step_at(0)
         if self.overlap:
             st._warm += 1

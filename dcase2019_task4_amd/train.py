@@ -236,7 +236,26 @@ class MeanTeacherStep:
                 _lib.check(self.l.sed_stream_prepare(C.c_void_p(st.cuda_stream)), "sed_stream_prepare")
         self._warm = 0
         self.steps_done = 0
-        self.global_step_host = 0          # host mirror of state.global_step (no device read in train())
+        self._gs_offset = 0                # global_step_host = steps_done + _gs_offset: host mirror of state.global_step
+        # Patch moments one step ahead (sed_crnn_moments, csrc/blk0.hip): block 0's train-mode BatchNorm statistics come from the
+        # 9 + 45 moments of the 3x3 input patch, a function of the BATCH only.  When the batch in self.x / self.x_ema is still the
+        # one the previous run() trained on (a resident batch: bench.py; anything that calls run() without load_batch() in
+        # between), the previous step has already computed them - on a third stream beside its heads / BiGRU backward, which
+        # leave most of the chip idle - and this step's forwards start at k_blk0_prep: 16 us (B = 24) off the head of the
+        # critical chain, every step still computing one pair of moments.  step() / load_batch() + run() never speculates:
+        # self.x may ONLY change through load_batch() (or be followed by invalidate_batch()).
+        self.moments_ahead = os.environ.get("SED_MOMENTS_AHEAD", "0") == "1"
+        self._mom_external = False         # features.WaveformFrontEnd: every batch arrives with its moments already in ctx
+        self._mom_valid = False            # ctx_s / ctx_t hold the moments of what is in self.x / self.x_ema right now
+        self._resident = False            # a run() has consumed the batch in self.x and no load_batch() came since
+        self._mom_ready = self._mom_next = False      # the variant being run / captured
+        self._mom_stream = self._stream("moments", int(os.environ.get("SED_MOM_PRIO", "0")))
+        self._mom_fork = os.environ.get("SED_MOM_FORK", "backward")
+        self._graph_sets = {}              # (mom_ready, mom_next) -> (graph_a, graph_w, graph_c, graph_b)
+
+    @property
+    def global_step_host(self):
+        return self.steps_done + self._gs_offset
 
     def _stream(self, role, priority=0):
         if self._pool_streams:
@@ -251,6 +270,7 @@ class MeanTeacherStep:
         step of the process and stay prepared.  The step must not be used afterwards."""
         torch.cuda.synchronize(self.device)
         self._graph_a = self._graph_w = self._graph_c = self._graph_b = None
+        self._graph_sets = {}
         if self._p2p is not None:
             self._p2p.close()
             self._p2p = None
@@ -263,6 +283,8 @@ class MeanTeacherStep:
         """strong = weak = None: output heads deferred to sed_mt_step_backward (the student's forward).  The teacher's forward is
         train-mode but never differentiated (main.py:87-89): train = 3 tells the library so."""
         train = 3 if (model is self.teacher and model is not None) else 1
+        if self._mom_ready:
+            train |= 4               # this batch's patch moments are already in ctx (the previous step's _moments_ahead)
         _lib.check(self.l.sed_crnn_forward(C.byref(self.dims), _lib.ptr(model._flat), _lib.ptr(model._bn_flat),
                                            _lib.ptr(model._bn_tracked), _lib.ptr(x), train, 1, seed, _lib.ptr(ctx),
                                            self.ctx_bytes, _lib.ptr(strong), _lib.ptr(weak), _lib.stream_ptr()),
@@ -270,6 +292,8 @@ class MeanTeacherStep:
 
     def _fwd_bwd(self, after_forward=None, at_recurrence=None):
         self._fork_exc = None
+        if self._mom_next and self._mom_fork == "gru" and at_recurrence is None:
+            at_recurrence = self._moments_ahead
         try:
             self._fwd_bwd_impl(after_forward, at_recurrence)
         finally:
@@ -322,6 +346,8 @@ class MeanTeacherStep:
             self._student_forward(at_recurrence)
         if after_forward is not None:
             after_forward()
+        if self._mom_next and self._mom_fork != "gru":
+            self._moments_ahead()
         # losses (main.py:93-145) + backward in one call: the heads-backward kernel forms the loss gradient per clip itself
         # (sed_mt_loss as a kernel of its own was 12 us on the critical path).  One process: the whole backward
         # (parts = 3), which lets the library overlap the GRU weight gradients with the conv-block backward;
@@ -349,6 +375,28 @@ class MeanTeacherStep:
                                                    _lib.ptr(self.losses), None, None, _lib.ptr(self.grads),
                                                    _lib.ptr(self.ws), self.ws_bytes, parts, _lib.stream_ptr()),
                        "sed_mt_loss_backward")
+
+        if self._mom_next:
+            torch.cuda.current_stream().wait_stream(self._mom_stream)
+
+    def _moments_ahead(self, x=None, x_ema=None):
+        """The patch moments of the batch the NEXT step trains on (default: the resident one in self.x / self.x_ema) into the
+        models' ctx, on a stream of their own beside this step's backward."""
+        cur = torch.cuda.current_stream()
+        self._mom_stream.wait_stream(cur)
+        with torch.cuda.stream(self._mom_stream):
+            self._moments(self.x if x is None else x, self.ctx_s)
+            if self.teacher is not None:
+                self._moments(self.x_ema if x_ema is None else x_ema, self.ctx_t)
+
+    def _moments(self, x, ctx):
+        _lib.check(self.l.sed_crnn_moments(C.byref(self.dims), _lib.ptr(x), _lib.ptr(ctx), self.ctx_bytes, _lib.stream_ptr()),
+                   "sed_crnn_moments")
+
+    def invalidate_batch(self):
+        """Tell the step that self.x / self.x_ema / self.target were written behind its back (anything but load_batch())."""
+        self._mom_valid = False
+        self._resident = False
 
     def _backward(self, parts):
         _lib.check(self.l.sed_crnn_backward(C.byref(self.dims), _lib.ptr(self.student._flat), _lib.ptr(self.x),
@@ -409,7 +457,7 @@ class MeanTeacherStep:
         sdist.broadcast_parameters(ts, self.pg, src=src)
         _lib.check(self.l.sed_step_state_update(_lib.ptr(self.state), self._folded_seed(), 0.0, 1, _lib.stream_ptr()),
                    "sed_step_state_update")
-        self.global_step_host = int(self.read_state().global_step)
+        self._gs_offset = int(self.read_state().global_step) - self.steps_done
 
     def set_global_step(self, global_step):
         """main.py:74 - ``global_step = epoch * len(train_loader) + i``: the reference recomputes the counter from the epoch
@@ -417,7 +465,7 @@ class MeanTeacherStep:
         derive from (Adam's own step count is the optimiser's and stays)."""
         _lib.check(self.l.sed_step_state_set_global_step(_lib.ptr(self.state), int(global_step), _lib.stream_ptr()),
                    "sed_step_state_set_global_step")
-        self.global_step_host = int(global_step)
+        self._gs_offset = int(global_step) - self.steps_done
 
     def set_lr(self, lr):
         """Honour an optimiser whose lr changed between epochs (main.py never does; utils.adjust_learning_rate exists)."""
@@ -504,6 +552,7 @@ class MeanTeacherStep:
 
     # ---- public ------------------------------------------------------------------------------------
     def load_batch(self, x, x_ema, target):
+        self.invalidate_batch()
         self.x.copy_(x.reshape(self.x.shape), non_blocking=True)
         if x_ema is not None:
             self.x_ema.copy_(x_ema.reshape(self.x.shape), non_blocking=True)
@@ -517,9 +566,21 @@ class MeanTeacherStep:
             raise _lib.SedError(f"peer all-reduce: {self._p2p.poll()} cross-rank waits ran out of their budget (a rank did not "
                                 "launch the same sequence of collectives, died, or fell further behind than SED_P2P_TIMEOUT_S); "
                                 "the gradients of that step were filled with NaN")
+        # which form of the step: forwards that find their patch moments in ctx (valid: the previous run left them there) and / or
+        # a tail that computes them for the next run (the batch is resident: nothing was loaded since the previous run)
+        key = (self._mom_valid, self._resident) if self.moments_ahead else (self._mom_external, False)
+        self._mom_ready, self._mom_next = key
         graph = self.use_graph and self._warm >= 2
-        if graph and self._graph_a is None:
-            self._capture()
+        if graph:
+            gs = self._graph_sets.get(key)
+            if gs is None:
+                mode = (self.dp_capture, self.dp_schedule)
+                self._graph_a = self._graph_w = self._graph_c = self._graph_b = None
+                self._capture()
+                if (self.dp_capture, self.dp_schedule) != mode:       # a capture fell back to another schedule: for every form
+                    self._graph_sets = {}
+                gs = self._graph_sets[key] = (self._graph_a, self._graph_w, self._graph_c, self._graph_b)
+            self._graph_a, self._graph_w, self._graph_c, self._graph_b = gs
         if not self.dp:
             if graph:
                 self._graph_a.replay()
@@ -532,7 +593,9 @@ class MeanTeacherStep:
             self._dp_step_eager_collectives(graph)
         self._warm += 1
         self.steps_done += 1
-        self.global_step_host += 1
+        self._mom_valid = self._mom_next       # (the tail computed them for the batch that is in self.x now)
+        self._resident = True
+        self._mom_ready = self._mom_next = False
 
     def step(self, x, x_ema, target):
         """``x_ema`` is ignored (may be None) in supervised mode."""
@@ -682,7 +745,7 @@ class MeanTeacherStep:
         self.state.copy_(torch.from_numpy(raw))
         self.seed_user = int(sd.get("seed_user", self.seed_user))
         self.steps_done = int(sd.get("steps_done", 0))
-        self.global_step_host = int(_lib.SedStepState.from_buffer_copy(bytes(sd["step_state"])).global_step)
+        self._gs_offset = int(_lib.SedStepState.from_buffer_copy(bytes(sd["step_state"])).global_step) - self.steps_done
         if self.rank != 0:       # the file holds rank 0's stream; every other rank re-folds its own rank into the seed
             _lib.check(self.l.sed_step_state_update(_lib.ptr(self.state), self._folded_seed(), 0.0, 1, _lib.stream_ptr()),
                        "sed_step_state_update")

@@ -140,7 +140,8 @@ int sed_param_layout(const sed_dims* d, int64_t* offsets);
  *               when update_bn != 0: BatchNorm2d momentum rule, CNN.py:49)
  *   bn_tracked  [3] int64 num_batches_tracked (incremented with bn_running), may be NULL
  *   x           [B][1][T][F] fp32
- *   train       1 = module.train() semantics (batch statistics, dropout), 0 = eval; 3 = train semantics for a forward whose
+ *   train       1 = module.train() semantics (batch statistics, dropout), 0 = eval; | 4 = this batch's patch moments are
+ *               already in ctx (sed_crnn_moments, below); 3 = train semantics for a forward whose
  *               backward will never run (the teacher's, main.py:87-89): bit 1 lets the library skip what only a backward reads
  *               (today: the bf16 activation copies of SED_DTYPE_F16); results are identical to train = 1
  *   seed_dev    device pointer to the 64-bit Philox key of this forward (ignored if p_drop==0
@@ -152,6 +153,13 @@ size_t sed_crnn_ctx_bytes(const sed_dims* d);
 int sed_crnn_forward(const sed_dims* d, const float* params, float* bn_running, int64_t* bn_tracked,
                      const float* x, int train, int update_bn, const uint64_t* seed_dev,
                      void* ctx, size_t ctx_bytes, float* strong, float* weak, void* stream);
+
+/* The patch moments of conv block 0's train-mode BatchNorm (csrc/blk0.hip: the statistics of BatchNorm2d(Conv2d(1, C, 3)(x)),
+ * baseline/models/CNN.py:46-55, follow from the 9 + 45 first / second moments of the 3x3 input patch) depend on the batch only.
+ * sed_crnn_forward computes them at its head (train = 1 / 3); a caller that already holds the NEXT batch while a step runs -
+ * one batch ahead like the reference's DataLoader workers (DataLoad.py:47-186) - calls this beside that step and then passes
+ * train | 4 to the forward that consumes them (same ctx): the launch leaves the head of the critical chain.  Bit-identical. */
+int sed_crnn_moments(const sed_dims* d, const float* x, void* ctx, size_t ctx_bytes, void* stream);
 
 /* Backward of the above in train mode (autograd of main.py:153 loss.backward()).
  *   d_strong/d_weak  gradients w.r.t. the two outputs

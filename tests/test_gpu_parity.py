@@ -458,6 +458,51 @@ def test_supervised_fused_steps_vs_real_main_simple_crnn_goldens(golden_dir, use
         np.testing.assert_allclose(v.cpu().numpy(), g["b_" + k.replace(".", "_")], rtol=3e-5, atol=atol, err_msg=k)
 
 
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("kw", [dict(), dict(C=128, H=256, mfma_dtype="bf16"), dict(mfma_dtype="f16")])
+def test_patch_moments_one_step_ahead_are_bit_identical(graph, kw):
+    """Round 6: with a RESIDENT batch (run() without load_batch() in between) the step computes block 0's patch moments for
+    the next step beside its own backward (sed_crnn_moments) and the next forwards start at k_blk0_prep (train | 4, packing
+    in the prep launch).  Same kernel, same partials, same order: parameters, BatchNorm buffers, Adam moments and meters must
+    be bit-identical to the plain form over 6 steps - through all three forms of the step ((plain), (moments at the head +
+    for the next step), (moments from the previous step)), eager and replayed; and a load_batch() in between falls back."""
+    from dcase2019_task4_amd.train import MeanTeacherStep
+    B, T = 8, 216
+    tgt, wm, sm = synth.make_target(1, B, T // 8)
+    xa, xea = synth.make_input(60, B, T).cuda(), synth.make_input(70, B, T).cuda()
+    xb, xeb = synth.make_input(61, B, T).cuda(), synth.make_input(71, B, T).cuda()
+    res = {}
+    for ahead in (False, True):
+        s, _ = gu.make_model(0, dropout=0.5, **kw)
+        t, _ = gu.make_model(1, dropout=0.5, **kw)
+        s.train(); t.train()
+        st = MeanTeacherStep(s, t, B, T, 40, wm, sm, seed=99, use_graph=graph)
+        st.moments_ahead = ahead
+        st.load_batch(xa, xea, tgt.cuda())
+        forms = []
+        for i in range(6):
+            if i == 4:
+                st.load_batch(xb, xeb, tgt.cuda())         # a new batch: the step must not use moments of the old one
+            st.run()
+            forms.append((st._mom_valid, st._resident))
+        torch.cuda.synchronize()
+        if ahead:      # after each run: (moments for the next run exist, batch resident)
+            assert forms == [(False, True), (True, True), (True, True), (True, True), (False, True), (True, True)], forms
+            assert not graph or set(st._graph_sets) >= {(True, True)}
+        else:
+            assert all(f == (False, True) for f in forms)
+        res[ahead] = [s._flat.clone(), t._flat.clone(), s._bn_flat.clone(), t._bn_flat.clone(), st.exp_avg.clone(),
+                      st.exp_avg_sq.clone(), st.losses[:8].clone(), st.strong.clone()]
+        st.close()
+    if kw.get("mfma_dtype") in ("bf16", "f16"):
+        # (the bf16 family's BatchNorm sums are fp64 atomics: two runs of the SAME form agree to bf16 noise, not to the bit)
+        for a, b in zip(res[False][:2], res[True][:2]):
+            assert float((a - b).abs().max()) < 5e-3
+    else:
+        for k, (a, b) in enumerate(zip(res[False], res[True])):
+            assert torch.equal(a, b), (k, float((a - b).abs().max()))
+
+
 def test_train_honours_the_epoch_argument_like_main_py_74():
     """main.py:74 recomputes ``global_step = epoch * len(train_loader) + i`` from the epoch argument at every call of train: the
     consistency weight a call logs must be the oracle's for THAT global step - over an epoch 0, 1 call sequence on one step

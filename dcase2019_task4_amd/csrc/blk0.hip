@@ -338,19 +338,24 @@ template <> struct Blk0A<2> { blk0_bf16x8 v, lo; };    // the same taps, hi and 
 template <> struct Blk0A<3> { blk0_bf16x8 v; };        // the same taps as fp16 bit patterns
 template <int MODE>
 __device__ __forceinline__ void blk0_load_a(Blk0A<MODE>& A, const float* xb, int base, int kh) {
+    // Every LDS read below is UNCONDITIONAL (clamped address) and the constant / zero taps are selected afterwards: written as
+    // `cond ? constant : xb[...]` each read became a divergent branch with its own s_waitcnt lgkmcnt(0) - one (fp32) or seven
+    // (bf16 family) serialized LDS round trips per 32-pixel row block in every block-0 kernel (round 6).
     if constexpr (MODE == 0) {
 #pragma unroll
-        for (int s5 = 0; s5 < 5; ++s5) {
+        for (int s5 = 0; s5 < 5; ++s5) {      // (only k = 9 - s5 = 4 of the kh = 1 lanes - is the constant: one conditional read)
             const int k = 2 * s5 + kh;
             A.v[s5] = (k == 9) ? 1.0f : xb[base + (k / 3) * XS_W + (k % 3)];
         }
     } else {
-        // kh = 0: taps 0 .. 7; kh = 1: tap 8, the constant, six zeros (those lanes read tap 8 once and clamp the rest)
+        // kh = 0: taps 0 .. 7; kh = 1: tap 8, the constant, six zeros
         float t[8];
         t[0] = xb[base + (kh ? 2 * XS_W + 2 : 0)];
-        t[1] = kh ? 1.0f : xb[base + 1];
 #pragma unroll
-        for (int i = 2; i < 8; ++i) t[i] = kh ? 0.f : xb[base + (i / 3) * XS_W + (i % 3)];
+        for (int i = 1; i < 8; ++i) t[i] = xb[base + (i / 3) * XS_W + (i % 3)];
+        t[1] = kh ? 1.0f : t[1];
+#pragma unroll
+        for (int i = 2; i < 8; ++i) t[i] = kh ? 0.f : t[i];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             A.v[i] = MODE == 3 ? blk0_h16(t[i]) : (__bf16)t[i];
@@ -692,9 +697,15 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
                     const int tc = n < 9 ? n : 0;
                     const float* src = xs + (2 * wv + kh + tc / 3) * XS_W + 16 * g + tc % 3;
                     const float other = n == 9 ? 1.0f : 0.f;
+                    // (all sixteen reads unconditional - the address is clamped - and selected afterwards: written as
+                    // `n < 9 ? src[r] : other` every read became a branch with its own s_waitcnt, sixteen serialized LDS round
+                    // trips per row block)
+                    float pv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pv[r] = src[r];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float v = n < 9 ? src[r] : other;
+                        const float v = n < 9 ? pv[r] : other;
                         const __bf16 hi = (__bf16)v;
                         pT[0][r >> 3][r & 7] = hi;
                         if constexpr (MODE != 1) pT[1][r >> 3][r & 7] = (__bf16)(v - (float)hi);

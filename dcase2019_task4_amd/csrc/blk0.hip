@@ -387,6 +387,14 @@ __device__ __forceinline__ void blk0_mma(const Blk0A<MODE>& A, const Blk0W<NH, M
         }
     }
 }
+// the lin half only (k_blk0_bwd<..., SG = 1>: the gate comes from the forward's saved bytes); bf16 family
+template <int NH, int MODE>
+__device__ __forceinline__ void blk0_mma_lin(const Blk0A<MODE>& A, const Blk0W<NH, MODE>& W, int h, f32x16& al) {
+    static_assert(MODE == 1, "saved gates: SED_DTYPE_BF16 / F16 backward only");
+#pragma unroll
+    for (int r = 0; r < 16; ++r) al[r] = 0.f;
+    al = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, W.bw[h], al, 0, 0, 0);
+}
 __device__ __forceinline__ void blk0_load_xs(float* xs, const float* __restrict__ x, int b, int T, int t0, int tid) {
     // XS_H rows of 64 contiguous floats: one float4 per thread (160 of the 256), zero rows outside the clip
     if (tid < XS_H * 16) {
@@ -414,12 +422,19 @@ __device__ __forceinline__ float blk0_half_sum(float x) {      // x + (the other
     const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return __uint_as_float(a[0]) + __uint_as_float(a[1]);
 }
-template <int NH, int DROP, bool SAVE, int MODE>
+// SG (bf16 family, round 6): the forward that WILL be differentiated also stores the GLU gate sigmoid(z) of every element as one
+// byte (round(255 s)), 16 bytes per lane and (row block, channel slice) beside the 16 keep bits - k_blk0_bwd<..., SG = 1> then
+// reads the gate instead of recomputing z on the MFMA and taking exp2 + rcp per element (8 of its 15 VALU issue slots per element;
+// it is the tail of every bf16-family step).  1 byte per element of B x T x 64 x C: written and read once, by VALU-bound kernels
+// whose memory pipes idle.  |error| <= 1 / 510 per gate, unbiased, entering only the block's parameter-gradient SUMS over
+// ~10^6 pixels (block 0 has no data gradient).
+template <int NH, int DROP, bool SAVE, int MODE, int SG = 0>
 __global__ __launch_bounds__(256, (NH == 2 ? 3 : 2)) void k_blk0_fwd(const float* __restrict__ x, const float* __restrict__ wz,
                                                    const float* __restrict__ wl, float* __restrict__ p0, int B, int T,
                                                    int H1, int tiles_per_clip, int n_tiles, float p_drop,
                                                    const uint64_t* __restrict__ seed_ptr, uint16_t* __restrict__ mask_out,
-                                                   void* __restrict__ p0_b16 /* MODE 3: bf16 copy of the output, may be null */) {
+                                                   void* __restrict__ p0_b16 /* MODE 3: bf16 copy of the output, may be null */,
+                                                   uint4* __restrict__ sg_out = nullptr /* SG: [unit][lane] 16 gate bytes */) {
     __shared__ float xs[2][FXS_H * XS_W];
     constexpr int C = 32 * NH;
     constexpr int NT = 2 * NH;                       // MFMA tiles of a wave: (row block g0 + {0, 1}, channel slice h)
@@ -502,16 +517,26 @@ __global__ __launch_bounds__(256, (NH == 2 ? 3 : 2)) void k_blk0_fwd(const float
                         m16 = philox_keep16(o, thr);
                     }
                     if (SAVE) mask_out[((size_t)(q0 >> 2) * NH + h) * 64 + lane] = (uint16_t)m16;
+                    uint32_t sgw[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         // keep bit r as an all-ones / all-zeros word (v_bfe_i32) ANDed onto lin: two plain VALU instructions
                         const int keep = __builtin_amdgcn_sbfe((int)m16, r, 1);
                         const float lm = __int_as_float(__float_as_int(l16[r]) & keep);
-                        pooled[r >> 2] = fmaf(lm, sigmoid_from_scaled(z16[r]), pooled[r >> 2]);
+                        const float sgv = sigmoid_from_scaled(z16[r]);
+                        pooled[r >> 2] = fmaf(lm, sgv, pooled[r >> 2]);
+                        if constexpr (SG != 0) sgw[r >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(sgv * 255.0f, r & 3, sgw[r >> 2]);
                     }
+                    if constexpr (SG != 0) sg_out[((size_t)(q0 >> 2) * NH + h) * 64 + lane] = uint4{sgw[0], sgw[1], sgw[2], sgw[3]};
                 } else {
+                    uint32_t sgw[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) pooled[r >> 2] = fmaf(l16[r], sigmoid_from_scaled(z16[r]), pooled[r >> 2]);
+                    for (int r = 0; r < 16; ++r) {
+                        const float sgv = sigmoid_from_scaled(z16[r]);
+                        pooled[r >> 2] = fmaf(l16[r], sgv, pooled[r >> 2]);
+                        if constexpr (SG != 0) sgw[r >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(sgv * 255.0f, r & 3, sgw[r >> 2]);
+                    }
+                    if constexpr (SG != 0) sg_out[((size_t)(q0 >> 2) * NH + h) * 64 + lane] = uint4{sgw[0], sgw[1], sgw[2], sgw[3]};
                 }
 #endif
                 // the two half-waves hold dt = 0 / 1 of the same pooled pixels
@@ -575,12 +600,13 @@ __global__ __launch_bounds__(256, (NH == 2 ? 3 : 2)) void k_blk0_fwd(const float
 // latency of its in-order stream exposed - 197 us against 2 x 53 for the halves at two waves per SIMD)
 // STRICT (fp32 only, debug bit 27 / SED_STRICT_F32=1): the 2 x 10 sums per channel as plain fp32 FMAs on the VALU instead of
 // split-bf16 MFMA products - the all-fp32 twin of the `dtype: f32` headline (bench.py extra_configs["mt-f32-strict"]).
-template <int NH, int MODE, int NHT, int STRICT = 0>
+template <int NH, int MODE, int NHT, int STRICT = 0, int SG = 0>
 __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float* __restrict__ x, const float* __restrict__ wz,
                                                    const float* __restrict__ wl, const float* __restrict__ dp0, int B,
                                                    int T, int H1, int tiles_per_clip, int n_tiles, int use_drop,
                                                    float p_drop, const uint16_t* __restrict__ mask_in,
-                                                   double* __restrict__ de /* [2][C][10] */, int no_atomic) {
+                                                   double* __restrict__ de /* [2][C][10] */, int no_atomic,
+                                                   const uint4* __restrict__ sg_in = nullptr /* SG: the forward's gate bytes */) {
     __shared__ float xs[XS_H * XS_W];
     __shared__ __attribute__((aligned(16))) float P[4][32 * 12];
     __shared__ float red[4][2][NH][32][10];
@@ -650,6 +676,7 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
         // HBM/L2 round trip (~1 us per row block in the first version)
         float gq_n[NH][4];
         uint32_t m_n[NH];
+        uint4 sg_n[SG ? NH : 1];
         auto fetch = [&](int g) {
             const int q0 = (b * H1 + to) * 16 + 4 * g;
 #pragma unroll
@@ -658,17 +685,21 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
 #pragma unroll
                 for (int jx = 0; jx < 4; ++jx) gq_n[h][jx] = ld1((const typename Stor<MODE == 1>::T*)dp0 + (size_t)(q0 + jx) * C + c);
                 m_n[h] = use_drop ? (uint32_t)mask_in[((size_t)(q0 >> 2) * NHT + h0 + h) * 64 + lane] : 0xffffu;
+                if constexpr (SG != 0) sg_n[h] = sg_in[((size_t)(q0 >> 2) * NHT + h0 + h) * 64 + lane];
             }
         };
         fetch(0);
         for (int g = 0; g < 4; ++g) {
             float gq_c[NH][4];
             uint32_t m_c[NH];
+            uint4 sg_c[SG ? NH : 1];
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
                 m_c[h] = m_n[h];
+                if constexpr (SG != 0) sg_c[h] = sg_n[h];
+                // (SG: the gate arrives as a byte u = round(255 s): the 1 / 255 rides in the pooled gradient's scale)
 #pragma unroll
-                for (int jx = 0; jx < 4; ++jx) gq_c[h][jx] = gq_n[h][jx] * (0.125f * keep_scale);
+                for (int jx = 0; jx < 4; ++jx) gq_c[h][jx] = gq_n[h][jx] * (0.125f * keep_scale * (SG ? (1.0f / 255.0f) : 1.0f));
             }
             if (g < 3) fetch(g + 1);
             // patch values: MFMA A operand (this lane's pixel m, taps 2s+kh) and the im2col rows for the reductions
@@ -714,14 +745,25 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
 #pragma unroll
                 for (int h = 0; h < NH; ++h) {
                     f32x16 al, az;
-                    blk0_mma<NH, MODE>(av, W, h, al, az);
+                    if constexpr (SG != 0) blk0_mma_lin<NH, MODE>(av, W, h, al);      // (z is not needed: its gate was saved)
+                    else blk0_mma<NH, MODE>(av, W, h, al, az);
                     blk0_bf16x8 fl[NP][2], fz[NP][2];
+                    const uint32_t sgw[4] = {SG ? sg_c[SG ? h : 0].x : 0u, SG ? sg_c[SG ? h : 0].y : 0u, SG ? sg_c[SG ? h : 0].z : 0u,
+                                             SG ? sg_c[SG ? h : 0].w : 0u};
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float gg = ((m_c[h] >> r) & 1u) ? gq_c[h][r >> 2] : 0.f;
-                        const float sg = sigmoid_from_scaled(az[r]);
-                        const float dl = gg * sg;
-                        const float dzg = dl * al[r] * (1.0f - sg);
+                        float dl, dzg;
+                        if constexpr (SG != 0) {
+                            // u = 255 s as a float (v_cvt_f32_ubyte<r & 3>); gg carries the 1 / 255: dl = gg' u, 1 - s = 1 - u / 255
+                            const float u = (float)((sgw[r >> 2] >> (8 * (r & 3))) & 0xffu);
+                            dl = gg * u;
+                            dzg = dl * al[r] * fmaf(u, -1.0f / 255.0f, 1.0f);
+                        } else {
+                            const float sg = sigmoid_from_scaled(az[r]);
+                            dl = gg * sg;
+                            dzg = dl * al[r] * (1.0f - sg);
+                        }
                         const __bf16 lh = (__bf16)dl, zh = (__bf16)dzg;
                         fl[0][r >> 3][r & 7] = lh;
                         fz[0][r >> 3][r & 7] = zh;
@@ -933,7 +975,7 @@ int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const flo
                         const float* beta, const float* wglu, const float* bglu, float* run_mean, float* run_var,
                         int64_t* tracked, int train, int update, const uint64_t* seed, double* mom, double* mompart,
                         float* wz, float* wl, float* bn, float* p0, uint16_t* mask_out, const ConvPackArgs* pack, hipStream_t st,
-                        int main_kernel_only, const GenAuxPack* aux, void* p0_b16, int mom_ready) {
+                        int main_kernel_only, const GenAuxPack* aux, void* p0_b16, int mom_ready, void* sg_out) {
     // main_kernel_only (sed_kernel_replay): the folded weights of the last real forward are still in wz / wl
     // mom_ready: mompart already holds this batch's patch moments (sed_crnn_moments) - no moments launch; the packing that would
     // have ridden in it rides in the prep launch
@@ -971,9 +1013,13 @@ int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const flo
     };
 #define BLK0_FWD_M(NH, DROP, SAVE, MODE) \
     k_blk0_fwd<NH, DROP, SAVE, MODE><<<grid_for((const void*)k_blk0_fwd<NH, DROP, SAVE, MODE>), 256, 0, st>>>(x, wz, wl, p0, g.B, g.T, g.H1, tpc, nt, g.p, seed, mask_out, p0_b16)
+#define BLK0_FWD_SG(NH, DROP, SAVE, MODE) \
+    k_blk0_fwd<NH, DROP, SAVE, MODE, 1><<<grid_for((const void*)k_blk0_fwd<NH, DROP, SAVE, MODE, 1>), 256, 0, st>>>(x, wz, wl, p0, g.B, g.T, g.H1, tpc, nt, g.p, seed, mask_out, p0_b16, (uint4*)sg_out)
 #define BLK0_FWD(NH, DROP, SAVE)                          \
     do {                                                  \
-        if (g.f16) BLK0_FWD_M(NH, DROP, SAVE, 3);         \
+        if (g.f16 && sg_out) BLK0_FWD_SG(NH, DROP, SAVE, 3);   \
+        else if (g.f16) BLK0_FWD_M(NH, DROP, SAVE, 3);    \
+        else if (g.mode == 1 && sg_out) BLK0_FWD_SG(NH, DROP, SAVE, 1);   \
         else if (g.mode == 1) BLK0_FWD_M(NH, DROP, SAVE, 1);   \
         else if (g.mode == 2) BLK0_FWD_M(NH, DROP, SAVE, 2);   \
         else BLK0_FWD_M(NH, DROP, SAVE, 0);               \
@@ -992,6 +1038,7 @@ int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const flo
 #undef BLK0_FWD_NH
 #undef BLK0_FWD
 #undef BLK0_FWD_M
+#undef BLK0_FWD_SG
     SED_CHECK_LAUNCH();
     return SED_OK;
 }
@@ -1000,7 +1047,7 @@ int launch_blk0_backward(const Geo& g, const float* x, const float* w0, const fl
                          const float* beta, const float* wglu, const uint16_t* mask_in, const double* mom,
                          const float* wz, const float* wl, const float* bn, const float* dp0, double* de, int zero_de,
                          float* g_w0, float* g_b0, float* g_gamma, float* g_beta, float* g_wglu, float* g_bglu,
-                         hipStream_t st) {
+                         hipStream_t st, const void* sg_in) {
     if (zero_de) SED_CHECK_HIP(hipMemsetAsync(de, 0, 2 * g.C * 10 * sizeof(double), st));
     const int tpc = (g.H1 + 3) / 4, nt = tpc * g.B;
     const int use_drop = (g.p > 0.f) ? 1 : 0;
@@ -1014,7 +1061,11 @@ int launch_blk0_backward(const Geo& g, const float* x, const float* w0, const fl
 #endif
 #define BLK0_BWD(NH, MODE, NHT, GRID) \
     k_blk0_bwd<NH, MODE, NHT><<<dim3(nt < (GRID) ? nt : (GRID), BLK0_YGRID((NHT) / (NH))), 256, 0, st>>>(x, wz, wl, dp0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, mask_in, de, g_sed_debug & 1)
-    if (g.C == 64 && g.mode == 1) BLK0_BWD(2, 1, 2, 512);
+    if (g.C == 64 && g.mode == 1 && sg_in)
+        k_blk0_bwd<2, 1, 2, 0, 1><<<dim3(nt < 512 ? nt : 512, 1), 256, 0, st>>>(x, wz, wl, dp0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, mask_in, de, g_sed_debug & 1, (const uint4*)sg_in);
+    else if (g.C == 128 && g.mode == 1 && sg_in)
+        k_blk0_bwd<2, 1, 4, 0, 1><<<dim3(nt < (BLK0_GRID128) ? nt : (BLK0_GRID128), BLK0_YGRID(2)), 256, 0, st>>>(x, wz, wl, dp0, g.B, g.T, g.H1, tpc, nt, use_drop, g.p, mask_in, de, g_sed_debug & 1, (const uint4*)sg_in);
+    else if (g.C == 64 && g.mode == 1) BLK0_BWD(2, 1, 2, 512);
     else if (g.C == 64 && g.mode == 2) BLK0_BWD(2, 2, 2, 512);
     else if (g.C == 128 && g.mode == 2) BLK0_BWD(2, 2, 4, BLK0_GRID128);
     else if (g.C == 64 && (g_sed_debug & 134217728))      // debug bit 27: strict fp32 (no split-bf16 products anywhere in the step)

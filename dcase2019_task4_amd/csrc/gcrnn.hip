@@ -35,8 +35,14 @@ struct GCtx {
     size_t xch[2], epoch[2], err;             // cluster recurrence: exchange granules, launch epochs, spin-timeout flag
     size_t logits_s, strong_sv, weak_sv, den_sv;
     size_t mask[3];
+    size_t sg0;                               // bf16 family: block 0's GLU gate, one byte per element (blk0.hip SG), 0 bytes otherwise
     size_t total;
 };
+// debug bit 28: block 0's forward SAVES its GLU gates (one byte per element) and the backward reads them instead of recomputing
+// z on the MFMA + exp2 + rcp per element.  Built and measured in round 6, NOT the default: at B = 64 the backward kernel goes
+// 89 -> 81 us but the student's forward 109 -> 128 us (164 MB of byte stores from a kernel that runs beside the teacher's) -
+// waveform-bf16 0.8008 -> 0.8211 ms, mt-bf16 0.4929 -> 0.4944 (profiles/r06_blk0_saved_gates_ab.txt).
+static inline bool blk0_saves_gates(const Geo& g) { return g.mode == SED_DTYPE_BF16 && (g_sed_debug & 268435456); }
 static size_t mask_bytes(size_t Q, int C) { return ((Q + 3) / 4) * (size_t)(C / 32) * 64 * sizeof(uint16_t); }
 
 static GCtx make_gctx(const Geo& g) {
@@ -72,6 +78,8 @@ static GCtx make_gctx(const Geo& g) {
     put(L.weak_sv, (size_t)g.B * g.NC * 4); put(L.den_sv, (size_t)g.B * g.NC * 4);
     put(L.mask[0], mask_bytes((size_t)g.B * g.H1 * g.W1, g.C)); put(L.mask[1], mask_bytes((size_t)g.B * g.H2 * g.W2, g.C));
     put(L.mask[2], mask_bytes((size_t)g.B * g.T3, g.C));
+    // (sized by the MODE alone, never by the debug bit: the caller allocated ctx from sed_crnn_ctx_bytes before any bit was set)
+    put(L.sg0, g.mode == SED_DTYPE_BF16 ? mask_bytes((size_t)g.B * g.H1 * g.W1, g.C) * 8 : 0);
     L.total = o;
     return L;
 }
@@ -249,7 +257,8 @@ int gen_forward(const Geo& g, const ParamOff& P, const float* params, float* bn_
                                 seed_dev, CTXD(L.mom0), CTXD(L.mompart), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0),
                                 g.f16 ? CTXF(L.ph[0]) : CTXF(L.p[0]),
                                 use_drop ? CTXM(L.mask[0]) : nullptr, nullptr, st, 0, aux_pack ? &aux : nullptr,
-                                (g.f16 && keep_b16) ? CTXV(L.p[0]) : nullptr, mom_ready));
+                                (g.f16 && keep_b16) ? CTXV(L.p[0]) : nullptr, mom_ready,
+                                (train && !(train & 2) && blk0_saves_gates(g)) ? CTXV(L.sg0) : nullptr));
     // ---- conv blocks 1, 2 -----------------------------------------------------------------------------------------------
     const size_t so[3] = {0, L.stat1, L.stat2};
     const int Hs[3] = {0, g.H1, g.H2}, Wd[3] = {0, g.W1, g.W2};
@@ -352,7 +361,7 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
     // throughput-bound, the GEMMs only trade places with the weight-gradient kernels and slow the latency-bound recurrence)
     // (H = 64, re-measured with the round-3 kernels: 0.580 against 0.569 ms - the GEMMs stretch the lower layer's recurrence from
     // 40 to 52 us)
-    const bool early_gru_w = parts == 3 && have_side && H != 64 && !(g_sed_debug & 131072);    // (debug bit 17: old schedule)
+    const bool early_gru_w = parts == 3 && have_side && (H != 64 || (g_sed_debug & 536870912)) && !(g_sed_debug & 131072);    // (debug bit 17: old schedule; bit 29: early at H = 64 too)
     bool forked = false, forked2 = false;
     auto fork = [&]() -> int {
         if (!have_side) return SED_OK;
@@ -528,7 +537,7 @@ int gen_backward(const Geo& g, const ParamOff& P, const float* params, const flo
     SED_TRY(launch_blk0_backward(g, x, params + P.conv_w[0], params + P.conv_b[0], params + P.bn_g[0], params + P.bn_b[0],
                                  params + P.glu_w[0], CTXM(L.mask[0]), CTXD(L.mom0), CTXF(L.wz0), CTXF(L.wl0), CTXF(L.bn0), WSF(W.dp[0]),
                                  WSD(W.de0), 0, grads + P.conv_w[0], grads + P.conv_b[0], grads + P.bn_g[0], grads + P.bn_b[0],
-                                 grads + P.glu_w[0], grads + P.glu_b[0], st));
+                                 grads + P.glu_w[0], grads + P.glu_b[0], st, blk0_saves_gates(g) ? CTXV(L.sg0) : nullptr));
     if (forked) {
         SED_CHECK_HIP(hipEventRecord(ev_join, ss));
         SED_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));

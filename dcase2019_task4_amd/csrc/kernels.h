@@ -17,12 +17,13 @@ int launch_blk0_forward(const Geo& g, const float* x, const float* w0, const flo
                         hipStream_t st,
                         int main_kernel_only = 0, const GenAuxPack* aux = nullptr,
                         void* p0_b16 = nullptr /* g.f16: p0 is fp16 and this (may be null) receives its bf16 copy */,
-                        int mom_ready = 0 /* the batch's patch moments are already in mompart (sed_crnn_moments) */);
+                        int mom_ready = 0 /* the batch's patch moments are already in mompart (sed_crnn_moments) */,
+                        void* sg_out = nullptr /* bf16 family, differentiated forward: receives the GLU gate bytes (blk0.hip SG) */);
 int launch_blk0_backward(const Geo& g, const float* x, const float* w0, const float* b0, const float* gamma,
                          const float* beta, const float* wglu, const uint16_t* mask_in, const double* mom,
                          const float* wz, const float* wl, const float* bn, const float* dp0, double* de, int zero_de,
                          float* g_w0, float* g_b0, float* g_gamma, float* g_beta, float* g_wglu, float* g_bglu,
-                         hipStream_t st);
+                         hipStream_t st, const void* sg_in = nullptr /* the forward's saved gate bytes (bf16 family) */);
 
 // conv.hip : 3x3, 64 -> 64 channels, channels-last, image [B][H][W][64] with W in {16, 4}
 // ---- conv weight packing (conv.hip; also called from k_x_moments, blk0.hip) -----------------------------------------

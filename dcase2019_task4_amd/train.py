@@ -108,6 +108,8 @@ class MeanTeacherStep:
         self.exp_avg = torch.zeros(n, **f32)
         self.exp_avg_sq = torch.zeros(n, **f32)
         self.state = torch.zeros(C.sizeof(_lib.SedStepState), device=dev, dtype=torch.uint8)
+        self.steps_done = 0
+        self._gs_offset = 0                # global_step_host = steps_done + _gs_offset: host mirror of state.global_step
         self.pg = process_group
         self.world, self.rank = 1, 0
         if process_group is not None:
@@ -235,8 +237,6 @@ class MeanTeacherStep:
             if st is not None:
                 _lib.check(self.l.sed_stream_prepare(C.c_void_p(st.cuda_stream)), "sed_stream_prepare")
         self._warm = 0
-        self.steps_done = 0
-        self._gs_offset = 0                # global_step_host = steps_done + _gs_offset: host mirror of state.global_step
         # Patch moments one step ahead (sed_crnn_moments, csrc/blk0.hip): block 0's train-mode BatchNorm statistics come from the
         # 9 + 45 moments of the 3x3 input patch, a function of the BATCH only.  When the batch in self.x / self.x_ema is still the
         # one the previous run() trained on (a resident batch: bench.py; anything that calls run() without load_batch() in

@@ -188,11 +188,16 @@ __device__ __forceinline__ void blk0_prep_body(const Blk0PrepArgs& a) {
                 for (int u = 0; u < 16; ++u) acc += v[u];
             }
             {   // the remaining (< 16) partials of this lane, still issued together
+                // (clamped index, then select: written as `in range ? load : 0` every load was a branch with its own s_waitcnt -
+                // up to fifteen serialized round trips in this one-workgroup kernel on the head of every forward)
                 double v[15];
 #pragma unroll
-                for (int u = 0; u < 15; ++u) v[u] = (w + 16 * u < a.n_part) ? a.mompart[(size_t)(w + 16 * u) * 54 + k] : 0.0;
+                for (int u = 0; u < 15; ++u) {
+                    const int wi = w + 16 * u;
+                    v[u] = a.mompart[(size_t)(wi < a.n_part ? wi : a.n_part - 1) * 54 + k];
+                }
 #pragma unroll
-                for (int u = 0; u < 15; ++u) acc += v[u];
+                for (int u = 0; u < 15; ++u) acc += (w + 16 * u < a.n_part) ? v[u] : 0.0;
             }
             mred[k][j] = acc;
         }
@@ -600,8 +605,14 @@ __global__ __launch_bounds__(256, (NH == 2 ? 3 : 2)) void k_blk0_fwd(const float
 // latency of its in-order stream exposed - 197 us against 2 x 53 for the halves at two waves per SIMD)
 // STRICT (fp32 only, debug bit 27 / SED_STRICT_F32=1): the 2 x 10 sums per channel as plain fp32 FMAs on the VALU instead of
 // split-bf16 MFMA products - the all-fp32 twin of the `dtype: f32` headline (bench.py extra_configs["mt-f32-strict"]).
+#ifndef BLK0_BWD_OCC16
+#define BLK0_BWD_OCC16 2
+#endif
+#ifndef BLK0_BWD_GUNROLL
+#define BLK0_BWD_GUNROLL 4      // (row-block loop fully unrolled: 97 -> 90 us solo at B = 64 in the bf16 family; 1: 103)
+#endif
 template <int NH, int MODE, int NHT, int STRICT = 0, int SG = 0>
-__global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float* __restrict__ x, const float* __restrict__ wz,
+__global__ __launch_bounds__(256, (NH == 2 ? (MODE == 1 ? BLK0_BWD_OCC16 : 2) : 1)) void k_blk0_bwd(const float* __restrict__ x, const float* __restrict__ wz,
                                                    const float* __restrict__ wl, const float* __restrict__ dp0, int B,
                                                    int T, int H1, int tiles_per_clip, int n_tiles, int use_drop,
                                                    float p_drop, const uint16_t* __restrict__ mask_in,
@@ -689,6 +700,8 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
             }
         };
         fetch(0);
+        constexpr int GUNROLL = STRICT != 0 ? 1 : BLK0_BWD_GUNROLL;      // (the strict-fp32 form spills when unrolled)
+#pragma unroll GUNROLL
         for (int g = 0; g < 4; ++g) {
             float gq_c[NH][4];
             uint32_t m_c[NH];
@@ -736,11 +749,22 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
                     for (int r = 0; r < 16; ++r) pv[r] = src[r];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float v = n < 9 ? pv[r] : other;
-                        const __bf16 hi = (__bf16)v;
+                        const __bf16 hi = (__bf16)pv[r];
                         pT[0][r >> 3][r & 7] = hi;
-                        if constexpr (MODE != 1) pT[1][r >> 3][r & 7] = (__bf16)(v - (float)hi);
+                        if constexpr (MODE != 1) pT[1][r >> 3][r & 7] = (__bf16)(pv[r] - (float)hi);
                     }
+                    // the constant / zero taps (lanes n >= 9) are selected on the PACKED pairs: 8 selects per plane instead of 16
+                    typedef __attribute__((ext_vector_type(4))) unsigned int blk0_u32x4;
+                    const unsigned int oth = __builtin_bit_cast(unsigned short, (__bf16)other) * 0x10001u;
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                        for (int hf = 0; hf < 2; ++hf) {
+                            blk0_u32x4 w = __builtin_bit_cast(blk0_u32x4, pT[pl][hf]);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) w[q] = n < 9 ? w[q] : (pl ? 0u : oth);
+                            pT[pl][hf] = __builtin_bit_cast(blk0_bf16x8, w);
+                        }
                 }
 #pragma unroll
                 for (int h = 0; h < NH; ++h) {
@@ -752,7 +776,12 @@ __global__ __launch_bounds__(256, (NH == 2 ? 2 : 1)) void k_blk0_bwd(const float
                                              SG ? sg_c[SG ? h : 0].w : 0u};
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float gg = ((m_c[h] >> r) & 1u) ? gq_c[h][r >> 2] : 0.f;
+                        // keep bit r as an all-ones / all-zeros word (v_bfe_i32) ANDed onto the pooled gradient: two plain VALU
+                        // instructions, as in the forward (`bit ? g : 0` compiled to and + compare + select)
+                        // (the v_bfe_i32 is assembly: LLVM folds `g & sext(bit)` back into the three-instruction select)
+                        int keepw;
+                        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keepw) : "v"(m_c[h]), "n"(r));
+                        const float gg = __int_as_float(__float_as_int(gq_c[h][r >> 2]) & keepw);
                         float dl, dzg;
                         if constexpr (SG != 0) {
                             // u = 255 s as a float (v_cvt_f32_ubyte<r & 3>); gg carries the 1 / 255: dl = gg' u, 1 - s = 1 - u / 255

@@ -413,8 +413,9 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
         SED_CHECK_ARG(!(g.p > 0.f) || seed_dev, "sed_crnn_backward: dropout enabled but seed_dev is null");
         hipStream_t st0 = (hipStream_t)stream;
         SideStream& sd0 = side_stream(st0);
+        // (debug bit 30: no helper stream - every kernel on the caller's stream, for near-solo kernel times under rocprofv3)
         return gen_backward(g, P, params, x, seed_dev, ctx, ctx_bytes, d_strong, d_weak, grads, ws, ws_bytes, parts, st0,
-                            sd0.ok ? sd0.s : st0, sd0.fork, sd0.join, (sd0.ok && (g_sed_debug & 2048)) ? sd0.s2 : nullptr, sd0.join2, hl, ho);
+                            (sd0.ok && !(g_sed_debug & 1073741824)) ? sd0.s : st0, sd0.fork, sd0.join, (sd0.ok && (g_sed_debug & 2048)) ? sd0.s2 : nullptr, sd0.join2, hl, ho);
     }
     const CtxLayout L = make_ctx_layout(g);
     const WsLayout W = make_ws_layout(g);
@@ -427,7 +428,7 @@ static int crnn_backward_impl(const sed_dims* d, const float* params, const floa
     hipStream_t st = (hipStream_t)stream;
     const int BT = g.B * g.T3;
     SideStream& sd = side_stream(st);
-    hipStream_t ss = sd.ok ? sd.s : st;       // without a side stream everything stays on the caller's
+    hipStream_t ss = (sd.ok && !(g_sed_debug & 1073741824)) ? sd.s : st;       // without a side stream everything stays on the caller's
     const bool defer_gru_w = (parts & 4) != 0;           // parts == 5: the caller runs them later (parts == 8)
     bool forked = false, forked2 = false;
 

@@ -24,6 +24,21 @@
 #include "gkernels.h"
 #include "gpack.h"
 
+SED_TS_DEFINE(grec)
+// tuning aid (make EXTRA=-DSED_TS; tools/ts_generic.py grec): shader-clock stamps of ONE time step (s = 20) of workgroup 0's
+// wave 0 - forward stamps 0 .. 6, backward 8 .. 14.  sched_barriers pin the phases; compiles to nothing in the product build.
+#ifdef SED_TS
+#define GREC_TS(k) do { if (s == 20) { __builtin_amdgcn_sched_barrier(0); TSC(k); __builtin_amdgcn_sched_barrier(0); } } while (0)
+// the values a phase produces are pinned in front of its stamp (every step, so that the stamped step runs the same code as the others)
+#define GREC_PIN6(a) asm volatile("" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]) :: "memory")
+#define GREC_PIN4(a) asm volatile("" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]) :: "memory")
+#define GREC_PIN1(x) asm volatile("" : "+v"(x) :: "memory")
+#else
+#define GREC_TS(k) do { } while (0)
+#define GREC_PIN6(a) do { } while (0)
+#define GREC_PIN4(a) do { } while (0)
+#define GREC_PIN1(x) do { } while (0)
+#endif
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4r;
 #define GREC_H 256
@@ -149,6 +164,7 @@ __global__ __launch_bounds__(GREC_T) void k_grec_fwd(const float* __restrict__ g
         const int ns = (T - s0 < TB) ? (T - s0) : TB;
         for (int st = 0; st < ns; ++st) {
             const int s = s0 + st;
+            GREC_TS(0);                                                // behind the previous step's barrier
             const float gi_r = gis[buf][st][0][u], gi_z = gis[buf][st][1][u], gi_n = gis[buf][st][2][u];
             float a[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
             const unsigned int* hb = hs[s & 1] + 32 * kq;
@@ -163,10 +179,14 @@ __global__ __launch_bounds__(GREC_T) void k_grec_fwd(const float* __restrict__ g
 #pragma unroll
                         for (int g = 0; g < 3; ++g) a[uu][g] = F16 ? dot2h(wr[uu][g][4 * c + q], hv[q], a[uu][g]) : dot2(wr[uu][g][4 * c + q], hv[q], a[uu][g]);
             }
+            GREC_PIN6(a);
+            GREC_TS(1);                                                // h reads + 192 dot2
 #pragma unroll
             for (int uu = 0; uu < 2; ++uu)
 #pragma unroll
                 for (int g = 0; g < 3; ++g) a[uu][g] = quad_sum(a[uu][g]);
+            GREC_PIN6(a);
+            GREC_TS(2);                                                // quad sums (12 DPP adds)
             const bool odd = (kq & 1) != 0;
             const float gh_r = (odd ? a[1][0] : a[0][0]) + bh_r, gh_z = (odd ? a[1][1] : a[0][1]) + bh_z,
                         ghn = (odd ? a[1][2] : a[0][2]) + bh_n;
@@ -175,12 +195,16 @@ __global__ __launch_bounds__(GREC_T) void k_grec_fwd(const float* __restrict__ g
             const float nn = tanh_fast(gi_n + r * ghn);
             const float h = (1.0f - z) * nn + z * hprev;
             hprev = h;
+            GREC_PIN1(hprev);
+            GREC_TS(3);                                                // gate chain (2 sigmoid + tanh)
             if (writer) {
                 if constexpr (F16 != 0) ((_Float16*)hs[(s + 1) & 1])[u] = (_Float16)h;
                 else ((__bf16*)hs[(s + 1) & 1])[u] = (__bf16)h;
                 outs[st][0][u] = r; outs[st][1][u] = z; outs[st][2][u] = nn; outs[st][3][u] = ghn; outs[st][4][u] = h;
             }
+            GREC_TS(4);                                                // publish: 6 LDS writes issued
             lds_barrier();
+            GREC_TS(5);                                                // barrier (incl. the writes' completion)
         }
     }
     out_flush(((T - 1) / TB) * TB);
@@ -264,6 +288,7 @@ __global__ __launch_bounds__(GREC_T) void k_grec_bwd(const float* __restrict__ d
         const int ns = (T - s0 < TB) ? (T - s0) : TB;
         for (int st = 0; st < ns; ++st) {
             const int s = s0 + st;
+            GREC_TS(8);
             const float dh = ins[buf][st][0][j] + carry;
             const float r = ins[buf][st][1][j], z = ins[buf][st][2][j], nn = ins[buf][st][3][j], ghn = ins[buf][st][4][j],
                         hp = ins[buf][st][5][j];
@@ -276,7 +301,9 @@ __global__ __launch_bounds__(GREC_T) void k_grec_bwd(const float* __restrict__ d
                 dd[j] = (__bf16)dr_pre; dd[H + j] = (__bf16)dz_pre; dd[2 * H + j] = (__bf16)dghn;
                 outs[st][0][j] = dr_pre; outs[st][1][j] = dz_pre; outs[st][2][j] = dn_pre; outs[st][3][j] = dghn; outs[st][4][j] = hp;
             }
+            GREC_TS(9);                                                // 6 input reads + gate gradients + 8 LDS writes issued
             lds_barrier();                                             // this step's 3H gate gradients are in ds[s & 1]
+            GREC_TS(10);                                               // barrier
             float a[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
             const unsigned int* db = ds[s & 1] + 96 * gq;
 #pragma unroll
@@ -290,8 +317,12 @@ __global__ __launch_bounds__(GREC_T) void k_grec_bwd(const float* __restrict__ d
                     a[jj][1] = dot2(wc[jj][4 * c + 3], d4.w, a[jj][1]);
                 }
             }
+            GREC_PIN4(a);
+            GREC_TS(11);                                               // 24 ds_read_b128 of gate gradients + 192 dot2
             const float c0 = quad_sum(a[0][0] + a[0][1]), c1 = quad_sum(a[1][0] + a[1][1]);
             carry = dh * z + ((gq & 1) ? c1 : c0);
+            GREC_PIN1(carry);
+            GREC_TS(12);                                               // quad sums + carry
             // (ds is double-buffered: the next step writes the other buffer, and every reader of this one has passed the
             // next barrier before it is written again)
         }

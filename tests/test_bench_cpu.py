@@ -36,3 +36,21 @@ def test_workload_strings_name_what_runs_on_which_operands():
     s = bench.workload_string(False, "bf16", True, 64, "f32")
     assert "raw 16 kHz waveforms" in s and "f32 butterflies" in s and "SED_DTYPE_BF16" in s
     assert "SED_DTYPE_BF16X3" in bench.workload_string(True, "bf16x3", False, 24)
+
+
+def test_round6_configs_frames_and_strict_strings():
+    import bench
+    for name in ("mt-f32-b64", "mt-f32-T864", "mt-f32-strict"):
+        assert name in bench.CONFIGS and bench.CONFIGS[name][1] == "f32"
+    assert bench.CONFIGS["mt-f32-b64"][3] == 64                       # configs[3]'s per-rank shape: [16 | 32 | 16]
+    assert bench.CONFIG_FRAMES["mt-f32-T864"] == 864                  # baseline/config.py:17-22 (44.1 kHz, hop 511)
+    assert bench.block_boundary_elements(628) == 428440               # S
+    fs, bs = bench.frames_scale(864)
+    assert abs(fs - 1180.8 / 858.1) < 1e-12 and 1.37 < bs < 1.38
+    r = bench.step_roofline(False, "f32", False, 24, 0.93, 864)
+    assert r["algorithmic_flops"] == int(3.432e9 * 24 * fs)
+    s = bench.workload_string(False, "f32", False, 24, T=864)
+    assert "[24,1,864,64]" in s
+    s = bench.workload_string(False, "f32", False, 24, strict=True)
+    assert "STRICT fp32" in s and "split" in s
+    assert bench.strict_f32("mt-f32-strict") and not bench.strict_f32("mt-f32")

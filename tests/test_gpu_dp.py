@@ -144,13 +144,13 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-def _run_world2(target, args):
+def _run_world2(target, args, world=2):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     out = ctx.SimpleQueue()
     port = _free_port()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    procs = [ctx.Process(target=target, args=(r, 2, port) + tuple(args) + (out,)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, world, port) + tuple(args) + (out,)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -292,6 +292,15 @@ def _worker_peer_allreduce(rank, world, port, mode, out):
 def test_peer_allreduce_world2_on_one_gpu(mode):
     ok = _run_world2(_worker_peer_allreduce, (mode,))
     print(f"[p2p all-reduce world 2] mode {mode}: {'fine-grained buffers' if ok[2] == 1.0 and mode == 'sums' else ok[2]}")
+
+
+@pytest.mark.parametrize("world", [3, 4])
+def test_peer_allreduce_other_world_sizes_on_one_gpu(world):
+    """World 3 takes the any-W instantiation of the kernel (k_p2p_allreduce<0>: run-time rank loop, 32-bit chunk arithmetic),
+    world 4 the compile-time one with two chunks x four ranks per load batch: the same size sweep, eager and replayed, every
+    rank bit-for-bit the rank-order sum (three / four processes sharing this box's GPU over gloo)."""
+    ok = _run_world2(_worker_peer_allreduce, ("sums",), world=world)
+    print(f"[p2p all-reduce world {world}] sums: {'fine-grained buffers' if ok[2] == 1.0 else ok[2]}")
 
 
 def _worker_skew(rank, world, port, collective, out):

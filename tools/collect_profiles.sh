@@ -1,12 +1,12 @@
 #!/bin/bash
-# Profile collection on the GPU box (rounds 3 - 5) (run through gpurun from the repo root); writes under gpurun_out/$PROF_TAG/.
+# Profile collection on the GPU box (rounds 3 - 6) (run through gpurun from the repo root); writes under gpurun_out/$PROF_TAG/.
 # Counters are collected in their own passes with --kernel-trace only (never with hip/hsa trace domains).
 set -u
-OUT=$GRAFT_REPO_ROOT/gpurun_out/${PROF_TAG:-r05}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${PROF_TAG:-r06}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-CFGS="${PROF_CFGS:-mt-f32 mt-bf16 mt-f16 mt-bf16x3 waveform-bf16 waveform-f16 wide-f32 wide-bf16 wide-f16 wide-bf16x3}"
+CFGS="${PROF_CFGS:-mt-f32 mt-f32-b64 mt-f32-T864 mt-f32-strict mt-bf16 mt-f16 mt-bf16x3 waveform-bf16 waveform-f16 wide-f32 wide-bf16 wide-f16 wide-bf16x3}"
 # 1. kernel stats + one step's timeline of the bench command, one per workload.  ONE traced process per summary: the headline's
 #    extra_configs child processes and its feature-path leg are suppressed (--trace-only-this-config keeps the kernel-table leg
 #    whose solo re-launches summarize_prof.py reports); timeline.py / summarize_prof.py refuse a trace with several databases and
@@ -17,14 +17,15 @@ for c in $CFGS; do
   python $R/tools/timeline.py $OUT/stats_$c 2 --config $c > $OUT/${c}_step_timeline.txt 2> $OUT/${c}_step_timeline.err
 done
 if [ "${PROF_ONLY_STATS:-0}" != "1" ]; then
-# 2. HBM traffic of the headline workload: FETCH_SIZE and WRITE_SIZE in separate passes (13 steps traced: 10 + 3 warm-up)
+# 2. HBM traffic of the headline workload: FETCH_SIZE and WRITE_SIZE in separate passes.  Steps traced = 3 warm-up + 10 timed (wall
+#    clock) + 10 + 10 of bench.py's hipEvent pass (time_steps: min(K, 50) untimed + K timed replays) = 33
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o p -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $OUT/pmc_fetch.log 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o p -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $OUT/pmc_write.log 2>&1
-python $R/tools/summarize_pmc.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json 13 > $OUT/mt-f32_pmc_hbm_traffic.md 2>/dev/null
-# 3. same for the wide bf16 step (9 steps traced)
+python $R/tools/summarize_pmc.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json 33 > $OUT/mt-f32_pmc_hbm_traffic.md 2>/dev/null
+# 3. same for the wide bf16 step (3 + 6 + 6 + 6 = 21 steps traced)
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmcw_fetch -o p -- python $R/bench.py --config wide-bf16 --steps 6 --warmup 3 --no-extras --no-cpu-baseline > $OUT/pmcw_fetch.log 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmcw_write -o p -- python $R/bench.py --config wide-bf16 --steps 6 --warmup 3 --no-extras --no-cpu-baseline > $OUT/pmcw_write.log 2>&1
-python $R/tools/summarize_pmc.py $OUT/pmcw_fetch $OUT/pmcw_write $OUT/pmc_traffic_wide_bf16.json 9 > $OUT/wide-bf16_pmc_hbm_traffic.md 2>/dev/null
+python $R/tools/summarize_pmc.py $OUT/pmcw_fetch $OUT/pmcw_write $OUT/pmc_traffic_wide_bf16.json 21 > $OUT/wide-bf16_pmc_hbm_traffic.md 2>/dev/null
 # 4. MFMA-busy / wait counters on supervised steps (student only: kernel durations close to solo) of the wide model, bf16 and bf16x3
 CNT="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
 for dt in bf16 bf16x3; do

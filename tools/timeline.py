@@ -10,6 +10,9 @@ import sys
 # kernels a workload's step must / must not contain (substrings of the kernel names)
 KERNEL_SETS = {
     "mt-f32": (("k_conv_wino", "k_wgrad_wino", "k_glu_pool_fwd", "k_gru4_"), ("k_bconv", "k_bglu", "k_gconv", "k_grec", "k_gclu", "k_stft")),
+    "mt-f32-b64": (("k_conv_wino", "k_wgrad_wino", "k_glu_pool_fwd", "k_gru4_"), ("k_bconv", "k_bglu", "k_gconv", "k_grec", "k_gclu", "k_stft")),
+    "mt-f32-T864": (("k_conv_wino", "k_wgrad_wino", "k_glu_pool_fwd", "k_gru4_"), ("k_bconv", "k_bglu", "k_gconv", "k_grec", "k_gclu", "k_stft")),
+    "mt-f32-strict": (("k_conv_wino", "k_wgrad_wino", "k_glu_pool_fwd", "k_gru4_"), ("k_bconv", "k_bglu", "k_gconv", "k_grec", "k_gclu", "k_stft")),
     "mt-bf16": (("k_bconv", "k_bglu_fwd", "k_gwgrad_bf16", "k_gru4_"), ("k_conv_wino", "k_grec", "k_gclu", "k_stft")),
     "mt-bf16x3": (("k_bconv", "k_gru4_"), ("k_conv_wino", "k_grec", "k_gclu", "k_stft")),
     "waveform-bf16": (("k_bconv", "k_gru4_", "k_stft_mel_p", "k_logmel"), ("k_conv_wino", "k_grec", "k_gclu")),

@@ -315,7 +315,10 @@ class _SampleTransforms:
                 "cannot use the parent's HIP context.  Use DataLoader(num_workers=0), or multiprocessing_context='spawn' "
                 "(one context + one launch per sample and worker), or - the fast path - keep linear-mel features in the "
                 "dataset and apply features.LogMelTransform / WaveformFrontEnd to whole batches on the training process.")
-        self.tr._seed = self.worker_seed(self.tr._seed, info.id)
+        # info.seed = the loader's per-EPOCH base seed + worker id (torch draws a new base seed for every iterator): folding it in
+        # gives every epoch its own noise - a worker re-created each epoch (persistent_workers=False) restarts its call counter
+        # and would otherwise replay the previous epoch's noise sample for sample.  Reproducible under torch.manual_seed.
+        self.tr._seed = self.worker_seed(int(self.tr._seed) ^ (int(info.seed) & 0x7FFFFFFFFFFFFFFF), info.id)
 
     def __call__(self, sample):
         if self._pid != os.getpid():

@@ -4,17 +4,23 @@ Same constructor signature, ``forward(x[B,1,T,F]) -> (strong[B,T//8,nclass], wea
 nested ``state_dict()`` / ``load`` / ``save`` / ``load_cnn`` contract and submodule class names
 (``weights_init`` in baseline/utils/utils.py:205-224 dispatches on ``__class__.__name__``
 substrings), so ``CRNN(**cfg.crnn_kwargs)`` drops into baseline/main.py:279-287 and
-baseline/TestModel.py:30-36 unchanged.  The torch submodules below are PARAMETER CONTAINERS
-only: ``forward`` never calls them.  All arithmetic runs in the hand-written HIP kernels behind
-the C-ABI (include/dcase_sed.h) on one flat fp32 parameter buffer the containers' parameters are
-views of.  No CPU / stock-torch fallback exists: without the library (or on a CPU tensor) it raises.
+baseline/TestModel.py:30-36 unchanged.  On the hot path the torch submodules below are PARAMETER
+CONTAINERS only: ``forward`` never calls them.  All arithmetic runs in the hand-written HIP kernels
+behind the C-ABI (include/dcase_sed.h) on one flat fp32 parameter buffer the containers' parameters
+are views of, and there is no CPU / stock-torch fallback for it: without the library (or on a CPU
+tensor) a hot-path module raises.
 
-Implemented (anything else raises NotImplementedError): activation="glu", attention=True, BGRU, n_in_channel=1,
-three 3x3 conv blocks of EQUAL width with (2,4) pooling, 1 or 2 GRU layers, and
+Hot path (``CRNN.hot_path``): activation="glu", attention=True, BGRU, n_in_channel=1, three 3x3 conv blocks of EQUAL
+width with (2,4) pooling, 1 or 2 GRU layers, and
   * nb_filters 3 x 64, n_RNN_cell 64 - cfg.crnn_kwargs (baseline/config.py:53-58), the specialised fp32 kernel set;
   * nb_filters 3 x 64 or 3 x 128, n_RNN_cell 64 or 256 - the generic kernel set (BASELINE.json configs[4]'s wide CRNN).
 ``mfma_dtype`` (extra keyword, or ``set_mfma_dtype``) states the arithmetic of the GEMM-shaped operators of conv blocks
 1 and 2: "f32" (default, exact fp32 MFMA) or "bf16" (bf16 operands, fp32 accumulation - include/dcase_sed.h sed_dims.dtype).
+
+Every OTHER argument combination the reference's constructor accepts (activation "Relu" - the class default - / "leakyrelu" /
+"cg", attention=False, other filter counts / kernels / poolings / cell counts; SURVEY.md 8(b): accept-and-fallback) builds the
+reference's module tree and runs its graph on stock torch operators (``hot_path`` False, one warning; pinned by golden G11
+against the real reference).  The fused step (train.MeanTeacherStep) and the C-ABI refuse such a module.
 """
 import ctypes as C
 import warnings
@@ -33,8 +39,24 @@ class GLU(nn.Module):
         self.sigmoid = nn.Sigmoid()
         self.linear = nn.Linear(input_num, input_num)
 
-    def forward(self, x):  # pragma: no cover - containers are never executed
-        raise RuntimeError("GLU is fused into the HIP conv-block kernels; call CRNN.forward")
+    def forward(self, x):
+        """CNN.py:11-16 - only executed by the stock-torch path of configurations outside the hot path (CRNN.hot_path False);
+        on the hot path the GLU is fused into the HIP conv-block kernels."""
+        lin = self.linear(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+        return lin * self.sigmoid(x)
+
+
+class ContextGating(nn.Module):
+    """baseline/models/CNN.py:19-30 (activation="cg"): never on the hot path, stock torch operators."""
+
+    def __init__(self, input_num):
+        super().__init__()
+        self.sigmoid = nn.Sigmoid()
+        self.linear = nn.Linear(input_num, input_num)
+
+    def forward(self, x):
+        lin = self.linear(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+        return x * self.sigmoid(lin)
 
 
 class CNN(nn.Module):
@@ -43,19 +65,28 @@ class CNN(nn.Module):
     def __init__(self, n_in_channel, activation="Relu", conv_dropout=0, kernel_size=[3, 3, 3], padding=[1, 1, 1],
                  stride=[1, 1, 1], nb_filters=[64, 64, 64], pooling=[(1, 4), (1, 4), (1, 4)]):
         super().__init__()
-        if activation.lower() != "glu":
-            raise NotImplementedError(f"hot path implements activation='glu' only (config.py:55), got {activation!r}")
-        if n_in_channel != 1 or list(nb_filters) not in ([64, 64, 64], [128, 128, 128]) or list(kernel_size) != [3, 3, 3] or \
-                list(padding) != [1, 1, 1] or list(stride) != [1, 1, 1] or [tuple(p) for p in pooling] != [(2, 4)] * 3:
-            raise NotImplementedError("hot path implements n_in_channel=1, 3x(64 or 128 filters, k3/s1/p1), pooling (2,4)x3 "
-                                      "(config.py:53-58; BASELINE.json configs[4] for 128)")
+        # The HIP kernels implement config.py:53-58's block (and BASELINE.json configs[4]'s width): GLU, n_in_channel = 1, three
+        # 3x3 / stride 1 / pad 1 convolutions of 64 or 128 filters, pooling (2, 4) x 3.  Everything else the reference's constructor
+        # accepts (CNN.py:35-67) is ACCEPTED and runs on stock torch operators (accept-and-fallback for what is not
+        # on the hot path); `hot` says which of the two this container is.
+        act = activation.lower()
+        self.hot = (act == "glu" and n_in_channel == 1 and list(nb_filters) in ([64, 64, 64], [128, 128, 128]) and
+                    list(kernel_size) == [3, 3, 3] and list(padding) == [1, 1, 1] and list(stride) == [1, 1, 1] and
+                    [tuple(p) for p in pooling] == [(2, 4)] * 3 and conv_dropout is not None)
         self.nb_filters = list(nb_filters)
         cnn = nn.Sequential()
-        for i in range(3):
+        for i in range(len(nb_filters)):
             n_in = n_in_channel if i == 0 else nb_filters[i - 1]
             cnn.add_module(f"conv{i}", nn.Conv2d(n_in, nb_filters[i], kernel_size[i], stride[i], padding[i]))
             cnn.add_module(f"batchnorm{i}", nn.BatchNorm2d(nb_filters[i], eps=0.001, momentum=0.99))
-            cnn.add_module(f"glu{i}", GLU(nb_filters[i]))
+            if act == "leakyrelu":
+                cnn.add_module(f"relu{i}", nn.LeakyReLU(0.2))
+            elif act == "relu":
+                cnn.add_module(f"relu{i}", nn.ReLU())
+            elif act == "glu":
+                cnn.add_module(f"glu{i}", GLU(nb_filters[i]))
+            elif act == "cg":
+                cnn.add_module(f"cg{i}", ContextGating(nb_filters[i]))
             if conv_dropout is not None:
                 cnn.add_module(f"dropout{i}", nn.Dropout(conv_dropout))
             cnn.add_module(f"pooling{i}", nn.AvgPool2d(pooling[i]))
@@ -75,8 +106,9 @@ class CNN(nn.Module):
     def save(self, filename):
         torch.save(self.cnn.state_dict(), filename)
 
-    def forward(self, x):  # pragma: no cover
-        raise RuntimeError("CNN is fused into the HIP kernels; call CRNN.forward")
+    def forward(self, x):
+        """CNN.py:85-89 on stock torch operators - reached only when CRNN.hot_path is False."""
+        return self.cnn(x)
 
 
 class BidirectionalGRU(nn.Module):
@@ -86,8 +118,10 @@ class BidirectionalGRU(nn.Module):
         super().__init__()
         self.rnn = nn.GRU(n_in, n_hidden, bidirectional=True, dropout=dropout, batch_first=True, num_layers=num_layers)
 
-    def forward(self, input_feat):  # pragma: no cover
-        raise RuntimeError("the GRU runs in the HIP recurrence kernels; call CRNN.forward")
+    def forward(self, input_feat):
+        """RNN.py:14-16 on stock torch operators - reached only when CRNN.hot_path is False."""
+        recurrent, _ = self.rnn(input_feat)
+        return recurrent
 
 
 class _CRNNFunction(torch.autograd.Function):
@@ -159,16 +193,19 @@ class CRNN(nn.Module):
                  rnn_type='BGRU', n_RNN_cell=64, n_layers_RNN=1, dropout_recurrent=0, **kwargs):
         super().__init__()
         mfma_dtype = kwargs.pop("mfma_dtype", "f32")
-        if not attention:
-            raise NotImplementedError("hot path implements attention=True only (config.py:53)")
         if rnn_type != 'BGRU':
-            raise NotImplementedError("Only BGRU supported for CRNN for now")
-        if n_RNN_cell not in (64, 256) or n_layers_RNN not in (1, 2) or dropout_recurrent != 0:
-            raise NotImplementedError("hot path implements n_RNN_cell in (64, 256), n_layers_RNN in (1,2), dropout_recurrent=0")
-        if not (1 <= nclass <= 16):
-            raise NotImplementedError("nclass must be in [1, 16]")
+            raise NotImplementedError("Only BGRU supported for CRNN for now")          # (the reference's own error, CRNN.py:26-27)
         self.attention = attention
         self.cnn = CNN(n_in_channel, activation, dropout, **kwargs)
+        # hot_path: the configuration the HIP kernels implement (cfg.crnn_kwargs and BASELINE.json configs[4]'s widths).  Every
+        # other combination the reference's constructor accepts - activation "Relu" (the class default) / "leakyrelu" / "cg",
+        # attention=False (weak = strong.mean(1), CRNN.py:82-83), other filter counts, kernels, poolings, cell counts, classes,
+        # recurrent dropout - is accepted too and runs the reference's graph on STOCK TORCH operators; forward
+        # warns once.  Nothing on the hot path ever takes that route: a hot-path module still raises on a CPU tensor or a
+        # missing library, and MeanTeacherStep / the HIP inference path refuse a module that is not hot_path.
+        self.hot_path = bool(self.cnn.hot and attention and n_RNN_cell in (64, 256) and n_layers_RNN in (1, 2) and
+                             dropout_recurrent == 0 and 1 <= nclass <= 16)
+        self._warned_stock = False
         if not train_cnn:
             for param in self.cnn.parameters():
                 param.requires_grad = False
@@ -178,8 +215,9 @@ class CRNN(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self.dense = nn.Linear(n_RNN_cell * 2, nclass)
         self.sigmoid = nn.Sigmoid()
-        self.dense_softmax = nn.Linear(n_RNN_cell * 2, nclass)
-        self.softmax = nn.Softmax(dim=-1)
+        if self.attention:                             # (CRNN.py:29-31: the attention layer only exists with attention=True)
+            self.dense_softmax = nn.Linear(n_RNN_cell * 2, nclass)
+            self.softmax = nn.Softmax(dim=-1)
         self._nclass, self._n_layers, self._p_drop = nclass, n_layers_RNN, float(dropout)
         self._C, self._H = int(self.cnn.nb_filters[-1]), int(n_RNN_cell)
         self._dtype = _lib.DTYPE_F32
@@ -209,15 +247,16 @@ class CRNN(nn.Module):
         self.cnn.load(parameters=parameters["cnn"])
         self.rnn.load_state_dict(parameters["rnn"])
         self.dense.load_state_dict(parameters["dense"])
-        if "dense_softmax" in parameters:            # superset key: the reference drops the attention layer
+        if "dense_softmax" in parameters and self.attention:      # superset key: the reference drops the attention layer
             self.dense_softmax.load_state_dict(parameters["dense_softmax"])
 
     def state_dict(self, destination=None, prefix='', keep_vars=False):
-        return {"cnn": self.cnn.state_dict(destination=destination, prefix=prefix, keep_vars=keep_vars),
-                "rnn": self.rnn.state_dict(destination=destination, prefix=prefix, keep_vars=keep_vars),
-                "dense": self.dense.state_dict(destination=destination, prefix=prefix, keep_vars=keep_vars),
-                "dense_softmax": self.dense_softmax.state_dict(destination=destination, prefix=prefix,
-                                                               keep_vars=keep_vars)}
+        sd = {"cnn": self.cnn.state_dict(destination=destination, prefix=prefix, keep_vars=keep_vars),
+              "rnn": self.rnn.state_dict(destination=destination, prefix=prefix, keep_vars=keep_vars),
+              "dense": self.dense.state_dict(destination=destination, prefix=prefix, keep_vars=keep_vars)}
+        if self.attention:
+            sd["dense_softmax"] = self.dense_softmax.state_dict(destination=destination, prefix=prefix, keep_vars=keep_vars)
+        return sd
 
     def save(self, filename):
         torch.save({k: v for k, v in self.state_dict().items()}, filename)
@@ -232,6 +271,9 @@ class CRNN(nn.Module):
 
     # ---- flat storage -----------------------------------------------------------------------------
     def make_dims(self, B, T, F=64, p_drop=None):
+        if not self.hot_path:
+            raise _lib.SedError("this CRNN configuration is outside the MI355X hot path (CRNN.hot_path is False): it runs on stock "
+                                "torch operators through forward() only - no flat buffers, no fused step, no HIP inference")
         return _lib.make_dims(B, T, F, self._C, self._H, self._nclass, self._n_layers,
                               self._p_drop if p_drop is None else p_drop, 1e-3, 0.99, self._dtype)
 
@@ -305,6 +347,8 @@ class CRNN(nn.Module):
     def forward(self, x, seed=None):
         """x: float32 [B, 1, T, 64] on the GPU -> (strong [B, T//8, nclass], weak [B, nclass]).
         ``seed`` (int64 device tensor [1]) pins the dropout stream for tests."""
+        if not self.hot_path:
+            return self._stock_forward(x)
         if x.dim() != 4 or x.shape[1] != 1:
             raise ValueError(f"expected input [B, 1, T, F], got {tuple(x.shape)}")
         if not x.is_cuda:
@@ -318,6 +362,30 @@ class CRNN(nn.Module):
         seed_t = (seed if seed is not None else self._next_seed(x.device)) if use_drop else None
         params = list(self.parameters())
         strong, weak = _CRNNFunction.apply(self, x, self.training, seed_t, *params)
+        return strong, weak
+
+    def _stock_forward(self, x):
+        """baseline/models/CRNN.py:59-84 for a configuration OUTSIDE the hot path, on stock torch operators (whatever device the
+        module and x live on).  Same graph, same warning for freq != 1 (which the reference then feeds, chan * freq wide, into a
+        GRU built for chan features - torch's size error is the reference's behaviour too)."""
+        if not self._warned_stock:
+            self._warned_stock = True
+            warnings.warn("CRNN: this configuration is outside the MI355X hot path (activation='glu', attention=True, 3 x 64 / 128 "
+                          "filters, pooling (2,4) x 3, n_RNN_cell 64 / 256): running the reference graph on stock torch operators")
+        x = self.cnn(x)
+        bs, chan, frames, freq = x.size()
+        if freq != 1:
+            warnings.warn("Output shape is: {}".format((bs, frames, chan * freq)))
+            x = x.permute(0, 2, 1, 3).contiguous().view(bs, frames, chan * freq)
+        else:
+            x = x.squeeze(-1).permute(0, 2, 1)
+        x = self.dropout(self.rnn(x))
+        strong = self.sigmoid(self.dense(x))
+        if self.attention:
+            sof = torch.clamp(self.softmax(self.dense_softmax(x)), min=1e-7, max=1)
+            weak = (strong * sof).sum(1) / sof.sum(1)
+        else:
+            weak = strong.mean(1)
         return strong, weak
 
     def check_recurrence(self):

@@ -77,6 +77,9 @@ class MeanTeacherStep:
                  betas=(0.9, 0.999), eps=1e-8, ema_decay=0.999, max_consistency_cost=2.0, seed=0, use_graph=True,
                  process_group=None, overlap_streams=True, dp_schedule=None, pool_streams=True, collective=None):
         assert isinstance(student, CRNN) and (teacher is None or isinstance(teacher, CRNN))
+        if not student.hot_path or (teacher is not None and not teacher.hot_path):
+            raise _lib.SedError("MeanTeacherStep runs the HIP hot path only: this CRNN configuration is served by stock torch "
+                                "operators (CRNN.hot_path is False) - use the reference's own loop for it")
         self.l = _lib.lib()
         self.student, self.teacher = student, teacher
         self.supervised = teacher is None

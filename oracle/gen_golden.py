@@ -395,8 +395,55 @@ def wide_():
     print("wrote g10_wide.npz", len(save), "arrays")
 
 
+VARIANTS = {   # G11: constructor variants OUTSIDE the hot path (served with stock torch operators)
+    "relu_mean": dict(attention=False, activation="Relu", n_RNN_cell=64, n_layers_RNN=1),          # the CLASS DEFAULTS (CRNN.py:12-13)
+    "leaky_att": dict(attention=True, activation="leakyrelu", n_RNN_cell=32, n_layers_RNN=2),
+    "cg_att": dict(attention=True, activation="cg", n_RNN_cell=64, n_layers_RNN=1, nb_filters=[32, 48, 64]),
+    "glu_mean_pool14": dict(attention=False, activation="glu", n_RNN_cell=64, n_layers_RNN=1, pooling=[(1, 4), (1, 4), (1, 4)]),
+}
+
+
+def variants_():
+    """G11: the REAL reference CRNN built with constructor arguments outside the hot path (activation relu / leakyrelu / cg,
+    attention = False -> weak = strong.mean(1), other widths / pooling / cell counts): eval-mode posteriors with synthetic running
+    statistics, and a train-mode forward (dropout 0) with the gradient norms of a simple loss."""
+    import torch
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    main, cfg, CRNN = import_reference()
+    from oracle import synth
+    out = {}
+    for k, (tag, kw) in enumerate(VARIANTS.items()):      # seeds: parameters k, BatchNorm buffers 30 + k, input 300 + k
+        full = dict(n_in_channel=1, nclass=10, dropout=0, kernel_size=3 * [3], padding=3 * [1], stride=3 * [1],
+                    nb_filters=[64, 64, 64], pooling=list(3 * ((2, 4),)))
+        full.update(kw)
+        m = CRNN(**full)
+        shapes = [(n, tuple(p.shape)) for n, p in m.named_parameters()]
+        params = synth.make_params_for(shapes, seed=k)
+        bn = synth_bn(30 + k, nb=full["nb_filters"])
+        load_params(m, params, bn)
+        T = 64 if full["pooling"][0][0] == 2 else 16
+        x = synth.make_input(300 + k, 3, T)
+        m.eval()
+        with torch.no_grad():
+            s, w = m(x)
+        out[f"{tag}_eval_strong"] = s.numpy(); out[f"{tag}_eval_weak"] = w.numpy()
+        m.train()
+        s, w = m(x)
+        loss = (s * s).mean() + w.sum()
+        loss.backward()
+        out[f"{tag}_train_strong"] = s.detach().numpy(); out[f"{tag}_train_weak"] = w.detach().numpy()
+        out[f"{tag}_grad_norms"] = np.array([float(p.grad.double().norm()) for _, p in m.named_parameters()])
+        out[f"{tag}_param_names"] = np.array([n for n, _ in m.named_parameters()])
+        out[f"{tag}_bn_mean0"] = dict(m.named_buffers())["cnn.cnn.batchnorm0.running_mean"].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "g11_variants.npz"), **out)
+    print("g11 written:", sorted(out)[:6], "...")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "g10":
+    if len(sys.argv) > 1 and sys.argv[1] == "g11":
+        variants_()
+    elif len(sys.argv) > 1 and sys.argv[1] == "g10":
         wide_()
     elif len(sys.argv) > 1 and sys.argv[1] == "g9":
         predictions_()

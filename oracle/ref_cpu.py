@@ -285,3 +285,62 @@ class MeanTeacherOracle:
         meters["cons_weight"] = cons_w
         meters["ema_alpha"] = a
         return meters, grads, (s.detach(), w.detach(), s_e, w_e)
+
+
+def crnn_variant_forward(params, x, bn_state, train, activation="relu", attention=True, n_conv=3, kernel_size=(3, 3, 3),
+                         padding=(1, 1, 1), stride=(1, 1, 1), pooling=((2, 4),) * 3, n_layers_RNN=1, n_RNN_cell=64):
+    """Functional restatement of the reference CRNN for the constructor variants OUTSIDE the hot path (what
+    dcase2019_task4_amd.crnn.CRNN serves with stock torch operators; pinned by G11 = outputs of the real reference):
+    baseline/models/CNN.py:46-67 (conv -> BatchNorm(eps 1e-3, momentum 0.99) -> LeakyReLU(0.2) | ReLU | GLU | ContextGating ->
+    [dropout] -> AvgPool), CNN.py:11-16 (GLU), CNN.py:25-30 (ContextGating), CRNN.py:59-84 (squeeze / permute, BiGRU,
+    dense + sigmoid, attention pooling or the mean over frames).  Dropout is the identity here (p = 0 / eval)."""
+    import torch.nn.functional as F
+    act = activation.lower()
+    h = x
+    for i in range(n_conv):
+        pre = f"cnn.cnn."
+        h = F.conv2d(h, params[pre + f"conv{i}.weight"], params[pre + f"conv{i}.bias"], stride=stride[i], padding=padding[i])
+        h = F.batch_norm(h, bn_state[pre + f"batchnorm{i}.running_mean"], bn_state[pre + f"batchnorm{i}.running_var"],
+                         params[pre + f"batchnorm{i}.weight"], params[pre + f"batchnorm{i}.bias"], training=train, momentum=0.99, eps=1e-3)
+        if act == "leakyrelu":
+            h = F.leaky_relu(h, 0.2)
+        elif act == "relu":
+            h = F.relu(h)
+        elif act == "glu":
+            lin = F.linear(h.permute(0, 2, 3, 1), params[pre + f"glu{i}.linear.weight"], params[pre + f"glu{i}.linear.bias"]).permute(0, 3, 1, 2)
+            h = lin * torch.sigmoid(h)
+        elif act == "cg":
+            lin = F.linear(h.permute(0, 2, 3, 1), params[pre + f"cg{i}.linear.weight"], params[pre + f"cg{i}.linear.bias"]).permute(0, 3, 1, 2)
+            h = h * torch.sigmoid(lin)
+        h = F.avg_pool2d(h, pooling[i])
+    bs, chan, frames, freq = h.shape
+    assert freq == 1, "the reference's freq != 1 branch feeds chan * freq features into a GRU built for chan: it cannot run"
+    h = h.squeeze(-1).permute(0, 2, 1)
+    H = n_RNN_cell
+    for l in range(n_layers_RNN):
+        outs = []
+        for sfx, rev in (("", False), ("_reverse", True)):
+            w_ih, w_hh = params[f"rnn.rnn.weight_ih_l{l}{sfx}"], params[f"rnn.rnn.weight_hh_l{l}{sfx}"]
+            b_ih, b_hh = params[f"rnn.rnn.bias_ih_l{l}{sfx}"], params[f"rnn.rnn.bias_hh_l{l}{sfx}"]
+            hs = torch.zeros(bs, H, dtype=h.dtype)
+            seq = []
+            steps = range(frames - 1, -1, -1) if rev else range(frames)
+            for t in steps:
+                gi = F.linear(h[:, t], w_ih, b_ih)
+                gh = F.linear(hs, w_hh, b_hh)
+                r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+                z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+                n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+                hs = (1 - z) * n + z * hs
+                seq.append(hs)
+            if rev:
+                seq = seq[::-1]
+            outs.append(torch.stack(seq, 1))
+        h = torch.cat(outs, -1)
+    strong = torch.sigmoid(F.linear(h, params["dense.weight"], params["dense.bias"]))
+    if attention:
+        sof = torch.softmax(F.linear(h, params["dense_softmax.weight"], params["dense_softmax.bias"]), dim=-1).clamp(min=1e-7, max=1)
+        weak = (strong * sof).sum(1) / sof.sum(1)
+    else:
+        weak = strong.mean(1)
+    return strong, weak

@@ -90,3 +90,21 @@ def make_posteriors(seed, N, T_out, nclass=10):
     p[0, :, 6] = 0.1; p[0, :3, 6] = 0.9; p[0, -1:, 6] = 0.9
     p[0, :, 7] = 0.5                                        # ... except exactly AT the threshold: p > 0.5 is False
     return torch.tensor(p, dtype=torch.float32)
+
+
+def make_params_for(named_shapes, seed=0, dtype=torch.float32):
+    """Procedural weights for ANY module layout (the constructor variants outside the hot path, G11): one draw per tensor in the
+    order given, statistics by tensor kind as in make_params."""
+    rs = np.random.RandomState(7000 + seed)
+    out = OrderedDict()
+    for name, shp in named_shapes:
+        shp = tuple(shp)
+        if "batchnorm" in name and name.endswith("weight"):
+            a = rs.normal(1.0, 0.1, shp)
+        elif name.endswith("bias") or len(shp) == 1:
+            a = rs.normal(0.0, 0.08, shp)
+        else:
+            fan_in = int(np.prod(shp[1:]))
+            a = rs.normal(0, 1.0 / np.sqrt(fan_in), shp)
+        out[name] = torch.tensor(a, dtype=dtype)
+    return out

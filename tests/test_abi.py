@@ -83,12 +83,66 @@ def test_module_refuses_configs_outside_the_hot_path_and_cpu_tensors():
     assert set(sd) == {"cnn", "rnn", "dense", "dense_softmax"}
     assert "conv0.weight" in sd["cnn"] and "batchnorm2.num_batches_tracked" in sd["cnn"]
     assert "rnn.weight_hh_l1_reverse" in sd["rnn"]
+    assert m.hot_path
     with pytest.raises(_lib.SedError):
-        m(torch.zeros(2, 1, 64, 64))               # CPU tensor: no fallback
+        m(torch.zeros(2, 1, 64, 64))               # hot-path configuration, CPU tensor: NO fallback of any kind
     with pytest.raises(NotImplementedError):
-        CRNN(**dict(kw, activation="relu"))
-    with pytest.raises(NotImplementedError):
-        CRNN(**dict(kw, attention=False))
+        CRNN(**dict(kw, rnn_type="LSTM"))          # (the reference's own refusal, CRNN.py:26-27)
+
+
+def test_constructor_variants_outside_the_hot_path_run_the_reference_graph_on_stock_torch(golden_dir):
+    """`activation="Relu"` (the class default), leakyrelu, cg, `attention=False` (weak = strong.mean(1)), other widths /
+    poolings / cell counts are ACCEPTED and served by stock torch operators (CRNN.hot_path False) - against G11, outputs of the REAL
+    reference built with the same constructor arguments (oracle/gen_golden.py g11): eval and train-mode posteriors, the gradient
+    norms of a loss, the updated BatchNorm running mean; parameter names and order as the reference's (`dense_softmax` only with
+    attention).  The same fixtures pin the oracle's functional restatement (ref_cpu.crnn_variant_forward).  The fused step refuses
+    such a module."""
+    import numpy as np
+    import torch
+    import warnings
+    from dcase2019_task4_amd.crnn import CRNN
+    from dcase2019_task4_amd.train import MeanTeacherStep
+    from oracle import gen_golden, ref_cpu, synth
+    g = np.load(os.path.join(golden_dir, "g11_variants.npz"))
+    for k, (tag, kwv) in enumerate(gen_golden.VARIANTS.items()):
+        full = dict(n_in_channel=1, nclass=10, dropout=0, kernel_size=3 * [3], padding=3 * [1], stride=3 * [1],
+                    nb_filters=[64, 64, 64], pooling=list(3 * ((2, 4),)))
+        full.update(kwv)
+        m = CRNN(**full)
+        assert not m.hot_path
+        names = [n for n, _ in m.named_parameters()]
+        assert names == list(g[f"{tag}_param_names"]), tag
+        params = synth.make_params_for([(n, tuple(p.shape)) for n, p in m.named_parameters()], seed=k)
+        bn = gen_golden.synth_bn(30 + k, nb=full["nb_filters"])
+        gen_golden.load_params(m, params, bn)
+        T = 64 if full["pooling"][0][0] == 2 else 16
+        x = synth.make_input(300 + k, 3, T)
+        m.eval()
+        with warnings.catch_warnings(record=True) as wrn:
+            warnings.simplefilter("always")
+            with torch.no_grad():
+                s, w = m(x)
+        assert any("outside the MI355X hot path" in str(v.message) for v in wrn)
+        np.testing.assert_allclose(s.numpy(), g[f"{tag}_eval_strong"], atol=2e-6)
+        np.testing.assert_allclose(w.numpy(), g[f"{tag}_eval_weak"], atol=2e-6)
+        # the oracle's restatement of the same variant, same fixtures
+        bn_o = {kk: v.clone() for kk, v in bn.items()}
+        so, wo = ref_cpu.crnn_variant_forward(params, x, bn_o, False, activation=full["activation"], attention=full["attention"],
+                                              pooling=full["pooling"], n_layers_RNN=full["n_layers_RNN"], n_RNN_cell=full["n_RNN_cell"])
+        np.testing.assert_allclose(so.numpy(), g[f"{tag}_eval_strong"], atol=2e-6)
+        np.testing.assert_allclose(wo.numpy(), g[f"{tag}_eval_weak"], atol=2e-6)
+        m.train()
+        s, w = m(x)
+        ((s * s).mean() + w.sum()).backward()
+        np.testing.assert_allclose(s.detach().numpy(), g[f"{tag}_train_strong"], atol=2e-6)
+        np.testing.assert_allclose(w.detach().numpy(), g[f"{tag}_train_weak"], atol=2e-6)
+        gn = np.array([float(p.grad.double().norm()) for _, p in m.named_parameters()])
+        np.testing.assert_allclose(gn, g[f"{tag}_grad_norms"], rtol=1e-4, atol=1e-9)
+        np.testing.assert_allclose(dict(m.named_buffers())["cnn.cnn.batchnorm0.running_mean"].numpy(), g[f"{tag}_bn_mean0"], atol=2e-6)
+        sd = m.state_dict()
+        assert ("dense_softmax" in sd) == bool(full["attention"])
+        with pytest.raises(_lib.SedError):
+            MeanTeacherStep(m, None, 3, T, 10, slice(1), slice(2, 3))
 
 
 def test_p2p_flag_never_overtakes_the_payload_in_the_compiled_kernel():

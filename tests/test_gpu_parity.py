@@ -503,6 +503,32 @@ def test_patch_moments_one_step_ahead_are_bit_identical(graph, kw):
             assert torch.equal(a, b), (k, float((a - b).abs().max()))
 
 
+def test_constructor_variants_outside_the_hot_path_on_the_gpu(golden_dir):
+    """The stock-torch route of configurations outside the hot path (CRNN.hot_path False; tests/test_abi.py checks it on the CPU
+    against G11) with the module and the input on the GPU: same posteriors as the real reference within fp32 library noise -
+    and a hot-path module beside it still goes through the HIP library (native path loaded, CPU tensors refused)."""
+    from dcase2019_task4_amd.crnn import CRNN
+    from oracle import gen_golden
+    g = _golden(golden_dir, "g11_variants.npz")
+    for k, (tag, kwv) in enumerate(gen_golden.VARIANTS.items()):
+        full = dict(n_in_channel=1, nclass=10, dropout=0, kernel_size=3 * [3], padding=3 * [1], stride=3 * [1],
+                    nb_filters=[64, 64, 64], pooling=list(3 * ((2, 4),)))
+        full.update(kwv)
+        m = CRNN(**full)
+        params = synth.make_params_for([(n, tuple(p.shape)) for n, p in m.named_parameters()], seed=k)
+        gen_golden.load_params(m, params, gen_golden.synth_bn(30 + k, nb=full["nb_filters"]))
+        m = m.cuda().eval()
+        T = 64 if full["pooling"][0][0] == 2 else 16
+        with torch.no_grad():
+            s, w = m(synth.make_input(300 + k, 3, T).cuda())
+        assert float(np.abs(s.cpu().numpy() - g[f"{tag}_eval_strong"]).max()) < 2e-5, tag
+        assert float(np.abs(w.cpu().numpy() - g[f"{tag}_eval_weak"]).max()) < 2e-5, tag
+    hot, _ = gu.make_model(0)
+    assert hot.hot_path
+    with pytest.raises(Exception):
+        hot.cpu()(torch.zeros(2, 1, 64, 64))
+
+
 def test_train_honours_the_epoch_argument_like_main_py_74():
     """main.py:74 recomputes ``global_step = epoch * len(train_loader) + i`` from the epoch argument at every call of train: the
     consistency weight a call logs must be the oracle's for THAT global step - over an epoch 0, 1 call sequence on one step

@@ -216,9 +216,16 @@ class PeerAllReduce:
             if obj is not None:
                 obj.close()
             return None
-        if verify and not obj.self_check():
-            obj.close()
-            return None
+        if verify:
+            # the self-check runs under a SHORT wait budget: if flags or payload do not become visible between these devices
+            # the construction must fall back to the process group's collective within seconds, not after the production
+            # budget (600 s per wait); the configured budget is restored once the check has passed
+            budget = float(kw.get("timeout_s") or os.environ.get("SED_P2P_TIMEOUT_S") or 600.0)
+            obj.set_timeout(float(os.environ.get("SED_P2P_CHECK_TIMEOUT_S", "5")))
+            if not obj.self_check():
+                obj.close()
+                return None
+            obj.set_timeout(budget)
         return obj
 
     def all_reduce(self, flat, lo=0, hi=None, stream=None):
@@ -291,6 +298,12 @@ class PeerAllReduce:
                     torch.cuda.synchronize(self.device)
                     if not torch.equal(y, want):
                         ok = 0.0
+                    # a wait ran out somewhere: no point in paying for the remaining calls' budgets - but every rank must leave
+                    # the loop TOGETHER (each turn holds an all_gather), so the decision is itself a collective
+                    bad = torch.tensor([1.0 if self.poll() else 0.0], device=self.device)
+                    dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.group)
+                    if bad.item() != 0.0:
+                        raise RuntimeError("a cross-rank wait timed out during the self-check")
             # captured: the launch must replay correctly (device-side epochs)
             x = torch.randn(sizes[-1], generator=g).to(self.device)
             parts = [torch.zeros_like(x) for _ in range(self.world)]

@@ -415,8 +415,10 @@ _TRAJ = {}
 TRAJ_STEPS, TRAJ_B, TRAJ_T = 50, 8, 216
 # loss of step k relative to the fp32 oracle's loss of step k, maximum over the 50 steps, and the strong posteriors after step 50.
 # Measured (round 4): f32 3.5e-6 / 1.2e-5, bf16x3 3.7e-6 / 1.3e-5, bf16 4.9e-4 / 3.5e-3; asserted with head-room.
-TRAJ_TOL = {"f32": 5e-5, "bf16x3": 5e-5, "bf16": 2e-3, "f16": 2e-3}      # (f16: the bf16 mode's backward steers the trajectory)
-TRAJ_POST_TOL = {"f32": 1e-4, "bf16x3": 1e-4, "bf16": 7e-3, "f16": 7e-3}
+# Round 6: the f16 mode has its OWN bounds (until then it borrowed bf16's): measured 1.06e-4 / 9.2e-4 - its fp16 forward keeps the
+# 50-step drift 4 x below the bf16 mode's although both share the bf16 backward.
+TRAJ_TOL = {"f32": 5e-5, "bf16x3": 5e-5, "bf16": 2e-3, "f16": 4e-4}
+TRAJ_POST_TOL = {"f32": 1e-4, "bf16x3": 1e-4, "bf16": 7e-3, "f16": 2e-3}
 
 
 def _hip_trajectory(dtype):

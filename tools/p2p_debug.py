@@ -1,4 +1,5 @@
-"""World-2 (shared GPU) check of the peer all-reduce with a per-size mismatch report (debug aid for csrc/p2p.hip)."""
+"""World-N (ranks sharing one GPU) soak of the peer all-reduce with a per-size mismatch report (debug aid for csrc/p2p.hip; it found
+the VMEM store-data hazard of round 6):   P2P_DEBUG_REPS=100 python tools/p2p_debug.py [world]"""
 import os
 import sys
 
@@ -34,9 +35,9 @@ def worker(rank, world, port):
             tot += nb
             if nb:
                 idx = bad.nonzero().flatten()[:8].tolist()
-                other = ys[1 - rank]
+                other = ys[(rank + 1) % world]
                 print(f"rank {rank} n {n} rep {rep}: {nb} wrong at {idx}; got {[float(y[i]) for i in idx[:4]]} want {[float(want[i]) for i in idx[:4]]} "
-                      f"mine {[float(x[i]) for i in idx[:4]]} peer-input {[float(parts[1 - rank][i]) for i in idx[:4]]} peer-result-ok "
+                      f"mine {[float(x[i]) for i in idx[:4]]} peer-input {[float(parts[(rank + 1) % world][i]) for i in idx[:4]]} peer-result-ok "
                       f"{[bool(other[i] == want[i]) for i in idx[:4]]} errors {ar.errors()}", flush=True)
             dist.barrier()
         print(f"rank {rank} n {n}: {tot} wrong elements over {reps} calls", flush=True)
@@ -51,4 +52,5 @@ if __name__ == "__main__":
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    mp.spawn(worker, args=(2, port), nprocs=2, join=True)
+    world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    mp.spawn(worker, args=(world, port), nprocs=world, join=True)

@@ -451,8 +451,16 @@ __global__ __launch_bounds__(512, 1) void k_gwgrad_bf16(const void* __restrict__
             *(u32x4g*)(plane + ((size_t)(4 * cq + q)) * XS + hr * 16 + 8 * cg) = (u32x4g){w[0], w[1], w[2], w[3]};
         }
     };
-    auto store_dy = [&](int tile) {
+    // `next`: the tile whose dz / y this thread fetches as soon as the current tile's are converted (bf16 path only) - i.e. BEFORE
+    // the 12 transposing LDS writes, the x staging, the barrier and the MFMA phase, not behind the barrier: the kernel moves 123 MB
+    // at B = 64 and the loads of a tile (3.1 us per round of 256 workgroups at ~4 TB/s) used to have only the 1.3 us MFMA phase to
+    // hide behind (round 6 experiment: without the staging 37 us, without the MFMAs 37 us, with both 50 us)
+    auto store_dy = [&](int tile, int next) {
         const int r0 = (tile % tiles_per_clip) * TH;
+#ifdef GW_EXP_NOSTAGE      // timing experiment only (tools/build_variant.sh): results are garbage
+        if (dzv[0][0] == 0x12345678u && dy_thread) dyT[tid] = (__bf16)1.0f;
+        return;
+#endif
         if (dy_thread) {
             const int r = pg >> 1, c0 = (pg & 1) * 8;
             const bool rok = r0 + r < H;
@@ -483,11 +491,12 @@ __global__ __launch_bounds__(512, 1) void k_gwgrad_bf16(const void* __restrict__
                         dyp[i] = __builtin_bit_cast(gw_u32x2, pk);
                     }
                 }
+                if constexpr (X3 == 0) load_dy(next);                 // (dzv / yv are dead from here on)
                 put_dy(dyp, dyT + pl * GWgB::DY_E, r, c0);
             }
         }
     };
-    auto store_x = [&](int tile) {
+    auto store_x = [&](int tile, int next) {
         const int r0 = (tile % tiles_per_clip) * TH;
         if (x_valid) {
             const int cg = (x_item >> 4) & 1, hr = x_item >> 5;
@@ -504,6 +513,7 @@ __global__ __launch_bounds__(512, 1) void k_gwgrad_bf16(const void* __restrict__
                 put_x(xl, xT + GWgB::X_E, hr, cg, ok);
             } else {
                 put_x(xv, xT, hr, cg, ok);
+                load_x(next);
             }
         }
     };
@@ -594,15 +604,11 @@ __global__ __launch_bounds__(512, 1) void k_gwgrad_bf16(const void* __restrict__
         if constexpr (X3 != 0) {
             x3_stage(tile);
         } else {
-            store_dy(tile);
-            store_x(tile);
+            const int nt = tile + walk.step, nxt = nt < walk.end ? nt : tile;
+            store_dy(tile, nxt);
+            store_x(tile, nxt);
         }
         __syncthreads();
-        if (!X3) {
-            const int nt = tile + walk.step;
-            load_dy(nt < walk.end ? nt : tile);
-            load_x(nt < walk.end ? nt : tile);
-        }
         const __bf16* Ap = dyT + (size_t)(32 * wa + n) * DS + 8 * kh;
         const __bf16* Bp = xT + (size_t)(32 * wb + n) * XS + 8 * kh;
         // tap t = 3 dr + dc multiplies dy copy dc (A) with x rows shifted by dr (B)
@@ -635,8 +641,10 @@ __global__ __launch_bounds__(512, 1) void k_gwgrad_bf16(const void* __restrict__
                 }
             }
         };
+#ifndef GW_EXP_NOMMA       // timing experiment only
         if (grp == 0) taps(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
         else taps(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
+#endif
         __syncthreads();
     }
     // every wave writes its own taps of the partial slab [tap][co (C)][ci (C)]
